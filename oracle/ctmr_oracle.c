@@ -1,0 +1,815 @@
+/*
+ * ctmr_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE ONLY; see ctmr_oracle.h header).
+ *
+ * Plain-C restatement of the ct-mapreduce per-entry map + known-certificates reduce.
+ * Citations are to /root/reference (jcjones/ct-mapreduce @ v1).
+ *
+ * The DER walk restates the part of x509.ParseCertificate (third-party,
+ * certificate-transparency-go v1.1.0 — not on this machine, PARITY UNPINNED there) that
+ * the reference path consumes, following RFC 5280 §4.1 and the Go encoding/asn1 rules
+ * recalled in DESIGN.md §3 ("DER walk profile").
+ */
+#include "ctmr_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ DER walk */
+
+typedef struct {
+  uint8_t tag;
+  uint32_t hl;  /* header length */
+  uint32_t len; /* content length */
+} tlv;
+
+/* One TLV header at p, which must lie wholly (header + content) inside [p, end).
+ * Length rules as Go encoding/asn1 parseTagAndLength: no high-tag-number form on this
+ * path, no indefinite length, long form without leading zero byte, minimal, < 2^31. */
+static int rd_tlv(const uint8_t* d, uint64_t p, uint64_t end, tlv* t) {
+  if (p + 2 > end) return 0;
+  t->tag = d[p];
+  if ((t->tag & 0x1f) == 0x1f) return 0;
+  uint8_t b = d[p + 1];
+  if (b < 0x80) {
+    t->hl = 2;
+    t->len = b;
+  } else {
+    uint32_t n = b & 0x7f;
+    if (n == 0 || n > 4) return 0;
+    if (p + 2 + n > end) return 0;
+    if (d[p + 2] == 0) return 0; /* superfluous leading zeros */
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < n; i++) v = (v << 8) | d[p + 2 + i];
+    if (v < 0x80) return 0;       /* non-minimal */
+    if (v > 0x7fffffffu) return 0; /* length too large */
+    t->hl = 2 + n;
+    t->len = (uint32_t)v;
+  }
+  if (p + t->hl + (uint64_t)t->len > end) return 0;
+  return 1;
+}
+
+static int is_digit(uint8_t c) { return c >= '0' && c <= '9'; }
+static int two(const uint8_t* s) { return (s[0] - '0') * 10 + (s[1] - '0'); }
+
+/* days since 1970-01-01 of a proleptic Gregorian civil date */
+static int64_t days_from_civil(int64_t y, int m, int d) {
+  y -= m <= 2;
+  int64_t era = (y >= 0 ? y : y - 399) / 400;
+  int64_t yoe = y - era * 400;
+  int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+  int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  return era * 146097 + doe - 719468;
+}
+
+static int days_in_month(int64_t y, int m) {
+  static const int dm[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+  if (m == 2) {
+    int leap = (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0);
+    return leap ? 29 : 28;
+  }
+  return dm[m - 1];
+}
+
+/* UTCTime (tag 0x17) "YYMMDDHHMMZ" / "YYMMDDHHMMSSZ", GeneralizedTime (0x18)
+ * "YYYYMMDDHHMMSSZ". Go asn1 parseUTCTime/parseGeneralizedTime; only the 'Z' zone forms
+ * are in the profile (numeric offsets → parse error; documented divergence). */
+static int parse_time(const uint8_t* d, const tlv* t, uint64_t content, int64_t* out) {
+  const uint8_t* s = d + content;
+  int64_t year;
+  int mon, day, hh, mm, ss = 0;
+  uint32_t n = t->len;
+  if (t->tag == 0x17) {
+    if (n != 11 && n != 13) return 0;
+    for (uint32_t i = 0; i + 1 < n; i++)
+      if (!is_digit(s[i])) return 0;
+    if (s[n - 1] != 'Z') return 0;
+    int yy = two(s);
+    year = yy < 50 ? 2000 + yy : 1900 + yy;
+    mon = two(s + 2);
+    day = two(s + 4);
+    hh = two(s + 6);
+    mm = two(s + 8);
+    if (n == 13) ss = two(s + 10);
+  } else if (t->tag == 0x18) {
+    if (n != 15) return 0;
+    for (uint32_t i = 0; i < 14; i++)
+      if (!is_digit(s[i])) return 0;
+    if (s[14] != 'Z') return 0;
+    year = two(s) * 100 + two(s + 2);
+    mon = two(s + 4);
+    day = two(s + 6);
+    hh = two(s + 8);
+    mm = two(s + 10);
+    ss = two(s + 12);
+  } else {
+    return 0;
+  }
+  if (mon < 1 || mon > 12) return 0;
+  if (day < 1 || day > days_in_month(year, mon)) return 0;
+  if (hh > 23 || mm > 59 || ss > 59) return 0;
+  *out = days_from_civil(year, mon, day) * 86400 + hh * 3600 + mm * 60 + ss;
+  return 1;
+}
+
+/* Go asn1 checkInteger: non-empty, minimally encoded. */
+static int check_integer(const uint8_t* d, uint64_t content, uint32_t len) {
+  if (len == 0) return 0;
+  if (len == 1) return 1;
+  if (d[content] == 0x00 && (d[content + 1] & 0x80) == 0) return 0;
+  if (d[content] == 0xff && (d[content + 1] & 0x80) == 0x80) return 0;
+  return 1;
+}
+
+static int is_string_tag(uint8_t tag) {
+  /* UTF8String, NumericString, PrintableString, T61String, IA5String: the value types Go's
+   * asn1 decodes to a Go string, which pkix.Name.FillFromRDNSequence requires */
+  return tag == 0x0c || tag == 0x12 || tag == 0x13 || tag == 0x14 || tag == 0x16;
+}
+
+#define FAIL(site)          \
+  do {                      \
+    out->ok = 0;            \
+    out->err_site = (site); \
+    return;                 \
+  } while (0)
+
+void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
+  memset(out, 0, sizeof(*out));
+  tlv t;
+  if (L > 0x7fffffffu) FAIL(1);
+  /* Certificate ::= SEQUENCE, no trailing data (x509.ParseCertificate) */
+  if (!rd_tlv(d, 0, L, &t) || t.tag != 0x30) FAIL(2);
+  if ((uint64_t)t.hl + t.len != L) FAIL(3);
+  uint64_t cert_end = L;
+  uint64_t p = t.hl;
+  /* tbsCertificate */
+  if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x30) FAIL(4);
+  out->tbs_off = (uint32_t)p;
+  out->tbs_len = t.hl + t.len;
+  uint64_t tbs_end = p + t.hl + t.len;
+  uint64_t q = p + t.hl;
+  /* version [0] EXPLICIT INTEGER DEFAULT v1 */
+  if (q < tbs_end && d[q] == 0xa0) {
+    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(5);
+    tlv v;
+    uint64_t vq = q + t.hl;
+    if (!rd_tlv(d, vq, vq + t.len, &v) || v.tag != 0x02) FAIL(6);
+    if ((uint64_t)v.hl + v.len != t.len) FAIL(7);
+    if (v.len > 4 || !check_integer(d, vq + v.hl, v.len)) FAIL(8);
+    q += t.hl + t.len;
+  }
+  /* serialNumber INTEGER: raw content octets kept verbatim (types.go:165-178) */
+  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x02) FAIL(9);
+  if (!check_integer(d, q + t.hl, t.len)) FAIL(10);
+  out->serial_off = (uint32_t)(q + t.hl);
+  out->serial_len = t.len;
+  q += t.hl + t.len;
+  /* signature AlgorithmIdentifier: skipped */
+  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(11);
+  q += t.hl + t.len;
+  /* issuer Name: RDNSequence; CommonName = last AttributeTypeAndValue with OID 2.5.4.3 whose
+   * value is a string type (pkix.Name.FillFromRDNSequence) */
+  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(12);
+  {
+    uint64_t r = q + t.hl, r_end = q + t.hl + t.len;
+    while (r < r_end) {
+      tlv set;
+      if (!rd_tlv(d, r, r_end, &set) || set.tag != 0x31) FAIL(13);
+      uint64_t a = r + set.hl, a_end = r + set.hl + set.len;
+      while (a < a_end) {
+        tlv atv, oid, val;
+        if (!rd_tlv(d, a, a_end, &atv) || atv.tag != 0x30) FAIL(14);
+        uint64_t b = a + atv.hl, b_end = a + atv.hl + atv.len;
+        if (!rd_tlv(d, b, b_end, &oid) || oid.tag != 0x06 || oid.len == 0) FAIL(15);
+        uint64_t vpos = b + oid.hl + oid.len;
+        if (!rd_tlv(d, vpos, b_end, &val)) FAIL(16);
+        if (oid.len == 3 && d[b + oid.hl] == 0x55 && d[b + oid.hl + 1] == 0x04 &&
+            d[b + oid.hl + 2] == 0x03 && is_string_tag(val.tag)) {
+          out->cn_off = (uint32_t)(vpos + val.hl);
+          out->cn_len = val.len;
+        }
+        a += atv.hl + atv.len;
+      }
+      r += set.hl + set.len;
+    }
+  }
+  q += t.hl + t.len;
+  /* validity SEQUENCE { notBefore Time, notAfter Time } */
+  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(17);
+  {
+    uint64_t v = q + t.hl, v_end = q + t.hl + t.len;
+    tlv tm;
+    if (!rd_tlv(d, v, v_end, &tm)) FAIL(18);
+    if (!parse_time(d, &tm, v + tm.hl, &out->not_before)) FAIL(19);
+    v += tm.hl + tm.len;
+    if (!rd_tlv(d, v, v_end, &tm)) FAIL(20);
+    if (!parse_time(d, &tm, v + tm.hl, &out->not_after)) FAIL(21);
+  }
+  q += t.hl + t.len;
+  /* subject Name: skipped */
+  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(22);
+  q += t.hl + t.len;
+  /* subjectPublicKeyInfo: full TLV = RawSubjectPublicKeyInfo (types.go:109-115) */
+  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(23);
+  out->spki_off = (uint32_t)q;
+  out->spki_len = t.hl + t.len;
+  q += t.hl + t.len;
+  /* issuerUniqueID [1], subjectUniqueID [2] IMPLICIT BIT STRING OPTIONAL: skipped */
+  if (q < tbs_end && d[q] == 0x81) {
+    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(24);
+    q += t.hl + t.len;
+  }
+  if (q < tbs_end && d[q] == 0x82) {
+    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(25);
+    q += t.hl + t.len;
+  }
+  /* extensions [3] EXPLICIT SEQUENCE OF Extension */
+  if (q < tbs_end && d[q] == 0xa3) {
+    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(26);
+    tlv seq;
+    uint64_t e0 = q + t.hl;
+    if (!rd_tlv(d, e0, e0 + t.len, &seq) || seq.tag != 0x30) FAIL(27);
+    uint64_t e = e0 + seq.hl, e_end = e0 + seq.hl + seq.len;
+    while (e < e_end) {
+      tlv ext, oid, val;
+      if (!rd_tlv(d, e, e_end, &ext) || ext.tag != 0x30) FAIL(28);
+      uint64_t x = e + ext.hl, x_end = e + ext.hl + ext.len;
+      if (!rd_tlv(d, x, x_end, &oid) || oid.tag != 0x06 || oid.len == 0) FAIL(29);
+      uint64_t oid_c = x + oid.hl;
+      x += oid.hl + oid.len;
+      if (!rd_tlv(d, x, x_end, &val)) FAIL(30);
+      if (val.tag == 0x01) { /* critical BOOLEAN DEFAULT FALSE */
+        if (val.len != 1) FAIL(31);
+        uint8_t bv = d[x + val.hl];
+        if (bv != 0x00 && bv != 0xff) FAIL(32);
+        x += val.hl + val.len;
+        if (!rd_tlv(d, x, x_end, &val)) FAIL(33);
+      }
+      if (val.tag != 0x04) FAIL(34);
+      if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x13) {
+        /* basicConstraints ::= SEQUENCE { cA BOOLEAN DEFAULT FALSE, pathLen INTEGER OPTIONAL };
+         * must fill the OCTET STRING (x509: trailing data after X.509 BasicConstraints) */
+        tlv bc;
+        uint64_t o = x + val.hl, o_end = x + val.hl + val.len;
+        if (!rd_tlv(d, o, o_end, &bc) || bc.tag != 0x30) FAIL(35);
+        if ((uint64_t)bc.hl + bc.len != val.len) FAIL(36);
+        uint64_t c = o + bc.hl, c_end = o + bc.hl + bc.len;
+        int ca = 0;
+        if (c < c_end) {
+          tlv f;
+          if (!rd_tlv(d, c, c_end, &f)) FAIL(37);
+          if (f.tag == 0x01) {
+            if (f.len != 1) FAIL(38);
+            uint8_t bv = d[c + f.hl];
+            if (bv != 0x00 && bv != 0xff) FAIL(39);
+            ca = bv == 0xff;
+            c += f.hl + f.len;
+            if (c < c_end) {
+              if (!rd_tlv(d, c, c_end, &f)) FAIL(40);
+            }
+          }
+          if (c < c_end) { /* pathLenConstraint */
+            if (f.tag != 0x02 || !check_integer(d, c + f.hl, f.len)) FAIL(41);
+          }
+        }
+        out->bc_valid = 1;
+        out->is_ca = ca; /* a repeated extension overwrites (last wins) */
+      }
+      e += ext.hl + ext.len;
+    }
+  }
+  /* signatureAlgorithm, signatureValue BIT STRING */
+  p = tbs_end;
+  if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x30) FAIL(42);
+  p += t.hl + t.len;
+  if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x03) FAIL(43);
+  {
+    /* Go asn1 parseBitString */
+    if (t.len == 0) FAIL(44);
+    uint8_t pad = d[p + t.hl];
+    if (pad > 7 || (t.len == 1 && pad > 0)) FAIL(45);
+    if (pad > 0 && (d[p + t.hl + t.len - 1] & ((1u << pad) - 1)) != 0) FAIL(46);
+  }
+  out->ok = 1;
+}
+
+/* ------------------------------------------------------------------ SHA-256 */
+
+static const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+static void sha256_block(uint32_t h[8], const uint8_t* blk) {
+  uint32_t w[64];
+  for (int i = 0; i < 16; i++)
+    w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) |
+           ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
+  for (int i = 16; i < 64; i++) {
+    uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+    uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+  for (int i = 0; i < 64; i++) {
+    uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+    uint32_t ch = (e & f) ^ (~e & g);
+    uint32_t t1 = hh + S1 + ch + K256[i] + w[i];
+    uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+    uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+    uint32_t t2 = S0 + mj;
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+void orc_sha256(const uint8_t* msg, size_t len, uint8_t out[32]) {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+                   0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  size_t i = 0;
+  for (; i + 64 <= len; i += 64) sha256_block(h, msg + i);
+  uint8_t tail[128];
+  size_t rem = len - i;
+  memset(tail, 0, sizeof(tail));
+  memcpy(tail, msg + i, rem);
+  tail[rem] = 0x80;
+  size_t tl = rem + 1 + 8 <= 64 ? 64 : 128;
+  uint64_t bits = (uint64_t)len * 8;
+  for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+  sha256_block(h, tail);
+  if (tl == 128) sha256_block(h, tail + 64);
+  for (int k = 0; k < 8; k++) {
+    out[4 * k] = (uint8_t)(h[k] >> 24);
+    out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+    out[4 * k + 2] = (uint8_t)(h[k] >> 8);
+    out[4 * k + 3] = (uint8_t)h[k];
+  }
+}
+
+/* ------------------------------------------------------------------ identities */
+
+size_t orc_b64url(const uint8_t* in, size_t n, char* out) {
+  static const char A[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_";
+  size_t o = 0, i = 0;
+  for (; i + 3 <= n; i += 3) {
+    uint32_t v = ((uint32_t)in[i] << 16) | ((uint32_t)in[i + 1] << 8) | in[i + 2];
+    out[o++] = A[(v >> 18) & 63];
+    out[o++] = A[(v >> 12) & 63];
+    out[o++] = A[(v >> 6) & 63];
+    out[o++] = A[v & 63];
+  }
+  if (n - i == 1) {
+    uint32_t v = (uint32_t)in[i] << 16;
+    out[o++] = A[(v >> 18) & 63];
+    out[o++] = A[(v >> 12) & 63];
+    out[o++] = '=';
+    out[o++] = '=';
+  } else if (n - i == 2) {
+    uint32_t v = ((uint32_t)in[i] << 16) | ((uint32_t)in[i + 1] << 8);
+    out[o++] = A[(v >> 18) & 63];
+    out[o++] = A[(v >> 12) & 63];
+    out[o++] = A[(v >> 6) & 63];
+    out[o++] = '=';
+  }
+  out[o] = 0;
+  return o;
+}
+
+void orc_issuer_id(const uint8_t* spki, size_t n, char out[45]) {
+  uint8_t dg[32];
+  orc_sha256(spki, n, dg);
+  orc_b64url(dg, 32, out);
+}
+
+int32_t orc_exp_hour(int64_t s) {
+  int64_t h = s / 3600;
+  if (s % 3600 < 0) h -= 1; /* Truncate rounds toward the zero Time, i.e. floor */
+  return (int32_t)h;
+}
+
+static void civil_from_days(int64_t z, int64_t* y, int* m, int* d) {
+  z += 719468;
+  int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  int64_t doe = z - era * 146097;
+  int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  int64_t yy = yoe + era * 400;
+  int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  int64_t mp = (5 * doy + 2) / 153;
+  *d = (int)(doy - (153 * mp + 2) / 5 + 1);
+  *m = (int)(mp < 10 ? mp + 3 : mp - 9);
+  *y = yy + (*m <= 2);
+}
+
+void orc_exp_date_id(int32_t exp_hour, char out[16]) {
+  int64_t days = exp_hour / 24;
+  int hh = exp_hour % 24;
+  if (hh < 0) {
+    hh += 24;
+    days -= 1;
+  }
+  int64_t y;
+  int m, d;
+  civil_from_days(days, &y, &m, &d);
+  snprintf(out, 16, "%04lld-%02d-%02d-%02d", (long long)y, m, d, hh);
+}
+
+void orc_day_id(int64_t s, char out[16]) {
+  int64_t days = s / 86400;
+  if (s % 86400 < 0) days -= 1;
+  int64_t y;
+  int m, d;
+  civil_from_days(days, &y, &m, &d);
+  snprintf(out, 16, "%04lld-%02d-%02d", (long long)y, m, d);
+}
+
+/* certIsFilteredOut — cmd/ct-fetch/ct-fetch.go:44-70 */
+int orc_cert_is_filtered_out(const uint8_t* der, const orc_cert* c, const char* filter,
+                             size_t filter_len, int log_expired, int64_t now) {
+  if (c->bc_valid && c->is_ca) return ORC_ST_FILTERED_CA; /* :47-50 */
+  if (c->not_after < now && !log_expired) return ORC_ST_FILTERED_EXPIRED; /* :52-55 */
+  int skip = filter_len != 0; /* :57 */
+  /* strings.Split(filter, ","): pieces are not trimmed; "" yields one empty piece, which
+   * HasPrefix matches — irrelevant because skip is already false for an empty filter. */
+  size_t s = 0;
+  for (;;) {
+    size_t e = s;
+    while (e < filter_len && filter[e] != ',') e++;
+    size_t pl = e - s;
+    if (pl <= c->cn_len && memcmp(der + c->cn_off, filter + s, pl) == 0) { /* HasPrefix :59 */
+      skip = 0;
+      break;
+    }
+    if (e >= filter_len) break;
+    s = e + 1;
+  }
+  return skip ? ORC_ST_FILTERED_CN : ORC_ST_PASS;
+}
+
+/* ------------------------------------------------------------------ set store
+ * Stands in for storage.RemoteCache set semantics (mockcache.go:38-61: sorted insert = set). */
+
+typedef struct {
+  uint8_t* bytes;   /* arena of [u32 len][data] */
+  size_t used, cap;
+  uint64_t* slots;  /* open addressing: arena offset+1, 0 = empty */
+  size_t nslots, count;
+} byteset;
+
+static uint64_t fnv1a(const uint8_t* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; i++) {
+    h ^= p[i];
+    h *= 1099511628211ull;
+  }
+  h ^= h >> 29;
+  h *= 0xbf58476d1ce4e5b9ull;
+  h ^= h >> 32;
+  return h;
+}
+
+static void bs_init(byteset* s) {
+  memset(s, 0, sizeof(*s));
+  s->nslots = 16;
+  s->slots = (uint64_t*)calloc(s->nslots, sizeof(uint64_t));
+}
+static void bs_free(byteset* s) {
+  free(s->bytes);
+  free(s->slots);
+}
+static void bs_rehash(byteset* s) {
+  size_t nn = s->nslots * 2;
+  uint64_t* ns = (uint64_t*)calloc(nn, sizeof(uint64_t));
+  for (size_t i = 0; i < s->nslots; i++) {
+    uint64_t o = s->slots[i];
+    if (!o) continue;
+    uint32_t len;
+    memcpy(&len, s->bytes + o - 1, 4);
+    size_t j = fnv1a(s->bytes + o - 1 + 4, len) & (nn - 1);
+    while (ns[j]) j = (j + 1) & (nn - 1);
+    ns[j] = o;
+  }
+  free(s->slots);
+  s->slots = ns;
+  s->nslots = nn;
+}
+/* returns index of member (arena offset) or -1; inserts when ins!=0; *was_new set */
+static int64_t bs_find(byteset* s, const uint8_t* m, size_t n, int ins, int* was_new) {
+  if (was_new) *was_new = 0;
+  size_t j = fnv1a(m, n) & (s->nslots - 1);
+  while (s->slots[j]) {
+    uint64_t o = s->slots[j] - 1;
+    uint32_t len;
+    memcpy(&len, s->bytes + o, 4);
+    if (len == n && memcmp(s->bytes + o + 4, m, n) == 0) return (int64_t)o;
+    j = (j + 1) & (s->nslots - 1);
+  }
+  if (!ins) return -1;
+  if (s->used + 4 + n > s->cap) {
+    size_t nc = s->cap ? s->cap * 2 : 256;
+    while (nc < s->used + 4 + n) nc *= 2;
+    s->bytes = (uint8_t*)realloc(s->bytes, nc);
+    s->cap = nc;
+  }
+  uint64_t o = s->used;
+  uint32_t len = (uint32_t)n;
+  memcpy(s->bytes + o, &len, 4);
+  memcpy(s->bytes + o + 4, m, n);
+  s->used += 4 + n;
+  s->slots[j] = o + 1;
+  s->count++;
+  if (was_new) *was_new = 1;
+  if (s->count * 2 > s->nslots) bs_rehash(s);
+  return (int64_t)o;
+}
+
+typedef struct {
+  byteset members;
+  int has_expiry;
+  int64_t expiry;
+  uint64_t key_off; /* offset of the key string in engine->keys arena */
+} setrec;
+
+struct orc_engine {
+  byteset keys;   /* key strings; arena offset identifies the key */
+  setrec* sets;   /* parallel array indexed by insertion order */
+  size_t nsets, capsets;
+  uint64_t* key_to_set; /* map arena offset -> set index: small open-addressing table */
+  size_t k2s_n;
+  char* filter;
+  size_t filter_len;
+  int log_expired;
+  int64_t now;
+  int64_t inserted;
+  int64_t* sorted; /* lazily built sorted key index */
+  size_t sorted_n;
+};
+
+orc_engine* orc_engine_new(const char* filter, size_t filter_len, int log_expired, int64_t now) {
+  orc_engine* e = (orc_engine*)calloc(1, sizeof(*e));
+  bs_init(&e->keys);
+  e->filter = (char*)malloc(filter_len + 1);
+  if (filter_len) memcpy(e->filter, filter, filter_len);
+  e->filter[filter_len] = 0;
+  e->filter_len = filter_len;
+  e->log_expired = log_expired;
+  e->now = now;
+  e->k2s_n = 64;
+  e->key_to_set = (uint64_t*)calloc(e->k2s_n * 2, sizeof(uint64_t));
+  return e;
+}
+
+void orc_engine_free(orc_engine* e) {
+  if (!e) return;
+  for (size_t i = 0; i < e->nsets; i++) bs_free(&e->sets[i].members);
+  free(e->sets);
+  bs_free(&e->keys);
+  free(e->key_to_set);
+  free(e->filter);
+  free(e->sorted);
+  free(e);
+}
+
+static setrec* get_set(orc_engine* e, const char* key, size_t key_len, int create) {
+  int was_new = 0;
+  int64_t off = bs_find(&e->keys, (const uint8_t*)key, key_len, create, &was_new);
+  if (off < 0) return NULL;
+  if (was_new) {
+    if (e->nsets == e->capsets) {
+      e->capsets = e->capsets ? e->capsets * 2 : 64;
+      e->sets = (setrec*)realloc(e->sets, e->capsets * sizeof(setrec));
+    }
+    setrec* s = &e->sets[e->nsets];
+    bs_init(&s->members);
+    s->has_expiry = 0;
+    s->expiry = 0;
+    s->key_off = (uint64_t)off;
+    /* map off -> index */
+    if ((e->nsets + 1) * 2 > e->k2s_n) {
+      size_t nn = e->k2s_n * 2;
+      uint64_t* nt = (uint64_t*)calloc(nn * 2, sizeof(uint64_t));
+      for (size_t i = 0; i < e->k2s_n; i++) {
+        if (!e->key_to_set[2 * i]) continue;
+        size_t j = (e->key_to_set[2 * i] * 0x9e3779b97f4a7c15ull >> 20) & (nn - 1);
+        while (nt[2 * j]) j = (j + 1) & (nn - 1);
+        nt[2 * j] = e->key_to_set[2 * i];
+        nt[2 * j + 1] = e->key_to_set[2 * i + 1];
+      }
+      free(e->key_to_set);
+      e->key_to_set = nt;
+      e->k2s_n = nn;
+    }
+    uint64_t tag = (uint64_t)off + 1;
+    size_t j = (tag * 0x9e3779b97f4a7c15ull >> 20) & (e->k2s_n - 1);
+    while (e->key_to_set[2 * j]) j = (j + 1) & (e->k2s_n - 1);
+    e->key_to_set[2 * j] = tag;
+    e->key_to_set[2 * j + 1] = e->nsets;
+    e->nsets++;
+    free(e->sorted);
+    e->sorted = NULL;
+    return s;
+  }
+  uint64_t tag = (uint64_t)off + 1;
+  size_t j = (tag * 0x9e3779b97f4a7c15ull >> 20) & (e->k2s_n - 1);
+  while (e->key_to_set[2 * j] != tag) j = (j + 1) & (e->k2s_n - 1);
+  return &e->sets[e->key_to_set[2 * j + 1]];
+}
+
+int orc_set_insert(orc_engine* e, const char* key, size_t key_len, const uint8_t* m, size_t n) {
+  setrec* s = get_set(e, key, key_len, 1);
+  int was_new = 0;
+  bs_find(&s->members, m, n, 1, &was_new);
+  return was_new;
+}
+
+int orc_set_contains(orc_engine* e, const char* key, size_t key_len, const uint8_t* m, size_t n) {
+  setrec* s = get_set(e, key, key_len, 0);
+  if (!s) return 0;
+  return bs_find(&s->members, m, n, 0, NULL) >= 0;
+}
+
+int64_t orc_set_cardinality(orc_engine* e, const char* key, size_t key_len) {
+  setrec* s = get_set(e, key, key_len, 0);
+  return s ? (int64_t)s->members.count : 0;
+}
+
+int64_t orc_key_count(orc_engine* e) { return (int64_t)e->nsets; }
+
+static orc_engine* g_sort_engine;
+static int cmp_keys(const void* a, const void* b) {
+  const setrec* sa = &g_sort_engine->sets[*(const int64_t*)a];
+  const setrec* sb = &g_sort_engine->sets[*(const int64_t*)b];
+  uint32_t la, lb;
+  memcpy(&la, g_sort_engine->keys.bytes + sa->key_off, 4);
+  memcpy(&lb, g_sort_engine->keys.bytes + sb->key_off, 4);
+  int c = memcmp(g_sort_engine->keys.bytes + sa->key_off + 4,
+                 g_sort_engine->keys.bytes + sb->key_off + 4, la < lb ? la : lb);
+  if (c) return c;
+  return la < lb ? -1 : la > lb;
+}
+
+size_t orc_key_at(orc_engine* e, int64_t i, char* out, size_t cap) {
+  if (!e->sorted) {
+    e->sorted = (int64_t*)malloc(sizeof(int64_t) * (e->nsets ? e->nsets : 1));
+    for (size_t k = 0; k < e->nsets; k++) e->sorted[k] = (int64_t)k;
+    g_sort_engine = e;
+    qsort(e->sorted, e->nsets, sizeof(int64_t), cmp_keys);
+  }
+  if (i < 0 || (size_t)i >= e->nsets) return 0;
+  setrec* s = &e->sets[e->sorted[i]];
+  uint32_t l;
+  memcpy(&l, e->keys.bytes + s->key_off, 4);
+  memcpy(out, e->keys.bytes + s->key_off + 4, l < cap ? l : cap);
+  return l;
+}
+
+int orc_key_expiry(orc_engine* e, const char* key, size_t key_len, int64_t* t) {
+  setrec* s = get_set(e, key, key_len, 0);
+  if (!s || !s->has_expiry) return 0;
+  *t = s->expiry;
+  return 1;
+}
+
+typedef struct {
+  const uint8_t* p;
+  uint32_t n;
+} mref;
+static int cmp_mref(const void* a, const void* b) {
+  const mref* x = (const mref*)a;
+  const mref* y = (const mref*)b;
+  int c = memcmp(x->p, y->p, x->n < y->n ? x->n : y->n);
+  if (c) return c;
+  return x->n < y->n ? -1 : x->n > y->n;
+}
+
+size_t orc_set_members(orc_engine* e, const char* key, size_t key_len, uint8_t* out, size_t cap) {
+  setrec* s = get_set(e, key, key_len, 0);
+  if (!s) return 0;
+  size_t need = s->members.used;
+  if (need > cap || !out) return need;
+  mref* r = (mref*)malloc(sizeof(mref) * (s->members.count ? s->members.count : 1));
+  size_t k = 0;
+  for (size_t o = 0; o < s->members.used;) {
+    uint32_t l;
+    memcpy(&l, s->members.bytes + o, 4);
+    r[k].p = s->members.bytes + o + 4;
+    r[k].n = l;
+    k++;
+    o += 4 + l;
+  }
+  qsort(r, k, sizeof(mref), cmp_mref);
+  size_t w = 0;
+  for (size_t i = 0; i < k; i++) {
+    memcpy(out + w, &r[i].n, 4);
+    memcpy(out + w + 4, r[i].p, r[i].n);
+    w += 4 + r[i].n;
+  }
+  free(r);
+  return need;
+}
+
+/* storage-statistics.go:28-82 via GetIssuerAndDatesFromCache (filesystemdatabase.go:59-100):
+ * keys "serials::<expDate>::<issuerID>" split on "::"; count = Σ SCARD per issuer. */
+int64_t orc_issuer_count(orc_engine* e, const char* issuer_id) {
+  size_t il = strlen(issuer_id);
+  int64_t total = 0;
+  for (size_t i = 0; i < e->nsets; i++) {
+    uint32_t l;
+    memcpy(&l, e->keys.bytes + e->sets[i].key_off, 4);
+    const char* k = (const char*)e->keys.bytes + e->sets[i].key_off + 4;
+    if (l < 9 + 2 + il || memcmp(k, "serials::", 9) != 0) continue;
+    /* parts[2] is everything after the second "::" provided there are exactly 3 parts */
+    const char* second = NULL;
+    for (size_t j = 9; j + 1 < l; j++)
+      if (k[j] == ':' && k[j + 1] == ':') {
+        second = k + j + 2;
+        break;
+      }
+    if (!second) continue;
+    size_t rest = l - (size_t)(second - k);
+    if (rest == il && memcmp(second, issuer_id, il) == 0) total += (int64_t)e->sets[i].members.count;
+  }
+  return total;
+}
+
+int64_t orc_total_count(orc_engine* e) {
+  int64_t total = 0;
+  for (size_t i = 0; i < e->nsets; i++) {
+    uint32_t l;
+    memcpy(&l, e->keys.bytes + e->sets[i].key_off, 4);
+    const char* k = (const char*)e->keys.bytes + e->sets[i].key_off + 4;
+    if (l >= 9 && memcmp(k, "serials::", 9) == 0) total += (int64_t)e->sets[i].members.count;
+  }
+  return total;
+}
+
+int64_t orc_inserted(orc_engine* e) { return e->inserted; }
+
+/* One pass of insertCTWorker's loop body + FilesystemDatabase.Store.
+ * ct-fetch.go:191-235; filesystemdatabase.go:158-211; knowncertificates.go:28-55. */
+int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, const uint8_t* issuer_der,
+                     size_t issuer_len, int* was_unknown, int32_t* exp_hour,
+                     const uint8_t** serial, uint32_t* serial_len) {
+  orc_cert c;
+  if (was_unknown) *was_unknown = 0;
+  orc_parse_cert(leaf, leaf_len, &c); /* :198-204 */
+  if (!c.ok) return ORC_ST_PARSE_ERROR; /* :206-209 */
+  if (exp_hour) *exp_hour = orc_exp_hour(c.not_after);
+  if (serial) *serial = leaf + c.serial_off;
+  if (serial_len) *serial_len = c.serial_len;
+  int f = orc_cert_is_filtered_out(leaf, &c, e->filter, e->filter_len, e->log_expired, e->now);
+  if (f != ORC_ST_PASS) return f; /* :211-213 */
+  if (!issuer_der) return ORC_ST_NO_ISSUER; /* :215-219 */
+  orc_cert ic;
+  orc_parse_cert(issuer_der, issuer_len, &ic); /* :221 */
+  if (!ic.ok) return ORC_ST_ISSUER_PARSE_ERROR; /* :222-225 */
+  /* Store: filesystemdatabase.go:158-211 */
+  int32_t eh = orc_exp_hour(c.not_after);           /* :160 */
+  char issuer_id[45];
+  orc_issuer_id(issuer_der + ic.spki_off, ic.spki_len, issuer_id); /* :161, types.go:124-130 */
+  char exp_id[16];
+  orc_exp_date_id(eh, exp_id);
+  char key[96];
+  int kl = snprintf(key, sizeof key, "serials::%s::%s", exp_id, issuer_id); /* knowncertificates.go:28-34 */
+  setrec* s = get_set(e, key, (size_t)kl, 1);
+  int was_new = 0;
+  bs_find(&s->members, leaf + c.serial_off, c.serial_len, 1, &was_new); /* SetInsert :39 */
+  if (!s->has_expiry) { /* :44-47 → ExpireAt(key, expDate.ExpireTime()) :98-104 */
+    s->has_expiry = 1;
+    s->expiry = (int64_t)eh * 3600;
+  }
+  if (was_unknown) *was_unknown = was_new;
+  e->inserted++; /* ct-fetch.go:235 */
+  return ORC_ST_PASS;
+}
+
+void orc_engine_batch(orc_engine* e, const uint8_t* payload, const uint64_t* offsets,
+                      const uint32_t* issuer_idx, uint64_t n, const uint8_t* issuer_payload,
+                      const uint64_t* issuer_offsets, uint32_t n_issuers, uint8_t* out_status,
+                      uint8_t* out_unknown, int32_t* out_exp_hour) {
+  for (uint64_t i = 0; i < n; i++) {
+    const uint8_t* leaf = payload + offsets[i];
+    size_t ll = (size_t)(offsets[i + 1] - offsets[i]);
+    const uint8_t* idr = NULL;
+    size_t il = 0;
+    uint32_t ii = issuer_idx[i];
+    if (ii != 0xffffffffu && ii < n_issuers) {
+      idr = issuer_payload + issuer_offsets[ii];
+      il = (size_t)(issuer_offsets[ii + 1] - issuer_offsets[ii]);
+    }
+    int unk = 0;
+    int32_t eh = 0;
+    int st = orc_engine_entry(e, leaf, ll, idr, il, &unk, &eh, NULL, NULL);
+    if (out_status) out_status[i] = (uint8_t)st;
+    if (out_unknown) out_unknown[i] = (uint8_t)unk;
+    if (out_exp_hour) out_exp_hour[i] = eh;
+  }
+}

@@ -1,0 +1,129 @@
+/*
+ * ctmr_oracle.h — CPU ORACLE for the ct-mapreduce map/reduce hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and
+ * there only as the checker.  The product (ct_mapreduce_amd/) never links or calls it.
+ *
+ * It is a plain-C restatement of the reference's algorithm (jcjones/ct-mapreduce),
+ * each function citing the reference file:line it follows.
+ *
+ * PARITY PIN STATUS
+ *   pinned by the reference's own golden vectors (tests/test_oracle_golden.py):
+ *     G1 Issuer.ID known answer          storage/types_test.go:41-57
+ *     G2 leading-zero serial 00aa / AKo= storage/types_test.go:21-39,81-101
+ *     G3/G4 kRealSPKI / kEmptySPKI parse storage/filesystemdatabase_test.go:16-65,80-111
+ *     G5 key format + expiry hour        storage/knowncertificates_test.go:85-110
+ *     G6 set semantics                   storage/knowncertificates_test.go:11-83
+ *     G9 ExpDate / UniqueCertIdentifier  storage/types_test.go:203-269
+ *   PARITY UNPINNED at the third-party parser boundary: x509.ParseCertificate is
+ *   github.com/google/certificate-transparency-go v1.1.0 (go.mod:10), absent from
+ *   /root/reference and from this machine; no Go toolchain exists here.  The fields
+ *   Issuer.CommonName, NotAfter, IsCA/BasicConstraintsValid and every accept/reject
+ *   decision follow RFC 5280 DER + the "DER walk profile" written down in DESIGN.md §3,
+ *   cross-checked against OpenSSL 3 (tests/test_oracle_openssl.py) but NOT against Go.
+ */
+#ifndef CTMR_ORACLE_H
+#define CTMR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-entry status: order == the order the reference tests things in
+ *      insertCTWorker (cmd/ct-fetch/ct-fetch.go:191-235) ---- */
+enum {
+  ORC_ST_PASS = 0,               /* reached database.Store                         :229 */
+  ORC_ST_PARSE_ERROR = 1,        /* x509.ParseCertificate(leaf) failed             :202-209 */
+  ORC_ST_FILTERED_CA = 2,        /* certIsFilteredOut: BasicConstraintsValid&&IsCA :47-50 */
+  ORC_ST_FILTERED_EXPIRED = 3,   /* NotAfter.Before(now) && !LogExpiredEntries     :52-55 */
+  ORC_ST_FILTERED_CN = 4,        /* issuerCNFilter prefix miss                     :57-69 */
+  ORC_ST_NO_ISSUER = 5,          /* len(Chain) < 1                                 :215-219 */
+  ORC_ST_ISSUER_PARSE_ERROR = 6  /* x509.ParseCertificate(Chain[0]) failed         :221-225 */
+};
+
+/* Result of the TBSCertificate field walk (the subset of *x509.Certificate the
+ * reference's path consumes — SURVEY.md §8(a) a2). Offsets are into the DER buffer. */
+typedef struct {
+  int32_t ok;            /* 1 = accepted by the walk profile, 0 = parse error */
+  int32_t err_site;      /* diagnostic: which check failed (not part of parity) */
+  uint32_t serial_off, serial_len;   /* raw INTEGER content octets (types.go:165-178) */
+  int64_t not_before;    /* unix seconds */
+  int64_t not_after;     /* unix seconds */
+  uint32_t cn_off, cn_len;           /* issuer CommonName (last CN wins), len 0 if none */
+  int32_t bc_valid;      /* basicConstraints extension present and parsed */
+  int32_t is_ca;
+  uint32_t spki_off, spki_len;       /* RawSubjectPublicKeyInfo: full TLV */
+  uint32_t tbs_off, tbs_len;         /* RawTBSCertificate: full TLV */
+} orc_cert;
+
+void orc_parse_cert(const uint8_t* der, size_t len, orc_cert* out);
+
+/* FIPS 180-4 SHA-256 (Go stdlib crypto/sha256 in types.go:155-159). */
+void orc_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
+/* base64.URLEncoding (padded) — types.go:146-159, 210-212. out must hold 4*ceil(n/3)+1. */
+size_t orc_b64url(const uint8_t* in, size_t n, char* out);
+/* Issuer.ID() = b64url(SHA-256(RawSubjectPublicKeyInfo)); 44 chars + NUL. types.go:124-130 */
+void orc_issuer_id(const uint8_t* spki, size_t n, char out[45]);
+/* floor(unix/3600): NewExpDateFromTime = NotAfter.Truncate(time.Hour) types.go:339-346 */
+int32_t orc_exp_hour(int64_t unix_seconds);
+/* ExpDate.ID() "2006-01-02-15", 13 chars + NUL. types.go:379-384 */
+void orc_exp_date_id(int32_t exp_hour, char out[16]);
+/* "2006-01-02" of a unix time — FilesystemDatabase.markDirty filesystemdatabase.go:141-144 */
+void orc_day_id(int64_t unix_seconds, char out[16]);
+
+/* certIsFilteredOut (ct-fetch.go:44-70).  filter = *ctconfig.IssuerCNFilter verbatim
+ * (comma-split, pieces NOT trimmed); now = time.Now() as unix seconds (H6: injected).
+ * Returns ORC_ST_PASS or one of the FILTERED_* codes. */
+int orc_cert_is_filtered_out(const uint8_t* der, const orc_cert* c, const char* filter,
+                             size_t filter_len, int log_expired, int64_t now);
+
+/* ---- the reduce: FilesystemDatabase.Store over a MockRemoteCache-like set store
+ *      (filesystemdatabase.go:158-211, knowncertificates.go:38-55, mockcache.go:38-61) ---- */
+typedef struct orc_engine orc_engine;
+
+orc_engine* orc_engine_new(const char* filter, size_t filter_len, int log_expired, int64_t now);
+void orc_engine_free(orc_engine*);
+
+/* One iteration of insertCTWorker's loop body.  issuer_der==NULL ⇔ len(Chain)<1.
+ * Returns the status; *was_unknown = knownCerts.WasUnknown(serial) when status==PASS.
+ * exp_hour/serial are filled whenever the leaf parsed. */
+int orc_engine_entry(orc_engine*, const uint8_t* leaf, size_t leaf_len, const uint8_t* issuer_der,
+                     size_t issuer_len, int* was_unknown, int32_t* exp_hour,
+                     const uint8_t** serial, uint32_t* serial_len);
+
+/* Direct RemoteCache-style access to the same store (types.go:83-102 subset). */
+int orc_set_insert(orc_engine*, const char* key, size_t key_len, const uint8_t* member, size_t n);
+int orc_set_contains(orc_engine*, const char* key, size_t key_len, const uint8_t* member, size_t n);
+int64_t orc_set_cardinality(orc_engine*, const char* key, size_t key_len);
+int64_t orc_key_count(orc_engine*);                       /* number of distinct set keys */
+/* i-th key in sorted order (bytewise); returns length, copies ≤cap bytes. */
+size_t orc_key_at(orc_engine*, int64_t i, char* out, size_t cap);
+/* expiry recorded by the first WasUnknown on a key (knowncertificates.go:44-47,98-104);
+ * returns 0 if none recorded. */
+int orc_key_expiry(orc_engine*, const char* key, size_t key_len, int64_t* unix_seconds);
+/* Members of a set, sorted bytewise (mockcache keeps them sorted, mockcache.go:38-61).
+ * Serialised as [u32 len][bytes]...; returns bytes needed; copies if cap suffices. */
+size_t orc_set_members(orc_engine*, const char* key, size_t key_len, uint8_t* out, size_t cap);
+/* Total members over all keys whose issuer part == issuer_id:
+ * storage-statistics.go:44-53 (Σ_expDate SCARD(serials::expDate::issuer)). */
+int64_t orc_issuer_count(orc_engine*, const char* issuer_id);
+int64_t orc_total_count(orc_engine*);
+/* Running `insertCTWorker.Inserted` counter (ct-fetch.go:235): PASS entries, dups included. */
+int64_t orc_inserted(orc_engine*);
+
+/* Batch driver over the packed layout: the same loop, used for the
+ * cpu_baseline timing and for bulk parity.  issuer_idx[i]==0xFFFFFFFF ⇔ no chain.
+ * out_status[n], out_unknown[n], out_exp_hour[n] may be NULL. */
+void orc_engine_batch(orc_engine*, const uint8_t* payload, const uint64_t* offsets,
+                      const uint32_t* issuer_idx, uint64_t n, const uint8_t* issuer_payload,
+                      const uint64_t* issuer_offsets, uint32_t n_issuers, uint8_t* out_status,
+                      uint8_t* out_unknown, int32_t* out_exp_hour);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+"""Pins the CPU oracle on the reference's own golden vectors (SURVEY.md §8(c) G1–G11)."""
+import base64
+import calendar
+import hashlib
+import json
+
+from oracle import oracle as orc
+
+
+def utc(y, mo, d, h=0, mi=0, s=0):
+    return calendar.timegm((y, mo, d, h, mi, s))
+
+
+# ---- G1: storage/types_test.go:41-57 --------------------------------------------------------
+def test_issuer_id_known_answer():
+    assert orc.issuer_id(b"\xff") == "qBAK5qoZQNC2Y7sxzUZhQuu9vVGHExuS2TgYmHgy64k="
+
+
+def test_sha256_against_hashlib():
+    for n in list(range(0, 200)) + [294, 1000, 4096, 65537]:
+        msg = bytes((i * 131 + n) & 0xff for i in range(n))
+        assert orc.sha256(msg) == hashlib.sha256(msg).digest(), n
+        assert orc.b64url(msg) == base64.urlsafe_b64encode(msg).decode(), n
+
+
+# ---- G2: storage/types_test.go:21-39,81-101 -------------------------------------------------
+def test_serial_with_leading_zeroes(golden_certs):
+    der = golden_certs["kLeadingZeroes"]
+    c = orc.parse_cert(der)
+    assert c.ok == 1
+    serial = der[c.serial_off:c.serial_off + c.serial_len]
+    assert serial.hex() == "00aa"                      # Serial.String()
+    assert orc.b64url(serial) == "AKo="                 # Serial.ID()
+    # fields implied mechanically (OpenSSL cross-check values)
+    assert c.not_after == utc(2020, 2, 5)
+    assert der[c.cn_off:c.cn_off + c.cn_len] == b"ca"
+    assert c.bc_valid == 0 and c.is_ca == 0
+    assert c.spki_len == 294
+    assert orc.issuer_id(der[c.spki_off:c.spki_off + c.spki_len]) == \
+        "VCIlmPM9NkgFQtrs4Oa5TeFcDu6MWRTKSNdePEhOgD8="
+
+
+# ---- G3/G4: storage/filesystemdatabase_test.go:16-65,80-111 ---------------------------------
+def test_real_spki_cert_parses(golden_certs):
+    der = golden_certs["kRealSPKI"]
+    c = orc.parse_cert(der)
+    assert c.ok == 1
+    assert der[c.serial_off:c.serial_off + c.serial_len].hex() == "12e3815300000000001d"
+    assert c.not_after == utc(2020, 12, 23, 10, 55, 32)
+    assert der[c.cn_off:c.cn_off + c.cn_len] == b"WISeKey CertifyID Standard G1 CA"
+    assert c.bc_valid == 1 and c.is_ca == 1
+    assert orc.issuer_id(der[c.spki_off:c.spki_off + c.spki_len]) == \
+        "d_Kor69hknpIfroNumzs6NkLxxCUNhMn46dzck_SZSQ="
+    # as a leaf it is dropped by filter (1): CA
+    assert orc.is_filtered_out(der, c, b"", False, utc(2019, 1, 1)) == orc.ST_FILTERED_CA
+
+
+def test_empty_spki_cert_parses(golden_certs):
+    der = golden_certs["kEmptySPKI"]
+    c = orc.parse_cert(der)
+    assert c.ok == 1
+    assert der[c.serial_off:c.serial_off + c.serial_len].hex() == \
+        "47139dbe6298d4b31e7a3b914e2b877860616 47c".replace(" ", "")
+    assert c.not_after == utc(2019, 2, 5)
+    assert c.bc_valid == 1 and c.is_ca == 1
+    assert c.spki_len == 294
+    # getSpki falls back to SHA-1(SPKI) = 20 bytes (filesystemdatabase.go:146-156): host-side,
+    # here we only pin that the SPKI range is the full TLV
+    assert der[c.spki_off] == 0x30
+
+
+# ---- G5: storage/knowncertificates_test.go:85-110 -------------------------------------------
+def test_expire_at_key_and_hour():
+    date = utc(2004, 1, 20, 4, 22, 19)
+    h = orc.exp_hour(date)
+    assert orc.exp_date_id(h) == "2004-01-20-04"
+    assert h * 3600 == utc(2004, 1, 20, 4, 0, 0)
+    key = ("serials::%s::%s" % (orc.exp_date_id(h), "test issuer")).encode()
+    assert key == b"serials::2004-01-20-04::test issuer"
+
+
+def test_store_sets_expiry_of_truncated_hour(golden_certs):
+    # leaf = kLeadingZeroes, issuer = kEmptySPKI (same "ca" key): derived expectation of SURVEY §8(c)
+    e = orc.Engine(b"", False, utc(2019, 1, 1))
+    st, unk, eh = e.entry(golden_certs["kLeadingZeroes"], golden_certs["kEmptySPKI"])
+    assert (st, unk) == (orc.ST_PASS, True)
+    key = b"serials::2020-02-05-00::VCIlmPM9NkgFQtrs4Oa5TeFcDu6MWRTKSNdePEhOgD8="
+    assert e.keys() == [key]
+    assert e.members(key) == [b"\x00\xaa"]
+    assert e.key_expiry(key) == utc(2020, 2, 5, 0)
+    st, unk, _ = e.entry(golden_certs["kLeadingZeroes"], golden_certs["kEmptySPKI"])
+    assert (st, unk) == (orc.ST_PASS, False)
+    assert e.inserted() == 2 and e.total_count() == 1
+    assert e.issuer_count("VCIlmPM9NkgFQtrs4Oa5TeFcDu6MWRTKSNdePEhOgD8=") == 1
+
+
+# ---- G6: storage/knowncertificates_test.go:11-83 --------------------------------------------
+def test_unknown_then_known():
+    e = orc.Engine()
+    key = b"serials::2029-01-30::test issuer"
+    for b in (b"\x01", b"\x02", b"\x03", b"\x04"):
+        assert e.set_insert(key, b)
+    for b in (b"\x01", b"\x02", b"\x03", b"\x04"):
+        assert not e.set_insert(key, b)          # WasUnknown == false
+    assert e.set_insert(key, b"\x05")            # unknown …
+    assert not e.set_insert(key, b"\x05")        # … then known
+    members = [m.decode("latin1") for m in e.members(key)]
+    assert json.dumps(members) == '["\\u0001", "\\u0002", "\\u0003", "\\u0004", "\\u0005"]'
+    assert e.set_cardinality(key) == 5
+
+
+def test_known_and_count():
+    e = orc.Engine()
+    key = b"serials::2029-01-30::test issuer"
+    for b in (b"\x01", b"\x03", b"\x05"):
+        e.set_insert(key, b)
+    assert e.members(key) == [b"\x01", b"\x03", b"\x05"]
+    assert e.set_cardinality(key) == 3
+
+
+# ---- G9: storage/types_test.go:203-269 ------------------------------------------------------
+def test_exp_date_ids():
+    assert orc.exp_date_id(orc.exp_hour(utc(2004, 1, 19, 4))) == "2004-01-19-04"
+    assert orc.exp_date_id(orc.exp_hour(utc(2004, 1, 19, 23, 59, 59))) == "2004-01-19-23"
+    assert orc.exp_date_id(orc.exp_hour(utc(2019, 4, 28, 22, 30))) == "2019-04-28-22"
+    assert orc.day_id(utc(2004, 1, 19, 23, 59, 59)) == "2004-01-19"
+    # pre-epoch: Truncate floors
+    assert orc.exp_date_id(orc.exp_hour(utc(1969, 12, 31, 23, 30))) == "1969-12-31-23"
+    assert orc.exp_date_id(orc.exp_hour(-1)) == "1969-12-31-23"
+    # UniqueCertIdentifier "2019-04-28-22::an issuer::AESq_w==" — serial ID is padded b64url
+    assert orc.b64url(bytes.fromhex("0044aaff")) == "AESq_w=="
+
+
+# ---- filters: cmd/ct-fetch/ct-fetch.go:44-70 (no reference test exists: semantics restated) ----
+def test_filter_order_and_untrimmed_pieces(golden_certs):
+    der = golden_certs["kLeadingZeroes"]           # issuer CN "ca", not a CA, notAfter 2020-02-05
+    c = orc.parse_cert(der)
+    now_ok, now_late = utc(2019, 1, 1), utc(2021, 1, 1)
+    assert orc.is_filtered_out(der, c, b"", False, now_ok) == orc.ST_PASS
+    assert orc.is_filtered_out(der, c, b"", False, now_late) == orc.ST_FILTERED_EXPIRED
+    assert orc.is_filtered_out(der, c, b"", True, now_late) == orc.ST_PASS
+    assert orc.is_filtered_out(der, c, b"c", False, now_ok) == orc.ST_PASS
+    assert orc.is_filtered_out(der, c, b"ca", False, now_ok) == orc.ST_PASS
+    assert orc.is_filtered_out(der, c, b"cab", False, now_ok) == orc.ST_FILTERED_CN
+    assert orc.is_filtered_out(der, c, b"x,ca", False, now_ok) == orc.ST_PASS
+    assert orc.is_filtered_out(der, c, b"x, ca", False, now_ok) == orc.ST_FILTERED_CN   # " ca" untrimmed
+    assert orc.is_filtered_out(der, c, b"x,", False, now_ok) == orc.ST_PASS            # empty piece
+    # NotAfter.Before(now) is strict
+    assert orc.is_filtered_out(der, c, b"", False, c.not_after) == orc.ST_PASS
+    assert orc.is_filtered_out(der, c, b"", False, c.not_after + 1) == orc.ST_FILTERED_EXPIRED
+    # expired is tested before the CN filter
+    assert orc.is_filtered_out(der, c, b"zz", False, now_late) == orc.ST_FILTERED_EXPIRED
+
+
+def test_entry_status_order(golden_certs):
+    e = orc.Engine(b"", False, utc(2019, 1, 1))
+    leaf = golden_certs["kLeadingZeroes"]
+    assert e.entry(b"\x30\x03\x02\x01\x00", golden_certs["kEmptySPKI"])[0] == orc.ST_PARSE_ERROR
+    assert e.entry(golden_certs["kRealSPKI"], None)[0] == orc.ST_FILTERED_CA      # filter before chain check
+    assert e.entry(leaf, None)[0] == orc.ST_NO_ISSUER
+    assert e.entry(leaf, b"\x30\x00")[0] == orc.ST_ISSUER_PARSE_ERROR
+    assert e.inserted() == 0
+
+
+def test_walk_rejects_truncations_and_accepts_only_exact_length(golden_certs):
+    for der in golden_certs.values():
+        assert orc.parse_cert(der).ok == 1
+        assert orc.parse_cert(der + b"\x00").ok == 0            # trailing data
+        for cut in (1, 2, 10, len(der) // 2, len(der) - 1):
+            assert orc.parse_cert(der[:cut]).ok == 0
