@@ -1,0 +1,107 @@
+"""ctypes binding of libctmr.so — exactly the symbols include/ctmr.h declares.
+
+The library is the product; this module only loads it.  There is no Python/CPU fallback: if the
+shared object is missing, or no HIP device is usable, the failure is raised to the caller.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libctmr.so")
+
+ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
+    ST_ISSUER_PARSE_ERROR = range(7)
+ST_COUNT = 7
+FL_PRECERT, FL_WAS_UNKNOWN, FL_LONG_SERIAL = 1, 2, 4
+NO_ISSUER = 0xFFFFFFFF
+PAYLOAD_PAD = 32
+MAX_SERIAL = 40
+E_INVAL, E_HIP, E_NOMEM, E_FULL, E_NOTFOUND, E_RANGE = -1, -2, -3, -4, -5, -6
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_slots", C.c_uint64),
+                ("pair_slots", C.c_uint64), ("max_issuers", C.c_uint32), ("certs_per_tile", C.c_uint32),
+                ("lds_tile_bytes", C.c_uint32), ("map_variant", C.c_uint32), ("profile", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("by_status", C.c_uint64 * ST_COUNT), ("n_new", C.c_uint64),
+                ("n_dup", C.c_uint64), ("n_host_set", C.c_uint64), ("payload_bytes", C.c_uint64),
+                ("ms_map", C.c_float), ("ms_insert", C.c_float), ("ms_resolve", C.c_float),
+                ("ms_compact", C.c_float), ("ms_total", C.c_float), ("map_launches", C.c_uint32)]
+
+
+class IssuerInfo(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("canonical_idx", C.c_uint32), ("spki_sha256", C.c_uint8 * 32),
+                ("issuer_id", C.c_char * 48)]
+
+
+class SynthConfig(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_issuers", C.c_uint32), ("zipf", C.c_uint32),
+                ("dup_permille", C.c_uint32), ("ca_permille", C.c_uint32),
+                ("expired_permille", C.c_uint32), ("mean_len", C.c_uint32), ("base_time", C.c_int64)]
+
+
+# name → (restype, argtypes); must list every function include/ctmr.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "ctmr_abi_version": (C.c_int, []),
+    "ctmr_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "ctmr_destroy": (None, [_P]),
+    "ctmr_last_error": (C.c_char_p, [_P]),
+    "ctmr_set_stream": (C.c_int, [_P, _P]),
+    "ctmr_synchronize": (C.c_int, [_P]),
+    "ctmr_add_issuers": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "ctmr_issuer_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "ctmr_issuer_info_get": (C.c_int, [_P, C.c_uint32, C.POINTER(IssuerInfo)]),
+    "ctmr_set_filter": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_int, C.c_int64]),
+    "ctmr_map_batch": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, _P, _P, C.POINTER(BatchStats)]),
+    "ctmr_map_batch_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, _P, _P, C.POINTER(BatchStats)]),
+    "ctmr_set_insert": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ctmr_set_contains": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ctmr_set_remove": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ctmr_set_cardinality": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "ctmr_exists": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ctmr_set_members": (C.c_int, [_P, C.c_char_p, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_uint64)]),
+    "ctmr_keys": (C.c_int, [_P, C.c_char_p, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t),
+                            C.POINTER(C.c_uint64)]),
+    "ctmr_expire_at": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_int64]),
+    "ctmr_expire_sweep": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_uint64)]),
+    "ctmr_issuer_counts": (C.c_int, [_P, _P, C.c_uint32]),
+    "ctmr_total_count": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ctmr_issuer_counts_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
+    "ctmr_reset_known": (C.c_int, [_P]),
+    "ctmr_synth_leaf_len": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64]),
+    "ctmr_synth_leaf": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64, _P, C.c_uint32,
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
+    "ctmr_synth_issuer": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint32, _P, C.c_uint32]),
+    "ctmr_synth_host": (C.c_uint64, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P, C.c_uint64,
+                                     _P, _P]),
+    "ctmr_synth_device": (C.c_int, [_P, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P,
+                                    C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libctmr.so (built in-tree by ct_mapreduce_amd.build).  Raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -m ct_mapreduce_amd.build, or __graft_entry__.build()). "
+                "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError ⇒ ABI mismatch, loudly
+            fn.restype = res
+            fn.argtypes = args
+        if L.ctmr_abi_version() != 1:
+            raise ImportError("libctmr ABI version mismatch")
+        _LIB = L
+    return _LIB

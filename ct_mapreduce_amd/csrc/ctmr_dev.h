@@ -1,0 +1,82 @@
+// ctmr_dev.h — device-side data layout shared by the kernels and the engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ctmr.h"
+#include "der_walk.h"
+
+namespace ctmr {
+
+// ---------------------------------------------------------------- known-certificate table
+// Open addressing, linear probing, one 64-byte slot per known certificate
+// (= one member of a Redis set "serials::<expDate>::<issuerID>", knowncertificates.go:28-55):
+//   w[0]  tag32 << 32 | min_idx32   claimed with atomicCAS(0 → …); same-key entries of one
+//                                   batch atomicMin their batch index into the low half so the
+//                                   lowest log index is the one that "was unknown"
+//   w[1]  VALID(63) | serial_len(62..56) | canonical issuer (55..32) | exp_hour (31..0)
+//                                   published last (write-through) — readers poll it
+//   w[2]  epoch of the batch that created the slot
+//   w[3..7] serial octets, zero padded (CTMR_MAX_SERIAL = 40)
+struct __attribute__((aligned(64))) Slot {
+  unsigned long long w[8];
+};
+static_assert(sizeof(Slot) == 64, "slot");
+
+constexpr unsigned long long SLOT_VALID = 1ull << 63;
+constexpr unsigned long long SLOT_TOMB = 0xffffffff00000000ull;  // removed member
+constexpr uint32_t SID_NONE = 0xffffffffu;       // entry did not reach the set
+constexpr uint32_t SID_HOST = 0xfffffffeu;       // serial longer than CTMR_MAX_SERIAL
+constexpr uint32_t SID_FULL = 0xfffffffdu;       // table full
+
+__host__ __device__ inline unsigned long long key_meta(int32_t exp_hour, uint32_t canon,
+                                                        uint32_t serial_len) {
+  return SLOT_VALID | ((unsigned long long)(serial_len & 0x7fu) << 56) |
+         ((unsigned long long)(canon & 0xffffffu) << 32) | (uint32_t)exp_hour;
+}
+
+__host__ __device__ inline unsigned long long mixk(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+// 64-bit hash of (meta, serial words)
+__host__ __device__ inline unsigned long long key_hash(unsigned long long meta,
+                                                        const unsigned long long s[5]) {
+  unsigned long long h = mixk(meta + 0x9e3779b97f4a7c15ull);
+#pragma unroll
+  for (int i = 0; i < 5; i++) h = mixk(h ^ (s[i] + 0x9e3779b97f4a7c15ull * (i + 2)));
+  return h;
+}
+__host__ __device__ inline uint32_t key_tag(unsigned long long h) {
+  uint32_t t = (uint32_t)(h >> 32);
+  if (t == 0u) t = 1u;
+  if (t == 0xffffffffu) t = 0xfffffffeu;
+  return t;
+}
+
+// ---------------------------------------------------------------- (expDate, issuer) → cardinality
+// 16-byte slots: key = (canon+1) << 32 | (uint32)exp_hour (0 = empty), count.
+struct PairSlot {
+  unsigned long long key, count;
+};
+
+// device-resident per-batch statistics
+struct DevStats {
+  unsigned long long by_status[CTMR_ST__COUNT];
+  unsigned long long n_new, n_dup, n_host, n_full, pair_full;
+};
+
+// map-kernel filter constants (device memory; uniform reads)
+struct FilterDev {
+  uint32_t active;       // len(*ctconfig.IssuerCNFilter) != 0
+  uint32_t n_pieces;     // strings.Split(filter, ",")
+  uint32_t log_expired;
+  uint32_t pad;
+  long long now;
+  uint32_t piece_len[64];
+  uint32_t piece_word[64];  // index of the piece's first word in words[]
+  uint32_t words[1024];     // pieces, zero padded to 4-byte multiples
+};
+
+}  // namespace ctmr

@@ -1,0 +1,1035 @@
+// ctmr_engine.hip — libctmr: the C ABI of include/ctmr.h over the gfx950 kernels.
+//
+// Plain HIP runtime, no torch, no CPU fallback: if the HIP device is unusable every entry
+// point fails with CTMR_E_HIP.  Host-side state kept here is only what the reference keeps in
+// Redis for keys that are not known-certificate sets (crl::, issuer::, log:: …) plus the
+// issuer registry.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace ctmr;
+
+namespace {
+
+struct HostReader {  // host instantiation of the walk for the long-serial slow path only
+  const uint8_t* p;
+  uint32_t ld4(uint32_t pos) const {
+    uint32_t v;
+    memcpy(&v, p + pos, 4);
+    return v;
+  }
+};
+
+struct IssuerRec {
+  bool valid;
+  uint32_t canon;
+  uint8_t digest[32];
+  std::string id;
+};
+
+std::string b64url(const uint8_t* in, size_t n) {
+  static const char A[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_";
+  std::string o;
+  size_t i = 0;
+  for (; i + 3 <= n; i += 3) {
+    uint32_t v = (in[i] << 16) | (in[i + 1] << 8) | in[i + 2];
+    o += A[(v >> 18) & 63]; o += A[(v >> 12) & 63]; o += A[(v >> 6) & 63]; o += A[v & 63];
+  }
+  if (n - i == 1) {
+    uint32_t v = in[i] << 16;
+    o += A[(v >> 18) & 63]; o += A[(v >> 12) & 63]; o += "==";
+  } else if (n - i == 2) {
+    uint32_t v = (in[i] << 16) | (in[i + 1] << 8);
+    o += A[(v >> 18) & 63]; o += A[(v >> 12) & 63]; o += A[(v >> 6) & 63]; o += '=';
+  }
+  return o;
+}
+
+// ExpDate.ID() "2006-01-02-15" ↔ hours since the epoch (storage/types.go:339-384)
+std::string exp_date_id(int32_t exp_hour) {
+  int64_t days = exp_hour / 24;
+  int hh = exp_hour % 24;
+  if (hh < 0) { hh += 24; days -= 1; }
+  int32_t y; uint32_t m, d;
+  civil_from_days(days, y, m, d);
+  char buf[32];
+  snprintf(buf, sizeof buf, "%04d-%02u-%02u-%02d", y, m, d, hh);
+  return buf;
+}
+
+bool parse_exp_date_id(const char* s, size_t n, int32_t* out) {
+  if (n != 13) return false;
+  for (int i = 0; i < 13; i++) {
+    if (i == 4 || i == 7 || i == 10) { if (s[i] != '-') return false; }
+    else if (s[i] < '0' || s[i] > '9') return false;
+  }
+  int y = (s[0]-'0')*1000 + (s[1]-'0')*100 + (s[2]-'0')*10 + (s[3]-'0');
+  uint32_t m = (s[5]-'0')*10 + (s[6]-'0'), d = (s[8]-'0')*10 + (s[9]-'0'), h = (s[11]-'0')*10 + (s[12]-'0');
+  if (m < 1 || m > 12 || d < 1 || d > 31 || h > 23) return false;
+  int64_t hours = days_from_civil(y, m, d) * 24 + h;
+  if (hours < INT32_MIN || hours > INT32_MAX) return false;
+  if (exp_date_id((int32_t)hours) != std::string(s, n)) return false;  // e.g. Feb 30
+  *out = (int32_t)hours;
+  return true;
+}
+
+// Redis-style glob (KEYS pattern, rediscache.go:153-169): * ? [set] backslash-escape
+bool glob_match(const char* p, size_t pn, const char* s, size_t sn) {
+  size_t pi = 0, si = 0, star_p = (size_t)-1, star_s = 0;
+  while (si < sn) {
+    bool adv = false;
+    if (pi < pn) {
+      char c = p[pi];
+      if (c == '*') { star_p = pi++; star_s = si; continue; }
+      if (c == '?') { pi++; si++; adv = true; }
+      else if (c == '[') {
+        size_t q = pi + 1; bool neg = false, hit = false;
+        if (q < pn && p[q] == '^') { neg = true; q++; }
+        while (q < pn && p[q] != ']') {
+          char lo = p[q];
+          if (lo == '\\' && q + 1 < pn) lo = p[++q];
+          char hi = lo;
+          if (q + 2 < pn && p[q + 1] == '-' && p[q + 2] != ']') { hi = p[q + 2]; q += 2; }
+          if (lo > hi) std::swap(lo, hi);
+          if (s[si] >= lo && s[si] <= hi) hit = true;
+          q++;
+        }
+        if (hit != neg) { pi = q < pn ? q + 1 : q; si++; adv = true; }
+      } else {
+        if (c == '\\' && pi + 1 < pn) c = p[++pi];
+        if (c == s[si]) { pi++; si++; adv = true; }
+      }
+    }
+    if (adv) continue;
+    if (star_p == (size_t)-1) return false;
+    pi = star_p + 1;
+    si = ++star_s;
+  }
+  while (pi < pn && p[pi] == '*') pi++;
+  return pi == pn;
+}
+
+}  // namespace
+
+struct ctmr_engine {
+  std::mutex mu;
+  mutable std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  ctmr_config cfg{};
+  // known-certificate table
+  Slot* table = nullptr;
+  uint64_t nslots = 0;
+  PairSlot* pairs = nullptr;
+  uint64_t npairs = 0;
+  unsigned long long* issuer_counts = nullptr;
+  uint32_t epoch = 0;
+  // issuer table
+  uint32_t max_issuers = 0;
+  uint8_t* d_issuer_valid = nullptr;
+  uint32_t* d_canon = nullptr;
+  std::vector<IssuerRec> issuers;
+  std::unordered_map<std::string, uint32_t> id_to_canon;
+  // filter
+  FilterDev* d_filter = nullptr;
+  FilterDev h_filter{};
+  // scratch
+  DevStats* d_stats = nullptr;
+  uint32_t* d_result = nullptr;        // 2 words for point ops
+  unsigned long long* d_count = nullptr;
+  void* d_scratch[8] = {};             // growable buffers
+  size_t scratch_cap[8] = {};
+  hipEvent_t ev[8] = {};
+  // host-side store: non-table keys + members with serials longer than CTMR_MAX_SERIAL
+  std::map<std::string, std::set<std::string>> hstore;
+  std::map<std::string, int64_t> expiry;          // explicit ExpireAt overrides / host keys
+  std::unordered_map<uint32_t, uint64_t> host_issuer_counts;  // canon → long-serial members
+};
+
+namespace {
+
+enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_NEWIDX, SC_STAGE_A, SC_STAGE_B, SC_MISC };
+
+int fail(const ctmr_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf;
+  return code;
+}
+
+#define HIPCHK(e, call)                                                                   \
+  do {                                                                                    \
+    hipError_t _r = (call);                                                               \
+    if (_r != hipSuccess)                                                                 \
+      return fail(e, _r == hipErrorOutOfMemory ? CTMR_E_NOMEM : CTMR_E_HIP, "%s: %s", #call, \
+                  hipGetErrorString(_r));                                                 \
+  } while (0)
+
+int ensure(ctmr_engine* e, int which, size_t bytes) {
+  if (e->scratch_cap[which] >= bytes) return CTMR_OK;
+  if (e->d_scratch[which]) {
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipFree(e->d_scratch[which]));
+    e->d_scratch[which] = nullptr;
+    e->scratch_cap[which] = 0;
+  }
+  size_t cap = bytes + bytes / 8 + 256;
+  HIPCHK(e, hipMalloc(&e->d_scratch[which], cap));
+  e->scratch_cap[which] = cap;
+  return CTMR_OK;
+}
+
+uint64_t pow2_at_least(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// "serials::<expDateID>::<issuerID>" of a registered issuer → (exp_hour, canon)
+bool table_key(ctmr_engine* e, const char* key, size_t n, int32_t* exp_hour, uint32_t* canon) {
+  if (n < 9 + 13 + 2 + 1 || memcmp(key, "serials::", 9) != 0) return false;
+  if (key[22] != ':' || key[23] != ':') return false;
+  if (!parse_exp_date_id(key + 9, 13, exp_hour)) return false;
+  auto it = e->id_to_canon.find(std::string(key + 24, n - 24));
+  if (it == e->id_to_canon.end()) return false;
+  *canon = it->second;
+  return true;
+}
+
+std::string make_key(ctmr_engine* e, int32_t exp_hour, uint32_t canon) {
+  return "serials::" + exp_date_id(exp_hour) + "::" + e->issuers[canon].id;
+}
+
+void pack_serial(const uint8_t* m, size_t n, unsigned long long s[5]) {
+  uint8_t buf[40] = {0};
+  memcpy(buf, m, n);
+  memcpy(s, buf, 40);
+}
+
+int upload_filter(ctmr_engine* e) {
+  HIPCHK(e, hipMemcpyAsync(e->d_filter, &e->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return CTMR_OK;
+}
+
+int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uint8_t* m, size_t n,
+             int* out) {
+  unsigned long long s[5];
+  pack_serial(m, n, s);
+  const unsigned long long meta = key_meta(exp_hour, canon, (uint32_t)n);
+  if (op == 0) e->epoch++;
+  hipLaunchKernelGGL(k_set_op, dim3(1), dim3(64), 0, e->stream, e->table, e->nslots - 1, meta, s[0],
+                     s[1], s[2], s[3], s[4], op, e->epoch, e->issuer_counts, e->pairs,
+                     e->npairs - 1, e->d_result);
+  uint32_t res[2];
+  HIPCHK(e, hipMemcpyAsync(res, e->d_result, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (res[1]) return fail(e, CTMR_E_FULL, "known-certificate or pair table is full");
+  *out = (int)res[0];
+  return CTMR_OK;
+}
+
+// device pairs → list of (key, count)
+int dump_pairs(ctmr_engine* e, std::vector<std::pair<unsigned long long, unsigned long long>>* out) {
+  HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+  size_t cap = 1 << 16;
+  for (;;) {
+    int r = ensure(e, SC_MISC, cap * 16);
+    if (r) return r;
+    HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+    hipLaunchKernelGGL(k_pairs, dim3((unsigned)((e->npairs + 255) / 256)), dim3(256), 0, e->stream,
+                       e->pairs, e->npairs, (unsigned long long*)e->d_scratch[SC_MISC],
+                       (uint64_t)cap, e->d_count);
+    unsigned long long cnt;
+    HIPCHK(e, hipMemcpyAsync(&cnt, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (cnt <= cap) {
+      std::vector<unsigned long long> buf(cnt * 2);
+      if (cnt) HIPCHK(e, hipMemcpy(buf.data(), e->d_scratch[SC_MISC], cnt * 16, hipMemcpyDeviceToHost));
+      out->clear();
+      for (size_t i = 0; i < cnt; i++) out->push_back({buf[2 * i], buf[2 * i + 1]});
+      return CTMR_OK;
+    }
+    cap = cnt + 1024;
+  }
+}
+
+int pair_count(ctmr_engine* e, int32_t exp_hour, uint32_t canon, uint64_t* n) {
+  // probe the pair table on the host side through a full dump would be wasteful: read slots
+  const unsigned long long key = ((unsigned long long)(canon + 1) << 32) | (uint32_t)exp_hour;
+  uint64_t j = mixk(key) & (e->npairs - 1);
+  *n = 0;
+  for (uint64_t probes = 0; probes < e->npairs; probes++) {
+    PairSlot ps;
+    HIPCHK(e, hipMemcpy(&ps, e->pairs + j, sizeof ps, hipMemcpyDeviceToHost));
+    if (ps.key == 0) return CTMR_OK;
+    if (ps.key == key) { *n = ps.count; return CTMR_OK; }
+    j = (j + 1) & (e->npairs - 1);
+  }
+  return CTMR_OK;
+}
+
+void serialise(const std::vector<std::string>& v, uint8_t* out, size_t cap, size_t* need,
+               uint64_t* count, int* rc) {
+  size_t tot = 0;
+  for (auto& s : v) tot += 4 + s.size();
+  if (need) *need = tot;
+  if (count) *count = v.size();
+  if (tot > cap || (!out && tot)) { *rc = CTMR_E_RANGE; return; }
+  size_t w = 0;
+  for (auto& s : v) {
+    uint32_t l = (uint32_t)s.size();
+    memcpy(out + w, &l, 4);
+    memcpy(out + w + 4, s.data(), l);
+    w += 4 + l;
+  }
+  *rc = CTMR_OK;
+}
+
+std::vector<uint32_t> zipf_cdf(uint32_t n) {
+  std::vector<uint32_t> cdf(n);
+  double hn = 0;
+  for (uint32_t k = 1; k <= n; k++) hn += 1.0 / k;
+  double acc = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    acc += 1.0 / (k + 1);
+    double t = std::floor(acc / hn * 4294967296.0);
+    cdf[k] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+  }
+  return cdf;
+}
+
+SynthCfg to_synth(const ctmr_synth_config* c, const uint32_t* cdf) {
+  SynthCfg s;
+  s.seed = c->seed;
+  s.n_issuers = c->n_issuers ? c->n_issuers : 1;
+  s.zipf = c->zipf;
+  s.dup_permille = c->dup_permille;
+  s.ca_permille = c->ca_permille;
+  s.expired_permille = c->expired_permille;
+  s.mean_len = c->mean_len ? c->mean_len : 1536;
+  s.base_time = c->base_time ? c->base_time : 1767225600ll;  // 2026-01-01T00:00:00Z
+  s.zipf_cdf = cdf;
+  return s;
+}
+
+const std::vector<uint32_t>& host_cdf(uint32_t n) {
+  static std::mutex mu;
+  static std::map<uint32_t, std::vector<uint32_t>> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(n);
+  if (it == cache.end()) it = cache.emplace(n, zipf_cdf(n)).first;
+  return it->second;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctmr_abi_version(void) { return CTMR_ABI_VERSION; }
+
+const char* ctmr_last_error(const ctmr_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int ctmr_create(const ctmr_config* cfg, ctmr_engine** out) {
+  if (!cfg || !out || cfg->struct_size != sizeof(ctmr_config)) return CTMR_E_INVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+    return CTMR_E_HIP;  // no GPU → no engine: there is no CPU fallback
+  ctmr_engine* e = new ctmr_engine();
+  e->cfg = *cfg;
+  e->device = cfg->device;
+  auto bail = [&](int rc) { std::string m = e->err; ctmr_destroy(e); fprintf(stderr, "ctmr_create: %s\n", m.c_str()); return rc; };
+#define CK(call) do { hipError_t _r = (call); if (_r != hipSuccess) { e->err = std::string(#call) + ": " + hipGetErrorString(_r); return bail(_r == hipErrorOutOfMemory ? CTMR_E_NOMEM : CTMR_E_HIP); } } while (0)
+  CK(hipSetDevice(e->device));
+  CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->own_stream = true;
+  e->nslots = pow2_at_least(cfg->table_slots ? cfg->table_slots : (1ull << 24));
+  e->npairs = pow2_at_least(cfg->pair_slots ? cfg->pair_slots : (1ull << 22));
+  e->max_issuers = cfg->max_issuers ? cfg->max_issuers : 65536;
+  if (e->max_issuers > (1u << 24) - 2) { e->err = "max_issuers > 2^24-2"; return bail(CTMR_E_INVAL); }
+  CK(hipMalloc(&e->table, e->nslots * sizeof(Slot)));
+  CK(hipMalloc(&e->pairs, e->npairs * sizeof(PairSlot)));
+  CK(hipMalloc(&e->issuer_counts, (size_t)e->max_issuers * 8));
+  CK(hipMalloc(&e->d_issuer_valid, e->max_issuers));
+  CK(hipMalloc(&e->d_canon, (size_t)e->max_issuers * 4));
+  CK(hipMalloc(&e->d_filter, sizeof(FilterDev)));
+  CK(hipMalloc(&e->d_stats, sizeof(DevStats)));
+  CK(hipMalloc(&e->d_result, 16));
+  CK(hipMalloc(&e->d_count, 16));
+  CK(hipMemsetAsync(e->table, 0, e->nslots * sizeof(Slot), e->stream));
+  CK(hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
+  CK(hipMemsetAsync(e->issuer_counts, 0, (size_t)e->max_issuers * 8, e->stream));
+  CK(hipMemsetAsync(e->d_issuer_valid, 0, e->max_issuers, e->stream));
+  CK(hipMemsetAsync(e->d_canon, 0, (size_t)e->max_issuers * 4, e->stream));
+  for (auto& ev : e->ev) CK(hipEventCreate(&ev));
+  memset(&e->h_filter, 0, sizeof e->h_filter);
+  e->h_filter.n_pieces = 1;  // strings.Split("", ",") = [""]
+  CK(hipMemcpyAsync(e->d_filter, &e->h_filter, sizeof(FilterDev), hipMemcpyHostToDevice, e->stream));
+  CK(hipStreamSynchronize(e->stream));
+#undef CK
+  *out = e;
+  return CTMR_OK;
+}
+
+void ctmr_destroy(ctmr_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  (void)hipFree(e->table); (void)hipFree(e->pairs); (void)hipFree(e->issuer_counts);
+  (void)hipFree(e->d_issuer_valid); (void)hipFree(e->d_canon); (void)hipFree(e->d_filter);
+  (void)hipFree(e->d_stats); (void)hipFree(e->d_result); (void)hipFree(e->d_count);
+  for (auto p : e->d_scratch) if (p) (void)hipFree(p);
+  for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int ctmr_set_stream(ctmr_engine* e, void* s) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (e->own_stream) { (void)hipStreamDestroy(e->stream); e->own_stream = false; }
+  e->stream = (hipStream_t)s;
+  return CTMR_OK;
+}
+
+int ctmr_synchronize(ctmr_engine* e) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return CTMR_OK;
+}
+
+int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets, uint32_t n,
+                     uint32_t* first_idx) {
+  if (!e || (n && (!der || !offsets))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  const uint32_t first = (uint32_t)e->issuers.size();
+  if (first_idx) *first_idx = first;
+  if (n == 0) return CTMR_OK;
+  if ((uint64_t)first + n > e->max_issuers) return fail(e, CTMR_E_FULL, "issuer table full (%u)", e->max_issuers);
+  for (uint32_t i = 0; i < n; i++)
+    if (offsets[i + 1] < offsets[i]) return fail(e, CTMR_E_INVAL, "issuer offsets not monotone");
+  const uint64_t base = offsets[0], bytes = offsets[n] - base;
+  int r;
+  if ((r = ensure(e, SC_STAGE_A, bytes + CTMR_PAYLOAD_PAD))) return r;
+  if ((r = ensure(e, SC_STAGE_B, (size_t)(n + 1) * 8))) return r;
+  if ((r = ensure(e, SC_MISC, (size_t)n * 32 + n))) return r;
+  std::vector<uint64_t> rel(n + 1);
+  for (uint32_t i = 0; i <= n; i++) rel[i] = offsets[i] - base;
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_STAGE_A], der + base, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_STAGE_B], rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  uint32_t* d_digest = (uint32_t*)e->d_scratch[SC_MISC];
+  uint8_t* d_valid = (uint8_t*)e->d_scratch[SC_MISC] + (size_t)n * 32;
+  hipLaunchKernelGGL(k_issuer_ids, dim3((n + 63) / 64), dim3(64), 0, e->stream,
+                     (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)e->d_scratch[SC_STAGE_B],
+                     n, d_valid, d_digest);
+  std::vector<uint32_t> dg(n * 8);
+  std::vector<uint8_t> valid(n);
+  HIPCHK(e, hipMemcpyAsync(dg.data(), d_digest, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(valid.data(), d_valid, n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  std::vector<uint32_t> canon(n);
+  for (uint32_t i = 0; i < n; i++) {
+    IssuerRec rec;
+    rec.valid = valid[i] != 0;
+    for (int k = 0; k < 8; k++) {
+      uint32_t w = dg[i * 8 + k];
+      rec.digest[4 * k] = w >> 24; rec.digest[4 * k + 1] = w >> 16;
+      rec.digest[4 * k + 2] = w >> 8; rec.digest[4 * k + 3] = w;
+    }
+    rec.canon = first + i;
+    if (rec.valid) {
+      rec.id = b64url(rec.digest, 32);
+      auto it = e->id_to_canon.find(rec.id);
+      if (it != e->id_to_canon.end()) rec.canon = it->second;
+      else e->id_to_canon.emplace(rec.id, rec.canon);
+    }
+    canon[i] = rec.canon;
+    e->issuers.push_back(rec);
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_issuer_valid + first, valid.data(), n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->d_canon + first, canon.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return CTMR_OK;
+}
+
+int ctmr_issuer_count(ctmr_engine* e, uint32_t* n) {
+  if (!e || !n) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  *n = (uint32_t)e->issuers.size();
+  return CTMR_OK;
+}
+
+int ctmr_issuer_info_get(ctmr_engine* e, uint32_t idx, ctmr_issuer_info* out) {
+  if (!e || !out) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  if (idx >= e->issuers.size()) return fail(e, CTMR_E_NOTFOUND, "issuer %u not registered", idx);
+  const IssuerRec& r = e->issuers[idx];
+  memset(out, 0, sizeof *out);
+  out->valid = r.valid;
+  out->canonical_idx = r.canon;
+  memcpy(out->spki_sha256, r.digest, 32);
+  snprintf(out->issuer_id, sizeof out->issuer_id, "%s", r.id.c_str());
+  return CTMR_OK;
+}
+
+int ctmr_set_filter(ctmr_engine* e, const char* filter, size_t len, int log_expired, int64_t now) {
+  if (!e || (len && !filter)) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  FilterDev f;
+  memset(&f, 0, sizeof f);
+  f.active = len != 0;
+  f.log_expired = log_expired != 0;
+  f.now = now;
+  // strings.Split(filter, ","): pieces are NOT trimmed (ct-fetch.go:58)
+  size_t s = 0;
+  uint32_t nw = 0;
+  for (;;) {
+    size_t t = s;
+    while (t < len && filter[t] != ',') t++;
+    const size_t pl = t - s;
+    if (f.n_pieces >= 64 || nw + (pl + 3) / 4 > 1024)
+      return fail(e, CTMR_E_INVAL, "issuerCNFilter too large (max 64 pieces / 4096 bytes)");
+    f.piece_len[f.n_pieces] = (uint32_t)pl;
+    f.piece_word[f.n_pieces] = nw;
+    memcpy((uint8_t*)(f.words + nw), filter + s, pl);
+    nw += (uint32_t)((pl + 3) / 4);
+    f.n_pieces++;
+    if (t >= len) break;
+    s = t + 1;
+  }
+  e->h_filter = f;
+  return upload_filter(e);
+}
+
+static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                             const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                             ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats) {
+  HIPCHK(e, hipSetDevice(e->device));
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (n == 0) return CTMR_OK;
+  if (n >= 0xfffffff0ull) return fail(e, CTMR_E_INVAL, "batch too large (n < 2^32-16)");
+  if (((uintptr_t)d_payload & 15) != 0) return fail(e, CTMR_E_INVAL, "payload must be 16-byte aligned");
+  int r;
+  if (!d_records) {
+    if ((r = ensure(e, SC_RECORDS, n * sizeof(ctmr_record)))) return r;
+    d_records = (ctmr_record*)e->d_scratch[SC_RECORDS];
+  }
+  const uint64_t nb = (n + 1023) / 1024;
+  if ((r = ensure(e, SC_SLOTID, n * 4))) return r;
+  if ((r = ensure(e, SC_BLKNEW, nb * 4))) return r;
+  if ((r = ensure(e, SC_BLKBASE, nb * 8))) return r;
+  uint32_t* d_slot = (uint32_t*)e->d_scratch[SC_SLOTID];
+  uint32_t* d_blk_new = (uint32_t*)e->d_scratch[SC_BLKNEW];
+  uint64_t* d_blk_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
+  const bool prof = e->cfg.profile != 0;
+  e->epoch++;
+  HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
+
+  // ---- map
+  MapArgs ma;
+  ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
+  ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
+  ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
+  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 1;
+  uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
+  if (C > 64) C = 64;
+  uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;
+  if (lds > 160 * 1024) lds = 160 * 1024;
+  ma.certs_per_tile = C; ma.lds_bytes = lds;
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
+  if (variant == 2) {
+    hipLaunchKernelGGL(k_map_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ma);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(e, hipFuncSetAttribute((const void*)k_map_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    const uint64_t tiles = (n + C - 1) / C;
+    hipLaunchKernelGGL(k_map_tile, dim3((unsigned)tiles), dim3(64), lds, e->stream, ma);
+  }
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
+  // ---- insert
+  InsertArgs ia;
+  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.canon = e->d_canon;
+  ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.n = n; ia.epoch = e->epoch;
+  hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
+  // ---- resolve
+  ResolveArgs ra;
+  ra.records = d_records; ra.slot_id = d_slot; ra.canon = e->d_canon; ra.table = e->table;
+  ra.issuer_counts = e->issuer_counts; ra.pairs = e->pairs; ra.pmask = e->npairs - 1;
+  ra.stats = e->d_stats; ra.blk_new = d_blk_new; ra.n = n; ra.epoch = e->epoch;
+  hipLaunchKernelGGL(k_resolve, dim3((unsigned)nb), dim3(1024), 0, e->stream, ra);
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[3], e->stream));
+  DevStats hs;
+  HIPCHK(e, hipMemcpyAsync(&hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  if (hs.n_full) return fail(e, CTMR_E_FULL, "known-certificate table full (%llu slots): %llu entries dropped",
+                             (unsigned long long)e->nslots, hs.n_full);
+  if (hs.pair_full) return fail(e, CTMR_E_FULL, "(expDate,issuer) table full (%llu slots)", (unsigned long long)e->npairs);
+
+  // ---- serials longer than CTMR_MAX_SERIAL: exact host-side set, in log order
+  uint64_t host_new = 0;
+  if (hs.n_host) {
+    std::vector<uint32_t> sid(n);
+    HIPCHK(e, hipMemcpy(sid.data(), d_slot, n * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; i++) {
+      if (sid[i] != SID_HOST) continue;
+      uint64_t off[2];
+      ctmr_record rec;
+      HIPCHK(e, hipMemcpy(off, d_offsets + i, 16, hipMemcpyDeviceToHost));
+      HIPCHK(e, hipMemcpy(&rec, d_records + i, sizeof rec, hipMemcpyDeviceToHost));
+      std::vector<uint8_t> der(off[1] - off[0] + 32);
+      HIPCHK(e, hipMemcpy(der.data(), d_payload + off[0], off[1] - off[0], hipMemcpyDeviceToHost));
+      HostReader hr{der.data()};
+      Walk w;
+      if (!walk_cert(hr, (uint32_t)(off[1] - off[0]), w)) continue;  // cannot happen: map accepted it
+      const uint32_t canon = e->issuers[rec.issuer_idx].canon;
+      std::string key = make_key(e, rec.exp_hour, canon);
+      std::string member((const char*)der.data() + w.serial_off, w.serial_len);
+      if (e->hstore[key].insert(member).second) {
+        host_new++;
+        e->host_issuer_counts[canon]++;
+        uint8_t fl = rec.flags | CTMR_FL_WAS_UNKNOWN;
+        HIPCHK(e, hipMemcpy((uint8_t*)(d_records + i) + 1, &fl, 1, hipMemcpyHostToDevice));
+        uint32_t bn;
+        HIPCHK(e, hipMemcpy(&bn, d_blk_new + i / 1024, 4, hipMemcpyDeviceToHost));
+        bn++;
+        HIPCHK(e, hipMemcpy(d_blk_new + i / 1024, &bn, 4, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  // ---- compaction of the NEW list
+  if (d_new_idx) {
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, d_records, n, d_blk_base, d_new_idx);
+  }
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[4], e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  if (stats) {
+    stats->n = n;
+    for (int k = 0; k < CTMR_ST__COUNT; k++) stats->by_status[k] = hs.by_status[k];
+    stats->n_new = hs.n_new + host_new;
+    stats->n_dup = hs.n_dup + (hs.n_host - host_new);
+    stats->n_host_set = hs.n_host;
+    uint64_t ends[2] = {0, 0};
+    HIPCHK(e, hipMemcpy(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost));
+    stats->payload_bytes = ends[1] - ends[0];
+    stats->map_launches = 1;
+    if (prof) {
+      (void)hipEventElapsedTime(&stats->ms_map, e->ev[0], e->ev[1]);
+      (void)hipEventElapsedTime(&stats->ms_insert, e->ev[1], e->ev[2]);
+      (void)hipEventElapsedTime(&stats->ms_resolve, e->ev[2], e->ev[3]);
+      (void)hipEventElapsedTime(&stats->ms_compact, e->ev[3], e->ev[4]);
+      (void)hipEventElapsedTime(&stats->ms_total, e->ev[0], e->ev[4]);
+    }
+  }
+  return CTMR_OK;
+}
+
+int ctmr_map_batch_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                          const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                          ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats) {
+  if (!e || (n && (!d_payload || !d_offsets || !d_issuer_idx))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return map_device_locked(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, d_new_idx, stats);
+}
+
+int ctmr_map_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offsets,
+                   const uint32_t* issuer_idx, const uint8_t* entry_type, uint64_t n,
+                   ctmr_record* records, uint64_t* new_idx, ctmr_batch_stats* stats) {
+  if (!e || (n && (!payload || !offsets || !issuer_idx))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (n == 0) return CTMR_OK;
+  for (uint64_t i = 0; i < n; i++)
+    if (offsets[i + 1] < offsets[i]) return fail(e, CTMR_E_INVAL, "offsets not monotone at %llu", (unsigned long long)i);
+  const uint64_t base = offsets[0], bytes = offsets[n] - base;
+  // staging layout in SC_STAGE_A: payload | pad ; SC_STAGE_B: offsets | issuer_idx | entry_type | new_idx
+  int r;
+  if ((r = ensure(e, SC_STAGE_A, bytes + CTMR_PAYLOAD_PAD + 16))) return r;
+  const size_t o_off = 0, o_iss = (n + 1) * 8, o_et = o_iss + n * 4, o_new = (o_et + n + 15) & ~(size_t)15;
+  if ((r = ensure(e, SC_STAGE_B, o_new + n * 8))) return r;
+  uint8_t* B = (uint8_t*)e->d_scratch[SC_STAGE_B];
+  std::vector<uint64_t> rel(n + 1);
+  for (uint64_t i = 0; i <= n; i++) rel[i] = offsets[i] - base;
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_STAGE_A], payload + base, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(B + o_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(B + o_iss, issuer_idx, n * 4, hipMemcpyHostToDevice, e->stream));
+  if (entry_type) HIPCHK(e, hipMemcpyAsync(B + o_et, entry_type, n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // rel[] is a local
+  ctmr_batch_stats st;
+  r = map_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)(B + o_off),
+                        (const uint32_t*)(B + o_iss), entry_type ? B + o_et : nullptr, n, nullptr,
+                        new_idx ? (uint64_t*)(B + o_new) : nullptr, &st);
+  if (r) return r;
+  if (records) HIPCHK(e, hipMemcpy(records, e->d_scratch[SC_RECORDS], n * sizeof(ctmr_record), hipMemcpyDeviceToHost));
+  if (new_idx && st.n_new) HIPCHK(e, hipMemcpy(new_idx, B + o_new, st.n_new * 8, hipMemcpyDeviceToHost));
+  if (stats) *stats = st;
+  return CTMR_OK;
+}
+
+// ------------------------------------------------------------------ RemoteCache set methods
+
+int ctmr_set_insert(ctmr_engine* e, const char* key, size_t kl, const uint8_t* m, size_t ml, int* was_new) {
+  if (!e || !key || (ml && !m) || !was_new) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  int32_t eh; uint32_t canon;
+  if (ml <= CTMR_MAX_SERIAL && table_key(e, key, kl, &eh, &canon)) return point_op(e, 0, eh, canon, m, ml, was_new);
+  std::string k(key, kl);
+  bool ins = e->hstore[k].insert(std::string((const char*)m, ml)).second;
+  if (ins && table_key(e, key, kl, &eh, &canon)) e->host_issuer_counts[canon]++;
+  *was_new = ins;
+  return CTMR_OK;
+}
+
+int ctmr_set_contains(ctmr_engine* e, const char* key, size_t kl, const uint8_t* m, size_t ml, int* present) {
+  if (!e || !key || (ml && !m) || !present) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  int32_t eh; uint32_t canon;
+  if (ml <= CTMR_MAX_SERIAL && table_key(e, key, kl, &eh, &canon)) return point_op(e, 1, eh, canon, m, ml, present);
+  auto it = e->hstore.find(std::string(key, kl));
+  *present = it != e->hstore.end() && it->second.count(std::string((const char*)m, ml));
+  return CTMR_OK;
+}
+
+int ctmr_set_remove(ctmr_engine* e, const char* key, size_t kl, const uint8_t* m, size_t ml, int* removed) {
+  if (!e || !key || (ml && !m) || !removed) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  int32_t eh; uint32_t canon;
+  if (ml <= CTMR_MAX_SERIAL && table_key(e, key, kl, &eh, &canon)) return point_op(e, 2, eh, canon, m, ml, removed);
+  std::string k(key, kl);
+  auto it = e->hstore.find(k);
+  *removed = 0;
+  if (it != e->hstore.end() && it->second.erase(std::string((const char*)m, ml))) {
+    *removed = 1;
+    if (table_key(e, key, kl, &eh, &canon)) e->host_issuer_counts[canon]--;
+    if (it->second.empty()) e->hstore.erase(it);
+  }
+  return CTMR_OK;
+}
+
+int ctmr_set_cardinality(ctmr_engine* e, const char* key, size_t kl, int64_t* n) {
+  if (!e || !key || !n) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  int64_t total = 0;
+  auto it = e->hstore.find(std::string(key, kl));
+  if (it != e->hstore.end()) total += (int64_t)it->second.size();
+  int32_t eh; uint32_t canon;
+  if (table_key(e, key, kl, &eh, &canon)) {
+    uint64_t c;
+    int r = pair_count(e, eh, canon, &c);
+    if (r) return r;
+    total += (int64_t)c;
+  }
+  *n = total;
+  return CTMR_OK;
+}
+
+int ctmr_exists(ctmr_engine* e, const char* key, size_t kl, int* exists) {
+  int64_t n;
+  int r = ctmr_set_cardinality(e, key, kl, &n);
+  if (r) return r;
+  *exists = n > 0;
+  return CTMR_OK;
+}
+
+int ctmr_set_members(ctmr_engine* e, const char* key, size_t kl, uint8_t* out, size_t cap, size_t* need, uint64_t* count) {
+  if (!e || !key) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  std::vector<std::string> v;
+  auto it = e->hstore.find(std::string(key, kl));
+  if (it != e->hstore.end()) v.assign(it->second.begin(), it->second.end());
+  int32_t eh; uint32_t canon;
+  if (table_key(e, key, kl, &eh, &canon)) {
+    size_t capn = 1 << 12;
+    for (;;) {
+      int r = ensure(e, SC_MISC, capn * 48);
+      if (r) return r;
+      HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+      hipLaunchKernelGGL(k_list, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream, e->table,
+                         e->nslots, (uint32_t)eh, canon, (uint8_t*)e->d_scratch[SC_MISC], (uint64_t)capn, e->d_count);
+      unsigned long long cnt;
+      HIPCHK(e, hipMemcpyAsync(&cnt, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      if (cnt <= capn) {
+        std::vector<uint8_t> buf(cnt * 48);
+        if (cnt) HIPCHK(e, hipMemcpy(buf.data(), e->d_scratch[SC_MISC], cnt * 48, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) {
+          uint64_t l;
+          memcpy(&l, &buf[i * 48], 8);
+          v.emplace_back((const char*)&buf[i * 48 + 8], (size_t)l);
+        }
+        break;
+      }
+      capn = cnt + 64;
+    }
+  }
+  std::sort(v.begin(), v.end());
+  int rc;
+  serialise(v, out, cap, need, count, &rc);
+  return rc == CTMR_OK ? rc : fail(e, rc, "buffer too small");
+}
+
+int ctmr_keys(ctmr_engine* e, const char* pat, size_t pl, uint8_t* out, size_t cap, size_t* need, uint64_t* count) {
+  if (!e || (pl && !pat)) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  std::set<std::string> keys;
+  for (auto& kv : e->hstore) if (!kv.second.empty()) keys.insert(kv.first);
+  std::vector<std::pair<unsigned long long, unsigned long long>> pr;
+  int r = dump_pairs(e, &pr);
+  if (r) return r;
+  for (auto& p : pr) {
+    const uint32_t canon = (uint32_t)(p.first >> 32) - 1;
+    if (canon < e->issuers.size()) keys.insert(make_key(e, (int32_t)(uint32_t)p.first, canon));
+  }
+  std::vector<std::string> v;
+  for (auto& k : keys) if (glob_match(pat, pl, k.data(), k.size())) v.push_back(k);
+  int rc;
+  serialise(v, out, cap, need, count, &rc);
+  return rc == CTMR_OK ? rc : fail(e, rc, "buffer too small");
+}
+
+int ctmr_expire_at(ctmr_engine* e, const char* key, size_t kl, int64_t t) {
+  if (!e || !key) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  e->expiry[std::string(key, kl)] = t;
+  return CTMR_OK;
+}
+
+int ctmr_expire_sweep(ctmr_engine* e, int64_t now, uint64_t* removed) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  uint64_t total = 0;
+  // (1) every table key carries ExpireAt(expDate hour) (knowncertificates.go:98-104), unless
+  //     overridden by an explicit later ExpireAt → handled in (2)
+  std::vector<std::pair<unsigned long long, unsigned long long>> pr;
+  int r = dump_pairs(e, &pr);
+  if (r) return r;
+  HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+  bool any_override = false;
+  for (auto& p : pr) {
+    const uint32_t canon = (uint32_t)(p.first >> 32) - 1;
+    if (canon < e->issuers.size() && e->expiry.count(make_key(e, (int32_t)(uint32_t)p.first, canon))) any_override = true;
+  }
+  const unsigned blocks = (unsigned)((e->nslots + 255) / 256);
+  if (!any_override) {
+    hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(256), 0, e->stream, e->table, e->nslots, 1, (long long)now, 0u, 0u,
+                       e->issuer_counts, e->pairs, e->npairs - 1, e->d_count);
+  } else {
+    for (auto& p : pr) {
+      const uint32_t canon = (uint32_t)(p.first >> 32) - 1;
+      const int32_t eh = (int32_t)(uint32_t)p.first;
+      if (canon >= e->issuers.size()) continue;
+      auto it = e->expiry.find(make_key(e, eh, canon));
+      const int64_t t = it != e->expiry.end() ? it->second : (int64_t)eh * 3600;
+      if (t <= now)
+        hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(256), 0, e->stream, e->table, e->nslots, 0, 0ll, (uint32_t)eh,
+                           canon, e->issuer_counts, e->pairs, e->npairs - 1, e->d_count);
+    }
+  }
+  unsigned long long cnt;
+  HIPCHK(e, hipMemcpyAsync(&cnt, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  total += cnt;
+  // (2) host-side keys
+  for (auto it = e->hstore.begin(); it != e->hstore.end();) {
+    int64_t t;
+    bool has = false;
+    auto ex = e->expiry.find(it->first);
+    int32_t eh; uint32_t canon;
+    const bool tk = table_key(e, it->first.data(), it->first.size(), &eh, &canon);
+    if (ex != e->expiry.end()) { t = ex->second; has = true; }
+    else if (tk) { t = (int64_t)eh * 3600; has = true; }
+    if (has && t <= now) {
+      total += it->second.size();
+      if (tk) e->host_issuer_counts[canon] -= it->second.size();
+      it = e->hstore.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  for (auto it = e->expiry.begin(); it != e->expiry.end();)
+    it = it->second <= now ? e->expiry.erase(it) : std::next(it);
+  if (removed) *removed = total;
+  return CTMR_OK;
+}
+
+int ctmr_issuer_counts(ctmr_engine* e, uint64_t* out, uint32_t n) {
+  if (!e || (n && !out)) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  const uint32_t have = (uint32_t)e->issuers.size();
+  std::vector<unsigned long long> c(have);
+  if (have) HIPCHK(e, hipMemcpy(c.data(), e->issuer_counts, (size_t)have * 8, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; i++) {
+    if (i >= have) { out[i] = 0; continue; }
+    const uint32_t canon = e->issuers[i].canon;
+    uint64_t v = c[canon];
+    auto it = e->host_issuer_counts.find(canon);
+    if (it != e->host_issuer_counts.end()) v += it->second;
+    out[i] = e->issuers[i].valid ? v : 0;
+  }
+  return CTMR_OK;
+}
+
+int ctmr_total_count(ctmr_engine* e, uint64_t* out) {
+  if (!e || !out) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  const uint32_t have = (uint32_t)e->issuers.size();
+  std::vector<unsigned long long> c(have);
+  if (have) HIPCHK(e, hipMemcpy(c.data(), e->issuer_counts, (size_t)have * 8, hipMemcpyDeviceToHost));
+  uint64_t t = 0;
+  for (uint32_t i = 0; i < have; i++) if (e->issuers[i].canon == i) t += c[i];
+  for (auto& kv : e->host_issuer_counts) t += kv.second;
+  *out = t;
+  return CTMR_OK;
+}
+
+int ctmr_issuer_counts_device(ctmr_engine* e, void** d, uint32_t* n) {
+  if (!e || !d) return CTMR_E_INVAL;
+  *d = e->issuer_counts;
+  if (n) *n = e->max_issuers;
+  return CTMR_OK;
+}
+
+int ctmr_reset_known(ctmr_engine* e) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemsetAsync(e->table, 0, e->nslots * sizeof(Slot), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->issuer_counts, 0, (size_t)e->max_issuers * 8, e->stream));
+  for (auto it = e->hstore.begin(); it != e->hstore.end();)
+    it = it->first.compare(0, 9, "serials::") == 0 ? e->hstore.erase(it) : std::next(it);
+  e->host_issuer_counts.clear();
+  return CTMR_OK;
+}
+
+// ------------------------------------------------------------------ synthetic generator
+
+uint32_t ctmr_synth_leaf_len(const ctmr_synth_config* c, uint64_t i) {
+  const auto& cdf = host_cdf(c->n_issuers ? c->n_issuers : 1);
+  SynthCfg s = to_synth(c, cdf.data());
+  BackWriter w{nullptr, SYNTH_MAX_LEN};
+  uint32_t iss; uint8_t et;
+  synth_leaf_emit(s, i, w, iss, et);
+  return SYNTH_MAX_LEN - w.pos;
+}
+
+uint32_t ctmr_synth_leaf(const ctmr_synth_config* c, uint64_t i, uint8_t* out, uint32_t cap,
+                         uint32_t* issuer_idx, uint8_t* entry_type) {
+  const auto& cdf = host_cdf(c->n_issuers ? c->n_issuers : 1);
+  SynthCfg s = to_synth(c, cdf.data());
+  uint8_t tmp[SYNTH_MAX_LEN];
+  BackWriter w{tmp, SYNTH_MAX_LEN};
+  uint32_t iss; uint8_t et;
+  synth_leaf_emit(s, i, w, iss, et);
+  const uint32_t len = SYNTH_MAX_LEN - w.pos;
+  if (issuer_idx) *issuer_idx = iss;
+  if (entry_type) *entry_type = et;
+  if (out && len <= cap) memcpy(out, tmp + w.pos, len);
+  return len;
+}
+
+uint32_t ctmr_synth_issuer(const ctmr_synth_config* c, uint32_t k, uint8_t* out, uint32_t cap) {
+  SynthCfg s = to_synth(c, nullptr);
+  uint8_t tmp[SYNTH_MAX_LEN];
+  BackWriter w{tmp, SYNTH_MAX_LEN};
+  synth_issuer_emit(s, k, w);
+  const uint32_t len = SYNTH_MAX_LEN - w.pos;
+  if (out && len <= cap) memcpy(out, tmp + w.pos, len);
+  return len;
+}
+
+uint64_t ctmr_synth_host(const ctmr_synth_config* c, uint64_t first, uint64_t n, uint64_t* offsets,
+                         uint8_t* payload, uint64_t cap, uint32_t* issuer_idx, uint8_t* entry_type) {
+  const auto& cdf = host_cdf(c->n_issuers ? c->n_issuers : 1);
+  SynthCfg s = to_synth(c, cdf.data());
+  uint8_t tmp[SYNTH_MAX_LEN];
+  uint64_t at = 0;
+  if (offsets) offsets[0] = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    BackWriter w{tmp, SYNTH_MAX_LEN};
+    uint32_t iss; uint8_t et;
+    synth_leaf_emit(s, first + i, w, iss, et);
+    const uint32_t len = SYNTH_MAX_LEN - w.pos;
+    if (payload && at + len <= cap) memcpy(payload + at, tmp + w.pos, len);
+    at += len;
+    if (offsets) offsets[i + 1] = at;
+    if (issuer_idx) issuer_idx[i] = iss;
+    if (entry_type) entry_type[i] = et;
+  }
+  return at;
+}
+
+int ctmr_synth_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n,
+                      uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
+                      uint32_t* d_issuer_idx, uint8_t* d_entry_type, uint64_t* payload_bytes) {
+  if (!e || !c || !d_offsets) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (n == 0) return CTMR_OK;
+  const uint32_t ni = c->n_issuers ? c->n_issuers : 1;
+  const auto& cdf = host_cdf(ni);
+  int r;
+  if ((r = ensure(e, SC_MISC, (size_t)ni * 4))) return r;
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_MISC], cdf.data(), (size_t)ni * 4, hipMemcpyHostToDevice, e->stream));
+  SynthCfg s = to_synth(c, (const uint32_t*)e->d_scratch[SC_MISC]);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_synth_len, dim3(blocks), dim3(256), 0, e->stream, s, first, n, d_offsets);
+  size_t tmp_bytes = 0;
+  HIPCHK(e, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_offsets + 1, d_offsets + 1, (int64_t)n, e->stream));
+  if ((r = ensure(e, SC_STAGE_B, tmp_bytes))) return r;
+  HIPCHK(e, hipcub::DeviceScan::InclusiveSum(e->d_scratch[SC_STAGE_B], tmp_bytes, d_offsets + 1, d_offsets + 1, (int64_t)n, e->stream));
+  uint64_t total = 0;
+  HIPCHK(e, hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (payload_bytes) *payload_bytes = total;
+  if (!d_payload) return CTMR_OK;
+  if (total + CTMR_PAYLOAD_PAD > payload_cap) return fail(e, CTMR_E_RANGE, "payload needs %llu bytes (+%d pad)", (unsigned long long)total, CTMR_PAYLOAD_PAD);
+  if (!d_issuer_idx || !d_entry_type) return CTMR_E_INVAL;
+  hipLaunchKernelGGL(k_synth_emit, dim3(blocks), dim3(256), 0, e->stream, s, first, n, (const uint64_t*)d_offsets,
+                     d_payload, d_issuer_idx, d_entry_type);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  return CTMR_OK;
+}
+
+}  // extern "C"

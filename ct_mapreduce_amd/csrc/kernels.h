@@ -1,0 +1,693 @@
+// kernels.h — hand-written HIP kernels for gfx950 (CDNA4, wave64).  No MFMA anywhere: this
+// path is byte/integer scan + hash work bounded by HBM bandwidth.
+//
+//   k_issuer_ids     issuer table: walk Chain[0], SHA-256(RawSubjectPublicKeyInfo)
+//   k_map_tile       THE dominant kernel: packed DER → LDS tile (coalesced 16 B/lane) →
+//                    one-cert-per-lane TBS walk → 3 filters → 32-B record
+//   k_map_direct     same map, reading DER straight from global memory (no LDS staging);
+//                    also the fallback for tiles larger than the LDS budget
+//   k_insert         known-certificate table insert (CAS claim + atomicMin of batch index)
+//   k_resolve        WasUnknown decision, wave-aggregated per-issuer / per-(expDate,issuer)
+//                    counters, status histogram, per-block NEW counts
+//   k_compact        ballot/popcount stream compaction of NEW entries (ascending log index)
+//   k_set_op / k_sweep / k_list   RemoteCache-style point ops and scans on the table
+//   k_synth_*        synthetic batch generator
+#pragma once
+#include "ctmr_dev.h"
+#include "synth.h"
+
+namespace ctmr {
+
+// ------------------------------------------------------------------ byte readers
+// 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
+struct LdsReader {
+  const uint32_t* lds;  // tile words (LDS)
+  uint32_t base;        // byte offset of this certificate inside the tile
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t a = base + pos;
+    const uint32_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(lds[i + 1], lds[i], a & 3u);
+  }
+};
+
+struct GlobalReader {
+  const uint8_t* p;  // certificate start (any alignment)
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uintptr_t a = (uintptr_t)p + pos;
+    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(a & 3u));
+  }
+};
+
+// ------------------------------------------------------------------ SHA-256 (issuer ids)
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) {
+  return __builtin_amdgcn_alignbit(x, x, n);
+}
+
+__constant__ uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+// One lane hashes one message; round constants come from LDS (kc), message bytes through the
+// reader.  w[] is a 16-word rolling schedule.
+template <class R>
+__device__ void sha256_lane(const R& r, uint32_t off, uint32_t len, const uint32_t* kc,
+                            uint32_t out[8]) {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a,
+                   0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  const uint32_t nblk = (len + 9 + 63) / 64;
+  for (uint32_t b = 0; b < nblk; b++) {
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const uint32_t pos = b * 64 + i * 4;
+      uint32_t v = 0;
+      if (pos + 4 <= len) {
+        v = __builtin_bswap32(r.ld4(off + pos));
+      } else if (pos <= len) {
+        // tail: message bytes, then 0x80, then zeros
+        const uint32_t rem = len - pos;  // 0..3 message bytes in this word
+        const uint32_t raw = rem ? r.ld4(off + pos) : 0u;
+        const uint32_t m = rem ? (raw & (0xffffffffu >> (8 * (4 - rem)))) : 0u;
+        v = __builtin_bswap32(m | (0x80u << (8 * rem)));
+      }
+      w[i] = v;
+    }
+    if (b == nblk - 1) {
+      w[14] = (uint32_t)(((unsigned long long)len * 8ull) >> 32);
+      w[15] = (uint32_t)((unsigned long long)len * 8ull);
+    }
+    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      if (i >= 16) {
+        const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+        const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+        const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+        w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+      }
+      const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+      const uint32_t ch = (e & f) ^ (~e & g);
+      const uint32_t t1 = hh + S1 + ch + kc[i] + w[i & 15];
+      const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+      const uint32_t mj = (a & bb) ^ (a & c) ^ (bb & c);
+      const uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) out[i] = h[i];
+}
+
+// Issuer table: one issuer certificate per lane.  Replaces x509.ParseCertificate(Chain[0])
+// (ct-fetch.go:221) + NewIssuer + Issuer.ID()'s SHA-256 (storage/types.go:109-130,155-159).
+__global__ void __launch_bounds__(64) k_issuer_ids(const uint8_t* der, const uint64_t* offsets,
+                                                   uint32_t n, uint8_t* valid, uint32_t* digest) {
+  __shared__ uint32_t kc[64];
+  kc[threadIdx.x] = K256[threadIdx.x];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  GlobalReader r{der + offsets[i]};
+  const uint32_t L = (uint32_t)(offsets[i + 1] - offsets[i]);
+  Walk w;
+  const bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w);
+  valid[i] = ok ? 1 : 0;
+  uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ok) sha256_lane(r, w.spki_off, w.spki_len, kc, dg);
+#pragma unroll
+  for (int k = 0; k < 8; k++) digest[i * 8 + k] = dg[k];
+}
+
+// ------------------------------------------------------------------ the map
+struct MapArgs {
+  const uint8_t* payload;
+  const uint64_t* offsets;
+  const uint32_t* issuer_idx;
+  const uint8_t* entry_type;  // may be null
+  ctmr_record* records;
+  const uint8_t* issuer_valid;
+  const FilterDev* filt;
+  uint64_t n;
+  uint32_t n_issuers;
+  uint32_t certs_per_tile;
+  uint32_t lds_bytes;  // dynamic LDS size of the launch
+};
+
+// certIsFilteredOut filter (3): no strings.Split(filter, ",") piece is a byte prefix of
+// Issuer.CommonName (ct-fetch.go:57-69).  Pieces are wave-uniform, the CN bytes per lane.
+template <class R>
+__device__ __forceinline__ bool cn_prefix_match(const R& r, const Walk& w, const FilterDev* f) {
+  const uint32_t np = f->n_pieces;
+  for (uint32_t j = 0; j < np; j++) {
+    const uint32_t pl = f->piece_len[j];
+    if (pl > w.cn_len) continue;
+    const uint32_t* pw = f->words + f->piece_word[j];
+    bool eq = true;
+    for (uint32_t k = 0; k < pl && eq; k += 4) {
+      const uint32_t rem = pl - k;
+      const uint32_t mask = rem >= 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - rem)));
+      eq = ((r.ld4(w.cn_off + k) ^ pw[k >> 2]) & mask) == 0;
+    }
+    if (eq) return true;
+  }
+  return false;
+}
+
+// Everything after the bytes are addressable: walk, filters, record.
+template <class R>
+__device__ __forceinline__ void map_one(const R& r, uint64_t len64, uint64_t idx, const MapArgs& a) {
+  Walk w;
+  const uint32_t L = (uint32_t)len64;
+  const bool ok = len64 <= 0x7fffffffull && walk_cert(r, L, w);
+  const uint32_t iss = a.issuer_idx[idx];
+  const FilterDev* f = a.filt;
+  uint32_t status;
+  if (!ok) {
+    status = CTMR_ST_PARSE_ERROR;
+  } else if (w.bc_valid && w.is_ca) {
+    status = CTMR_ST_FILTERED_CA;
+  } else if (w.not_after < f->now && !f->log_expired) {
+    status = CTMR_ST_FILTERED_EXPIRED;
+  } else if (f->active && !cn_prefix_match(r, w, f)) {
+    status = CTMR_ST_FILTERED_CN;
+  } else if (iss == CTMR_NO_ISSUER || iss >= a.n_issuers) {
+    status = CTMR_ST_NO_ISSUER;
+  } else if (!a.issuer_valid[iss]) {
+    status = CTMR_ST_ISSUER_PARSE_ERROR;
+  } else {
+    status = CTMR_ST_PASS;
+  }
+  uint32_t flags = (a.entry_type && a.entry_type[idx] == 1) ? CTMR_FL_PRECERT : 0u;
+  uint32_t slen = 0, s[5] = {0, 0, 0, 0, 0};
+  int32_t exp_hour = 0;
+  if (ok) {
+    // NewExpDateFromTime: Truncate(time.Hour) = floor (storage/types.go:339-346)
+    long long q = w.not_after / 3600;
+    if (w.not_after % 3600 < 0) q -= 1;
+    exp_hour = (int32_t)q;
+    slen = w.serial_len > 0xffffu ? 0xffffu : w.serial_len;
+    if (w.serial_len > 20) flags |= CTMR_FL_LONG_SERIAL;
+    const uint32_t take = w.serial_len < 20 ? w.serial_len : 20;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const uint32_t pos = 4u * k;
+      if (pos < take) {
+        const uint32_t rem = take - pos;
+        const uint32_t v = r.ld4(w.serial_off + pos);
+        s[k] = rem >= 4 ? v : (v & (0xffffffffu >> (8 * (4 - rem))));
+      }
+    }
+  }
+  uint4* out = (uint4*)(a.records + idx);
+  out[0] = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
+  out[1] = make_uint4(s[1], s[2], s[3], s[4]);
+}
+
+// LDS-tile map.  One wave per workgroup, one tile of `certs_per_tile` consecutive
+// certificates per workgroup: the tile's byte range [offsets[first], offsets[last+1]) is
+// contiguous in the packed payload, so it is copied with perfectly coalesced 16-B/lane loads
+// (1 KiB per wave instruction) into LDS; then lane l walks certificate first+l out of LDS.
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+__global__ void __launch_bounds__(64) k_map_tile(MapArgs a) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t C = a.certs_per_tile;
+  const uint64_t first = (uint64_t)blockIdx.x * C;
+  if (first >= a.n) return;
+  const uint32_t cnt = (uint32_t)((a.n - first) < C ? (a.n - first) : C);
+  uint64_t my_lo = 0, my_hi = 0;
+  if (lane < cnt) {
+    my_lo = a.offsets[first + lane];
+    my_hi = a.offsets[first + lane + 1];
+  }
+  const uint64_t tile_lo = __shfl(my_lo, 0);
+  const uint64_t tile_hi = __shfl(my_hi, cnt - 1);
+  const uint64_t a_lo = tile_lo & ~15ull;
+  const uint64_t span = tile_hi - a_lo;
+  if (tile_hi < tile_lo || span + 48 > a.lds_bytes) {
+    // oversize (or malformed offsets): walk straight from global memory
+    if (lane < cnt) {
+      if (my_hi < my_lo) my_hi = my_lo;
+      GlobalReader r{a.payload + my_lo};
+      map_one(r, my_hi - my_lo, first + lane, a);
+    }
+    return;
+  }
+  // ---- stage the tile: global → VGPR → LDS, 8 × 1 KiB in flight per wave
+  {
+    const uint4* src = (const uint4*)(a.payload + a_lo);
+    uint4* dst = (uint4*)smem;
+    const uint32_t nvec = (uint32_t)((span + 15) >> 4);
+    for (uint32_t base = 0; base < nvec; base += 8 * 64) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t i = base + k * 64 + lane;
+        if (i < nvec) v[k] = src[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t i = base + k * 64 + lane;
+        if (i < nvec) dst[i] = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < cnt) {
+    if (my_hi < my_lo) my_hi = my_lo;
+    LdsReader r{(const uint32_t*)smem, (uint32_t)(my_lo - a_lo)};
+    map_one(r, my_hi - my_lo, first + lane, a);
+  }
+}
+
+// Direct map: one certificate per lane straight from global memory.
+__global__ void __launch_bounds__(256) k_map_direct(MapArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const uint64_t lo = a.offsets[i];
+  uint64_t hi = a.offsets[i + 1];
+  if (hi < lo) hi = lo;
+  GlobalReader r{a.payload + lo};
+  map_one(r, hi - lo, i, a);
+}
+
+// ------------------------------------------------------------------ the reduce
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, AGENT);
+}
+
+// Find-or-insert one key.  Returns the slot index (or SID_FULL); *created tells whether this
+// call claimed the slot.  idx32 = batch index merged with atomicMin (pass 0xffffffff for
+// point operations).  Visibility: payload words are written through (agent-scope atomic
+// stores), drained with s_waitcnt vmcnt(0), then w[1] is published; readers poll w[1] with
+// agent-scope loads (MI355X_MICROARCH.md "handoff-flag": write-through payload + drained flag).
+__device__ __forceinline__ uint32_t table_upsert(Slot* table, uint64_t mask, unsigned long long meta,
+                                                 const unsigned long long s[5], uint32_t idx32,
+                                                 uint32_t epoch, bool insert, bool* created) {
+  const unsigned long long h = key_hash(meta, s);
+  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  uint64_t j = h & mask;
+  *created = false;
+  uint64_t probes = 0;
+  for (;;) {
+    Slot* sl = table + j;
+    unsigned long long w0 = ld_agent(&sl->w[0]);
+    if (w0 == 0ull) {
+      if (!insert) return SID_NONE;
+      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | idx32);
+      if (old == 0ull) {
+        st_agent(&sl->w[2], (unsigned long long)epoch);
+#pragma unroll
+        for (int k = 0; k < 5; k++) st_agent(&sl->w[3 + k], s[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(&sl->w[1], meta);
+        *created = true;
+        return (uint32_t)j;
+      }
+      w0 = old;
+    }
+    if ((w0 & 0xffffffff00000000ull) == tagw && w0 != SLOT_TOMB) {
+      const unsigned long long m = ld_agent(&sl->w[1]);
+      if (!(m & SLOT_VALID)) continue;  // creator has not published yet: poll again
+      bool eq = m == meta;
+#pragma unroll
+      for (int k = 0; k < 5; k++) eq = eq && ld_agent(&sl->w[3 + k]) == s[k];
+      if (eq) {
+        if (insert && idx32 != 0xffffffffu) atomicMin(&sl->w[0], tagw | idx32);
+        return (uint32_t)j;
+      }
+    }
+    j = (j + 1) & mask;
+    if (++probes > mask) return SID_FULL;
+  }
+}
+
+struct InsertArgs {
+  const ctmr_record* records;
+  const uint8_t* payload;  // for serials longer than the 20 octets a record carries
+  const uint64_t* offsets;
+  const uint32_t* canon;   // issuer_idx → canonical issuer
+  Slot* table;
+  uint64_t mask;
+  uint32_t* slot_id;
+  uint64_t n;
+  uint32_t epoch;
+};
+
+// Offset of the serialNumber content octets (certificate already accepted by the map).
+__device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, uint32_t L) {
+  Hdr h;
+  rd_hdr(r, 0, L, h);
+  uint32_t p = h.hl;
+  rd_hdr(r, p, L, h);
+  uint32_t q = p + h.hl;
+  if ((r.ld4(q) & 0xffu) == 0xa0u) {
+    rd_hdr(r, q, L, h);
+    q += h.hl + h.len;
+  }
+  rd_hdr(r, q, L, h);
+  return q + h.hl;
+}
+
+// KnownCertificates.WasUnknown → RemoteCache.SetInsert (knowncertificates.go:38-55) for every
+// PASS entry, against the in-HBM table.
+__global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const uint4* rp = (const uint4*)(a.records + i);
+  const uint4 r0 = rp[0];
+  uint32_t sid = SID_NONE;
+  if ((r0.x & 0xffu) == CTMR_ST_PASS) {
+    const uint32_t slen = r0.x >> 16;
+    if (slen > CTMR_MAX_SERIAL) {
+      sid = SID_HOST;
+    } else {
+      const uint4 r1 = rp[1];
+      unsigned long long s[5];
+      s[0] = (unsigned long long)r0.w | ((unsigned long long)r1.x << 32);
+      s[1] = (unsigned long long)r1.y | ((unsigned long long)r1.z << 32);
+      s[2] = (unsigned long long)r1.w;
+      s[3] = 0;
+      s[4] = 0;
+      if (slen > 20) {
+        // octets 20..slen-1 come from the certificate itself
+        const uint64_t lo = a.offsets[i];
+        GlobalReader g{a.payload + lo};
+        const uint32_t so = serial_content_off(g, (uint32_t)(a.offsets[i + 1] - lo));
+        uint32_t x[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          const uint32_t pos = 20u + 4u * k;
+          if (pos < slen) {
+            const uint32_t rem = slen - pos;
+            const uint32_t v = g.ld4(so + pos);
+            x[k] = rem >= 4 ? v : (v & (0xffffffffu >> (8 * (4 - rem))));
+          }
+        }
+        s[2] |= (unsigned long long)x[0] << 32;
+        s[3] = (unsigned long long)x[1] | ((unsigned long long)x[2] << 32);
+        s[4] = (unsigned long long)x[3] | ((unsigned long long)x[4] << 32);
+      }
+      const uint32_t canon = a.canon[r0.z];
+      const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
+      bool created;
+      sid = table_upsert(a.table, a.mask, meta, s, (uint32_t)i, a.epoch, true, &created);
+    }
+  }
+  a.slot_id[i] = sid;
+}
+
+// Wave-aggregated add: one atomic per distinct key per wave (the "match-any" loop).
+__device__ __forceinline__ void wave_agg_add(bool active, uint32_t key, unsigned long long* arr) {
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k = __shfl(key, leader);
+    const unsigned long long same = __ballot(active && key == k) & todo;
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&arr[k], (unsigned long long)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+__device__ __forceinline__ bool pair_add(PairSlot* pairs, uint64_t pmask, unsigned long long key,
+                                         long long delta) {
+  uint64_t j = mixk(key) & pmask;
+  for (uint64_t probes = 0; probes <= pmask; probes++) {
+    unsigned long long k = ld_agent(&pairs[j].key);
+    if (k == 0ull) {
+      const unsigned long long old = atomicCAS(&pairs[j].key, 0ull, key);
+      k = old == 0ull ? key : old;
+    }
+    if (k == key) {
+      atomicAdd(&pairs[j].count, (unsigned long long)delta);
+      return true;
+    }
+    j = (j + 1) & pmask;
+  }
+  return false;
+}
+
+struct ResolveArgs {
+  ctmr_record* records;
+  const uint32_t* slot_id;
+  const uint32_t* canon;
+  const Slot* table;
+  unsigned long long* issuer_counts;  // per canonical issuer
+  PairSlot* pairs;
+  uint64_t pmask;
+  DevStats* stats;
+  uint32_t* blk_new;  // NEW count per 1024-entry block
+  uint64_t n;
+  uint32_t epoch;
+};
+
+// Decide WasUnknown for every PASS entry (lowest batch index of a new key wins — what the
+// reference does with numThreads = 1), bump counters, histogram statuses.
+__global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a) {
+  __shared__ uint32_t hist[CTMR_ST__COUNT + 4];
+  if (threadIdx.x < CTMR_ST__COUNT + 4) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  bool is_new = false, is_dup = false, is_host = false, is_full = false;
+  uint32_t status = CTMR_ST__COUNT, canon = 0;
+  unsigned long long pkey = 0;
+  if (i < a.n) {
+    const uint32_t head = *(const uint32_t*)(a.records + i);
+    status = head & 0xffu;
+    const uint32_t sid = a.slot_id[i];
+    if (sid == SID_HOST) {
+      is_host = true;
+    } else if (sid == SID_FULL) {
+      is_full = true;
+    } else if (sid != SID_NONE) {
+      const Slot* sl = a.table + sid;
+      const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
+      is_new = (uint32_t)w2 == a.epoch && (uint32_t)w0 == (uint32_t)i;
+      is_dup = !is_new;
+      canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+      pkey = ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1;
+      if (is_new) ((uint8_t*)(a.records + i))[1] = (uint8_t)((head >> 8) | CTMR_FL_WAS_UNKNOWN);
+    }
+  }
+  // per-issuer unique counts: Σ_expDate SCARD (storage-statistics.go:44-53)
+  wave_agg_add(is_new, canon, a.issuer_counts);
+  // per-(expDate, issuer) cardinality: SCARD(serials::expDate::issuer)
+  {
+    unsigned long long todo = __ballot(is_new);
+    bool okp = true;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned long long k = __shfl(pkey, leader);
+      const unsigned long long same = __ballot(is_new && pkey == k) & todo;
+      if ((int)(threadIdx.x & 63) == leader) okp = pair_add(a.pairs, a.pmask, k, __popcll(same));
+      todo &= ~same;
+    }
+    if (!okp) atomicAdd(&a.stats->pair_full, 1ull);
+  }
+  // block-level histogram → one atomic per bucket per block
+  const unsigned long long m_new = __ballot(is_new);
+  if ((threadIdx.x & 63) == 0) {
+    if (m_new) atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(m_new));
+  }
+  {
+    const unsigned long long m_dup = __ballot(is_dup), m_host = __ballot(is_host),
+                             m_full = __ballot(is_full);
+    if ((threadIdx.x & 63) == 0) {
+      if (m_dup) atomicAdd(&hist[CTMR_ST__COUNT + 1], (uint32_t)__popcll(m_dup));
+      if (m_host) atomicAdd(&hist[CTMR_ST__COUNT + 2], (uint32_t)__popcll(m_host));
+      if (m_full) atomicAdd(&hist[CTMR_ST__COUNT + 3], (uint32_t)__popcll(m_full));
+    }
+#pragma unroll
+    for (uint32_t st = 0; st < CTMR_ST__COUNT; st++) {
+      const unsigned long long m = __ballot(status == st);
+      if ((threadIdx.x & 63) == 0 && m) atomicAdd(&hist[st], (uint32_t)__popcll(m));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CTMR_ST__COUNT) {
+    if (hist[threadIdx.x]) atomicAdd(&a.stats->by_status[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+  } else if (threadIdx.x == CTMR_ST__COUNT) {
+    a.blk_new[blockIdx.x] = hist[CTMR_ST__COUNT];
+    if (hist[CTMR_ST__COUNT]) atomicAdd(&a.stats->n_new, (unsigned long long)hist[CTMR_ST__COUNT]);
+  } else if (threadIdx.x == CTMR_ST__COUNT + 1) {
+    if (hist[CTMR_ST__COUNT + 1]) atomicAdd(&a.stats->n_dup, (unsigned long long)hist[CTMR_ST__COUNT + 1]);
+  } else if (threadIdx.x == CTMR_ST__COUNT + 2) {
+    if (hist[CTMR_ST__COUNT + 2]) atomicAdd(&a.stats->n_host, (unsigned long long)hist[CTMR_ST__COUNT + 2]);
+  } else if (threadIdx.x == CTMR_ST__COUNT + 3) {
+    if (hist[CTMR_ST__COUNT + 3]) atomicAdd(&a.stats->n_full, (unsigned long long)hist[CTMR_ST__COUNT + 3]);
+  }
+}
+
+// Stream compaction of the NEW entries, ascending: wave ballot + popcount prefix inside a
+// 1024-entry block, block bases from the exclusive scan of blk_new.
+__global__ void __launch_bounds__(1024) k_compact(const ctmr_record* records, uint64_t n,
+                                                  const uint64_t* blk_base, uint64_t* new_idx) {
+  __shared__ uint32_t wave_cnt[16];
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  bool is_new = false;
+  if (i < n) is_new = (((const uint8_t*)(records + i))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
+  const unsigned long long m = __ballot(is_new);
+  if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (is_new) {
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < wv; k++) before += wave_cnt[k];
+    const uint32_t rank = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    new_idx[blk_base[blockIdx.x] + rank] = i;
+  }
+}
+
+// exclusive scan of blk_new (u32) into blk_base (u64): single workgroup, chunked
+__global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* blk_new, uint64_t nb,
+                                                      uint64_t* blk_base) {
+  __shared__ unsigned long long part[1024];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < nb; base += 1024) {
+    const uint64_t i = base + threadIdx.x;
+    const unsigned long long v = i < nb ? blk_new[i] : 0ull;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      const unsigned long long t = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) blk_base[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ RemoteCache point ops
+// op: 0 = SetInsert, 1 = SetContains, 2 = SetRemove.  result[0] = 1 when inserted / present /
+// removed; result[1] = SID_FULL marker on a full table.
+__global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, unsigned long long s0,
+                         unsigned long long s1, unsigned long long s2, unsigned long long s3,
+                         unsigned long long s4, int op, uint32_t epoch,
+                         unsigned long long* issuer_counts, PairSlot* pairs, uint64_t pmask,
+                         uint32_t* result) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long s[5] = {s0, s1, s2, s3, s4};
+  bool created = false;
+  const uint32_t sid = table_upsert(table, mask, meta, s, 0xffffffffu, epoch, op == 0, &created);
+  result[0] = 0;
+  result[1] = sid == SID_FULL;
+  if (sid == SID_FULL) return;
+  const uint32_t canon = (uint32_t)(meta >> 32) & 0xffffffu;
+  const unsigned long long pkey = ((unsigned long long)(canon + 1) << 32) | (uint32_t)meta;
+  if (op == 0) {
+    result[0] = created;
+    if (created) {
+      atomicAdd(&issuer_counts[canon], 1ull);
+      if (!pair_add(pairs, pmask, pkey, 1)) result[1] = 1;
+    }
+  } else if (op == 1) {
+    result[0] = sid != SID_NONE;
+  } else if (sid != SID_NONE) {
+    table[sid].w[0] = SLOT_TOMB;
+    table[sid].w[1] = 0;
+    atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
+    pair_add(pairs, pmask, pkey, -1);
+    result[0] = 1;
+  }
+}
+
+// Drop every member whose (exp_hour, canonical issuer) matches, or — with any_key — every
+// member with exp_hour*3600 <= now (Redis EXPIREAT set by knowncertificates.go:98-104).
+__global__ void __launch_bounds__(256) k_sweep(Slot* table, uint64_t nslots, int any_key,
+                                               long long now, uint32_t exp_hour_key, uint32_t canon_key,
+                                               unsigned long long* issuer_counts, PairSlot* pairs,
+                                               uint64_t pmask, unsigned long long* removed) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nslots) return;
+  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  const int32_t eh = (int32_t)(uint32_t)w1;
+  const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+  const bool hit = any_key ? ((long long)eh * 3600 <= now) : ((uint32_t)eh == exp_hour_key && canon == canon_key);
+  if (!hit) return;
+  table[j].w[0] = SLOT_TOMB;
+  table[j].w[1] = 0;
+  atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
+  pair_add(pairs, pmask, ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1, -1);
+  atomicAdd(removed, 1ull);
+}
+
+// SetList / SetToChan: gather the serials of one set.  out entries are 48 bytes:
+// [u32 len][40 bytes serial][u32 pad].
+__global__ void __launch_bounds__(256) k_list(const Slot* table, uint64_t nslots, uint32_t exp_hour_key,
+                                              uint32_t canon_key, uint8_t* out, uint64_t cap,
+                                              unsigned long long* count) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nslots) return;
+  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  if ((uint32_t)w1 != exp_hour_key || ((uint32_t)(w1 >> 32) & 0xffffffu) != canon_key) return;
+  const unsigned long long k = atomicAdd(count, 1ull);
+  if (k >= cap) return;
+  unsigned long long* o = (unsigned long long*)(out + k * 48);
+  o[0] = (w1 >> 56) & 0x7full;
+#pragma unroll
+  for (int q = 0; q < 5; q++) o[1 + q] = table[j].w[3 + q];
+}
+
+// KeysToChan: dump the non-empty (expDate, issuer) pairs.
+__global__ void __launch_bounds__(256) k_pairs(const PairSlot* pairs, uint64_t npairs,
+                                               unsigned long long* out, uint64_t cap,
+                                               unsigned long long* count) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= npairs) return;
+  const unsigned long long k = pairs[j].key, c = pairs[j].count;
+  if (k == 0ull || c == 0ull) return;
+  const unsigned long long at = atomicAdd(count, 1ull);
+  if (at >= cap) return;
+  out[2 * at] = k;
+  out[2 * at + 1] = c;
+}
+
+// ------------------------------------------------------------------ synthetic generator
+__global__ void __launch_bounds__(256) k_synth_len(SynthCfg c, uint64_t first, uint64_t n,
+                                                   uint64_t* offsets) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  BackWriter w{nullptr, SYNTH_MAX_LEN};
+  uint32_t iss;
+  uint8_t et;
+  synth_leaf_emit(c, first + i, w, iss, et);
+  offsets[i + 1] = SYNTH_MAX_LEN - w.pos;
+  if (i == 0) offsets[0] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_synth_emit(SynthCfg c, uint64_t first, uint64_t n,
+                                                    const uint64_t* offsets, uint8_t* payload,
+                                                    uint32_t* issuer_idx, uint8_t* entry_type) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+  BackWriter w{payload + offsets[i], len};
+  uint32_t iss;
+  uint8_t et;
+  synth_leaf_emit(c, first + i, w, iss, et);
+  issuer_idx[i] = iss;
+  entry_type[i] = et;
+}
+
+}  // namespace ctmr

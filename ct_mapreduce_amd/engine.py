@@ -1,0 +1,255 @@
+"""Host mirror of the reference's per-entry path over the C ABI (include/ctmr.h).
+
+Names follow the reference: `Engine.map_batch` is the batched body of insertCTWorker
+(cmd/ct-fetch/ct-fetch.go:191-235) through FilesystemDatabase.Store's WasUnknown
+(storage/filesystemdatabase.go:158-183); the set_* methods are storage.RemoteCache
+(storage/types.go:83-102) on byte strings.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+RECORD_DTYPE = np.dtype([("status", "u1"), ("flags", "u1"), ("serial_len", "<u2"),
+                         ("exp_hour", "<i4"), ("issuer_idx", "<u4"), ("serial", "u1", (20,))])
+assert RECORD_DTYPE.itemsize == 32
+
+
+class CtmrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ctmr error {code}: {msg}")
+        self.code = code
+
+
+@dataclass
+class Batch:
+    """Packed CT-entry batch (SURVEY.md §8(d) layout), host side."""
+    payload: np.ndarray      # u8, leaf DER back to back
+    offsets: np.ndarray      # u64[n+1]
+    issuer_idx: np.ndarray   # u32[n], NO_ISSUER = chain empty
+    entry_type: np.ndarray   # u8[n], 0 = X509, 1 = precert
+
+    @property
+    def n(self):
+        return len(self.offsets) - 1
+
+    def cert(self, i):
+        return self.payload[int(self.offsets[i]):int(self.offsets[i + 1])].tobytes()
+
+    @staticmethod
+    def from_certs(certs, issuer_idx, entry_type=None):
+        offs = np.zeros(len(certs) + 1, dtype=np.uint64)
+        if certs:
+            offs[1:] = np.cumsum([len(c) for c in certs], dtype=np.uint64)
+        payload = np.frombuffer(b"".join(certs), dtype=np.uint8).copy() if certs else np.zeros(0, np.uint8)
+        et = np.zeros(len(certs), np.uint8) if entry_type is None else np.asarray(entry_type, np.uint8)
+        return Batch(payload, offs, np.asarray(issuer_idx, dtype=np.uint32), et)
+
+
+@dataclass
+class BatchResult:
+    records: np.ndarray      # RECORD_DTYPE[n]
+    new_idx: np.ndarray      # u64[n_new], ascending
+    stats: N.BatchStats
+
+
+class Engine:
+    def __init__(self, device=0, table_slots=0, pair_slots=0, max_issuers=0, certs_per_tile=0,
+                 lds_tile_bytes=0, map_variant=0, profile=False):
+        self._lib = N.lib()
+        cfg = N.Config(struct_size=C.sizeof(N.Config), device=device, table_slots=table_slots,
+                       pair_slots=pair_slots, max_issuers=max_issuers, certs_per_tile=certs_per_tile,
+                       lds_tile_bytes=lds_tile_bytes, map_variant=map_variant, profile=int(profile))
+        h = C.c_void_p()
+        rc = self._lib.ctmr_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise CtmrError(rc, "ctmr_create failed (no usable HIP device? there is no CPU fallback)")
+        self._h = h
+
+    # ---- lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ctmr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CtmrError(rc, self._lib.ctmr_last_error(self._h).decode(errors="replace"))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream):
+        self._ck(self._lib.ctmr_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self._ck(self._lib.ctmr_synchronize(self._h))
+
+    # ---- issuers / filter
+    def add_issuers(self, certs):
+        blob = b"".join(certs)
+        offs = np.zeros(len(certs) + 1, dtype=np.uint64)
+        if certs:
+            offs[1:] = np.cumsum([len(c) for c in certs], dtype=np.uint64)
+        first = C.c_uint32()
+        buf = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(1, np.uint8)
+        self._ck(self._lib.ctmr_add_issuers(self._h, buf.ctypes.data, offs.ctypes.data, len(certs),
+                                            C.byref(first)))
+        return first.value
+
+    def issuer_count(self):
+        n = C.c_uint32()
+        self._ck(self._lib.ctmr_issuer_count(self._h, C.byref(n)))
+        return n.value
+
+    def issuer_info(self, idx):
+        info = N.IssuerInfo()
+        self._ck(self._lib.ctmr_issuer_info_get(self._h, idx, C.byref(info)))
+        return info
+
+    def issuer_id(self, idx):
+        return self.issuer_info(idx).issuer_id.decode()
+
+    def set_filter(self, issuer_cn_filter=b"", log_expired=False, now=0):
+        if isinstance(issuer_cn_filter, str):
+            issuer_cn_filter = issuer_cn_filter.encode()
+        self._ck(self._lib.ctmr_set_filter(self._h, issuer_cn_filter, len(issuer_cn_filter),
+                                           int(log_expired), int(now)))
+
+    # ---- the batched map + reduce
+    def map_batch(self, batch: Batch, want_records=True, want_new=True) -> BatchResult:
+        n = batch.n
+        payload = np.ascontiguousarray(batch.payload, dtype=np.uint8)
+        if payload.size == 0:
+            payload = np.zeros(1, np.uint8)
+        offsets = np.ascontiguousarray(batch.offsets, dtype=np.uint64)
+        iss = np.ascontiguousarray(batch.issuer_idx, dtype=np.uint32)
+        et = np.ascontiguousarray(batch.entry_type, dtype=np.uint8)
+        records = np.zeros(n, dtype=RECORD_DTYPE)
+        new_idx = np.zeros(max(n, 1), dtype=np.uint64)
+        st = N.BatchStats()
+        self._ck(self._lib.ctmr_map_batch(
+            self._h, payload.ctypes.data, offsets.ctypes.data, iss.ctypes.data if n else None,
+            et.ctypes.data if n else None, n, records.ctypes.data if (want_records and n) else None,
+            new_idx.ctypes.data if (want_new and n) else None, C.byref(st)))
+        return BatchResult(records, new_idx[:st.n_new] if want_new else new_idx[:0], st)
+
+    def map_batch_device(self, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records=0,
+                         d_new_idx=0) -> N.BatchStats:
+        """All pointers are device addresses (ints), e.g. torch tensors' data_ptr()."""
+        st = N.BatchStats()
+        self._ck(self._lib.ctmr_map_batch_device(
+            self._h, C.c_void_p(d_payload), C.c_void_p(d_offsets), C.c_void_p(d_issuer_idx),
+            C.c_void_p(d_entry_type) if d_entry_type else None, n,
+            C.c_void_p(d_records) if d_records else None,
+            C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
+        return st
+
+    # ---- storage.RemoteCache set methods (storage/types.go:83-102)
+    @staticmethod
+    def _b(x):
+        return x.encode() if isinstance(x, str) else bytes(x)
+
+    def set_insert(self, key, member) -> bool:
+        key, member = self._b(key), self._b(member)
+        out = C.c_int()
+        self._ck(self._lib.ctmr_set_insert(self._h, key, len(key), member, len(member), C.byref(out)))
+        return bool(out.value)
+
+    def set_contains(self, key, member) -> bool:
+        key, member = self._b(key), self._b(member)
+        out = C.c_int()
+        self._ck(self._lib.ctmr_set_contains(self._h, key, len(key), member, len(member), C.byref(out)))
+        return bool(out.value)
+
+    def set_remove(self, key, member) -> bool:
+        key, member = self._b(key), self._b(member)
+        out = C.c_int()
+        self._ck(self._lib.ctmr_set_remove(self._h, key, len(key), member, len(member), C.byref(out)))
+        return bool(out.value)
+
+    def set_cardinality(self, key) -> int:
+        key = self._b(key)
+        out = C.c_int64()
+        self._ck(self._lib.ctmr_set_cardinality(self._h, key, len(key), C.byref(out)))
+        return out.value
+
+    def exists(self, key) -> bool:
+        key = self._b(key)
+        out = C.c_int()
+        self._ck(self._lib.ctmr_exists(self._h, key, len(key), C.byref(out)))
+        return bool(out.value)
+
+    def _listing(self, fn, arg):
+        need = C.c_size_t()
+        cnt = C.c_uint64()
+        rc = fn(self._h, arg, len(arg), None, 0, C.byref(need), C.byref(cnt))
+        if rc not in (0, N.E_RANGE):
+            self._ck(rc)
+        buf = (C.c_uint8 * max(need.value, 1))()
+        self._ck(fn(self._h, arg, len(arg), buf, need.value, C.byref(need), C.byref(cnt)))
+        raw = bytes(buf)[:need.value]
+        out, o = [], 0
+        while o < len(raw):
+            l = int.from_bytes(raw[o:o + 4], "little")
+            out.append(raw[o + 4:o + 4 + l])
+            o += 4 + l
+        return out
+
+    def set_list(self, key):
+        """SetList / SetToChan: members, sorted bytewise."""
+        return self._listing(self._lib.ctmr_set_members, self._b(key))
+
+    def keys(self, pattern=b"*"):
+        """KeysToChan(pattern)."""
+        return self._listing(self._lib.ctmr_keys, self._b(pattern))
+
+    def expire_at(self, key, unix_seconds):
+        key = self._b(key)
+        self._ck(self._lib.ctmr_expire_at(self._h, key, len(key), int(unix_seconds)))
+
+    def expire_sweep(self, now) -> int:
+        out = C.c_uint64()
+        self._ck(self._lib.ctmr_expire_sweep(self._h, int(now), C.byref(out)))
+        return out.value
+
+    # ---- counts (cmd/storage-statistics/storage-statistics.go:44-53)
+    def issuer_counts(self):
+        n = self.issuer_count()
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self._lib.ctmr_issuer_counts(self._h, out.ctypes.data, n))
+        return out[:n]
+
+    def total_count(self) -> int:
+        out = C.c_uint64()
+        self._ck(self._lib.ctmr_total_count(self._h, C.byref(out)))
+        return out.value
+
+    def issuer_counts_device(self):
+        p = C.c_void_p()
+        n = C.c_uint32()
+        self._ck(self._lib.ctmr_issuer_counts_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def reset_known(self):
+        self._ck(self._lib.ctmr_reset_known(self._h))
+
+    # ---- synthetic input (bench / tests)
+    def synth_device(self, cfg: N.SynthConfig, first, n, d_offsets, d_payload, payload_cap,
+                     d_issuer_idx, d_entry_type) -> int:
+        out = C.c_uint64()
+        self._ck(self._lib.ctmr_synth_device(
+            self._h, C.byref(cfg), first, n, C.c_void_p(d_offsets),
+            C.c_void_p(d_payload) if d_payload else None, payload_cap,
+            C.c_void_p(d_issuer_idx) if d_issuer_idx else None,
+            C.c_void_p(d_entry_type) if d_entry_type else None, C.byref(out)))
+        return out.value

@@ -1,0 +1,220 @@
+/*
+ * ctmr.h — C ABI of libctmr (MI355X-native ct-mapreduce map/reduce hot path).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  A Go host
+ * binds it through cgo (INTEGRATION.md shows the stub); the C++ host mirror in
+ * ct_mapreduce_amd/csrc/storage.hpp and the Python ctypes binding in
+ * ct_mapreduce_amd/_native.py bind exactly the same symbols.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to
+ * jcjones/ct-mapreduce).  The reference has no FFI of its own (100 % Go): the seam is the
+ * `entryChan` consumer (cmd/ct-fetch/ct-fetch.go:191) for the batched map, and the
+ * storage.RemoteCache set methods (storage/types.go:83-102) for the reduce state.
+ *
+ * Conventions
+ *   - every function returns CTMR_OK (0) or a negative CTMR_E_* code; ctmr_last_error()
+ *     gives the message of the last failure on that engine.
+ *   - strings/members are (ptr,len) byte ranges, never NUL-terminated (serials contain \0).
+ *   - no pointer passed in is retained after the call returns (cgo rule).
+ *   - all entry points are thread-safe (one mutex per engine; GPU work is stream-ordered).
+ *   - there is NO CPU fallback: without a usable HIP device ctmr_create fails loudly.
+ */
+#ifndef CTMR_H
+#define CTMR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTMR_ABI_VERSION 1
+
+enum {
+  CTMR_OK = 0,
+  CTMR_E_INVAL = -1,     /* bad argument */
+  CTMR_E_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+  CTMR_E_NOMEM = -3,     /* device or host allocation failed */
+  CTMR_E_FULL = -4,      /* known-certificate table / issuer table / pair table is full */
+  CTMR_E_NOTFOUND = -5,
+  CTMR_E_RANGE = -6      /* caller buffer too small; *need tells the size */
+};
+
+/* Per-entry status, in the order insertCTWorker tests things
+ * (cmd/ct-fetch/ct-fetch.go:191-235). */
+enum {
+  CTMR_ST_PASS = 0,               /* reached database.Store (:229) */
+  CTMR_ST_PARSE_ERROR = 1,        /* x509.ParseCertificate(leaf) failed (:202-209) */
+  CTMR_ST_FILTERED_CA = 2,        /* certIsFilteredOut :47-50 */
+  CTMR_ST_FILTERED_EXPIRED = 3,   /* :52-55 */
+  CTMR_ST_FILTERED_CN = 4,        /* :57-69 */
+  CTMR_ST_NO_ISSUER = 5,          /* len(Chain) < 1 (:215-219) */
+  CTMR_ST_ISSUER_PARSE_ERROR = 6, /* x509.ParseCertificate(Chain[0]) failed (:221-225) */
+  CTMR_ST__COUNT = 7
+};
+
+/* record.flags */
+#define CTMR_FL_PRECERT 0x01      /* entry_type == 1 (ct.PrecertLogEntryType, :201) */
+#define CTMR_FL_WAS_UNKNOWN 0x02  /* KnownCertificates.WasUnknown == true (knowncertificates.go:38) */
+#define CTMR_FL_LONG_SERIAL 0x04  /* serial_len > 20: serial[] holds only the first 20 octets */
+
+#define CTMR_NO_ISSUER 0xFFFFFFFFu /* issuer_idx value meaning "len(Chain) < 1" */
+#define CTMR_PAYLOAD_PAD 32        /* readable bytes required after offsets[n] (device inputs) */
+#define CTMR_MAX_SERIAL 40         /* longest serial the in-HBM set stores; longer → host set */
+
+/* One 32-byte output record per entry (the "+32 B" of B_alg). */
+typedef struct {
+  uint8_t status;       /* CTMR_ST_* */
+  uint8_t flags;        /* CTMR_FL_* */
+  uint16_t serial_len;  /* raw INTEGER content length (storage/types.go:171-178) */
+  int32_t exp_hour;     /* floor(NotAfter/3600): NewExpDateFromTime (types.go:339-346) */
+  uint32_t issuer_idx;  /* as passed in */
+  uint8_t serial[20];   /* first min(20,serial_len) raw serial octets, zero padded */
+} ctmr_record;
+
+typedef struct {
+  uint32_t struct_size;       /* sizeof(ctmr_config) */
+  int32_t device;             /* HIP device ordinal */
+  uint64_t table_slots;       /* known-certificate table capacity (64-B slots; rounded up to 2^k); 0 = 2^24 */
+  uint64_t pair_slots;        /* (expDate,issuer) cardinality table capacity; 0 = 2^22 */
+  uint32_t max_issuers;       /* 0 = 65536 */
+  uint32_t certs_per_tile;    /* map-kernel tuning; 0 = default */
+  uint32_t lds_tile_bytes;    /* map-kernel tuning; 0 = default */
+  uint32_t map_variant;       /* 0 = default; see DESIGN.md §5 (1 = LDS tile, 2 = direct global) */
+  uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
+  uint32_t reserved;
+} ctmr_config;
+
+typedef struct {
+  uint64_t n;                          /* entries in the batch */
+  uint64_t by_status[CTMR_ST__COUNT];  /* histogram of record.status */
+  uint64_t n_new;                      /* PASS entries whose key was unknown (first by log index) */
+  uint64_t n_dup;                      /* PASS entries already known */
+  uint64_t n_host_set;                 /* PASS entries with serial_len > CTMR_MAX_SERIAL (host-side set) */
+  uint64_t payload_bytes;              /* offsets[n]-offsets[0] */
+  /* filled when config.profile: per-kernel GPU time of this batch, milliseconds */
+  float ms_map, ms_insert, ms_resolve, ms_compact, ms_total;
+  uint32_t map_launches;
+} ctmr_batch_stats;
+
+typedef struct {
+  int32_t valid;          /* the issuer certificate parsed (else entries get ISSUER_PARSE_ERROR) */
+  uint32_t canonical_idx; /* first registered issuer with the same SPKI digest */
+  uint8_t spki_sha256[32];/* SHA-256(RawSubjectPublicKeyInfo), computed on the GPU */
+  char issuer_id[48];     /* Issuer.ID(): padded base64url of the digest, NUL terminated (types.go:124-130) */
+} ctmr_issuer_info;
+
+typedef struct ctmr_engine ctmr_engine;
+
+/* ---- lifecycle (no reference equivalent; engine.GetConfiguredStorage engine/engine.go:19-48
+ *      is where a Go host would construct it) ---- */
+int ctmr_abi_version(void);
+int ctmr_create(const ctmr_config* cfg, ctmr_engine** out);
+void ctmr_destroy(ctmr_engine* e);
+const char* ctmr_last_error(const ctmr_engine* e);
+/* Launch all GPU work on this hipStream_t (default: a stream the engine owns). */
+int ctmr_set_stream(ctmr_engine* e, void* hip_stream);
+int ctmr_synchronize(ctmr_engine* e);
+
+/* ---- issuer table: replaces x509.ParseCertificate(Chain[0]) + NewIssuer + Issuer.ID()
+ *      (ct-fetch.go:221; storage/types.go:109-130,155-159).  Appends n issuer certificates
+ *      (DER blob + n+1 offsets); *first_idx receives the index of the first one. ---- */
+int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets, uint32_t n,
+                     uint32_t* first_idx);
+int ctmr_issuer_count(ctmr_engine* e, uint32_t* n);
+int ctmr_issuer_info_get(ctmr_engine* e, uint32_t idx, ctmr_issuer_info* out);
+
+/* ---- filter configuration: *ctconfig.IssuerCNFilter, *ctconfig.LogExpiredEntries and the
+ *      time.Now() of certIsFilteredOut (ct-fetch.go:44-70; config/config.go:194-196) ---- */
+int ctmr_set_filter(ctmr_engine* e, const char* issuer_cn_filter, size_t len, int log_expired,
+                    int64_t now_unix);
+
+/* ---- the batched map + reduce: replaces the body of insertCTWorker's loop
+ *      (ct-fetch.go:191-235) through FilesystemDatabase.Store's WasUnknown
+ *      (storage/filesystemdatabase.go:158-183; storage/knowncertificates.go:38-55).
+ *   payload      packed leaf DER (the X509 cert or Precert.Submitted.Data, :198-204)
+ *   offsets      n+1 byte offsets into payload
+ *   issuer_idx   per entry index into the issuer table, or CTMR_NO_ISSUER
+ *   entry_type   per entry 0 = X509LogEntryType, 1 = PrecertLogEntryType (may be NULL = all 0)
+ *   records      n records out (may be NULL)
+ *   new_idx      indices (ascending) of entries with CTMR_FL_WAS_UNKNOWN; capacity n (may be NULL)
+ * Host variant: all pointers are host memory; the library stages through pinned buffers. */
+int ctmr_map_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offsets,
+                   const uint32_t* issuer_idx, const uint8_t* entry_type, uint64_t n,
+                   ctmr_record* records, uint64_t* new_idx, ctmr_batch_stats* stats);
+/* Device variant: payload/offsets/issuer_idx/entry_type/records/new_idx are DEVICE pointers
+ * (payload 16-byte aligned, CTMR_PAYLOAD_PAD readable bytes after offsets[n]); stats is host. */
+int ctmr_map_batch_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                          const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                          ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats);
+
+/* ---- storage.RemoteCache set methods on byte strings (storage/types.go:83-102;
+ *      Redis impl storage/rediscache.go:57-120,153-169; mock storage/mockcache.go:38-166).
+ *      Keys of the form "serials::<expDateID-with-hour>::<issuerID of a registered issuer>"
+ *      live in the HBM table; every other key lives in a host-side string-set store. ---- */
+int ctmr_set_insert(ctmr_engine* e, const char* key, size_t key_len, const uint8_t* member,
+                    size_t member_len, int* was_new);                      /* SetInsert  */
+int ctmr_set_contains(ctmr_engine* e, const char* key, size_t key_len, const uint8_t* member,
+                      size_t member_len, int* present);                    /* SetContains */
+int ctmr_set_remove(ctmr_engine* e, const char* key, size_t key_len, const uint8_t* member,
+                    size_t member_len, int* removed);                      /* SetRemove  */
+int ctmr_set_cardinality(ctmr_engine* e, const char* key, size_t key_len, int64_t* n); /* SetCardinality */
+int ctmr_exists(ctmr_engine* e, const char* key, size_t key_len, int* exists);         /* Exists */
+/* SetList / SetToChan: members serialised [u32 len][bytes]…, sorted bytewise.  *need = bytes
+ * required; returns CTMR_E_RANGE (and copies nothing) when cap < *need. */
+int ctmr_set_members(ctmr_engine* e, const char* key, size_t key_len, uint8_t* out, size_t cap,
+                     size_t* need, uint64_t* count);
+/* KeysToChan(pattern): glob as path.Match ('*', '?', '[..]', '\\'); same serialisation, sorted. */
+int ctmr_keys(ctmr_engine* e, const char* pattern, size_t pattern_len, uint8_t* out, size_t cap,
+              size_t* need, uint64_t* count);
+/* ExpireAt: records the key's expiry; ctmr_expire_sweep(now) drops every key whose expiry
+ * is <= now (what Redis does lazily).  map_batch records ExpireAt(key, expDate hour) for
+ * every serials key it creates (knowncertificates.go:44-47,98-104). */
+int ctmr_expire_at(ctmr_engine* e, const char* key, size_t key_len, int64_t unix_seconds);
+int ctmr_expire_sweep(ctmr_engine* e, int64_t now_unix, uint64_t* members_removed);
+
+/* ---- per-issuer unique counts: Σ_expDate SCARD(serials::expDate::issuer), the quantity
+ *      storage-statistics reports (cmd/storage-statistics/storage-statistics.go:44-53).
+ *      out[i] is the count for registered issuer i (equal for issuers sharing an SPKI). ---- */
+int ctmr_issuer_counts(ctmr_engine* e, uint64_t* out, uint32_t n);
+int ctmr_total_count(ctmr_engine* e, uint64_t* out);
+/* Device pointer to the live u64[max_issuers] canonical-issuer counters (for an RCCL
+ * all-reduce by the multi-GPU driver). */
+int ctmr_issuer_counts_device(ctmr_engine* e, void** d_counts, uint32_t* n);
+/* Drop every known certificate (table, pair counts, counters, host-side sets keep keys). */
+int ctmr_reset_known(ctmr_engine* e);
+
+/* ---- benchmark / test input generator (SURVEY.md §8(d) synthetic CT batch); not part of the
+ *      reference's surface.  Deterministic in (seed, index); host and device emit identical bytes. */
+typedef struct {
+  uint64_t seed;
+  uint32_t n_issuers;      /* 1 or 256 … */
+  uint32_t zipf;           /* 1 = Zipf(s=1) issuer popularity, 0 = uniform */
+  uint32_t dup_permille;   /* entries re-emitting an earlier (issuer, serial, notAfter) */
+  uint32_t ca_permille;    /* basicConstraints CA:TRUE leaves (filter 1) */
+  uint32_t expired_permille; /* notAfter < base time (filter 2 when now == base) */
+  uint32_t mean_len;       /* 0 = 1536 */
+  int64_t base_time;       /* 0 = 2026-01-01T00:00:00Z */
+} ctmr_synth_config;
+
+/* Length of synthetic leaf i / issuer certificate k, and their bytes (host side). */
+uint32_t ctmr_synth_leaf_len(const ctmr_synth_config* c, uint64_t i);
+uint32_t ctmr_synth_leaf(const ctmr_synth_config* c, uint64_t i, uint8_t* out, uint32_t cap,
+                         uint32_t* issuer_idx, uint8_t* entry_type);
+uint32_t ctmr_synth_issuer(const ctmr_synth_config* c, uint32_t k, uint8_t* out, uint32_t cap);
+/* Host batch [first, first+n): offsets u64[n+1] (relative), payload (capacity cap), issuer_idx,
+ * entry_type.  Returns the payload bytes needed (nothing is written past cap). */
+uint64_t ctmr_synth_host(const ctmr_synth_config* c, uint64_t first, uint64_t n, uint64_t* offsets,
+                         uint8_t* payload, uint64_t cap, uint32_t* issuer_idx, uint8_t* entry_type);
+/* Generate entries [first, first+n) directly in HBM: d_offsets u64[n+1] (relative to the
+ * batch start), d_payload (capacity payload_cap), d_issuer_idx u32[n], d_entry_type u8[n].
+ * *payload_bytes = bytes written.  With d_payload == NULL only offsets are produced. */
+int ctmr_synth_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n,
+                      uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
+                      uint32_t* d_issuer_idx, uint8_t* d_entry_type, uint64_t* payload_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTMR_H */

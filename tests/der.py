@@ -1,0 +1,67 @@
+"""Tiny DER encoder for hand-built edge-case certificates (test helper)."""
+
+
+def tlv(tag, content=b""):
+    n = len(content)
+    if n < 0x80:
+        l = bytes([n])
+    else:
+        b = n.to_bytes((n.bit_length() + 7) // 8, "big")
+        l = bytes([0x80 | len(b)]) + b
+    return bytes([tag]) + l + content
+
+
+def seq(*items):
+    return tlv(0x30, b"".join(items))
+
+
+def oid(*bs):
+    return tlv(0x06, bytes(bs))
+
+
+def rdn(attr, value, tag=0x0c):
+    return tlv(0x31, seq(oid(0x55, 0x04, attr), tlv(tag, value)))
+
+
+def name(*rdns):
+    return seq(*rdns)
+
+
+def utctime(s):
+    return tlv(0x17, s.encode())
+
+
+def gentime(s):
+    return tlv(0x18, s.encode())
+
+
+SIGALG = bytes.fromhex("300d06092a864886f70d01010b0500")
+EC_SPKI = bytes.fromhex("3059301306072a8648ce3d020106082a8648ce3d030107034200") + bytes(range(1, 66))
+
+
+def ext(oid_last, value, critical=None):
+    items = [oid(0x55, 0x1d, oid_last)]
+    if critical is not None:
+        items.append(tlv(0x01, b"\xff" if critical else b"\x00"))
+    items.append(tlv(0x04, value))
+    return seq(*items)
+
+
+def cert(serial=b"\x01", issuer=None, not_before=None, not_after=None, subject=None, spki=EC_SPKI,
+         exts=None, version=True, sig=b"\x00" + b"\x5a" * 64, extra_tbs=b""):
+    issuer = issuer if issuer is not None else name(rdn(3, b"Test CA"))
+    subject = subject if subject is not None else name(rdn(3, b"leaf"))
+    not_before = not_before or utctime("250101000000Z")
+    not_after = not_after or utctime("270101000000Z")
+    tbs = b""
+    if version:
+        tbs += tlv(0xa0, tlv(0x02, b"\x02"))
+    tbs += tlv(0x02, serial) + SIGALG + issuer + seq(not_before, not_after) + subject + spki
+    if exts is not None:
+        tbs += tlv(0xa3, seq(*exts))
+    tbs += extra_tbs
+    return seq(tlv(0x30, tbs), SIGALG, tlv(0x03, sig))
+
+
+BC_CA = ext(0x13, seq(tlv(0x01, b"\xff")), critical=True)
+BC_NOT_CA = ext(0x13, seq(), critical=True)

@@ -1,0 +1,61 @@
+"""Builds and binds the test-only helpers (host build of the product walk, OpenSSL extractor)."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _build(src, out, cmd):
+    outp = os.path.join(HERE, out)
+    srcp = os.path.join(HERE, src)
+    dep = os.path.join(HERE, "..", "..", "ct_mapreduce_amd", "csrc", "der_walk.h")
+    if (not os.path.exists(outp) or os.path.getmtime(outp) < os.path.getmtime(srcp)
+            or os.path.getmtime(outp) < os.path.getmtime(dep)):
+        subprocess.check_call(cmd + [srcp, "-o", outp])
+    return outp
+
+
+class HarnessOut(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("serial_off", C.c_uint32), ("serial_len", C.c_uint32),
+                ("not_before", C.c_int64), ("not_after", C.c_int64), ("cn_off", C.c_uint32),
+                ("cn_len", C.c_uint32), ("bc_valid", C.c_int32), ("is_ca", C.c_int32),
+                ("spki_off", C.c_uint32), ("spki_len", C.c_uint32)]
+
+
+class OsslOut(C.Structure):
+    _fields_ = [("ok", C.c_int), ("not_before", C.c_longlong), ("not_after", C.c_longlong),
+                ("is_ca", C.c_int), ("has_bc", C.c_int), ("serial_len", C.c_int),
+                ("serial", C.c_ubyte * 64), ("serial_neg", C.c_int), ("cn_len", C.c_int),
+                ("cn", C.c_ubyte * 256), ("spki_len", C.c_int), ("spki", C.c_ubyte * 1024)]
+
+
+_walk = None
+_ossl = None
+
+
+def product_walk(der: bytes, fill=0xA5) -> HarnessOut:
+    global _walk
+    if _walk is None:
+        p = _build("walk_harness.cpp", "libwalk_harness.so",
+                   ["g++", "-O2", "-std=c++17", "-shared", "-fPIC"])
+        _walk = C.CDLL(p)
+        _walk.harness_walk.argtypes = [C.c_char_p, C.c_uint32, C.c_uint8, C.POINTER(HarnessOut)]
+    o = HarnessOut()
+    _walk.harness_walk(der, len(der), fill, C.byref(o))
+    return o
+
+
+def ossl_extract(der: bytes):
+    global _ossl
+    if _ossl is None:
+        outp = os.path.join(HERE, "libossl_extract.so")
+        srcp = os.path.join(HERE, "ossl_extract.c")
+        if not os.path.exists(outp) or os.path.getmtime(outp) < os.path.getmtime(srcp):
+            subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", srcp, "-o", outp, "-lcrypto"])
+        _ossl = C.CDLL(outp)
+        _ossl.ossl_extract.argtypes = [C.c_char_p, C.c_long, C.POINTER(OsslOut)]
+    o = OsslOut()
+    if not _ossl.ossl_extract(der, len(der), C.byref(o)):
+        return None
+    return o

@@ -1,0 +1,158 @@
+"""CPU-side checks of the walk: oracle vs OpenSSL (independent extractor) on goldens + synthetic
+certs, and the PRODUCT's device walk (host build, tests/harness) vs the oracle on valid, mutated
+and truncated inputs.  No GPU needed; the GPU parity tests repeat the fuzz through the C ABI."""
+import random
+
+import pytest
+
+from ct_mapreduce_amd import synth
+from oracle import oracle as orc
+from tests import harness
+
+FIELDS = ("serial_off", "serial_len", "not_before", "not_after", "cn_off", "cn_len", "bc_valid",
+          "is_ca", "spki_off", "spki_len")
+
+
+def same(der):
+    o = orc.parse_cert(der)
+    p = harness.product_walk(der, 0xA5)
+    p2 = harness.product_walk(der, 0x30)   # different garbage after the cert: must not matter
+    assert bool(p.ok) == bool(p2.ok)
+    assert bool(o.ok) == bool(p.ok), (o.ok, o.err_site, p.ok)
+    if o.ok:
+        for f in FIELDS:
+            assert getattr(o, f) == getattr(p, f) == getattr(p2, f), f
+    return bool(o.ok)
+
+
+def check_against_openssl(der):
+    o = orc.parse_cert(der)
+    x = harness.ossl_extract(der)
+    assert o.ok == 1 and x is not None
+    assert o.not_after == x.not_after and o.not_before == x.not_before
+    assert bool(o.bc_valid) == bool(x.has_bc) and bool(o.is_ca) == bool(x.is_ca)
+    raw = der[o.serial_off:o.serial_off + o.serial_len]
+    mag = bytes(x.serial[:x.serial_len])
+    assert not x.serial_neg
+    assert raw.lstrip(b"\x00") == mag.lstrip(b"\x00")          # OpenSSL normalises; we keep raw
+    assert der[o.cn_off:o.cn_off + o.cn_len] == bytes(x.cn[:x.cn_len])
+    assert der[o.spki_off:o.spki_off + o.spki_len] == bytes(x.spki[:x.spki_len])
+
+
+def test_goldens_against_openssl(golden_certs):
+    for der in golden_certs.values():
+        check_against_openssl(der)
+        assert same(der)
+
+
+def test_synthetic_certs_against_openssl():
+    cfg = synth.config(seed=7, n_issuers=256, dup_permille=100, ca_permille=100, expired_permille=100)
+    for i in range(400):
+        der, iss, et = synth.leaf(cfg, i)
+        check_against_openssl(der)
+        assert same(der)
+    for k in (0, 1, 17, 255):
+        der = synth.issuer(cfg, k)
+        check_against_openssl(der)
+        assert same(der)
+        c = orc.parse_cert(der)
+        assert c.is_ca == 1
+
+
+def test_synthetic_length_distribution_and_features():
+    cfg = synth.config(seed=11, n_issuers=256, dup_permille=0, ca_permille=10, expired_permille=10)
+    lens, cas, exps, lead0 = [], 0, 0, 0
+    for i in range(3000):
+        der, iss, et = synth.leaf(cfg, i)
+        c = orc.parse_cert(der)
+        assert c.ok
+        lens.append(len(der))
+        cas += c.is_ca
+        exps += c.not_after < synth.BASE_TIME
+        lead0 += der[c.serial_off] == 0
+        assert der[c.cn_off:c.cn_off + c.cn_len] == b"Synth Issuer %03d" % iss
+    assert 1200 <= min(lens) and max(lens) <= 2010
+    assert 1500 < sum(lens) / len(lens) < 1570
+    assert 5 <= cas <= 70 and 5 <= exps <= 70
+    assert 1200 < lead0 < 1800          # ≈50 % carry the leading 00 (G2 semantics exercised)
+
+
+def mutate(rng, der):
+    b = bytearray(der)
+    kind = rng.randrange(6)
+    if kind == 0:      # flip a byte in the first 300 (headers live there)
+        i = rng.randrange(min(len(b), 300))
+        b[i] ^= 1 << rng.randrange(8)
+    elif kind == 1:    # flip anywhere
+        i = rng.randrange(len(b))
+        b[i] = rng.randrange(256)
+    elif kind == 2:    # truncate
+        b = b[:rng.randrange(len(b))]
+    elif kind == 3:    # extend
+        b += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 8)))
+    elif kind == 4:    # overwrite a short run
+        i = rng.randrange(len(b))
+        for k in range(i, min(len(b), i + rng.randrange(1, 6))):
+            b[k] = rng.choice((0x00, 0x30, 0x80, 0x81, 0x82, 0x83, 0x84, 0xff, 0xa0, 0xa3, 0x02, 0x17, 0x18))
+    else:              # two flips
+        for _ in range(2):
+            i = rng.randrange(len(b))
+            b[i] ^= 1 << rng.randrange(8)
+    return bytes(b)
+
+
+def test_product_walk_equals_oracle_on_mutations(golden_certs):
+    rng = random.Random(20260921)
+    cfg = synth.config(seed=3, n_issuers=16, ca_permille=200, expired_permille=50)
+    seeds = list(golden_certs.values()) + [synth.leaf(cfg, i)[0] for i in range(40)]
+    accepted = 0
+    for r in range(6000):
+        der = mutate(rng, seeds[r % len(seeds)])
+        accepted += same(der)
+    assert 300 < accepted < 5700      # both outcomes are exercised
+
+
+@pytest.mark.parametrize("t,ok,exp", [
+    (b"\x17\x0d" + b"260101000000Z", True, 1767225600),
+    (b"\x17\x0b" + b"2601010000Z", True, 1767225600),
+    (b"\x18\x0f" + b"20260101000000Z", True, 1767225600),
+    (b"\x17\x0d" + b"491231235959Z", True, 2524607999),
+    (b"\x17\x0d" + b"500101000000Z", True, -631152000),
+    (b"\x18\x0f" + b"19691231235959Z", True, -1),
+    (b"\x18\x0f" + b"00010101000000Z", True, -62135596800),
+    (b"\x17\x0d" + b"260230000000Z", False, 0),       # Feb 30
+    (b"\x17\x0d" + b"240229000000Z", True, 1709164800),
+    (b"\x17\x0d" + b"250229000000Z", False, 0),
+    (b"\x17\x0d" + b"261301000000Z", False, 0),
+    (b"\x17\x0d" + b"260101240000Z", False, 0),
+    (b"\x17\x0d" + b"260101006000Z", False, 0),
+    (b"\x17\x0d" + b"260101000060Z", False, 0),
+    (b"\x17\x0d" + b"26010100000 Z", False, 0),
+    (b"\x17\x0d" + b"260101000000+", False, 0),
+    (b"\x17\x11" + b"260101000000+0100", False, 0),   # numeric zone: outside the profile
+    (b"\x18\x0d" + b"260101000000Z", False, 0),
+    (b"\x16\x0d" + b"260101000000Z", False, 0),
+])
+def test_time_forms(golden_certs, t, ok, exp):
+    """Swap notAfter of the leading-zeroes golden (GeneralizedTime at a fixed offset)."""
+    der = golden_certs["kLeadingZeroes"]
+    c = orc.parse_cert(der)
+    # find notAfter TLV: second time inside validity; golden uses 18 0f … twice
+    i = der.index(b"\x18\x0f20200205000000Z")
+    old = der[i:i + 17]
+    body = der[:i] + t + der[i + 17:]
+    delta = len(t) - len(old)
+    # patch the three enclosing lengths (validity SEQ short form, TBS and Certificate long form)
+    b = bytearray(body)
+    vi = der.index(b"\x30\x22\x18\x0f")
+    b[vi + 1] = 0x22 + delta
+    tbs = int.from_bytes(der[6:8], "big") + delta
+    tot = int.from_bytes(der[2:4], "big") + delta
+    b[6:8] = tbs.to_bytes(2, "big")
+    b[2:4] = tot.to_bytes(2, "big")
+    der2 = bytes(b)
+    o = orc.parse_cert(der2)
+    assert bool(o.ok) == ok
+    if ok:
+        assert o.not_after == exp
+    assert same(der2) == ok
