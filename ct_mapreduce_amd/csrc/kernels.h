@@ -484,19 +484,10 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a) {
   }
   // per-issuer unique counts: Σ_expDate SCARD (storage-statistics.go:44-53)
   wave_agg_add(is_new, canon, a.issuer_counts);
-  // per-(expDate, issuer) cardinality: SCARD(serials::expDate::issuer)
-  {
-    unsigned long long todo = __ballot(is_new);
-    bool okp = true;
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const unsigned long long k = __shfl(pkey, leader);
-      const unsigned long long same = __ballot(is_new && pkey == k) & todo;
-      if ((int)(threadIdx.x & 63) == leader) okp = pair_add(a.pairs, a.pmask, k, __popcll(same));
-      todo &= ~same;
-    }
-    if (!okp) atomicAdd(&a.stats->pair_full, 1ull);
-  }
+  // per-(expDate, issuer) cardinality: SCARD(serials::expDate::issuer).  Keys are nearly all
+  // distinct inside a wave (≈2 000 expiry hours × issuers), so every lane probes on its own —
+  // a leader-serialised match-any loop costs one dependent global round trip per distinct key.
+  if (is_new && !pair_add(a.pairs, a.pmask, pkey, 1)) atomicAdd(&a.stats->pair_full, 1ull);
   // block-level histogram → one atomic per bucket per block
   const unsigned long long m_new = __ballot(is_new);
   if ((threadIdx.x & 63) == 0) {
