@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+           "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -583,7 +583,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   ra.records = d_records; ra.slot_id = d_slot; ra.canon = e->d_canon; ra.table = e->table;
   ra.issuer_counts = e->issuer_counts; ra.pairs = e->pairs; ra.pmask = e->npairs - 1;
   ra.stats = e->d_stats; ra.blk_new = d_blk_new; ra.n = n; ra.epoch = e->epoch;
-  hipLaunchKernelGGL(k_resolve, dim3((unsigned)nb), dim3(1024), 0, e->stream, ra);
+  hipLaunchKernelGGL(k_resolve, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(1024), 0, e->stream, ra, nb);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[3], e->stream));
   DevStats hs;
   HIPCHK(e, hipMemcpyAsync(&hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));

@@ -30,45 +30,40 @@ struct Walk {
   bool bc_valid, is_ca;
 };
 
-struct Hdr {
-  uint32_t tag, hl, len;
-};
+// ---------------------------------------------------------------------------------------------
+// Control-flow style: SIMD lanes walk different certificates, so the walk never returns early.
+// Every check is AND-ed into `ok`; after a failed check the remaining steps run on whatever
+// values they have (every load address is clamped to the certificate, every loop also tests
+// `ok`), and only the final `ok` is observable.  This keeps the exec-mask bookkeeping down to
+// the loops and the few optional elements.
 
-// Decode the TLV header at p; header and content must fit inside [p, end).
+// TLV header at p, which must lie wholly inside [p, end): tag, content start, content end.
 // Go encoding/asn1 parseTagAndLength rules: single-byte tags, definite minimal lengths < 2^31.
 template <class R>
-CTMR_HD bool rd_hdr(const R& r, uint32_t p, uint32_t end, Hdr& h) {
-  if (end < 2 || p > end - 2) return false;
-  const uint32_t w = r.ld4(p);
-  h.tag = w & 0xffu;
-  if ((h.tag & 0x1fu) == 0x1fu) return false;
-  const uint32_t b = (w >> 8) & 0xffu;
-  if (b < 0x80u) {
-    h.hl = 2;
-    h.len = b;
-  } else {
-    const uint32_t n = b & 0x7fu;
-    if (n == 0 || n > 4) return false;
-    if (end - p - 2 < n) return false;
-    uint32_t v;
-    if (n == 1) {
-      v = (w >> 16) & 0xffu;
-      if (v < 0x80u) return false;  // non-minimal (also covers a zero byte)
-    } else if (n == 2) {
-      const uint32_t b2 = (w >> 16) & 0xffu;
-      if (b2 == 0) return false;    // superfluous leading zero
-      v = (b2 << 8) | (w >> 24);
-    } else {
-      const uint32_t x = r.ld4(p + 2);  // the n length bytes, big endian
-      if ((x & 0xffu) == 0) return false;
-      const uint32_t be = __builtin_bswap32(x);
-      v = n == 3 ? (be >> 8) : be;
-      if (v > 0x7fffffffu) return false;
-    }
-    h.hl = 2 + n;
-    h.len = v;
+CTMR_HD void rd_hdr(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& tag,
+                    uint32_t& cs, uint32_t& ce) {
+  const uint32_t w = r.ld4(p < L ? p : L);
+  tag = w & 0xffu;
+  const uint32_t b = (w >> 8) & 0xffu, b2 = (w >> 16) & 0xffu, b3 = w >> 24;
+  const uint32_t n = b & 0x7fu;
+  const bool lng = b >= 0x80u;
+  uint32_t len = lng ? (n == 1 ? b2 : ((b2 << 8) | b3)) : b;
+  const uint32_t hl = lng ? 2u + n : 2u;
+  // short form | 0x81 vv (vv >= 0x80) | 0x82 hh ll (hh != 0): minimal, no leading zero
+  bool good = ((tag & 0x1fu) != 0x1fu) & (!lng | (n == 1 ? b2 >= 0x80u : b2 != 0u)) & (!lng | (n != 0u));
+  if (lng & (n > 2u)) {  // > 64 KiB contents: rare
+    const uint32_t q = p + 2u;
+    const uint32_t x = r.ld4(q < L ? q : L);  // the n length bytes, big endian
+    const uint32_t be = __builtin_bswap32(x);
+    len = n == 3 ? (be >> 8) : be;
+    good = good & (n <= 4u) & ((x & 0xffu) != 0u) & (len <= 0x7fffffffu);
   }
-  return h.len <= end - p - h.hl;
+  const uint32_t c = p + hl;              // p <= 2^31, hl <= 6: no wrap
+  good = good & (p <= end) & (c <= end);  // header bytes inside [p, end)
+  good = good & (len <= end - c);         // (end - c wraps only when good is already false)
+  ok = ok & good;
+  cs = c;
+  ce = c + len;
 }
 
 CTMR_HD bool digits4(uint32_t w) {  // four ASCII digits?
@@ -76,7 +71,7 @@ CTMR_HD bool digits4(uint32_t w) {  // four ASCII digits?
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const uint32_t c = (w >> (8 * i)) & 0xffu;
-    ok = ok && (c - 0x30u) <= 9u;
+    ok = ok & ((c - 0x30u) <= 9u);
   }
   return ok;
 }
@@ -95,64 +90,52 @@ CTMR_HD int64_t days_from_civil(int32_t y, uint32_t m, uint32_t d) {
 }
 
 // UTCTime "YYMMDDHHMM[SS]Z" (tag 0x17, len 11/13) or GeneralizedTime "YYYYMMDDHHMMSSZ"
-// (tag 0x18, len 15).  Only the Z forms are in the profile.
+// (tag 0x18, len 15) at content offset c.  Only the Z forms are in the profile.
 template <class R>
-CTMR_HD bool rd_time(const R& r, uint32_t c, const Hdr& h, int64_t& out) {
-  uint32_t w0 = r.ld4(c), w1 = r.ld4(c + 4), w2 = r.ld4(c + 8), w3 = r.ld4(c + 12);
-  int32_t year;
-  if (h.tag == 0x18u) {
-    if (h.len != 15) return false;
-    if (!digits4(w0)) return false;
-    year = (int32_t)(d2(w0, 0) * 100u + d2(w0, 16));
-    // drop the century: shift the 16-byte window down by two bytes
+CTMR_HD void rd_time(const R& r, uint32_t L, uint32_t c, uint32_t tag, uint32_t len, bool& ok,
+                     int64_t& out) {
+  const uint32_t cc = c < L ? c : L;
+  uint32_t w0 = r.ld4(cc), w1 = r.ld4(cc + 4), w2 = r.ld4(cc + 8), w3 = r.ld4(cc + 12);
+  const bool gt = tag == 0x18u;
+  bool good = gt ? (len == 15u) : ((tag == 0x17u) & ((len == 13u) | (len == 11u)));
+  uint32_t century = 0;
+  if (gt) {
+    good = good & digits4(w0);
+    century = d2(w0, 0);
+    // drop the century: shift the 16-byte window down by two bytes → "YYMMDDHHMMSSZ"
     w0 = (w0 >> 16) | (w1 << 16);
     w1 = (w1 >> 16) | (w2 << 16);
     w2 = (w2 >> 16) | (w3 << 16);
     w3 = w3 >> 16;
-    // now w0.. = "YYMMDDHHMMSSZ"
-    if (!digits4(w0) || !digits4(w1) || !digits4(w2)) return false;
-    if ((w3 & 0xffu) != 'Z') return false;
-  } else if (h.tag == 0x17u) {
-    if (h.len == 13) {
-      if (!digits4(w0) || !digits4(w1) || !digits4(w2)) return false;
-      if ((w3 & 0xffu) != 'Z') return false;
-    } else if (h.len == 11) {
-      if (!digits4(w0) || !digits4(w1)) return false;
-      if (!digits4((w2 & 0xffffu) | 0x30300000u)) return false;
-      if (((w2 >> 16) & 0xffu) != 'Z') return false;
-      w2 = (w2 & 0xffffu) | 0x30300000u;  // seconds = "00"
-    } else {
-      return false;
-    }
-    const uint32_t yy = d2(w0, 0);
-    year = (int32_t)(yy < 50 ? 2000 + yy : 1900 + yy);
-  } else {
-    return false;
   }
+  const bool short_form = !gt & (len == 11u);  // "YYMMDDHHMMZ": seconds = 00
+  const uint32_t z = short_form ? (w2 >> 16) : w3;
+  if (short_form) w2 = (w2 & 0xffffu) | 0x30300000u;
+  good = good & digits4(w0) & digits4(w1) & digits4(w2) & ((z & 0xffu) == (uint32_t)'Z');
+  const uint32_t yy = d2(w0, 0);
+  const int32_t year = gt ? (int32_t)(century * 100u + yy) : (int32_t)(yy < 50u ? 2000u + yy : 1900u + yy);
   const uint32_t mon = d2(w0, 16), day = d2(w1, 0), hh = d2(w1, 16), mm = d2(w2, 0), ss = d2(w2, 16);
-  if (mon < 1 || mon > 12) return false;
-  uint32_t dim = 31u - ((0xA50u >> mon) & 1u);  // 30-day months: Apr Jun Sep Nov
-  if (mon == 2) dim = ((year % 4 == 0) && (year % 100 != 0 || year % 400 == 0)) ? 29 : 28;
-  if (day < 1 || day > dim) return false;
-  if (hh > 23 || mm > 59 || ss > 59) return false;
+  uint32_t dim = 31u - ((0xA50u >> (mon & 15u)) & 1u);  // 30-day months: Apr Jun Sep Nov
+  const bool leap = (year % 4 == 0) & ((year % 100 != 0) | (year % 400 == 0));
+  dim = mon == 2u ? (leap ? 29u : 28u) : dim;
+  good = good & (mon >= 1u) & (mon <= 12u) & (day >= 1u) & (day <= dim) & (hh <= 23u) & (mm <= 59u) & (ss <= 59u);
+  ok = ok & good;
   out = days_from_civil(year, mon, day) * 86400 + (int64_t)(hh * 3600u + mm * 60u + ss);
-  return true;
 }
 
 // Go asn1 checkInteger on content [c, c+len): non-empty and minimally encoded.
 template <class R>
-CTMR_HD bool int_ok(const R& r, uint32_t c, uint32_t len) {
-  if (len == 0) return false;
-  if (len == 1) return true;
-  const uint32_t w = r.ld4(c);
+CTMR_HD bool int_ok(const R& r, uint32_t L, uint32_t c, uint32_t len) {
+  const uint32_t w = r.ld4(c < L ? c : L);
   const uint32_t b0 = w & 0xffu, b1 = (w >> 8) & 0xffu;
-  if (b0 == 0x00u && (b1 & 0x80u) == 0) return false;
-  if (b0 == 0xffu && (b1 & 0x80u) != 0) return false;
-  return true;
+  const bool pad0 = (b0 == 0x00u) & ((b1 & 0x80u) == 0u);
+  const bool padf = (b0 == 0xffu) & ((b1 & 0x80u) != 0u);
+  return (len != 0u) & ((len == 1u) | !(pad0 | padf));
 }
 
 CTMR_HD bool string_tag(uint32_t t) {
-  return t == 0x0cu || t == 0x12u || t == 0x13u || t == 0x14u || t == 0x16u;
+  // UTF8String, NumericString, PrintableString, T61String, IA5String
+  return (t == 0x0cu) | (t == 0x12u) | (t == 0x13u) | (t == 0x14u) | (t == 0x16u);
 }
 
 template <class R>
@@ -162,133 +145,132 @@ CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
   o.cn_off = o.cn_len = 0;
   o.spki_off = o.spki_len = 0;
   o.bc_valid = o.is_ca = false;
-  if (L > 0x7fffffffu) return false;
-  Hdr h;
+  bool ok = L <= 0x7fffffffu;
+  if (!ok) return false;
+  uint32_t tag, cs, ce;
   // Certificate ::= SEQUENCE filling the buffer exactly
-  if (!rd_hdr(r, 0, L, h) || h.tag != 0x30u || h.hl + h.len != L) return false;
-  uint32_t p = h.hl;
-  if (!rd_hdr(r, p, L, h) || h.tag != 0x30u) return false;
-  const uint32_t tbs_end = p + h.hl + h.len;
-  uint32_t q = p + h.hl;
+  rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u) & (ce == L);
+  // tbsCertificate
+  rd_hdr(r, L, cs, L, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
+  const uint32_t tbs_end = ce;
+  uint32_t q = cs;
   // version [0] EXPLICIT INTEGER
-  if (q < tbs_end && (r.ld4(q) & 0xffu) == 0xa0u) {
-    if (!rd_hdr(r, q, tbs_end, h)) return false;
-    Hdr v;
-    const uint32_t vq = q + h.hl;
-    if (!rd_hdr(r, vq, vq + h.len, v) || v.tag != 0x02u) return false;
-    if (v.hl + v.len != h.len || v.len > 4 || !int_ok(r, vq + v.hl, v.len)) return false;
-    q += h.hl + h.len;
+  if ((q < tbs_end) & ((r.ld4(q < L ? q : L) & 0xffu) == 0xa0u)) {
+    uint32_t vs, ve, t2, is_, ie;
+    rd_hdr(r, L, q, tbs_end, ok, tag, vs, ve);
+    rd_hdr(r, L, vs, ve, ok, t2, is_, ie);
+    ok = ok & (t2 == 0x02u) & (ie == ve) & (ie - is_ <= 4u) & int_ok(r, L, is_, ie - is_);
+    q = ve;
   }
-  // serialNumber
-  if (!rd_hdr(r, q, tbs_end, h) || h.tag != 0x02u) return false;
-  if (!int_ok(r, q + h.hl, h.len)) return false;
-  o.serial_off = q + h.hl;
-  o.serial_len = h.len;
-  q += h.hl + h.len;
+  // serialNumber: raw content octets
+  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+  ok = ok & (tag == 0x02u) & int_ok(r, L, cs, ce - cs);
+  o.serial_off = cs;
+  o.serial_len = ce - cs;
+  q = ce;
   // signature AlgorithmIdentifier
-  if (!rd_hdr(r, q, tbs_end, h) || h.tag != 0x30u) return false;
-  q += h.hl + h.len;
-  // issuer Name → last string-typed CommonName
-  if (!rd_hdr(r, q, tbs_end, h) || h.tag != 0x30u) return false;
+  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
+  q = ce;
+  // issuer Name → last string-typed CommonName.  One flattened loop: each iteration decodes
+  // either a SET (RDN) header or one AttributeTypeAndValue.
+  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
   {
-    uint32_t s = q + h.hl;
-    const uint32_t s_end = s + h.len;
-    while (s < s_end) {
-      Hdr set;
-      if (!rd_hdr(r, s, s_end, set) || set.tag != 0x31u) return false;
-      uint32_t a = s + set.hl;
-      const uint32_t a_end = a + set.len;
-      while (a < a_end) {
-        Hdr atv, oid, val;
-        if (!rd_hdr(r, a, a_end, atv) || atv.tag != 0x30u) return false;
-        const uint32_t b = a + atv.hl, b_end = b + atv.len;
-        if (!rd_hdr(r, b, b_end, oid) || oid.tag != 0x06u || oid.len == 0) return false;
-        const uint32_t vpos = b + oid.hl + oid.len;
-        if (!rd_hdr(r, vpos, b_end, val)) return false;
-        if (oid.len == 3 && (r.ld4(b + oid.hl) & 0xffffffu) == 0x030455u && string_tag(val.tag)) {
-          o.cn_off = vpos + val.hl;
-          o.cn_len = val.len;
-        }
-        a = b_end;
+    const uint32_t s_end = ce;
+    uint32_t a = cs, a_end = cs;
+    while (ok & (a < s_end)) {
+      uint32_t t1, c1, e1;
+      if (a == a_end) {  // next RDN
+        rd_hdr(r, L, a, s_end, ok, t1, c1, e1);
+        ok = ok & (t1 == 0x31u);
+        a = c1;
+        a_end = e1;
+      } else {
+        uint32_t to, co, eo, tv, cv, ev;
+        rd_hdr(r, L, a, a_end, ok, t1, c1, e1);      // AttributeTypeAndValue
+        rd_hdr(r, L, c1, e1, ok, to, co, eo);        // type OID
+        const uint32_t oidw = r.ld4(co < L ? co : L);
+        rd_hdr(r, L, eo, e1, ok, tv, cv, ev);        // value
+        ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co);
+        const bool is_cn = (eo - co == 3u) & ((oidw & 0xffffffu) == 0x030455u) & string_tag(tv);
+        o.cn_off = is_cn ? cv : o.cn_off;
+        o.cn_len = is_cn ? ev - cv : o.cn_len;
+        a = e1;
       }
-      s = a_end;
     }
   }
-  q += h.hl + h.len;
+  q = ce;
   // validity
-  if (!rd_hdr(r, q, tbs_end, h) || h.tag != 0x30u) return false;
+  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
   {
-    uint32_t v = q + h.hl;
-    const uint32_t v_end = v + h.len;
-    Hdr tm;
-    if (!rd_hdr(r, v, v_end, tm) || !rd_time(r, v + tm.hl, tm, o.not_before)) return false;
-    v += tm.hl + tm.len;
-    if (!rd_hdr(r, v, v_end, tm) || !rd_time(r, v + tm.hl, tm, o.not_after)) return false;
+    uint32_t t1, c1, e1;
+    rd_hdr(r, L, cs, ce, ok, t1, c1, e1);
+    rd_time(r, L, c1, t1, e1 - c1, ok, o.not_before);
+    rd_hdr(r, L, e1, ce, ok, t1, c1, e1);
+    rd_time(r, L, c1, t1, e1 - c1, ok, o.not_after);
   }
-  q += h.hl + h.len;
+  q = ce;
   // subject
-  if (!rd_hdr(r, q, tbs_end, h) || h.tag != 0x30u) return false;
-  q += h.hl + h.len;
+  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
+  q = ce;
   // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo)
-  if (!rd_hdr(r, q, tbs_end, h) || h.tag != 0x30u) return false;
+  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
   o.spki_off = q;
-  o.spki_len = h.hl + h.len;
-  q += h.hl + h.len;
-  // [1] issuerUniqueID, [2] subjectUniqueID
-  uint32_t nt = q < tbs_end ? (r.ld4(q) & 0xffu) : 0u;
+  o.spki_len = ce - q;
+  q = ce;
+  // [1] issuerUniqueID, [2] subjectUniqueID: skipped
+  uint32_t nt = (ok & (q < tbs_end)) ? (r.ld4(q < L ? q : L) & 0xffu) : 0u;
   if (nt == 0x81u) {
-    if (!rd_hdr(r, q, tbs_end, h)) return false;
-    q += h.hl + h.len;
-    nt = q < tbs_end ? (r.ld4(q) & 0xffu) : 0u;
+    rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+    q = ce;
+    nt = (ok & (q < tbs_end)) ? (r.ld4(q < L ? q : L) & 0xffu) : 0u;
   }
   if (nt == 0x82u) {
-    if (!rd_hdr(r, q, tbs_end, h)) return false;
-    q += h.hl + h.len;
-    nt = q < tbs_end ? (r.ld4(q) & 0xffu) : 0u;
+    rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+    q = ce;
+    nt = (ok & (q < tbs_end)) ? (r.ld4(q < L ? q : L) & 0xffu) : 0u;
   }
   // [3] EXPLICIT Extensions
   if (nt == 0xa3u) {
-    if (!rd_hdr(r, q, tbs_end, h)) return false;
-    Hdr seq;
-    const uint32_t e0 = q + h.hl;
-    if (!rd_hdr(r, e0, e0 + h.len, seq) || seq.tag != 0x30u) return false;
-    uint32_t e = e0 + seq.hl;
-    const uint32_t e_end = e + seq.len;
-    while (e < e_end) {
-      Hdr ext, oid, val;
-      if (!rd_hdr(r, e, e_end, ext) || ext.tag != 0x30u) return false;
-      uint32_t x = e + ext.hl;
-      const uint32_t x_end = x + ext.len;
-      if (!rd_hdr(r, x, x_end, oid) || oid.tag != 0x06u || oid.len == 0) return false;
-      const bool is_bc = oid.len == 3 && (r.ld4(x + oid.hl) & 0xffffffu) == 0x131d55u;
-      x += oid.hl + oid.len;
-      if (!rd_hdr(r, x, x_end, val)) return false;
-      if (val.tag == 0x01u) {  // critical
-        if (val.len != 1) return false;
-        const uint32_t bv = r.ld4(x + val.hl) & 0xffu;
-        if (bv != 0x00u && bv != 0xffu) return false;
-        x += val.hl + val.len;
-        if (!rd_hdr(r, x, x_end, val)) return false;
+    uint32_t e, e_end;
+    rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+    rd_hdr(r, L, cs, ce, ok, tag, e, e_end);
+    ok = ok & (tag == 0x30u);
+    while (ok & (e < e_end)) {
+      uint32_t t1, x, x_end, to, co, eo, tv, cv, ev;
+      rd_hdr(r, L, e, e_end, ok, t1, x, x_end);   // Extension
+      rd_hdr(r, L, x, x_end, ok, to, co, eo);     // extnID
+      const uint32_t oidw = r.ld4(co < L ? co : L);
+      rd_hdr(r, L, eo, x_end, ok, tv, cv, ev);    // critical or extnValue
+      ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co);
+      if (tv == 0x01u) {  // critical BOOLEAN
+        const uint32_t bv = r.ld4(cv < L ? cv : L) & 0xffu;
+        ok = ok & (ev - cv == 1u) & ((bv == 0x00u) | (bv == 0xffu));
+        rd_hdr(r, L, ev, x_end, ok, tv, cv, ev);
       }
-      if (val.tag != 0x04u) return false;
-      if (is_bc) {
-        Hdr bc, f;
-        const uint32_t ob = x + val.hl, ob_end = ob + val.len;
-        if (!rd_hdr(r, ob, ob_end, bc) || bc.tag != 0x30u || bc.hl + bc.len != val.len) return false;
-        uint32_t c = ob + bc.hl;
-        const uint32_t c_end = c + bc.len;
+      ok = ok & (tv == 0x04u);
+      if (ok & (eo - co == 3u) & ((oidw & 0xffffffu) == 0x131d55u)) {
+        // basicConstraints ::= SEQUENCE { cA BOOLEAN DEFAULT FALSE, pathLen INTEGER OPTIONAL }
+        uint32_t tb, c, c_end, tf, cf, ef;
+        rd_hdr(r, L, cv, ev, ok, tb, c, c_end);
+        ok = ok & (tb == 0x30u) & (c_end == ev);
         bool ca = false;
-        if (c < c_end) {
-          if (!rd_hdr(r, c, c_end, f)) return false;
-          if (f.tag == 0x01u) {
-            if (f.len != 1) return false;
-            const uint32_t bv = r.ld4(c + f.hl) & 0xffu;
-            if (bv != 0x00u && bv != 0xffu) return false;
+        if (ok & (c < c_end)) {
+          rd_hdr(r, L, c, c_end, ok, tf, cf, ef);
+          if (tf == 0x01u) {
+            const uint32_t bv = r.ld4(cf < L ? cf : L) & 0xffu;
+            ok = ok & (ef - cf == 1u) & ((bv == 0x00u) | (bv == 0xffu));
             ca = bv == 0xffu;
-            c += f.hl + f.len;
-            if (c < c_end && !rd_hdr(r, c, c_end, f)) return false;
+            c = ef;
+            if (ok & (c < c_end)) rd_hdr(r, L, c, c_end, ok, tf, cf, ef);
           }
-          if (c < c_end && (f.tag != 0x02u || !int_ok(r, c + f.hl, f.len))) return false;
+          if (ok & (c < c_end)) ok = ok & (tf == 0x02u) & int_ok(r, L, cf, ef - cf);
         }
         o.bc_valid = true;
         o.is_ca = ca;
@@ -297,14 +279,17 @@ CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
     }
   }
   // signatureAlgorithm, signatureValue BIT STRING (Go asn1 parseBitString)
-  p = tbs_end;
-  if (!rd_hdr(r, p, L, h) || h.tag != 0x30u) return false;
-  p += h.hl + h.len;
-  if (!rd_hdr(r, p, L, h) || h.tag != 0x03u || h.len == 0) return false;
-  const uint32_t pad = r.ld4(p + h.hl) & 0xffu;
-  if (pad > 7 || (h.len == 1 && pad > 0)) return false;
-  if (pad > 0 && ((r.ld4(p + h.hl + h.len - 1) & 0xffu) & ((1u << pad) - 1u)) != 0) return false;
-  return true;
+  rd_hdr(r, L, tbs_end, L, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
+  rd_hdr(r, L, ce, L, ok, tag, cs, ce);
+  ok = ok & (tag == 0x03u) & (ce != cs);
+  {
+    const uint32_t pad = r.ld4(cs < L ? cs : L) & 0xffu;
+    const uint32_t lastp = ce - 1u;
+    const uint32_t last = r.ld4(lastp < L ? lastp : L) & 0xffu;
+    ok = ok & (pad <= 7u) & ((ce - cs != 1u) | (pad == 0u)) & ((last & ((1u << (pad & 7u)) - 1u)) == 0u);
+  }
+  return ok;
 }
 
 }  // namespace ctmr

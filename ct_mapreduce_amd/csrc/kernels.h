@@ -31,11 +31,12 @@ struct LdsReader {
 };
 
 struct GlobalReader {
-  const uint8_t* p;  // certificate start (any alignment)
+  const uint32_t* words;  // 4-byte aligned base of the buffer (kernel argument: global address space)
+  uint64_t base;          // byte offset of this certificate inside the buffer
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
-    const uintptr_t a = (uintptr_t)p + pos;
-    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
-    return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(a & 3u));
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(words[i + 1], words[i], (uint32_t)a & 3u);
   }
 };
 
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(64) k_issuer_ids(const uint8_t* der, const uin
   __syncthreads();
   const uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
-  GlobalReader r{der + offsets[i]};
+  GlobalReader r{(const uint32_t*)der, offsets[i]};
   const uint32_t L = (uint32_t)(offsets[i + 1] - offsets[i]);
   Walk w;
   const bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w);
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(64) k_map_tile(MapArgs a) {
     // oversize (or malformed offsets): walk straight from global memory
     if (lane < cnt) {
       if (my_hi < my_lo) my_hi = my_lo;
-      GlobalReader r{a.payload + my_lo};
+      GlobalReader r{(const uint32_t*)a.payload, my_lo};
       map_one(r, my_hi - my_lo, first + lane, a);
     }
     return;
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(256) k_map_direct(MapArgs a) {
   const uint64_t lo = a.offsets[i];
   uint64_t hi = a.offsets[i + 1];
   if (hi < lo) hi = lo;
-  GlobalReader r{a.payload + lo};
+  GlobalReader r{(const uint32_t*)a.payload, lo};
   map_one(r, hi - lo, i, a);
 }
 
@@ -349,17 +350,17 @@ struct InsertArgs {
 
 // Offset of the serialNumber content octets (certificate already accepted by the map).
 __device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, uint32_t L) {
-  Hdr h;
-  rd_hdr(r, 0, L, h);
-  uint32_t p = h.hl;
-  rd_hdr(r, p, L, h);
-  uint32_t q = p + h.hl;
+  bool ok = true;
+  uint32_t tag, cs, ce;
+  rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+  rd_hdr(r, L, cs, L, ok, tag, cs, ce);
+  uint32_t q = cs;
   if ((r.ld4(q) & 0xffu) == 0xa0u) {
-    rd_hdr(r, q, L, h);
-    q += h.hl + h.len;
+    rd_hdr(r, L, q, L, ok, tag, cs, ce);
+    q = ce;
   }
-  rd_hdr(r, q, L, h);
-  return q + h.hl;
+  rd_hdr(r, L, q, L, ok, tag, cs, ce);
+  return cs;
 }
 
 // KnownCertificates.WasUnknown → RemoteCache.SetInsert (knowncertificates.go:38-55) for every
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
       if (slen > 20) {
         // octets 20..slen-1 come from the certificate itself
         const uint64_t lo = a.offsets[i];
-        GlobalReader g{a.payload + lo};
+        GlobalReader g{(const uint32_t*)a.payload, lo};
         const uint32_t so = serial_content_off(g, (uint32_t)(a.offsets[i + 1] - lo));
         uint32_t x[5] = {0, 0, 0, 0, 0};
 #pragma unroll
@@ -456,47 +457,57 @@ struct ResolveArgs {
 
 // Decide WasUnknown for every PASS entry (lowest batch index of a new key wins — what the
 // reference does with numThreads = 1), bump counters, histogram statuses.
-__global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a) {
+// Persistent blocks: per-issuer counts are first accumulated in an LDS histogram (issuers
+// below RES_LDS_ISSUERS) and flushed with ONE global atomic per non-empty bin per block —
+// hundreds of thousands of device atomics on the few cache lines of the hot issuers serialise
+// at the memory side otherwise.  Issuers beyond the LDS bins use wave-aggregated global atomics.
+constexpr uint32_t RES_LDS_ISSUERS = 4096;
+
+__global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
   __shared__ uint32_t hist[CTMR_ST__COUNT + 4];
+  __shared__ uint32_t ih[RES_LDS_ISSUERS];
+  __shared__ uint32_t blk_cnt;
   if (threadIdx.x < CTMR_ST__COUNT + 4) hist[threadIdx.x] = 0;
+  for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024) ih[k] = 0;
   __syncthreads();
-  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  bool is_new = false, is_dup = false, is_host = false, is_full = false;
-  uint32_t status = CTMR_ST__COUNT, canon = 0;
-  unsigned long long pkey = 0;
-  if (i < a.n) {
-    const uint32_t head = *(const uint32_t*)(a.records + i);
-    status = head & 0xffu;
-    const uint32_t sid = a.slot_id[i];
-    if (sid == SID_HOST) {
-      is_host = true;
-    } else if (sid == SID_FULL) {
-      is_full = true;
-    } else if (sid != SID_NONE) {
-      const Slot* sl = a.table + sid;
-      const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
-      is_new = (uint32_t)w2 == a.epoch && (uint32_t)w0 == (uint32_t)i;
-      is_dup = !is_new;
-      canon = (uint32_t)(w1 >> 32) & 0xffffffu;
-      pkey = ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1;
-      if (is_new) ((uint8_t*)(a.records + i))[1] = (uint8_t)((head >> 8) | CTMR_FL_WAS_UNKNOWN);
+  for (uint64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    if (threadIdx.x == 0) blk_cnt = 0;
+    __syncthreads();
+    const uint64_t i = blk * 1024 + threadIdx.x;
+    bool is_new = false, is_dup = false, is_host = false, is_full = false;
+    uint32_t status = CTMR_ST__COUNT, canon = 0;
+    unsigned long long pkey = 0;
+    if (i < a.n) {
+      const uint32_t head = *(const uint32_t*)(a.records + i);
+      status = head & 0xffu;
+      const uint32_t sid = a.slot_id[i];
+      if (sid == SID_HOST) {
+        is_host = true;
+      } else if (sid == SID_FULL) {
+        is_full = true;
+      } else if (sid != SID_NONE) {
+        const Slot* sl = a.table + sid;
+        const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
+        is_new = (uint32_t)w2 == a.epoch && (uint32_t)w0 == (uint32_t)i;
+        is_dup = !is_new;
+        canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+        pkey = ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1;
+        if (is_new) ((uint8_t*)(a.records + i))[1] = (uint8_t)((head >> 8) | CTMR_FL_WAS_UNKNOWN);
+      }
     }
-  }
-  // per-issuer unique counts: Σ_expDate SCARD (storage-statistics.go:44-53)
-  wave_agg_add(is_new, canon, a.issuer_counts);
-  // per-(expDate, issuer) cardinality: SCARD(serials::expDate::issuer).  Keys are nearly all
-  // distinct inside a wave (≈2 000 expiry hours × issuers), so every lane probes on its own —
-  // a leader-serialised match-any loop costs one dependent global round trip per distinct key.
-  if (is_new && !pair_add(a.pairs, a.pmask, pkey, 1)) atomicAdd(&a.stats->pair_full, 1ull);
-  // block-level histogram → one atomic per bucket per block
-  const unsigned long long m_new = __ballot(is_new);
-  if ((threadIdx.x & 63) == 0) {
-    if (m_new) atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(m_new));
-  }
-  {
-    const unsigned long long m_dup = __ballot(is_dup), m_host = __ballot(is_host),
-                             m_full = __ballot(is_full);
+    // per-issuer unique counts: Σ_expDate SCARD (storage-statistics.go:44-53)
+    if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
+    wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, a.issuer_counts);
+    // per-(expDate, issuer) cardinality: SCARD(serials::expDate::issuer).  Keys are nearly all
+    // distinct inside a wave (≈2 000 expiry hours × issuers), so every lane probes on its own.
+    if (is_new && !pair_add(a.pairs, a.pmask, pkey, 1)) atomicAdd(&a.stats->pair_full, 1ull);
+    const unsigned long long m_new = __ballot(is_new), m_dup = __ballot(is_dup),
+                             m_host = __ballot(is_host), m_full = __ballot(is_full);
     if ((threadIdx.x & 63) == 0) {
+      if (m_new) {
+        atomicAdd(&blk_cnt, (uint32_t)__popcll(m_new));
+        atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(m_new));
+      }
       if (m_dup) atomicAdd(&hist[CTMR_ST__COUNT + 1], (uint32_t)__popcll(m_dup));
       if (m_host) atomicAdd(&hist[CTMR_ST__COUNT + 2], (uint32_t)__popcll(m_host));
       if (m_full) atomicAdd(&hist[CTMR_ST__COUNT + 3], (uint32_t)__popcll(m_full));
@@ -506,12 +517,15 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a) {
       const unsigned long long m = __ballot(status == st);
       if ((threadIdx.x & 63) == 0 && m) atomicAdd(&hist[st], (uint32_t)__popcll(m));
     }
+    __syncthreads();
+    if (threadIdx.x == 0) a.blk_new[blk] = blk_cnt;
   }
   __syncthreads();
+  for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024)
+    if (ih[k]) atomicAdd(&a.issuer_counts[k], (unsigned long long)ih[k]);
   if (threadIdx.x < CTMR_ST__COUNT) {
     if (hist[threadIdx.x]) atomicAdd(&a.stats->by_status[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
   } else if (threadIdx.x == CTMR_ST__COUNT) {
-    a.blk_new[blockIdx.x] = hist[CTMR_ST__COUNT];
     if (hist[CTMR_ST__COUNT]) atomicAdd(&a.stats->n_new, (unsigned long long)hist[CTMR_ST__COUNT]);
   } else if (threadIdx.x == CTMR_ST__COUNT + 1) {
     if (hist[CTMR_ST__COUNT + 1]) atomicAdd(&a.stats->n_dup, (unsigned long long)hist[CTMR_ST__COUNT + 1]);
