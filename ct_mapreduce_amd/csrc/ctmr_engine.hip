@@ -32,6 +32,7 @@ struct HostReader {  // host instantiation of the walk for the long-serial slow 
     memcpy(&v, p + pos, 4);
     return v;
   }
+  void touch(uint32_t, uint32_t) const {}
 };
 
 struct IssuerRec {
@@ -562,6 +563,10 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
   if (variant == 2) {
     hipLaunchKernelGGL(k_map_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ma);
+  } else if (variant == 3) {
+    hipLaunchKernelGGL(k_map_win<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
+  } else if (variant == 4) {
+    hipLaunchKernelGGL(k_map_win<8>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (8 * 16 + 16), e->stream, ma);
   } else {
     static bool attr_set = false;
     if (!attr_set) {

@@ -28,7 +28,39 @@ struct Walk {
   uint32_t cn_off, cn_len;
   uint32_t spki_off, spki_len;
   bool bc_valid, is_ca;
+  // captured while the bytes are at hand (a windowed reader may have moved on afterwards):
+  uint32_t serial_w[5];  // first min(20, serial_len) serial octets, little-endian words, zero padded
+  bool cn_match;         // some issuerCNFilter piece is a byte prefix of the CommonName
 };
+
+// strings.Split(*ctconfig.IssuerCNFilter, ",") — pieces NOT trimmed (ct-fetch.go:57-59)
+struct FilterView {
+  uint32_t n_pieces;
+  const uint32_t* piece_len;   // bytes
+  const uint32_t* piece_word;  // index of the piece's first word in words[]
+  const uint32_t* words;       // piece bytes, zero padded to 4-byte multiples
+};
+
+// certIsFilteredOut filter (3): strings.HasPrefix(Issuer.CommonName, piece) for some piece
+// (ct-fetch.go:57-69).  Pieces are wave-uniform, the CN bytes per lane.
+template <class R>
+CTMR_HD bool cn_prefix_match(const R& r, uint32_t L, uint32_t cn_off, uint32_t cn_len,
+                             const FilterView& f) {
+  for (uint32_t j = 0; j < f.n_pieces; j++) {
+    const uint32_t pl = f.piece_len[j];
+    if (pl > cn_len) continue;
+    const uint32_t* pw = f.words + f.piece_word[j];
+    bool eq = true;
+    for (uint32_t k = 0; (k < pl) & eq; k += 4) {
+      const uint32_t rem = pl - k;
+      const uint32_t mask = rem >= 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - rem)));
+      const uint32_t at = cn_off + k;
+      eq = ((r.ld4(at < L ? at : L) ^ pw[k >> 2]) & mask) == 0;
+    }
+    if (eq) return true;
+  }
+  return false;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Control-flow style: SIMD lanes walk different certificates, so the walk never returns early.
@@ -138,9 +170,14 @@ CTMR_HD bool string_tag(uint32_t t) {
   return (t == 0x0cu) | (t == 0x12u) | (t == 0x13u) | (t == 0x14u) | (t == 0x16u);
 }
 
+// `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
+// windowed reader that about `need` bytes from pos are read next; other readers ignore it.
 template <class R>
-CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
+CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr) {
   o.serial_off = o.serial_len = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) o.serial_w[k] = 0;
+  o.cn_match = true;
   o.not_before = o.not_after = 0;
   o.cn_off = o.cn_len = 0;
   o.spki_off = o.spki_len = 0;
@@ -148,6 +185,7 @@ CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
   bool ok = L <= 0x7fffffffu;
   if (!ok) return false;
   uint32_t tag, cs, ce;
+  r.touch(0, 256);
   // Certificate ::= SEQUENCE filling the buffer exactly
   rd_hdr(r, L, 0, L, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u) & (ce == L);
@@ -169,6 +207,18 @@ CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
   ok = ok & (tag == 0x02u) & int_ok(r, L, cs, ce - cs);
   o.serial_off = cs;
   o.serial_len = ce - cs;
+  {
+    const uint32_t take = ok ? (o.serial_len < 20u ? o.serial_len : 20u) : 0u;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const uint32_t pos = 4u * k;
+      if (pos < take) {
+        const uint32_t rem = take - pos;
+        const uint32_t v = r.ld4(cs + pos);
+        o.serial_w[k] = rem >= 4 ? v : (v & (0xffffffffu >> (8 * (4 - rem))));
+      }
+    }
+  }
   q = ce;
   // signature AlgorithmIdentifier
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
@@ -183,6 +233,7 @@ CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
     uint32_t a = cs, a_end = cs;
     while (ok & (a < s_end)) {
       uint32_t t1, c1, e1;
+      r.touch(a, 32);
       if (a == a_end) {  // next RDN
         rd_hdr(r, L, a, s_end, ok, t1, c1, e1);
         ok = ok & (t1 == 0x31u);
@@ -201,8 +252,10 @@ CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
         a = e1;
       }
     }
+    if (filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, *filter) : false;
   }
   q = ce;
+  r.touch(q, 48);
   // validity
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
@@ -239,11 +292,13 @@ CTMR_HD bool walk_cert(const R& r, uint32_t L, Walk& o) {
   // [3] EXPLICIT Extensions
   if (nt == 0xa3u) {
     uint32_t e, e_end;
+    r.touch(q, 256);
     rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
     rd_hdr(r, L, cs, ce, ok, tag, e, e_end);
     ok = ok & (tag == 0x30u);
     while (ok & (e < e_end)) {
       uint32_t t1, x, x_end, to, co, eo, tv, cv, ev;
+      r.touch(e, 48);
       rd_hdr(r, L, e, e_end, ok, t1, x, x_end);   // Extension
       rd_hdr(r, L, x, x_end, ok, to, co, eo);     // extnID
       const uint32_t oidw = r.ld4(co < L ? co : L);

@@ -28,6 +28,7 @@ struct LdsReader {
     const uint32_t i = a >> 2;
     return __builtin_amdgcn_alignbyte(lds[i + 1], lds[i], a & 3u);
   }
+  __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
 };
 
 struct GlobalReader {
@@ -37,6 +38,52 @@ struct GlobalReader {
     const uint64_t a = base + pos;
     const uint64_t i = a >> 2;
     return __builtin_amdgcn_alignbyte(words[i + 1], words[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
+};
+
+// Per-lane LDS window ("software cache") over a certificate that stays in global memory.
+// Each lane owns WCH 16-byte chunks of LDS (lane stride WCH*16+16 bytes: 16-B aligned for
+// ds_write_b128, and ≤4-way bank conflicts on the dword reads).  touch(pos, need) refills the
+// window with WCH independent global_load_dwordx4 (one burst, one memory latency) when the next
+// `need` bytes are not resident; ld4 hits LDS inside the window and falls back to a plain global
+// load outside it — so correctness never depends on where the window is.  The walk touches the
+// front of the certificate and the extension block; SPKI body, SAN body and signature are
+// skipped by length and therefore never fetched from HBM.
+template <int WCH>
+struct WinReader {
+  const uint32_t* g32;  // payload, dword view (global)
+  uint64_t base;        // certificate start (byte offset into payload)
+  uint64_t limit;       // readable bytes of payload (offsets[n] + CTMR_PAYLOAD_PAD)
+  uint32_t* win;        // this lane's window words in LDS
+  int32_t grel;         // window start relative to the certificate start; (base+grel) % 16 == 0
+  static constexpr uint32_t WBYTES = WCH * 16;
+
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel <= WBYTES - 8u) {
+      const uint32_t i = rel >> 2;
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
+    }
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ void refill(uint32_t pos) {
+    const uint64_t g = (base + pos) & ~15ull;
+    grel = (int32_t)(int64_t)(g - base);
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    uint4 v[WCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++)
+      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+  }
+  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
+    if (need > WBYTES) need = WBYTES;
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel > WBYTES - need) refill(pos);
   }
 };
 
@@ -142,34 +189,15 @@ struct MapArgs {
   uint32_t lds_bytes;  // dynamic LDS size of the launch
 };
 
-// certIsFilteredOut filter (3): no strings.Split(filter, ",") piece is a byte prefix of
-// Issuer.CommonName (ct-fetch.go:57-69).  Pieces are wave-uniform, the CN bytes per lane.
-template <class R>
-__device__ __forceinline__ bool cn_prefix_match(const R& r, const Walk& w, const FilterDev* f) {
-  const uint32_t np = f->n_pieces;
-  for (uint32_t j = 0; j < np; j++) {
-    const uint32_t pl = f->piece_len[j];
-    if (pl > w.cn_len) continue;
-    const uint32_t* pw = f->words + f->piece_word[j];
-    bool eq = true;
-    for (uint32_t k = 0; k < pl && eq; k += 4) {
-      const uint32_t rem = pl - k;
-      const uint32_t mask = rem >= 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - rem)));
-      eq = ((r.ld4(w.cn_off + k) ^ pw[k >> 2]) & mask) == 0;
-    }
-    if (eq) return true;
-  }
-  return false;
-}
-
 // Everything after the bytes are addressable: walk, filters, record.
 template <class R>
-__device__ __forceinline__ void map_one(const R& r, uint64_t len64, uint64_t idx, const MapArgs& a) {
+__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a) {
   Walk w;
   const uint32_t L = (uint32_t)len64;
-  const bool ok = len64 <= 0x7fffffffull && walk_cert(r, L, w);
-  const uint32_t iss = a.issuer_idx[idx];
   const FilterDev* f = a.filt;
+  const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
+  const bool ok = len64 <= 0x7fffffffull && walk_cert(r, L, w, f->active ? &fv : nullptr);
+  const uint32_t iss = a.issuer_idx[idx];
   uint32_t status;
   if (!ok) {
     status = CTMR_ST_PARSE_ERROR;
@@ -177,7 +205,7 @@ __device__ __forceinline__ void map_one(const R& r, uint64_t len64, uint64_t idx
     status = CTMR_ST_FILTERED_CA;
   } else if (w.not_after < f->now && !f->log_expired) {
     status = CTMR_ST_FILTERED_EXPIRED;
-  } else if (f->active && !cn_prefix_match(r, w, f)) {
+  } else if (!w.cn_match) {
     status = CTMR_ST_FILTERED_CN;
   } else if (iss == CTMR_NO_ISSUER || iss >= a.n_issuers) {
     status = CTMR_ST_NO_ISSUER;
@@ -196,16 +224,8 @@ __device__ __forceinline__ void map_one(const R& r, uint64_t len64, uint64_t idx
     exp_hour = (int32_t)q;
     slen = w.serial_len > 0xffffu ? 0xffffu : w.serial_len;
     if (w.serial_len > 20) flags |= CTMR_FL_LONG_SERIAL;
-    const uint32_t take = w.serial_len < 20 ? w.serial_len : 20;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const uint32_t pos = 4u * k;
-      if (pos < take) {
-        const uint32_t rem = take - pos;
-        const uint32_t v = r.ld4(w.serial_off + pos);
-        s[k] = rem >= 4 ? v : (v & (0xffffffffu >> (8 * (4 - rem))));
-      }
-    }
+    for (int k = 0; k < 5; k++) s[k] = w.serial_w[k];
   }
   uint4* out = (uint4*)(a.records + idx);
   out[0] = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
@@ -277,6 +297,23 @@ __global__ void __launch_bounds__(256) k_map_direct(MapArgs a) {
   uint64_t hi = a.offsets[i + 1];
   if (hi < lo) hi = lo;
   GlobalReader r{(const uint32_t*)a.payload, lo};
+  map_one(r, hi - lo, i, a);
+}
+
+// Window map: one certificate per lane, all 64 lanes busy, DER stays in global memory and is
+// pulled through a per-lane LDS window (WinReader).  One wave per workgroup, so LDS (not the
+// 256-thread granule) sets the occupancy: 64 × (WCH·16+16) bytes per wave.
+template <int WCH>
+__global__ void __launch_bounds__(64) k_map_win(MapArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  const uint64_t lo = a.offsets[i];
+  uint64_t hi = a.offsets[i + 1];
+  if (hi < lo) hi = lo;
+  constexpr uint32_t STRIDE = WCH * 16 + 16;
+  WinReader<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+                   (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
+  r.refill(0);
   map_one(r, hi - lo, i, a);
 }
 

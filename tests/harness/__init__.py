@@ -20,7 +20,8 @@ class HarnessOut(C.Structure):
     _fields_ = [("ok", C.c_int32), ("serial_off", C.c_uint32), ("serial_len", C.c_uint32),
                 ("not_before", C.c_int64), ("not_after", C.c_int64), ("cn_off", C.c_uint32),
                 ("cn_len", C.c_uint32), ("bc_valid", C.c_int32), ("is_ca", C.c_int32),
-                ("spki_off", C.c_uint32), ("spki_len", C.c_uint32)]
+                ("spki_off", C.c_uint32), ("spki_len", C.c_uint32), ("serial_w", C.c_uint32 * 5),
+                ("cn_match", C.c_int32)]
 
 
 class OsslOut(C.Structure):
@@ -34,15 +35,18 @@ _walk = None
 _ossl = None
 
 
-def product_walk(der: bytes, fill=0xA5) -> HarnessOut:
+def product_walk(der: bytes, fill=0xA5, cn_filter=None) -> HarnessOut:
+    """cn_filter=None: no issuerCNFilter (cn_match is True); bytes: the raw filter string."""
     global _walk
     if _walk is None:
         p = _build("walk_harness.cpp", "libwalk_harness.so",
                    ["g++", "-O2", "-std=c++17", "-shared", "-fPIC"])
         _walk = C.CDLL(p)
-        _walk.harness_walk.argtypes = [C.c_char_p, C.c_uint32, C.c_uint8, C.POINTER(HarnessOut)]
+        _walk.harness_walk_f.argtypes = [C.c_char_p, C.c_uint32, C.c_uint8, C.c_char_p, C.c_uint32,
+                                         C.c_int, C.POINTER(HarnessOut)]
     o = HarnessOut()
-    _walk.harness_walk(der, len(der), fill, C.byref(o))
+    f = cn_filter if cn_filter is not None else b""
+    _walk.harness_walk_f(der, len(der), fill, f, len(f), int(cn_filter is not None), C.byref(o))
     return o
 
 

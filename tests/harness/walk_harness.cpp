@@ -13,6 +13,7 @@ struct PaddedReader {
     memcpy(&v, p + pos, 4);
     return v;
   }
+  void touch(uint32_t, uint32_t) const {}
 };
 
 struct HarnessOut {
@@ -22,15 +23,39 @@ struct HarnessOut {
   uint32_t cn_off, cn_len;
   int32_t bc_valid, is_ca;
   uint32_t spki_off, spki_len;
+  uint32_t serial_w[5];
+  int32_t cn_match;
 };
 
+extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, const char* filter,
+                               uint32_t flen, int use_filter, HarnessOut* out);
+
 extern "C" void harness_walk(const uint8_t* der, uint32_t len, uint8_t fill, HarnessOut* out) {
+  harness_walk_f(der, len, fill, nullptr, 0, 0, out);
+}
+
+extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, const char* filter,
+                               uint32_t flen, int use_filter, HarnessOut* out) {
+  // strings.Split(filter, ",") laid out exactly as ctmr_set_filter does
+  uint32_t piece_len[64], piece_word[64], words[1024] = {0}, np = 0, nw = 0;
+  for (uint32_t s = 0;;) {
+    uint32_t t = s;
+    while (t < flen && filter[t] != ',') t++;
+    piece_len[np] = t - s;
+    piece_word[np] = nw;
+    memcpy((uint8_t*)(words + nw), filter + s, t - s);
+    nw += (t - s + 3) / 4;
+    np++;
+    if (t >= flen) break;
+    s = t + 1;
+  }
+  ctmr::FilterView fv{np, piece_len, piece_word, words};
   // bytes past the certificate are garbage the walk must never depend on
   std::vector<uint8_t> buf((size_t)len + 64, fill);
   memcpy(buf.data(), der, len);
   PaddedReader r{buf.data()};
   ctmr::Walk w;
-  const bool ok = ctmr::walk_cert(r, len, w);
+  const bool ok = ctmr::walk_cert(r, len, w, use_filter ? &fv : nullptr);
   memset(out, 0, sizeof *out);
   out->ok = ok;
   if (!ok) return;
@@ -39,4 +64,6 @@ extern "C" void harness_walk(const uint8_t* der, uint32_t len, uint8_t fill, Har
   out->cn_off = w.cn_off; out->cn_len = w.cn_len;
   out->bc_valid = w.bc_valid; out->is_ca = w.is_ca;
   out->spki_off = w.spki_off; out->spki_len = w.spki_len;
+  memcpy(out->serial_w, w.serial_w, 20);
+  out->cn_match = w.cn_match;
 }

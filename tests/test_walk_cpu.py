@@ -22,6 +22,16 @@ def same(der):
     if o.ok:
         for f in FIELDS:
             assert getattr(o, f) == getattr(p, f) == getattr(p2, f), f
+        s20 = der[o.serial_off:o.serial_off + min(o.serial_len, 20)].ljust(20, b"\0")
+        assert b"".join(int(w).to_bytes(4, "little") for w in p.serial_w) == s20
+        assert p.cn_match == 1
+        cn = der[o.cn_off:o.cn_off + o.cn_len]
+        for filt in (b"Synth Issuer 0,Synth Issuer 1", b"c", b"ca", b"cab,x", b"x, ca", b"", b",", cn, cn + b"x", cn[:5] + b",zz"):
+            pf = harness.product_walk(der, 0x11, filt)
+            want = orc.is_filtered_out(der, o, filt, True, 0) != orc.ST_FILTERED_CN or filt == b""
+            if o.bc_valid and o.is_ca:
+                want = any(cn.startswith(piece) for piece in filt.split(b","))
+            assert bool(pf.cn_match) == want, (filt, cn)
     return bool(o.ok)
 
 
