@@ -161,9 +161,9 @@ def main():
                                "issuerCN prefix filter + known-certificate dedup + per-issuer unique counts "
                                "(BASELINE configs[2]/[3] shape)",
                    "entries_per_gpu": E, "mean_der_bytes": stats.payload_bytes / E,
-                   "parallelism": f"log-index shards x{world}", "map_variant": args.variant or 1,
-                   "certs_per_tile": args.certs_per_tile or 32, "gen_seconds": round(t_gen, 2)},
-        "roofline": {"bound": "hbm", "kernel": "k_map_tile" if (args.variant or 1) == 1 else "k_map_direct",
+                   "parallelism": f"log-index shards x{world}", "map_variant": args.variant or 3,
+                   "gen_seconds": round(t_gen, 2)},
+        "roofline": {"bound": "hbm", "kernel": {1: "k_map_tile", 2: "k_map_direct", 3: "k_map_win<16>", 4: "k_map_win<8>"}[args.variant or 3],
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic_bytes,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms},

@@ -554,7 +554,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
   ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
   ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
-  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 1;
+  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 3;
   uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
   if (C > 64) C = 64;
   uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;

@@ -81,7 +81,8 @@ typedef struct {
   uint32_t max_issuers;       /* 0 = 65536 */
   uint32_t certs_per_tile;    /* map-kernel tuning; 0 = default */
   uint32_t lds_tile_bytes;    /* map-kernel tuning; 0 = default */
-  uint32_t map_variant;       /* 0 = default; see DESIGN.md §5 (1 = LDS tile, 2 = direct global) */
+  uint32_t map_variant;       /* 0 = default (3); DESIGN.md §5: 1 = whole-cert LDS tile, 2 = direct global,
+                                 3 = per-lane 256-B LDS window, 4 = 128-B window */
   uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
   uint32_t reserved;
 } ctmr_config;
