@@ -367,6 +367,7 @@ int ctmr_create(const ctmr_config* cfg, ctmr_engine** out) {
   e->npairs = pow2_at_least(cfg->pair_slots ? cfg->pair_slots : (1ull << 22));
   e->max_issuers = cfg->max_issuers ? cfg->max_issuers : 65536;
   if (e->max_issuers > (1u << 24) - 2) { e->err = "max_issuers > 2^24-2"; return bail(CTMR_E_INVAL); }
+  if (e->nslots > (1ull << 31)) { e->err = "table_slots > 2^31"; return bail(CTMR_E_INVAL); }
   CK(hipMalloc(&e->table, e->nslots * sizeof(Slot)));
   CK(hipMalloc(&e->pairs, e->npairs * sizeof(PairSlot)));
   CK(hipMalloc(&e->issuer_counts, (size_t)e->max_issuers * 8));
@@ -582,6 +583,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.canon = e->d_canon;
   ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.n = n; ia.epoch = e->epoch;
   hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
+  hipLaunchKernelGGL(k_insert2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
   // ---- resolve
   ResolveArgs ra;

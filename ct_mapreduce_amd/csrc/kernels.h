@@ -400,8 +400,45 @@ __device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, ui
   return cs;
 }
 
+constexpr uint32_t SID_DEFER = 0x80000000u;  // slot_id bit: candidate slot, full compare in pass 2
+
+__device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, const uint4& r0,
+                                           const uint4& r1, unsigned long long s[5]) {
+  const uint32_t slen = r0.x >> 16;
+  s[0] = (unsigned long long)r0.w | ((unsigned long long)r1.x << 32);
+  s[1] = (unsigned long long)r1.y | ((unsigned long long)r1.z << 32);
+  s[2] = (unsigned long long)r1.w;
+  s[3] = 0;
+  s[4] = 0;
+  if (slen > 20) {
+    // octets 20..slen-1 come from the certificate itself
+    const uint64_t lo = a.offsets[i];
+    GlobalReader g{(const uint32_t*)a.payload, lo};
+    const uint32_t so = serial_content_off(g, (uint32_t)(a.offsets[i + 1] - lo));
+    uint32_t x[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const uint32_t pos = 20u + 4u * k;
+      if (pos < slen) {
+        const uint32_t rem = slen - pos;
+        const uint32_t v = g.ld4(so + pos);
+        x[k] = rem >= 4 ? v : (v & (0xffffffffu >> (8 * (4 - rem))));
+      }
+    }
+    s[2] |= (unsigned long long)x[0] << 32;
+    s[3] = (unsigned long long)x[1] | ((unsigned long long)x[2] << 32);
+    s[4] = (unsigned long long)x[3] | ((unsigned long long)x[4] << 32);
+  }
+}
+
 // KnownCertificates.WasUnknown → RemoteCache.SetInsert (knowncertificates.go:38-55) for every
-// PASS entry, against the in-HBM table.
+// PASS entry, against the in-HBM table.  PASS 1 (this kernel) never reads anything another lane
+// of the same launch wrote except the CAS word itself:
+//   empty slot      → one atomicCAS claims it; the key is written with plain wide stores
+//   same tag, slot of an OLDER batch (epoch in [1, cur)) → fully visible: compare now
+//   same tag, slot of THIS batch (epoch cur or not yet visible) → remember the slot, decide in
+//                     pass 2 after the kernel boundary has made every pass-1 store visible
+// so no write-through stores, drains or polling are needed on the common path.
 __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
@@ -415,35 +452,71 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
     } else {
       const uint4 r1 = rp[1];
       unsigned long long s[5];
-      s[0] = (unsigned long long)r0.w | ((unsigned long long)r1.x << 32);
-      s[1] = (unsigned long long)r1.y | ((unsigned long long)r1.z << 32);
-      s[2] = (unsigned long long)r1.w;
-      s[3] = 0;
-      s[4] = 0;
-      if (slen > 20) {
-        // octets 20..slen-1 come from the certificate itself
-        const uint64_t lo = a.offsets[i];
-        GlobalReader g{(const uint32_t*)a.payload, lo};
-        const uint32_t so = serial_content_off(g, (uint32_t)(a.offsets[i + 1] - lo));
-        uint32_t x[5] = {0, 0, 0, 0, 0};
+      record_key(a, i, r0, r1, s);
+      const unsigned long long meta = key_meta((int32_t)r0.y, a.canon[r0.z], slen);
+      const unsigned long long h = key_hash(meta, s);
+      const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+      uint64_t j = h & a.mask;
+      sid = SID_FULL;
+      for (uint64_t probes = 0; probes <= a.mask; probes++) {
+        Slot* sl = a.table + j;
+        const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | (uint32_t)i);
+        if (old == 0ull) {  // claimed: write the key (w[0] stays atomic-only)
+          sl->w[1] = meta;
+          uint4* q = (uint4*)&sl->w[2];
+          q[0] = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+          q[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+          q[2] = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+          sid = (uint32_t)j;
+          break;
+        }
+        if ((old & 0xffffffff00000000ull) == tagw) {
+          const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
+          if (ep != 0u && ep != a.epoch) {  // older batch: complete and visible
+            bool eq = sl->w[1] == meta;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-          const uint32_t pos = 20u + 4u * k;
-          if (pos < slen) {
-            const uint32_t rem = slen - pos;
-            const uint32_t v = g.ld4(so + pos);
-            x[k] = rem >= 4 ? v : (v & (0xffffffffu >> (8 * (4 - rem))));
+            for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+            if (eq) {
+              sid = (uint32_t)j;
+              break;
+            }
+          } else {
+            sid = (uint32_t)j | SID_DEFER;
+            break;
           }
         }
-        s[2] |= (unsigned long long)x[0] << 32;
-        s[3] = (unsigned long long)x[1] | ((unsigned long long)x[2] << 32);
-        s[4] = (unsigned long long)x[3] | ((unsigned long long)x[4] << 32);
+        j = (j + 1) & a.mask;
       }
-      const uint32_t canon = a.canon[r0.z];
-      const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
-      bool created;
-      sid = table_upsert(a.table, a.mask, meta, s, (uint32_t)i, a.epoch, true, &created);
     }
+  }
+  a.slot_id[i] = sid;
+}
+
+// PASS 2: entries whose candidate slot was created by the same batch.  Everything pass 1 wrote
+// is visible now.  Equal key → merge the batch index (lowest log index wins); a 32-bit tag
+// collision between different keys (≈2^-32 per probe) falls back to the fully synchronised
+// upsert, which is also safe against other pass-2 lanes inserting the same key concurrently.
+__global__ void __launch_bounds__(256) k_insert2(InsertArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t sid = a.slot_id[i];
+  if (sid >= SID_FULL || !(sid & SID_DEFER)) return;
+  sid &= ~SID_DEFER;
+  const uint4* rp = (const uint4*)(a.records + i);
+  const uint4 r0 = rp[0], r1 = rp[1];
+  unsigned long long s[5];
+  record_key(a, i, r0, r1, s);
+  const unsigned long long meta = key_meta((int32_t)r0.y, a.canon[r0.z], r0.x >> 16);
+  Slot* sl = a.table + sid;
+  bool eq = sl->w[1] == meta;
+#pragma unroll
+  for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+  if (eq) {
+    const unsigned long long tagw = (unsigned long long)key_tag(key_hash(meta, s)) << 32;
+    atomicMin(&sl->w[0], tagw | (uint32_t)i);
+  } else {
+    bool created;
+    sid = table_upsert(a.table, a.mask, meta, s, (uint32_t)i, a.epoch, true, &created);
   }
   a.slot_id[i] = sid;
 }
