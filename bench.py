@@ -57,8 +57,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--entries", type=int, default=int(os.environ.get("CTMR_BENCH_ENTRIES", 10_000_000)),
-                    help="entries per GPU (weak scaling)")
+    ap.add_argument("--entries", type=int, default=int(os.environ.get("CTMR_BENCH_ENTRIES", 100_000_000)),
+                    help="entries per GPU (weak scaling); default = BASELINE's 100M-entry batch "
+                         "(≈152 GB of DER resident in HBM); halved automatically if it does not fit")
     ap.add_argument("--issuers", type=int, default=256)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--certs-per-tile", type=int, default=0)
@@ -86,32 +87,45 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    E = args.entries
     filt = b"Synth Issuer 0,Synth Issuer 1"      # BASELINE config 3: passes issuers 000-199
     cfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=0,
                        ca_permille=10, expired_permille=10)
     now = synth.BASE_TIME
     issuers = synth.issuers(cfg)
 
-    eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
-                      map_variant=args.variant, certs_per_tile=args.certs_per_tile,
-                      lds_tile_bytes=args.lds_bytes, profile=True)
-    eng.add_issuers(issuers)
-    eng.set_filter(filt, False, now)
+    def setup(E):
+        eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
+                          map_variant=args.variant, certs_per_tile=args.certs_per_tile,
+                          lds_tile_bytes=args.lds_bytes, profile=True)
+        eng.add_issuers(issuers)
+        eng.set_filter(filt, False, now)
+        # ---- synthetic shard [rank·E, (rank+1)·E), generated directly in HBM
+        first = rank * E
+        d_off = torch.empty(E + 1, dtype=torch.int64, device=dev)
+        total = eng.synth_device(cfg, first, E, d_off.data_ptr(), 0, 0, 0, 0)
+        d_pay = torch.empty(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+        d_iss = torch.empty(E, dtype=torch.int32, device=dev)
+        d_et = torch.empty(E, dtype=torch.uint8, device=dev)
+        eng.synth_device(cfg, first, E, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(),
+                         d_iss.data_ptr(), d_et.data_ptr())
+        d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
+        d_new = torch.empty(E, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        return eng, d_off, d_pay, d_iss, d_et, d_rec, d_new
 
-    # ---- synthetic shard, generated directly in HBM
-    first = rank * E
+    E = args.entries
     t_gen = time.perf_counter()
-    d_off = torch.empty(E + 1, dtype=torch.int64, device=dev)
-    total = eng.synth_device(cfg, first, E, d_off.data_ptr(), 0, 0, 0, 0)
-    d_pay = torch.empty(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
-    d_iss = torch.empty(E, dtype=torch.int32, device=dev)
-    d_et = torch.empty(E, dtype=torch.uint8, device=dev)
-    eng.synth_device(cfg, first, E, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(),
-                     d_iss.data_ptr(), d_et.data_ptr())
-    d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
-    d_new = torch.empty(E, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
+    while True:
+        try:
+            eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(E)
+            break
+        except (ctmr.CtmrError, RuntimeError) as ex:   # does not fit in this GPU's HBM: halve
+            if E <= 1_000_000:
+                raise
+            sys.stderr.write(f"bench: {E} entries do not fit ({ex}); trying {E // 2}\n")
+            eng = d_off = d_pay = d_iss = d_et = d_rec = d_new = None
+            torch.cuda.empty_cache()
+            E //= 2
     t_gen = time.perf_counter() - t_gen
     counts_dev = torch.zeros(len(issuers), dtype=torch.int64, device=dev)
 
