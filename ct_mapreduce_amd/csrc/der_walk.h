@@ -9,8 +9,9 @@
 // x509.ParseCertificate at cmd/ct-fetch/ct-fetch.go:202,221 and storage.NewSerial
 // (storage/types.go:165-178).  The accept/reject profile is DESIGN.md §3.
 //
-// CTMR_HD lets tests/harness compile this exact code for the host to fuzz it against the
-// oracle without a GPU; the shipped library only ever instantiates it in device code.
+// CTMR_HD lets tests/harness compile this exact code for the host, to fuzz it without a GPU; the
+// shipped library instantiates it in device code (plus one host instantiation for the exact
+// slow path of serials longer than CTMR_MAX_SERIAL, ctmr_engine.hip).
 #pragma once
 #include <stdint.h>
 
