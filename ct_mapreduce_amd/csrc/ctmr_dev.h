@@ -28,6 +28,7 @@ constexpr unsigned long long SLOT_TOMB = 0xffffffff00000000ull;  // removed memb
 constexpr uint32_t SID_NONE = 0xffffffffu;       // entry did not reach the set
 constexpr uint32_t SID_HOST = 0xfffffffeu;       // serial longer than CTMR_MAX_SERIAL
 constexpr uint32_t SID_FULL = 0xfffffffdu;       // table full
+constexpr uint32_t SID_DUP_OLD = 0xfffffffcu;    // key known since an earlier batch
 
 __host__ __device__ inline unsigned long long key_meta(int32_t exp_hour, uint32_t canon,
                                                         uint32_t serial_len) {

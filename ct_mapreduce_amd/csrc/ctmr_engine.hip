@@ -140,6 +140,7 @@ struct ctmr_engine {
   uint64_t npairs = 0;
   unsigned long long* issuer_counts = nullptr;
   uint32_t epoch = 0;
+  bool pairs_dirty = false;  // pair table must be rebuilt before the next cardinality / keys query
   // issuer table
   uint32_t max_issuers = 0;
   uint8_t* d_issuer_valid = nullptr;
@@ -237,6 +238,7 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
   pack_serial(m, n, s);
   const unsigned long long meta = key_meta(exp_hour, canon, (uint32_t)n);
   if (op == 0) e->epoch++;
+  if (op != 1) e->pairs_dirty = true;
   hipLaunchKernelGGL(k_set_op, dim3(1), dim3(64), 0, e->stream, e->table, e->nslots - 1, meta, s[0],
                      s[1], s[2], s[3], s[4], op, e->epoch, e->issuer_counts, e->pairs,
                      e->npairs - 1, e->d_result);
@@ -248,8 +250,23 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
   return CTMR_OK;
 }
 
+int ensure_pairs(ctmr_engine* e) {
+  if (!e->pairs_dirty) return CTMR_OK;
+  HIPCHK(e, hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+  hipLaunchKernelGGL(k_build_pairs, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream,
+                     e->table, e->nslots, e->pairs, e->npairs - 1, e->d_count);
+  unsigned long long full;
+  HIPCHK(e, hipMemcpyAsync(&full, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (full) return fail(e, CTMR_E_FULL, "(expDate,issuer) table full (%llu slots)", (unsigned long long)e->npairs);
+  e->pairs_dirty = false;
+  return CTMR_OK;
+}
+
 // device pairs → list of (key, count)
 int dump_pairs(ctmr_engine* e, std::vector<std::pair<unsigned long long, unsigned long long>>* out) {
+  { int r0 = ensure_pairs(e); if (r0) return r0; }
   HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
   size_t cap = 1 << 16;
   for (;;) {
@@ -276,6 +293,7 @@ int dump_pairs(ctmr_engine* e, std::vector<std::pair<unsigned long long, unsigne
 int pair_count(ctmr_engine* e, int32_t exp_hour, uint32_t canon, uint64_t* n) {
   // probe the pair table on the host side through a full dump would be wasteful: read slots
   const unsigned long long key = ((unsigned long long)(canon + 1) << 32) | (uint32_t)exp_hour;
+  { int r0 = ensure_pairs(e); if (r0) return r0; }
   uint64_t j = mixk(key) & (e->npairs - 1);
   *n = 0;
   for (uint64_t probes = 0; probes < e->npairs; probes++) {
@@ -548,6 +566,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   uint64_t* d_blk_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
   const bool prof = e->cfg.profile != 0;
   e->epoch++;
+  e->pairs_dirty = true;
   HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
 
   // ---- map
@@ -568,6 +587,10 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
     hipLaunchKernelGGL(k_map_win<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
   } else if (variant == 4) {
     hipLaunchKernelGGL(k_map_win<8>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (8 * 16 + 16), e->stream, ma);
+  } else if (variant == 5) {
+    hipLaunchKernelGGL(k_map_win<12>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (12 * 16 + 16), e->stream, ma);
+  } else if (variant == 6) {
+    hipLaunchKernelGGL(k_map_win<14>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (14 * 16 + 16), e->stream, ma);
   } else {
     static bool attr_set = false;
     if (!attr_set) {
@@ -598,7 +621,6 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   HIPCHK(e, hipGetLastError());
   if (hs.n_full) return fail(e, CTMR_E_FULL, "known-certificate table full (%llu slots): %llu entries dropped",
                              (unsigned long long)e->nslots, hs.n_full);
-  if (hs.pair_full) return fail(e, CTMR_E_FULL, "(expDate,issuer) table full (%llu slots)", (unsigned long long)e->npairs);
 
   // ---- serials longer than CTMR_MAX_SERIAL: exact host-side set, in log order
   uint64_t host_new = 0;
@@ -855,6 +877,7 @@ int ctmr_expire_sweep(ctmr_engine* e, int64_t now, uint64_t* removed) {
     if (canon < e->issuers.size() && e->expiry.count(make_key(e, (int32_t)(uint32_t)p.first, canon))) any_override = true;
   }
   const unsigned blocks = (unsigned)((e->nslots + 255) / 256);
+  e->pairs_dirty = true;
   if (!any_override) {
     hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(256), 0, e->stream, e->table, e->nslots, 1, (long long)now, 0u, 0u,
                        e->issuer_counts, e->pairs, e->npairs - 1, e->d_count);
@@ -942,6 +965,7 @@ int ctmr_reset_known(ctmr_engine* e) {
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, hipMemsetAsync(e->table, 0, e->nslots * sizeof(Slot), e->stream));
   HIPCHK(e, hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
+  e->pairs_dirty = false;
   HIPCHK(e, hipMemsetAsync(e->issuer_counts, 0, (size_t)e->max_issuers * 8, e->stream));
   for (auto it = e->hstore.begin(); it != e->hstore.end();)
     it = it->first.compare(0, 9, "serials::") == 0 ? e->hstore.erase(it) : std::next(it);

@@ -81,7 +81,7 @@ struct WinReader {
     for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
   }
   __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
-    if (need > WBYTES) need = WBYTES;
+    if (need > WBYTES - 16u) need = WBYTES - 16u;  // the window start is 16-B aligned in HBM
     const uint32_t rel = pos - (uint32_t)grel;
     if (rel > WBYTES - need) refill(pos);
   }
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
 #pragma unroll
             for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
             if (eq) {
-              sid = (uint32_t)j;
+              sid = SID_DUP_OLD;
               break;
             }
           } else {
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
   uint32_t sid = a.slot_id[i];
-  if (sid >= SID_FULL || !(sid & SID_DEFER)) return;
+  if (sid >= SID_DUP_OLD || !(sid & SID_DEFER)) return;
   sid &= ~SID_DEFER;
   const uint4* rp = (const uint4*)(a.records + i);
   const uint4 r0 = rp[0], r1 = rp[1];
@@ -586,7 +586,6 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
     const uint64_t i = blk * 1024 + threadIdx.x;
     bool is_new = false, is_dup = false, is_host = false, is_full = false;
     uint32_t status = CTMR_ST__COUNT, canon = 0;
-    unsigned long long pkey = 0;
     if (i < a.n) {
       const uint32_t head = *(const uint32_t*)(a.records + i);
       status = head & 0xffu;
@@ -595,22 +594,22 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
         is_host = true;
       } else if (sid == SID_FULL) {
         is_full = true;
+      } else if (sid == SID_DUP_OLD) {
+        is_dup = true;  // known since an earlier batch: nothing to look up
       } else if (sid != SID_NONE) {
         const Slot* sl = a.table + sid;
         const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
         is_new = (uint32_t)w2 == a.epoch && (uint32_t)w0 == (uint32_t)i;
         is_dup = !is_new;
         canon = (uint32_t)(w1 >> 32) & 0xffffffu;
-        pkey = ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1;
         if (is_new) ((uint8_t*)(a.records + i))[1] = (uint8_t)((head >> 8) | CTMR_FL_WAS_UNKNOWN);
       }
     }
     // per-issuer unique counts: Σ_expDate SCARD (storage-statistics.go:44-53)
     if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
     wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, a.issuer_counts);
-    // per-(expDate, issuer) cardinality: SCARD(serials::expDate::issuer).  Keys are nearly all
-    // distinct inside a wave (≈2 000 expiry hours × issuers), so every lane probes on its own.
-    if (is_new && !pair_add(a.pairs, a.pmask, pkey, 1)) atomicAdd(&a.stats->pair_full, 1ull);
+    // (the per-(expDate, issuer) cardinalities are rebuilt lazily by k_build_pairs on the first
+    //  SetCardinality/KeysToChan after a mutation — they are statistics, not hot-path state)
     const unsigned long long m_new = __ballot(is_new), m_dup = __ballot(is_dup),
                              m_host = __ballot(is_host), m_full = __ballot(is_full);
     if ((threadIdx.x & 63) == 0) {
@@ -707,20 +706,15 @@ __global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, un
   result[1] = sid == SID_FULL;
   if (sid == SID_FULL) return;
   const uint32_t canon = (uint32_t)(meta >> 32) & 0xffffffu;
-  const unsigned long long pkey = ((unsigned long long)(canon + 1) << 32) | (uint32_t)meta;
   if (op == 0) {
     result[0] = created;
-    if (created) {
-      atomicAdd(&issuer_counts[canon], 1ull);
-      if (!pair_add(pairs, pmask, pkey, 1)) result[1] = 1;
-    }
+    if (created) atomicAdd(&issuer_counts[canon], 1ull);
   } else if (op == 1) {
     result[0] = sid != SID_NONE;
   } else if (sid != SID_NONE) {
     table[sid].w[0] = SLOT_TOMB;
     table[sid].w[1] = 0;
     atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
-    pair_add(pairs, pmask, pkey, -1);
     result[0] = 1;
   }
 }
@@ -742,8 +736,19 @@ __global__ void __launch_bounds__(256) k_sweep(Slot* table, uint64_t nslots, int
   table[j].w[0] = SLOT_TOMB;
   table[j].w[1] = 0;
   atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
-  pair_add(pairs, pmask, ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1, -1);
   atomicAdd(removed, 1ull);
+}
+
+// Rebuild the (expDate, issuer) → SCARD table from the known-certificate table (lazy: only the
+// statistics-style queries SetCardinality / Exists / KeysToChan need it).
+__global__ void __launch_bounds__(256) k_build_pairs(const Slot* table, uint64_t nslots, PairSlot* pairs,
+                                                     uint64_t pmask, unsigned long long* full) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nslots) return;
+  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+  if (!pair_add(pairs, pmask, ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1, 1)) atomicAdd(full, 1ull);
 }
 
 // SetList / SetToChan: gather the serials of one set.  out entries are 48 bytes:
