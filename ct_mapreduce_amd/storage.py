@@ -1,0 +1,782 @@
+"""Host mirror of the reference's `storage` package over the C ABI — same names, argument meaning
+and error behaviour, so the tests read like the reference's own (storage/*_test.go).
+
+  types        Issuer, SPKI, Serial, ExpDate, UniqueCertIdentifier, CertificateLog   storage/types.go
+  RemoteCache  GpuRemoteCache (libctmr: serials sets in HBM) / MockRemoteCache       storage/types.go:83-102, mockcache.go
+  KnownCertificates, IssuerMetadata                                                  storage/knowncertificates.go, issuermetadata.go
+  StorageBackend: NoopBackend, MockBackend, LocalDiskBackend                         storage/{noop,mock,localdisk}backend.go
+  FilesystemDatabase (Store / StoreBatch = batched insertCTWorker + Store)           storage/filesystemdatabase.go
+
+The per-entry hot path (parse, filters, WasUnknown) runs on the GPU through Engine.map_batch; what
+stays here is what the reference also does only for *newly unknown* certificates (IssuerMetadata,
+PEM write-back, dirty markers) plus bookkeeping strings.  Nothing here calls the oracle.
+"""
+import base64
+import calendar
+import datetime as _dt
+import fnmatch
+import hashlib
+import json
+import os
+import time as _time
+from urllib.parse import urlsplit
+
+import numpy as np
+
+from . import _native as N
+from .engine import Batch, Engine
+
+kExpirationFormat = "%Y-%m-%d"
+kExpirationFormatWithHour = "%Y-%m-%d-%H"
+
+
+# --------------------------------------------------------------------------------------- types.go
+class SPKI:
+    def __init__(self, spki: bytes):
+        self.spki = bytes(spki)
+
+    def ID(self):
+        return base64.urlsafe_b64encode(self.spki).decode()
+
+    def String(self):
+        return self.spki.hex()
+
+    def Sha256DigestURLEncodedBase64(self):       # types.go:155-159
+        return base64.urlsafe_b64encode(hashlib.sha256(self.spki).digest()).decode()
+
+
+class Issuer:
+    """types.go:104-143.  id is lazily b64url(SHA-256(RawSubjectPublicKeyInfo))."""
+
+    def __init__(self, spki: bytes = None, id: str = None):
+        self.id = id
+        self.spki = SPKI(spki) if spki is not None else None
+
+    @staticmethod
+    def FromString(s):
+        return Issuer(id=s)
+
+    def ID(self):
+        if self.id is None:
+            self.id = self.spki.Sha256DigestURLEncodedBase64()
+        return self.id
+
+    def __eq__(self, o):
+        return isinstance(o, Issuer) and self.ID() == o.ID()
+
+    def __hash__(self):
+        return hash(self.ID())
+
+    def __repr__(self):
+        return f"Issuer({self.ID()})"
+
+
+class Serial:
+    """types.go:161-246 — the raw INTEGER content octets, leading zeroes preserved."""
+
+    def __init__(self, b: bytes):
+        self.serial = bytes(b)
+
+    @staticmethod
+    def FromHex(s):
+        return Serial(bytes.fromhex(s))          # panics (raises) on bad hex like the reference
+
+    @staticmethod
+    def FromIDString(s):
+        return Serial(base64.urlsafe_b64decode(s.encode()))
+
+    @staticmethod
+    def FromBinaryString(s: bytes):
+        return Serial(s)
+
+    def ID(self):
+        return base64.urlsafe_b64encode(self.serial).decode()
+
+    def String(self):
+        return self.HexString()
+
+    def HexString(self):
+        return self.serial.hex()
+
+    def BinaryString(self):
+        return self.serial
+
+    def Cmp(self, o):
+        return (self.serial > o.serial) - (self.serial < o.serial)
+
+    def MarshalJSON(self):
+        return json.dumps(self.HexString())
+
+    @staticmethod
+    def UnmarshalJSON(data: str):
+        if not (data.startswith('"') and data.endswith('"')):
+            raise ValueError("Expected surrounding quotes")
+        return Serial(bytes.fromhex(data[1:-1]))
+
+    def AsBigInt(self):
+        return int.from_bytes(self.serial, "big")
+
+    def __eq__(self, o):
+        return isinstance(o, Serial) and self.serial == o.serial
+
+    def __hash__(self):
+        return hash(self.serial)
+
+    def __lt__(self, o):
+        return self.serial < o.serial
+
+    def __repr__(self):
+        return f"Serial({self.serial.hex()})"
+
+
+def _utc_ms(y, mo, d, h=0, mi=0, s=0, ms=0):
+    return calendar.timegm((y, mo, d, h, mi, s)) * 1000 + ms
+
+
+class ExpDate:
+    """types.go:333-405.  Times are integer milliseconds since the epoch (UTC)."""
+
+    def __init__(self, date_ms, last_good_ms, hour_resolution):
+        self.date = date_ms
+        self.lastGood = last_good_ms
+        self.hourResolution = hour_resolution
+
+    @staticmethod
+    def FromTime(unix_seconds):                   # NewExpDateFromTime :339-346
+        trunc = (int(unix_seconds) // 3600) * 3600 * 1000
+        return ExpDate(trunc, trunc - 1, True)
+
+    @staticmethod
+    def FromHour(exp_hour):                       # the device encoding of the same thing
+        return ExpDate.FromTime(int(exp_hour) * 3600)
+
+    @staticmethod
+    def Parse(s):                                 # NewExpDate :348-367
+        if len(s) > 10:
+            try:
+                t = _dt.datetime.strptime(s, kExpirationFormatWithHour)
+                if t.strftime(kExpirationFormatWithHour) == s or True:
+                    ms = _utc_ms(t.year, t.month, t.day, t.hour)
+                    return ExpDate(ms, ms + 3600_000 - 1, True)
+            except ValueError:
+                pass
+        t = _dt.datetime.strptime(s, kExpirationFormat)      # raises ValueError like the Go error
+        ms = _utc_ms(t.year, t.month, t.day)
+        return ExpDate(ms, ms + 24 * 3600_000 - 1, False)
+
+    def IsExpiredAt(self, t_ms):
+        return self.lastGood < t_ms
+
+    def ExpireTime(self):
+        return self.date // 1000
+
+    def hour(self):
+        return self.date // 3600_000
+
+    def ID(self):
+        t = _time.gmtime(self.date // 1000)
+        if self.hourResolution:
+            return "%04d-%02d-%02d-%02d" % (t.tm_year, t.tm_mon, t.tm_mday, t.tm_hour)
+        return "%04d-%02d-%02d" % (t.tm_year, t.tm_mon, t.tm_mday)
+
+    String = ID
+
+    def __eq__(self, o):
+        return isinstance(o, ExpDate) and self.ID() == o.ID()
+
+    def __hash__(self):
+        return hash(self.ID())
+
+    def __lt__(self, o):
+        return self.date < o.date
+
+    def __repr__(self):
+        return f"ExpDate({self.ID()})"
+
+
+class UniqueCertIdentifier:
+    def __init__(self, expDate, issuer, serial):
+        self.ExpDate, self.Issuer, self.SerialNum = expDate, issuer, serial
+
+    @staticmethod
+    def Parse(s):                                 # types.go:286-311
+        parts = s.split("::")
+        if len(parts) != 3:
+            raise ValueError("Expected 3 parts, got %d" % len(parts))
+        return UniqueCertIdentifier(ExpDate.Parse(parts[0]), Issuer.FromString(parts[1]),
+                                    Serial.FromIDString(parts[2]))
+
+    def String(self):
+        return "%s::%s::%s" % (self.ExpDate.ID(), self.Issuer.ID(), self.SerialNum.ID())
+
+
+def CertificateLogIDFromShortURL(shortURL):
+    return base64.urlsafe_b64encode(shortURL.encode()).decode()
+
+
+class CertificateLog:
+    """types.go:25-44.  Times are unix seconds (0 = Go's zero time)."""
+
+    def __init__(self, ShortURL="", MaxEntry=0, LastEntryTime=0, LastUpdateTime=0):
+        self.ShortURL, self.MaxEntry = ShortURL, MaxEntry
+        self.LastEntryTime, self.LastUpdateTime = LastEntryTime, LastUpdateTime
+
+    def ID(self):
+        return CertificateLogIDFromShortURL(self.ShortURL)
+
+    def to_json(self):
+        return json.dumps({"ShortURL": self.ShortURL, "MaxEntry": self.MaxEntry,
+                           "LastEntryTime": self.LastEntryTime, "LastUpdateTime": self.LastUpdateTime})
+
+    @staticmethod
+    def from_json(s):
+        d = json.loads(s)
+        return CertificateLog(d["ShortURL"], d["MaxEntry"], d["LastEntryTime"], d["LastUpdateTime"])
+
+    def __eq__(self, o):
+        return isinstance(o, CertificateLog) and self.__dict__ == o.__dict__
+
+
+# ---------------------------------------------------------------------------------- RemoteCache
+class RemoteCache:
+    """storage/types.go:83-102."""
+
+    def Exists(self, key): raise NotImplementedError
+    def SetInsert(self, key, entry): raise NotImplementedError
+    def SetRemove(self, key, entry): raise NotImplementedError
+    def SetContains(self, key, entry): raise NotImplementedError
+    def SetList(self, key): raise NotImplementedError
+    def SetToChan(self, key): raise NotImplementedError
+    def SetCardinality(self, key): raise NotImplementedError
+    def ExpireAt(self, key, unix_seconds): raise NotImplementedError
+    def KeysToChan(self, pattern): raise NotImplementedError
+    def StoreLogState(self, log): raise NotImplementedError
+    def LoadLogState(self, shortUrl): raise NotImplementedError
+
+
+def _b(x):
+    return x.encode() if isinstance(x, str) else bytes(x)
+
+
+class MockRemoteCache(RemoteCache):
+    """storage/mockcache.go: sorted-slice sets; used by the CPU tests of the host logic."""
+
+    def __init__(self):
+        self.Data = {}
+        self.Expirations = {}
+        self.Duplicate = 0
+
+    def SetInsert(self, key, entry):
+        key, entry = _b(key), _b(entry)
+        lst = self.Data.setdefault(key, [])
+        import bisect
+        i = bisect.bisect_left(lst, entry)
+        if i < len(lst) and lst[i] == entry:
+            return False
+        lst.insert(i, entry)
+        return True
+
+    def SetRemove(self, key, entry):
+        key, entry = _b(key), _b(entry)
+        lst = self.Data.get(key, [])
+        if entry in lst:
+            lst.remove(entry)
+            return True
+        return False
+
+    def SetContains(self, key, entry):
+        return _b(entry) in self.Data.get(_b(key), [])
+
+    def SetList(self, key):
+        return list(self.Data.get(_b(key), []))
+
+    def SetToChan(self, key):
+        for _ in range(self.Duplicate + 1):
+            for v in self.Data.get(_b(key), []):
+                yield v
+
+    def SetCardinality(self, key):
+        return len(self.Data.get(_b(key), []))
+
+    def Exists(self, key):
+        return _b(key) in self.Data
+
+    def ExpireAt(self, key, unix_seconds):
+        self.Expirations[_b(key)] = unix_seconds
+
+    def KeysToChan(self, pattern):
+        pat = _b(pattern).decode("latin1")
+        for k in list(self.Data):
+            if fnmatch.fnmatchcase(k.decode("latin1"), pat):
+                yield k
+
+    def StoreLogState(self, log):
+        self.Data[_b(log.ShortURL)] = [log.to_json().encode()]
+
+    def LoadLogState(self, shortUrl):
+        d = self.Data.get(_b(shortUrl))
+        if d is None:
+            raise KeyError("Log state not found")
+        if len(d) != 1:
+            raise ValueError("Unexpected number of log states")
+        return CertificateLog.from_json(d[0].decode())
+
+
+class GpuRemoteCache(RemoteCache):
+    """The drop-in for RedisCache on this path: `serials::…` sets live in the HBM table behind
+    libctmr; every other key (crl::, issuer::, log state) in the library's host-side store."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+
+    def SetInsert(self, key, entry): return self.engine.set_insert(_b(key), _b(entry))
+    def SetRemove(self, key, entry): return self.engine.set_remove(_b(key), _b(entry))
+    def SetContains(self, key, entry): return self.engine.set_contains(_b(key), _b(entry))
+    def SetList(self, key): return self.engine.set_list(_b(key))
+    def SetToChan(self, key): return iter(self.engine.set_list(_b(key)))
+    def SetCardinality(self, key): return self.engine.set_cardinality(_b(key))
+    def Exists(self, key): return self.engine.exists(_b(key))
+    def ExpireAt(self, key, unix_seconds): self.engine.expire_at(_b(key), unix_seconds)
+    def KeysToChan(self, pattern): return iter(self.engine.keys(_b(pattern)))
+
+    def StoreLogState(self, log):                 # rediscache.go:180-190: key "log::<shortURL>"
+        key = b"log::" + _b(log.ShortURL)
+        for old in self.engine.set_list(key):
+            self.engine.set_remove(key, old)
+        self.engine.set_insert(key, log.to_json().encode())
+
+    def LoadLogState(self, shortUrl):
+        d = self.engine.set_list(b"log::" + _b(shortUrl))
+        if not d:
+            raise KeyError("Log state not found")
+        return CertificateLog.from_json(d[0].decode())
+
+
+# -------------------------------------------------------------------------- KnownCertificates
+kSerials = "serials"
+
+
+class KnownCertificates:
+    """storage/knowncertificates.go."""
+
+    def __init__(self, expDate: ExpDate, issuer: Issuer, cache: RemoteCache):
+        self.expDate, self.issuer, self.cache = expDate, issuer, cache
+        self.expirySet = False
+
+    def id(self, *params):
+        return "%s%s::%s" % (self.expDate.ID(), "".join(params), self.issuer.ID())
+
+    def serialId(self, *params):
+        return "%s::%s" % (kSerials, self.id(*params))
+
+    def WasUnknown(self, serial: Serial) -> bool:             # :38-55
+        result = self.cache.SetInsert(self.serialId(), serial.BinaryString())
+        if not self.expirySet:
+            self.cache.ExpireAt(self.serialId(), self.expDate.ExpireTime())   # :98-104
+            self.expirySet = True
+        return result
+
+    def Count(self) -> int:                                    # :57-63
+        return self.cache.SetCardinality(self.serialId())
+
+    def Known(self):                                           # :65-96 (dedups what SetToChan yields)
+        return [Serial.FromBinaryString(s) for s in set(self.cache.SetToChan(self.serialId()))]
+
+
+# ----------------------------------------------------------------------------- IssuerMetadata
+kIssuers = "issuer"
+kCrls = "crl"
+
+_ATTR_NAMES = {3: "CN", 5: "SERIALNUMBER", 6: "C", 7: "L", 8: "ST", 9: "STREET", 10: "O", 11: "OU",
+               17: "POSTALCODE"}
+_ORDER = [6, 8, 7, 9, 17, 10, 11, 3, 5]     # pkix.Name.ToRDNSequence: C, ST, L, STREET, POSTALCODE, O, OU, CN, SERIALNUMBER
+
+
+def _tlv(d, p):
+    tag = d[p]
+    b = d[p + 1]
+    if b < 0x80:
+        return tag, p + 2, p + 2 + b
+    n = b & 0x7f
+    ln = int.from_bytes(d[p + 2:p + 2 + n], "big")
+    return tag, p + 2 + n, p + 2 + n + ln
+
+
+def _children(d, s, e):
+    out = []
+    while s < e:
+        tag, cs, ce = _tlv(d, s)
+        out.append((tag, cs, ce))
+        s = ce
+    return out
+
+
+def _escape_rdn_value(v: str) -> str:
+    out = []
+    for k, c in enumerate(v):
+        esc = c in ',+"\\<>;' or (k == 0 and c in " #") or (k == len(v) - 1 and c == " ")
+        out.append("\\" + c if esc else c)
+    return "".join(out)
+
+
+class HostCert:
+    """The few fields the host-only branch needs from a *newly unknown* certificate
+    (issuermetadata.go:92-138): Issuer.String() and CRLDistributionPoints.  Pure Python: this is
+    the rare path; the per-entry parse is the GPU's."""
+
+    def __init__(self, der: bytes):
+        d = der
+        _, cs, ce = _tlv(d, 0)
+        _, ts, te = _tlv(d, cs)
+        kids = _children(d, ts, te)
+        k = 1 if kids[0][0] == 0xa0 else 0
+        self.serial = d[kids[k][1]:kids[k][2]]
+        issuer = kids[k + 2]
+        validity = kids[k + 3]
+        self.issuer_atvs = []
+        for (_, ss, se) in _children(d, issuer[1], issuer[2]):
+            for (_, a_s, a_e) in _children(d, ss, se):
+                (ot, os_, oe), (vt, vs, ve) = _children(d, a_s, a_e)[:2]
+                self.issuer_atvs.append((bytes(d[os_:oe]), vt, bytes(d[vs:ve])))
+        times = _children(d, validity[1], validity[2])
+        self.not_after_raw = bytes(d[times[1][1]:times[1][2]])
+        self.crl_dps = []
+        for (tag, s, e) in kids[k + 6:]:
+            if tag != 0xa3:
+                continue
+            _, es, ee = _tlv(d, s)
+            for (_, xs, xe) in _children(d, es, ee):
+                parts = _children(d, xs, xe)
+                if bytes(d[parts[0][1]:parts[0][2]]) != b"\x55\x1d\x1f":
+                    continue
+                _, vs, ve = parts[-1]
+                _, dps, dpe = _tlv(d, vs)
+                for (_, ps, pe) in _children(d, dps, dpe):            # DistributionPoint
+                    for (t1, a, b_) in _children(d, ps, pe):
+                        if t1 != 0xa0:
+                            continue
+                        for (t2, c, e2) in _children(d, a, b_):         # fullName [0]
+                            if t2 != 0xa0:
+                                continue
+                            for (t3, u, v) in _children(d, c, e2):
+                                if t3 == 0x86:                           # uniformResourceIdentifier
+                                    self.crl_dps.append(bytes(d[u:v]).decode("latin1"))
+
+    def issuer_string(self) -> str:
+        """pkix.Name.String(): RDNs of ToRDNSequence() reversed, multi-values joined with '+'."""
+        named, extra = {}, []
+        for oid, vt, val in self.issuer_atvs:
+            s = val.decode("utf-8", "replace")
+            if len(oid) == 3 and oid[:2] == b"\x55\x04" and oid[2] in _ATTR_NAMES:
+                named.setdefault(oid[2], []).append(s)
+            else:
+                extra.append((oid, s))
+        rdns = []
+        for oid, s in extra:
+            arcs = [oid[0] // 40, oid[0] % 40]
+            v = 0
+            for b in oid[1:]:
+                v = (v << 7) | (b & 0x7f)
+                if not b & 0x80:
+                    arcs.append(v)
+                    v = 0
+            rdns.append(".".join(map(str, arcs)) + "=" + _escape_rdn_value(s))
+        for a in _ORDER:
+            if a in named:
+                rdns.append("+".join(_ATTR_NAMES[a] + "=" + _escape_rdn_value(x) for x in named[a]))
+        return ",".join(reversed(rdns))
+
+
+class IssuerMetadata:
+    """storage/issuermetadata.go."""
+
+    def __init__(self, issuer: Issuer, cache: RemoteCache):
+        self.issuer, self.cache = issuer, cache
+        self.knownCrlDPs, self.knownIssuerDNs, self.knownExpDates = set(), set(), set()
+
+    def id(self): return self.issuer.ID()
+    def crlId(self): return "%s::%s" % (kCrls, self.id())
+    def issuersId(self): return "%s::%s" % (kIssuers, self.id())
+
+    def addCRL(self, aCRL: str):                               # :48-73
+        try:
+            u = urlsplit(aCRL.strip())
+        except ValueError:
+            return
+        if u.scheme in ("ldap", "ldaps"):
+            return
+        if u.scheme not in ("http", "https"):
+            return
+        self.cache.SetInsert(self.crlId(), u.geturl())
+
+    def addIssuerDN(self, dn: str):                            # :75-87
+        self.cache.SetInsert(self.issuersId(), dn)
+
+    def Accumulate(self, cert: HostCert, exp_hour: int) -> bool:   # :92-138
+        expID = ExpDate.FromHour(exp_hour).ID()
+        dn = cert.issuer_string()
+        seenExpDateBefore = expID in self.knownExpDates
+        seenIssuerDn = dn in self.knownIssuerDNs
+        self.knownExpDates.add(expID)
+        for dp in cert.crl_dps:
+            if dp not in self.knownCrlDPs:
+                self.knownCrlDPs.add(dp)
+                self.addCRL(dp)
+        if not seenIssuerDn:
+            self.knownIssuerDNs.add(dn)
+            self.addIssuerDN(dn)
+        return seenExpDateBefore
+
+    def Issuers(self): return [x.decode() for x in self.cache.SetList(self.issuersId())]
+    def CRLs(self): return [x.decode() for x in self.cache.SetList(self.crlId())]
+
+
+# ----------------------------------------------------------------------------- StorageBackend
+class NoopBackend:
+    """storage/noopbackend.go: stores succeed silently, loads/listings error."""
+
+    def _err(self): return RuntimeError("Unable to load from the NoopBackend.")
+    def MarkDirty(self, id): return None
+    def AllocateExpDateAndIssuer(self, expDate, issuer): return None
+    def StoreCertificatePEM(self, serial, expDate, issuer, b): return None
+    def StoreLogState(self, log): return None
+    def StoreKnownCertificateList(self, issuer, serials): return None
+    def LoadCertificatePEM(self, serial, expDate, issuer): raise self._err()
+    def LoadLogState(self, logURL): raise self._err()
+    def ListExpirationDates(self, notBefore): raise self._err()
+    def ListIssuersForExpirationDate(self, expDate): raise self._err()
+    def ListSerialsForExpirationDateAndIssuer(self, expDate, issuer): raise self._err()
+
+
+class MockBackend:
+    """storage/mockbackend.go."""
+
+    def __init__(self):
+        self.expDateToIssuer, self.expDateIssuerIDToSerials, self.store = {}, {}, {}
+        self.dirty = []
+
+    def MarkDirty(self, id):
+        self.dirty.append(id)
+
+    def AllocateExpDateAndIssuer(self, expDate, issuer):
+        lst = self.expDateToIssuer.setdefault(expDate.ID(), [])
+        if issuer.ID() not in [i.ID() for i in lst]:
+            lst.append(issuer)
+            lst.sort(key=lambda i: i.ID())
+
+    def StoreCertificatePEM(self, serial, expDate, issuer, b):
+        self.store["pem" + expDate.ID() + issuer.ID() + serial.ID()] = b
+        self.expDateIssuerIDToSerials.setdefault(expDate.ID() + issuer.ID(), []).append(serial)
+
+    def StoreLogState(self, log):
+        self.store["logstate" + log.ShortURL] = log.to_json()
+
+    def StoreKnownCertificateList(self, issuer, serials):
+        self.store[issuer.ID()] = json.dumps([s.HexString() for s in serials])
+
+    def LoadCertificatePEM(self, serial, expDate, issuer):
+        k = "pem" + expDate.ID() + issuer.ID() + serial.ID()
+        if k in self.store:
+            return self.store[k]
+        raise KeyError("Couldn't find")
+
+    def LoadLogState(self, logURL):
+        if "logstate" + logURL in self.store:
+            return CertificateLog.from_json(self.store["logstate" + logURL])
+        return CertificateLog(ShortURL=logURL)
+
+    def ListExpirationDates(self, notBefore_unix):
+        day = (int(notBefore_unix) // 86400) * 86400 * 1000
+        out = []
+        for key in self.expDateToIssuer:
+            ed = ExpDate.Parse(key)
+            t = _dt.datetime.strptime(key[:10], kExpirationFormat)
+            if _utc_ms(t.year, t.month, t.day) >= day:
+                out.append(ed)
+        return out
+
+    def ListIssuersForExpirationDate(self, expDate):
+        return self.expDateToIssuer.get(expDate.ID(), [])
+
+    def ListSerialsForExpirationDateAndIssuer(self, expDate, issuer):
+        return self.expDateIssuerIDToSerials.get(expDate.ID() + issuer.ID(), [])
+
+
+class LocalDiskBackend:
+    """storage/localdiskbackend.go — including its quirks: certificates are written WITHOUT the
+    `.pem` suffix the listers look for (:194-199 vs :131,170), and MarkDirty writes `<id>/dirty`
+    relative to the current directory, not rootPath (:89-91)."""
+    kStateDirName, kDirtyMarker = "state", "dirty"
+
+    def __init__(self, perms, path):
+        self.perms, self.rootPath = perms, path
+
+    def _store(self, path, data: bytes):
+        d = os.path.dirname(path)
+        if d and not os.path.isdir(d):
+            os.makedirs(d, exist_ok=True)
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, self.perms)
+        try:
+            os.write(fd, data)
+        finally:
+            os.close(fd)
+
+    def MarkDirty(self, id):
+        self._store(os.path.join(id, self.kDirtyMarker), b"\x00")
+
+    def AllocateExpDateAndIssuer(self, expDate, issuer):
+        d = os.path.dirname(os.path.join(self.rootPath, expDate.ID(), issuer.ID()))
+        os.makedirs(d, exist_ok=True)               # makeDirectoryIfNotExist splits off the last element
+
+    def StoreCertificatePEM(self, serial, expDate, issuer, b):
+        self.AllocateExpDateAndIssuer(expDate, issuer)
+        self._store(os.path.join(self.rootPath, expDate.ID(), issuer.ID(), serial.ID()), b)
+
+    def StoreLogState(self, log):
+        self._store(os.path.join(self.rootPath, self.kStateDirName, log.ID()), log.to_json().encode())
+
+    def StoreKnownCertificateList(self, issuer, serials):
+        self._store(os.path.join(self.rootPath, issuer.ID()),
+                    b"".join((s.HexString() + "\n").encode() for s in serials))
+
+    def LoadCertificatePEM(self, serial, expDate, issuer):
+        raise NotImplementedError("Unimplemented")  # :239-242
+
+    def LoadLogState(self, logURL):
+        path = os.path.join(self.rootPath, self.kStateDirName, CertificateLogIDFromShortURL(logURL))
+        try:
+            return CertificateLog.from_json(open(path).read())
+        except OSError:
+            return CertificateLog(ShortURL=logURL)
+
+
+def pem_encode(der: bytes) -> bytes:
+    """encoding/pem.EncodeToMemory of {Type: CERTIFICATE, no headers} (filesystemdatabase.go:167-175)."""
+    b64 = base64.b64encode(der)
+    lines = [b64[i:i + 64] for i in range(0, len(b64), 64)]
+    return b"-----BEGIN CERTIFICATE-----\n" + b"\n".join(lines) + b"\n-----END CERTIFICATE-----\n"
+
+
+# ------------------------------------------------------------------------- FilesystemDatabase
+class IssuerDate:
+    def __init__(self, issuer):
+        self.Issuer, self.ExpDates = issuer, []
+
+
+class FilesystemDatabase:
+    """storage/filesystemdatabase.go with the per-entry part moved onto the GPU.
+
+    Store(cert_der, issuer_der, …) keeps the reference's signature for one entry; StoreBatch is
+    the batched insertCTWorker+Store: one Engine.map_batch, then — exactly as Store does after
+    WasUnknown (:183-201) — IssuerMetadata.Accumulate, AllocateExpDateAndIssuer and
+    StoreCertificatePEM for the newly unknown certificates, and markDirty for every stored entry."""
+
+    def __init__(self, backend, cache: RemoteCache, engine: Engine = None):
+        self.backend, self.extCache = backend, cache
+        self.engine = engine if engine is not None else getattr(cache, "engine", None)
+        self.meta = {}
+        self._issuer_idx = {}            # sha256(chain[0] DER) → index in the GPU issuer table
+
+    # -- reference API --------------------------------------------------------------------
+    def GetIssuerMetadata(self, issuer: Issuer) -> IssuerMetadata:
+        im = self.meta.get(issuer.ID())
+        if im is None:
+            im = self.meta[issuer.ID()] = IssuerMetadata(issuer, self.extCache)
+        return im
+
+    def GetKnownCertificates(self, expDate: ExpDate, issuer: Issuer) -> KnownCertificates:
+        return KnownCertificates(expDate, issuer, self.extCache)
+
+    def GetIssuerAndDatesFromCache(self):                        # :59-100
+        issuerMap = {}
+        for entry in self.extCache.KeysToChan("serials::*"):
+            parts = entry.decode("latin1").split("::")
+            if len(parts) != 3:
+                raise ValueError("Unexpected key format: %s" % entry)
+            try:
+                expDate = ExpDate.Parse(parts[1])
+            except ValueError:
+                continue
+            issuerMap.setdefault(parts[2], IssuerDate(Issuer.FromString(parts[2]))).ExpDates.append(expDate)
+        return list(issuerMap.values())
+
+    def ListExpirationDates(self, notBefore_unix): return self.backend.ListExpirationDates(notBefore_unix)
+    def ListIssuersForExpirationDate(self, expDate): return self.backend.ListIssuersForExpirationDate(expDate)
+
+    def SaveLogState(self, log):                                  # :110-118
+        try:
+            self.extCache.StoreLogState(log)
+        except Exception:
+            pass
+        return self.backend.StoreLogState(log)
+
+    def GetLogState(self, host, path):                            # :120-139
+        shortUrl = "%s%s" % (host, path)
+        try:
+            return self.extCache.LoadLogState(shortUrl)
+        except Exception:
+            pass
+        try:
+            log = self.backend.LoadLogState(shortUrl)
+            if log is not None:
+                return log
+        except Exception:
+            pass
+        return CertificateLog(ShortURL=shortUrl)
+
+    def markDirty(self, not_after_day: str):                      # :141-144
+        return self.backend.MarkDirty(not_after_day)
+
+    # -- the batched path -----------------------------------------------------------------
+    def _register_issuers(self, chain0_ders):
+        idx, fresh = [], []
+        for d in chain0_ders:
+            if d is None:
+                idx.append(N.NO_ISSUER)
+                continue
+            h = hashlib.sha256(d).digest()
+            if h not in self._issuer_idx:
+                self._issuer_idx[h] = self.engine.issuer_count() + len(fresh)
+                fresh.append(d)
+            idx.append(self._issuer_idx[h])
+        if fresh:
+            self.engine.add_issuers(fresh)
+        return idx
+
+    def StoreBatch(self, leaf_ders, chain0_ders, entry_types=None):
+        """leaf_ders[i]: the X509 cert or the precert's Submitted.Data (ct-fetch.go:198-204);
+        chain0_ders[i]: Chain[0].Data or None.  Returns the BatchResult (records, new_idx, stats)."""
+        iss = self._register_issuers(chain0_ders)
+        res = self.engine.map_batch(Batch.from_certs(list(leaf_ders), iss, entry_types))
+        rec = res.records
+        for i in res.new_idx:                                     # certWasUnknown branch :183-201
+            i = int(i)
+            info = self.engine.issuer_info(int(rec["issuer_idx"][i]))
+            issuer = Issuer.FromString(info.issuer_id.decode())
+            expDate = ExpDate.FromHour(int(rec["exp_hour"][i]))
+            cert = HostCert(leaf_ders[i])
+            seenBefore = self.GetIssuerMetadata(issuer).Accumulate(cert, int(rec["exp_hour"][i]))
+            if not seenBefore:
+                self.backend.AllocateExpDateAndIssuer(expDate, issuer)
+            self.backend.StoreCertificatePEM(Serial(cert.serial), expDate, issuer, pem_encode(leaf_ders[i]))
+        for i in np.nonzero(rec["status"] == N.ST_PASS)[0]:       # :205 — every stored entry
+            hour = int(rec["exp_hour"][int(i)])
+            t = _time.gmtime(hour * 3600)
+            self.markDirty("%04d-%02d-%02d" % (t.tm_year, t.tm_mon, t.tm_mday))
+        return res
+
+    def Store(self, cert_der, issuer_der, logURL=None, entryId=None):
+        return self.StoreBatch([cert_der], [issuer_der])
+
+
+def storage_statistics(db: FilesystemDatabase):
+    """cmd/storage-statistics/storage-statistics.go:28-82 → {issuerID: (hours, serials, crls, dns)}, totals."""
+    out, totalSerials, totalCRLs = {}, 0, 0
+    for issuerObj in db.GetIssuerAndDatesFromCache():
+        md = db.GetIssuerMetadata(issuerObj.Issuer)
+        crls, dns = md.CRLs(), md.Issuers()
+        count = sum(db.GetKnownCertificates(e, issuerObj.Issuer).Count() for e in issuerObj.ExpDates)
+        totalSerials += count
+        totalCRLs += len(crls)
+        out[issuerObj.Issuer.ID()] = (len(issuerObj.ExpDates), count, sorted(crls), sorted(dns))
+    return out, totalSerials, totalCRLs

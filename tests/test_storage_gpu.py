@@ -1,0 +1,113 @@
+"""-m gpu: the reference's cache-facing test suites against the HBM-backed GpuRemoteCache, and
+FilesystemDatabase.StoreBatch (batched insertCTWorker + Store) end to end."""
+import calendar
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402,F401
+
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import storage as S, synth
+from oracle import oracle as orc
+from tests.test_storage_cpu import (known_certificates_suite, duplicate_crls_suite, accumulate_suite,
+                                    issuer_and_dates_suite, log_state_suite, utc)
+
+
+@pytest.fixture
+def engine():
+    e = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12)
+    yield e
+    e.close()
+
+
+def test_Unknown_and_Known_gpu_cache(engine):
+    known_certificates_suite(S.GpuRemoteCache(engine))          # "test issuer": host-side store
+    # the same suite on a key that lives in the HBM table
+    cfg = synth.config(n_issuers=1)
+    engine.add_issuers(synth.issuers(cfg))
+    cache = S.GpuRemoteCache(engine)
+    kc = S.KnownCertificates(S.ExpDate.Parse("2029-01-30-00"), S.Issuer.FromString(engine.issuer_id(0)), cache)
+    for h in ("01", "02", "03", "04"):
+        cache.SetInsert(kc.serialId(), S.Serial.FromHex(h).BinaryString())
+    for h in ("01", "02", "03", "04"):
+        assert kc.WasUnknown(S.Serial.FromHex(h)) is False
+    assert kc.WasUnknown(S.Serial.FromHex("05")) is True and kc.WasUnknown(S.Serial.FromHex("05")) is False
+    assert sorted(kc.Known()) == [S.Serial.FromHex(h) for h in ("01", "02", "03", "04", "05")]
+    assert kc.Count() == 5 and int(engine.issuer_counts()[0]) == 5
+
+
+def test_DuplicateCRLs_and_Accumulate_gpu_cache(engine):
+    duplicate_crls_suite(S.GpuRemoteCache(engine))
+    engine2 = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+    accumulate_suite(S.GpuRemoteCache(engine2))
+    engine2.close()
+
+
+def test_IssuerAndDates_and_LogState_gpu_cache(engine):
+    cache = S.GpuRemoteCache(engine)
+    issuer_and_dates_suite(S.FilesystemDatabase(S.MockBackend(), cache))
+    log_state_suite(cache, S.FilesystemDatabase(S.MockBackend(), cache))
+
+
+def test_StoreBatch_end_to_end(tmp_path):
+    """Batched insertCTWorker + FilesystemDatabase.Store: same sets, counts, metadata and files as
+    feeding the entries one at a time through the oracle's restatement of the reference loop."""
+    cfg = synth.config(seed=9, n_issuers=6, dup_permille=150, ca_permille=50, expired_permille=50)
+    n = 1500
+    batch = synth.host_batch(cfg, 0, n)
+    issuers = synth.issuers(cfg)
+    leafs = [batch.cert(i) for i in range(n)]
+    chain0 = [issuers[int(k)] for k in batch.issuer_idx]
+    chain0[17] = None                                            # len(Chain) < 1
+    now = synth.BASE_TIME
+    eng = ctmr.Engine(device=0, table_slots=1 << 14, pair_slots=1 << 12)
+    eng.set_filter(b"Synth Issuer 00", False, now)
+    root = str(tmp_path / "certs")
+    backend = S.LocalDiskBackend(0o644, root)
+    db = S.FilesystemDatabase(backend, S.GpuRemoteCache(eng))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        r1 = db.StoreBatch(leafs[:700], chain0[:700], batch.entry_type[:700])
+        r2 = db.StoreBatch(leafs[700:], chain0[700:], batch.entry_type[700:])
+    finally:
+        os.chdir(cwd)
+    # oracle, entry by entry (ct-fetch.go:191-235)
+    o = orc.Engine(b"Synth Issuer 00", False, now)
+    status, unknown = [], []
+    for i in range(n):
+        st, unk, eh = o.entry(leafs[i], chain0[i])
+        status.append(st)
+        unknown.append(unk)
+    rec = np.concatenate([r1.records, r2.records])
+    assert list(rec["status"]) == status
+    assert list((rec["flags"] & 2) != 0) == unknown
+    assert status[17] == orc.ST_NO_ISSUER
+    # known-certificate sets and the statistics tool's numbers
+    okeys = [k for k in o.keys() if k.startswith(b"serials::")]
+    assert sorted(eng.keys(b"serials::*")) == okeys
+    stats, total, total_crls = S.storage_statistics(db)
+    assert total == o.total_count() == sum(unknown)
+    for iid, (hours, serials, crls, dns) in stats.items():
+        assert serials == o.issuer_count(iid)
+        k = [j for j in range(len(issuers)) if eng.issuer_id(j) == iid][0]
+        assert dns == ["CN=Synth Issuer %03d,O=Synth CA Org,C=US" % k]
+        assert crls == ["http://crl.synth-%03d.example/ca.crl" % k]
+        assert hours == len([x for x in okeys if x.endswith(iid.encode())])
+    # PEM write-back: one file per newly unknown certificate at root/expDate/issuer/serialID
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(root) for f in fs]
+    assert len(files) == sum(unknown)
+    i = unknown.index(True)
+    c = orc.parse_cert(leafs[i])
+    serial = S.Serial(leafs[i][c.serial_off:c.serial_off + c.serial_len])
+    path = os.path.join(root, orc.exp_date_id(orc.exp_hour(c.not_after)),
+                        eng.issuer_id(int(batch.issuer_idx[i])), serial.ID())
+    assert open(path, "rb").read() == S.pem_encode(leafs[i])
+    # dirty markers: one per NotAfter day of every stored entry (relative to the CWD, as the reference)
+    days = {orc.day_id(orc.parse_cert(leafs[j]).not_after) for j in range(n) if status[j] == 0}
+    assert {d for d in os.listdir(tmp_path) if os.path.exists(tmp_path / d / "dirty")} == days
+    eng.close()
