@@ -74,6 +74,11 @@ SIGNATURES = {
     "ctmr_total_count": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ctmr_issuer_counts_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
     "ctmr_reset_known": (C.c_int, [_P]),
+    "ctmr_exchange_export_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, _P, C.c_uint32, _P,
+                                              C.POINTER(C.c_uint64)]),
+    "ctmr_exchange_insert_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
+    "ctmr_exchange_apply_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
+                                             C.POINTER(BatchStats)]),
     "ctmr_synth_leaf_len": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64]),
     "ctmr_synth_leaf": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64, _P, C.c_uint32,
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),

@@ -544,6 +544,41 @@ int ctmr_set_filter(ctmr_engine* e, const char* filter, size_t len, int log_expi
   return upload_filter(e);
 }
 
+static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                      const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                      ctmr_record* d_records) {
+  MapArgs ma;
+  ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
+  ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
+  ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
+  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 3;
+  uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
+  if (C > 64) C = 64;
+  uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;
+  if (lds > 160 * 1024) lds = 160 * 1024;
+  ma.certs_per_tile = C; ma.lds_bytes = lds;
+  if (variant == 2) {
+    hipLaunchKernelGGL(k_map_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ma);
+  } else if (variant == 3) {
+    hipLaunchKernelGGL(k_map_win<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
+  } else if (variant == 4) {
+    hipLaunchKernelGGL(k_map_win<8>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (8 * 16 + 16), e->stream, ma);
+  } else if (variant == 5) {
+    hipLaunchKernelGGL(k_map_win<12>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (12 * 16 + 16), e->stream, ma);
+  } else if (variant == 6) {
+    hipLaunchKernelGGL(k_map_win<14>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (14 * 16 + 16), e->stream, ma);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(e, hipFuncSetAttribute((const void*)k_map_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    const uint64_t tiles = (n + C - 1) / C;
+    hipLaunchKernelGGL(k_map_tile, dim3((unsigned)tiles), dim3(64), lds, e->stream, ma);
+  }
+  return CTMR_OK;
+}
+
 static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                              const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
                              ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats) {
@@ -570,36 +605,8 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
 
   // ---- map
-  MapArgs ma;
-  ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
-  ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
-  ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
-  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 3;
-  uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
-  if (C > 64) C = 64;
-  uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;
-  if (lds > 160 * 1024) lds = 160 * 1024;
-  ma.certs_per_tile = C; ma.lds_bytes = lds;
   if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
-  if (variant == 2) {
-    hipLaunchKernelGGL(k_map_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ma);
-  } else if (variant == 3) {
-    hipLaunchKernelGGL(k_map_win<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
-  } else if (variant == 4) {
-    hipLaunchKernelGGL(k_map_win<8>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (8 * 16 + 16), e->stream, ma);
-  } else if (variant == 5) {
-    hipLaunchKernelGGL(k_map_win<12>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (12 * 16 + 16), e->stream, ma);
-  } else if (variant == 6) {
-    hipLaunchKernelGGL(k_map_win<14>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (14 * 16 + 16), e->stream, ma);
-  } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIPCHK(e, hipFuncSetAttribute((const void*)k_map_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
-    const uint64_t tiles = (n + C - 1) / C;
-    hipLaunchKernelGGL(k_map_tile, dim3((unsigned)tiles), dim3(64), lds, e->stream, ma);
-  }
+  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records))) return r;
   if (prof) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
   // ---- insert
   InsertArgs ia;
@@ -723,6 +730,122 @@ int ctmr_map_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offse
   if (records) HIPCHK(e, hipMemcpy(records, e->d_scratch[SC_RECORDS], n * sizeof(ctmr_record), hipMemcpyDeviceToHost));
   if (new_idx && st.n_new) HIPCHK(e, hipMemcpy(new_idx, B + o_new, st.n_new * 8, hipMemcpyDeviceToHost));
   if (stats) *stats = st;
+  return CTMR_OK;
+}
+
+// ------------------------------------------------------------------ cross-GPU key exchange
+
+int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                                const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                                ctmr_record* d_records, uint32_t world, void* d_keys_out,
+                                uint64_t* counts) {
+  if (!e || !d_records || !d_keys_out || !counts || world == 0 || world > MAX_WORLD ||
+      (n && (!d_payload || !d_offsets || !d_issuer_idx)))
+    return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  for (uint32_t w = 0; w < world; w++) counts[w] = 0;
+  if (n == 0) return CTMR_OK;
+  if (n >= 0xfffffff0ull) return fail(e, CTMR_E_INVAL, "batch too large (n < 2^32-16)");
+  int r;
+  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records))) return r;
+  const uint64_t nb = (n + 1023) / 1024;
+  const uint64_t ncnt = (uint64_t)world * nb;
+  if ((r = ensure(e, SC_SLOTID, n))) return r;                 // owner byte per entry
+  if ((r = ensure(e, SC_BLKNEW, (ncnt + 1) * 4))) return r;     // counts u32
+  if ((r = ensure(e, SC_BLKBASE, (ncnt + 1) * 8))) return r;    // bases u64
+  uint8_t* d_owner = (uint8_t*)e->d_scratch[SC_SLOTID];
+  uint32_t* d_cnt = (uint32_t*)e->d_scratch[SC_BLKNEW];
+  uint64_t* d_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
+  InsertArgs ia;
+  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.canon = e->d_canon;
+  ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = nullptr; ia.n = n; ia.epoch = e->epoch;
+  HIPCHK(e, hipMemsetAsync(d_cnt, 0, (ncnt + 1) * 4, e->stream));
+  hipLaunchKernelGGL(k_key_count, dim3((unsigned)nb), dim3(1024), 0, e->stream, ia, world, nb, d_owner, d_cnt);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_cnt, ncnt + 1, d_base);
+  hipLaunchKernelGGL(k_key_scatter, dim3((unsigned)nb), dim3(1024), 0, e->stream, ia, world, nb,
+                     (const uint8_t*)d_owner, (const uint64_t*)d_base, (KeyRec*)d_keys_out);
+  std::vector<uint64_t> base(world + 1);
+  for (uint32_t w = 0; w <= world; w++)
+    HIPCHK(e, hipMemcpyAsync(&base[w], d_base + (uint64_t)w * nb, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  for (uint32_t w = 0; w < world; w++) counts[w] = base[w + 1] - base[w];
+  return CTMR_OK;
+}
+
+int ctmr_exchange_insert_device(ctmr_engine* e, const void* d_keys, uint64_t n_keys, uint8_t* d_flags,
+                                uint64_t* n_new) {
+  if (!e || (n_keys && (!d_keys || !d_flags))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (n_new) *n_new = 0;
+  if (n_keys == 0) return CTMR_OK;
+  if (n_keys >= 0xfffffff0ull) return fail(e, CTMR_E_INVAL, "too many keys");
+  int r;
+  if ((r = ensure(e, SC_SLOTID, n_keys * 4))) return r;
+  uint32_t* d_slot = (uint32_t*)e->d_scratch[SC_SLOTID];
+  e->epoch++;
+  e->pairs_dirty = true;
+  HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
+  const KeyRec* keys = (const KeyRec*)d_keys;
+  const unsigned b256 = (unsigned)((n_keys + 255) / 256);
+  const uint64_t nb = (n_keys + 1023) / 1024;
+  hipLaunchKernelGGL(k_keys_insert, dim3(b256), dim3(256), 0, e->stream, keys, n_keys, e->table, e->nslots - 1, e->epoch, d_slot);
+  hipLaunchKernelGGL(k_keys_insert2, dim3(b256), dim3(256), 0, e->stream, keys, n_keys, e->table, e->nslots - 1, e->epoch, d_slot);
+  hipLaunchKernelGGL(k_keys_resolve, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(1024), 0, e->stream, keys, n_keys, nb,
+                     (const Slot*)e->table, e->epoch, (const uint32_t*)d_slot, d_flags, e->issuer_counts, e->d_stats);
+  DevStats hs;
+  HIPCHK(e, hipMemcpyAsync(&hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  if (hs.n_full) return fail(e, CTMR_E_FULL, "known-certificate table full (%llu slots)", (unsigned long long)e->nslots);
+  if (n_new) *n_new = hs.n_new;
+  return CTMR_OK;
+}
+
+int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, const void* d_keys_sent,
+                               const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx,
+                               ctmr_batch_stats* stats) {
+  if (!e || (n && !d_records) || (n_keys && (!d_keys_sent || !d_flags))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (n == 0) return CTMR_OK;
+  const uint64_t nb = (n + 1023) / 1024;
+  int r;
+  if ((r = ensure(e, SC_BLKNEW, nb * 4))) return r;
+  if ((r = ensure(e, SC_BLKBASE, nb * 8))) return r;
+  uint32_t* d_blk_new = (uint32_t*)e->d_scratch[SC_BLKNEW];
+  uint64_t* d_blk_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
+  HIPCHK(e, hipMemsetAsync(d_blk_new, 0, nb * 4, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
+  if (n_keys)
+    hipLaunchKernelGGL(k_apply_flags, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, e->stream,
+                       (const KeyRec*)d_keys_sent, d_flags, n_keys, d_records, d_blk_new);
+  hipLaunchKernelGGL(k_status_hist, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(1024), 0, e->stream,
+                     (const ctmr_record*)d_records, n, nb, e->d_stats);
+  if (d_new_idx) {
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records, n,
+                       (const uint64_t*)d_blk_base, d_new_idx);
+  }
+  DevStats hs;
+  HIPCHK(e, hipMemcpyAsync(&hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
+  // NEW count = Σ blk_new
+  std::vector<uint32_t> bn(nb);
+  HIPCHK(e, hipMemcpyAsync(bn.data(), d_blk_new, nb * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  if (stats) {
+    stats->n = n;
+    for (int k = 0; k < CTMR_ST__COUNT; k++) stats->by_status[k] = hs.by_status[k];
+    uint64_t nn = 0;
+    for (auto v : bn) nn += v;
+    stats->n_new = nn;
+    stats->n_host_set = hs.n_host;
+    stats->n_dup = hs.by_status[CTMR_ST_PASS] - nn - hs.n_host;
+  }
   return CTMR_OK;
 }
 

@@ -690,6 +690,235 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* blk_new, u
   }
 }
 
+// ------------------------------------------------------------------ cross-GPU key exchange
+// Global dedup over G GPUs: every key has one OWNER = hash(key) mod G.  A
+// rank exports the keys of its PASS entries partitioned by owner (ascending log index inside each
+// partition), the partitions are exchanged (RCCL send/recv), the owner inserts what it received
+// — concatenated in sender-rank order, which IS global log order because shards are contiguous
+// log-index ranges — and returns one "was unknown" byte per key.
+struct KeyRec {  // 64 bytes
+  unsigned long long meta;  // key_meta(exp_hour, canonical issuer, serial_len)
+  unsigned long long s[5];  // serial octets
+  uint32_t src;             // index of the entry in the sender's batch
+  uint32_t owner;
+  unsigned long long pad;
+};
+static_assert(sizeof(KeyRec) == 64, "KeyRec");
+
+constexpr uint32_t KEY_NO_OWNER = 0xffu;
+constexpr uint32_t MAX_WORLD = 16;
+
+__device__ __forceinline__ bool entry_key(const InsertArgs& a, uint64_t i, unsigned long long& meta,
+                                          unsigned long long s[5]) {
+  const uint4* rp = (const uint4*)(a.records + i);
+  const uint4 r0 = rp[0];
+  if ((r0.x & 0xffu) != CTMR_ST_PASS) return false;
+  const uint32_t slen = r0.x >> 16;
+  if (slen > CTMR_MAX_SERIAL) return false;  // host-side set, shard-local
+  const uint4 r1 = rp[1];
+  record_key(a, i, r0, r1, s);
+  meta = key_meta((int32_t)r0.y, a.canon[r0.z], slen);
+  return true;
+}
+
+__device__ __forceinline__ uint32_t key_owner(unsigned long long meta, const unsigned long long s[5],
+                                              uint32_t world) {
+  return (uint32_t)(mixk(key_hash(meta, s) ^ 0x5bd1e995u) % world);
+}
+
+// pass A: owner of every entry + per-(owner, 1024-entry block) counts (owner-major layout)
+__global__ void __launch_bounds__(1024) k_key_count(InsertArgs a, uint32_t world, uint64_t nb,
+                                                    uint8_t* owner_out, uint32_t* cnt) {
+  __shared__ uint32_t c[MAX_WORLD];
+  if (threadIdx.x < MAX_WORLD) c[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  uint32_t owner = KEY_NO_OWNER;
+  if (i < a.n) {
+    unsigned long long meta, s[5];
+    if (entry_key(a, i, meta, s)) owner = key_owner(meta, s, world);
+    owner_out[i] = (uint8_t)owner;
+  }
+  for (uint32_t w = 0; w < world; w++) {
+    const unsigned long long m = __ballot(owner == w);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[w], (uint32_t)__popcll(m));
+  }
+  __syncthreads();
+  if (threadIdx.x < world) cnt[(uint64_t)threadIdx.x * nb + blockIdx.x] = c[threadIdx.x];
+}
+
+// pass B: stable scatter into the owner partitions
+__global__ void __launch_bounds__(1024) k_key_scatter(InsertArgs a, uint32_t world, uint64_t nb,
+                                                      const uint8_t* owner_in, const uint64_t* base,
+                                                      KeyRec* out) {
+  __shared__ uint32_t wc[16][MAX_WORLD];
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t owner = i < a.n ? owner_in[i] : KEY_NO_OWNER;
+  uint32_t my_rank = 0;
+  for (uint32_t w = 0; w < world; w++) {
+    const unsigned long long m = __ballot(owner == w);
+    if (lane == 0) wc[wv][w] = (uint32_t)__popcll(m);
+    if (owner == w) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (owner != KEY_NO_OWNER) {
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < wv; k++) before += wc[k][owner];
+    unsigned long long meta, s[5];
+    entry_key(a, i, meta, s);
+    KeyRec* o = out + base[(uint64_t)owner * nb + blockIdx.x] + before + my_rank;
+    uint4* q = (uint4*)o;
+    q[0] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+    q[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+    q[2] = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+    q[3] = make_uint4((uint32_t)i, owner, 0u, 0u);
+  }
+}
+
+// Owner side, pass 1 / pass 2 / resolve on received key records (same protocol as k_insert…)
+__global__ void __launch_bounds__(256) k_keys_insert(const KeyRec* keys, uint64_t n, Slot* table,
+                                                     uint64_t mask, uint32_t epoch, uint32_t* slot_id) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const KeyRec k = keys[i];
+  const unsigned long long h = key_hash(k.meta, k.s);
+  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  uint64_t j = h & mask;
+  uint32_t sid = SID_FULL;
+  for (uint64_t probes = 0; probes <= mask; probes++) {
+    Slot* sl = table + j;
+    const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | (uint32_t)i);
+    if (old == 0ull) {
+      sl->w[1] = k.meta;
+      uint4* q = (uint4*)&sl->w[2];
+      q[0] = make_uint4(epoch, 0u, (uint32_t)k.s[0], (uint32_t)(k.s[0] >> 32));
+      q[1] = make_uint4((uint32_t)k.s[1], (uint32_t)(k.s[1] >> 32), (uint32_t)k.s[2], (uint32_t)(k.s[2] >> 32));
+      q[2] = make_uint4((uint32_t)k.s[3], (uint32_t)(k.s[3] >> 32), (uint32_t)k.s[4], (uint32_t)(k.s[4] >> 32));
+      sid = (uint32_t)j;
+      break;
+    }
+    if ((old & 0xffffffff00000000ull) == tagw) {
+      const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
+      if (ep != 0u && ep != epoch) {
+        bool eq = sl->w[1] == k.meta;
+#pragma unroll
+        for (int q = 0; q < 5; q++) eq = eq && sl->w[3 + q] == k.s[q];
+        if (eq) {
+          sid = SID_DUP_OLD;
+          break;
+        }
+      } else {
+        sid = (uint32_t)j | SID_DEFER;
+        break;
+      }
+    }
+    j = (j + 1) & mask;
+  }
+  slot_id[i] = sid;
+}
+
+__global__ void __launch_bounds__(256) k_keys_insert2(const KeyRec* keys, uint64_t n, Slot* table,
+                                                      uint64_t mask, uint32_t epoch, uint32_t* slot_id) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sid = slot_id[i];
+  if (sid >= SID_DUP_OLD || !(sid & SID_DEFER)) return;
+  sid &= ~SID_DEFER;
+  const KeyRec k = keys[i];
+  Slot* sl = table + sid;
+  bool eq = sl->w[1] == k.meta;
+#pragma unroll
+  for (int q = 0; q < 5; q++) eq = eq && sl->w[3 + q] == k.s[q];
+  if (eq) {
+    atomicMin(&sl->w[0], ((unsigned long long)key_tag(key_hash(k.meta, k.s)) << 32) | (uint32_t)i);
+  } else {
+    bool created;
+    sid = table_upsert(table, mask, k.meta, k.s, (uint32_t)i, epoch, true, &created);
+  }
+  slot_id[i] = sid;
+}
+
+__global__ void __launch_bounds__(1024) k_keys_resolve(const KeyRec* keys, uint64_t n, uint64_t nb,
+                                                       const Slot* table, uint32_t epoch,
+                                                       const uint32_t* slot_id, uint8_t* flags,
+                                                       unsigned long long* issuer_counts, DevStats* stats) {
+  __shared__ uint32_t ih[RES_LDS_ISSUERS];
+  __shared__ uint32_t cnt[2];
+  for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024) ih[k] = 0;
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    const uint64_t i = blk * 1024 + threadIdx.x;
+    bool is_new = false, is_full = false;
+    uint32_t canon = 0;
+    if (i < n) {
+      const uint32_t sid = slot_id[i];
+      if (sid == SID_FULL) {
+        is_full = true;
+      } else if (sid < SID_DUP_OLD) {
+        const Slot* sl = table + sid;
+        const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
+        is_new = (uint32_t)w2 == epoch && (uint32_t)w0 == (uint32_t)i;
+        canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+      }
+      flags[i] = is_new ? 1 : 0;
+    }
+    if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
+    wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, issuer_counts);
+    const unsigned long long m_new = __ballot(is_new), m_full = __ballot(is_full);
+    if ((threadIdx.x & 63) == 0) {
+      if (m_new) atomicAdd(&cnt[0], (uint32_t)__popcll(m_new));
+      if (m_full) atomicAdd(&cnt[1], (uint32_t)__popcll(m_full));
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024)
+    if (ih[k]) atomicAdd(&issuer_counts[k], (unsigned long long)ih[k]);
+  if (threadIdx.x == 0 && cnt[0]) atomicAdd(&stats->n_new, (unsigned long long)cnt[0]);
+  if (threadIdx.x == 1 && cnt[1]) atomicAdd(&stats->n_full, (unsigned long long)cnt[1]);
+}
+
+// Sender side: apply the returned flags to the local records, count NEW per 1024-entry block
+__global__ void __launch_bounds__(256) k_apply_flags(const KeyRec* sent, const uint8_t* flags, uint64_t n_keys,
+                                                     ctmr_record* records, uint32_t* blk_new) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_keys || !flags[k]) return;
+  const uint32_t src = sent[k].src;
+  uint8_t* fl = (uint8_t*)(records + src) + 1;
+  *fl = (uint8_t)(*fl | CTMR_FL_WAS_UNKNOWN);
+  atomicAdd(&blk_new[src >> 10], 1u);
+}
+
+// status histogram of a record array (exchange mode has no local resolve pass)
+__global__ void __launch_bounds__(1024) k_status_hist(const ctmr_record* records, uint64_t n, uint64_t nb,
+                                                      DevStats* stats) {
+  __shared__ uint32_t hist[CTMR_ST__COUNT + 1];
+  if (threadIdx.x <= CTMR_ST__COUNT) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    const uint64_t i = blk * 1024 + threadIdx.x;
+    uint32_t status = CTMR_ST__COUNT, longs = 0;
+    if (i < n) {
+      const uint32_t head = *(const uint32_t*)(records + i);
+      status = head & 0xffu;
+      longs = status == CTMR_ST_PASS && (head >> 16) > CTMR_MAX_SERIAL;
+    }
+#pragma unroll
+    for (uint32_t st = 0; st < CTMR_ST__COUNT; st++) {
+      const unsigned long long m = __ballot(status == st);
+      if ((threadIdx.x & 63) == 0 && m) atomicAdd(&hist[st], (uint32_t)__popcll(m));
+    }
+    const unsigned long long ml = __ballot(longs != 0);
+    if ((threadIdx.x & 63) == 0 && ml) atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(ml));
+  }
+  __syncthreads();
+  if (threadIdx.x < CTMR_ST__COUNT && hist[threadIdx.x])
+    atomicAdd(&stats->by_status[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+  if (threadIdx.x == CTMR_ST__COUNT && hist[CTMR_ST__COUNT])
+    atomicAdd(&stats->n_host, (unsigned long long)hist[CTMR_ST__COUNT]);
+}
+
 // ------------------------------------------------------------------ RemoteCache point ops
 // op: 0 = SetInsert, 1 = SetContains, 2 = SetRemove.  result[0] = 1 when inserted / present /
 // removed; result[1] = SID_FULL marker on a full table.

@@ -55,3 +55,116 @@ def run_sharded(n_total: int, n_issuers: int, make_batch, map_fn, counts_fn, dev
     glob = merge_counts(local, device)
     tot = merge_counts(np.array([n_new], dtype=np.uint64), device)
     return ShardResult(lo, hi, local, glob, n_new, int(tot[0]))
+
+
+# ------------------------------------------------------------------------------------------------
+# Global dedup across GPUs: owner-computes key exchange (BASELINE config 5).
+#
+#   phase 1  export   map the shard, write one 64-byte key record per PASS entry, partitioned by
+#                     owner = hash(key) mod world                       (Engine.exchange_export)
+#   exchange A        partitions → owners (RCCL send/recv; sender-rank order = global log order)
+#   phase 2  insert   owner inserts what it received, one "was unknown" byte per key
+#                                                                        (Engine.exchange_insert)
+#   exchange B        bytes → senders
+#   phase 3  apply    sender flags its records, compacts new_idx        (Engine.exchange_apply)
+#   counts            owner-local per-issuer counters, all-reduced as in the shard-local mode
+#
+# The per-rank phases are methods so that a test can drive several "ranks" inside one process
+# (tests/test_gpu_exchange.py: two engines on one GPU); run_global_dedup() drives one rank over
+# torch.distributed.
+
+class GlobalDedupRank:
+    KEY = 64
+
+    def __init__(self, engine, rank, world, torch_device):
+        self.eng, self.rank, self.world, self.dev = engine, rank, world, torch_device
+
+    def export(self, d_payload, d_offsets, d_iss, d_et, n, d_records):
+        import torch
+        self.n, self.d_records = n, d_records
+        self.keys = torch.empty(max(n, 1) * self.KEY, dtype=torch.uint8, device=self.dev)
+        self.send_counts = self.eng.exchange_export(d_payload, d_offsets, d_iss, d_et, n, d_records,
+                                                    self.world, self.keys.data_ptr())
+        self.n_keys = sum(self.send_counts)
+        return self.send_counts
+
+    def partition(self, owner):
+        """Key records destined to `owner` (a view of the export buffer)."""
+        lo = sum(self.send_counts[:owner]) * self.KEY
+        return self.keys[lo:lo + self.send_counts[owner] * self.KEY]
+
+    def insert(self, received, recv_counts):
+        """received: key records concatenated in sender-rank order."""
+        import torch
+        self.recv_counts = list(recv_counts)
+        nrecv = sum(recv_counts)
+        self.flags_out = torch.zeros(max(nrecv, 1), dtype=torch.uint8, device=self.dev)
+        self.n_new_owned = self.eng.exchange_insert(received.data_ptr(), nrecv, self.flags_out.data_ptr()) \
+            if nrecv else 0
+        return self.flags_out
+
+    def flags_for(self, sender):
+        lo = sum(self.recv_counts[:sender])
+        return self.flags_out[lo:lo + self.recv_counts[sender]]
+
+    def apply(self, flags_mine, d_new_idx=0):
+        """flags_mine: one byte per exported key, in export (owner-major) order."""
+        return self.eng.exchange_apply(self.d_records, self.n, self.keys.data_ptr(),
+                                       flags_mine.data_ptr(), self.n_keys, d_new_idx)
+
+
+def run_global_dedup(rank_obj: GlobalDedupRank, d_payload, d_offsets, d_iss, d_et, n, d_records,
+                     d_new_idx=0):
+    """One rank's step over torch.distributed (backend nccl = RCCL)."""
+    import torch
+    import torch.distributed as dist
+    world, rank, dev = rank_obj.world, rank_obj.rank, rank_obj.dev
+    send_counts = rank_obj.export(d_payload, d_offsets, d_iss, d_et, n, d_records)
+    if world == 1:
+        flags = rank_obj.insert(rank_obj.partition(0), [send_counts[0]])
+        return rank_obj.apply(flags, d_new_idx)
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    allc = [torch.empty_like(sc) for _ in range(world)]
+    dist.all_gather(allc, sc)
+    recv_counts = [int(allc[s][rank].item()) for s in range(world)]
+    K = GlobalDedupRank.KEY
+    recv = torch.empty(max(sum(recv_counts), 1) * K, dtype=torch.uint8, device=dev)
+    ops, off = [], 0
+    for s in range(world):                      # exchange A: key partitions
+        if recv_counts[s]:
+            ops.append(dist.P2POp(dist.irecv, recv[off * K:(off + recv_counts[s]) * K], s))
+        off += recv_counts[s]
+        if send_counts[s]:
+            ops.append(dist.P2POp(dist.isend, rank_obj.partition(s), s))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    rank_obj.insert(recv, recv_counts)
+    flags_mine = torch.zeros(max(sum(send_counts), 1), dtype=torch.uint8, device=dev)
+    ops, off = [], 0
+    for s in range(world):                      # exchange B: flags back, export order = owner-major
+        if send_counts[s]:
+            ops.append(dist.P2POp(dist.irecv, flags_mine[off:off + send_counts[s]], s))
+        off += send_counts[s]
+        if recv_counts[s]:
+            ops.append(dist.P2POp(dist.isend, rank_obj.flags_for(s), s))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return rank_obj.apply(flags_mine, d_new_idx)
+
+
+def run_simulated(rank_objs, shards, new_idx_ptrs=None):
+    """Drive all ranks of a world inside ONE process (tests): shards[r] = (d_payload, d_offsets,
+    d_iss, d_et, n, d_records).  Same data movement as run_global_dedup, with tensor slicing
+    instead of send/recv."""
+    import torch
+    world = len(rank_objs)
+    counts = [r.export(*shards[k]) for k, r in enumerate(rank_objs)]
+    for o, r in enumerate(rank_objs):
+        parts = [rank_objs[s].partition(o) for s in range(world)]
+        r.insert(torch.cat(parts) if world > 1 else parts[0], [counts[s][o] for s in range(world)])
+    out = []
+    for k, r in enumerate(rank_objs):
+        fl = [rank_objs[o].flags_for(k) for o in range(world)]
+        out.append(r.apply(torch.cat(fl) if world > 1 else fl[0],
+                           new_idx_ptrs[k] if new_idx_ptrs else 0))
+    return out

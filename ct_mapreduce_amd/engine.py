@@ -154,6 +154,32 @@ class Engine:
             C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
         return st
 
+    # ---- cross-GPU key exchange (global dedup), device pointers as ints
+    KEY_BYTES = 64
+
+    def exchange_export(self, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, world,
+                        d_keys_out):
+        counts = (C.c_uint64 * world)()
+        self._ck(self._lib.ctmr_exchange_export_device(
+            self._h, C.c_void_p(d_payload), C.c_void_p(d_offsets), C.c_void_p(d_issuer_idx),
+            C.c_void_p(d_entry_type) if d_entry_type else None, n, C.c_void_p(d_records), world,
+            C.c_void_p(d_keys_out), counts))
+        return [int(c) for c in counts]
+
+    def exchange_insert(self, d_keys, n_keys, d_flags) -> int:
+        out = C.c_uint64()
+        self._ck(self._lib.ctmr_exchange_insert_device(self._h, C.c_void_p(d_keys), n_keys,
+                                                       C.c_void_p(d_flags), C.byref(out)))
+        return out.value
+
+    def exchange_apply(self, d_records, n, d_keys_sent, d_flags, n_keys, d_new_idx=0) -> N.BatchStats:
+        st = N.BatchStats()
+        self._ck(self._lib.ctmr_exchange_apply_device(
+            self._h, C.c_void_p(d_records), n, C.c_void_p(d_keys_sent) if n_keys else None,
+            C.c_void_p(d_flags) if n_keys else None, n_keys,
+            C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
+        return st
+
     # ---- storage.RemoteCache set methods (storage/types.go:83-102)
     @staticmethod
     def _b(x):

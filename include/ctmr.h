@@ -186,6 +186,28 @@ int ctmr_issuer_counts_device(ctmr_engine* e, void** d_counts, uint32_t* n);
 /* Drop every known certificate (table, pair counts, counters, host-side sets keep keys). */
 int ctmr_reset_known(ctmr_engine* e);
 
+/* ---- cross-GPU global dedup: replaces the shared Redis set service
+ *      (storage/rediscache.go:57-65) between shards.  owner(key) = hash(key) mod world.
+ *   export: runs the map into d_records and writes one 64-byte key record per PASS entry into
+ *           d_keys_out (capacity n), partitioned by owner, ascending log index inside a partition;
+ *           counts[w] (host) = keys for owner w.
+ *   insert: the owner inserts the key records it received — concatenated in sender-rank order, which
+ *           is global log order for contiguous log-index shards — and writes one byte per key:
+ *           1 = was unknown.  Bumps the owner's per-issuer counters.
+ *   apply:  the sender sets CTMR_FL_WAS_UNKNOWN in its records from the returned bytes (same order
+ *           as d_keys_sent), compacts new_idx, fills stats.
+ *   Every rank must have registered the same issuers in the same order.  Serials longer than
+ *   CTMR_MAX_SERIAL are not exchanged (they stay shard-local on the host side). ---- */
+int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                                const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                                ctmr_record* d_records, uint32_t world, void* d_keys_out,
+                                uint64_t* counts);
+int ctmr_exchange_insert_device(ctmr_engine* e, const void* d_keys, uint64_t n_keys, uint8_t* d_flags,
+                                uint64_t* n_new);
+int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, const void* d_keys_sent,
+                               const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx,
+                               ctmr_batch_stats* stats);
+
 /* ---- benchmark / test input generator (SURVEY.md §8(d) synthetic CT batch); not part of the
  *      reference's surface.  Deterministic in (seed, index); host and device emit identical bytes. */
 typedef struct {
