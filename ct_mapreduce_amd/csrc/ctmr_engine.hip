@@ -33,6 +33,7 @@ struct HostReader {  // host instantiation of the walk for the long-serial slow 
     return v;
   }
   void touch(uint32_t, uint32_t) const {}
+  void touch_tail(uint32_t, uint32_t) const {}
 };
 
 struct IssuerRec {
@@ -567,6 +568,12 @@ static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* 
     hipLaunchKernelGGL(k_map_win<12>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (12 * 16 + 16), e->stream, ma);
   } else if (variant == 6) {
     hipLaunchKernelGGL(k_map_win<14>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (14 * 16 + 16), e->stream, ma);
+  } else if (variant == 7) {
+    hipLaunchKernelGGL(k_map_win2<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (19 * 16), e->stream, ma);
+  } else if (variant == 8) {
+    hipLaunchKernelGGL(k_map_win2<14>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (17 * 16), e->stream, ma);
+  } else if (variant == 9) {
+    hipLaunchKernelGGL(k_map_win2<12>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (15 * 16), e->stream, ma);
   } else {
     static bool attr_set = false;
     if (!attr_set) {

@@ -172,7 +172,8 @@ CTMR_HD bool string_tag(uint32_t t) {
 }
 
 // `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
-// windowed reader that about `need` bytes from pos are read next; other readers ignore it.
+// windowed reader that about `need` bytes from pos are read next; r.touch_tail(pos, tail) that the
+// bytes from pos AND the bytes at `tail` are read next; other readers ignore both.
 template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr) {
   o.serial_off = o.serial_len = 0;
@@ -278,6 +279,9 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nul
   o.spki_off = q;
   o.spki_len = ce - q;
   q = ce;
+  // what follows the key (unique ids, extensions) and the tail behind the TBS are both known now:
+  // a two-region reader fetches them in one burst
+  r.touch_tail(q, tbs_end);
   // [1] issuerUniqueID, [2] subjectUniqueID: skipped
   uint32_t nt = (ok & (q < tbs_end)) ? (r.ld4(q < L ? q : L) & 0xffu) : 0u;
   if (nt == 0x81u) {
@@ -293,7 +297,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nul
   // [3] EXPLICIT Extensions
   if (nt == 0xa3u) {
     uint32_t e, e_end;
-    r.touch(q, 256);
+    r.touch(q, 48);
     rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
     rd_hdr(r, L, cs, ce, ok, tag, e, e_end);
     ok = ok & (tag == 0x30u);
@@ -341,9 +345,12 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nul
   ok = ok & (tag == 0x03u) & (ce != cs);
   {
     const uint32_t pad = r.ld4(cs < L ? cs : L) & 0xffu;
-    const uint32_t lastp = ce - 1u;
-    const uint32_t last = r.ld4(lastp < L ? lastp : L) & 0xffu;
-    ok = ok & (pad <= 7u) & ((ce - cs != 1u) | (pad == 0u)) & ((last & ((1u << (pad & 7u)) - 1u)) == 0u);
+    ok = ok & (pad <= 7u) & ((ce - cs != 1u) | (pad == 0u));
+    if (ok & (pad != 0u)) {  // padding bits must be zero: only then is the last octet needed
+      const uint32_t lastp = ce - 1u;
+      const uint32_t last = r.ld4(lastp < L ? lastp : L) & 0xffu;
+      ok = (last & ((1u << (pad & 7u)) - 1u)) == 0u;
+    }
   }
   return ok;
 }

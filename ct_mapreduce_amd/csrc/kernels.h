@@ -29,6 +29,7 @@ struct LdsReader {
     return __builtin_amdgcn_alignbyte(lds[i + 1], lds[i], a & 3u);
   }
   __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void touch_tail(uint32_t, uint32_t) const {}
 };
 
 struct GlobalReader {
@@ -40,6 +41,7 @@ struct GlobalReader {
     return __builtin_amdgcn_alignbyte(words[i + 1], words[i], (uint32_t)a & 3u);
   }
   __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void touch_tail(uint32_t, uint32_t) const {}
 };
 
 // Per-lane LDS window ("software cache") over a certificate that stays in global memory.
@@ -84,6 +86,78 @@ struct WinReader {
     if (need > WBYTES - 16u) need = WBYTES - 16u;  // the window start is 16-B aligned in HBM
     const uint32_t rel = pos - (uint32_t)grel;
     if (rel > WBYTES - need) refill(pos);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, 256); }
+};
+
+// Two-region window: MAIN (WCH chunks, moves with the walk) + TAIL (3 chunks pinned at the end of
+// the TBSCertificate: signatureAlgorithm and the BIT STRING header of signatureValue).  The walk
+// knows both addresses as soon as it has decoded the SubjectPublicKeyInfo header — the extension
+// block starts right behind the key, the tail at tbs_end — so touch_tail() fetches both regions
+// in ONE burst of WCH+3 independent global_load_dwordx4: the dependent HBM round trips per
+// certificate drop from ≈8 (front, [3] tag, extensions, sigalg header, BIT STRING header, pad
+// byte, last byte, …) to 2 (front; extensions + tail).  Lane stride (WCH+3)·16 B with WCH even:
+// an odd number of 16-B chunks keeps the dword reads at ≤4-way bank conflicts without a pad chunk.
+template <int WCH>
+struct WinReader2 {
+  static constexpr int TCH = 3;
+  static constexpr uint32_t WBYTES = WCH * 16, TBYTES = TCH * 16;
+  const uint32_t* g32;
+  uint64_t base;
+  uint64_t limit;
+  uint32_t* win;  // main window words; the tail window follows at win + WCH*4
+  int32_t grel;   // main window start relative to the certificate start
+  int32_t trel;   // tail window start (0x7fffff00 = not loaded)
+
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel <= WBYTES - 8u) {
+      const uint32_t i = rel >> 2;
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
+    }
+    const uint32_t rel2 = pos - (uint32_t)trel;
+    if (rel2 <= TBYTES - 8u) {
+      const uint32_t i = WCH * 4 + (rel2 >> 2);
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel2 & 3u);
+    }
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ void refill(uint32_t pos) {
+    const uint64_t g = (base + pos) & ~15ull;
+    grel = (int32_t)(int64_t)(g - base);
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    uint4 v[WCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++)
+      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+  }
+  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
+    if (need > WBYTES - 16u) need = WBYTES - 16u;
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel > WBYTES - need) refill(pos);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t tailpos) {
+    const uint64_t g = (base + pos) & ~15ull;
+    const uint64_t t = (base + tailpos) & ~15ull;
+    grel = (int32_t)(int64_t)(g - base);
+    trel = (int32_t)(int64_t)(t - base);
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    const uint4* tsrc = (const uint4*)g32 + (t >> 4);
+    uint4 v[WCH], u[TCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++)
+      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < TCH; k++)
+      u[k] = (t + 16u * k + 16u <= limit) ? tsrc[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+#pragma unroll
+    for (int k = 0; k < TCH; k++) ((uint4*)win)[WCH + k] = u[k];
   }
 };
 
@@ -313,6 +387,21 @@ __global__ void __launch_bounds__(64) k_map_win(MapArgs a) {
   constexpr uint32_t STRIDE = WCH * 16 + 16;
   WinReader<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
                    (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
+  r.refill(0);
+  map_one(r, hi - lo, i, a);
+}
+
+// Two-region window map (WinReader2): same walk, 2 dependent HBM round trips per certificate.
+template <int WCH>
+__global__ void __launch_bounds__(64) k_map_win2(MapArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  const uint64_t lo = a.offsets[i];
+  uint64_t hi = a.offsets[i + 1];
+  if (hi < lo) hi = lo;
+  constexpr uint32_t STRIDE = (WCH + 3) * 16;
+  WinReader2<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+                    (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0x7fffff00};
   r.refill(0);
   map_one(r, hi - lo, i, a);
 }

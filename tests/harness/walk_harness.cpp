@@ -14,6 +14,7 @@ struct PaddedReader {
     return v;
   }
   void touch(uint32_t, uint32_t) const {}
+  void touch_tail(uint32_t, uint32_t) const {}
 };
 
 struct HarnessOut {
