@@ -166,7 +166,7 @@ struct ctmr_engine {
 
 namespace {
 
-enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_NEWIDX, SC_STAGE_A, SC_STAGE_B, SC_MISC };
+enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC };
 
 int fail(const ctmr_engine* e, int code, const char* fmt, ...) {
   char buf[512];
@@ -547,8 +547,9 @@ int ctmr_set_filter(ctmr_engine* e, const char* filter, size_t len, int log_expi
 
 static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                       const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
-                      ctmr_record* d_records) {
+                      ctmr_record* d_records, bool optimistic_new) {
   MapArgs ma;
+  ma.optimistic_new = optimistic_new ? 1u : 0u;
   ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
   ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
   ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
@@ -601,9 +602,11 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   }
   const uint64_t nb = (n + 1023) / 1024;
   if ((r = ensure(e, SC_SLOTID, n * 4))) return r;
+  if ((r = ensure(e, SC_ENT, n * 4))) return r;
   if ((r = ensure(e, SC_BLKNEW, nb * 4))) return r;
   if ((r = ensure(e, SC_BLKBASE, nb * 8))) return r;
   uint32_t* d_slot = (uint32_t*)e->d_scratch[SC_SLOTID];
+  uint32_t* d_ent = (uint32_t*)e->d_scratch[SC_ENT];
   uint32_t* d_blk_new = (uint32_t*)e->d_scratch[SC_BLKNEW];
   uint64_t* d_blk_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
   const bool prof = e->cfg.profile != 0;
@@ -611,22 +614,20 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   e->pairs_dirty = true;
   HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
 
-  // ---- map
+  // ---- map (PASS records leave it with WAS_UNKNOWN set; the reduce clears it for duplicates)
   if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
-  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records))) return r;
+  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, true))) return r;
   if (prof) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
   // ---- insert
   InsertArgs ia;
   ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.canon = e->d_canon;
-  ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.n = n; ia.epoch = e->epoch;
+  ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.ent = d_ent; ia.n = n; ia.epoch = e->epoch;
   hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
-  hipLaunchKernelGGL(k_insert2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
+  hipLaunchKernelGGL(k_insert2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia, d_records);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
   // ---- resolve
   ResolveArgs ra;
-  ra.records = d_records; ra.slot_id = d_slot; ra.canon = e->d_canon; ra.table = e->table;
-  ra.issuer_counts = e->issuer_counts; ra.pairs = e->pairs; ra.pmask = e->npairs - 1;
-  ra.stats = e->d_stats; ra.blk_new = d_blk_new; ra.n = n; ra.epoch = e->epoch;
+  ra.ent = d_ent; ra.issuer_counts = e->issuer_counts; ra.stats = e->d_stats; ra.blk_new = d_blk_new; ra.n = n;
   hipLaunchKernelGGL(k_resolve, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(1024), 0, e->stream, ra, nb);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[3], e->stream));
   DevStats hs;
@@ -639,10 +640,10 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   // ---- serials longer than CTMR_MAX_SERIAL: exact host-side set, in log order
   uint64_t host_new = 0;
   if (hs.n_host) {
-    std::vector<uint32_t> sid(n);
-    HIPCHK(e, hipMemcpy(sid.data(), d_slot, n * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> ent(n);
+    HIPCHK(e, hipMemcpy(ent.data(), d_ent, n * 4, hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; i++) {
-      if (sid[i] != SID_HOST) continue;
+      if (((ent[i] >> 3) & 7u) != ES_HOST) continue;
       uint64_t off[2];
       ctmr_record rec;
       HIPCHK(e, hipMemcpy(off, d_offsets + i, 16, hipMemcpyDeviceToHost));
@@ -660,6 +661,8 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
         e->host_issuer_counts[canon]++;
         uint8_t fl = rec.flags | CTMR_FL_WAS_UNKNOWN;
         HIPCHK(e, hipMemcpy((uint8_t*)(d_records + i) + 1, &fl, 1, hipMemcpyHostToDevice));
+        const uint32_t en = (ent[i] & ~(7u << 3)) | (ES_CLAIMED << 3);  // compaction reads ent[]
+        HIPCHK(e, hipMemcpy(d_ent + i, &en, 4, hipMemcpyHostToDevice));
         uint32_t bn;
         HIPCHK(e, hipMemcpy(&bn, d_blk_new + i / 1024, 4, hipMemcpyDeviceToHost));
         bn++;
@@ -670,7 +673,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   // ---- compaction of the NEW list
   if (d_new_idx) {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, d_records, n, d_blk_base, d_new_idx);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records, (const uint32_t*)d_ent, n, (const uint64_t*)d_blk_base, d_new_idx);
   }
   if (prof) HIPCHK(e, hipEventRecord(e->ev[4], e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -755,7 +758,7 @@ int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const 
   if (n == 0) return CTMR_OK;
   if (n >= 0xfffffff0ull) return fail(e, CTMR_E_INVAL, "batch too large (n < 2^32-16)");
   int r;
-  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records))) return r;
+  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, false))) return r;
   const uint64_t nb = (n + 1023) / 1024;
   const uint64_t ncnt = (uint64_t)world * nb;
   if ((r = ensure(e, SC_SLOTID, n))) return r;                 // owner byte per entry
@@ -834,8 +837,8 @@ int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t 
                      (const ctmr_record*)d_records, n, nb, e->d_stats);
   if (d_new_idx) {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records, n,
-                       (const uint64_t*)d_blk_base, d_new_idx);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records,
+                       (const uint32_t*)nullptr, n, (const uint64_t*)d_blk_base, d_new_idx);
   }
   DevStats hs;
   HIPCHK(e, hipMemcpyAsync(&hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));

@@ -261,11 +261,17 @@ struct MapArgs {
   uint32_t n_issuers;
   uint32_t certs_per_tile;
   uint32_t lds_bytes;  // dynamic LDS size of the launch
+  uint32_t optimistic_new;  // 1: PASS records leave the map with CTMR_FL_WAS_UNKNOWN already set — the
+                            // reduce only CLEARS it for the (rare) duplicates, so the common case costs
+                            // no second scattered write into the record array
 };
+
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
 // Everything after the bytes are addressable: walk, filters, record.
 template <class R>
-__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a) {
+__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, uint4& o0,
+                                        uint4& o1) {
   Walk w;
   const uint32_t L = (uint32_t)len64;
   const FilterDev* f = a.filt;
@@ -289,6 +295,7 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
     status = CTMR_ST_PASS;
   }
   uint32_t flags = (a.entry_type && a.entry_type[idx] == 1) ? CTMR_FL_PRECERT : 0u;
+  if (a.optimistic_new && status == CTMR_ST_PASS) flags |= CTMR_FL_WAS_UNKNOWN;
   uint32_t slen = 0, s[5] = {0, 0, 0, 0, 0};
   int32_t exp_hour = 0;
   if (ok) {
@@ -301,16 +308,44 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
 #pragma unroll
     for (int k = 0; k < 5; k++) s[k] = w.serial_w[k];
   }
+  o0 = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
+  o1 = make_uint4(s[1], s[2], s[3], s[4]);
+}
+
+template <class R>
+__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a) {
+  uint4 o0, o1;
+  map_one(r, len64, idx, a, o0, o1);
   uint4* out = (uint4*)(a.records + idx);
-  out[0] = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
-  out[1] = make_uint4(s[1], s[2], s[3], s[4]);
+  out[0] = o0;
+  out[1] = o1;
+}
+
+// Record store for the one-wave-per-workgroup window kernels: the 64 records of the wave (2 KiB,
+// contiguous) are transposed through LDS so that each of the two store instructions writes 1 KiB of
+// consecutive bytes (whole 64-B sectors) instead of 64 half-sectors 32 B apart.  The window area is
+// free by now: every lane of the wave has finished its walk.
+__device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t first, bool live, const uint4& o0,
+                                                   const uint4& o1) {
+  uint4* t = (uint4*)smem;
+  const uint32_t lane = threadIdx.x;
+  __builtin_amdgcn_wave_barrier();
+  if (live) {
+    t[2 * lane] = o0;
+    t[2 * lane + 1] = o1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t rem = a.n - first;  // records of this wave
+  const uint32_t nvec = rem >= 64 ? 128u : (uint32_t)rem * 2u;
+  uint4* out = (uint4*)(a.records + first);
+  if (lane < nvec) out[lane] = t[lane];
+  if (64u + lane < nvec) out[64 + lane] = t[64 + lane];
 }
 
 // LDS-tile map.  One wave per workgroup, one tile of `certs_per_tile` consecutive
 // certificates per workgroup: the tile's byte range [offsets[first], offsets[last+1]) is
 // contiguous in the packed payload, so it is copied with perfectly coalesced 16-B/lane loads
 // (1 KiB per wave instruction) into LDS; then lane l walks certificate first+l out of LDS.
-extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
 __global__ void __launch_bounds__(64) k_map_tile(MapArgs a) {
   const uint32_t lane = threadIdx.x;
@@ -379,31 +414,41 @@ __global__ void __launch_bounds__(256) k_map_direct(MapArgs a) {
 // 256-thread granule) sets the occupancy: 64 × (WCH·16+16) bytes per wave.
 template <int WCH>
 __global__ void __launch_bounds__(64) k_map_win(MapArgs a) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= a.n) return;
-  const uint64_t lo = a.offsets[i];
-  uint64_t hi = a.offsets[i + 1];
-  if (hi < lo) hi = lo;
-  constexpr uint32_t STRIDE = WCH * 16 + 16;
-  WinReader<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
-                   (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
-  r.refill(0);
-  map_one(r, hi - lo, i, a);
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint64_t i = first + threadIdx.x;
+  const bool live = i < a.n;
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    const uint64_t lo = a.offsets[i];
+    uint64_t hi = a.offsets[i + 1];
+    if (hi < lo) hi = lo;
+    constexpr uint32_t STRIDE = WCH * 16 + 16;
+    WinReader<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+                     (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
+    r.refill(0);
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
 }
 
 // Two-region window map (WinReader2): same walk, 2 dependent HBM round trips per certificate.
 template <int WCH>
 __global__ void __launch_bounds__(64) k_map_win2(MapArgs a) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= a.n) return;
-  const uint64_t lo = a.offsets[i];
-  uint64_t hi = a.offsets[i + 1];
-  if (hi < lo) hi = lo;
-  constexpr uint32_t STRIDE = (WCH + 3) * 16;
-  WinReader2<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
-                    (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0x7fffff00};
-  r.refill(0);
-  map_one(r, hi - lo, i, a);
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint64_t i = first + threadIdx.x;
+  const bool live = i < a.n;
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    const uint64_t lo = a.offsets[i];
+    uint64_t hi = a.offsets[i + 1];
+    if (hi < lo) hi = lo;
+    constexpr uint32_t STRIDE = (WCH + 3) * 16;
+    WinReader2<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+                      (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0x7fffff00};
+    r.refill(0);
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
 }
 
 // ------------------------------------------------------------------ the reduce
@@ -423,7 +468,8 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 // agent-scope loads (MI355X_MICROARCH.md "handoff-flag": write-through payload + drained flag).
 __device__ __forceinline__ uint32_t table_upsert(Slot* table, uint64_t mask, unsigned long long meta,
                                                  const unsigned long long s[5], uint32_t idx32,
-                                                 uint32_t epoch, bool insert, bool* created) {
+                                                 uint32_t epoch, bool insert, bool* created,
+                                                 unsigned long long* prev_w0 = nullptr) {
   const unsigned long long h = key_hash(meta, s);
   const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
   uint64_t j = h & mask;
@@ -453,7 +499,10 @@ __device__ __forceinline__ uint32_t table_upsert(Slot* table, uint64_t mask, uns
 #pragma unroll
       for (int k = 0; k < 5; k++) eq = eq && ld_agent(&sl->w[3 + k]) == s[k];
       if (eq) {
-        if (insert && idx32 != 0xffffffffu) atomicMin(&sl->w[0], tagw | idx32);
+        if (insert && idx32 != 0xffffffffu) {
+          const unsigned long long old = atomicMin(&sl->w[0], tagw | idx32);
+          if (prev_w0) *prev_w0 = old;
+        }
         return (uint32_t)j;
       }
     }
@@ -469,10 +518,35 @@ struct InsertArgs {
   const uint32_t* canon;   // issuer_idx → canonical issuer
   Slot* table;
   uint64_t mask;
-  uint32_t* slot_id;
+  uint32_t* slot_id;       // candidate slot of DEFER entries (written for those only)
+  uint32_t* ent;           // per entry: status(0..2) | state(3..5) | canonical issuer << 8
   uint64_t n;
   uint32_t epoch;
 };
+
+// Per-entry state of the reduce (bits 3..5 of ent[i]); the low 3 bits carry record.status.
+enum : uint32_t {
+  ES_NONE = 0,     // did not reach the set (filtered / parse error / no issuer)
+  ES_CLAIMED = 1,  // claimed an empty slot: WasUnknown unless a lower log index of the same key marks it
+  ES_DEFER = 2,    // met a same-tag slot of this batch: decided in pass 2; WasUnknown unless marked
+  ES_DUP = 3,      // known: since an earlier batch, or a lower log index of this batch holds the key
+  ES_HOST = 4,     // serial longer than CTMR_MAX_SERIAL: exact host-side set
+  ES_FULL = 5      // table full
+};
+__device__ __forceinline__ uint32_t ent_pack(uint32_t status, uint32_t state, uint32_t canon) {
+  return (status & 7u) | (state << 3) | (canon << 8);
+}
+__device__ __forceinline__ uint32_t ent_state(uint32_t e) { return (e >> 3) & 7u; }
+__device__ __forceinline__ bool ent_is_new(uint32_t e) {
+  const uint32_t st = ent_state(e);
+  return (st == ES_CLAIMED) | (st == ES_DEFER);
+}
+// a PASS entry lost to a lower log index of the same key: its ent byte 0 and its record flag
+__device__ __forceinline__ void mark_dup(uint32_t* ent, ctmr_record* records, uint32_t loser) {
+  ((uint8_t*)(ent + loser))[0] = (uint8_t)(CTMR_ST_PASS | (ES_DUP << 3));
+  uint8_t* fl = (uint8_t*)(records + loser) + 1;
+  *fl = (uint8_t)(*fl & ~CTMR_FL_WAS_UNKNOWN);
+}
 
 // Offset of the serialNumber content octets (certificate already accepted by the map).
 __device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, uint32_t L) {
@@ -488,8 +562,6 @@ __device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, ui
   rd_hdr(r, L, q, L, ok, tag, cs, ce);
   return cs;
 }
-
-constexpr uint32_t SID_DEFER = 0x80000000u;  // slot_id bit: candidate slot, full compare in pass 2
 
 __device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, const uint4& r0,
                                            const uint4& r1, unsigned long long s[5]) {
@@ -523,91 +595,133 @@ __device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, cons
 // KnownCertificates.WasUnknown → RemoteCache.SetInsert (knowncertificates.go:38-55) for every
 // PASS entry, against the in-HBM table.  PASS 1 (this kernel) never reads anything another lane
 // of the same launch wrote except the CAS word itself:
-//   empty slot      → one atomicCAS claims it; the key is written with plain wide stores
-//   same tag, slot of an OLDER batch (epoch in [1, cur)) → fully visible: compare now
-//   same tag, slot of THIS batch (epoch cur or not yet visible) → remember the slot, decide in
-//                     pass 2 after the kernel boundary has made every pass-1 store visible
-// so no write-through stores, drains or polling are needed on the common path.
+//   empty slot      → one atomicCAS claims it (state CLAIMED); the 64-byte slot image is written
+//                     after the probe loop, four lanes per slot, so that one store instruction emits
+//                     whole 64-byte slots (one memory transaction each) instead of four partial ones
+//   same tag, slot of an OLDER batch (epoch in [1, cur)) → fully visible: compare now (state DUP)
+//   same tag, slot of THIS batch (epoch 0 = not written yet, or cur) → remember the slot (state
+//                     DEFER), decide in pass 2 after the kernel boundary made every pass-1 store visible
+// Records arrive with WAS_UNKNOWN set optimistically by the map; it is cleared here / in pass 2
+// for duplicates only.  The reduce's later passes read the 4-byte ent[] word, never the table.
 __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 slot images
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  const uint4* rp = (const uint4*)(a.records + i);
-  const uint4 r0 = rp[0];
-  uint32_t sid = SID_NONE;
-  if ((r0.x & 0xffu) == CTMR_ST_PASS) {
-    const uint32_t slen = r0.x >> 16;
-    if (slen > CTMR_MAX_SERIAL) {
-      sid = SID_HOST;
-    } else {
-      const uint4 r1 = rp[1];
-      unsigned long long s[5];
-      record_key(a, i, r0, r1, s);
-      const unsigned long long meta = key_meta((int32_t)r0.y, a.canon[r0.z], slen);
-      const unsigned long long h = key_hash(meta, s);
-      const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
-      uint64_t j = h & a.mask;
-      sid = SID_FULL;
-      for (uint64_t probes = 0; probes <= a.mask; probes++) {
-        Slot* sl = a.table + j;
-        const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | (uint32_t)i);
-        if (old == 0ull) {  // claimed: write the key (w[0] stays atomic-only)
-          sl->w[1] = meta;
-          uint4* q = (uint4*)&sl->w[2];
-          q[0] = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
-          q[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
-          q[2] = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
-          sid = (uint32_t)j;
-          break;
-        }
-        if ((old & 0xffffffff00000000ull) == tagw) {
-          const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
-          if (ep != 0u && ep != a.epoch) {  // older batch: complete and visible
-            bool eq = sl->w[1] == meta;
-#pragma unroll
-            for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
-            if (eq) {
-              sid = SID_DUP_OLD;
-              break;
-            }
-          } else {
-            sid = (uint32_t)j | SID_DEFER;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t state = ES_NONE, status = CTMR_ST__COUNT, canon = 0;
+  uint64_t claimed = ~0ull;  // slot index when this lane claimed one
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  if (i < a.n) {
+    const uint4* rp = (const uint4*)(a.records + i);
+    const uint4 r0 = rp[0];
+    status = r0.x & 0xffu;
+    if (status == CTMR_ST_PASS) {
+      const uint32_t slen = r0.x >> 16;
+      canon = a.canon[r0.z];
+      if (slen > CTMR_MAX_SERIAL) {
+        state = ES_HOST;
+      } else {
+        const uint4 r1 = rp[1];
+        unsigned long long s[5];
+        record_key(a, i, r0, r1, s);
+        const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
+        const unsigned long long h = key_hash(meta, s);
+        const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+        uint64_t j = h & a.mask;
+        state = ES_FULL;
+        for (uint64_t probes = 0; probes <= a.mask; probes++) {
+          Slot* sl = a.table + j;
+          const unsigned long long w0 = tagw | (uint32_t)i;
+          const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
+          if (old == 0ull) {  // claimed
+            q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)meta, (uint32_t)(meta >> 32));
+            q1 = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+            q2 = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+            q3 = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+            claimed = j;
+            state = ES_CLAIMED;
             break;
           }
+          if ((old & 0xffffffff00000000ull) == tagw) {
+            const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
+            if (ep != 0u && ep != a.epoch) {  // older batch: complete and visible
+              bool eq = sl->w[1] == meta;
+#pragma unroll
+              for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+              if (eq) {
+                state = ES_DUP;
+                break;
+              }
+            } else {
+              a.slot_id[i] = (uint32_t)j;
+              state = ES_DEFER;
+              break;
+            }
+          }
+          j = (j + 1) & a.mask;
         }
-        j = (j + 1) & a.mask;
+      }
+      if (state != ES_CLAIMED && state != ES_DEFER) {  // not (yet) unknown: drop the optimistic flag
+        uint8_t* fl = (uint8_t*)(a.records + i) + 1;
+        *fl = (uint8_t)((r0.x >> 8) & ~CTMR_FL_WAS_UNKNOWN);
       }
     }
+    a.ent[i] = ent_pack(status, state, canon);
   }
-  a.slot_id[i] = sid;
+  // ---- cooperative slot write: lane L parks its 64-byte image at img[wv][L*4 .. L*4+3]; store
+  // instruction r then has lane L write quarter L%4 of the slot of lane 16r + L/4, so four adjacent
+  // lanes emit one whole slot.  (w[0] is rewritten with the value the CAS stored: concurrent CAS
+  // attempts of this pass see a non-zero word either way; atomicMin only runs in pass 2.)
+  uint4* my = &img[wv][lane * 4];
+  my[0] = q0; my[1] = q1; my[2] = q2; my[3] = q3;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t src = 16u * r + (lane >> 2);
+    const uint64_t sj = __shfl(claimed, src);
+    if (sj != ~0ull) {
+      const uint4 v = img[wv][r * 64 + lane];
+      ((uint4*)(a.table + sj))[lane & 3u] = v;
+    }
+  }
 }
 
-// PASS 2: entries whose candidate slot was created by the same batch.  Everything pass 1 wrote
-// is visible now.  Equal key → merge the batch index (lowest log index wins); a 32-bit tag
-// collision between different keys (≈2^-32 per probe) falls back to the fully synchronised
-// upsert, which is also safe against other pass-2 lanes inserting the same key concurrently.
-__global__ void __launch_bounds__(256) k_insert2(InsertArgs a) {
+// PASS 2: DEFER entries — their candidate slot was created by this batch and is complete now.
+// Equal key → atomicMin the batch index into w[0]; the RETURNED previous minimum tells who loses:
+// whichever of (previous holder, me) has the higher log index is marked DUP, so after this pass
+// exactly the lowest log index of every new key is still CLAIMED/DEFER — nobody has to re-read the
+// table to find out.  A 32-bit tag collision between different keys (≈2^-32 per probe) falls back
+// to the fully synchronised upsert, which is also safe against other pass-2 lanes inserting the
+// same key concurrently.
+__global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* records) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  uint32_t sid = a.slot_id[i];
-  if (sid >= SID_DUP_OLD || !(sid & SID_DEFER)) return;
-  sid &= ~SID_DEFER;
+  const uint32_t e = a.ent[i];
+  if (ent_state(e) != ES_DEFER) return;
+  const uint32_t sid = a.slot_id[i];
   const uint4* rp = (const uint4*)(a.records + i);
   const uint4 r0 = rp[0], r1 = rp[1];
   unsigned long long s[5];
   record_key(a, i, r0, r1, s);
-  const unsigned long long meta = key_meta((int32_t)r0.y, a.canon[r0.z], r0.x >> 16);
+  const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
   Slot* sl = a.table + sid;
   bool eq = sl->w[1] == meta;
 #pragma unroll
   for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+  unsigned long long prev = ~0ull;
   if (eq) {
     const unsigned long long tagw = (unsigned long long)key_tag(key_hash(meta, s)) << 32;
-    atomicMin(&sl->w[0], tagw | (uint32_t)i);
+    prev = atomicMin(&sl->w[0], tagw | (uint32_t)i);
   } else {
     bool created;
-    sid = table_upsert(a.table, a.mask, meta, s, (uint32_t)i, a.epoch, true, &created);
+    const uint32_t r = table_upsert(a.table, a.mask, meta, s, (uint32_t)i, a.epoch, true, &created, &prev);
+    if (r == SID_FULL) {
+      ((uint8_t*)(a.ent + i))[0] = (uint8_t)(CTMR_ST_PASS | (ES_FULL << 3));
+      return;
+    }
+    if (created) return;  // stays DEFER = unknown unless a lower index joins and marks it
   }
-  a.slot_id[i] = sid;
+  const uint32_t other = (uint32_t)prev;
+  mark_dup(a.ent, records, other < (uint32_t)i ? (uint32_t)i : other);
 }
 
 // Wave-aggregated add: one atomic per distinct key per wave (the "match-any" loop).
@@ -641,21 +755,16 @@ __device__ __forceinline__ bool pair_add(PairSlot* pairs, uint64_t pmask, unsign
 }
 
 struct ResolveArgs {
-  ctmr_record* records;
-  const uint32_t* slot_id;
-  const uint32_t* canon;
-  const Slot* table;
+  const uint32_t* ent;
   unsigned long long* issuer_counts;  // per canonical issuer
-  PairSlot* pairs;
-  uint64_t pmask;
   DevStats* stats;
   uint32_t* blk_new;  // NEW count per 1024-entry block
   uint64_t n;
-  uint32_t epoch;
 };
 
-// Decide WasUnknown for every PASS entry (lowest batch index of a new key wins — what the
-// reference does with numThreads = 1), bump counters, histogram statuses.
+// One streaming pass over ent[] (4 bytes per entry; no table or record access): per-issuer unique
+// counts of the entries that WERE unknown (Σ_expDate SCARD, storage-statistics.go:44-53), status
+// histogram, NEW count per 1024-entry block for the compaction.
 // Persistent blocks: per-issuer counts are first accumulated in an LDS histogram (issuers
 // below RES_LDS_ISSUERS) and flushed with ONE global atomic per non-empty bin per block —
 // hundreds of thousands of device atomics on the few cache lines of the hot issuers serialise
@@ -676,25 +785,15 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
     bool is_new = false, is_dup = false, is_host = false, is_full = false;
     uint32_t status = CTMR_ST__COUNT, canon = 0;
     if (i < a.n) {
-      const uint32_t head = *(const uint32_t*)(a.records + i);
-      status = head & 0xffu;
-      const uint32_t sid = a.slot_id[i];
-      if (sid == SID_HOST) {
-        is_host = true;
-      } else if (sid == SID_FULL) {
-        is_full = true;
-      } else if (sid == SID_DUP_OLD) {
-        is_dup = true;  // known since an earlier batch: nothing to look up
-      } else if (sid != SID_NONE) {
-        const Slot* sl = a.table + sid;
-        const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
-        is_new = (uint32_t)w2 == a.epoch && (uint32_t)w0 == (uint32_t)i;
-        is_dup = !is_new;
-        canon = (uint32_t)(w1 >> 32) & 0xffffffu;
-        if (is_new) ((uint8_t*)(a.records + i))[1] = (uint8_t)((head >> 8) | CTMR_FL_WAS_UNKNOWN);
-      }
+      const uint32_t e = a.ent[i];
+      status = e & 7u;
+      const uint32_t st = ent_state(e);
+      canon = e >> 8;
+      is_new = (st == ES_CLAIMED) | (st == ES_DEFER);
+      is_dup = st == ES_DUP;
+      is_host = st == ES_HOST;
+      is_full = st == ES_FULL;
     }
-    // per-issuer unique counts: Σ_expDate SCARD (storage-statistics.go:44-53)
     if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
     wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, a.issuer_counts);
     // (the per-(expDate, issuer) cardinalities are rebuilt lazily by k_build_pairs on the first
@@ -735,14 +834,16 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
 }
 
 // Stream compaction of the NEW entries, ascending: wave ballot + popcount prefix inside a
-// 1024-entry block, block bases from the exclusive scan of blk_new.
-__global__ void __launch_bounds__(1024) k_compact(const ctmr_record* records, uint64_t n,
+// 1024-entry block, block bases from the exclusive scan of blk_new.  The NEW predicate comes
+// from ent[] (local reduce) or from the record flag (exchange mode, ent == nullptr).
+__global__ void __launch_bounds__(1024) k_compact(const ctmr_record* records, const uint32_t* ent, uint64_t n,
                                                   const uint64_t* blk_base, uint64_t* new_idx) {
   __shared__ uint32_t wave_cnt[16];
   const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   bool is_new = false;
-  if (i < n) is_new = (((const uint8_t*)(records + i))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
+  if (i < n)
+    is_new = ent ? ent_is_new(ent[i]) : (((const uint8_t*)(records + i))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
   const unsigned long long m = __ballot(is_new);
   if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
   __syncthreads();
@@ -795,6 +896,7 @@ struct KeyRec {  // 64 bytes
 static_assert(sizeof(KeyRec) == 64, "KeyRec");
 
 constexpr uint32_t KEY_NO_OWNER = 0xffu;
+constexpr uint32_t SID_DEFER = 0x80000000u;  // slot_id bit (owner-side kernels): candidate slot, full compare in pass 2
 constexpr uint32_t MAX_WORLD = 16;
 
 __device__ __forceinline__ bool entry_key(const InsertArgs& a, uint64_t i, unsigned long long& meta,
