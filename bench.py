@@ -26,6 +26,10 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32
 
 
+MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 3: "k_map_win<16>", 4: "k_map_win<8>", 5: "k_map_win<12>",
+               6: "k_map_win<14>", 7: "k_map_win2<16>", 8: "k_map_win2<14>", 9: "k_map_win2<12>"}
+
+
 def pow2_at_least(v):
     p = 1
     while p < v:
@@ -66,8 +70,10 @@ def main():
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per map launch from a separate rocprofv3 --pmc pass")
+    ap.add_argument("--traffic-file", default=None,
+                    help="JSON written by scripts/make_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / "
+                         "WRITE_SIZE passes of this command (default: profiles/traffic_map.json when it was "
+                         "measured on the same entries/variant)")
     args = ap.parse_args()
 
     import numpy as np
@@ -161,6 +167,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # HBM traffic of the map kernel per launch: PMC counters can only be collected under rocprofv3, in their
+    # own passes; the committed measurement of the same command is reported when workload and kernel match.
+    traffic = None
+    traffic_src = None
+    tf = args.traffic_file or os.path.join(ROOT, "profiles", "traffic_map.json")
+    if os.path.exists(tf):
+        try:
+            t = json.load(open(tf))
+            if int(t.get("entries", -1)) == E and int(t.get("map_variant", -1)) == (args.variant or 3):
+                traffic = t.get("traffic_bytes")
+                traffic_src = os.path.relpath(tf, ROOT)
+        except (ValueError, OSError):
+            pass
+
     n_total = E * world
     value = n_total * args.steps / dt
     alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E
@@ -177,9 +197,10 @@ def main():
                    "entries_per_gpu": E, "mean_der_bytes": stats.payload_bytes / E,
                    "parallelism": f"log-index shards x{world}", "map_variant": args.variant or 3,
                    "gen_seconds": round(t_gen, 2)},
-        "roofline": {"bound": "hbm", "kernel": {1: "k_map_tile", 2: "k_map_direct", 3: "k_map_win<16>", 4: "k_map_win<8>"}[args.variant or 3],
+        "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or 3],
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic_bytes,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms},
         "kernel_ms": {"map": stats.ms_map, "insert": stats.ms_insert, "resolve": stats.ms_resolve,
                       "compact": stats.ms_compact, "total": stats.ms_total},

@@ -174,8 +174,10 @@ CTMR_HD bool string_tag(uint32_t t) {
 // `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
 // windowed reader that about `need` bytes from pos are read next; r.touch_tail(pos, tail) that the
 // bytes from pos AND the bytes at `tail` are read next; other readers ignore both.
+// The filter view is passed BY VALUE (use_filter + fv): a pointer that is either &local or null makes
+// the compiler materialise the view in scratch memory — 28 bytes of HBM writes per certificate.
 template <class R>
-CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr) {
+CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv) {
   o.serial_off = o.serial_len = 0;
 #pragma unroll
   for (int k = 0; k < 5; k++) o.serial_w[k] = 0;
@@ -254,7 +256,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nul
         a = e1;
       }
     }
-    if (filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, *filter) : false;
+    if (use_filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, fv) : false;
   }
   q = ce;
   r.touch(q, 48);
@@ -353,6 +355,11 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nul
     }
   }
   return ok;
+}
+
+template <class R>
+CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr) {
+  return filter ? walk_cert(r, L, o, true, *filter) : walk_cert(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
 }
 
 }  // namespace ctmr

@@ -276,7 +276,7 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   const uint32_t L = (uint32_t)len64;
   const FilterDev* f = a.filt;
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
-  const bool ok = len64 <= 0x7fffffffull && walk_cert(r, L, w, f->active ? &fv : nullptr);
+  const bool ok = len64 <= 0x7fffffffull && walk_cert(r, L, w, f->active != 0u, fv);
   const uint32_t iss = a.issuer_idx[idx];
   uint32_t status;
   if (!ok) {

@@ -58,6 +58,45 @@ __global__ void __launch_bounds__(64) k_win(const uint8_t* buf, uint64_t lanes, 
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// streaming write, 16 B per lane, coalesced (WRITE_SIZE calibration)
+__global__ void __launch_bounds__(256) k_fill(uint4* p, uint64_t nvec) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * 256)
+    p[i] = make_uint4((uint32_t)i, 1u, 2u, 3u);
+}
+
+// the reduce's access pattern: one 64-bit atomicCAS on a random 64-byte slot of a large table, then the
+// whole 64-byte slot written by four adjacent lanes (k_insert's cooperative store).  mode 0: CAS only,
+// 1: CAS + slot store, 2: plain 16-byte load of the slot instead of the CAS (random read ceiling)
+__global__ void __launch_bounds__(256) k_rand_rmw(unsigned long long* table, uint64_t mask, uint64_t n, int mode,
+                                                  uint32_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  unsigned long long z = (i + 1) * 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  const uint64_t j = z & mask;
+  unsigned long long old = 1;
+  if (i < n) {
+    if (mode == 2) {
+      const uint4 v = *(const uint4*)(table + j * 8);
+      old = v.x | v.y;
+    } else {
+      old = atomicCAS(table + j * 8, 0ull, z | 1ull);
+    }
+  }
+  if (mode == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t src = 16u * r + (lane >> 2);
+      const uint64_t sj = __shfl(j, src);
+      const unsigned long long so = __shfl(old, src);
+      if (so == 0ull) ((uint4*)(table + sj * 8))[lane & 3u] = make_uint4((uint32_t)z | 1u, 7u, (uint32_t)sj, lane);
+    }
+  }
+  if (old == 0x1234567ull) out[0] = 1;
+}
+
 static double unique_bytes(uint64_t lanes, uint32_t stride, uint32_t off, uint32_t wstep, int nwin, uint32_t gran) {
   // windows of one lane do not overlap windows of another when stride >= off + nwin*wstep + 256
   double tot = 0;
@@ -121,6 +160,35 @@ int main(int argc, char** argv) {
                u128 / ms / 1e6);
       }
     }
+  }
+  // ---- WRITE_SIZE calibration: coalesced fill of the whole buffer
+  for (int rep = 0; rep < 2; rep++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_fill, dim3(256 * 16), dim3(256), 0, 0, (uint4*)buf, bytes / 16);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep)
+      printf("{\"kernel\": \"k_fill\", \"bytes\": %.0f, \"ms\": %.4f, \"GBps\": %.1f}\n", (double)bytes, ms,
+             bytes / ms / 1e6);
+  }
+  // ---- random 64-byte-slot RMW ceiling (the known-certificate insert), table = 2^27 slots (8.6 GB), load 0.35
+  {
+    const uint64_t slots = 1ull << 27, nkeys = 47000000ull;
+    unsigned long long* table;
+    CK(hipMalloc(&table, slots * 64));
+    for (int mode = 0; mode < 3; mode++) {
+      CK(hipMemset(table, 0, slots * 64));
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_rand_rmw, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, 0, table, slots - 1, nkeys, mode, out);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("{\"kernel\": \"k_rand_rmw\", \"mode\": %d, \"keys\": %llu, \"slots\": %llu, \"ms\": %.4f, \"Gkeys_per_s\": %.2f}\n",
+             mode, (unsigned long long)nkeys, (unsigned long long)slots, ms, nkeys / ms / 1e6);
+    }
+    CK(hipFree(table));
   }
   CK(hipDeviceSynchronize());
   return 0;
