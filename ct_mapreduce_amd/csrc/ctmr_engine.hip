@@ -553,7 +553,7 @@ static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* 
   ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
   ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
   ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
-  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 3;
+  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 13;
   uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
   if (C > 64) C = 64;
   uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;
@@ -569,6 +569,14 @@ static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* 
     hipLaunchKernelGGL(k_map_win<12>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (12 * 16 + 16), e->stream, ma);
   } else if (variant == 6) {
     hipLaunchKernelGGL(k_map_win<14>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (14 * 16 + 16), e->stream, ma);
+  } else if (variant == 13) {
+    hipLaunchKernelGGL(k_map_winc<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
+  } else if (variant == 10) {
+    hipLaunchKernelGGL((k_map_wint<16, 192, 208>), dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
+  } else if (variant == 11) {
+    hipLaunchKernelGGL((k_map_wint<16, 208, 224>), dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
+  } else if (variant == 12) {
+    hipLaunchKernelGGL((k_map_wint<16, 176, 192>), dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
   } else if (variant == 7) {
     hipLaunchKernelGGL(k_map_win2<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (19 * 16), e->stream, ma);
   } else if (variant == 8) {

@@ -187,7 +187,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   o.spki_off = o.spki_len = 0;
   o.bc_valid = o.is_ca = false;
   bool ok = L <= 0x7fffffffu;
-  if (!ok) return false;
+  L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
   uint32_t tag, cs, ce;
   r.touch(0, 256);
   // Certificate ::= SEQUENCE filling the buffer exactly

@@ -90,6 +90,88 @@ struct WinReader {
   __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, 256); }
 };
 
+// WinReader whose touch_tail() (the one refill every lane of the wave reaches at the same program point,
+// right behind the SubjectPublicKeyInfo header) is wave-cooperative like the first fill of k_map_winc:
+// 16 adjacent lanes fetch the 16 chunks of one certificate's window, 4 certificates per load
+// instruction.  Falls back to the per-lane refill when some lane of the wave is not at that point.
+template <int WCH>
+struct WinReaderC : WinReader<WCH> {
+  static constexpr uint32_t STRIDE = WCH * 16 + 16;
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) {
+    if (__ballot(1) != ~0ull) {
+      this->refill(pos);
+      return;
+    }
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 15u;
+    const uint64_t g_me = (this->base + pos) & ~15ull;
+    this->grel = (int32_t)(int64_t)(g_me - this->base);
+    uint8_t* lds0 = (uint8_t*)this->win - lane * STRIDE;
+    uint4 v[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+      const uint64_t at = g + 16u * sub;
+      v[it] = (at + 16u <= this->limit) ? *((const uint4*)this->g32 + (at >> 4)) : make_uint4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      *(uint4*)(lds0 + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+// Line-trimmed window.  HBM is fetched in 128-byte lines (scripts/calib_fetch.hip: FETCH_SIZE x2 equals
+// the unique 128-B lines of every window pattern tried), so a refill that ends in the middle of a line
+// pays for the whole line and keeps only part of it.  This reader ends every refill at the end of the
+// line that holds byte pos+N-1 (N = bytes the walk is expected to need from there: NF for the front of
+// the certificate, NE for the extension block and on-demand refills), capped at WCH chunks: a 256-byte
+// refill at a random 16-byte phase touches 2.875 lines on average, a trimmed one 2.4.  Shorter windows
+// only ever cost an extra refill — ld4 falls back to global loads outside the window as before.
+template <int WCH, int NF, int NE>
+struct WinReaderT {
+  const uint32_t* g32;
+  uint64_t base;
+  uint64_t limit;
+  uint32_t* win;
+  int32_t grel;
+  uint32_t wlen;  // valid bytes in the window (multiple of 16)
+
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel + 8u <= wlen && rel < 0x7fffffffu) {
+      const uint32_t i = rel >> 2;
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
+    }
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ void refill(uint32_t pos, uint32_t n) {
+    const uint64_t p = base + pos;
+    const uint64_t g = p & ~15ull;
+    const uint64_t end = ((p + n - 1u) | 127ull) + 1ull;
+    grel = (int32_t)(int64_t)(g - base);
+    uint32_t cnt = (uint32_t)((end - g) >> 4);
+    cnt = cnt < (uint32_t)WCH ? cnt : (uint32_t)WCH;
+    const uint64_t room = limit > g ? (limit - g) >> 4 : 0ull;
+    cnt = room < cnt ? (uint32_t)room : cnt;
+    wlen = cnt * 16u;
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    uint4 v[WCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++) v[k] = (uint32_t)k < cnt ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+  }
+  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
+    if (need > (uint32_t)NE) need = NE;
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel + need > wlen || rel >= 0x7fffffffu) refill(pos, NE);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, NE); }
+};
+
 // Two-region window: MAIN (WCH chunks, moves with the walk) + TAIL (3 chunks pinned at the end of
 // the TBSCertificate: signatureAlgorithm and the BIT STRING header of signatureValue).  The walk
 // knows both addresses as soon as it has decoded the SubjectPublicKeyInfo header — the extension
@@ -273,10 +355,10 @@ template <class R>
 __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, uint4& o0,
                                         uint4& o1) {
   Walk w;
-  const uint32_t L = (uint32_t)len64;
+  const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
   const FilterDev* f = a.filt;
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
-  const bool ok = len64 <= 0x7fffffffull && walk_cert(r, L, w, f->active != 0u, fv);
+  const bool ok = walk_cert(r, L, w, f->active != 0u, fv);  // L > 2^31-1 is rejected inside, without divergence
   const uint32_t iss = a.issuer_idx[idx];
   uint32_t status;
   if (!ok) {
@@ -426,6 +508,69 @@ __global__ void __launch_bounds__(64) k_map_win(MapArgs a) {
     WinReader<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
                      (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
     r.refill(0);
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
+}
+
+// Window map with a wave-cooperative first fill: instead of every lane issuing 16 loads of ITS certificate
+// (64 uncoalesced 16-byte requests per instruction), 16 adjacent lanes fetch the 16 chunks of one
+// certificate's front window, 4 certificates per instruction — the texture addresser sees 8 lanes per
+// 128-byte line — and each lane parks its chunk directly in the owning lane's LDS window.
+template <int WCH>
+__global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
+  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t i = first + lane;
+  const bool live = i < a.n;
+  constexpr uint32_t STRIDE = WCH * 16 + 16;
+  const uint64_t limit = a.offsets[a.n] + CTMR_PAYLOAD_PAD;
+  uint64_t lo = 0, hi = 0;
+  if (live) {
+    lo = a.offsets[i];
+    hi = a.offsets[i + 1];
+    if (hi < lo) hi = lo;
+  }
+  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
+  {
+    uint4 v[16];
+    const uint32_t sub = lane & 15u;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+      const uint64_t at = g + 16u * sub;
+      v[it] = (g != ~0ull && at + 16u <= limit) ? *(const uint4*)(a.payload + at) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                       (int32_t)(int64_t)(g_me - lo)}};
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
+}
+
+// Line-trimmed window map (WinReaderT).
+template <int WCH, int NF, int NE>
+__global__ void __launch_bounds__(64) k_map_wint(MapArgs a) {
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint64_t i = first + threadIdx.x;
+  const bool live = i < a.n;
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    const uint64_t lo = a.offsets[i];
+    uint64_t hi = a.offsets[i + 1];
+    if (hi < lo) hi = lo;
+    constexpr uint32_t STRIDE = WCH * 16 + 16;
+    WinReaderT<WCH, NF, NE> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+                              (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0};
+    r.refill(0, NF);
     map_one(r, hi - lo, i, a, o0, o1);
   }
   store_records_wave(a, first, live, o0, o1);
