@@ -79,6 +79,8 @@ SIGNATURES = {
     "ctmr_exchange_insert_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "ctmr_exchange_apply_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
                                              C.POINTER(BatchStats)]),
+    "ctmr_pem_encode_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
+    "ctmr_pem_new": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "ctmr_synth_leaf_len": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64]),
     "ctmr_synth_leaf": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64, _P, C.c_uint32,
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),

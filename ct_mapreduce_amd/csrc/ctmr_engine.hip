@@ -155,8 +155,11 @@ struct ctmr_engine {
   DevStats* d_stats = nullptr;
   uint32_t* d_result = nullptr;        // 2 words for point ops
   unsigned long long* d_count = nullptr;
-  void* d_scratch[8] = {};             // growable buffers
-  size_t scratch_cap[8] = {};
+  void* d_scratch[12] = {};            // growable buffers
+  size_t scratch_cap[12] = {};
+  // the last ctmr_map_batch (host variant): what ctmr_pem_new encodes
+  uint64_t last_n = 0, last_n_new = 0;
+  size_t last_o_off = 0, last_o_new = 0;
   hipEvent_t ev[8] = {};
   // host-side store: non-table keys + members with serials longer than CTMR_MAX_SERIAL
   std::map<std::string, std::set<std::string>> hstore;
@@ -166,7 +169,7 @@ struct ctmr_engine {
 
 namespace {
 
-enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC };
+enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP };
 
 int fail(const ctmr_engine* e, int code, const char* fmt, ...) {
   char buf[512];
@@ -748,6 +751,78 @@ int ctmr_map_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offse
   if (records) HIPCHK(e, hipMemcpy(records, e->d_scratch[SC_RECORDS], n * sizeof(ctmr_record), hipMemcpyDeviceToHost));
   if (new_idx && st.n_new) HIPCHK(e, hipMemcpy(new_idx, B + o_new, st.n_new * 8, hipMemcpyDeviceToHost));
   if (stats) *stats = st;
+  e->last_n = n; e->last_n_new = new_idx ? st.n_new : 0; e->last_o_off = o_off; e->last_o_new = o_new;
+  return CTMR_OK;
+}
+
+// ------------------------------------------------------------------ PEM write-back (N1)
+
+static int pem_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                             const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,
+                             uint64_t* d_pem_offsets, uint64_t* pem_bytes) {
+  HIPCHK(e, hipSetDevice(e->device));
+  if (pem_bytes) *pem_bytes = 0;
+  if (n_idx == 0) {
+    if (d_pem_offsets) HIPCHK(e, hipMemsetAsync(d_pem_offsets, 0, 8, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return CTMR_OK;
+  }
+  if (n_idx >= 0x7fffffffull) return fail(e, CTMR_E_INVAL, "too many certificates in one PEM call");
+  hipLaunchKernelGGL(k_pem_len, dim3((unsigned)((n_idx + 1 + 255) / 256)), dim3(256), 0, e->stream, d_offsets, d_idx,
+                     n_idx, d_pem_offsets);
+  size_t tmp_bytes = 0;
+  HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_pem_offsets, d_pem_offsets, (int64_t)(n_idx + 1), e->stream));
+  int r;
+  if ((r = ensure(e, SC_TMP, tmp_bytes))) return r;
+  HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->d_scratch[SC_TMP], tmp_bytes, d_pem_offsets, d_pem_offsets,
+                                             (int64_t)(n_idx + 1), e->stream));
+  uint64_t total = 0;
+  HIPCHK(e, hipMemcpyAsync(&total, d_pem_offsets + n_idx, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (pem_bytes) *pem_bytes = total;
+  if (!d_pem) return CTMR_OK;  // size query
+  if (total > pem_cap) return fail(e, CTMR_E_RANGE, "PEM buffer too small: need %llu bytes", (unsigned long long)total);
+  hipLaunchKernelGGL(k_pem_encode, dim3((unsigned)n_idx), dim3(128), 0, e->stream, d_payload, d_offsets, d_idx,
+                     (const uint64_t*)d_pem_offsets, d_pem);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  return CTMR_OK;
+}
+
+int ctmr_pem_encode_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                           const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,
+                           uint64_t* d_pem_offsets, uint64_t* pem_bytes) {
+  if (!e || !d_pem_offsets || (n_idx && (!d_payload || !d_offsets || !d_idx))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return pem_device_locked(e, d_payload, d_offsets, d_idx, n_idx, d_pem, pem_cap, d_pem_offsets, pem_bytes);
+}
+
+int ctmr_pem_new(ctmr_engine* e, uint8_t* out, size_t cap, uint64_t* pem_offsets, size_t* need, uint64_t* count) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  const uint64_t nn = e->last_n_new;
+  if (count) *count = nn;
+  if (need) *need = 0;
+  if (nn == 0) {
+    if (pem_offsets) pem_offsets[0] = 0;
+    return CTMR_OK;
+  }
+  int r;
+  if ((r = ensure(e, SC_PEMOFF, (nn + 1) * 8))) return r;
+  uint8_t* B = (uint8_t*)e->d_scratch[SC_STAGE_B];
+  uint64_t* d_po = (uint64_t*)e->d_scratch[SC_PEMOFF];
+  uint64_t total = 0;
+  r = pem_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)(B + e->last_o_off),
+                        (const uint64_t*)(B + e->last_o_new), nn, nullptr, 0, d_po, &total);
+  if (r) return r;
+  if (need) *need = total;
+  if (!out || cap < total) return out ? fail(e, CTMR_E_RANGE, "PEM buffer too small: need %llu bytes", (unsigned long long)total) : CTMR_E_RANGE;
+  if ((r = ensure(e, SC_PEM, total + 64))) return r;
+  r = pem_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)(B + e->last_o_off),
+                        (const uint64_t*)(B + e->last_o_new), nn, (uint8_t*)e->d_scratch[SC_PEM], total + 64, d_po, &total);
+  if (r) return r;
+  HIPCHK(e, hipMemcpy(out, e->d_scratch[SC_PEM], total, hipMemcpyDeviceToHost));
+  if (pem_offsets) HIPCHK(e, hipMemcpy(pem_offsets, d_po, (nn + 1) * 8, hipMemcpyDeviceToHost));
   return CTMR_OK;
 }
 

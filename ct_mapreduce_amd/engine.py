@@ -154,6 +154,29 @@ class Engine:
             C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
         return st
 
+    # ---- PEM write-back (N1): pem.EncodeToMemory of the newly unknown certificates, on the GPU
+    def pem_new(self):
+        """PEM blocks (bytes) of every WAS_UNKNOWN entry of the last map_batch(), ascending entry order."""
+        need, count = C.c_size_t(0), C.c_uint64(0)
+        rc = self._lib.ctmr_pem_new(self._h, None, 0, None, C.byref(need), C.byref(count))
+        if rc not in (0, N.E_RANGE):
+            self._ck(rc)
+        if count.value == 0:
+            return []
+        out = np.zeros(need.value, np.uint8)
+        offs = np.zeros(count.value + 1, np.uint64)
+        self._ck(self._lib.ctmr_pem_new(self._h, out.ctypes.data, out.size, offs.ctypes.data, C.byref(need),
+                                        C.byref(count)))
+        raw = out.tobytes()
+        return [raw[int(offs[k]):int(offs[k + 1])] for k in range(count.value)]
+
+    def pem_encode_device(self, d_payload, d_offsets, d_idx, n_idx, d_pem, pem_cap, d_pem_offsets) -> int:
+        total = C.c_uint64(0)
+        self._ck(self._lib.ctmr_pem_encode_device(
+            self._h, C.c_void_p(d_payload), C.c_void_p(d_offsets), C.c_void_p(d_idx), n_idx,
+            C.c_void_p(d_pem) if d_pem else None, pem_cap, C.c_void_p(d_pem_offsets), C.byref(total)))
+        return int(total.value)
+
     # ---- cross-GPU key exchange (global dedup), device pointers as ints
     KEY_BYTES = 64
 

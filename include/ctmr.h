@@ -209,6 +209,20 @@ int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t 
                                const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx,
                                ctmr_batch_stats* stats);
 
+/* ---- PEM write-back: replaces pem.EncodeToMemory(&pem.Block{Type: "CERTIFICATE",
+ *      Bytes: aCert.Raw}) of FilesystemDatabase.Store (storage/filesystemdatabase.go:167-175,196-200); the host
+ *      hands each PEM to StorageBackend.StoreCertificatePEM (storage/localdiskbackend.go:194-199).
+ *   device variant: d_idx = n_idx entry indices (e.g. the new_idx list of ctmr_map_batch_device); PEM r is written
+ *           at d_pem + d_pem_offsets[r]; d_pem_offsets has n_idx+1 slots; *pem_bytes = total.  With d_pem == NULL
+ *           only the offsets and the total are produced (size query).
+ *   ctmr_pem_new: PEM of every CTMR_FL_WAS_UNKNOWN entry of the LAST ctmr_map_batch (host variant, called with
+ *           new_idx != NULL), ascending entry order; *need = bytes required (CTMR_E_RANGE when cap is smaller),
+ *           *count = number of PEMs, pem_offsets = count+1 offsets into out (may be NULL). ---- */
+int ctmr_pem_encode_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                           const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,
+                           uint64_t* d_pem_offsets, uint64_t* pem_bytes);
+int ctmr_pem_new(ctmr_engine* e, uint8_t* out, size_t cap, uint64_t* pem_offsets, size_t* need, uint64_t* count);
+
 /* ---- benchmark / test input generator (SURVEY.md §8(d) synthetic CT batch); not part of the
  *      reference's surface.  Deterministic in (seed, index); host and device emit identical bytes. */
 typedef struct {

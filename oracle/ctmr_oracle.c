@@ -384,6 +384,51 @@ size_t orc_b64url(const uint8_t* in, size_t n, char* out) {
   return o;
 }
 
+/* pem.EncodeToMemory(&pem.Block{Type: "CERTIFICATE", Headers: {}, Bytes: der}) as called by
+ * FilesystemDatabase.Store (storage/filesystemdatabase.go:167-175,196-200).  Go stdlib encoding/pem
+ * Encode: "-----BEGIN " Type "-----\n", no header block when len(Headers) == 0, then base64.StdEncoding
+ * through a lineBreaker (64 characters then "\n"; Close() flushes a non-empty last line plus "\n"),
+ * then "-----END " Type "-----\n".  Returns the length; out needs 28 + 4*ceil(n/3)*(65/64)+1 + 26. */
+size_t orc_pem_encode(const uint8_t* der, size_t n, char* out) {
+  static const char A[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  size_t o = 0, col = 0, i = 0;
+  memcpy(out + o, "-----BEGIN CERTIFICATE-----\n", 28);
+  o += 28;
+#define PUTC(ch)                 \
+  do {                           \
+    out[o++] = (ch);             \
+    if (++col == 64) {           \
+      out[o++] = '\n';           \
+      col = 0;                   \
+    }                            \
+  } while (0)
+  for (; i + 3 <= n; i += 3) {
+    uint32_t v = ((uint32_t)der[i] << 16) | ((uint32_t)der[i + 1] << 8) | der[i + 2];
+    PUTC(A[(v >> 18) & 63]);
+    PUTC(A[(v >> 12) & 63]);
+    PUTC(A[(v >> 6) & 63]);
+    PUTC(A[v & 63]);
+  }
+  if (n - i == 1) {
+    uint32_t v = (uint32_t)der[i] << 16;
+    PUTC(A[(v >> 18) & 63]);
+    PUTC(A[(v >> 12) & 63]);
+    PUTC('=');
+    PUTC('=');
+  } else if (n - i == 2) {
+    uint32_t v = ((uint32_t)der[i] << 16) | ((uint32_t)der[i + 1] << 8);
+    PUTC(A[(v >> 18) & 63]);
+    PUTC(A[(v >> 12) & 63]);
+    PUTC(A[(v >> 6) & 63]);
+    PUTC('=');
+  }
+#undef PUTC
+  if (col) out[o++] = '\n';
+  memcpy(out + o, "-----END CERTIFICATE-----\n", 26);
+  o += 26;
+  return o;
+}
+
 void orc_issuer_id(const uint8_t* spki, size_t n, char out[45]) {
   uint8_t dg[32];
   orc_sha256(spki, n, dg);

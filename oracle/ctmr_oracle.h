@@ -66,6 +66,8 @@ void orc_parse_cert(const uint8_t* der, size_t len, orc_cert* out);
 void orc_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
 /* base64.URLEncoding (padded) — types.go:146-159, 210-212. out must hold 4*ceil(n/3)+1. */
 size_t orc_b64url(const uint8_t* in, size_t n, char* out);
+/* storage/filesystemdatabase.go:167-175,196-200: pem.EncodeToMemory of a CERTIFICATE block without headers */
+size_t orc_pem_encode(const uint8_t* der, size_t n, char* out);
 /* Issuer.ID() = b64url(SHA-256(RawSubjectPublicKeyInfo)); 44 chars + NUL. types.go:124-130 */
 void orc_issuer_id(const uint8_t* spki, size_t n, char out[45]);
 /* floor(unix/3600): NewExpDateFromTime = NotAfter.Truncate(time.Hour) types.go:339-346 */

@@ -24,6 +24,12 @@ class Cert(C.Structure):
                 ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32)]
 
 
+def pem_encode(der: bytes) -> bytes:
+    out = C.create_string_buffer(len(der) * 2 + 128)
+    n = lib().orc_pem_encode(bytes(der), len(der), out)
+    return out.raw[:n]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -40,6 +46,8 @@ def lib():
         L.orc_b64url.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.restype = C.c_size_t
         L.orc_issuer_id.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.orc_pem_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.orc_pem_encode.restype = C.c_size_t
         L.orc_exp_hour.argtypes = [C.c_int64]
         L.orc_exp_hour.restype = C.c_int32
         L.orc_exp_date_id.argtypes = [C.c_int32, C.c_char_p]

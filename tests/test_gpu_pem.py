@@ -1,0 +1,61 @@
+"""N1: GPU PEM write-back ≡ the oracle's restatement of pem.EncodeToMemory
+(storage/filesystemdatabase.go:167-175,196-200), through the C ABI."""
+import numpy as np
+import pytest
+
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pem_new_matches_oracle_on_synthetic_batch():
+    cfg = synth.config(seed=20260921 + 7, n_issuers=16, dup_permille=150, ca_permille=20, expired_permille=20)
+    batch = synth.host_batch(cfg, 0, 5000)
+    eng = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 14)
+    eng.add_issuers(synth.issuers(cfg))
+    eng.set_filter(b"", False, synth.BASE_TIME)
+    res = eng.map_batch(batch)
+    pems = eng.pem_new()
+    assert len(pems) == len(res.new_idx) == res.stats.n_new > 0
+    for pem, i in zip(pems, res.new_idx):
+        assert pem == orc.pem_encode(bytes(batch.cert(int(i)))), int(i)
+    # a second batch of pure duplicates: nothing new, nothing to encode
+    res2 = eng.map_batch(batch)
+    assert res2.stats.n_new == 0 and eng.pem_new() == []
+    eng.close()
+
+
+def test_pem_device_every_length_and_padding_case():
+    """Arbitrary byte strings (the encoder does not care that they are not certificates): all lengths
+    0..200 cover every quarter-line / padding / line-end combination; plus typical DER sizes."""
+    import torch
+    rng = np.random.default_rng(5)
+    lens = list(range(0, 201)) + [717, 1297, 1523, 1536, 2000, 4095]
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+    offs = np.zeros(len(blobs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in blobs])
+    payload = np.frombuffer(b"".join(blobs) + bytes(64), np.uint8)
+    idx = np.arange(len(blobs), dtype=np.uint64)[::-1].copy()      # any order
+    dev = torch.device("cuda:0")
+    d_pay = torch.from_numpy(payload.copy()).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_idx = torch.from_numpy(idx.astype(np.int64)).to(dev)
+    d_po = torch.zeros(len(idx) + 1, dtype=torch.int64, device=dev)
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+    total = eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), len(idx), 0, 0,
+                                  d_po.data_ptr())
+    exp = [orc.pem_encode(blobs[int(i)]) for i in idx]
+    assert total == sum(len(x) for x in exp)
+    d_pem = torch.zeros(total, dtype=torch.uint8, device=dev)
+    eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), len(idx), d_pem.data_ptr(), total,
+                          d_po.data_ptr())
+    po = d_po.cpu().numpy()
+    raw = d_pem.cpu().numpy().tobytes()
+    for k in range(len(idx)):
+        assert raw[po[k]:po[k + 1]] == exp[k], int(idx[k])
+    with pytest.raises(ctmr.CtmrError):
+        eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), len(idx), d_pem.data_ptr(),
+                              total - 1, d_po.data_ptr())
+    eng.close()

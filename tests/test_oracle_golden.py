@@ -168,3 +168,29 @@ def test_walk_rejects_truncations_and_accepts_only_exact_length(golden_certs):
         assert orc.parse_cert(der + b"\x00").ok == 0            # trailing data
         for cut in (1, 2, 10, len(der) // 2, len(der) - 1):
             assert orc.parse_cert(der[:cut]).ok == 0
+
+
+# ---- N1: pem.EncodeToMemory (storage/filesystemdatabase.go:167-175,196-200) -----------------------
+def test_pem_encode_reproduces_the_reference_pem_literals():
+    """The three PEM constants of the reference's tests (types_test.go:21-39,
+    filesystemdatabase_test.go:17-64) are canonical encoding/pem output: decoding them and re-encoding
+    with the oracle must give the literal back byte for byte."""
+    import base64
+    import os
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    for name in ("kLeadingZeroes", "kEmptySPKI", "kRealSPKI"):
+        txt = open(os.path.join(here, name + ".pem"), "rb").read().strip() + b"\n"
+        der = base64.b64decode(b"".join(txt.split(b"\n")[1:-2]))
+        assert orc.pem_encode(der) == txt
+
+
+def test_pem_encode_line_breaking_edges():
+    """lineBreaker: 64 columns, no empty last line when the base64 length is a multiple of 64."""
+    import base64
+    import textwrap
+    for n in list(range(0, 100)) + [143, 144, 145, 717, 1297, 1523]:
+        der = bytes((i * 7 + 3) & 255 for i in range(n))
+        lines = textwrap.wrap(base64.b64encode(der).decode(), 64)
+        exp = b"-----BEGIN CERTIFICATE-----\n" + b"".join(l.encode() + b"\n" for l in lines) + \
+              b"-----END CERTIFICATE-----\n"
+        assert orc.pem_encode(der) == exp, n
