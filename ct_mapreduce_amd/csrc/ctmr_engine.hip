@@ -498,6 +498,27 @@ int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets
   return CTMR_OK;
 }
 
+int ctmr_sha256(ctmr_engine* e, const uint8_t* data, size_t len, uint8_t out[32]) {
+  if (!e || !out || (len && !data) || len > 0x7fffff00u) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  int r;
+  if ((r = ensure(e, SC_TMP, len + 128))) return r;
+  uint8_t* d = (uint8_t*)e->d_scratch[SC_TMP];
+  uint32_t* d_dg = (uint32_t*)(d + ((len + 3) & ~(size_t)3) + 32);
+  HIPCHK(e, hipMemsetAsync(d + (len & ~(size_t)3), 0, 8, e->stream));  // the reader loads whole words
+  if (len) HIPCHK(e, hipMemcpyAsync(d, data, len, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_sha256_one, dim3(1), dim3(64), 0, e->stream, (const uint8_t*)d, (uint32_t)len, d_dg);
+  uint32_t dg[8];
+  HIPCHK(e, hipMemcpyAsync(dg, d_dg, 32, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int k = 0; k < 8; k++) {
+    out[4 * k] = (uint8_t)(dg[k] >> 24); out[4 * k + 1] = (uint8_t)(dg[k] >> 16);
+    out[4 * k + 2] = (uint8_t)(dg[k] >> 8); out[4 * k + 3] = (uint8_t)dg[k];
+  }
+  return CTMR_OK;
+}
+
 int ctmr_issuer_count(ctmr_engine* e, uint32_t* n) {
   if (!e || !n) return CTMR_E_INVAL;
   std::lock_guard<std::mutex> g(e->mu);

@@ -330,6 +330,20 @@ __global__ void __launch_bounds__(64) k_issuer_ids(const uint8_t* der, const uin
   for (int k = 0; k < 8; k++) digest[i * 8 + k] = dg[k];
 }
 
+// SHA-256 of one host-supplied message (SPKI.Sha256DigestURLEncodedBase64 for an Issuer built from raw SPKI
+// bytes, storage/types.go:155-159): one lane, round constants in LDS.
+__global__ void __launch_bounds__(64) k_sha256_one(const uint8_t* msg, uint32_t len, uint32_t* digest) {
+  __shared__ uint32_t kc[64];
+  kc[threadIdx.x] = K256[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  GlobalReader r{(const uint32_t*)msg, 0};
+  uint32_t dg[8];
+  sha256_lane(r, 0, len, kc, dg);
+#pragma unroll
+  for (int k = 0; k < 8; k++) digest[k] = dg[k];
+}
+
 // ------------------------------------------------------------------ the map
 struct MapArgs {
   const uint8_t* payload;

@@ -125,6 +125,9 @@ int ctmr_synchronize(ctmr_engine* e);
 int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets, uint32_t n,
                      uint32_t* first_idx);
 int ctmr_issuer_count(ctmr_engine* e, uint32_t* n);
+/* SHA-256 of one byte string, on the GPU: SPKI.Sha256DigestURLEncodedBase64 for an Issuer constructed from raw
+ * SPKI bytes instead of a chain certificate (storage/types.go:155-159).  Not a hot-path call. */
+int ctmr_sha256(ctmr_engine* e, const uint8_t* data, size_t len, uint8_t out[32]);
 int ctmr_issuer_info_get(ctmr_engine* e, uint32_t idx, ctmr_issuer_info* out);
 
 /* ---- filter configuration: *ctconfig.IssuerCNFilter, *ctconfig.LogExpiredEntries and the
