@@ -28,8 +28,10 @@ ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32 (
 
 MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 3: "k_map_win<16>", 4: "k_map_win<8>", 5: "k_map_win<12>",
                6: "k_map_win<14>", 7: "k_map_win2<16>", 8: "k_map_win2<14>", 9: "k_map_win2<12>", 10: "k_map_wint<16,192,208>",
-               11: "k_map_wint<16,208,224>", 12: "k_map_wint<16,176,192>", 13: "k_map_winc<16>"}
-DEFAULT_VARIANT = 13
+               11: "k_map_wint<16,208,224>", 12: "k_map_wint<16,176,192>", 13: "k_map_winc<16>", 14: "k_map_fused<16>"}
+DEFAULT_VARIANT = 14
+FUSED = (14,)          # map kernels that also do pass 1 of the known-certificate insert
+ALG_BYTES_PROBE = 64   # per PASS entry: 32 B slot read + 32 B slot write — fused kernels only
 
 
 def pow2_at_least(v):
@@ -186,6 +188,8 @@ def main():
     n_total = E * world
     value = n_total * args.steps / dt
     alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E
+    if (args.variant or DEFAULT_VARIANT) in FUSED:
+        alg_bytes += ALG_BYTES_PROBE * int(stats.by_status[0])
     avg_ms = sum(ms_map) / len(ms_map)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     out = {
@@ -206,7 +210,8 @@ def main():
                      # the walk skips key, SAN body and signature: fewer bytes move than the algorithmic
                      # figure, so frac can exceed 1; frac_physical = measured traffic / time / peak
                      "frac_physical": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms},
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                     "alg_bytes_formula": "sum(L_i) + 45*E" + (" + 64*PASS (table probe)" if (args.variant or DEFAULT_VARIANT) in FUSED else "")},
         "kernel_ms": {"map": stats.ms_map, "insert": stats.ms_insert, "resolve": stats.ms_resolve,
                       "compact": stats.ms_compact, "total": stats.ms_total},
         "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},

@@ -571,19 +571,22 @@ int ctmr_set_filter(ctmr_engine* e, const char* filter, size_t len, int log_expi
 
 static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                       const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
-                      ctmr_record* d_records, bool optimistic_new) {
+                      ctmr_record* d_records, bool optimistic_new, const InsertArgs* fuse = nullptr) {
   MapArgs ma;
   ma.optimistic_new = optimistic_new ? 1u : 0u;
   ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
   ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
   ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
-  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 13;
+  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 14;
+  if (variant == 14 && !fuse) variant = 13;  // the fused kernel only exists with the local reduce behind it
   uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
   if (C > 64) C = 64;
   uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;
   if (lds > 160 * 1024) lds = 160 * 1024;
   ma.certs_per_tile = C; ma.lds_bytes = lds;
-  if (variant == 2) {
+  if (variant == 14) {
+    hipLaunchKernelGGL(k_map_fused<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma, *fuse);
+  } else if (variant == 2) {
     hipLaunchKernelGGL(k_map_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ma);
   } else if (variant == 3) {
     hipLaunchKernelGGL(k_map_win<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma);
@@ -647,14 +650,15 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
 
   // ---- map (PASS records leave it with WAS_UNKNOWN set; the reduce clears it for duplicates)
-  if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
-  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, true))) return r;
-  if (prof) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
-  // ---- insert
   InsertArgs ia;
   ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.canon = e->d_canon;
   ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.ent = d_ent; ia.n = n; ia.epoch = e->epoch;
-  hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
+  const bool fused = e->cfg.map_variant == 14 || e->cfg.map_variant == 0;
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
+  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, true, fused ? &ia : nullptr))) return r;
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
+  // ---- insert (pass 1 ran inside the map kernel when fused)
+  if (!fused) hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
   hipLaunchKernelGGL(k_insert2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia, d_records);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
   // ---- resolve

@@ -762,6 +762,69 @@ __device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, cons
 //                     DEFER), decide in pass 2 after the kernel boundary made every pass-1 store visible
 // Records arrive with WAS_UNKNOWN set optimistically by the map; it is cleared here / in pass 2
 // for duplicates only.  The reduce's later passes read the 4-byte ent[] word, never the table.
+// Pass-1 set insert of one PASS record held in registers (r0, r1 = the two 16-byte halves of the record).
+// On a claim the 64-byte slot image is returned in q0..q3 and `claimed` is the slot index; the caller
+// stores it cooperatively (store_slots_wave).  Returns the ES_* state.
+__device__ __forceinline__ uint32_t insert_probe(const InsertArgs& a, uint64_t i, const uint4& r0, const uint4& r1,
+                                                 uint32_t canon, uint64_t& claimed, uint4& q0, uint4& q1, uint4& q2,
+                                                 uint4& q3) {
+  const uint32_t slen = r0.x >> 16;
+  if (slen > CTMR_MAX_SERIAL) return ES_HOST;
+  unsigned long long s[5];
+  record_key(a, i, r0, r1, s);
+  const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
+  const unsigned long long h = key_hash(meta, s);
+  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  uint64_t j = h & a.mask;
+  for (uint64_t probes = 0; probes <= a.mask; probes++) {
+    Slot* sl = a.table + j;
+    const unsigned long long w0 = tagw | (uint32_t)i;
+    const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
+    if (old == 0ull) {  // claimed
+      q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)meta, (uint32_t)(meta >> 32));
+      q1 = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+      q2 = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+      q3 = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+      claimed = j;
+      return ES_CLAIMED;
+    }
+    if ((old & 0xffffffff00000000ull) == tagw) {
+      const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
+      if (ep != 0u && ep != a.epoch) {  // older batch: complete and visible
+        bool eq = sl->w[1] == meta;
+#pragma unroll
+        for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+        if (eq) return ES_DUP;
+      } else {
+        a.slot_id[i] = (uint32_t)j;
+        return ES_DEFER;
+      }
+    }
+    j = (j + 1) & a.mask;
+  }
+  return ES_FULL;
+}
+
+// Cooperative slot write of one wave: lane L parks its 64-byte image at img[L*4 .. L*4+3]; store
+// instruction r then has lane L write quarter L%4 of the slot of lane 16r + L/4, so four adjacent
+// lanes emit one whole slot.  (w[0] is rewritten with the value the CAS stored: concurrent CAS
+// attempts of this pass see a non-zero word either way; atomicMin only runs in pass 2.)
+__device__ __forceinline__ void store_slots_wave(Slot* table, uint4* img, uint32_t lane, uint64_t claimed,
+                                                 const uint4& q0, const uint4& q1, const uint4& q2, const uint4& q3) {
+  uint4* my = img + lane * 4;
+  my[0] = q0; my[1] = q1; my[2] = q2; my[3] = q3;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t src = 16u * r + (lane >> 2);
+    const uint64_t sj = __shfl(claimed, src);
+    if (sj != ~0ull) {
+      const uint4 v = img[r * 64 + lane];
+      ((uint4*)(table + sj))[lane & 3u] = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 slot images
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -774,51 +837,9 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
     const uint4 r0 = rp[0];
     status = r0.x & 0xffu;
     if (status == CTMR_ST_PASS) {
-      const uint32_t slen = r0.x >> 16;
       canon = a.canon[r0.z];
-      if (slen > CTMR_MAX_SERIAL) {
-        state = ES_HOST;
-      } else {
-        const uint4 r1 = rp[1];
-        unsigned long long s[5];
-        record_key(a, i, r0, r1, s);
-        const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
-        const unsigned long long h = key_hash(meta, s);
-        const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
-        uint64_t j = h & a.mask;
-        state = ES_FULL;
-        for (uint64_t probes = 0; probes <= a.mask; probes++) {
-          Slot* sl = a.table + j;
-          const unsigned long long w0 = tagw | (uint32_t)i;
-          const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
-          if (old == 0ull) {  // claimed
-            q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)meta, (uint32_t)(meta >> 32));
-            q1 = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
-            q2 = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
-            q3 = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
-            claimed = j;
-            state = ES_CLAIMED;
-            break;
-          }
-          if ((old & 0xffffffff00000000ull) == tagw) {
-            const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
-            if (ep != 0u && ep != a.epoch) {  // older batch: complete and visible
-              bool eq = sl->w[1] == meta;
-#pragma unroll
-              for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
-              if (eq) {
-                state = ES_DUP;
-                break;
-              }
-            } else {
-              a.slot_id[i] = (uint32_t)j;
-              state = ES_DEFER;
-              break;
-            }
-          }
-          j = (j + 1) & a.mask;
-        }
-      }
+      const uint4 r1 = rp[1];
+      state = insert_probe(a, i, r0, r1, canon, claimed, q0, q1, q2, q3);
       if (state != ES_CLAIMED && state != ES_DEFER) {  // not (yet) unknown: drop the optimistic flag
         uint8_t* fl = (uint8_t*)(a.records + i) + 1;
         *fl = (uint8_t)((r0.x >> 8) & ~CTMR_FL_WAS_UNKNOWN);
@@ -826,22 +847,7 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
     }
     a.ent[i] = ent_pack(status, state, canon);
   }
-  // ---- cooperative slot write: lane L parks its 64-byte image at img[wv][L*4 .. L*4+3]; store
-  // instruction r then has lane L write quarter L%4 of the slot of lane 16r + L/4, so four adjacent
-  // lanes emit one whole slot.  (w[0] is rewritten with the value the CAS stored: concurrent CAS
-  // attempts of this pass see a non-zero word either way; atomicMin only runs in pass 2.)
-  uint4* my = &img[wv][lane * 4];
-  my[0] = q0; my[1] = q1; my[2] = q2; my[3] = q3;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t src = 16u * r + (lane >> 2);
-    const uint64_t sj = __shfl(claimed, src);
-    if (sj != ~0ull) {
-      const uint4 v = img[wv][r * 64 + lane];
-      ((uint4*)(a.table + sj))[lane & 3u] = v;
-    }
-  }
+  store_slots_wave(a.table, img[wv], lane, claimed, q0, q1, q2, q3);
 }
 
 // PASS 2: DEFER entries — their candidate slot was created by this batch and is complete now.
@@ -881,6 +887,65 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
   }
   const uint32_t other = (uint32_t)prev;
   mark_dup(a.ent, records, other < (uint32_t)i ? (uint32_t)i : other);
+}
+
+// Fused map + pass-1 insert (variant 14): the lane that just finished walking a certificate probes the
+// known-certificate table straight from its registers — the 32-byte record is not re-read (−3.2 GB per
+// 100 M entries), the WAS_UNKNOWN flag is final before the record is stored (no second scattered write for
+// old-batch duplicates) and the random-access latency of the CAS hides behind the walks of the other
+// waves of the CU instead of being a kernel of its own.  Pass 2 (k_insert2) is unchanged.
+// (Tried and dropped: loading the slot's claim word early, when the key is known but the extension block
+// is still in flight, so that the CAS finds the line on-die — +0.6 ms at 100 M entries: the kernel is bound
+// by memory transactions, not by the latency of the probe.)
+template <int WCH>
+__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
+  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t i = first + lane;
+  const bool live = i < a.n;
+  constexpr uint32_t STRIDE = WCH * 16 + 16;
+  const uint64_t limit = a.offsets[a.n] + CTMR_PAYLOAD_PAD;
+  uint64_t lo = 0, hi = 0;
+  if (live) {
+    lo = a.offsets[i];
+    hi = a.offsets[i + 1];
+    if (hi < lo) hi = lo;
+  }
+  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
+  {
+    uint4 v[16];
+    const uint32_t sub = lane & 15u;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+      const uint64_t at = g + 16u * sub;
+      v[it] = (g != ~0ull && at + 16u <= limit) ? *(const uint4*)(a.payload + at) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  uint64_t claimed = ~0ull;
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  if (live) {
+    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                       (int32_t)(int64_t)(g_me - lo)}};
+    map_one(r, hi - lo, i, a, o0, o1);
+    const uint32_t status = o0.x & 0xffu;
+    uint32_t state = ES_NONE, canon = 0;
+    if (status == CTMR_ST_PASS) {
+      canon = ia.canon[o0.z];
+      state = insert_probe(ia, i, o0, o1, canon, claimed, q0, q1, q2, q3);
+      if (state != ES_CLAIMED && state != ES_DEFER) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
+    }
+    ia.ent[i] = ent_pack(status, state, canon);
+  }
+  store_records_wave(a, first, live, o0, o1);
+  __builtin_amdgcn_wave_barrier();
+  store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
 }
 
 // Wave-aggregated add: one atomic per distinct key per wave (the "match-any" loop).

@@ -81,9 +81,10 @@ typedef struct {
   uint32_t max_issuers;       /* 0 = 65536 */
   uint32_t certs_per_tile;    /* map-kernel tuning; 0 = default */
   uint32_t lds_tile_bytes;    /* map-kernel tuning; 0 = default */
-  uint32_t map_variant;       /* 0 = default (13); DESIGN.md §5: 1 = whole-cert LDS tile, 2 = direct global,
+  uint32_t map_variant;       /* 0 = default (14); DESIGN.md §5: 1 = whole-cert LDS tile, 2 = direct global,
                                  3/4/5/6 = per-lane 256/128/192/224-B LDS window, 7-9 = window + pinned tail,
-                                 10-12 = line-trimmed windows, 13 = 256-B window with wave-cooperative fills */
+                                 10-12 = line-trimmed windows, 13 = 256-B window with wave-cooperative fills,
+                                 14 = 13 fused with pass 1 of the known-certificate insert */
   uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
   uint32_t reserved;
 } ctmr_config;
