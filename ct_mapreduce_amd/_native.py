@@ -10,8 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libctmr.so")
 
 ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
-    ST_ISSUER_PARSE_ERROR = range(7)
-ST_COUNT = 7
+    ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
+ST_COUNT = 8
+ABI_VERSION = 2
+ENTRY_INVALID = 0xFF
 FL_PRECERT, FL_WAS_UNKNOWN, FL_LONG_SERIAL = 1, 2, 4
 NO_ISSUER = 0xFFFFFFFF
 PAYLOAD_PAD = 32
@@ -31,6 +33,18 @@ class BatchStats(C.Structure):
                 ("n_dup", C.c_uint64), ("n_host_set", C.c_uint64), ("payload_bytes", C.c_uint64),
                 ("ms_map", C.c_float), ("ms_insert", C.c_float), ("ms_resolve", C.c_float),
                 ("ms_compact", C.c_float), ("ms_total", C.c_float), ("map_launches", C.c_uint32)]
+
+
+class EntryView(C.Structure):
+    _fields_ = [("cert_start", C.c_void_p), ("cert_end", C.c_void_p), ("issuer_idx", C.c_void_p),
+                ("entry_type", C.c_void_p), ("timestamp", C.c_void_p), ("chain0_start", C.c_void_p),
+                ("chain0_len", C.c_void_p)]
+
+
+class DecodeStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_x509", C.c_uint64), ("n_precert", C.c_uint64),
+                ("n_decode_error", C.c_uint64), ("n_no_chain", C.c_uint64), ("n_issuers_added", C.c_uint64),
+                ("blob_bytes", C.c_uint64), ("ms_decode", C.c_float), ("ms_match", C.c_float)]
 
 
 class IssuerInfo(C.Structure):
@@ -82,6 +96,16 @@ SIGNATURES = {
                                              C.POINTER(BatchStats)]),
     "ctmr_pem_encode_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "ctmr_pem_new": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "ctmr_decode_entries_device": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(EntryView), C.POINTER(DecodeStats)]),
+    "ctmr_map_view_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(EntryView), C.c_uint64, _P, _P,
+                                       C.POINTER(BatchStats)]),
+    "ctmr_map_entries_device": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P, C.POINTER(DecodeStats),
+                                          C.POINTER(BatchStats)]),
+    "ctmr_map_entries": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P, C.POINTER(DecodeStats),
+                                   C.POINTER(BatchStats)]),
+    "ctmr_synth_entries_host": (C.c_uint64, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P, C.c_uint64]),
+    "ctmr_synth_entries_device": (C.c_int, [_P, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P, C.c_uint64,
+                                            C.POINTER(C.c_uint64)]),
     "ctmr_synth_leaf_len": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64]),
     "ctmr_synth_leaf": (C.c_uint32, [C.POINTER(SynthConfig), C.c_uint64, _P, C.c_uint32,
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
@@ -109,7 +133,7 @@ def lib():
             fn = getattr(L, name)   # AttributeError ⇒ ABI mismatch, loudly
             fn.restype = res
             fn.argtypes = args
-        if L.ctmr_abi_version() != 1:
+        if L.ctmr_abi_version() != ABI_VERSION:
             raise ImportError("libctmr ABI version mismatch")
         _LIB = L
     return _LIB

@@ -148,6 +148,24 @@ struct ctmr_engine {
   uint32_t* d_canon = nullptr;
   std::vector<IssuerRec> issuers;
   std::unordered_map<std::string, uint32_t> id_to_canon;
+  // issuer certificate store for the Chain[0] match of the raw-entry path (k_chain0_match): every registered
+  // certificate's bytes at a 16-byte aligned offset, its length and candidate hash, and a hash table index+1
+  uint8_t* d_idb_der = nullptr;
+  size_t idb_cap = 0, idb_used = 0;
+  uint64_t* d_idb_off = nullptr;
+  uint32_t* d_idb_len = nullptr;
+  unsigned long long* d_idb_qh = nullptr;
+  uint32_t* d_idb_ht = nullptr;
+  uint32_t idb_ht_size = 0;
+  std::vector<uint32_t> h_idb_ht;
+  std::vector<unsigned long long> h_idb_qh;
+  std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
+  unsigned long long* d_pend = nullptr;    // PEND_SLOTS claim words
+  uint32_t* d_unreg = nullptr;             // UNREG_CAP entry indices
+  unsigned long long* d_dcount = nullptr;  // 8 counters of the decode / match kernels
+  // the last ctmr_map_entries (host variant): ctmr_pem_new encodes from its view
+  bool last_is_view = false;
+  size_t last_o_start = 0, last_o_end = 0;
   // filter
   FilterDev* d_filter = nullptr;
   FilterDev h_filter{};
@@ -155,8 +173,8 @@ struct ctmr_engine {
   DevStats* d_stats = nullptr;
   uint32_t* d_result = nullptr;        // 2 words for point ops
   unsigned long long* d_count = nullptr;
-  void* d_scratch[12] = {};            // growable buffers
-  size_t scratch_cap[12] = {};
+  void* d_scratch[16] = {};            // growable buffers
+  size_t scratch_cap[16] = {};
   // the last ctmr_map_batch (host variant): what ctmr_pem_new encodes
   uint64_t last_n = 0, last_n_new = 0;
   size_t last_o_off = 0, last_o_new = 0;
@@ -169,7 +187,8 @@ struct ctmr_engine {
 
 namespace {
 
-enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP };
+enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP, SC_VIEW, SC_ISS_A, SC_ISS_B, SC_ISS_C };
+constexpr uint32_t UNREG_CAP = 16384;
 
 int fail(const ctmr_engine* e, int code, const char* fmt, ...) {
   char buf[512];
@@ -399,6 +418,16 @@ int ctmr_create(const ctmr_config* cfg, ctmr_engine** out) {
   CK(hipMalloc(&e->d_stats, sizeof(DevStats)));
   CK(hipMalloc(&e->d_result, 16));
   CK(hipMalloc(&e->d_count, 16));
+  e->idb_ht_size = (uint32_t)pow2_at_least((uint64_t)e->max_issuers * 4 < 1024 ? 1024 : (uint64_t)e->max_issuers * 4);
+  CK(hipMalloc(&e->d_idb_off, (size_t)e->max_issuers * 8));
+  CK(hipMalloc(&e->d_idb_len, (size_t)e->max_issuers * 4));
+  CK(hipMalloc(&e->d_idb_qh, (size_t)e->max_issuers * 8));
+  CK(hipMalloc(&e->d_idb_ht, (size_t)e->idb_ht_size * 4));
+  CK(hipMalloc(&e->d_pend, (size_t)PEND_SLOTS * 8));
+  CK(hipMalloc(&e->d_unreg, (size_t)UNREG_CAP * 4));
+  CK(hipMalloc(&e->d_dcount, 64));
+  CK(hipMemsetAsync(e->d_idb_ht, 0, (size_t)e->idb_ht_size * 4, e->stream));
+  e->h_idb_ht.assign(e->idb_ht_size, 0u);
   CK(hipMemsetAsync(e->table, 0, e->nslots * sizeof(Slot), e->stream));
   CK(hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
   CK(hipMemsetAsync(e->issuer_counts, 0, (size_t)e->max_issuers * 8, e->stream));
@@ -421,6 +450,8 @@ void ctmr_destroy(ctmr_engine* e) {
   (void)hipFree(e->table); (void)hipFree(e->pairs); (void)hipFree(e->issuer_counts);
   (void)hipFree(e->d_issuer_valid); (void)hipFree(e->d_canon); (void)hipFree(e->d_filter);
   (void)hipFree(e->d_stats); (void)hipFree(e->d_result); (void)hipFree(e->d_count);
+  (void)hipFree(e->d_idb_der); (void)hipFree(e->d_idb_off); (void)hipFree(e->d_idb_len); (void)hipFree(e->d_idb_qh);
+  (void)hipFree(e->d_idb_ht); (void)hipFree(e->d_pend); (void)hipFree(e->d_unreg); (void)hipFree(e->d_dcount);
   for (auto p : e->d_scratch) if (p) (void)hipFree(p);
   for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -443,10 +474,8 @@ int ctmr_synchronize(ctmr_engine* e) {
   return CTMR_OK;
 }
 
-int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets, uint32_t n,
-                     uint32_t* first_idx) {
-  if (!e || (n && (!der || !offsets))) return CTMR_E_INVAL;
-  std::lock_guard<std::mutex> g(e->mu);
+static int add_issuers_locked(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets, uint32_t n,
+                              uint32_t* first_idx) {
   HIPCHK(e, hipSetDevice(e->device));
   const uint32_t first = (uint32_t)e->issuers.size();
   if (first_idx) *first_idx = first;
@@ -456,17 +485,17 @@ int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets
     if (offsets[i + 1] < offsets[i]) return fail(e, CTMR_E_INVAL, "issuer offsets not monotone");
   const uint64_t base = offsets[0], bytes = offsets[n] - base;
   int r;
-  if ((r = ensure(e, SC_STAGE_A, bytes + CTMR_PAYLOAD_PAD))) return r;
-  if ((r = ensure(e, SC_STAGE_B, (size_t)(n + 1) * 8))) return r;
-  if ((r = ensure(e, SC_MISC, (size_t)n * 32 + n))) return r;
+  if ((r = ensure(e, SC_ISS_A, bytes + CTMR_PAYLOAD_PAD))) return r;
+  if ((r = ensure(e, SC_ISS_B, (size_t)(n + 1) * 8))) return r;
+  if ((r = ensure(e, SC_ISS_C, (size_t)n * 32 + n))) return r;
   std::vector<uint64_t> rel(n + 1);
   for (uint32_t i = 0; i <= n; i++) rel[i] = offsets[i] - base;
-  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_STAGE_A], der + base, bytes, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_STAGE_B], rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, e->stream));
-  uint32_t* d_digest = (uint32_t*)e->d_scratch[SC_MISC];
-  uint8_t* d_valid = (uint8_t*)e->d_scratch[SC_MISC] + (size_t)n * 32;
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_ISS_A], der + base, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_ISS_B], rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  uint32_t* d_digest = (uint32_t*)e->d_scratch[SC_ISS_C];
+  uint8_t* d_valid = (uint8_t*)e->d_scratch[SC_ISS_C] + (size_t)n * 32;
   hipLaunchKernelGGL(k_issuer_ids, dim3((n + 63) / 64), dim3(64), 0, e->stream,
-                     (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)e->d_scratch[SC_STAGE_B],
+                     (const uint8_t*)e->d_scratch[SC_ISS_A], (const uint64_t*)e->d_scratch[SC_ISS_B],
                      n, d_valid, d_digest);
   std::vector<uint32_t> dg(n * 8);
   std::vector<uint8_t> valid(n);
@@ -495,7 +524,57 @@ int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets
   HIPCHK(e, hipMemcpyAsync(e->d_issuer_valid + first, valid.data(), n, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync(e->d_canon + first, canon.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  // ---- certificate store for the Chain[0] match (raw-entry path)
+  {
+    std::vector<uint64_t> off(n);
+    std::vector<uint32_t> len(n);
+    size_t need = e->idb_used;
+    for (uint32_t i = 0; i < n; i++) {
+      off[i] = need;
+      len[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+      need += ((size_t)len[i] + 15) / 16 * 16 + 16;
+    }
+    if (need > e->idb_cap) {
+      const size_t cap = std::max(need * 2, (size_t)1 << 20);
+      uint8_t* nb = nullptr;
+      HIPCHK(e, hipMalloc(&nb, cap));
+      HIPCHK(e, hipMemsetAsync(nb, 0, cap, e->stream));
+      if (e->idb_used) HIPCHK(e, hipMemcpyAsync(nb, e->d_idb_der, e->idb_used, hipMemcpyDeviceToDevice, e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      (void)hipFree(e->d_idb_der);
+      e->d_idb_der = nb;
+      e->idb_cap = cap;
+    }
+    e->h_idb_qh.resize(first + n);
+    bool ht_dirty = false;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint8_t* c = der + offsets[i];
+      if (len[i]) HIPCHK(e, hipMemcpyAsync(e->d_idb_der + off[i], c, len[i], hipMemcpyHostToDevice, e->stream));
+      const unsigned long long qh = cert_quick_hash(HostBytes{c}, 0, len[i]);
+      e->h_idb_qh[first + i] = qh;
+      if (len[i] && e->der_to_idx.emplace(std::string((const char*)c, len[i]), first + i).second) {
+        uint32_t j = (uint32_t)qh & (e->idb_ht_size - 1);
+        while (e->h_idb_ht[j]) j = (j + 1) & (e->idb_ht_size - 1);
+        e->h_idb_ht[j] = first + i + 1;
+        ht_dirty = true;
+      }
+    }
+    e->idb_used = need;
+    HIPCHK(e, hipMemcpyAsync(e->d_idb_off + first, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_idb_len + first, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_idb_qh + first, e->h_idb_qh.data() + first, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+    if (ht_dirty)
+      HIPCHK(e, hipMemcpyAsync(e->d_idb_ht, e->h_idb_ht.data(), (size_t)e->idb_ht_size * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
   return CTMR_OK;
+}
+
+int ctmr_add_issuers(ctmr_engine* e, const uint8_t* der, const uint64_t* offsets, uint32_t n,
+                     uint32_t* first_idx) {
+  if (!e || (n && (!der || !offsets))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return add_issuers_locked(e, der, offsets, n, first_idx);
 }
 
 int ctmr_sha256(ctmr_engine* e, const uint8_t* data, size_t len, uint8_t out[32]) {
@@ -571,14 +650,17 @@ int ctmr_set_filter(ctmr_engine* e, const char* filter, size_t len, int log_expi
 
 static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                       const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
-                      ctmr_record* d_records, bool optimistic_new, const InsertArgs* fuse = nullptr) {
+                      ctmr_record* d_records, bool optimistic_new, const InsertArgs* fuse = nullptr,
+                      const uint64_t* d_ends = nullptr, uint64_t limit = 0) {
   MapArgs ma;
   ma.optimistic_new = optimistic_new ? 1u : 0u;
+  ma.ends = d_ends; ma.limit = limit;
   ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
   ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
   ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
   uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 14;
   if (variant == 14 && !fuse) variant = 13;  // the fused kernel only exists with the local reduce behind it
+  if (variant == 1 && d_ends) variant = 13;  // the whole-certificate tile copy needs the packed layout
   uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
   if (C > 64) C = 64;
   uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;
@@ -624,7 +706,8 @@ static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* 
 
 static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                              const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
-                             ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats) {
+                             ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats,
+                             const uint64_t* d_ends = nullptr, uint64_t blob_bytes = 0) {
   HIPCHK(e, hipSetDevice(e->device));
   if (stats) memset(stats, 0, sizeof *stats);
   if (n == 0) return CTMR_OK;
@@ -651,11 +734,12 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
 
   // ---- map (PASS records leave it with WAS_UNKNOWN set; the reduce clears it for duplicates)
   InsertArgs ia;
-  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.canon = e->d_canon;
+  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.ends = d_ends; ia.canon = e->d_canon;
   ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.ent = d_ent; ia.n = n; ia.epoch = e->epoch;
   const bool fused = e->cfg.map_variant == 14 || e->cfg.map_variant == 0;
   if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
-  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, true, fused ? &ia : nullptr))) return r;
+  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, true, fused ? &ia : nullptr,
+                      d_ends, blob_bytes + CTMR_PAYLOAD_PAD))) return r;
   if (prof) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
   // ---- insert (pass 1 ran inside the map kernel when fused)
   if (!fused) hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
@@ -682,7 +766,8 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
       if (((ent[i] >> 3) & 7u) != ES_HOST) continue;
       uint64_t off[2];
       ctmr_record rec;
-      HIPCHK(e, hipMemcpy(off, d_offsets + i, 16, hipMemcpyDeviceToHost));
+      HIPCHK(e, hipMemcpy(off, d_offsets + i, d_ends ? 8 : 16, hipMemcpyDeviceToHost));
+      if (d_ends) HIPCHK(e, hipMemcpy(off + 1, d_ends + i, 8, hipMemcpyDeviceToHost));
       HIPCHK(e, hipMemcpy(&rec, d_records + i, sizeof rec, hipMemcpyDeviceToHost));
       std::vector<uint8_t> der(off[1] - off[0] + 32);
       HIPCHK(e, hipMemcpy(der.data(), d_payload + off[0], off[1] - off[0], hipMemcpyDeviceToHost));
@@ -720,10 +805,12 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
     stats->n_new = hs.n_new + host_new;
     stats->n_dup = hs.n_dup + (hs.n_host - host_new);
     stats->n_host_set = hs.n_host;
-    uint64_t ends[2] = {0, 0};
-    HIPCHK(e, hipMemcpy(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost));
-    stats->payload_bytes = ends[1] - ends[0];
+    uint64_t ends[2] = {0, blob_bytes};
+    if (!d_ends) {
+      HIPCHK(e, hipMemcpy(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost));
+      HIPCHK(e, hipMemcpy(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost));
+    }
+    stats->payload_bytes = ends[1] - ends[0];  // entry view: the whole blob (leaf_input + extra_data)
     stats->map_launches = 1;
     if (prof) {
       (void)hipEventElapsedTime(&stats->ms_map, e->ev[0], e->ev[1]);
@@ -777,6 +864,200 @@ int ctmr_map_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offse
   if (new_idx && st.n_new) HIPCHK(e, hipMemcpy(new_idx, B + o_new, st.n_new * 8, hipMemcpyDeviceToHost));
   if (stats) *stats = st;
   e->last_n = n; e->last_n_new = new_idx ? st.n_new : 0; e->last_o_off = o_off; e->last_o_new = o_new;
+  e->last_is_view = false;
+  return CTMR_OK;
+}
+
+// ------------------------------------------------------------------ CT get-entries decode (N2)
+
+static int decode_locked(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
+                         const ctmr_entry_view* v, ctmr_decode_stats* stats) {
+  HIPCHK(e, hipSetDevice(e->device));
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (n == 0) return CTMR_OK;
+  if (n >= 0xfffffff0ull) return fail(e, CTMR_E_INVAL, "batch too large (n < 2^32-16)");
+  if (!v->cert_start || !v->cert_end || !v->issuer_idx || !v->entry_type)
+    return fail(e, CTMR_E_INVAL, "entry view: cert_start, cert_end, issuer_idx and entry_type are required");
+  int r;
+  uint64_t* c0s = v->chain0_start;
+  uint32_t* c0l = v->chain0_len;
+  if (!c0s || !c0l) {
+    if ((r = ensure(e, SC_VIEW, n * 12 + 64))) return r;
+    if (!c0s) c0s = (uint64_t*)e->d_scratch[SC_VIEW];
+    if (!c0l) c0l = (uint32_t*)((uint8_t*)e->d_scratch[SC_VIEW] + n * 8);
+  }
+  const bool prof = e->cfg.profile != 0;
+  HIPCHK(e, hipMemsetAsync(e->d_dcount, 0, 64, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_pend, 0, (size_t)PEND_SLOTS * 8, e->stream));
+  DecodeArgs da;
+  da.blob = d_blob; da.bounds = d_bounds; da.n = n; da.cert_start = v->cert_start; da.cert_end = v->cert_end;
+  da.entry_type = v->entry_type; da.timestamp = v->timestamp; da.chain0_start = c0s; da.chain0_len = c0l;
+  da.counters = e->d_dcount;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[5], e->stream));
+  hipLaunchKernelGGL(k_entry_decode, dim3(blocks), dim3(256), 0, e->stream, da);
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[6], e->stream));
+  MatchArgs ma;
+  ma.blob = d_blob; ma.chain0_start = c0s; ma.chain0_len = c0l; ma.entry_type = v->entry_type;
+  ma.issuer_idx = v->issuer_idx; ma.n = n;
+  ma.ht_mask = e->idb_ht_size - 1; ma.retry = 0;
+  ma.pend = e->d_pend; ma.unreg_list = e->d_unreg; ma.unreg_cap = UNREG_CAP; ma.counters = e->d_dcount + 4;
+  uint64_t added = 0;
+  unsigned long long hc[8];
+  for (int round = 0;; round++) {
+    ma.idb_der = e->d_idb_der; ma.idb_off = e->d_idb_off; ma.idb_len = e->d_idb_len; ma.idb_qh = e->d_idb_qh;
+    ma.ht = e->d_idb_ht;
+    hipLaunchKernelGGL(k_chain0_match, dim3(blocks), dim3(256), 0, e->stream, ma);
+    if (round == 0 && prof) HIPCHK(e, hipEventRecord(e->ev[7], e->stream));
+    HIPCHK(e, hipMemcpyAsync(hc, e->d_dcount, 64, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipGetLastError());
+    if (hc[4] == 0) break;  // every Chain[0] is registered
+    if (round > 64) return fail(e, CTMR_E_HIP, "Chain[0] registration does not converge");
+    // ---- register the distinct unknown Chain[0] certificates (x509.ParseCertificate(Chain[0]) + NewIssuer once each)
+    const uint32_t nl = (uint32_t)std::min<unsigned long long>(hc[5], UNREG_CAP);
+    std::vector<uint32_t> list(nl);
+    HIPCHK(e, hipMemcpy(list.data(), e->d_unreg, (size_t)nl * 4, hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end());  // ascending log index: registration order is deterministic
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> off{0};
+    std::set<std::string> seen;
+    for (uint32_t k = 0; k < nl; k++) {
+      uint64_t lo;
+      uint32_t len;
+      HIPCHK(e, hipMemcpy(&lo, c0s + list[k], 8, hipMemcpyDeviceToHost));
+      HIPCHK(e, hipMemcpy(&len, c0l + list[k], 4, hipMemcpyDeviceToHost));
+      std::string der(len, '\0');
+      HIPCHK(e, hipMemcpy(&der[0], d_blob + lo, len, hipMemcpyDeviceToHost));
+      if (e->der_to_idx.count(der) || !seen.insert(der).second) continue;
+      blob.insert(blob.end(), der.begin(), der.end());
+      off.push_back(blob.size());
+    }
+    const uint32_t fresh = (uint32_t)off.size() - 1;
+    if (fresh == 0) return fail(e, CTMR_E_HIP, "Chain[0] match reported unregistered certificates but none is new");
+    blob.resize(blob.size() + CTMR_PAYLOAD_PAD);
+    if ((r = add_issuers_locked(e, blob.data(), off.data(), fresh, nullptr))) return r;
+    added += fresh;
+    HIPCHK(e, hipMemsetAsync(e->d_dcount + 4, 0, 32, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_pend, 0, (size_t)PEND_SLOTS * 8, e->stream));
+    ma.retry = 1;
+  }
+  if (stats) {
+    stats->n = n;
+    stats->n_x509 = hc[0]; stats->n_precert = hc[1]; stats->n_decode_error = hc[2]; stats->n_no_chain = hc[3];
+    stats->n_issuers_added = added;
+    uint64_t b[2];
+    HIPCHK(e, hipMemcpy(&b[0], d_bounds, 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&b[1], d_bounds + 2 * n, 8, hipMemcpyDeviceToHost));
+    stats->blob_bytes = b[1] - b[0];
+    if (prof) {
+      (void)hipEventElapsedTime(&stats->ms_decode, e->ev[5], e->ev[6]);
+      (void)hipEventElapsedTime(&stats->ms_match, e->ev[6], e->ev[7]);
+    }
+  }
+  return CTMR_OK;
+}
+
+int ctmr_decode_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
+                               const ctmr_entry_view* d_view, ctmr_decode_stats* stats) {
+  if (!e || !d_view || (n && (!d_blob || !d_bounds))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return decode_locked(e, d_blob, d_bounds, n, d_view, stats);
+}
+
+int ctmr_map_view_device(ctmr_engine* e, const uint8_t* d_blob, uint64_t blob_bytes, const ctmr_entry_view* v,
+                         uint64_t n, ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats) {
+  if (!e || !v || (n && (!d_blob || !v->cert_start || !v->cert_end || !v->issuer_idx))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return map_device_locked(e, d_blob, v->cert_start, v->issuer_idx, v->entry_type, n, d_records, d_new_idx, stats,
+                           v->cert_end, blob_bytes);
+}
+
+// view arrays in SC_VIEW behind the chain0 scratch: start | end | issuer_idx | entry_type
+static int view_in_scratch(ctmr_engine* e, uint64_t n, ctmr_entry_view* v, uint64_t* d_timestamp) {
+  int r;
+  const size_t o_c0 = 0, o_start = (n * 12 + 63) & ~(size_t)63, o_end = o_start + n * 8, o_iss = o_end + n * 8,
+               o_et = o_iss + n * 4;
+  if ((r = ensure(e, SC_VIEW, o_et + n + 64))) return r;
+  uint8_t* V = (uint8_t*)e->d_scratch[SC_VIEW];
+  v->chain0_start = (uint64_t*)(V + o_c0);
+  v->chain0_len = (uint32_t*)(V + o_c0 + n * 8);
+  v->cert_start = (uint64_t*)(V + o_start);
+  v->cert_end = (uint64_t*)(V + o_end);
+  v->issuer_idx = (uint32_t*)(V + o_iss);
+  v->entry_type = V + o_et;
+  v->timestamp = d_timestamp;
+  return CTMR_OK;
+}
+
+static int map_entries_locked(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
+                              ctmr_record* d_records, uint64_t* d_new_idx, uint64_t* d_timestamp,
+                              ctmr_decode_stats* dstats, ctmr_batch_stats* stats, ctmr_entry_view* view_out) {
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (dstats) memset(dstats, 0, sizeof *dstats);
+  if (n == 0) return CTMR_OK;
+  ctmr_entry_view v;
+  int r;
+  if ((r = view_in_scratch(e, n, &v, d_timestamp))) return r;
+  ctmr_decode_stats ds;
+  if ((r = decode_locked(e, d_blob, d_bounds, n, &v, &ds))) return r;
+  if (dstats) *dstats = ds;
+  if (view_out) *view_out = v;
+  return map_device_locked(e, d_blob, v.cert_start, v.issuer_idx, v.entry_type, n, d_records, d_new_idx, stats,
+                           v.cert_end, ds.blob_bytes);
+}
+
+int ctmr_map_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
+                            ctmr_record* d_records, uint64_t* d_new_idx, uint64_t* d_timestamp,
+                            ctmr_decode_stats* dstats, ctmr_batch_stats* stats) {
+  if (!e || (n && (!d_blob || !d_bounds))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  if (n) {
+    uint64_t b0 = 0;
+    HIPCHK(e, hipMemcpy(&b0, d_bounds, 8, hipMemcpyDeviceToHost));
+    if (b0 != 0) return fail(e, CTMR_E_INVAL, "bounds[0] must be 0 (bounds are relative to d_blob)");
+  }
+  return map_entries_locked(e, d_blob, d_bounds, n, d_records, d_new_idx, d_timestamp, dstats, stats, nullptr);
+}
+
+int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n, ctmr_record* records,
+                     uint64_t* new_idx, uint64_t* timestamp, ctmr_decode_stats* dstats, ctmr_batch_stats* stats) {
+  if (!e || (n && (!blob || !bounds))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (dstats) memset(dstats, 0, sizeof *dstats);
+  if (n == 0) return CTMR_OK;
+  for (uint64_t i = 0; i < 2 * n; i++)
+    if (bounds[i + 1] < bounds[i]) return fail(e, CTMR_E_INVAL, "bounds not monotone at %llu", (unsigned long long)i);
+  const uint64_t base = bounds[0], bytes = bounds[2 * n] - base;
+  int r;
+  if ((r = ensure(e, SC_STAGE_A, bytes + CTMR_PAYLOAD_PAD + 16))) return r;
+  // SC_STAGE_B: bounds | new_idx | timestamp
+  const size_t o_b = 0, o_new = (2 * n + 1) * 8, o_ts = o_new + n * 8;
+  if ((r = ensure(e, SC_STAGE_B, o_ts + n * 8))) return r;
+  uint8_t* B = (uint8_t*)e->d_scratch[SC_STAGE_B];
+  std::vector<uint64_t> rel(2 * n + 1);
+  for (uint64_t i = 0; i <= 2 * n; i++) rel[i] = bounds[i] - base;
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_STAGE_A], blob + base, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemsetAsync((uint8_t*)e->d_scratch[SC_STAGE_A] + bytes, 0, CTMR_PAYLOAD_PAD, e->stream));
+  HIPCHK(e, hipMemcpyAsync(B + o_b, rel.data(), (2 * n + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  ctmr_batch_stats st;
+  ctmr_entry_view v;
+  r = map_entries_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)(B + o_b), n, nullptr,
+                         new_idx ? (uint64_t*)(B + o_new) : nullptr, timestamp ? (uint64_t*)(B + o_ts) : nullptr,
+                         dstats, &st, &v);
+  if (r) return r;
+  if (records) HIPCHK(e, hipMemcpy(records, e->d_scratch[SC_RECORDS], n * sizeof(ctmr_record), hipMemcpyDeviceToHost));
+  if (new_idx && st.n_new) HIPCHK(e, hipMemcpy(new_idx, B + o_new, st.n_new * 8, hipMemcpyDeviceToHost));
+  if (timestamp) HIPCHK(e, hipMemcpy(timestamp, B + o_ts, n * 8, hipMemcpyDeviceToHost));
+  if (stats) *stats = st;
+  // what ctmr_pem_new encodes: the view lives in SC_VIEW, the new list in SC_STAGE_B
+  e->last_n = n; e->last_n_new = new_idx ? st.n_new : 0; e->last_o_new = o_new;
+  e->last_is_view = true;
+  e->last_o_start = (size_t)((uint8_t*)v.cert_start - (uint8_t*)e->d_scratch[SC_VIEW]);
+  e->last_o_end = (size_t)((uint8_t*)v.cert_end - (uint8_t*)e->d_scratch[SC_VIEW]);
   return CTMR_OK;
 }
 
@@ -784,7 +1065,7 @@ int ctmr_map_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offse
 
 static int pem_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                              const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,
-                             uint64_t* d_pem_offsets, uint64_t* pem_bytes) {
+                             uint64_t* d_pem_offsets, uint64_t* pem_bytes, const uint64_t* d_ends = nullptr) {
   HIPCHK(e, hipSetDevice(e->device));
   if (pem_bytes) *pem_bytes = 0;
   if (n_idx == 0) {
@@ -793,8 +1074,8 @@ static int pem_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
     return CTMR_OK;
   }
   if (n_idx >= 0x7fffffffull) return fail(e, CTMR_E_INVAL, "too many certificates in one PEM call");
-  hipLaunchKernelGGL(k_pem_len, dim3((unsigned)((n_idx + 1 + 255) / 256)), dim3(256), 0, e->stream, d_offsets, d_idx,
-                     n_idx, d_pem_offsets);
+  hipLaunchKernelGGL(k_pem_len, dim3((unsigned)((n_idx + 1 + 255) / 256)), dim3(256), 0, e->stream, d_offsets, d_ends,
+                     d_idx, n_idx, d_pem_offsets);
   size_t tmp_bytes = 0;
   HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_pem_offsets, d_pem_offsets, (int64_t)(n_idx + 1), e->stream));
   int r;
@@ -807,7 +1088,7 @@ static int pem_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   if (pem_bytes) *pem_bytes = total;
   if (!d_pem) return CTMR_OK;  // size query
   if (total > pem_cap) return fail(e, CTMR_E_RANGE, "PEM buffer too small: need %llu bytes", (unsigned long long)total);
-  hipLaunchKernelGGL(k_pem_encode, dim3((unsigned)n_idx), dim3(128), 0, e->stream, d_payload, d_offsets, d_idx,
+  hipLaunchKernelGGL(k_pem_encode, dim3((unsigned)n_idx), dim3(128), 0, e->stream, d_payload, d_offsets, d_ends, d_idx,
                      (const uint64_t*)d_pem_offsets, d_pem);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipGetLastError());
@@ -837,14 +1118,17 @@ int ctmr_pem_new(ctmr_engine* e, uint8_t* out, size_t cap, uint64_t* pem_offsets
   uint8_t* B = (uint8_t*)e->d_scratch[SC_STAGE_B];
   uint64_t* d_po = (uint64_t*)e->d_scratch[SC_PEMOFF];
   uint64_t total = 0;
-  r = pem_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)(B + e->last_o_off),
-                        (const uint64_t*)(B + e->last_o_new), nn, nullptr, 0, d_po, &total);
+  const uint8_t* V = (const uint8_t*)e->d_scratch[SC_VIEW];
+  const uint64_t* offs = e->last_is_view ? (const uint64_t*)(V + e->last_o_start) : (const uint64_t*)(B + e->last_o_off);
+  const uint64_t* ends = e->last_is_view ? (const uint64_t*)(V + e->last_o_end) : nullptr;
+  r = pem_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], offs,
+                        (const uint64_t*)(B + e->last_o_new), nn, nullptr, 0, d_po, &total, ends);
   if (r) return r;
   if (need) *need = total;
   if (!out || cap < total) return out ? fail(e, CTMR_E_RANGE, "PEM buffer too small: need %llu bytes", (unsigned long long)total) : CTMR_E_RANGE;
   if ((r = ensure(e, SC_PEM, total + 64))) return r;
-  r = pem_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)(B + e->last_o_off),
-                        (const uint64_t*)(B + e->last_o_new), nn, (uint8_t*)e->d_scratch[SC_PEM], total + 64, d_po, &total);
+  r = pem_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], offs,
+                        (const uint64_t*)(B + e->last_o_new), nn, (uint8_t*)e->d_scratch[SC_PEM], total + 64, d_po, &total, ends);
   if (r) return r;
   HIPCHK(e, hipMemcpy(out, e->d_scratch[SC_PEM], total, hipMemcpyDeviceToHost));
   if (pem_offsets) HIPCHK(e, hipMemcpy(pem_offsets, d_po, (nn + 1) * 8, hipMemcpyDeviceToHost));
@@ -876,7 +1160,7 @@ int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const 
   uint32_t* d_cnt = (uint32_t*)e->d_scratch[SC_BLKNEW];
   uint64_t* d_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
   InsertArgs ia;
-  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.canon = e->d_canon;
+  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.ends = nullptr; ia.canon = e->d_canon;
   ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = nullptr; ia.n = n; ia.epoch = e->epoch;
   HIPCHK(e, hipMemsetAsync(d_cnt, 0, (ncnt + 1) * 4, e->stream));
   hipLaunchKernelGGL(k_key_count, dim3((unsigned)nb), dim3(1024), 0, e->stream, ia, world, nb, d_owner, d_cnt);
@@ -1299,6 +1583,58 @@ int ctmr_synth_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first
   if (!d_issuer_idx || !d_entry_type) return CTMR_E_INVAL;
   hipLaunchKernelGGL(k_synth_emit, dim3(blocks), dim3(256), 0, e->stream, s, first, n, (const uint64_t*)d_offsets,
                      d_payload, d_issuer_idx, d_entry_type);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  return CTMR_OK;
+}
+
+
+uint64_t ctmr_synth_entries_host(const ctmr_synth_config* c, uint64_t first, uint64_t n, uint64_t* bounds,
+                                 uint8_t* blob, uint64_t cap) {
+  const auto& cdf = host_cdf(c->n_issuers ? c->n_issuers : 1);
+  SynthCfg s = to_synth(c, cdf.data());
+  std::vector<uint8_t> tmp(SYNTH_ENTRY_MAX);
+  uint64_t at = 0;
+  if (bounds) bounds[0] = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    BackWriter w{tmp.data(), SYNTH_ENTRY_MAX};
+    const uint32_t leaf = synth_entry_emit(s, first + i, w);
+    const uint32_t len = SYNTH_ENTRY_MAX - w.pos;
+    if (blob && at + len <= cap) memcpy(blob + at, tmp.data() + w.pos, len);
+    if (bounds) {
+      bounds[2 * i + 1] = at + leaf;
+      bounds[2 * i + 2] = at + len;
+    }
+    at += len;
+  }
+  return at;
+}
+
+int ctmr_synth_entries_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n,
+                              uint64_t* d_bounds, uint8_t* d_blob, uint64_t blob_cap, uint64_t* blob_bytes) {
+  if (!e || !c || !d_bounds) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (n == 0) return CTMR_OK;
+  const uint32_t ni = c->n_issuers ? c->n_issuers : 1;
+  const auto& cdf = host_cdf(ni);
+  int r;
+  if ((r = ensure(e, SC_MISC, (size_t)ni * 4))) return r;
+  HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_MISC], cdf.data(), (size_t)ni * 4, hipMemcpyHostToDevice, e->stream));
+  SynthCfg s = to_synth(c, (const uint32_t*)e->d_scratch[SC_MISC]);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_synth_entries_len, dim3(blocks), dim3(256), 0, e->stream, s, first, n, d_bounds);
+  size_t tmp_bytes = 0;
+  HIPCHK(e, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d_bounds + 1, d_bounds + 1, (int64_t)(2 * n), e->stream));
+  if ((r = ensure(e, SC_TMP, tmp_bytes))) return r;
+  HIPCHK(e, hipcub::DeviceScan::InclusiveSum(e->d_scratch[SC_TMP], tmp_bytes, d_bounds + 1, d_bounds + 1, (int64_t)(2 * n), e->stream));
+  uint64_t total = 0;
+  HIPCHK(e, hipMemcpyAsync(&total, d_bounds + 2 * n, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (blob_bytes) *blob_bytes = total;
+  if (!d_blob) return CTMR_OK;
+  if (total + CTMR_PAYLOAD_PAD > blob_cap) return fail(e, CTMR_E_RANGE, "blob needs %llu bytes (+%d pad)", (unsigned long long)total, CTMR_PAYLOAD_PAD);
+  hipLaunchKernelGGL(k_synth_entries_emit, dim3(blocks), dim3(256), 0, e->stream, s, first, n, (const uint64_t*)d_bounds, d_blob);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipGetLastError());
   return CTMR_OK;

@@ -14,6 +14,7 @@
 //   k_synth_*        synthetic batch generator
 #pragma once
 #include "ctmr_dev.h"
+#include "entry_decode.h"
 #include "synth.h"
 
 namespace ctmr {
@@ -347,7 +348,9 @@ __global__ void __launch_bounds__(64) k_sha256_one(const uint8_t* msg, uint32_t 
 // ------------------------------------------------------------------ the map
 struct MapArgs {
   const uint8_t* payload;
-  const uint64_t* offsets;
+  const uint64_t* offsets;    // packed batch: n+1 offsets; entry view (ends != null): n range starts
+  const uint64_t* ends;       // null = packed batch; else certificate i is [offsets[i], ends[i]) (ctmr_entry_view)
+  uint64_t limit;             // entry view: readable bytes of payload (blob bytes + CTMR_PAYLOAD_PAD)
   const uint32_t* issuer_idx;
   const uint8_t* entry_type;  // may be null
   ctmr_record* records;
@@ -364,6 +367,17 @@ struct MapArgs {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
+// Byte range of certificate i and the readable size of the payload, for both input forms.
+__device__ __forceinline__ void cert_range(const uint64_t* offsets, const uint64_t* ends, uint64_t i, uint64_t& lo,
+                                           uint64_t& hi) {
+  lo = offsets[i];
+  hi = ends ? ends[i] : offsets[i + 1];
+  if (hi < lo) hi = lo;
+}
+__device__ __forceinline__ uint64_t map_limit(const MapArgs& a) {
+  return a.ends ? a.limit : a.offsets[a.n] + CTMR_PAYLOAD_PAD;
+}
+
 // Everything after the bytes are addressable: walk, filters, record.
 template <class R>
 __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, uint4& o0,
@@ -374,8 +388,11 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
   const bool ok = walk_cert(r, L, w, f->active != 0u, fv);  // L > 2^31-1 is rejected inside, without divergence
   const uint32_t iss = a.issuer_idx[idx];
+  const uint32_t et = a.entry_type ? a.entry_type[idx] : 0u;
   uint32_t status;
-  if (!ok) {
+  if (et == CTMR_ENTRY_INVALID) {
+    status = CTMR_ST_ENTRY_DECODE_ERROR;  // never reached entryChan (ct-fetch.go:452-459)
+  } else if (!ok) {
     status = CTMR_ST_PARSE_ERROR;
   } else if (w.bc_valid && w.is_ca) {
     status = CTMR_ST_FILTERED_CA;
@@ -390,7 +407,7 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   } else {
     status = CTMR_ST_PASS;
   }
-  uint32_t flags = (a.entry_type && a.entry_type[idx] == 1) ? CTMR_FL_PRECERT : 0u;
+  uint32_t flags = et == 1u ? CTMR_FL_PRECERT : 0u;
   if (a.optimistic_new && status == CTMR_ST_PASS) flags |= CTMR_FL_WAS_UNKNOWN;
   uint32_t slen = 0, s[5] = {0, 0, 0, 0, 0};
   int32_t exp_hour = 0;
@@ -498,9 +515,8 @@ __global__ void __launch_bounds__(64) k_map_tile(MapArgs a) {
 __global__ void __launch_bounds__(256) k_map_direct(MapArgs a) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  const uint64_t lo = a.offsets[i];
-  uint64_t hi = a.offsets[i + 1];
-  if (hi < lo) hi = lo;
+  uint64_t lo, hi;
+  cert_range(a.offsets, a.ends, i, lo, hi);
   GlobalReader r{(const uint32_t*)a.payload, lo};
   map_one(r, hi - lo, i, a);
 }
@@ -515,11 +531,10 @@ __global__ void __launch_bounds__(64) k_map_win(MapArgs a) {
   const bool live = i < a.n;
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   if (live) {
-    const uint64_t lo = a.offsets[i];
-    uint64_t hi = a.offsets[i + 1];
-    if (hi < lo) hi = lo;
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
     constexpr uint32_t STRIDE = WCH * 16 + 16;
-    WinReader<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+    WinReader<WCH> r{(const uint32_t*)a.payload, lo, map_limit(a),
                      (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
     r.refill(0);
     map_one(r, hi - lo, i, a, o0, o1);
@@ -539,13 +554,9 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   const uint64_t i = first + lane;
   const bool live = i < a.n;
   constexpr uint32_t STRIDE = WCH * 16 + 16;
-  const uint64_t limit = a.offsets[a.n] + CTMR_PAYLOAD_PAD;
+  const uint64_t limit = map_limit(a);
   uint64_t lo = 0, hi = 0;
-  if (live) {
-    lo = a.offsets[i];
-    hi = a.offsets[i + 1];
-    if (hi < lo) hi = lo;
-  }
+  if (live) cert_range(a.offsets, a.ends, i, lo, hi);
   const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
   {
     uint4 v[16];
@@ -578,11 +589,10 @@ __global__ void __launch_bounds__(64) k_map_wint(MapArgs a) {
   const bool live = i < a.n;
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   if (live) {
-    const uint64_t lo = a.offsets[i];
-    uint64_t hi = a.offsets[i + 1];
-    if (hi < lo) hi = lo;
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
     constexpr uint32_t STRIDE = WCH * 16 + 16;
-    WinReaderT<WCH, NF, NE> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+    WinReaderT<WCH, NF, NE> r{(const uint32_t*)a.payload, lo, map_limit(a),
                               (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0};
     r.refill(0, NF);
     map_one(r, hi - lo, i, a, o0, o1);
@@ -598,11 +608,10 @@ __global__ void __launch_bounds__(64) k_map_win2(MapArgs a) {
   const bool live = i < a.n;
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   if (live) {
-    const uint64_t lo = a.offsets[i];
-    uint64_t hi = a.offsets[i + 1];
-    if (hi < lo) hi = lo;
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
     constexpr uint32_t STRIDE = (WCH + 3) * 16;
-    WinReader2<WCH> r{(const uint32_t*)a.payload, lo, a.offsets[a.n] + CTMR_PAYLOAD_PAD,
+    WinReader2<WCH> r{(const uint32_t*)a.payload, lo, map_limit(a),
                       (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0x7fffff00};
     r.refill(0);
     map_one(r, hi - lo, i, a, o0, o1);
@@ -674,6 +683,7 @@ struct InsertArgs {
   const ctmr_record* records;
   const uint8_t* payload;  // for serials longer than the 20 octets a record carries
   const uint64_t* offsets;
+  const uint64_t* ends;    // null = packed batch (MapArgs)
   const uint32_t* canon;   // issuer_idx → canonical issuer
   Slot* table;
   uint64_t mask;
@@ -732,9 +742,10 @@ __device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, cons
   s[4] = 0;
   if (slen > 20) {
     // octets 20..slen-1 come from the certificate itself
-    const uint64_t lo = a.offsets[i];
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
     GlobalReader g{(const uint32_t*)a.payload, lo};
-    const uint32_t so = serial_content_off(g, (uint32_t)(a.offsets[i + 1] - lo));
+    const uint32_t so = serial_content_off(g, (uint32_t)(hi - lo));
     uint32_t x[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -905,13 +916,9 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   const uint64_t i = first + lane;
   const bool live = i < a.n;
   constexpr uint32_t STRIDE = WCH * 16 + 16;
-  const uint64_t limit = a.offsets[a.n] + CTMR_PAYLOAD_PAD;
+  const uint64_t limit = map_limit(a);
   uint64_t lo = 0, hi = 0;
-  if (live) {
-    lo = a.offsets[i];
-    hi = a.offsets[i + 1];
-    if (hi < lo) hi = lo;
-  }
+  if (live) cert_range(a.offsets, a.ends, i, lo, hi);
   const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
   {
     uint4 v[16];
@@ -1343,17 +1350,17 @@ __host__ __device__ inline uint64_t pem_len(uint64_t L) {
   return 28 + b64 + (b64 + 63) / 64 + 26;
 }
 
-__global__ void __launch_bounds__(256) k_pem_len(const uint64_t* offsets, const uint64_t* idx, uint64_t n_idx,
-                                                 uint64_t* pem_off) {
+__global__ void __launch_bounds__(256) k_pem_len(const uint64_t* offsets, const uint64_t* ends, const uint64_t* idx,
+                                                 uint64_t n_idx, uint64_t* pem_off) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r > n_idx) return;
   if (r == n_idx) {
     pem_off[r] = 0;  // the exclusive scan turns this slot into the total
     return;
   }
-  const uint64_t i = idx[r];
-  const uint64_t lo = offsets[i], hi = offsets[i + 1];
-  pem_off[r] = pem_len(hi > lo ? hi - lo : 0);
+  uint64_t lo, hi;
+  cert_range(offsets, ends, idx[r], lo, hi);
+  pem_off[r] = pem_len(hi - lo);
 }
 
 struct __attribute__((packed, aligned(1))) U12 { uint32_t a, b, c; };
@@ -1379,12 +1386,11 @@ __device__ __forceinline__ uint32_t b64_group(uint32_t w) {
 // adjacent lanes read adjacent 12-byte pieces and write adjacent 16-byte pieces (unaligned
 // dwordx3 / dwordx4 accesses; gfx950 runs with unaligned access mode).
 __global__ void __launch_bounds__(128) k_pem_encode(const uint8_t* payload, const uint64_t* offsets,
-                                                    const uint64_t* idx, const uint64_t* pem_off, uint8_t* out) {
+                                                    const uint64_t* ends, const uint64_t* idx,
+                                                    const uint64_t* pem_off, uint8_t* out) {
   const uint64_t r = blockIdx.x;
-  const uint64_t i = idx[r];
-  const uint64_t lo = offsets[i];
-  uint64_t hi = offsets[i + 1];
-  if (hi < lo) hi = lo;
+  uint64_t lo, hi;
+  cert_range(offsets, ends, idx[r], lo, hi);
   const uint64_t L = hi - lo;
   const uint8_t* in = payload + lo;
   uint8_t* o = out + pem_off[r];
@@ -1425,6 +1431,203 @@ __global__ void __launch_bounds__(128) k_pem_encode(const uint8_t* payload, cons
         c += 4;
       }
       q[c] = (uint8_t)'\n';
+    }
+  }
+}
+
+// ------------------------------------------------------------------ CT get-entries decode
+struct __attribute__((packed, aligned(1))) U4 { uint32_t a; };
+struct DevBytes {  // arbitrary byte positions of the blob (gfx950 runs with unaligned access mode)
+  const uint8_t* p;
+  __device__ __forceinline__ uint32_t le32(uint64_t pos) const { return ((const U4*)(p + pos))->a; }
+  __device__ __forceinline__ uint32_t u8(uint64_t pos) const { return p[pos]; }
+  __device__ __forceinline__ uint32_t be(uint64_t pos, int k) const {  // reads ≤ 3 bytes past pos+k: CTMR_PAYLOAD_PAD
+    return __builtin_bswap32(le32(pos)) >> (32 - 8 * k);
+  }
+};
+
+struct DecodeArgs {
+  const uint8_t* blob;
+  const uint64_t* bounds;  // 2n+1
+  uint64_t n;
+  uint64_t* cert_start;
+  uint64_t* cert_end;
+  uint8_t* entry_type;
+  uint64_t* timestamp;     // may be null
+  uint64_t* chain0_start;
+  uint32_t* chain0_len;
+  unsigned long long* counters;  // [0] x509 [1] precert [2] decode error [3] len(Chain) < 1
+};
+
+// ct.LogEntryFromLeaf, one raw entry per lane (entry_decode.h).  Reads ≈ 5 scattered header words per entry
+// (leaf header, extensions length behind the certificate, the chain headers); the certificates themselves
+// are skipped by length.
+__global__ void __launch_bounds__(256) k_entry_decode(DecodeArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < a.n;
+  EntryDec d;
+  d.ok = false;
+  d.entry_type = 0;
+  d.n_chain = 0;
+  if (live) {
+    DevBytes b{a.blob};
+    decode_entry(b, a.bounds[2 * i], a.bounds[2 * i + 1], a.bounds[2 * i + 2], d);
+    a.cert_start[i] = d.ok ? d.cert_lo : 0ull;
+    a.cert_end[i] = d.ok ? d.cert_hi : 0ull;
+    a.entry_type[i] = d.ok ? (uint8_t)d.entry_type : (uint8_t)CTMR_ENTRY_INVALID;
+    if (a.timestamp) a.timestamp[i] = d.ok ? d.timestamp : 0ull;
+    a.chain0_start[i] = d.ok ? d.chain0_lo : 0ull;
+    a.chain0_len[i] = d.ok ? d.chain0_len : 0u;
+  }
+  const unsigned long long m0 = __ballot(live && d.ok && d.entry_type == 0), m1 = __ballot(live && d.ok && d.entry_type == 1),
+                           m2 = __ballot(live && !d.ok), m3 = __ballot(live && d.ok && d.n_chain == 0);
+  if ((threadIdx.x & 63) == 0) {
+    if (m0) atomicAdd(&a.counters[0], (unsigned long long)__popcll(m0));
+    if (m1) atomicAdd(&a.counters[1], (unsigned long long)__popcll(m1));
+    if (m2) atomicAdd(&a.counters[2], (unsigned long long)__popcll(m2));
+    if (m3) atomicAdd(&a.counters[3], (unsigned long long)__popcll(m3));
+  }
+}
+
+// Chain[0] → issuer table index: replaces, per entry, x509.ParseCertificate(Chain[0]) + NewIssuer
+// (ct-fetch.go:221; storage/types.go:109-115) by a bytewise match against the issuer certificates registered so
+// far (each of which went through exactly that parse once, k_issuer_ids).  Phase 1, per lane: candidate from a
+// small hash table keyed by cert_quick_hash.  Phase 2, wave-cooperative: the 64 lanes stream the candidate's
+// bytes (16 B per lane per step, 1 KiB per instruction) against the registered copy — every byte of Chain[0]
+// is compared, so equal means identical.  Unregistered certificates are reported once per distinct hash
+// (pend[] claims) for the host to register; `retry` re-examines only entries still marked unregistered.
+constexpr uint32_t ISS_UNREGISTERED = 0xfffffffeu;
+constexpr uint32_t PEND_SLOTS = 8192;  // distinct unknown Chain[0] hashes remembered per launch
+
+struct MatchArgs {
+  const uint8_t* blob;
+  const uint64_t* chain0_start;
+  const uint32_t* chain0_len;
+  const uint8_t* entry_type;
+  uint32_t* issuer_idx;
+  uint64_t n;
+  // issuer certificate store
+  const uint8_t* idb_der;       // registered certificates, each at a 16-byte aligned offset, zero padded
+  const uint64_t* idb_off;      // per issuer: offset into idb_der
+  const uint32_t* idb_len;
+  const unsigned long long* idb_qh;
+  const uint32_t* ht;           // open addressing: issuer index + 1, 0 = empty
+  uint32_t ht_mask;
+  uint32_t retry;
+  // unregistered report
+  unsigned long long* pend;     // PEND_SLOTS claim words (zeroed by the host)
+  uint32_t* unreg_list;         // entry indices, one per distinct hash
+  uint32_t unreg_cap;
+  unsigned long long* counters; // [0] entries left unregistered, [1] list entries, [2] pend overflow
+};
+
+__device__ __forceinline__ bool eq16_prefix(const U16& x, const uint4& y, uint32_t rem) {  // first min(rem,16) bytes equal
+  const uint32_t d[4] = {x.a ^ y.x, x.b ^ y.y, x.c ^ y.z, x.d ^ y.w};
+  bool eq = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t have = rem > 4u * k ? rem - 4u * k : 0u;
+    const uint32_t mask = have >= 4u ? 0xffffffffu : (have ? (0xffffffffu >> (8 * (4 - have))) : 0u);
+    eq = eq && (d[k] & mask) == 0u;
+  }
+  return eq;
+}
+
+__global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < a.n;
+  uint64_t lo = 0;
+  uint32_t len = 0;
+  bool need = false;
+  uint32_t result = CTMR_NO_ISSUER;
+  if (live) {
+    if (a.retry) {
+      result = a.issuer_idx[i];
+      need = result == ISS_UNREGISTERED;
+    } else {
+      need = a.entry_type[i] != CTMR_ENTRY_INVALID;
+    }
+    if (need) {
+      lo = a.chain0_start[i];
+      len = a.chain0_len[i];
+      need = len != 0u;
+      if (!need) result = CTMR_NO_ISSUER;
+    }
+  }
+  DevBytes b{a.blob};
+  unsigned long long qh = 0;
+  uint32_t j = 0;
+  if (need) {
+    qh = cert_quick_hash(b, lo, len);
+    j = (uint32_t)qh & a.ht_mask;
+    result = ISS_UNREGISTERED;
+  }
+  bool searching = need;
+  while (__ballot(searching)) {
+    // next candidate of every searching lane
+    uint32_t cand = 0xffffffffu;
+    if (searching) {
+      for (;;) {
+        const uint32_t v = a.ht[j];
+        if (v == 0u) {
+          searching = false;
+          break;
+        }
+        j = (j + 1u) & a.ht_mask;
+        if (a.idb_qh[v - 1u] == qh && a.idb_len[v - 1u] == len) {
+          cand = v - 1u;
+          break;
+        }
+      }
+    }
+    // cooperative bytewise verification, one candidate at a time
+    unsigned long long todo = __ballot(cand != 0xffffffffu);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const uint64_t s_lo = __shfl(lo, src);
+      const uint32_t s_len = __shfl(len, src);
+      const uint32_t s_c = __shfl(cand, src);
+      const uint8_t* db = a.idb_der + a.idb_off[s_c];
+      bool eq = true;
+      for (uint32_t off = lane * 16u; off < s_len; off += 1024u) {
+        const U16 x = *(const U16*)(a.blob + s_lo + off);  // ≤ 15 bytes past Chain[0]: CTMR_PAYLOAD_PAD
+        const uint4 y = *(const uint4*)(db + off);
+        eq = eq && eq16_prefix(x, y, s_len - off);
+      }
+      const bool all = __ballot(!eq) == 0ull;
+      if ((int)lane == src && all) {
+        result = s_c;
+        searching = false;
+      }
+    }
+  }
+  if (live) a.issuer_idx[i] = result;
+  // report unregistered certificates, once per distinct hash
+  const bool unreg = live && result == ISS_UNREGISTERED;
+  const unsigned long long mu = __ballot(unreg);
+  if (lane == 0 && mu) atomicAdd(&a.counters[0], (unsigned long long)__popcll(mu));
+  if (unreg) {
+    uint32_t k = (uint32_t)(qh >> 32) & (PEND_SLOTS - 1u);
+    bool first = false, placed = false;
+    for (uint32_t probes = 0; probes < 64u && !placed; probes++) {
+      const unsigned long long old = atomicCAS(&a.pend[k], 0ull, qh);
+      if (old == 0ull) {
+        first = true;
+        placed = true;
+      } else if (old == qh) {
+        placed = true;
+      }
+      k = (k + 1u) & (PEND_SLOTS - 1u);
+    }
+    if (!placed) {
+      atomicAdd(&a.counters[2], 1ull);
+      first = true;  // overflow: report it anyway (the host dedups by bytes)
+    }
+    if (first) {
+      const unsigned long long at = atomicAdd(&a.counters[1], 1ull);
+      if (at < a.unreg_cap) a.unreg_list[at] = (uint32_t)i;
     }
   }
 }
@@ -1547,6 +1750,27 @@ __global__ void __launch_bounds__(256) k_synth_emit(SynthCfg c, uint64_t first, 
   synth_leaf_emit(c, first + i, w, iss, et);
   issuer_idx[i] = iss;
   entry_type[i] = et;
+}
+
+
+// raw get-entries form: lens[2i] = leaf_input bytes, lens[2i+1] = extra_data bytes (scanned into bounds by the host)
+__global__ void __launch_bounds__(256) k_synth_entries_len(SynthCfg c, uint64_t first, uint64_t n, uint64_t* bounds) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  BackWriter w{nullptr, SYNTH_ENTRY_MAX};
+  const uint32_t leaf = synth_entry_emit(c, first + i, w);
+  bounds[2 * i + 1] = leaf;
+  bounds[2 * i + 2] = SYNTH_ENTRY_MAX - w.pos - leaf;
+  if (i == 0) bounds[0] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_synth_entries_emit(SynthCfg c, uint64_t first, uint64_t n,
+                                                            const uint64_t* bounds, uint8_t* blob) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = (uint32_t)(bounds[2 * i + 2] - bounds[2 * i]);
+  BackWriter w{blob + bounds[2 * i], len};
+  synth_entry_emit(c, first + i, w);
 }
 
 }  // namespace ctmr

@@ -251,7 +251,7 @@ CTMR_HD uint32_t synth_pick_issuer(const SynthCfg& c, uint32_t u) {
 
 // Emit leaf certificate i backward into w; returns nothing — length = cap - w.pos afterwards.
 CTMR_HD void synth_leaf_emit(const SynthCfg& c, uint64_t i, BackWriter& w, uint32_t& issuer_idx,
-                             uint8_t& entry_type) {
+                             uint8_t& entry_type, uint32_t* tbs_total = nullptr) {
   const uint64_t src = synth_src(c, i);
   const bool identical = src != i && (h3(c.seed, i, SALT_IDENT) & 1u);
   Rng kr{h3(c.seed, src, SALT_KEY)};
@@ -410,6 +410,7 @@ CTMR_HD void synth_leaf_emit(const SynthCfg& c, uint64_t i, BackWriter& w, uint3
   }
   w.put(0x02); w.put(0x01); w.put(0x02); w.put(0x03); w.put(0xa0);  // [0] { INTEGER 2 }
   w.hdr(0x30, tbs_end);
+  if (tbs_total) *tbs_total = tbs_end - w.pos;  // the TBSCertificate TLV
   w.hdr(0x30, cap);
 }
 
@@ -464,5 +465,75 @@ CTMR_HD void synth_issuer_emit(const SynthCfg& c, uint32_t k, BackWriter& w) {
 }
 
 constexpr uint32_t SYNTH_MAX_LEN = 2560;  // scratch size for one certificate
+
+// ---------------------------------------------------------------- raw get-entries form (RFC 6962 §3.4, §4.6)
+// entry i = leaf_input ‖ extra_data around the certificate of synth_leaf_emit(i):
+//   entry_type 0: MerkleTreeLeaf{v1, timestamped_entry, ts, x509_entry, ASN.1Cert cert, ext<>} ‖ chain<[issuer]>
+//   entry_type 1: MerkleTreeLeaf{v1, timestamped_entry, ts, precert_entry, issuer_key_hash, TBS, ext<>} ‖
+//                 PrecertChainEntry{pre_certificate = cert, chain<[issuer]>}
+// (the synthetic precertificate carries no poison extension and issuer_key_hash is pseudo-random: neither is
+// consumed by the path).  Written backward like everything else; returns the length of leaf_input.
+constexpr uint32_t SYNTH_ENTRY_MAX = 6144;  // scratch size for one raw entry
+
+CTMR_HD void put_be24(BackWriter& w, uint32_t v) {
+  w.put((uint8_t)v); w.put((uint8_t)(v >> 8)); w.put((uint8_t)(v >> 16));
+}
+
+CTMR_HD uint32_t synth_entry_issuer(const SynthCfg& c, uint64_t i) {  // the issuer synth_leaf_emit(i) picks
+  Rng kr{h3(c.seed, synth_src(c, i), SALT_KEY)};
+  return synth_pick_issuer(c, (uint32_t)(kr.next() >> 32));
+}
+
+CTMR_HD uint32_t synth_entry_emit(const SynthCfg& c, uint64_t i, BackWriter& w) {
+  const uint32_t cap = w.pos;
+  const uint8_t et = (uint8_t)(h3(c.seed, i, SALT_TYPE) & 1u);
+  const uint32_t issuer = synth_entry_issuer(c, i);
+  uint32_t iss2, tbs_total = 0;
+  uint8_t et2;
+  // ---- extra_data (behind the leaf in memory, so written first)
+  {
+    const uint32_t e = w.pos;
+    synth_issuer_emit(c, issuer, w);
+    put_be24(w, e - w.pos);  // ASN.1Cert
+    put_be24(w, e - w.pos);  // chain<0..2^24-1>
+  }
+  uint32_t cert_pos = 0;
+  if (et == 1) {
+    const uint32_t e = w.pos;
+    synth_leaf_emit(c, i, w, iss2, et2, &tbs_total);
+    cert_pos = w.pos;
+    put_be24(w, e - w.pos);  // pre_certificate
+  }
+  const uint32_t extra_len = cap - w.pos;
+  // ---- leaf_input
+  w.put(0); w.put(0);  // CtExtensions<>
+  if (et == 0) {
+    const uint32_t e = w.pos;
+    synth_leaf_emit(c, i, w, iss2, et2);
+    put_be24(w, e - w.pos);
+  } else {
+    const uint32_t e = w.pos;
+    // TBSCertificate = the TBS TLV of the certificate just written (it starts behind the 4-byte outer header)
+    if (w.buf) {
+      for (uint32_t k = tbs_total; k > 0; k--) w.put(w.buf[cert_pos + 4 + k - 1]);
+    } else {
+      w.pos -= tbs_total;
+    }
+    put_be24(w, e - w.pos);
+    Rng hr{h3(c.seed, issuer, SALT_ISSUER) ^ 0x1b5};
+    w.random(hr, 32);  // issuer_key_hash
+  }
+  w.put(et); w.put(0);  // entry_type (u16)
+  {
+    uint64_t ts = (uint64_t)c.base_time * 1000ull + i;
+    for (int k = 0; k < 8; k++) {
+      w.put((uint8_t)ts);
+      ts >>= 8;
+    }
+  }
+  w.put(0);  // leaf_type timestamped_entry
+  w.put(0);  // version v1
+  return cap - w.pos - extra_len;
+}
 
 }  // namespace ctmr

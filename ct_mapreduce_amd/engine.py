@@ -49,6 +49,44 @@ class Batch:
 
 
 @dataclass
+class RawEntries:
+    """Raw get-entries batch: blob = leaf_input_0 ‖ extra_data_0 ‖ leaf_input_1 ‖ …, bounds u64[2n+1] (include/ctmr.h)."""
+    blob: np.ndarray         # u8
+    bounds: np.ndarray       # u64[2n+1]
+
+    @property
+    def n(self):
+        return (len(self.bounds) - 1) // 2
+
+    def leaf_input(self, i):
+        return self.blob[int(self.bounds[2 * i]):int(self.bounds[2 * i + 1])].tobytes()
+
+    def extra_data(self, i):
+        return self.blob[int(self.bounds[2 * i + 1]):int(self.bounds[2 * i + 2])].tobytes()
+
+    @staticmethod
+    def from_pairs(pairs):
+        """pairs: [(leaf_input bytes, extra_data bytes)] — the base64-decoded members of a get-entries response."""
+        parts, bounds, at = [], [0], 0
+        for leaf, extra in pairs:
+            for b in (leaf, extra):
+                parts.append(bytes(b))
+                at += len(b)
+                bounds.append(at)
+        blob = np.frombuffer(b"".join(parts), np.uint8).copy() if at else np.zeros(0, np.uint8)
+        return RawEntries(blob, np.asarray(bounds, np.uint64))
+
+
+@dataclass
+class EntriesResult:
+    records: np.ndarray      # RECORD_DTYPE[n]
+    new_idx: np.ndarray      # u64[n_new], ascending
+    timestamp: np.ndarray    # u64[n], ms
+    stats: N.BatchStats
+    decode: N.DecodeStats
+
+
+@dataclass
 class BatchResult:
     records: np.ndarray      # RECORD_DTYPE[n]
     new_idx: np.ndarray      # u64[n_new], ascending
@@ -153,6 +191,51 @@ class Engine:
             C.c_void_p(d_records) if d_records else None,
             C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
         return st
+
+    # ---- raw get-entries input (N2): ct.LogEntryFromLeaf + the choice of certificate and Chain[0] on the GPU
+    def map_entries(self, raw: RawEntries) -> EntriesResult:
+        """Downloader decode (ct-fetch.go:452) + insertCTWorker (:191-235) over raw entries.  Chain[0] certificates
+        are registered as issuers by the call; entries LogEntryFromLeaf rejects get ST_ENTRY_DECODE_ERROR."""
+        n = raw.n
+        blob = np.ascontiguousarray(raw.blob, dtype=np.uint8)
+        if blob.size == 0:
+            blob = np.zeros(1, np.uint8)
+        bounds = np.ascontiguousarray(raw.bounds, dtype=np.uint64)
+        records = np.zeros(n, dtype=RECORD_DTYPE)
+        new_idx = np.zeros(max(n, 1), dtype=np.uint64)
+        ts = np.zeros(max(n, 1), dtype=np.uint64)
+        st, ds = N.BatchStats(), N.DecodeStats()
+        self._ck(self._lib.ctmr_map_entries(self._h, blob.ctypes.data, bounds.ctypes.data, n,
+                                            records.ctypes.data if n else None, new_idx.ctypes.data if n else None,
+                                            ts.ctypes.data if n else None, C.byref(ds), C.byref(st)))
+        return EntriesResult(records, new_idx[:st.n_new], ts[:n], st, ds)
+
+    def decode_entries_device(self, d_blob, d_bounds, n, view: N.EntryView) -> N.DecodeStats:
+        ds = N.DecodeStats()
+        self._ck(self._lib.ctmr_decode_entries_device(self._h, C.c_void_p(d_blob), C.c_void_p(d_bounds), n,
+                                                      C.byref(view), C.byref(ds)))
+        return ds
+
+    def map_view_device(self, d_blob, blob_bytes, view: N.EntryView, n, d_records=0, d_new_idx=0) -> N.BatchStats:
+        st = N.BatchStats()
+        self._ck(self._lib.ctmr_map_view_device(self._h, C.c_void_p(d_blob), blob_bytes, C.byref(view), n,
+                                                C.c_void_p(d_records) if d_records else None,
+                                                C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
+        return st
+
+    def map_entries_device(self, d_blob, d_bounds, n, d_records=0, d_new_idx=0, d_timestamp=0):
+        st, ds = N.BatchStats(), N.DecodeStats()
+        self._ck(self._lib.ctmr_map_entries_device(
+            self._h, C.c_void_p(d_blob), C.c_void_p(d_bounds), n, C.c_void_p(d_records) if d_records else None,
+            C.c_void_p(d_new_idx) if d_new_idx else None, C.c_void_p(d_timestamp) if d_timestamp else None,
+            C.byref(ds), C.byref(st)))
+        return st, ds
+
+    def synth_entries_device(self, cfg: N.SynthConfig, first, n, d_bounds, d_blob, blob_cap) -> int:
+        out = C.c_uint64()
+        self._ck(self._lib.ctmr_synth_entries_device(self._h, C.byref(cfg), first, n, C.c_void_p(d_bounds),
+                                                     C.c_void_p(d_blob) if d_blob else None, blob_cap, C.byref(out)))
+        return out.value
 
     # ---- PEM write-back (N1): pem.EncodeToMemory of the newly unknown certificates, on the GPU
     def pem_new(self):

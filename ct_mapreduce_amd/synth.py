@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .engine import Batch
+from .engine import Batch, RawEntries
 
 BASE_TIME = 1767225600  # 2026-01-01T00:00:00Z
 
@@ -46,3 +46,14 @@ def host_batch(cfg, first, n) -> Batch:
                              iss.ctypes.data, et.ctypes.data)
     assert used <= cap
     return Batch(payload[:used + N.PAYLOAD_PAD], offsets, iss[:n], et[:n])
+
+
+def host_entries(cfg, first, n) -> RawEntries:
+    """Raw get-entries form (leaf_input ‖ extra_data per entry) of the same synthetic entries."""
+    L = N.lib()
+    bounds = np.zeros(2 * n + 1, dtype=np.uint64)
+    cap = n * 6144 + 64
+    blob = np.zeros(cap, dtype=np.uint8)
+    used = L.ctmr_synth_entries_host(C.byref(cfg), first, n, bounds.ctypes.data, blob.ctypes.data, cap)
+    assert used <= cap
+    return RawEntries(blob[:used + N.PAYLOAD_PAD], bounds)

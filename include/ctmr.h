@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTMR_ABI_VERSION 1
+#define CTMR_ABI_VERSION 2
 
 enum {
   CTMR_OK = 0,
@@ -51,7 +51,9 @@ enum {
   CTMR_ST_FILTERED_CN = 4,        /* :57-69 */
   CTMR_ST_NO_ISSUER = 5,          /* len(Chain) < 1 (:215-219) */
   CTMR_ST_ISSUER_PARSE_ERROR = 6, /* x509.ParseCertificate(Chain[0]) failed (:221-225) */
-  CTMR_ST__COUNT = 7
+  CTMR_ST_ENTRY_DECODE_ERROR = 7, /* ct.LogEntryFromLeaf failed: the downloader drops the entry before entryChan
+                                     (:452-459); only produced by the raw-entry calls (ctmr_decode_entries_*) */
+  CTMR_ST__COUNT = 8
 };
 
 /* record.flags */
@@ -60,6 +62,7 @@ enum {
 #define CTMR_FL_LONG_SERIAL 0x04  /* serial_len > 20: serial[] holds only the first 20 octets */
 
 #define CTMR_NO_ISSUER 0xFFFFFFFFu /* issuer_idx value meaning "len(Chain) < 1" */
+#define CTMR_ENTRY_INVALID 0xFFu   /* entry_type value meaning "LogEntryFromLeaf failed" → CTMR_ST_ENTRY_DECODE_ERROR */
 #define CTMR_PAYLOAD_PAD 32        /* readable bytes required after offsets[n] (device inputs) */
 #define CTMR_MAX_SERIAL 40         /* longest serial the in-HBM set stores; longer → host set */
 
@@ -227,6 +230,50 @@ int ctmr_pem_encode_device(ctmr_engine* e, const uint8_t* d_payload, const uint6
                            uint64_t* d_pem_offsets, uint64_t* pem_bytes);
 int ctmr_pem_new(ctmr_engine* e, uint8_t* out, size_t cap, uint64_t* pem_offsets, size_t* need, uint64_t* count);
 
+/* ---- CT get-entries leaf decode: replaces ct.LogEntryFromLeaf
+ *      (cmd/ct-fetch/ct-fetch.go:452; RFC 6962 §3.4 MerkleTreeLeaf, §4.6 extra_data) and insertCTWorker's choice of
+ *      certificate and issuer (:198-204 X509Cert | Precert.Submitted.Data; :215 len(Chain) < 1; :221 Chain[0]).
+ *   raw entries: ONE blob holding, back to back, leaf_input_0 ‖ extra_data_0 ‖ leaf_input_1 ‖ extra_data_1 ‖ … (the
+ *           base64-decoded "leaf_input"/"extra_data" members of get-entries); bounds u64[2n+1]: leaf_input_i =
+ *           [bounds[2i], bounds[2i+1]), extra_data_i = [bounds[2i+1], bounds[2i+2]).  The blob is 16-byte aligned
+ *           with CTMR_PAYLOAD_PAD readable bytes behind bounds[2n] (device inputs).
+ *   decode: per entry the byte range of the certificate the map parses (inside the blob — nothing is copied), the
+ *           entry type, the timestamp and the index of Chain[0] in the issuer table.  Chain[0] is matched bytewise
+ *           against the certificates registered so far; one that is not registered yet is registered by the call
+ *           (exactly what ctmr_add_issuers does), so a host that feeds raw entries never manages the issuer table.
+ *           An entry ct.LogEntryFromLeaf would reject gets entry_type CTMR_ENTRY_INVALID.
+ *   map_view: the batched map + reduce of ctmr_map_batch_device over such a view (certificates addressed by
+ *           [cert_start, cert_end) instead of n+1 packed offsets).
+ *   map_entries: decode + map_view in one call; host variant stages the blob through the engine's buffers. ---- */
+typedef struct {
+  uint64_t* cert_start;   /* n: first byte of the certificate inside the blob */
+  uint64_t* cert_end;     /* n: one past its last byte */
+  uint32_t* issuer_idx;   /* n: issuer table index of Chain[0]; CTMR_NO_ISSUER when len(Chain) < 1 */
+  uint8_t* entry_type;    /* n: 0 X509LogEntryType, 1 PrecertLogEntryType, CTMR_ENTRY_INVALID */
+  uint64_t* timestamp;    /* n or NULL: TimestampedEntry.Timestamp, ms since the epoch (ct-fetch.go:476) */
+  uint64_t* chain0_start; /* n or NULL: Chain[0].Data inside the blob */
+  uint32_t* chain0_len;   /* n or NULL: 0 when len(Chain) < 1 */
+} ctmr_entry_view;
+
+typedef struct {
+  uint64_t n;
+  uint64_t n_x509, n_precert, n_decode_error;
+  uint64_t n_no_chain;        /* decoded entries with len(Chain) < 1 */
+  uint64_t n_issuers_added;   /* distinct Chain[0] certificates this call registered */
+  uint64_t blob_bytes;        /* bounds[2n] - bounds[0] */
+  float ms_decode, ms_match;  /* filled when config.profile */
+} ctmr_decode_stats;
+
+int ctmr_decode_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
+                               const ctmr_entry_view* d_view, ctmr_decode_stats* stats);
+int ctmr_map_view_device(ctmr_engine* e, const uint8_t* d_blob, uint64_t blob_bytes, const ctmr_entry_view* d_view,
+                         uint64_t n, ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats);
+int ctmr_map_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
+                            ctmr_record* d_records, uint64_t* d_new_idx, uint64_t* d_timestamp,
+                            ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
+int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n, ctmr_record* records,
+                     uint64_t* new_idx, uint64_t* timestamp, ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
+
 /* ---- benchmark / test input generator (SURVEY.md §8(d) synthetic CT batch); not part of the
  *      reference's surface.  Deterministic in (seed, index); host and device emit identical bytes. */
 typedef struct {
@@ -255,6 +302,15 @@ uint64_t ctmr_synth_host(const ctmr_synth_config* c, uint64_t first, uint64_t n,
 int ctmr_synth_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n,
                       uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
                       uint32_t* d_issuer_idx, uint8_t* d_entry_type, uint64_t* payload_bytes);
+
+/* Raw get-entries form of the same synthetic entries (input of ctmr_decode_entries_*): entry i is
+ * leaf_input ‖ extra_data with the certificate of ctmr_synth_leaf(i) as X509Entry (entry_type 0; extra_data = chain
+ * [issuer]) or as PrecertChainEntry.pre_certificate (entry_type 1; the leaf carries issuer_key_hash + the TBS; chain
+ * [issuer]).  bounds u64[2n+1] relative to the batch start.  Same conventions as ctmr_synth_host / _device. */
+uint64_t ctmr_synth_entries_host(const ctmr_synth_config* c, uint64_t first, uint64_t n, uint64_t* bounds,
+                                 uint8_t* blob, uint64_t cap);
+int ctmr_synth_entries_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n,
+                              uint64_t* d_bounds, uint8_t* d_blob, uint64_t blob_cap, uint64_t* blob_bytes);
 
 #ifdef __cplusplus
 }

@@ -858,3 +858,126 @@ void orc_engine_batch(orc_engine* e, const uint8_t* payload, const uint64_t* off
     if (out_exp_hour) out_exp_hour[i] = eh;
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * ct.LogEntryFromLeaf (cmd/ct-fetch/ct-fetch.go:452) — TLS presentation-language reader.
+ * A cursor over one buffer; every read checks what is left (CT-go tls.Unmarshal: "truncated"), and the
+ * two top-level structures must consume their buffer exactly ("trailing data"). */
+typedef struct {
+  const uint8_t* p;
+  size_t left;
+  int bad;
+} tls_cur;
+
+static uint64_t tls_uint(tls_cur* c, int nbytes) {
+  if (c->bad || c->left < (size_t)nbytes) {
+    c->bad = 1;
+    return 0;
+  }
+  uint64_t v = 0;
+  for (int i = 0; i < nbytes; i++) v = (v << 8) | c->p[i];
+  c->p += nbytes;
+  c->left -= (size_t)nbytes;
+  return v;
+}
+
+/* opaque<min..max> with an nbytes length prefix: returns a sub-cursor over the contents */
+static tls_cur tls_opaque(tls_cur* c, int nbytes, uint64_t minlen) {
+  tls_cur sub = {NULL, 0, 1};
+  uint64_t n = tls_uint(c, nbytes);
+  if (c->bad || n < minlen || n > c->left) {
+    c->bad = 1;
+    return sub;
+  }
+  sub.p = c->p;
+  sub.left = (size_t)n;
+  sub.bad = 0;
+  c->p += n;
+  c->left -= (size_t)n;
+  return sub;
+}
+
+void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t* extra_data, size_t extra_len,
+                      orc_entry* out) {
+  memset(out, 0, sizeof *out);
+  /* MerkleTreeLeaf (RFC 6962 §3.4): Version version; MerkleLeafType leaf_type; TimestampedEntry */
+  tls_cur L = {leaf_input, leaf_len, 0};
+  (void)tls_uint(&L, 1);                 /* version: a uint8 enum, v1(0); CT-go only bounds it by 255 */
+  uint64_t leaf_type = tls_uint(&L, 1);  /* timestamped_entry(0) selects the only variant */
+  if (L.bad || leaf_type != 0) return;
+  out->timestamp = tls_uint(&L, 8);
+  uint64_t et = tls_uint(&L, 2);
+  if (L.bad) return;
+  tls_cur cert = {NULL, 0, 1};
+  if (et == 0) {                         /* x509_entry: ASN.1Cert = opaque<1..2^24-1> */
+    cert = tls_opaque(&L, 3, 1);
+    if (L.bad) return;
+    out->cert_in_extra = 0;
+    out->cert_off = (uint32_t)(cert.p - leaf_input);
+    out->cert_len = (uint32_t)cert.left;
+  } else if (et == 1) {                  /* precert_entry: opaque issuer_key_hash[32]; TBSCertificate<1..2^24-1> */
+    if (L.left < 32) return;
+    L.p += 32;
+    L.left -= 32;
+    tls_cur tbs = tls_opaque(&L, 3, 1);
+    if (L.bad) return;
+    out->tbs_off = (uint32_t)(tbs.p - leaf_input);
+    out->tbs_len = (uint32_t)tbs.left;
+  } else {
+    return;                              /* RawLogEntryFromLeaf: "unknown entry type" */
+  }
+  (void)tls_opaque(&L, 2, 0);            /* CtExtensions extensions<0..2^16-1> */
+  if (L.bad || L.left != 0) return;      /* "MerkleTreeLeaf: trailing data" */
+
+  /* extra_data (RFC 6962 §4.6) */
+  tls_cur X = {extra_data, extra_len, 0};
+  if (et == 1) {                         /* PrecertChainEntry.pre_certificate → Precert.Submitted (ct-fetch.go:202) */
+    cert = tls_opaque(&X, 3, 1);
+    if (X.bad) return;
+    out->cert_in_extra = 1;
+    out->cert_off = (uint32_t)(cert.p - extra_data);
+    out->cert_len = (uint32_t)cert.left;
+  }
+  tls_cur chain = tls_opaque(&X, 3, 0);  /* ASN.1Cert chain<0..2^24-1> */
+  if (X.bad || X.left != 0) return;      /* "CertificateChain / PrecertChainEntry: trailing data" */
+  uint32_t n = 0;
+  while (chain.left > 0) {
+    tls_cur one = tls_opaque(&chain, 3, 1);
+    if (chain.bad) {
+      out->chain0_off = out->chain0_len = 0;
+      return;
+    }
+    if (n == 0) {
+      out->chain0_off = (uint32_t)(one.p - extra_data);
+      out->chain0_len = (uint32_t)one.left;
+    }
+    n++;
+  }
+  out->n_chain = n;
+  out->entry_type = (int32_t)et;
+  out->ok = 1;
+}
+
+void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
+                          uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,
+                          uint64_t* out_timestamp) {
+  for (uint64_t i = 0; i < n; i++) {
+    const uint8_t* leaf = blob + bounds[2 * i];
+    const uint8_t* extra = blob + bounds[2 * i + 1];
+    orc_entry d;
+    orc_decode_entry(leaf, (size_t)(bounds[2 * i + 1] - bounds[2 * i]), extra,
+                     (size_t)(bounds[2 * i + 2] - bounds[2 * i + 1]), &d);
+    int st = ORC_ST_ENTRY_DECODE_ERROR, unk = 0;
+    int32_t eh = 0;
+    if (d.ok) {
+      /* ct-fetch.go:198-204 the certificate; :215 len(Chain) < 1; :221 Chain[0] */
+      const uint8_t* c = (d.cert_in_extra ? extra : leaf) + d.cert_off;
+      st = orc_engine_entry(e, c, d.cert_len, d.n_chain ? extra + d.chain0_off : NULL, d.chain0_len, &unk, &eh,
+                            NULL, NULL);
+    }
+    if (out_status) out_status[i] = (uint8_t)st;
+    if (out_unknown) out_unknown[i] = (uint8_t)unk;
+    if (out_exp_hour) out_exp_hour[i] = eh;
+    if (out_timestamp) out_timestamp[i] = d.ok ? d.timestamp : 0;
+  }
+}

@@ -42,7 +42,8 @@ enum {
   ORC_ST_FILTERED_EXPIRED = 3,   /* NotAfter.Before(now) && !LogExpiredEntries     :52-55 */
   ORC_ST_FILTERED_CN = 4,        /* issuerCNFilter prefix miss                     :57-69 */
   ORC_ST_NO_ISSUER = 5,          /* len(Chain) < 1                                 :215-219 */
-  ORC_ST_ISSUER_PARSE_ERROR = 6  /* x509.ParseCertificate(Chain[0]) failed         :221-225 */
+  ORC_ST_ISSUER_PARSE_ERROR = 6, /* x509.ParseCertificate(Chain[0]) failed         :221-225 */
+  ORC_ST_ENTRY_DECODE_ERROR = 7  /* ct.LogEntryFromLeaf failed: dropped by the downloader :452-459 */
 };
 
 /* Result of the TBSCertificate field walk (the subset of *x509.Certificate the
@@ -124,6 +125,33 @@ void orc_engine_batch(orc_engine*, const uint8_t* payload, const uint64_t* offse
                       const uint32_t* issuer_idx, uint64_t n, const uint8_t* issuer_payload,
                       const uint64_t* issuer_offsets, uint32_t n_issuers, uint8_t* out_status,
                       uint8_t* out_unknown, int32_t* out_exp_hour);
+
+/* ---- ct.LogEntryFromLeaf as far as the path consumes it (cmd/ct-fetch/ct-fetch.go:452; call sites of the
+ *      result :198-204,:215,:221,:476).  The TLS structures are RFC 6962 §3.4 (MerkleTreeLeaf /
+ *      TimestampedEntry) and §4.6 (extra_data: certificate_chain | PrecertChainEntry), with the field limits of
+ *      certificate-transparency-go v1.1.0's struct tags.  PARITY UNPINNED: the reference holds no raw get-entries
+ *      fixture and CT-go is not on this machine; the hand-built vectors of tests/test_entry_decode_cpu.py follow
+ *      the RFC text.  Offsets are into the respective buffer. ---- */
+typedef struct {
+  int32_t ok;              /* 0 = LogEntryFromLeaf returns an error */
+  int32_t entry_type;      /* 0 X509LogEntryType, 1 PrecertLogEntryType */
+  uint64_t timestamp;      /* TimestampedEntry.Timestamp (ms) */
+  int32_t cert_in_extra;   /* 1: the certificate insertCTWorker parses lies in extra_data (Precert.Submitted) */
+  uint32_t cert_off, cert_len;
+  uint32_t chain0_off, chain0_len;   /* in extra_data; len 0 = len(Chain) < 1 */
+  uint32_t n_chain;
+  uint32_t tbs_off, tbs_len;         /* precert: TBSCertificate in leaf_input */
+} orc_entry;
+
+void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t* extra_data, size_t extra_len,
+                      orc_entry* out);
+
+/* The downloader + insertCTWorker over raw entries: blob/bounds layout of include/ctmr.h (leaf_input_i =
+ * [bounds[2i], bounds[2i+1]), extra_data_i = [bounds[2i+1], bounds[2i+2])).  Entries LogEntryFromLeaf rejects get
+ * ORC_ST_ENTRY_DECODE_ERROR.  out_timestamp may be NULL. */
+void orc_engine_raw_batch(orc_engine*, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
+                          uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,
+                          uint64_t* out_timestamp);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
-    ST_ISSUER_PARSE_ERROR = range(7)
+    ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
+
+
+class Entry(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("entry_type", C.c_int32), ("timestamp", C.c_uint64),
+                ("cert_in_extra", C.c_int32), ("cert_off", C.c_uint32), ("cert_len", C.c_uint32),
+                ("chain0_off", C.c_uint32), ("chain0_len", C.c_uint32), ("n_chain", C.c_uint32),
+                ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32)]
 
 
 class Cert(C.Structure):
@@ -80,8 +87,17 @@ def lib():
         L.orc_engine_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
+        L.orc_decode_entry.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(Entry)]
+        L.orc_engine_raw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def decode_entry(leaf_input: bytes, extra_data: bytes) -> Entry:
+    e = Entry()
+    lib().orc_decode_entry(leaf_input, len(leaf_input), extra_data, len(extra_data), C.byref(e))
+    return e
 
 
 def parse_cert(der: bytes) -> Cert:
@@ -168,6 +184,19 @@ class Engine:
                                issuer_offsets.ctypes.data, len(issuer_offsets) - 1,
                                status.ctypes.data, unknown.ctypes.data, exp.ctypes.data)
         return status, unknown, exp
+
+    def raw_batch(self, blob, bounds):
+        import numpy as np
+        n = (len(bounds) - 1) // 2
+        status = np.zeros(n, dtype=np.uint8)
+        unknown = np.zeros(n, dtype=np.uint8)
+        exp = np.zeros(n, dtype=np.int32)
+        ts = np.zeros(n, dtype=np.uint64)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        bounds = np.ascontiguousarray(bounds, dtype=np.uint64)
+        lib().orc_engine_raw_batch(self._h, blob.ctypes.data, bounds.ctypes.data, n, status.ctypes.data,
+                                   unknown.ctypes.data, exp.ctypes.data, ts.ctypes.data)
+        return status, unknown, exp, ts
 
     def set_insert(self, key: bytes, member: bytes) -> bool:
         return bool(lib().orc_set_insert(self._h, key, len(key), member, len(member)))

@@ -53,7 +53,7 @@ def assert_records_equal(res, batch, st, unk, eh):
     assert (res.new_idx == np.nonzero(unk)[0]).all()
     assert res.stats.n_new == int(unk.sum())
     assert res.stats.n == batch.n
-    for k in range(7):
+    for k in range(8):
         assert res.stats.by_status[k] == int((st == k).sum()), k
 
 

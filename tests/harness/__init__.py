@@ -9,9 +9,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _build(src, out, cmd):
     outp = os.path.join(HERE, out)
     srcp = os.path.join(HERE, src)
-    dep = os.path.join(HERE, "..", "..", "ct_mapreduce_amd", "csrc", "der_walk.h")
+    csrc = os.path.join(HERE, "..", "..", "ct_mapreduce_amd", "csrc")
+    deps = [os.path.join(csrc, h) for h in ("der_walk.h", "entry_decode.h")]
     if (not os.path.exists(outp) or os.path.getmtime(outp) < os.path.getmtime(srcp)
-            or os.path.getmtime(outp) < os.path.getmtime(dep)):
+            or any(os.path.getmtime(outp) < os.path.getmtime(d) for d in deps)):
         subprocess.check_call(cmd + [srcp, "-o", outp])
     return outp
 
@@ -31,8 +32,32 @@ class OsslOut(C.Structure):
                 ("cn", C.c_ubyte * 256), ("spki_len", C.c_int), ("spki", C.c_ubyte * 1024)]
 
 
+class EntryOut(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("entry_type", C.c_int32), ("timestamp", C.c_uint64), ("cert_lo", C.c_uint64),
+                ("cert_hi", C.c_uint64), ("chain0_lo", C.c_uint64), ("chain0_len", C.c_uint32),
+                ("n_chain", C.c_uint32), ("tbs_lo", C.c_uint64), ("tbs_len", C.c_uint32)]
+
+
 _walk = None
 _ossl = None
+_entry = None
+
+
+def product_decode_entry(leaf_input: bytes, extra_data: bytes, fill=0xA5, prefix=b"") -> EntryOut:
+    """The product's decode_entry (host build) on blob = prefix ‖ leaf_input ‖ extra_data."""
+    global _entry
+    if _entry is None:
+        p = _build("entry_harness.cpp", "libentry_harness.so", ["g++", "-O2", "-std=c++17", "-shared", "-fPIC"])
+        _entry = C.CDLL(p)
+        _entry.harness_decode_entry.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint8,
+                                                C.POINTER(EntryOut)]
+        _entry.harness_quick_hash.argtypes = [C.c_char_p, C.c_uint32]
+        _entry.harness_quick_hash.restype = C.c_uint64
+    blob = prefix + leaf_input + extra_data
+    o = EntryOut()
+    l0 = len(prefix)
+    _entry.harness_decode_entry(blob, len(blob), l0, l0 + len(leaf_input), len(blob), fill, C.byref(o))
+    return o
 
 
 def product_walk(der: bytes, fill=0xA5, cn_filter=None) -> HarnessOut:

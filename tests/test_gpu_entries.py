@@ -1,0 +1,168 @@
+"""-m gpu, N2: raw get-entries → k_entry_decode → k_chain0_match → the map/reduce, through the C
+ABI, bit for bit against the oracle's LogEntryFromLeaf + insertCTWorker restatement (orc_engine_raw_batch)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402,F401
+
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import synth, _native as N
+from ct_mapreduce_amd.engine import RawEntries
+from oracle import oracle as orc
+from tests.test_entry_decode_cpu import mutate_entry, x509_leaf, precert_leaf, chain, asn1cert
+
+NOW = synth.BASE_TIME
+
+
+def check_against_oracle(eng, raw, o, res):
+    st, unk, eh, ts = o.raw_batch(raw.blob if len(raw.blob) else np.zeros(1, np.uint8), raw.bounds)
+    r = res.records
+    assert (r["status"] == st).all(), np.nonzero(r["status"] != st)[0][:10]
+    assert (((r["flags"] & 2) != 0) == (unk != 0)).all()
+    parsed = (st != orc.ST_PARSE_ERROR) & (st != orc.ST_ENTRY_DECODE_ERROR)
+    assert (r["exp_hour"][parsed] == eh[parsed]).all()
+    assert (res.timestamp == ts).all()
+    assert (res.new_idx == np.nonzero(unk)[0]).all()
+    for k in range(8):
+        assert res.stats.by_status[k] == int((st == k).sum()), k
+    assert res.decode.n_decode_error == int((st == orc.ST_ENTRY_DECODE_ERROR).sum())
+    okeys = [k for k in o.keys() if k.startswith(b"serials::")]
+    assert sorted(eng.keys(b"serials::*")) == okeys
+    assert eng.total_count() == o.total_count()
+    return st, unk
+
+
+def test_synthetic_raw_entries_bit_exact_and_issuers_self_register():
+    cfg = synth.config(seed=20260921 + 11, n_issuers=64, dup_permille=100, ca_permille=10, expired_permille=10)
+    raw = synth.host_entries(cfg, 0, 20000)
+    filt = b"Synth Issuer 00,Synth Issuer 01,Synth Issuer 02,Synth Issuer 03,Synth Issuer 04,Synth Issuer 05"
+    eng = ctmr.Engine(device=0, table_slots=1 << 17, pair_slots=1 << 16)
+    eng.set_filter(filt, False, NOW)
+    assert eng.issuer_count() == 0                                  # the host registers nothing
+    res = eng.map_entries(raw)
+    o = orc.Engine(filt, False, NOW)
+    st, unk = check_against_oracle(eng, raw, o, res)
+    assert res.decode.n_x509 + res.decode.n_precert == 20000 and res.decode.n_precert > 5000
+    assert 0 < res.decode.n_issuers_added <= 64 and eng.issuer_count() == res.decode.n_issuers_added
+    assert (st == 0).sum() > 1000 and 0 < unk.sum() < (st == 0).sum()
+    # per-issuer unique counts (storage-statistics.go:44-53), issuers identified by the ids the GPU computed
+    counts = eng.issuer_counts()
+    for k in range(eng.issuer_count()):
+        assert int(counts[k]) == o.issuer_count(eng.issuer_id(k)), k
+    # the same job from the packed form on a second engine: identical records
+    b = synth.host_batch(cfg, 0, 20000)
+    eng2 = ctmr.Engine(device=0, table_slots=1 << 17, pair_slots=1 << 16)
+    eng2.add_issuers(synth.issuers(cfg))
+    eng2.set_filter(filt, False, NOW)
+    res2 = eng2.map_batch(b)
+    for f in ("status", "flags", "serial_len", "exp_hour", "serial"):
+        assert (res.records[f] == res2.records[f]).all(), f
+    assert (res.new_idx == res2.new_idx).all()
+    # PEM write-back of the new certificates straight out of the raw blob
+    pems = eng.pem_new()
+    assert len(pems) == len(res.new_idx)
+    for pem, i in list(zip(pems, res.new_idx))[::37]:
+        assert pem == orc.pem_encode(b.cert(int(i)))
+    # a second window overlapping the first: no issuer is added again, duplicates are known
+    raw2 = synth.host_entries(cfg, 15000, 10000)
+    res3 = eng.map_entries(raw2)
+    check_against_oracle(eng, raw2, o, res3)
+    assert res3.decode.n_issuers_added <= 64 - res.decode.n_issuers_added
+    eng.close()
+    eng2.close()
+
+
+def test_mutated_and_edge_entries():
+    rng = random.Random(20260923)
+    cfg = synth.config(seed=5, n_issuers=8, dup_permille=50)
+    raw = synth.host_entries(cfg, 0, 3000)
+    pairs = []
+    for i in range(raw.n):
+        leaf, extra = raw.leaf_input(i), raw.extra_data(i)
+        if rng.random() < 0.4:
+            leaf, extra = mutate_entry(rng, leaf, extra)
+        pairs.append((leaf, extra))
+    cert = synth.leaf(cfg, 7)[0]
+    iss = synth.issuer(cfg, 3)
+    pairs += [
+        (x509_leaf(cert), chain([])),                                   # len(Chain) < 1
+        (precert_leaf(b"\x30\x00"), asn1cert(cert) + chain([])),
+        (x509_leaf(cert), chain([b"\x30\x03abc"])),                     # Chain[0] does not parse
+        (x509_leaf(cert), chain([iss[:-1]])),                           # … a truncated issuer certificate
+        (x509_leaf(cert, ext=b"\x00" * 5), chain([iss, iss, iss])),
+        (x509_leaf(b"\x30\x00"), chain([iss])),                         # leaf certificate does not parse
+        (b"", b""),
+        (x509_leaf(cert), b""),
+        (x509_leaf(cert, entry_type=3), chain([iss])),
+    ]
+    rng.shuffle(pairs)
+    mixed = RawEntries.from_pairs(pairs)
+    mixed.blob = np.concatenate([mixed.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    eng = ctmr.Engine(device=0, table_slots=1 << 15, pair_slots=1 << 14)
+    eng.set_filter(b"", True, NOW)
+    res = eng.map_entries(mixed)
+    o = orc.Engine(b"", True, NOW)
+    st, _ = check_against_oracle(eng, mixed, o, res)
+    for code in (orc.ST_ENTRY_DECODE_ERROR, orc.ST_NO_ISSUER, orc.ST_ISSUER_PARSE_ERROR, orc.ST_PARSE_ERROR, orc.ST_PASS):
+        assert (st == code).sum() > 0, code
+    # empty batch
+    empty = eng.map_entries(RawEntries(np.zeros(0, np.uint8), np.zeros(1, np.uint64)))
+    assert empty.stats.n == 0 and len(empty.new_idx) == 0
+    eng.close()
+
+
+def test_device_generator_and_device_path_match_the_host_path():
+    cfg = synth.config(seed=20260921 + 12, n_issuers=256, dup_permille=100)
+    n = 50000
+    dev = torch.device("cuda:0")
+    eng = ctmr.Engine(device=0, table_slots=1 << 18, pair_slots=1 << 16, profile=True)
+    eng.set_filter(b"Synth Issuer 0,Synth Issuer 1", False, NOW)
+    d_bounds = torch.empty(2 * n + 1, dtype=torch.int64, device=dev)
+    total = eng.synth_entries_device(cfg, 0, n, d_bounds.data_ptr(), 0, 0)
+    d_blob = torch.zeros(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+    assert eng.synth_entries_device(cfg, 0, n, d_bounds.data_ptr(), d_blob.data_ptr(), d_blob.numel()) == total
+    raw = synth.host_entries(cfg, 0, n)
+    assert (d_bounds.cpu().numpy().astype(np.uint64) == raw.bounds).all()
+    assert (d_blob[:total].cpu().numpy() == raw.blob[:total]).all()          # host and device emit identical bytes
+    d_rec = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+    d_new = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_ts = torch.zeros(n, dtype=torch.int64, device=dev)
+    st, ds = eng.map_entries_device(d_blob.data_ptr(), d_bounds.data_ptr(), n, d_rec.data_ptr(), d_new.data_ptr(),
+                                    d_ts.data_ptr())
+    assert ds.n_issuers_added == eng.issuer_count() <= 256 and ds.blob_bytes == total
+    o = orc.Engine(b"Synth Issuer 0,Synth Issuer 1", False, NOW)
+    ost, ounk, oeh, ots = o.raw_batch(raw.blob, raw.bounds)
+    rec = d_rec.cpu().numpy().view(ctmr.engine.RECORD_DTYPE)
+    assert (rec["status"] == ost).all() and (((rec["flags"] & 2) != 0) == (ounk != 0)).all()
+    assert (d_ts.cpu().numpy().astype(np.uint64) == ots).all()
+    assert (d_new[:st.n_new].cpu().numpy() == np.nonzero(ounk)[0]).all()
+    # explicit two-step form with a caller-owned view
+    eng.reset_known()
+    v_start = torch.zeros(n, dtype=torch.int64, device=dev)
+    v_end = torch.zeros(n, dtype=torch.int64, device=dev)
+    v_iss = torch.zeros(n, dtype=torch.int32, device=dev)
+    v_et = torch.zeros(n, dtype=torch.uint8, device=dev)
+    view = N.EntryView(cert_start=v_start.data_ptr(), cert_end=v_end.data_ptr(), issuer_idx=v_iss.data_ptr(),
+                       entry_type=v_et.data_ptr(), timestamp=None, chain0_start=None, chain0_len=None)
+    ds2 = eng.decode_entries_device(d_blob.data_ptr(), d_bounds.data_ptr(), n, view)
+    assert ds2.n_issuers_added == 0 and ds2.n_x509 + ds2.n_precert == n
+    st2 = eng.map_view_device(d_blob.data_ptr(), total, view, n, d_rec.data_ptr(), d_new.data_ptr())
+    rec2 = d_rec.cpu().numpy().view(ctmr.engine.RECORD_DTYPE)
+    assert (rec2["status"] == ost).all() and st2.n_new == st.n_new
+    # issuer indices name the right certificates
+    b = synth.host_batch(cfg, 0, n)
+    iss_idx = v_iss.cpu().numpy().astype(np.uint32)
+    ids = {k: eng.issuer_id(k) for k in range(eng.issuer_count())}
+    want = {k: orc.issuer_id(_spki(c)) for k, c in enumerate(synth.issuers(cfg))}
+    for i in range(0, n, 997):
+        assert ids[int(iss_idx[i])] == want[int(b.issuer_idx[i])]
+    eng.close()
+
+
+def _spki(der):
+    c = orc.parse_cert(der)
+    return der[c.spki_off:c.spki_off + c.spki_len]
