@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--lds-bytes", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--raw", action="store_true",
+                    help="feed raw get-entries blobs (leaf_input ‖ extra_data, ≈3.06 KB per entry): adds the "
+                         "LogEntryFromLeaf decode and the Chain[0] → issuer match in front of the map (SURVEY §8(f) N2); "
+                         "not the default workload")
     ap.add_argument("--traffic-file", default=None,
                     help="JSON written by scripts/make_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / "
                          "WRITE_SIZE passes of this command (default: profiles/traffic_map.json when it was "
@@ -103,7 +107,24 @@ def main():
     now = synth.BASE_TIME
     issuers = synth.issuers(cfg)
 
+    def setup_raw(E):
+        eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
+                          map_variant=args.variant, profile=True)
+        eng.set_filter(filt, False, now)              # no add_issuers: Chain[0] certificates register themselves
+        first = rank * E
+        d_bounds = torch.empty(2 * E + 1, dtype=torch.int64, device=dev)
+        total = eng.synth_entries_device(cfg, first, E, d_bounds.data_ptr(), 0, 0)
+        d_blob = torch.empty(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+        eng.synth_entries_device(cfg, first, E, d_bounds.data_ptr(), d_blob.data_ptr(), d_blob.numel())
+        d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
+        d_new = torch.empty(E, dtype=torch.int64, device=dev)
+        d_ts = torch.empty(E, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        return eng, d_bounds, d_blob, d_ts, None, d_rec, d_new
+
     def setup(E):
+        if args.raw:
+            return setup_raw(E)
         eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
                           map_variant=args.variant, certs_per_tile=args.certs_per_tile,
                           lds_tile_bytes=args.lds_bytes, profile=True)
@@ -124,6 +145,8 @@ def main():
         return eng, d_off, d_pay, d_iss, d_et, d_rec, d_new
 
     E = args.entries
+    if args.raw and "CTMR_BENCH_ENTRIES" not in os.environ and E == 100_000_000:
+        E = 40_000_000          # ≈122 GB of raw entries + the table
     t_gen = time.perf_counter()
     while True:
         try:
@@ -139,10 +162,17 @@ def main():
     t_gen = time.perf_counter() - t_gen
     counts_dev = torch.zeros(len(issuers), dtype=torch.int64, device=dev)
 
+    dstats = []
+
     def step():
         eng.reset_known()
-        st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
-                                  E, d_rec.data_ptr(), d_new.data_ptr())
+        if args.raw:   # d_off = bounds, d_pay = blob, d_iss = timestamps
+            st, ds = eng.map_entries_device(d_pay.data_ptr(), d_off.data_ptr(), E, d_rec.data_ptr(), d_new.data_ptr(),
+                                            d_iss.data_ptr())
+            dstats.append(ds)
+        else:
+            st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
+                                      E, d_rec.data_ptr(), d_new.data_ptr())
         if dist is not None:
             # per-issuer unique counts merged over xGMI (RCCL all-reduce, 2 KiB)
             c = torch.from_numpy(eng.issuer_counts().astype(np.int64)).to(dev)
@@ -187,7 +217,7 @@ def main():
 
     n_total = E * world
     value = n_total * args.steps / dt
-    alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E
+    alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E     # raw mode: payload_bytes is the whole blob — see "raw"
     if (args.variant or DEFAULT_VARIANT) in FUSED:
         alg_bytes += ALG_BYTES_PROBE * int(stats.by_status[0])
     avg_ms = sum(ms_map) / len(ms_map)
@@ -216,8 +246,19 @@ def main():
                       "compact": stats.ms_compact, "total": stats.ms_total},
         "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},
     }
+    if args.raw:
+        ds = dstats[-1]
+        out["config"]["workload"] = (f"{E} RAW get-entries (leaf_input+extra_data, {stats.payload_bytes / E:.0f} B/entry) per GPU: "
+                                     "LogEntryFromLeaf decode + Chain[0] issuer match + " + out["config"]["workload"])
+        out["raw"] = {"blob_bytes": int(ds.blob_bytes), "ms_decode": ds.ms_decode, "ms_match": ds.ms_match,
+                      "n_x509": int(ds.n_x509), "n_precert": int(ds.n_precert),
+                      "issuers_registered_by_the_engine": eng.issuer_count(),
+                      "note": "roofline.achieved counts the WHOLE blob as the map kernel's algorithmic bytes although it "
+                              "skips extra_data and the precert TBS; ms_decode/ms_match are the two kernels in front of it"}
+        out["kernel_ms"]["decode"] = ds.ms_decode
+        out["kernel_ms"]["match"] = ds.ms_match
     if rank == 0:
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.raw:
             sample = min(args.cpu_sample, E)
             base, (ost, ounk) = cpu_baseline(cfg, issuers, filt, now, sample)
             out["cpu_baseline"] = base

@@ -25,7 +25,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_slots", C.c_uint64),
                 ("pair_slots", C.c_uint64), ("max_issuers", C.c_uint32), ("certs_per_tile", C.c_uint32),
                 ("lds_tile_bytes", C.c_uint32), ("map_variant", C.c_uint32), ("profile", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("collect_meta", C.c_uint32)]
 
 
 class BatchStats(C.Structure):
@@ -45,6 +45,14 @@ class DecodeStats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_x509", C.c_uint64), ("n_precert", C.c_uint64),
                 ("n_decode_error", C.c_uint64), ("n_no_chain", C.c_uint64), ("n_issuers_added", C.c_uint64),
                 ("blob_bytes", C.c_uint64), ("ms_decode", C.c_float), ("ms_match", C.c_float)]
+
+
+MK_EXPDATE, MK_CRL, MK_DN, MK_HOST = range(4)
+
+
+class MetaItem(C.Structure):
+    _fields_ = [("entry", C.c_uint64), ("kind", C.c_uint32), ("issuer_idx", C.c_uint32), ("exp_hour", C.c_int32),
+                ("off", C.c_uint32), ("len", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class IssuerInfo(C.Structure):
@@ -103,6 +111,9 @@ SIGNATURES = {
                                           C.POINTER(BatchStats)]),
     "ctmr_map_entries": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, _P, C.POINTER(DecodeStats),
                                    C.POINTER(BatchStats)]),
+    "ctmr_meta_new_device": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ctmr_meta_new": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]),
+    "ctmr_meta_reset": (C.c_int, [_P]),
     "ctmr_synth_entries_host": (C.c_uint64, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P, C.c_uint64]),
     "ctmr_synth_entries_device": (C.c_int, [_P, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P, C.c_uint64,
                                             C.POINTER(C.c_uint64)]),

@@ -163,6 +163,15 @@ struct ctmr_engine {
   unsigned long long* d_pend = nullptr;    // PEND_SLOTS claim words
   uint32_t* d_unreg = nullptr;             // UNREG_CAP entry indices
   unsigned long long* d_dcount = nullptr;  // 8 counters of the decode / match kernels
+  // IssuerMetadata memo on device (k_meta_new)
+  MetaSlot* d_meta_slots = nullptr;
+  uint64_t n_meta_slots = 0;
+  uint8_t* d_meta_arena = nullptr;
+  uint64_t meta_arena_cap = 0;
+  unsigned long long* d_mcount = nullptr;  // [0] arena used [1] items [2] overflow events
+  uint64_t meta_n = 0;                     // entries the SC_META scratch describes (the last map call)
+  bool last_meta_valid = false;            // SC_ITEMS holds the items of the last host batch
+  uint64_t last_meta_items = 0;
   // the last ctmr_map_entries (host variant): ctmr_pem_new encodes from its view
   bool last_is_view = false;
   size_t last_o_start = 0, last_o_end = 0;
@@ -173,8 +182,8 @@ struct ctmr_engine {
   DevStats* d_stats = nullptr;
   uint32_t* d_result = nullptr;        // 2 words for point ops
   unsigned long long* d_count = nullptr;
-  void* d_scratch[16] = {};            // growable buffers
-  size_t scratch_cap[16] = {};
+  void* d_scratch[20] = {};            // growable buffers
+  size_t scratch_cap[20] = {};
   // the last ctmr_map_batch (host variant): what ctmr_pem_new encodes
   uint64_t last_n = 0, last_n_new = 0;
   size_t last_o_off = 0, last_o_new = 0;
@@ -187,7 +196,7 @@ struct ctmr_engine {
 
 namespace {
 
-enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP, SC_VIEW, SC_ISS_A, SC_ISS_B, SC_ISS_C };
+enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP, SC_VIEW, SC_ISS_A, SC_ISS_B, SC_ISS_C, SC_META, SC_ITEMS };
 constexpr uint32_t UNREG_CAP = 16384;
 
 int fail(const ctmr_engine* e, int code, const char* fmt, ...) {
@@ -426,6 +435,15 @@ int ctmr_create(const ctmr_config* cfg, ctmr_engine** out) {
   CK(hipMalloc(&e->d_pend, (size_t)PEND_SLOTS * 8));
   CK(hipMalloc(&e->d_unreg, (size_t)UNREG_CAP * 4));
   CK(hipMalloc(&e->d_dcount, 64));
+  if (cfg->collect_meta) {
+    e->n_meta_slots = 1ull << 20;
+    e->meta_arena_cap = 64ull << 20;
+    CK(hipMalloc(&e->d_meta_slots, e->n_meta_slots * sizeof(MetaSlot)));
+    CK(hipMalloc(&e->d_meta_arena, e->meta_arena_cap));
+    CK(hipMalloc(&e->d_mcount, 64));
+    CK(hipMemsetAsync(e->d_meta_slots, 0, e->n_meta_slots * sizeof(MetaSlot), e->stream));
+    CK(hipMemsetAsync(e->d_mcount, 0, 64, e->stream));
+  }
   CK(hipMemsetAsync(e->d_idb_ht, 0, (size_t)e->idb_ht_size * 4, e->stream));
   e->h_idb_ht.assign(e->idb_ht_size, 0u);
   CK(hipMemsetAsync(e->table, 0, e->nslots * sizeof(Slot), e->stream));
@@ -452,6 +470,7 @@ void ctmr_destroy(ctmr_engine* e) {
   (void)hipFree(e->d_stats); (void)hipFree(e->d_result); (void)hipFree(e->d_count);
   (void)hipFree(e->d_idb_der); (void)hipFree(e->d_idb_off); (void)hipFree(e->d_idb_len); (void)hipFree(e->d_idb_qh);
   (void)hipFree(e->d_idb_ht); (void)hipFree(e->d_pend); (void)hipFree(e->d_unreg); (void)hipFree(e->d_dcount);
+  (void)hipFree(e->d_meta_slots); (void)hipFree(e->d_meta_arena); (void)hipFree(e->d_mcount);
   for (auto p : e->d_scratch) if (p) (void)hipFree(p);
   for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -655,6 +674,14 @@ static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* 
   MapArgs ma;
   ma.optimistic_new = optimistic_new ? 1u : 0u;
   ma.ends = d_ends; ma.limit = limit;
+  ma.meta_loc = nullptr;
+  if (e->cfg.collect_meta) {
+    int mr;
+    if ((mr = ensure(e, SC_META, n * 8))) return mr;
+    ma.meta_loc = (uint2*)e->d_scratch[SC_META];
+    e->meta_n = n;
+    e->last_meta_valid = false;
+  }
   ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
   ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
   ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
@@ -895,7 +922,7 @@ static int decode_locked(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* 
   da.counters = e->d_dcount;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[5], e->stream));
-  hipLaunchKernelGGL(k_entry_decode, dim3(blocks), dim3(256), 0, e->stream, da);
+  hipLaunchKernelGGL(k_entry_decode, dim3((unsigned)((n + DECODE_PER_BLOCK - 1) / DECODE_PER_BLOCK)), dim3(256), 0, e->stream, da);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[6], e->stream));
   MatchArgs ma;
   ma.blob = d_blob; ma.chain0_start = c0s; ma.chain0_len = c0l; ma.entry_type = v->entry_type;
@@ -1058,6 +1085,116 @@ int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds
   e->last_is_view = true;
   e->last_o_start = (size_t)((uint8_t*)v.cert_start - (uint8_t*)e->d_scratch[SC_VIEW]);
   e->last_o_end = (size_t)((uint8_t*)v.cert_end - (uint8_t*)e->d_scratch[SC_VIEW]);
+  return CTMR_OK;
+}
+
+// ------------------------------------------------------------------ IssuerMetadata on device (N3)
+
+static int meta_reset_locked(ctmr_engine* e) {
+  if (!e->d_meta_slots) return CTMR_OK;
+  HIPCHK(e, hipMemsetAsync(e->d_meta_slots, 0, e->n_meta_slots * sizeof(MetaSlot), e->stream));
+  HIPCHK(e, hipMemsetAsync(e->d_mcount, 0, 64, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->last_meta_valid = false;
+  return CTMR_OK;
+}
+
+static int meta_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets, const uint64_t* d_ends,
+                              const ctmr_record* d_records, const uint64_t* d_new_idx, uint64_t n_new,
+                              ctmr_meta_item* d_items, uint64_t items_cap, uint64_t* n_items) {
+  HIPCHK(e, hipSetDevice(e->device));
+  if (n_items) *n_items = 0;
+  if (!e->cfg.collect_meta || !e->d_meta_slots) return fail(e, CTMR_E_INVAL, "engine created without collect_meta");
+  if (n_new == 0) return CTMR_OK;
+  if (!e->d_scratch[SC_META] || e->meta_n == 0) return fail(e, CTMR_E_INVAL, "no map call precedes ctmr_meta_new");
+  MetaArgs a;
+  a.payload = d_payload; a.offsets = d_offsets; a.ends = d_ends; a.records = d_records; a.canon = e->d_canon;
+  a.meta_loc = (const uint2*)e->d_scratch[SC_META]; a.new_idx = d_new_idx; a.n_new = n_new;
+  a.slots = e->d_meta_slots; a.mask = e->n_meta_slots - 1; a.arena = e->d_meta_arena; a.arena_cap = e->meta_arena_cap;
+  a.counters = e->d_mcount; a.items = (MetaItem*)d_items; a.items_cap = items_cap;
+  HIPCHK(e, hipMemsetAsync(e->d_mcount + 1, 0, 8, e->stream));
+  hipLaunchKernelGGL(k_meta_new, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, e->stream, a);
+  unsigned long long hc[3];
+  HIPCHK(e, hipMemcpyAsync(hc, e->d_mcount, 24, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  if (n_items) *n_items = hc[1];
+  if (hc[1] > items_cap) {
+    int r = meta_reset_locked(e);
+    if (r) return r;
+    return fail(e, CTMR_E_RANGE, "meta item buffer too small: %llu items (memo cleared; call again)", hc[1]);
+  }
+  return CTMR_OK;
+}
+
+int ctmr_meta_new_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets, const uint64_t* d_ends,
+                         const ctmr_record* d_records, const uint64_t* d_new_idx, uint64_t n_new,
+                         ctmr_meta_item* d_items, uint64_t items_cap, uint64_t* n_items) {
+  if (!e || (n_new && (!d_payload || !d_offsets || !d_records || !d_new_idx || !d_items))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return meta_device_locked(e, d_payload, d_offsets, d_ends, d_records, d_new_idx, n_new, d_items, items_cap, n_items);
+}
+
+int ctmr_meta_reset(ctmr_engine* e) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  return meta_reset_locked(e);
+}
+
+int ctmr_meta_new(ctmr_engine* e, ctmr_meta_item* items, uint64_t items_cap, uint8_t* bytes, size_t bytes_cap,
+                  uint64_t* n_items, size_t* bytes_need) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (n_items) *n_items = 0;
+  if (bytes_need) *bytes_need = 0;
+  const uint64_t nn = e->last_n_new;
+  if (nn == 0) return CTMR_OK;
+  uint8_t* B = (uint8_t*)e->d_scratch[SC_STAGE_B];
+  const uint8_t* V = (const uint8_t*)e->d_scratch[SC_VIEW];
+  const uint64_t* offs = e->last_is_view ? (const uint64_t*)(V + e->last_o_start) : (const uint64_t*)(B + e->last_o_off);
+  const uint64_t* ends = e->last_is_view ? (const uint64_t*)(V + e->last_o_end) : nullptr;
+  int r;
+  if (!e->last_meta_valid) {
+    uint64_t cap = std::min<uint64_t>(3 * nn + 1024, 16ull << 20);
+    for (int attempt = 0;; attempt++) {
+      if ((r = ensure(e, SC_ITEMS, cap * sizeof(ctmr_meta_item)))) return r;
+      uint64_t got = 0;
+      r = meta_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], offs, ends,
+                             (const ctmr_record*)e->d_scratch[SC_RECORDS], (const uint64_t*)(B + e->last_o_new), nn,
+                             (ctmr_meta_item*)e->d_scratch[SC_ITEMS], cap, &got);
+      if (r == CTMR_OK) {
+        e->last_meta_items = got;
+        break;
+      }
+      if (r != CTMR_E_RANGE || attempt) return r;
+      cap = got + 1024;  // the memo was cleared: the second run re-reports everything into a buffer that fits
+    }
+    e->last_meta_valid = true;
+  }
+  const uint64_t ni = e->last_meta_items;
+  if (n_items) *n_items = ni;
+  std::vector<ctmr_meta_item> h(ni);
+  if (ni) HIPCHK(e, hipMemcpy(h.data(), e->d_scratch[SC_ITEMS], ni * sizeof(ctmr_meta_item), hipMemcpyDeviceToHost));
+  size_t need = 0;
+  for (auto& it : h) {
+    if (it.kind == CTMR_MK_HOST || it.kind == CTMR_MK_EXPDATE) it.len = 0;
+    need += it.len;
+  }
+  if (bytes_need) *bytes_need = need;
+  if (ni > items_cap || need > bytes_cap || (ni && !items) || (need && !bytes))
+    return fail(e, CTMR_E_RANGE, "meta buffers too small: %llu items, %llu bytes", (unsigned long long)ni, (unsigned long long)need);
+  size_t at = 0;
+  for (uint64_t k = 0; k < ni; k++) {
+    if (h[k].len) {
+      uint64_t lo = 0;
+      HIPCHK(e, hipMemcpy(&lo, offs + h[k].entry, 8, hipMemcpyDeviceToHost));
+      HIPCHK(e, hipMemcpy(bytes + at, (const uint8_t*)e->d_scratch[SC_STAGE_A] + lo + h[k].off, h[k].len, hipMemcpyDeviceToHost));
+      at += h[k].len;
+    }
+    items[k] = h[k];
+  }
   return CTMR_OK;
 }
 

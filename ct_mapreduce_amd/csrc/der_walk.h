@@ -32,7 +32,16 @@ struct Walk {
   // captured while the bytes are at hand (a windowed reader may have moved on afterwards):
   uint32_t serial_w[5];  // first min(20, serial_len) serial octets, little-endian words, zero padded
   bool cn_match;         // some issuerCNFilter piece is a byte prefix of the CommonName
+  // where IssuerMetadata.Accumulate's inputs lie (storage/issuermetadata.go:92-138), packed off | len << 16
+  // (meta_pack): the issuer Name TLV, and the OCTET STRING content of extension 2.5.29.31
+  uint32_t meta_issuer, meta_crl;
 };
+
+constexpr uint32_t META_NONE = 0u;           // no such element
+constexpr uint32_t META_HOST = 0xffffffffu;  // does not fit 16+16 bits, or the extension occurs twice: host parse
+CTMR_HD uint32_t meta_pack(uint32_t off, uint32_t len) {
+  return ((off > 0xfffeu) | (len > 0xfffeu)) ? META_HOST : (off | (len << 16));
+}
 
 // strings.Split(*ctconfig.IssuerCNFilter, ",") — pieces NOT trimmed (ct-fetch.go:57-59)
 struct FilterView {
@@ -186,6 +195,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   o.cn_off = o.cn_len = 0;
   o.spki_off = o.spki_len = 0;
   o.bc_valid = o.is_ca = false;
+  o.meta_issuer = o.meta_crl = META_NONE;
   bool ok = L <= 0x7fffffffu;
   L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
   uint32_t tag, cs, ce;
@@ -232,6 +242,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // either a SET (RDN) header or one AttributeTypeAndValue.
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
+  o.meta_issuer = meta_pack(q, ce - q);
   {
     const uint32_t s_end = ce;
     uint32_t a = cs, a_end = cs;
@@ -317,6 +328,11 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         rd_hdr(r, L, ev, x_end, ok, tv, cv, ev);
       }
       ok = ok & (tv == 0x04u);
+      {  // cRLDistributionPoints 2.5.29.31: only located here, decoded by k_meta_new for new certificates
+        const bool is_crl = (eo - co == 3u) & ((oidw & 0xffffffu) == 0x1f1d55u);
+        const uint32_t pk = o.meta_crl == META_NONE ? meta_pack(cv, ev - cv) : META_HOST;
+        o.meta_crl = is_crl ? pk : o.meta_crl;
+      }
       if (ok & (eo - co == 3u) & ((oidw & 0xffffffu) == 0x131d55u)) {
         // basicConstraints ::= SEQUENCE { cA BOOLEAN DEFAULT FALSE, pathLen INTEGER OPTIONAL }
         uint32_t tb, c, c_end, tf, cf, ef;

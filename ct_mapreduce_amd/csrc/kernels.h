@@ -360,6 +360,7 @@ struct MapArgs {
   uint32_t n_issuers;
   uint32_t certs_per_tile;
   uint32_t lds_bytes;  // dynamic LDS size of the launch
+  uint2* meta_loc;          // null, or per entry (Walk.meta_issuer, Walk.meta_crl) for k_meta_new (config.collect_meta)
   uint32_t optimistic_new;  // 1: PASS records leave the map with CTMR_FL_WAS_UNKNOWN already set — the
                             // reduce only CLEARS it for the (rare) duplicates, so the common case costs
                             // no second scattered write into the record array
@@ -423,6 +424,7 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   }
   o0 = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
   o1 = make_uint4(s[1], s[2], s[3], s[4]);
+  if (a.meta_loc) a.meta_loc[idx] = make_uint2(ok ? w.meta_issuer : META_NONE, ok ? w.meta_crl : META_NONE);
 }
 
 template <class R>
@@ -1462,15 +1464,19 @@ struct DecodeArgs {
 // ct.LogEntryFromLeaf, one raw entry per lane (entry_decode.h).  Reads ≈ 5 scattered header words per entry
 // (leaf header, extensions length behind the certificate, the chain headers); the certificates themselves
 // are skipped by length.
+constexpr uint32_t DECODE_PER_BLOCK = 2048;  // entries per workgroup: counters reach global memory once per 2048 entries
 __global__ void __launch_bounds__(256) k_entry_decode(DecodeArgs a) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < a.n;
-  EntryDec d;
-  d.ok = false;
-  d.entry_type = 0;
-  d.n_chain = 0;
-  if (live) {
-    DevBytes b{a.blob};
+  __shared__ uint32_t cnt[4];
+  if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const uint64_t base = (uint64_t)blockIdx.x * DECODE_PER_BLOCK;
+  DevBytes b{a.blob};
+#pragma unroll 2
+  for (uint32_t k = 0; k < DECODE_PER_BLOCK / 256; k++) {
+    const uint64_t i = base + k * 256u + threadIdx.x;
+    if (i >= a.n) break;
+    EntryDec d;
     decode_entry(b, a.bounds[2 * i], a.bounds[2 * i + 1], a.bounds[2 * i + 2], d);
     a.cert_start[i] = d.ok ? d.cert_lo : 0ull;
     a.cert_end[i] = d.ok ? d.cert_hi : 0ull;
@@ -1478,15 +1484,19 @@ __global__ void __launch_bounds__(256) k_entry_decode(DecodeArgs a) {
     if (a.timestamp) a.timestamp[i] = d.ok ? d.timestamp : 0ull;
     a.chain0_start[i] = d.ok ? d.chain0_lo : 0ull;
     a.chain0_len[i] = d.ok ? d.chain0_len : 0u;
+    c0 += d.ok && d.entry_type == 0;
+    c1 += d.ok && d.entry_type == 1;
+    c2 += !d.ok;
+    c3 += d.ok && d.n_chain == 0;
   }
-  const unsigned long long m0 = __ballot(live && d.ok && d.entry_type == 0), m1 = __ballot(live && d.ok && d.entry_type == 1),
-                           m2 = __ballot(live && !d.ok), m3 = __ballot(live && d.ok && d.n_chain == 0);
-  if ((threadIdx.x & 63) == 0) {
-    if (m0) atomicAdd(&a.counters[0], (unsigned long long)__popcll(m0));
-    if (m1) atomicAdd(&a.counters[1], (unsigned long long)__popcll(m1));
-    if (m2) atomicAdd(&a.counters[2], (unsigned long long)__popcll(m2));
-    if (m3) atomicAdd(&a.counters[3], (unsigned long long)__popcll(m3));
-  }
+  // hundreds of thousands of device atomics on one cache line serialise at the memory side (measured: 12 of the
+  // 15 ms of the first version of this kernel at 40 M entries): LDS first, then four atomics per workgroup
+  if (c0) atomicAdd(&cnt[0], c0);
+  if (c1) atomicAdd(&cnt[1], c1);
+  if (c2) atomicAdd(&cnt[2], c2);
+  if (c3) atomicAdd(&cnt[3], c3);
+  __syncthreads();
+  if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(&a.counters[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
 }
 
 // Chain[0] → issuer table index: replaces, per entry, x509.ParseCertificate(Chain[0]) + NewIssuer
@@ -1581,25 +1591,50 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
         }
       }
     }
-    // cooperative bytewise verification, one candidate at a time
+    // cooperative bytewise verification, four candidates per step so that their loads are in flight together
+    // (a step costs one memory latency; certificates up to 2 KiB need no inner loop)
     unsigned long long todo = __ballot(cand != 0xffffffffu);
     while (todo) {
-      const int src = __ffsll((long long)todo) - 1;
-      todo &= todo - 1ull;
-      const uint64_t s_lo = __shfl(lo, src);
-      const uint32_t s_len = __shfl(len, src);
-      const uint32_t s_c = __shfl(cand, src);
-      const uint8_t* db = a.idb_der + a.idb_off[s_c];
-      bool eq = true;
-      for (uint32_t off = lane * 16u; off < s_len; off += 1024u) {
-        const U16 x = *(const U16*)(a.blob + s_lo + off);  // ≤ 15 bytes past Chain[0]: CTMR_PAYLOAD_PAD
-        const uint4 y = *(const uint4*)(db + off);
-        eq = eq && eq16_prefix(x, y, s_len - off);
+      int src[4];
+      bool eq[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        src[u] = todo ? __ffsll((long long)todo) - 1 : -1;
+        todo &= todo - 1ull;  // 0 stays 0
+        eq[u] = true;
       }
-      const bool all = __ballot(!eq) == 0ull;
-      if ((int)lane == src && all) {
-        result = s_c;
-        searching = false;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (src[u] < 0) continue;  // wave-uniform
+        const uint64_t s_lo = __shfl(lo, src[u]);
+        const uint32_t s_len = __shfl(len, src[u]);
+        const uint32_t s_c = __shfl(cand, src[u]);
+        const uint8_t* db = a.idb_der + a.idb_off[s_c];
+        const uint32_t off0 = lane * 16u, off1 = off0 + 1024u;
+        if (off0 < s_len) {
+          const U16 x = *(const U16*)(a.blob + s_lo + off0);  // ≤ 15 bytes past Chain[0]: CTMR_PAYLOAD_PAD
+          const uint4 y = *(const uint4*)(db + off0);
+          eq[u] = eq16_prefix(x, y, s_len - off0);
+        }
+        if (off1 < s_len) {
+          const U16 x = *(const U16*)(a.blob + s_lo + off1);
+          const uint4 y = *(const uint4*)(db + off1);
+          eq[u] = eq[u] && eq16_prefix(x, y, s_len - off1);
+        }
+        for (uint32_t off = off0 + 2048u; off < s_len; off += 1024u) {  // > 2 KiB: rare
+          const U16 x = *(const U16*)(a.blob + s_lo + off);
+          const uint4 y = *(const uint4*)(db + off);
+          eq[u] = eq[u] && eq16_prefix(x, y, s_len - off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (src[u] < 0) continue;
+        const bool all = __ballot(!eq[u]) == 0ull;
+        if ((int)lane == src[u] && all) {
+          result = cand;
+          searching = false;
+        }
       }
     }
   }
@@ -1608,7 +1643,14 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
   const bool unreg = live && result == ISS_UNREGISTERED;
   const unsigned long long mu = __ballot(unreg);
   if (lane == 0 && mu) atomicAdd(&a.counters[0], (unsigned long long)__popcll(mu));
-  if (unreg) {
+  // one claim per distinct hash per wave (a cold start has every lane here)
+  unsigned long long todo_u = mu;
+  while (todo_u) {
+    const int leader = __ffsll((long long)todo_u) - 1;
+    const unsigned long long lq = __shfl(qh, leader);
+    const unsigned long long same = __ballot(unreg && qh == lq) & todo_u;
+    todo_u &= ~same;
+    if ((int)lane != leader) continue;
     uint32_t k = (uint32_t)(qh >> 32) & (PEND_SLOTS - 1u);
     bool first = false, placed = false;
     for (uint32_t probes = 0; probes < 64u && !placed; probes++) {
@@ -1630,6 +1672,182 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
       if (at < a.unreg_cap) a.unreg_list[at] = (uint32_t)i;
     }
   }
+}
+
+// ------------------------------------------------------------------ IssuerMetadata on device
+// IssuerMetadata.Accumulate (storage/issuermetadata.go:92-138) runs for every newly unknown certificate but changes
+// state only the first time an issuer meets an (expDate), a CRL distribution point or an issuer DN: its three
+// per-issuer memo maps (knownExpDates :96, knownCrlDPs :113, knownIssuerDNs :97) live here as ONE device hash set of
+// (kind, issuer, bytes).  k_meta_new walks the NEW list of a batch, and appends an item only for first sightings —
+// the host then formats/inserts those few (addCRL :48-73, addIssuerDN :75-87, AllocateExpDateAndIssuer
+// filesystemdatabase.go:189-195) instead of parsing every new certificate.
+// Set semantics are exact: a slot is claimed by CAS on the 64-bit hash, its bytes are copied into an arena and
+// published (write-through payload, drained, then the VALID word — the table_upsert recipe); equal hash is
+// followed by a full comparison, so a hash collision only costs a probe.
+struct MetaSlot {
+  unsigned long long w[4];  // w0 hash (claim, never 0) | w1 VALID(63) kind(61..60) len(59..40) arena_off/8(39..0)
+};                          // w2 issuer << 32 | key2 | w3 unused
+constexpr unsigned long long META_VALID = 1ull << 63;
+constexpr uint32_t MK_EXPDATE = 0, MK_CRL = 1, MK_DN = 2, MK_HOST = 3;  // item kinds; MK_HOST = parse this one on the host
+constexpr uint32_t META_MAX_BYTES = 4096;
+
+struct MetaItem {  // 32 bytes, = ctmr_meta_item
+  uint64_t entry;
+  uint32_t kind, issuer_idx;
+  int32_t exp_hour;
+  uint32_t off, len, pad;
+};
+static_assert(sizeof(MetaItem) == 32, "MetaItem");
+
+struct MetaArgs {
+  const uint8_t* payload;
+  const uint64_t* offsets;
+  const uint64_t* ends;
+  const ctmr_record* records;
+  const uint32_t* canon;
+  const uint2* meta_loc;
+  const uint64_t* new_idx;
+  uint64_t n_new;
+  MetaSlot* slots;
+  uint64_t mask;
+  uint8_t* arena;
+  uint64_t arena_cap;
+  unsigned long long* counters;  // [0] arena bytes used [1] items appended [2] set/arena overflow events
+  MetaItem* items;
+  uint64_t items_cap;
+};
+
+__device__ __forceinline__ uint32_t meta_word(const uint8_t* p, uint32_t len, uint32_t k) {  // k-th dword, tail zeroed
+  const uint32_t rem = len - 4u * k;
+  const uint32_t v = ((const U4*)(p + 4u * k))->a;
+  return rem >= 4u ? v : (v & (0xffffffffu >> (8u * (4u - rem))));
+}
+
+// true = first sighting of (kind, issuer, key2, bytes)
+__device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, uint32_t issuer, uint32_t key2,
+                                            const uint8_t* p, uint32_t len) {
+  const uint32_t nw = (len + 3u) >> 2;
+  unsigned long long h = mixk(((unsigned long long)issuer << 32 | key2) + 0x9e3779b97f4a7c15ull * (kind + 1u));
+  h = mixk(h ^ len);
+  for (uint32_t k = 0; k < nw; k++) h = mixk(h ^ ((unsigned long long)meta_word(p, len, k) + 0x9e3779b97f4a7c15ull * (k + 2u)));
+  if (h == 0ull) h = 1ull;
+  const unsigned long long w2 = ((unsigned long long)issuer << 32) | key2;
+  uint64_t j = h & a.mask;
+  uint64_t probes = 0;
+  for (;;) {
+    MetaSlot* sl = a.slots + j;
+    unsigned long long w0 = ld_agent(&sl->w[0]);
+    if (w0 == 0ull) {
+      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, h);
+      if (old == 0ull) {  // claimed: copy the bytes, publish
+        const unsigned long long need = ((unsigned long long)len + 7ull) & ~7ull;
+        unsigned long long at = need ? atomicAdd(&a.counters[0], need) : 0ull;
+        uint32_t pk = kind;
+        if (at + need > a.arena_cap) {  // arena exhausted: a dead slot (never equal to anything); always "new"
+          atomicAdd(&a.counters[2], 1ull);
+          pk = MK_HOST;
+          at = 0;
+        } else {
+          uint32_t* dst = (uint32_t*)(a.arena + at);
+          for (uint32_t k = 0; k < nw; k++) __hip_atomic_store(dst + k, meta_word(p, len, k), __ATOMIC_RELAXED, AGENT);
+        }
+        st_agent(&sl->w[2], w2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(&sl->w[1], META_VALID | ((unsigned long long)pk << 60) | ((unsigned long long)len << 40) | (at >> 3));
+        return true;
+      }
+      w0 = old;
+    }
+    if (w0 == h) {
+      const unsigned long long m = ld_agent(&sl->w[1]);
+      if (!(m & META_VALID)) continue;  // the claimer has not published yet: poll again (as table_upsert does)
+      bool eq = ((m >> 60) & 3ull) == kind && ((m >> 40) & 0xfffffull) == len && ld_agent(&sl->w[2]) == w2;
+      if (eq) {
+        const uint32_t* src = (const uint32_t*)(a.arena + ((m & 0xffffffffffull) << 3));
+        for (uint32_t k = 0; (k < nw) & eq; k++)
+          eq = __hip_atomic_load(src + k, __ATOMIC_RELAXED, AGENT) == meta_word(p, len, k);
+      }
+      if (eq) return false;
+    }
+    j = (j + 1) & a.mask;
+    if (++probes > a.mask) break;
+  }
+  atomicAdd(&a.counters[2], 1ull);  // set full: report every time (the host's sets dedup)
+  return true;
+}
+
+__device__ __forceinline__ void meta_emit(const MetaArgs& a, uint64_t entry, uint32_t kind, uint32_t issuer_idx,
+                                          int32_t exp_hour, uint32_t off, uint32_t len) {
+  const unsigned long long at = atomicAdd(&a.counters[1], 1ull);
+  if (at < a.items_cap) a.items[at] = MetaItem{entry, kind, issuer_idx, exp_hour, off, len, 0u};
+}
+
+__global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n_new) return;
+  const uint64_t i = a.new_idx[r];
+  const uint4 r0 = *(const uint4*)(a.records + i);
+  const int32_t exp_hour = (int32_t)r0.y;
+  const uint32_t iss = r0.z, canon = a.canon[iss];
+  uint64_t lo, hi;
+  cert_range(a.offsets, a.ends, i, lo, hi);
+  const uint32_t L = (uint32_t)(hi - lo);
+  const uint8_t* cert = a.payload + lo;
+  const uint2 ml = a.meta_loc[i];
+  // knownExpDates → seenExpDateBefore (issuermetadata.go:96-108)
+  if (meta_upsert(a, MK_EXPDATE, canon, (uint32_t)exp_hour, cert, 0)) meta_emit(a, i, MK_EXPDATE, iss, exp_hour, 0, 0);
+  bool host = ml.x == META_HOST || ml.y == META_HOST || ml.x == META_NONE;
+  // knownIssuerDNs (:97,:130-135): keyed by the Name's DER bytes (Issuer.String() is a function of them)
+  if (!host) {
+    const uint32_t off = ml.x & 0xffffu, len = ml.x >> 16;
+    if (len > META_MAX_BYTES || off + len > L) host = true;
+    else if (meta_upsert(a, MK_DN, canon, 0, cert + off, len)) meta_emit(a, i, MK_DN, iss, exp_hour, off, len);
+  }
+  // knownCrlDPs (:111-127): CRLDistributionPoints ::= SEQUENCE OF DistributionPoint { [0] { [0] GeneralNames { [6] URI }}}
+  if (!host && ml.y != META_NONE) {
+    GlobalReader g{(const uint32_t*)a.payload, lo};
+    const uint32_t s = ml.y & 0xffffu, e = s + (ml.y >> 16);
+    bool ok = e <= L;
+    uint32_t tag, cs, ce;
+    rd_hdr(g, L, s, e, ok, tag, cs, ce);
+    ok = ok && tag == 0x30u && ce == e;
+    // two passes over the same structure: validate everything first (a malformed value yields NO URIs, as the
+    // oracle defines), then upsert
+    for (int pass = 0; pass < 2 && ok; pass++) {
+      uint32_t p = cs;
+      while (ok && p < e) {
+        uint32_t t1, f, f_end;
+        rd_hdr(g, L, p, e, ok, t1, f, f_end);
+        ok = ok && t1 == 0x30u;
+        while (ok && f < f_end) {
+          uint32_t t2, n, n_end;
+          rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
+          if (ok && t2 == 0xa0u) {
+            while (ok && n < n_end) {
+              uint32_t t3, q, q_end;
+              rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
+              if (ok && t3 == 0xa0u) {
+                while (ok && q < q_end) {
+                  uint32_t t4, u, u_end;
+                  rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
+                  if (ok && t4 == 0x86u && pass == 1) {
+                    if (u_end - u > META_MAX_BYTES) host = true;
+                    else if (meta_upsert(a, MK_CRL, canon, 0, cert + u, u_end - u))
+                      meta_emit(a, i, MK_CRL, iss, exp_hour, u, u_end - u);
+                  }
+                  q = u_end;
+                }
+              }
+              n = q_end;
+            }
+          }
+          f = n_end;
+        }
+        p = f_end;
+      }
+    }
+  }
+  if (host) meta_emit(a, i, MK_HOST, iss, exp_hour, 0, L);
 }
 
 // ------------------------------------------------------------------ RemoteCache point ops

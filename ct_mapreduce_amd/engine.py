@@ -95,16 +95,18 @@ class BatchResult:
 
 class Engine:
     def __init__(self, device=0, table_slots=0, pair_slots=0, max_issuers=0, certs_per_tile=0,
-                 lds_tile_bytes=0, map_variant=0, profile=False):
+                 lds_tile_bytes=0, map_variant=0, profile=False, collect_meta=False):
         self._lib = N.lib()
         cfg = N.Config(struct_size=C.sizeof(N.Config), device=device, table_slots=table_slots,
                        pair_slots=pair_slots, max_issuers=max_issuers, certs_per_tile=certs_per_tile,
-                       lds_tile_bytes=lds_tile_bytes, map_variant=map_variant, profile=int(profile))
+                       lds_tile_bytes=lds_tile_bytes, map_variant=map_variant, profile=int(profile),
+                       collect_meta=int(collect_meta))
         h = C.c_void_p()
         rc = self._lib.ctmr_create(C.byref(cfg), C.byref(h))
         if rc != 0:
             raise CtmrError(rc, "ctmr_create failed (no usable HIP device? there is no CPU fallback)")
         self._h = h
+        self.collect_meta = bool(collect_meta)
 
     # ---- lifecycle
     def close(self):
@@ -236,6 +238,36 @@ class Engine:
         self._ck(self._lib.ctmr_synth_entries_device(self._h, C.byref(cfg), first, n, C.c_void_p(d_bounds),
                                                      C.c_void_p(d_blob) if d_blob else None, blob_cap, C.byref(out)))
         return out.value
+
+    # ---- IssuerMetadata on device (N3): first sightings among the new certificates of the last host batch
+    def meta_new(self):
+        """[(kind, entry, issuer_idx, exp_hour, bytes)] — kind N.MK_EXPDATE / MK_CRL (URI bytes) / MK_DN (issuer Name
+        TLV) / MK_HOST (parse certificate `entry` on the host).  Needs collect_meta=True."""
+        ni, need = C.c_uint64(0), C.c_size_t(0)
+        rc = self._lib.ctmr_meta_new(self._h, None, 0, None, 0, C.byref(ni), C.byref(need))
+        if rc not in (0, N.E_RANGE):
+            self._ck(rc)
+        if ni.value == 0:
+            return []
+        items = (N.MetaItem * ni.value)()
+        buf = np.zeros(max(need.value, 1), np.uint8)
+        self._ck(self._lib.ctmr_meta_new(self._h, items, ni.value, buf.ctypes.data, need.value, C.byref(ni),
+                                         C.byref(need)))
+        raw, at, out = buf.tobytes(), 0, []
+        for it in items:
+            out.append((it.kind, int(it.entry), it.issuer_idx, it.exp_hour, raw[at:at + it.len]))
+            at += it.len
+        return out
+
+    def meta_new_device(self, d_payload, d_offsets, d_ends, d_records, d_new_idx, n_new, d_items, items_cap) -> int:
+        n = C.c_uint64(0)
+        self._ck(self._lib.ctmr_meta_new_device(
+            self._h, C.c_void_p(d_payload), C.c_void_p(d_offsets), C.c_void_p(d_ends) if d_ends else None,
+            C.c_void_p(d_records), C.c_void_p(d_new_idx), n_new, C.c_void_p(d_items), items_cap, C.byref(n)))
+        return n.value
+
+    def meta_reset(self):
+        self._ck(self._lib.ctmr_meta_reset(self._h))
 
     # ---- PEM write-back (N1): pem.EncodeToMemory of the newly unknown certificates, on the GPU
     def pem_new(self):

@@ -463,9 +463,26 @@ class HostCert:
                                     self.crl_dps.append(bytes(d[u:v]).decode("latin1"))
 
     def issuer_string(self) -> str:
-        """pkix.Name.String(): RDNs of ToRDNSequence() reversed, multi-values joined with '+'."""
+        return name_string(self.issuer_atvs)
+
+
+def name_atvs(name_der: bytes):
+    """AttributeTypeAndValues of a Name TLV (the bytes a CTMR_MK_DN item carries)."""
+    d = name_der
+    _, cs, ce = _tlv(d, 0)
+    out = []
+    for (_, ss, se) in _children(d, cs, ce):
+        for (_, a_s, a_e) in _children(d, ss, se):
+            (ot, os_, oe), (vt, vs, ve) = _children(d, a_s, a_e)[:2]
+            out.append((bytes(d[os_:oe]), vt, bytes(d[vs:ve])))
+    return out
+
+
+def name_string(atvs) -> str:
+    """pkix.Name.String(): RDNs of ToRDNSequence() reversed, multi-values joined with '+'."""
+    if True:
         named, extra = {}, []
-        for oid, vt, val in self.issuer_atvs:
+        for oid, vt, val in atvs:
             s = val.decode("utf-8", "replace")
             if len(oid) == 3 and oid[:2] == b"\x55\x04" and oid[2] in _ATTR_NAMES:
                 named.setdefault(oid[2], []).append(s)
@@ -748,23 +765,77 @@ class FilesystemDatabase:
         chain0_ders[i]: Chain[0].Data or None.  Returns the BatchResult (records, new_idx, stats)."""
         iss = self._register_issuers(chain0_ders)
         res = self.engine.map_batch(Batch.from_certs(list(leaf_ders), iss, entry_types))
+        self._after_map(res, lambda i: leaf_ders[i])
+        return res
+
+    def StoreRawBatch(self, raw):
+        """Raw get-entries input (engine.RawEntries): ct.LogEntryFromLeaf, the choice of certificate and Chain[0]
+        and the issuer registration all happen on the GPU (Engine.map_entries); the host work is the same."""
+        res = self.engine.map_entries(raw)
+        cache = {}
+
+        def cert_of(i):                      # only for the rare CTMR_MK_HOST / long-serial certificates
+            if i not in cache:
+                from . import _entry_host
+                cache[i] = _entry_host.certificate_of(raw.leaf_input(i), raw.extra_data(i))
+            return cache[i]
+        self._after_map(res, cert_of)
+        return res
+
+    def _after_map(self, res, cert_of):
+        """FilesystemDatabase.Store after WasUnknown (:183-205) for a whole batch."""
         rec = res.records
         pems = self.engine.pem_new()                              # pem.EncodeToMemory on the GPU (N1)
-        for k, i in enumerate(res.new_idx):                       # certWasUnknown branch :183-201
-            i = int(i)
-            info = self.engine.issuer_info(int(rec["issuer_idx"][i]))
-            issuer = Issuer.FromString(info.issuer_id.decode())
-            expDate = ExpDate.FromHour(int(rec["exp_hour"][i]))
-            cert = HostCert(leaf_ders[i])
-            seenBefore = self.GetIssuerMetadata(issuer).Accumulate(cert, int(rec["exp_hour"][i]))
-            if not seenBefore:
-                self.backend.AllocateExpDateAndIssuer(expDate, issuer)
-            self.backend.StoreCertificatePEM(Serial(cert.serial), expDate, issuer, pems[k])
-        for i in np.nonzero(rec["status"] == N.ST_PASS)[0]:       # :205 — every stored entry
-            hour = int(rec["exp_hour"][int(i)])
-            t = _time.gmtime(hour * 3600)
+        issuers, exp_dates = {}, {}
+
+        def issuer_of(idx):
+            if idx not in issuers:
+                issuers[idx] = Issuer.FromString(self.engine.issuer_info(idx).issuer_id.decode())
+            return issuers[idx]
+
+        def serial_of(i):
+            n = int(rec["serial_len"][i])
+            return Serial(bytes(rec["serial"][i][:n])) if n <= 20 else Serial(HostCert(cert_of(i)).serial)
+
+        if getattr(self.engine, "collect_meta", False):
+            # N3: the memo maps of IssuerMetadata live on the GPU; only first sightings come back
+            for kind, i, idx, exp_hour, b in self.engine.meta_new():
+                issuer, md = issuer_of(idx), self.GetIssuerMetadata(issuer_of(idx))
+                if kind == N.MK_EXPDATE:                          # seenExpDateBefore == false (:189-195)
+                    md.knownExpDates.add(ExpDate.FromHour(exp_hour).ID())
+                    self.backend.AllocateExpDateAndIssuer(ExpDate.FromHour(exp_hour), issuer)
+                elif kind == N.MK_CRL:
+                    dp = b.decode("latin1")
+                    if dp not in md.knownCrlDPs:
+                        md.knownCrlDPs.add(dp)
+                        md.addCRL(dp)
+                elif kind == N.MK_DN:
+                    dn = name_string(name_atvs(b))
+                    if dn not in md.knownIssuerDNs:
+                        md.knownIssuerDNs.add(dn)
+                        md.addIssuerDN(dn)
+                else:                                             # CTMR_MK_HOST: the reference's own per-cert path
+                    if not md.Accumulate(HostCert(cert_of(i)), exp_hour):
+                        self.backend.AllocateExpDateAndIssuer(ExpDate.FromHour(exp_hour), issuer)
+            for k, i in enumerate(res.new_idx):
+                i = int(i)
+                self.backend.StoreCertificatePEM(serial_of(i), ExpDate.FromHour(int(rec["exp_hour"][i])),
+                                                 issuer_of(int(rec["issuer_idx"][i])), pems[k])
+        else:
+            for k, i in enumerate(res.new_idx):                   # certWasUnknown branch :183-201, per certificate
+                i = int(i)
+                issuer = issuer_of(int(rec["issuer_idx"][i]))
+                expDate = ExpDate.FromHour(int(rec["exp_hour"][i]))
+                cert = HostCert(cert_of(i))
+                seenBefore = self.GetIssuerMetadata(issuer).Accumulate(cert, int(rec["exp_hour"][i]))
+                if not seenBefore:
+                    self.backend.AllocateExpDateAndIssuer(expDate, issuer)
+                self.backend.StoreCertificatePEM(Serial(cert.serial), expDate, issuer, pems[k])
+        # :205 — every stored entry marks its NotAfter day dirty (distinct days only: the marker is idempotent)
+        hours = np.unique(rec["exp_hour"][rec["status"] == N.ST_PASS] // 24)
+        for day in hours:
+            t = _time.gmtime(int(day) * 86400)
             self.markDirty("%04d-%02d-%02d" % (t.tm_year, t.tm_mon, t.tm_mday))
-        return res
 
     def Store(self, cert_der, issuer_der, logURL=None, entryId=None):
         return self.StoreBatch([cert_der], [issuer_der])

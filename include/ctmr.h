@@ -89,7 +89,8 @@ typedef struct {
                                  10-12 = line-trimmed windows, 13 = 256-B window with wave-cooperative fills,
                                  14 = 13 fused with pass 1 of the known-certificate insert */
   uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
-  uint32_t reserved;
+  uint32_t collect_meta;      /* 1 = the map also records where each certificate's issuer Name and
+                                 cRLDistributionPoints lie (8 B per entry) so that ctmr_meta_new* can run */
 } ctmr_config;
 
 typedef struct {
@@ -273,6 +274,41 @@ int ctmr_map_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_
                             ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
 int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n, ctmr_record* records,
                      uint64_t* new_idx, uint64_t* timestamp, ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
+
+/* ---- IssuerMetadata on device: replaces the per-new-certificate part of
+ *      IssuerMetadata.Accumulate (storage/issuermetadata.go:92-138) — its three per-issuer memo maps knownExpDates,
+ *      knownCrlDPs, knownIssuerDNs live in HBM — so that the host only handles FIRST sightings:
+ *        CTMR_MK_EXPDATE  (issuer, expDate hour) not seen before → seenExpDateBefore == false →
+ *                         backend.AllocateExpDateAndIssuer (storage/filesystemdatabase.go:189-195)
+ *        CTMR_MK_CRL      a CRLDistributionPoints URI not seen for this issuer → addCRL (issuermetadata.go:48-73);
+ *                         off/len = the URI bytes inside the certificate
+ *        CTMR_MK_DN       an issuer Name not seen for this issuer → addIssuerDN(aCert.Issuer.String()) (:75-87);
+ *                         off/len = the Name TLV inside the certificate (the host formats pkix.Name.String())
+ *        CTMR_MK_HOST     this certificate must be parsed by the host (an element does not fit the device fast
+ *                         path: > 64 KiB offsets, > 4 KiB strings, a repeated extension)
+ *      Needs config.collect_meta; call right after the map call of the same batch.  Items are in no particular
+ *      order.  Device variant: d_offsets/d_ends/d_records/d_new_idx as given to / produced by that map call
+ *      (d_ends NULL for a packed batch); when more than items_cap items exist the call fails with CTMR_E_RANGE,
+ *      *n_items = the number needed, and the memo is cleared (a retry re-reports earlier sightings, which the
+ *      host's sets tolerate — "Must tolerate duplicate information", issuermetadata.go:89).
+ *      Host variant (after ctmr_map_batch / ctmr_map_entries called with new_idx != NULL): items plus their bytes
+ *      (item k's bytes follow item k-1's; CTMR_MK_HOST and CTMR_MK_EXPDATE carry none); buffers too small →
+ *      CTMR_E_RANGE with *n_items / *bytes_need set, nothing lost — call again. ---- */
+enum { CTMR_MK_EXPDATE = 0, CTMR_MK_CRL = 1, CTMR_MK_DN = 2, CTMR_MK_HOST = 3 };
+typedef struct {
+  uint64_t entry;       /* index into the batch */
+  uint32_t kind;        /* CTMR_MK_* */
+  uint32_t issuer_idx;  /* as in the record */
+  int32_t exp_hour;
+  uint32_t off, len;    /* byte range inside the certificate */
+  uint32_t pad;
+} ctmr_meta_item;
+int ctmr_meta_new_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets, const uint64_t* d_ends,
+                         const ctmr_record* d_records, const uint64_t* d_new_idx, uint64_t n_new,
+                         ctmr_meta_item* d_items, uint64_t items_cap, uint64_t* n_items);
+int ctmr_meta_new(ctmr_engine* e, ctmr_meta_item* items, uint64_t items_cap, uint8_t* bytes, size_t bytes_cap,
+                  uint64_t* n_items, size_t* bytes_need);
+int ctmr_meta_reset(ctmr_engine* e);
 
 /* ---- benchmark / test input generator (SURVEY.md §8(d) synthetic CT batch); not part of the
  *      reference's surface.  Deterministic in (seed, index); host and device emit identical bytes. */

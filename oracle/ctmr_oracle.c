@@ -981,3 +981,96 @@ void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bo
     if (out_timestamp) out_timestamp[i] = d.ok ? d.timestamp : 0;
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * IssuerMetadata.Accumulate inputs (storage/issuermetadata.go:92-138): RawIssuer and CRLDistributionPoints. */
+static int collect_dp_uris(const uint8_t* d, uint64_t s, uint64_t e, orc_meta* m) {
+  /* CRLDistributionPoints ::= SEQUENCE OF DistributionPoint, filling the OCTET STRING */
+  tlv seq;
+  if (!rd_tlv(d, s, e, &seq) || seq.tag != 0x30 || (uint64_t)seq.hl + seq.len != e - s) return 0;
+  uint64_t p = s + seq.hl, p_end = e;
+  while (p < p_end) {
+    tlv dp;
+    if (!rd_tlv(d, p, p_end, &dp) || dp.tag != 0x30) return 0;
+    uint64_t f = p + dp.hl, f_end = p + dp.hl + dp.len;
+    while (f < f_end) {          /* distributionPoint [0], reasons [1], cRLIssuer [2] */
+      tlv fld;
+      if (!rd_tlv(d, f, f_end, &fld)) return 0;
+      if (fld.tag == 0xa0) {     /* DistributionPointName: fullName [0] | nameRelativeToCRLIssuer [1] */
+        uint64_t n = f + fld.hl, n_end = f + fld.hl + fld.len;
+        while (n < n_end) {
+          tlv nm;
+          if (!rd_tlv(d, n, n_end, &nm)) return 0;
+          if (nm.tag == 0xa0) {  /* GeneralNames */
+            uint64_t g = n + nm.hl, g_end = n + nm.hl + nm.len;
+            while (g < g_end) {
+              tlv gn;
+              if (!rd_tlv(d, g, g_end, &gn)) return 0;
+              if (gn.tag == 0x86) {  /* uniformResourceIdentifier [6] IA5String */
+                if (m->n_crl < ORC_MAX_CRL) {
+                  m->crl_off[m->n_crl] = (uint32_t)(g + gn.hl);
+                  m->crl_len[m->n_crl] = gn.len;
+                }
+                m->n_crl++;
+              }
+              g += gn.hl + gn.len;
+            }
+          }
+          n += nm.hl + nm.len;
+        }
+      }
+      f += fld.hl + fld.len;
+    }
+    p += dp.hl + dp.len;
+  }
+  return 1;
+}
+
+int orc_cert_meta(const uint8_t* d, size_t L, orc_meta* m) {
+  memset(m, 0, sizeof *m);
+  orc_cert c;
+  orc_parse_cert(d, L, &c);
+  if (!c.ok) return 0;
+  /* the certificate is well formed as far as orc_parse_cert checks: walk to the two fields without re-checking */
+  tlv t;
+  uint64_t tbs_end = (uint64_t)c.tbs_off + c.tbs_len;
+  rd_tlv(d, c.tbs_off, tbs_end, &t);
+  uint64_t q = c.tbs_off + t.hl;
+  if (d[q] == 0xa0) { rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len; }
+  rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len;   /* serialNumber */
+  rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len;   /* signature */
+  rd_tlv(d, q, tbs_end, &t);                      /* issuer */
+  m->issuer_off = (uint32_t)q;
+  m->issuer_len = t.hl + t.len;
+  q = (uint64_t)c.spki_off + c.spki_len;
+  if (q < tbs_end && d[q] == 0x81) { rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len; }
+  if (q < tbs_end && d[q] == 0x82) { rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len; }
+  if (q < tbs_end && d[q] == 0xa3) {
+    rd_tlv(d, q, tbs_end, &t);
+    tlv seq;
+    uint64_t e0 = q + t.hl;
+    rd_tlv(d, e0, e0 + t.len, &seq);
+    uint64_t e = e0 + seq.hl, e_end = e0 + seq.hl + seq.len;
+    while (e < e_end) {
+      tlv ext, oid, val;
+      rd_tlv(d, e, e_end, &ext);
+      uint64_t x = e + ext.hl, x_end = e + ext.hl + ext.len;
+      rd_tlv(d, x, x_end, &oid);
+      uint64_t oid_c = x + oid.hl;
+      x += oid.hl + oid.len;
+      rd_tlv(d, x, x_end, &val);
+      if (val.tag == 0x01) { x += val.hl + val.len; rd_tlv(d, x, x_end, &val); }
+      if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x1f) {
+        m->n_crl_ext++;
+        uint32_t before = m->n_crl;
+        if (!collect_dp_uris(d, x + val.hl, x + val.hl + val.len, m)) {
+          m->bad_crl = 1;
+          m->n_crl = before;
+        }
+      }
+      e += ext.hl + ext.len;
+    }
+  }
+  if (m->bad_crl) m->n_crl = 0;
+  return 1;
+}

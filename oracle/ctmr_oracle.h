@@ -126,6 +126,22 @@ void orc_engine_batch(orc_engine*, const uint8_t* payload, const uint64_t* offse
                       const uint64_t* issuer_offsets, uint32_t n_issuers, uint8_t* out_status,
                       uint8_t* out_unknown, int32_t* out_exp_hour);
 
+/* ---- what IssuerMetadata.Accumulate reads from a newly unknown certificate (storage/issuermetadata.go:92-138):
+ *      aCert.Issuer (→ .String(), formatted by the host) as the RawIssuer Name TLV, and aCert.CRLDistributionPoints
+ *      = the uniformResourceIdentifier [6] members of every DistributionPoint.distributionPoint.fullName of every
+ *      extension 2.5.29.31, in order (Go x509 parseCertificate, RFC 5280 §4.2.1.13).  A DistributionPoints value
+ *      that does not decode yields no URIs and bad_crl = 1 (Go would have rejected the certificate: outside the walk
+ *      profile of DESIGN.md §3).  Returns 0 when the certificate itself does not parse. ---- */
+#define ORC_MAX_CRL 16
+typedef struct {
+  uint32_t issuer_off, issuer_len;   /* full Name TLV */
+  uint32_t n_crl;                    /* URIs found (only the first ORC_MAX_CRL are recorded) */
+  uint32_t crl_off[ORC_MAX_CRL], crl_len[ORC_MAX_CRL];
+  uint32_t n_crl_ext;                /* occurrences of extension 2.5.29.31 */
+  int32_t bad_crl;
+} orc_meta;
+int orc_cert_meta(const uint8_t* der, size_t len, orc_meta* out);
+
 /* ---- ct.LogEntryFromLeaf as far as the path consumes it (cmd/ct-fetch/ct-fetch.go:452; call sites of the
  *      result :198-204,:215,:221,:476).  The TLS structures are RFC 6962 §3.4 (MerkleTreeLeaf /
  *      TimestampedEntry) and §4.6 (extra_data: certificate_chain | PrecertChainEntry), with the field limits of

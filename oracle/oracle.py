@@ -14,6 +14,12 @@ ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST
     ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
 
 
+class Meta(C.Structure):
+    _fields_ = [("issuer_off", C.c_uint32), ("issuer_len", C.c_uint32), ("n_crl", C.c_uint32),
+                ("crl_off", C.c_uint32 * 16), ("crl_len", C.c_uint32 * 16), ("n_crl_ext", C.c_uint32),
+                ("bad_crl", C.c_int32)]
+
+
 class Entry(C.Structure):
     _fields_ = [("ok", C.c_int32), ("entry_type", C.c_int32), ("timestamp", C.c_uint64),
                 ("cert_in_extra", C.c_int32), ("cert_off", C.c_uint32), ("cert_len", C.c_uint32),
@@ -87,11 +93,21 @@ def lib():
         L.orc_engine_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
+        L.orc_cert_meta.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Meta)]
         L.orc_decode_entry.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(Entry)]
         L.orc_engine_raw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def cert_meta(der: bytes):
+    """(RawIssuer bytes, [CRL DP URI bytes…], Meta) or None when the certificate does not parse."""
+    m = Meta()
+    if not lib().orc_cert_meta(der, len(der), C.byref(m)):
+        return None
+    uris = [der[m.crl_off[k]:m.crl_off[k] + m.crl_len[k]] for k in range(min(m.n_crl, 16))]
+    return der[m.issuer_off:m.issuer_off + m.issuer_len], uris, m
 
 
 def decode_entry(leaf_input: bytes, extra_data: bytes) -> Entry:

@@ -53,9 +53,12 @@ def test_IssuerAndDates_and_LogState_gpu_cache(engine):
     log_state_suite(cache, S.FilesystemDatabase(S.MockBackend(), cache))
 
 
-def test_StoreBatch_end_to_end(tmp_path):
+@pytest.mark.parametrize("mode", ["host_meta", "device_meta", "raw_entries"])
+def test_StoreBatch_end_to_end(tmp_path, mode):
     """Batched insertCTWorker + FilesystemDatabase.Store: same sets, counts, metadata and files as
-    feeding the entries one at a time through the oracle's restatement of the reference loop."""
+    feeding the entries one at a time through the oracle's restatement of the reference loop.
+    host_meta: IssuerMetadata.Accumulate per new certificate on the host; device_meta: its memo on the GPU (N3);
+    raw_entries: additionally fed with raw get-entries blobs (N2: decode + Chain[0] registration on the GPU)."""
     cfg = synth.config(seed=9, n_issuers=6, dup_permille=150, ca_permille=50, expired_permille=50)
     n = 1500
     batch = synth.host_batch(cfg, 0, n)
@@ -64,7 +67,7 @@ def test_StoreBatch_end_to_end(tmp_path):
     chain0 = [issuers[int(k)] for k in batch.issuer_idx]
     chain0[17] = None                                            # len(Chain) < 1
     now = synth.BASE_TIME
-    eng = ctmr.Engine(device=0, table_slots=1 << 14, pair_slots=1 << 12)
+    eng = ctmr.Engine(device=0, table_slots=1 << 14, pair_slots=1 << 12, collect_meta=mode != "host_meta")
     eng.set_filter(b"Synth Issuer 00", False, now)
     root = str(tmp_path / "certs")
     backend = S.LocalDiskBackend(0o644, root)
@@ -72,8 +75,25 @@ def test_StoreBatch_end_to_end(tmp_path):
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
-        r1 = db.StoreBatch(leafs[:700], chain0[:700], batch.entry_type[:700])
-        r2 = db.StoreBatch(leafs[700:], chain0[700:], batch.entry_type[700:])
+        if mode == "raw_entries":
+            from tests.test_entry_decode_cpu import x509_leaf, precert_leaf, chain, asn1cert
+            from ct_mapreduce_amd.engine import RawEntries
+
+            def raw_of(lo, hi):
+                pairs = []
+                for i in range(lo, hi):
+                    ch = chain([chain0[i]] if chain0[i] is not None else [])
+                    if batch.entry_type[i] == 0:
+                        pairs.append((x509_leaf(leafs[i], ts=i), ch))
+                    else:
+                        pairs.append((precert_leaf(b"\x30\x00", ts=i), asn1cert(leafs[i]) + ch))
+                r = RawEntries.from_pairs(pairs)
+                r.blob = np.concatenate([r.blob, np.zeros(32, np.uint8)])
+                return r
+            r1, r2 = db.StoreRawBatch(raw_of(0, 700)), db.StoreRawBatch(raw_of(700, n))
+        else:
+            r1 = db.StoreBatch(leafs[:700], chain0[:700], batch.entry_type[:700])
+            r2 = db.StoreBatch(leafs[700:], chain0[700:], batch.entry_type[700:])
     finally:
         os.chdir(cwd)
     # oracle, entry by entry (ct-fetch.go:191-235)
