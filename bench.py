@@ -41,23 +41,106 @@ def pow2_at_least(v):
     return p
 
 
-def cpu_baseline(cfg, issuers, filt, now, sample):
-    """The oracle's restatement of the reference loop, timed on one host core (kind "port")."""
+def cpu_baseline(batch_arrays, issuers, filt, now, sample):
+    """The oracle's restatement of the reference loop, timed on one host core (kind "port").  The sample is the
+    first `sample` entries of the SAME batch the GPU processed, copied back from HBM (payload, offsets, issuer_idx)."""
     import numpy as np
-    from ct_mapreduce_amd import synth
     from oracle import oracle as orc
-    batch = synth.host_batch(cfg, 0, sample)
+    payload, offsets, issuer_idx = batch_arrays
     io = np.zeros(len(issuers) + 1, np.uint64)
     io[1:] = np.cumsum([len(x) for x in issuers])
     blob = np.frombuffer(b"".join(issuers), np.uint8)
     o = orc.Engine(filt, False, now)
     t0 = time.perf_counter()
-    st, unk, eh = o.batch(batch.payload, batch.offsets, batch.issuer_idx, blob, io)
+    st, unk, eh = o.batch(payload, offsets, issuer_idx, blob, io)
     dt = time.perf_counter() - t0
     return {"value": sample / dt, "unit": "certificates/sec", "cores": 1, "kind": "port",
             "sample": f"first {sample} entries of the same synthetic batch, oracle/ctmr_oracle.c "
                       f"(in-process hash set stands in for Redis; not the Go binary), {dt:.1f} s",
             "host_cores_available": os.cpu_count()}, (st, unk)
+
+
+def _mix64(z, np):
+    z = z + np.uint64(0x9e3779b97f4a7c15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+    return z ^ (z >> np.uint64(31))
+
+
+def synth_is_dup(seed, first, n, dup_permille, np):
+    """numpy restatement of csrc/synth.h synth_is_dup for entries [first, first+n)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(first, first + n, dtype=np.uint64)
+        base = _mix64(np.uint64(seed) ^ np.uint64((1 * 0xd6e8feb86659fd93) & 0xffffffffffffffff), np)
+        h = _mix64(base + i, np)
+        return (i > 0) & ((h % np.uint64(1000)) < np.uint64(dup_permille))
+
+
+def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers):
+    """BASELINE config 5 on ONE GPU (the cross-GPU form is distributed.run_global_dedup): a long stream with 10 %
+    duplicates, the known-certificate table persisting across waves."""
+    T = args.stream
+    W = args.entries if args.entries != 100_000_000 else 50_000_000
+    W = min(W, T)
+    cfg = synth.config(seed=20260921 + 5, n_issuers=args.issuers, zipf=1, dup_permille=100, ca_permille=10,
+                       expired_permille=10)
+    slots = pow2_at_least(int(T * 1.6))
+    eng = ctmr.Engine(device=local, table_slots=min(slots, 1 << 31), pair_slots=1 << 22, map_variant=args.variant,
+                      profile=True)
+    eng.add_issuers(synth.issuers(cfg))
+    eng.set_filter(filt, False, now)
+    d_off = torch.empty(W + 1, dtype=torch.int64, device=dev)
+    d_iss = torch.empty(W, dtype=torch.int32, device=dev)
+    d_et = torch.empty(W, dtype=torch.uint8, device=dev)
+    d_rec = torch.empty(W * 32, dtype=torch.uint8, device=dev)
+    d_new = torch.empty(W, dtype=torch.int64, device=dev)
+    d_pay = torch.empty(int(W * 1600) + 4096, dtype=torch.uint8, device=dev)
+    t_gpu = t_map = 0.0
+    tot_new = tot_dup = tot_pass = tot_bytes = 0
+    ok = True
+    waves = 0
+    first = 0
+    while first < T:
+        n = min(W, T - first)
+        eng.synth_device(cfg, first, n, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_iss.data_ptr(),
+                         d_et.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
+                                  d_rec.data_ptr(), d_new.data_ptr())
+        t_gpu += time.perf_counter() - t0
+        t_map += st.ms_map
+        # the generator's structure: entry i duplicates an EARLIER entry's key iff synth_is_dup(i) — in this wave or
+        # any earlier one — so PASS ∧ dup must be known and PASS ∧ ¬dup must be new, wave by wave
+        status = d_rec.view(-1, 32)[:n, 0].cpu().numpy()
+        dup = synth_is_dup(cfg.seed, first, n, 100, np)
+        exp_new = int(((status == 0) & ~dup).sum())
+        exp_dup = int(((status == 0) & dup).sum())
+        good = exp_new == int(st.n_new) and exp_dup == int(st.n_dup)
+        ok = ok and good
+        sys.stderr.write(f"stream: wave {waves} [{first}, {first + n}) new {st.n_new} dup {st.n_dup} "
+                         f"({'ok' if good else 'MISMATCH: expected %d/%d' % (exp_new, exp_dup)}) "
+                         f"map {st.ms_map:.2f} ms total {st.ms_total:.2f} ms\n")
+        tot_new += int(st.n_new); tot_dup += int(st.n_dup); tot_pass += int(st.by_status[0])
+        tot_bytes += int(st.payload_bytes) + ALG_BYTES_FIXED * n + ALG_BYTES_PROBE * int(st.by_status[0])
+        first += n
+        waves += 1
+    ok = ok and eng.total_count() == tot_new
+    achieved = tot_bytes / (t_map * 1e-3) / 1e9
+    out = {"metric": "certificates/sec whole-node + achieved HBM GB/s, 100M-entry synthetic CT batch",
+           "value": T / t_gpu, "unit": "certificates/sec", "n_gpus": 1, "steps": waves, "warmup": 0,
+           "ms_per_step": t_gpu / waves * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"STREAM of {T} entries with 10% duplicates in {waves} waves of {W} through one "
+                                  "known-certificate table (BASELINE configs[4] on one GPU); generation untimed",
+                      "table_slots": int(min(slots, 1 << 31)), "map_variant": args.variant or DEFAULT_VARIANT},
+           "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or DEFAULT_VARIANT], "achieved": achieved,
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                        "alg_bytes_formula": "sum(L_i) + 45*E + 64*PASS (table probe), summed over the waves"},
+           "result": {"n_new": tot_new, "n_dup": tot_dup, "n_pass": tot_pass, "total_count": eng.total_count(),
+                      "duplicate_structure_matches_generator_in_every_wave": bool(ok)}}
+    print(json.dumps(out))
+    eng.close()
 
 
 def main():
@@ -72,8 +155,15 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--certs-per-tile", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=6_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--meta", action="store_true",
+                    help="also run the IssuerMetadata memo kernel (k_meta_new, SURVEY §8(f) N3) over the NEW list of "
+                         "every step (engine created with collect_meta) and report its time")
+    ap.add_argument("--stream", type=int, default=0, metavar="TOTAL",
+                    help="BASELINE config 5 on one GPU: stream TOTAL entries with 10%% duplicates through one engine in "
+                         "waves of --entries (default 50M), the known-certificate table persisting across waves; "
+                         "checks n_new / n_dup of every wave against the generator's duplicate structure")
     ap.add_argument("--raw", action="store_true",
                     help="feed raw get-entries blobs (leaf_input ‖ extra_data, ≈3.06 KB per entry): adds the "
                          "LogEntryFromLeaf decode and the Chain[0] → issuer match in front of the map (SURVEY §8(f) N2); "
@@ -127,7 +217,7 @@ def main():
             return setup_raw(E)
         eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
                           map_variant=args.variant, certs_per_tile=args.certs_per_tile,
-                          lds_tile_bytes=args.lds_bytes, profile=True)
+                          lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
         eng.add_issuers(issuers)
         eng.set_filter(filt, False, now)
         # ---- synthetic shard [rank·E, (rank+1)·E), generated directly in HBM
@@ -143,6 +233,9 @@ def main():
         d_new = torch.empty(E, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         return eng, d_off, d_pay, d_iss, d_et, d_rec, d_new
+
+    if args.stream:
+        return run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers)
 
     E = args.entries
     if args.raw and "CTMR_BENCH_ENTRIES" not in os.environ and E == 100_000_000:
@@ -163,9 +256,13 @@ def main():
     counts_dev = torch.zeros(len(issuers), dtype=torch.int64, device=dev)
 
     dstats = []
+    meta_ms, meta_items = [], []
+    d_items = torch.empty(32 * (1 << 22), dtype=torch.uint8, device=dev) if args.meta else None
 
     def step():
         eng.reset_known()
+        if args.meta:
+            eng.meta_reset()
         if args.raw:   # d_off = bounds, d_pay = blob, d_iss = timestamps
             st, ds = eng.map_entries_device(d_pay.data_ptr(), d_off.data_ptr(), E, d_rec.data_ptr(), d_new.data_ptr(),
                                             d_iss.data_ptr())
@@ -173,6 +270,11 @@ def main():
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
                                       E, d_rec.data_ptr(), d_new.data_ptr())
+        if args.meta and not args.raw:
+            t_m = time.perf_counter()
+            meta_items.append(eng.meta_new_device(d_pay.data_ptr(), d_off.data_ptr(), 0, d_rec.data_ptr(),
+                                                  d_new.data_ptr(), int(st.n_new), d_items.data_ptr(), 1 << 22))
+            meta_ms.append((time.perf_counter() - t_m) * 1e3)
         if dist is not None:
             # per-issuer unique counts merged over xGMI (RCCL all-reduce, 2 KiB)
             c = torch.from_numpy(eng.issuer_counts().astype(np.int64)).to(dev)
@@ -246,6 +348,10 @@ def main():
                       "compact": stats.ms_compact, "total": stats.ms_total},
         "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},
     }
+    if args.meta and meta_ms:
+        out["kernel_ms"]["meta_new_wall"] = sum(meta_ms) / len(meta_ms)
+        out["meta"] = {"first_sightings_per_step": meta_items[-1], "new_certificates": int(stats.n_new),
+                       "note": "memo cleared every step: every step is a cold start (all first sightings)"}
     if args.raw:
         ds = dstats[-1]
         out["config"]["workload"] = (f"{E} RAW get-entries (leaf_input+extra_data, {stats.payload_bytes / E:.0f} B/entry) per GPU: "
@@ -260,7 +366,11 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu and not args.raw:
             sample = min(args.cpu_sample, E)
-            base, (ost, ounk) = cpu_baseline(cfg, issuers, filt, now, sample)
+            offs = d_off[: sample + 1].cpu().numpy().astype(np.uint64)
+            nbytes = int(offs[-1])
+            arrays = (np.concatenate([d_pay[:nbytes].cpu().numpy(), np.zeros(N.PAYLOAD_PAD, np.uint8)]), offs,
+                      d_iss[:sample].cpu().numpy().astype(np.uint32))
+            base, (ost, ounk) = cpu_baseline(arrays, issuers, filt, now, sample)
             out["cpu_baseline"] = base
             # the bench doubles as a parity check on that sample
             rec = d_rec[: sample * 32].cpu().numpy().view(ctmr.engine.RECORD_DTYPE)

@@ -598,7 +598,10 @@ class MockRemoteCache : public RemoteCache {  // storage/mockcache.go (sorted sl
 // RAII handle on a libctmr engine.  Fails loudly without a usable MI355X: there is no CPU fallback.
 class GpuEngine {
  public:
-  explicit GpuEngine(int device = 0, uint64_t table_slots = 0, uint64_t pair_slots = 0, uint32_t max_issuers = 0) {
+  // collect_meta: IssuerMetadata's memo maps live on the GPU (ctmr_meta_new) and StoreBatch only sees first sightings
+  explicit GpuEngine(int device = 0, uint64_t table_slots = 0, uint64_t pair_slots = 0, uint32_t max_issuers = 0,
+                     bool collect_meta = false)
+      : collect_meta_(collect_meta) {
     ctmr_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
@@ -606,6 +609,7 @@ class GpuEngine {
     cfg.table_slots = table_slots;
     cfg.pair_slots = pair_slots;
     cfg.max_issuers = max_issuers;
+    cfg.collect_meta = collect_meta ? 1 : 0;
     const int rc = ctmr_create(&cfg, &h_);
     if (rc != CTMR_OK) throw Error("ctmr_create failed (" + std::to_string(rc) + "): no usable HIP device — libctmr has no CPU fallback");
     ctmr_engine* h = h_;
@@ -622,6 +626,7 @@ class GpuEngine {
   GpuEngine(const GpuEngine&) = delete;
   GpuEngine& operator=(const GpuEngine&) = delete;
   ctmr_engine* handle() const { return h_; }
+  bool collect_meta() const { return collect_meta_; }
   void ck(int rc) const {
     if (rc != CTMR_OK) throw Error(std::string("libctmr: ") + ctmr_last_error(h_) + " (" + std::to_string(rc) + ")");
   }
@@ -650,6 +655,7 @@ class GpuEngine {
 
  private:
   ctmr_engine* h_ = nullptr;
+  bool collect_meta_ = false;
 };
 
 // storage.RemoteCache over libctmr: "serials::<expDate>::<issuerID>" sets live in HBM, every other key in the
@@ -819,13 +825,7 @@ class HostCert {
     size_t k = (!kids.empty() && kids[0][0] == 0xa0) ? 1 : 0;
     if (kids.size() < k + 6) throw Error("x509: malformed tbsCertificate");
     serial = d_.substr(kids[k][1], kids[k][2] - kids[k][1]);
-    for (auto& rdn : children(kids[k + 2][1], kids[k + 2][2]))
-      for (auto& atv : children(rdn[1], rdn[2])) {
-        auto parts = children(atv[1], atv[2]);
-        if (parts.size() < 2) throw Error("x509: malformed AttributeTypeAndValue");
-        issuer_atvs.push_back({d_.substr(parts[0][1], parts[0][2] - parts[0][1]), (uint8_t)parts[1][0],
-                               d_.substr(parts[1][1], parts[1][2] - parts[1][1]), rdn[1]});
-      }
+    parseName(kids[k + 2][1], kids[k + 2][2]);
     for (size_t i = k + 6; i < kids.size(); i++) {
       if (kids[i][0] != 0xa3) continue;
       size_t es, ee;
@@ -848,16 +848,22 @@ class HostCert {
     }
   }
   struct ATV { std::string oid; uint8_t tag; std::string value; size_t rdn; };
+  // pkix.Name.String() of a bare Name TLV — the bytes a CTMR_MK_DN item carries (ctmr.h, N3)
+  static std::string NameString(const std::string& name_tlv) {
+    HostCert h(name_tlv, 0);
+    return h.IssuerString();
+  }
   std::string serial;
   std::vector<ATV> issuer_atvs;
   std::vector<std::string> crlDistributionPoints;
 
-  // pkix.Name.String(): known attribute types in ToRDNSequence() order (C, O, OU, L, ST, STREET, POSTALCODE,
-  // SERIALNUMBER, CN), unknown ones first as dotted OIDs, the whole sequence reversed, multi-values joined by '+'
+  // pkix.Name.String(): known attribute types in ToRDNSequence() order (C, ST, L, STREET, POSTALCODE, O, OU, CN,
+  // SERIALNUMBER — Go ≥ 1.10; same order as the Python mirror), unknown ones first as dotted OIDs, the whole
+  // sequence reversed, multi-values joined by '+'
   std::string IssuerString() const {
     static const std::map<uint8_t, const char*> names = {{6, "C"}, {10, "O"}, {11, "OU"}, {3, "CN"}, {5, "SERIALNUMBER"},
                                                          {7, "L"}, {8, "ST"}, {9, "STREET"}, {17, "POSTALCODE"}};
-    static const uint8_t order[] = {6, 10, 11, 7, 8, 9, 17, 5, 3};
+    static const uint8_t order[] = {6, 8, 7, 9, 17, 10, 11, 3, 5};
     std::map<uint8_t, std::vector<std::string>> named;
     std::vector<std::string> rdns;
     for (auto& a : issuer_atvs) {
@@ -892,6 +898,21 @@ class HostCert {
   }
 
  private:
+  HostCert(const std::string& name_tlv, int) : d_(name_tlv) {
+    uint8_t tag;
+    size_t cs, ce;
+    tlv(0, d_.size(), &tag, &cs, &ce);
+    parseName(cs, ce);
+  }
+  void parseName(size_t s, size_t e) {
+    for (auto& rdn : children(s, e))
+      for (auto& atv : children(rdn[1], rdn[2])) {
+        auto parts = children(atv[1], atv[2]);
+        if (parts.size() < 2) throw Error("x509: malformed AttributeTypeAndValue");
+        issuer_atvs.push_back({d_.substr(parts[0][1], parts[0][2] - parts[0][1]), (uint8_t)parts[1][0],
+                               d_.substr(parts[1][1], parts[1][2] - parts[1][1]), rdn[1]});
+      }
+  }
   static std::string escape(const std::string& v) {
     std::string o;
     for (size_t k = 0; k < v.size(); k++) {
@@ -1029,6 +1050,10 @@ class IssuerMetadata {  // storage/issuermetadata.go
     }
     return seenExpDateBefore;
   }
+  // first sightings reported by the GPU memo (ctmr_meta_new): the same three steps of Accumulate, one at a time
+  void firstExpDate(const ExpDate& expDate) { knownExpDates_.insert(expDate.ID()); }
+  void firstCRL(const std::string& dp) { if (knownCrlDPs_.insert(dp).second) addCRL(dp); }
+  void firstIssuerDN(const std::string& dn) { if (knownIssuerDNs_.insert(dn).second) addIssuerDN(dn); }
   std::vector<std::string> Issuers() const { return cache_->SetList(issuersId()); }
   std::vector<std::string> CRLs() const { return cache_->SetList(crlId()); }
 
@@ -1235,7 +1260,33 @@ struct CtLogEntry {
 struct BatchResult {
   std::vector<ctmr_record> records;
   std::vector<uint64_t> new_idx;
+  std::vector<uint64_t> timestamps;  // raw-entry batches: TimestampedEntry.Timestamp (ms)
   ctmr_batch_stats stats{};
+  ctmr_decode_stats decode{};
+};
+
+// Raw get-entries batch (ctmr.h, N2): blob = leaf_input_0 ‖ extra_data_0 ‖ leaf_input_1 ‖ …, bounds[2n+1].
+// What the downloader holds before ct.LogEntryFromLeaf (ct-fetch.go:446-452), base64 already decoded.
+struct RawEntries {
+  std::string blob;
+  std::vector<uint64_t> bounds{0};
+  uint64_t size() const { return (bounds.size() - 1) / 2; }
+  void Append(const std::string& leaf_input, const std::string& extra_data) {
+    blob += leaf_input;
+    bounds.push_back(blob.size());
+    blob += extra_data;
+    bounds.push_back(blob.size());
+  }
+  std::string LeafInput(uint64_t i) const { return blob.substr(bounds[2 * i], bounds[2 * i + 1] - bounds[2 * i]); }
+  std::string ExtraData(uint64_t i) const { return blob.substr(bounds[2 * i + 1], bounds[2 * i + 2] - bounds[2 * i + 1]); }
+  // the certificate insertCTWorker parses (ct-fetch.go:198-204) of an entry the GPU decode accepted
+  std::string Certificate(uint64_t i) const {
+    const std::string leaf = LeafInput(i);
+    auto be = [](const std::string& s, size_t p, int k) { size_t v = 0; for (int j = 0; j < k; j++) v = (v << 8) | (uint8_t)s[p + j]; return v; };
+    if (be(leaf, 10, 2) == 0) return leaf.substr(15, be(leaf, 12, 3));
+    const std::string extra = ExtraData(i);
+    return extra.substr(3, be(extra, 0, 3));
+  }
 };
 
 // ------------------------------------------------------------------------------------------ FilesystemDatabase
@@ -1323,6 +1374,35 @@ class FilesystemDatabase {  // storage/filesystemdatabase.go
     engine_->ck(ctmr_map_batch(engine_->handle(), (const uint8_t*)payload.data(), offsets.data(), issuer_idx.data(),
                                entry_type.data(), n, res.records.data(), res.new_idx.data(), &res.stats));
     res.new_idx.resize(res.stats.n_new);
+    afterMap(res, [&](uint64_t i) { return entries[i].leaf_der; });
+    return res;
+  }
+  // The same from raw get-entries buffers (N2): ct.LogEntryFromLeaf, the choice of certificate and Chain[0] and the
+  // issuer registration happen on the GPU (ctmr_map_entries); entries LogEntryFromLeaf rejects get
+  // CTMR_ST_ENTRY_DECODE_ERROR (the downloader would have dropped them, ct-fetch.go:452-459).
+  BatchResult StoreRawBatch(const RawEntries& raw) {
+    if (!engine_) throw Error("StoreRawBatch needs a GpuEngine (no CPU fallback)");
+    const uint64_t n = raw.size();
+    BatchResult res;
+    if (n == 0) return res;
+    std::string blob = raw.blob;
+    blob.append(CTMR_PAYLOAD_PAD + 16, '\0');
+    res.records.resize(n);
+    res.new_idx.resize(n);
+    res.timestamps.resize(n);
+    engine_->ck(ctmr_map_entries(engine_->handle(), (const uint8_t*)blob.data(), raw.bounds.data(), n, res.records.data(),
+                                 res.new_idx.data(), res.timestamps.data(), &res.decode, &res.stats));
+    res.new_idx.resize(res.stats.n_new);
+    afterMap(res, [&](uint64_t i) { return raw.Certificate(i); });
+    return res;
+  }
+
+ private:
+  // FilesystemDatabase.Store after WasUnknown (filesystemdatabase.go:183-205) for a whole batch.  cert_of(i) is only
+  // called for the certificates the host has to parse itself.
+  template <class F>
+  void afterMap(BatchResult& res, F cert_of) {
+    const uint64_t n = res.records.size();
     // PEM blocks of the newly unknown certificates, encoded on the GPU
     size_t need = 0;
     uint64_t count = 0;
@@ -1332,22 +1412,76 @@ class FilesystemDatabase {  // storage/filesystemdatabase.go
     std::vector<uint64_t> pem_off(count + 1, 0);
     if (count) engine_->ck(ctmr_pem_new(engine_->handle(), (uint8_t*)&pems[0], pems.size(), pem_off.data(), &need, &count));
     if (count != res.new_idx.size()) throw Error("ctmr_pem_new: count mismatch");
-    for (uint64_t k = 0; k < count; k++) {  // certWasUnknown branch, filesystemdatabase.go:183-201
-      const uint64_t i = res.new_idx[k];
+    std::map<uint32_t, Issuer> issuers;
+    auto issuer_of = [&](uint32_t idx) -> const Issuer& {
+      auto f = issuers.find(idx);
+      if (f == issuers.end()) f = issuers.emplace(idx, Issuer::FromString(engine_->IssuerInfo(idx).issuer_id)).first;
+      return f->second;
+    };
+    auto serial_of = [&](uint64_t i) {
       const ctmr_record& r = res.records[i];
-      const ctmr_issuer_info info = engine_->IssuerInfo(r.issuer_idx);
-      const Issuer issuer = Issuer::FromString(info.issuer_id);
-      const ExpDate expDate = ExpDate::FromHour(r.exp_hour);
-      const HostCert cert(entries[i].leaf_der);
-      const bool issuerDateSeenBefore = GetIssuerMetadata(issuer)->Accumulate(cert, expDate);
-      if (!issuerDateSeenBefore) backend_->AllocateExpDateAndIssuer(expDate, issuer);
-      backend_->StoreCertificatePEM(Serial::FromBytes(cert.serial), expDate, issuer,
-                                    pems.substr(pem_off[k], pem_off[k + 1] - pem_off[k]));
+      if (r.serial_len <= 20) return Serial::FromBytes(std::string((const char*)r.serial, r.serial_len));
+      const std::string der = cert_of(i);
+      return Serial::FromBytes(HostCert(der).serial);
+    };
+    if (engine_->collect_meta()) {
+      // N3: IssuerMetadata's memo maps live on the GPU; only first sightings come back (issuermetadata.go:92-138)
+      uint64_t ni = 0;
+      size_t nb = 0;
+      rc = ctmr_meta_new(engine_->handle(), nullptr, 0, nullptr, 0, &ni, &nb);
+      if (rc != CTMR_OK && rc != CTMR_E_RANGE) engine_->ck(rc);
+      std::vector<ctmr_meta_item> items(ni);
+      std::string bytes(nb, '\0');
+      if (ni) engine_->ck(ctmr_meta_new(engine_->handle(), items.data(), ni, (uint8_t*)&bytes[0], nb, &ni, &nb));
+      size_t at = 0;
+      for (const ctmr_meta_item& it : items) {
+        const Issuer& issuer = issuer_of(it.issuer_idx);
+        IssuerMetadata* md = GetIssuerMetadata(issuer);
+        const ExpDate expDate = ExpDate::FromHour(it.exp_hour);
+        const std::string b = bytes.substr(at, it.len);
+        at += it.len;
+        if (it.kind == CTMR_MK_EXPDATE) {          // seenExpDateBefore == false (filesystemdatabase.go:189-195)
+          md->firstExpDate(expDate);
+          backend_->AllocateExpDateAndIssuer(expDate, issuer);
+        } else if (it.kind == CTMR_MK_CRL) {
+          md->firstCRL(b);
+        } else if (it.kind == CTMR_MK_DN) {
+          md->firstIssuerDN(HostCert::NameString(b));
+        } else {                                   // CTMR_MK_HOST: the reference's own per-certificate route
+          const std::string der = cert_of(it.entry);
+          if (!md->Accumulate(HostCert(der), expDate)) backend_->AllocateExpDateAndIssuer(expDate, issuer);
+        }
+      }
+      for (uint64_t k = 0; k < count; k++) {
+        const uint64_t i = res.new_idx[k];
+        const ctmr_record& r = res.records[i];
+        backend_->StoreCertificatePEM(serial_of(i), ExpDate::FromHour(r.exp_hour), issuer_of(r.issuer_idx),
+                                      pems.substr(pem_off[k], pem_off[k + 1] - pem_off[k]));
+      }
+    } else {
+      for (uint64_t k = 0; k < count; k++) {  // certWasUnknown branch, filesystemdatabase.go:183-201, per certificate
+        const uint64_t i = res.new_idx[k];
+        const ctmr_record& r = res.records[i];
+        const Issuer& issuer = issuer_of(r.issuer_idx);
+        const ExpDate expDate = ExpDate::FromHour(r.exp_hour);
+        const std::string der = cert_of(i);
+        const HostCert cert(der);
+        const bool issuerDateSeenBefore = GetIssuerMetadata(issuer)->Accumulate(cert, expDate);
+        if (!issuerDateSeenBefore) backend_->AllocateExpDateAndIssuer(expDate, issuer);
+        backend_->StoreCertificatePEM(Serial::FromBytes(cert.serial), expDate, issuer,
+                                      pems.substr(pem_off[k], pem_off[k + 1] - pem_off[k]));
+      }
     }
-    for (uint64_t i = 0; i < n; i++)  // :204-208 — every entry that reached Store marks its day dirty
-      if (res.records[i].status == CTMR_ST_PASS) markDirty(Time::Unix((int64_t)res.records[i].exp_hour * 3600));
-    return res;
+    std::set<int32_t> days;  // :204-208 — every entry that reached Store marks its day dirty (the marker is idempotent)
+    for (uint64_t i = 0; i < n; i++)
+      if (res.records[i].status == CTMR_ST_PASS) {
+        const int32_t h = res.records[i].exp_hour;
+        days.insert(h >= 0 ? h / 24 : -((-h + 23) / 24));
+      }
+    for (int32_t d : days) markDirty(Time::Unix((int64_t)d * 86400));
   }
+
+ public:
   // Store(aCert, aIssuer, aLogURL, aEntryId) for one entry, DER in (types.go:74-75)
   BatchResult Store(const std::string& cert_der, const std::string& issuer_der, const std::string& aLogURL = "",
                     int64_t aEntryId = 0) {

@@ -436,6 +436,73 @@ static void Test_StoreBatch_Gpu(GpuEngine& eng) {
   }
 }
 
+// N2 + N3 through the host mirror: raw get-entries buffers + the IssuerMetadata memo on the GPU must leave the
+// cache and the backend in the same state as the packed batch with per-certificate Accumulate on the host.
+static void Test_StoreRawBatch_DeviceMeta_Gpu() {
+  ctmr_synth_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.seed = 78; cfg.n_issuers = 7; cfg.dup_permille = 150; cfg.ca_permille = 30; cfg.expired_permille = 30;
+  const size_t N = 2500;
+  std::vector<std::string> issuers(7);
+  for (uint32_t k = 0; k < 7; k++) {
+    issuers[k].resize(4096);
+    issuers[k].resize(ctmr_synth_issuer(&cfg, k, (uint8_t*)&issuers[k][0], 4096));
+  }
+  GpuEngine ea(0, 1 << 14, 1 << 12), eb(0, 1 << 14, 1 << 12, 0, /*collect_meta=*/true);
+  GpuRemoteCache ca(ea), cb(eb);
+  MockBackend ba, bb;
+  FilesystemDatabase da(&ba, &ca, &ea), db(&bb, &cb, &eb);
+  ea.SetFilter("Synth Issuer 00", false, 1767225600ll);
+  eb.SetFilter("Synth Issuer 00", false, 1767225600ll);
+  std::vector<uint8_t> status_a, status_b;
+  uint64_t new_a = 0, new_b = 0;
+  for (size_t first = 0; first < N; first += 900) {
+    const size_t n = std::min<size_t>(900, N - first);
+    std::vector<CtLogEntry> entries(n);
+    for (size_t i = 0; i < n; i++) {
+      CtLogEntry& e = entries[i];
+      e.leaf_der.resize(4096);
+      uint32_t iss; uint8_t et;
+      e.leaf_der.resize(ctmr_synth_leaf(&cfg, first + i, (uint8_t*)&e.leaf_der[0], 4096, &iss, &et));
+      e.chain0_der = issuers[iss];
+      e.precert = et == 1;
+    }
+    const BatchResult ra = da.StoreBatch(entries);
+    RawEntries raw;
+    raw.bounds.resize(2 * n + 1);
+    raw.blob.resize(n * 6144);
+    raw.blob.resize(ctmr_synth_entries_host(&cfg, first, n, raw.bounds.data(), (uint8_t*)&raw.blob[0], raw.blob.size()));
+    const BatchResult rb = db.StoreRawBatch(raw);
+    CHECK_EQ(rb.decode.n_x509 + rb.decode.n_precert, (uint64_t)n);
+    CHECK(rb.timestamps[0] == (uint64_t)(1767225600ll * 1000 + (long long)first));
+    for (size_t i = 0; i < n; i++) {
+      status_a.push_back(ra.records[i].status);
+      status_b.push_back(rb.records[i].status);
+      CHECK(raw.Certificate(i) == entries[i].leaf_der);
+    }
+    CHECK(ra.new_idx == rb.new_idx);
+    new_a += ra.stats.n_new;
+    new_b += rb.stats.n_new;
+  }
+  CHECK(status_a == status_b);
+  CHECK(new_a == new_b && new_a > 0);
+  const StorageStatistics sa = StorageStatistics::Collect(&da), sb = StorageStatistics::Collect(&db);
+  CHECK_EQ(sa.totalSerials, sb.totalSerials);
+  CHECK_EQ(sa.issuers.size(), sb.issuers.size());
+  for (auto& ia : sa.issuers)
+    for (auto& ib : sb.issuers)
+      if (ia.issuerID == ib.issuerID) {
+        CHECK(ia.crls == ib.crls && ia.dns == ib.dns && ia.crls.size() == 1 && ia.dns.size() == 1);
+        CHECK_EQ(ia.serials, ib.serials);
+      }
+  CHECK(ba.store == bb.store);   // same PEM files, byte for byte
+  auto as_set = [](const std::vector<std::string>& v) { return std::set<std::string>(v.begin(), v.end()); };
+  CHECK(as_set(ba.allocations) == as_set(bb.allocations));
+  CHECK(as_set(ba.dirty) == as_set(bb.dirty));
+  // the engine registered the issuers itself, the same seven
+  CHECK_EQ(eb.IssuerCounts().size(), (size_t)7);
+}
+
 int main(int argc, char** argv) {
   bool gpu = false;
   for (int i = 1; i < argc; i++) {
@@ -469,6 +536,7 @@ int main(int argc, char** argv) {
       RUN(Test_ExpireAt_Gpu(eng));
       GpuEngine eng3(0, 1 << 16, 1 << 14);
       RUN(Test_StoreBatch_Gpu(eng3));
+      RUN(Test_StoreRawBatch_DeviceMeta_Gpu());
     } catch (const std::exception& ex) {
       fprintf(stderr, "GPU suites aborted: %s\n", ex.what());
       g_fail++;

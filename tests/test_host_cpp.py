@@ -45,5 +45,6 @@ def test_host_mirror_cpu_suites(tmp_path):
 def test_host_mirror_gpu_suites(tmp_path):
     out = run(["--gpu"], tmp_path)
     for name in ("Test_IssuerLazyInit_Gpu", "Suite_KnownCertificates", "Suite_DuplicateCRLs", "Suite_Accumulate",
-                 "Suite_GetIssuerAndDatesFromCache", "Suite_LogState", "Test_ExpireAt_Gpu", "Test_StoreBatch_Gpu"):
+                 "Suite_GetIssuerAndDatesFromCache", "Suite_LogState", "Test_ExpireAt_Gpu", "Test_StoreBatch_Gpu",
+                 "Test_StoreRawBatch_DeviceMeta_Gpu"):
         assert "ok   " + name in out, out
