@@ -28,9 +28,10 @@ ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32 (
 
 MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 3: "k_map_win<16>", 4: "k_map_win<8>", 5: "k_map_win<12>",
                6: "k_map_win<14>", 7: "k_map_win2<16>", 8: "k_map_win2<14>", 9: "k_map_win2<12>", 10: "k_map_wint<16,192,208>",
-               11: "k_map_wint<16,208,224>", 12: "k_map_wint<16,176,192>", 13: "k_map_winc<16>", 14: "k_map_fused<16>"}
-DEFAULT_VARIANT = 14
-FUSED = (14,)          # map kernels that also do pass 1 of the known-certificate insert
+               11: "k_map_wint<16,208,224>", 12: "k_map_wint<16,176,192>", 13: "k_map_winc<16>", 14: "k_map_fused<16>",
+               15: "k_map_fused<16, true>"}
+DEFAULT_VARIANT = 15
+FUSED = (14, 15)          # map kernels that also do pass 1 of the known-certificate insert
 ALG_BYTES_PROBE = 64   # per PASS entry: 32 B slot read + 32 B slot write — fused kernels only
 
 
@@ -160,6 +161,9 @@ def main():
     ap.add_argument("--meta", action="store_true",
                     help="also run the IssuerMetadata memo kernel (k_meta_new, SURVEY §8(f) N3) over the NEW list of "
                          "every step (engine created with collect_meta) and report its time")
+    ap.add_argument("--fingerprint", action="store_true",
+                    help="also time the auxiliary whole-certificate SHA-256 kernel (k_fingerprint; VALU-bound, not on "
+                         "the reference's path) over the batch")
     ap.add_argument("--stream", type=int, default=0, metavar="TOTAL",
                     help="BASELINE config 5 on one GPU: stream TOTAL entries with 10%% duplicates through one engine in "
                          "waves of --entries (default 50M), the known-certificate table persisting across waves; "
@@ -261,8 +265,6 @@ def main():
 
     def step():
         eng.reset_known()
-        if args.meta:
-            eng.meta_reset()
         if args.raw:   # d_off = bounds, d_pay = blob, d_iss = timestamps
             st, ds = eng.map_entries_device(d_pay.data_ptr(), d_off.data_ptr(), E, d_rec.data_ptr(), d_new.data_ptr(),
                                             d_iss.data_ptr())
@@ -348,10 +350,30 @@ def main():
                       "compact": stats.ms_compact, "total": stats.ms_total},
         "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},
     }
+    if args.fingerprint and not args.raw:
+        d_dg = torch.empty(E * 32, dtype=torch.uint8, device=dev)
+        fp_ms = [eng.fingerprint_device(d_pay.data_ptr(), d_off.data_ptr(), 0, E, d_dg.data_ptr()) for _ in range(3)]
+        import hashlib
+        okfp = True
+        offs_h = d_off[:1001].cpu().numpy()
+        pay_h = d_pay[: int(offs_h[-1])].cpu().numpy().tobytes()
+        dg_h = d_dg[: 1000 * 32].cpu().numpy().tobytes()
+        for k in range(1000):
+            okfp = okfp and hashlib.sha256(pay_h[int(offs_h[k]):int(offs_h[k + 1])]).digest() == dg_h[32 * k:32 * k + 32]
+        ms_fp = min(fp_ms)
+        out["fingerprint"] = {"kernel": "k_fingerprint", "ms": ms_fp, "certs_per_s": E / (ms_fp * 1e-3),
+                              "hashed_GBps": stats.payload_bytes / (ms_fp * 1e-3) / 1e9,
+                              "bound": "valu", "blocks_per_s": (stats.payload_bytes / 64 + 1.5 * E) / (ms_fp * 1e-3),
+                              "matches_hashlib_on_first_1000": bool(okfp),
+                              "note": "auxiliary op, not on the reference's path (SURVEY D2); VALU roofline in DESIGN.md §5"}
     if args.meta and meta_ms:
-        out["kernel_ms"]["meta_new_wall"] = sum(meta_ms) / len(meta_ms)
-        out["meta"] = {"first_sightings_per_step": meta_items[-1], "new_certificates": int(stats.n_new),
-                       "note": "memo cleared every step: every step is a cold start (all first sightings)"}
+        out["kernel_ms"]["meta_new_cold_wall"] = meta_ms[0]
+        out["kernel_ms"]["meta_new_warm_wall"] = sum(meta_ms[1:]) / max(len(meta_ms) - 1, 1)
+        out["meta"] = {"first_sightings_cold": meta_items[0], "first_sightings_warm": meta_items[-1],
+                       "new_certificates": int(stats.n_new),
+                       "note": "cold = first call (empty memo: every (issuer, expDate), DN and CRL DP is a first "
+                               "sighting); warm = later steps (the known-certificate table is cleared every step, the "
+                               "memo is not: every certificate is new again, nothing is a first sighting)"}
     if args.raw:
         ds = dstats[-1]
         out["config"]["workload"] = (f"{E} RAW get-entries (leaf_input+extra_data, {stats.payload_bytes / E:.0f} B/entry) per GPU: "

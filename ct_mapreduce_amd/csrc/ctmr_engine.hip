@@ -32,6 +32,7 @@ struct HostReader {  // host instantiation of the walk for the long-serial slow 
     memcpy(&v, p + pos, 4);
     return v;
   }
+  uint32_t ldg(uint32_t pos) const { return ld4(pos); }
   void touch(uint32_t, uint32_t) const {}
   void touch_tail(uint32_t, uint32_t) const {}
 };
@@ -170,6 +171,7 @@ struct ctmr_engine {
   uint64_t meta_arena_cap = 0;
   unsigned long long* d_mcount = nullptr;  // [0] arena used [1] items [2] overflow events
   uint64_t meta_n = 0;                     // entries the SC_META scratch describes (the last map call)
+  uint32_t meta_epoch = 0;                 // k_meta_new launches so far
   bool last_meta_valid = false;            // SC_ITEMS holds the items of the last host batch
   uint64_t last_meta_items = 0;
   // the last ctmr_map_entries (host variant): ctmr_pem_new encodes from its view
@@ -685,16 +687,19 @@ static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* 
   ma.payload = d_payload; ma.offsets = d_offsets; ma.issuer_idx = d_issuer_idx;
   ma.entry_type = d_entry_type; ma.records = d_records; ma.issuer_valid = e->d_issuer_valid;
   ma.filt = e->d_filter; ma.n = n; ma.n_issuers = (uint32_t)e->issuers.size();
-  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 14;
-  if (variant == 14 && !fuse) variant = 13;  // the fused kernel only exists with the local reduce behind it
+  uint32_t variant = e->cfg.map_variant ? e->cfg.map_variant : 15;
+  if (variant == 14 && !fuse) variant = 13;  // the fused kernels only exist with the local reduce behind them
   if (variant == 1 && d_ends) variant = 13;  // the whole-certificate tile copy needs the packed layout
   uint32_t C = e->cfg.certs_per_tile ? e->cfg.certs_per_tile : 32;
   if (C > 64) C = 64;
   uint32_t lds = e->cfg.lds_tile_bytes ? e->cfg.lds_tile_bytes : 65536;
   if (lds > 160 * 1024) lds = 160 * 1024;
   ma.certs_per_tile = C; ma.lds_bytes = lds;
+  if (variant == 15 && !fuse) variant = 13;
   if (variant == 14) {
-    hipLaunchKernelGGL(k_map_fused<16>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma, *fuse);
+    hipLaunchKernelGGL((k_map_fused<16, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma, *fuse);
+  } else if (variant == 15) {
+    hipLaunchKernelGGL((k_map_fused<16, true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (16 * 16 + 16), e->stream, ma, *fuse);
   } else if (variant == 2) {
     hipLaunchKernelGGL(k_map_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ma);
   } else if (variant == 3) {
@@ -763,7 +768,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   InsertArgs ia;
   ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.ends = d_ends; ia.canon = e->d_canon;
   ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.ent = d_ent; ia.n = n; ia.epoch = e->epoch;
-  const bool fused = e->cfg.map_variant == 14 || e->cfg.map_variant == 0;
+  const bool fused = e->cfg.map_variant == 14 || e->cfg.map_variant == 15 || e->cfg.map_variant == 0;
   if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
   if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, true, fused ? &ia : nullptr,
                       d_ends, blob_bytes + CTMR_PAYLOAD_PAD))) return r;
@@ -1112,6 +1117,7 @@ static int meta_device_locked(ctmr_engine* e, const uint8_t* d_payload, const ui
   a.meta_loc = (const uint2*)e->d_scratch[SC_META]; a.new_idx = d_new_idx; a.n_new = n_new;
   a.slots = e->d_meta_slots; a.mask = e->n_meta_slots - 1; a.arena = e->d_meta_arena; a.arena_cap = e->meta_arena_cap;
   a.counters = e->d_mcount; a.items = (MetaItem*)d_items; a.items_cap = items_cap;
+  a.epoch = ++e->meta_epoch;
   HIPCHK(e, hipMemsetAsync(e->d_mcount + 1, 0, 8, e->stream));
   hipLaunchKernelGGL(k_meta_new, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, e->stream, a);
   unsigned long long hc[3];
@@ -1195,6 +1201,25 @@ int ctmr_meta_new(ctmr_engine* e, ctmr_meta_item* items, uint64_t items_cap, uin
     }
     items[k] = h[k];
   }
+  return CTMR_OK;
+}
+
+// ------------------------------------------------------------------ whole-certificate SHA-256 (auxiliary)
+int ctmr_fingerprint_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                            const uint64_t* d_ends, uint64_t n, uint8_t* d_digests, float* ms) {
+  if (!e || (n && (!d_payload || !d_offsets || !d_digests))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (ms) *ms = 0.f;
+  if (n == 0) return CTMR_OK;
+  if (((uintptr_t)d_digests & 15) != 0) return fail(e, CTMR_E_INVAL, "digests must be 16-byte aligned");
+  HIPCHK(e, hipEventRecord(e->ev[5], e->stream));
+  hipLaunchKernelGGL(k_fingerprint, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, d_payload, d_offsets,
+                     d_ends, n, (uint32_t*)d_digests);
+  HIPCHK(e, hipEventRecord(e->ev[6], e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  if (ms) (void)hipEventElapsedTime(ms, e->ev[5], e->ev[6]);
   return CTMR_OK;
 }
 

@@ -180,6 +180,15 @@ CTMR_HD bool string_tag(uint32_t t) {
   return (t == 0x0cu) | (t == 0x12u) | (t == 0x13u) | (t == 0x14u) | (t == 0x16u);
 }
 
+// The three reads behind the TBSCertificate (signatureAlgorithm header, signatureValue header, its pad octet) lie
+// ~1 KB past everything else the walk touches: they go through Reader::ldg(pos) — "known to be far away" — so that
+// a windowed reader can serve ld4 from its window alone.
+template <class R>
+struct TailView {
+  const R& r;
+  CTMR_HD uint32_t ld4(uint32_t pos) const { return r.ldg(pos); }
+};
+
 // `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
 // windowed reader that about `need` bytes from pos are read next; r.touch_tail(pos, tail) that the
 // bytes from pos AND the bytes at `tail` are read next; other readers ignore both.
@@ -357,16 +366,17 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     }
   }
   // signatureAlgorithm, signatureValue BIT STRING (Go asn1 parseBitString)
-  rd_hdr(r, L, tbs_end, L, ok, tag, cs, ce);
+  const TailView<R> tv{r};
+  rd_hdr(tv, L, tbs_end, L, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
-  rd_hdr(r, L, ce, L, ok, tag, cs, ce);
+  rd_hdr(tv, L, ce, L, ok, tag, cs, ce);
   ok = ok & (tag == 0x03u) & (ce != cs);
   {
-    const uint32_t pad = r.ld4(cs < L ? cs : L) & 0xffu;
+    const uint32_t pad = tv.ld4(cs < L ? cs : L) & 0xffu;
     ok = ok & (pad <= 7u) & ((ce - cs != 1u) | (pad == 0u));
     if (ok & (pad != 0u)) {  // padding bits must be zero: only then is the last octet needed
       const uint32_t lastp = ce - 1u;
-      const uint32_t last = r.ld4(lastp < L ? lastp : L) & 0xffu;
+      const uint32_t last = tv.ld4(lastp < L ? lastp : L) & 0xffu;
       ok = (last & ((1u << (pad & 7u)) - 1u)) == 0u;
     }
   }

@@ -138,8 +138,11 @@ template <class B>
 CTMR_HD uint64_t cert_quick_hash(const B& b, uint64_t lo, uint32_t len) {
   uint64_t h = qh_mix(0x9e3779b97f4a7c15ull + len);
   if (len >= 32) {
-    for (int k = 0; k < 4; k++) h = qh_mix(h ^ ((uint64_t)b.le32(lo + 4 * k) << 1 | 1));
-    for (int k = 0; k < 4; k++) h = qh_mix(h ^ ((uint64_t)b.le32(lo + len - 16 + 4 * k) << 1));
+    uint32_t hd[4], tl[4];
+    b.le128(lo, hd);             // one 16-byte load each on the device
+    b.le128(lo + len - 16, tl);
+    for (int k = 0; k < 4; k++) h = qh_mix(h ^ ((uint64_t)hd[k] << 1 | 1));
+    for (int k = 0; k < 4; k++) h = qh_mix(h ^ ((uint64_t)tl[k] << 1));
   } else {
     for (uint32_t k = 0; k < len; k++) h = qh_mix(h ^ b.u8(lo + k));
   }
@@ -156,6 +159,9 @@ struct HostBytes {  // host instantiation (registration, staging checks, tests)
   }
   uint32_t le32(uint64_t pos) const {
     return (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16) | ((uint32_t)p[pos + 3] << 24);
+  }
+  void le128(uint64_t pos, uint32_t out[4]) const {
+    for (int k = 0; k < 4; k++) out[k] = le32(pos + 4 * k);
   }
 };
 

@@ -29,6 +29,7 @@ struct LdsReader {
     const uint32_t i = a >> 2;
     return __builtin_amdgcn_alignbyte(lds[i + 1], lds[i], a & 3u);
   }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
   __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
   __device__ __forceinline__ void touch_tail(uint32_t, uint32_t) const {}
 };
@@ -41,6 +42,7 @@ struct GlobalReader {
     const uint64_t i = a >> 2;
     return __builtin_amdgcn_alignbyte(words[i + 1], words[i], (uint32_t)a & 3u);
   }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
   __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
   __device__ __forceinline__ void touch_tail(uint32_t, uint32_t) const {}
 };
@@ -68,6 +70,11 @@ struct WinReader {
       const uint32_t i = rel >> 2;
       return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
     }
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {  // straight from global memory
     const uint64_t a = base + pos;
     const uint64_t i = a >> 2;
     return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
@@ -122,6 +129,24 @@ struct WinReaderC : WinReader<WCH> {
   }
 };
 
+// WinReaderC whose ld4() is served by the LDS window ALONE: no per-access "outside the window → global load"
+// branch (88 ld4 per certificate, each of which used to carry its own exec-mask dance).  An access that does fall
+// outside is clamped and remembered in `miss`; the kernel then repeats that certificate with the exact GlobalReader.
+// On well-formed certificates the walk's touch() hints keep every ld4 inside (measured on the synthetic corpus: 0
+// misses in 200 000 certificates once the three reads behind the TBS go through ldg()).
+template <int WCH>
+struct WinReaderS : WinReaderC<WCH> {
+  mutable uint32_t miss;
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    uint32_t rel = pos - (uint32_t)this->grel;
+    constexpr uint32_t LAST = WinReader<WCH>::WBYTES - 8u;
+    miss |= (uint32_t)(rel > LAST);
+    rel = rel > LAST ? LAST : rel;
+    const uint32_t i = rel >> 2;
+    return __builtin_amdgcn_alignbyte(this->win[i + 1], this->win[i], rel & 3u);
+  }
+};
+
 // Line-trimmed window.  HBM is fetched in 128-byte lines (scripts/calib_fetch.hip: FETCH_SIZE x2 equals
 // the unique 128-B lines of every window pattern tried), so a refill that ends in the middle of a line
 // pays for the whole line and keeps only part of it.  This reader ends every refill at the end of the
@@ -138,6 +163,7 @@ struct WinReaderT {
   int32_t grel;
   uint32_t wlen;  // valid bytes in the window (multiple of 16)
 
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     const uint32_t rel = pos - (uint32_t)grel;
     if (rel + 8u <= wlen && rel < 0x7fffffffu) {
@@ -192,6 +218,7 @@ struct WinReader2 {
   int32_t grel;   // main window start relative to the certificate start
   int32_t trel;   // tail window start (0x7fffff00 = not loaded)
 
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     const uint32_t rel = pos - (uint32_t)grel;
     if (rel <= WBYTES - 8u) {
@@ -259,6 +286,28 @@ __constant__ uint32_t K256[64] = {
     0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
     0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
+// One SHA-256 compression: h += F(h, w); w[] is the 16-word block, used as the rolling schedule.
+__device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16], const uint32_t* kc) {
+  uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    if (i >= 16) {
+      const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+      const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+    }
+    const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+    const uint32_t ch = (e & f) ^ (~e & g);
+    const uint32_t t1 = hh + S1 + ch + kc[i] + w[i & 15];
+    const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+    const uint32_t mj = (a & bb) ^ (a & c) ^ (bb & c);
+    const uint32_t t2 = S0 + mj;
+    hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
 // One lane hashes one message; round constants come from LDS (kc), message bytes through the
 // reader.  w[] is a 16-word rolling schedule.
 template <class R>
@@ -288,24 +337,7 @@ __device__ void sha256_lane(const R& r, uint32_t off, uint32_t len, const uint32
       w[14] = (uint32_t)(((unsigned long long)len * 8ull) >> 32);
       w[15] = (uint32_t)((unsigned long long)len * 8ull);
     }
-    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-      if (i >= 16) {
-        const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-        const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-        const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
-        w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
-      }
-      const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
-      const uint32_t ch = (e & f) ^ (~e & g);
-      const uint32_t t1 = hh + S1 + ch + kc[i] + w[i & 15];
-      const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
-      const uint32_t mj = (a & bb) ^ (a & c) ^ (bb & c);
-      const uint32_t t2 = S0 + mj;
-      hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    sha256_compress(h, w, kc);
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) out[i] = h[i];
@@ -910,7 +942,7 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 // (Tried and dropped: loading the slot's claim word early, when the key is known but the extension block
 // is still in flight, so that the CAS finds the line on-die — +0.6 ms at 100 M entries: the kernel is bound
 // by memory transactions, not by the latency of the probe.)
-template <int WCH>
+template <int WCH, bool STRICT>
 __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
@@ -940,9 +972,19 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   uint64_t claimed = ~0ull;
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
   if (live) {
-    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
-                       (int32_t)(int64_t)(g_me - lo)}};
-    map_one(r, hi - lo, i, a, o0, o1);
+    if constexpr (STRICT) {
+      WinReaderS<WCH> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                          (int32_t)(int64_t)(g_me - lo)}}, 0u};
+      map_one(r, hi - lo, i, a, o0, o1);
+      if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
+        GlobalReader g{(const uint32_t*)a.payload, lo};
+        map_one(g, hi - lo, i, a, o0, o1);
+      }
+    } else {
+      WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                         (int32_t)(int64_t)(g_me - lo)}};
+      map_one(r, hi - lo, i, a, o0, o1);
+    }
     const uint32_t status = o0.x & 0xffu;
     uint32_t state = ES_NONE, canon = 0;
     if (status == CTMR_ST_PASS) {
@@ -1442,6 +1484,10 @@ struct __attribute__((packed, aligned(1))) U4 { uint32_t a; };
 struct DevBytes {  // arbitrary byte positions of the blob (gfx950 runs with unaligned access mode)
   const uint8_t* p;
   __device__ __forceinline__ uint32_t le32(uint64_t pos) const { return ((const U4*)(p + pos))->a; }
+  __device__ __forceinline__ void le128(uint64_t pos, uint32_t out[4]) const {
+    const U16 v = *(const U16*)(p + pos);
+    out[0] = v.a; out[1] = v.b; out[2] = v.c; out[3] = v.d;
+  }
   __device__ __forceinline__ uint32_t u8(uint64_t pos) const { return p[pos]; }
   __device__ __forceinline__ uint32_t be(uint64_t pos, int k) const {  // reads ≤ 3 bytes past pos+k: CTMR_PAYLOAD_PAD
     return __builtin_bswap32(le32(pos)) >> (32 - 8 * k);
@@ -1686,10 +1732,15 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
 // followed by a full comparison, so a hash collision only costs a probe.
 struct MetaSlot {
   unsigned long long w[4];  // w0 hash (claim, never 0) | w1 VALID(63) kind(61..60) len(59..40) arena_off/8(39..0)
-};                          // w2 issuer << 32 | key2 | w3 unused
+};                          // w2 issuer << 32 | key2 | w3 launch number that created the slot
 constexpr unsigned long long META_VALID = 1ull << 63;
 constexpr uint32_t MK_EXPDATE = 0, MK_CRL = 1, MK_DN = 2, MK_HOST = 3;  // item kinds; MK_HOST = parse this one on the host
 constexpr uint32_t META_MAX_BYTES = 4096;
+constexpr uint32_t META_MAX_URIS = 4;  // CRL distribution point URIs per certificate on the device path; more → host
+struct ByteReader {  // one unaligned dword per access (k_meta_new's TLV reads)
+  const uint8_t* p;
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const { return ((const U4*)(p + pos))->a; }
+};
 
 struct MetaItem {  // 32 bytes, = ctmr_meta_item
   uint64_t entry;
@@ -1715,32 +1766,54 @@ struct MetaArgs {
   unsigned long long* counters;  // [0] arena bytes used [1] items appended [2] set/arena overflow events
   MetaItem* items;
   uint64_t items_cap;
+  uint32_t epoch;  // launch number (≥ 1): slots of earlier launches are immutable and read through the caches
 };
 
-__device__ __forceinline__ uint32_t meta_word(const uint8_t* p, uint32_t len, uint32_t k) {  // k-th dword, tail zeroed
-  const uint32_t rem = len - 4u * k;
-  const uint32_t v = ((const U4*)(p + 4u * k))->a;
-  return rem >= 4u ? v : (v & (0xffffffffu >> (8u * (4u - rem))));
+// k-th 16-byte chunk of an item, bytes past its end zeroed (one unaligned dwordx4 load; ≤ 15 bytes past the item,
+// which lies inside a certificate inside the payload + CTMR_PAYLOAD_PAD).  Items are hashed and compared in these
+// chunks: the first version of this kernel used dwords and was bound by L2 REQUESTS (1.46 G for 18.8 M new
+// certificates, 76 % of its L1 accesses missing — profiles/r01/s4/pmc_meta_20m_dword_version.txt).
+__device__ __forceinline__ uint4 meta_chunk(const uint8_t* p, uint32_t len, uint32_t k) {
+  const U16 v = *(const U16*)(p + 16u * k);
+  const uint32_t rem = len - 16u * k;  // > 0
+  uint32_t w[4] = {v.a, v.b, v.c, v.d};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t have = rem > 4u * q ? rem - 4u * q : 0u;
+    w[q] = have >= 4u ? w[q] : (have ? (w[q] & (0xffffffffu >> (8u * (4u - have)))) : 0u);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Plain (cacheable) load the compiler may not merge or hoist: wavefront-scope atomic.  Used for memo slots of EARLIER
+// launches, which are immutable — the steady state, where the same few hundred DN/CRL slots are read by every new
+// certificate and should come out of L1/L2 instead of device-coherent loads.
+__device__ __forceinline__ unsigned long long ld_wave(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // true = first sighting of (kind, issuer, key2, bytes)
 __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, uint32_t issuer, uint32_t key2,
                                             const uint8_t* p, uint32_t len) {
-  const uint32_t nw = (len + 3u) >> 2;
+  const uint32_t nc = (len + 15u) >> 4;
   unsigned long long h = mixk(((unsigned long long)issuer << 32 | key2) + 0x9e3779b97f4a7c15ull * (kind + 1u));
   h = mixk(h ^ len);
-  for (uint32_t k = 0; k < nw; k++) h = mixk(h ^ ((unsigned long long)meta_word(p, len, k) + 0x9e3779b97f4a7c15ull * (k + 2u)));
+  for (uint32_t k = 0; k < nc; k++) {
+    const uint4 c = meta_chunk(p, len, k);
+    h = mixk(h ^ (((unsigned long long)c.y << 32 | c.x) + 0x9e3779b97f4a7c15ull * (2u * k + 2u)));
+    h = mixk(h ^ (((unsigned long long)c.w << 32 | c.z) + 0x9e3779b97f4a7c15ull * (2u * k + 3u)));
+  }
   if (h == 0ull) h = 1ull;
   const unsigned long long w2 = ((unsigned long long)issuer << 32) | key2;
   uint64_t j = h & a.mask;
   uint64_t probes = 0;
   for (;;) {
     MetaSlot* sl = a.slots + j;
-    unsigned long long w0 = ld_agent(&sl->w[0]);
+    unsigned long long w0 = ld_wave(&sl->w[0]);  // a stale 0 only sends us to the CAS, which tells the truth
     if (w0 == 0ull) {
       const unsigned long long old = atomicCAS(&sl->w[0], 0ull, h);
       if (old == 0ull) {  // claimed: copy the bytes, publish
-        const unsigned long long need = ((unsigned long long)len + 7ull) & ~7ull;
+        const unsigned long long need = (unsigned long long)nc * 16ull;
         unsigned long long at = need ? atomicAdd(&a.counters[0], need) : 0ull;
         uint32_t pk = kind;
         if (at + need > a.arena_cap) {  // arena exhausted: a dead slot (never equal to anything); always "new"
@@ -1748,10 +1821,15 @@ __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, ui
           pk = MK_HOST;
           at = 0;
         } else {
-          uint32_t* dst = (uint32_t*)(a.arena + at);
-          for (uint32_t k = 0; k < nw; k++) __hip_atomic_store(dst + k, meta_word(p, len, k), __ATOMIC_RELAXED, AGENT);
+          unsigned long long* dst = (unsigned long long*)(a.arena + at);
+          for (uint32_t k = 0; k < nc; k++) {
+            const uint4 c = meta_chunk(p, len, k);
+            st_agent(dst + 2 * k, (unsigned long long)c.y << 32 | c.x);
+            st_agent(dst + 2 * k + 1, (unsigned long long)c.w << 32 | c.z);
+          }
         }
         st_agent(&sl->w[2], w2);
+        st_agent(&sl->w[3], (unsigned long long)a.epoch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         st_agent(&sl->w[1], META_VALID | ((unsigned long long)pk << 60) | ((unsigned long long)len << 40) | (at >> 3));
         return true;
@@ -1759,13 +1837,30 @@ __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, ui
       w0 = old;
     }
     if (w0 == h) {
-      const unsigned long long m = ld_agent(&sl->w[1]);
-      if (!(m & META_VALID)) continue;  // the claimer has not published yet: poll again (as table_upsert does)
-      bool eq = ((m >> 60) & 3ull) == kind && ((m >> 40) & 0xfffffull) == len && ld_agent(&sl->w[2]) == w2;
+      unsigned long long m = ld_wave(&sl->w[1]);
+      const unsigned long long ep = ld_wave(&sl->w[3]);
+      const bool settled = (m & META_VALID) && ep != 0ull && ep < a.epoch;  // published by an earlier launch: immutable
+      if (!settled) {
+        m = ld_agent(&sl->w[1]);
+        if (!(m & META_VALID)) continue;  // the claimer has not published yet: poll again (as table_upsert does)
+      }
+      bool eq = ((m >> 60) & 3ull) == kind && ((m >> 40) & 0xfffffull) == len &&
+                (settled ? ld_wave(&sl->w[2]) : ld_agent(&sl->w[2])) == w2;
       if (eq) {
-        const uint32_t* src = (const uint32_t*)(a.arena + ((m & 0xffffffffffull) << 3));
-        for (uint32_t k = 0; (k < nw) & eq; k++)
-          eq = __hip_atomic_load(src + k, __ATOMIC_RELAXED, AGENT) == meta_word(p, len, k);
+        const unsigned long long* src = (const unsigned long long*)(a.arena + ((m & 0xffffffffffull) << 3));
+        for (uint32_t k = 0; (k < nc) & eq; k++) {
+          const uint4 c = meta_chunk(p, len, k);
+          unsigned long long s0, s1;
+          if (settled) {
+            const uint4 v = *(const uint4*)(src + 2 * k);  // immutable: plain 16-byte load
+            s0 = (unsigned long long)v.y << 32 | v.x;
+            s1 = (unsigned long long)v.w << 32 | v.z;
+          } else {
+            s0 = ld_agent(src + 2 * k);
+            s1 = ld_agent(src + 2 * k + 1);
+          }
+          eq = s0 == ((unsigned long long)c.y << 32 | c.x) && s1 == ((unsigned long long)c.w << 32 | c.z);
+        }
       }
       if (eq) return false;
     }
@@ -1797,57 +1892,129 @@ __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
   // knownExpDates → seenExpDateBefore (issuermetadata.go:96-108)
   if (meta_upsert(a, MK_EXPDATE, canon, (uint32_t)exp_hour, cert, 0)) meta_emit(a, i, MK_EXPDATE, iss, exp_hour, 0, 0);
   bool host = ml.x == META_HOST || ml.y == META_HOST || ml.x == META_NONE;
-  // knownIssuerDNs (:97,:130-135): keyed by the Name's DER bytes (Issuer.String() is a function of them)
+  uint32_t dn_off = 0, dn_len = 0;
   if (!host) {
-    const uint32_t off = ml.x & 0xffffu, len = ml.x >> 16;
-    if (len > META_MAX_BYTES || off + len > L) host = true;
-    else if (meta_upsert(a, MK_DN, canon, 0, cert + off, len)) meta_emit(a, i, MK_DN, iss, exp_hour, off, len);
+    dn_off = ml.x & 0xffffu;
+    dn_len = ml.x >> 16;
+    host = dn_len > META_MAX_BYTES || dn_off + dn_len > L;
   }
   // knownCrlDPs (:111-127): CRLDistributionPoints ::= SEQUENCE OF DistributionPoint { [0] { [0] GeneralNames { [6] URI }}}
+  // One validating pass collects the URI ranges (a malformed value yields NO URIs, as the oracle defines; more than
+  // META_MAX_URIS → host), then the memo is consulted.
   if (!host && ml.y != META_NONE) {
-    GlobalReader g{(const uint32_t*)a.payload, lo};
+    ByteReader g{cert};
     const uint32_t s = ml.y & 0xffffu, e = s + (ml.y >> 16);
     bool ok = e <= L;
     uint32_t tag, cs, ce;
     rd_hdr(g, L, s, e, ok, tag, cs, ce);
     ok = ok && tag == 0x30u && ce == e;
-    // two passes over the same structure: validate everything first (a malformed value yields NO URIs, as the
-    // oracle defines), then upsert
-    for (int pass = 0; pass < 2 && ok; pass++) {
-      uint32_t p = cs;
-      while (ok && p < e) {
-        uint32_t t1, f, f_end;
-        rd_hdr(g, L, p, e, ok, t1, f, f_end);
-        ok = ok && t1 == 0x30u;
-        while (ok && f < f_end) {
-          uint32_t t2, n, n_end;
-          rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
-          if (ok && t2 == 0xa0u) {
-            while (ok && n < n_end) {
-              uint32_t t3, q, q_end;
-              rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
-              if (ok && t3 == 0xa0u) {
-                while (ok && q < q_end) {
-                  uint32_t t4, u, u_end;
-                  rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
-                  if (ok && t4 == 0x86u && pass == 1) {
-                    if (u_end - u > META_MAX_BYTES) host = true;
-                    else if (meta_upsert(a, MK_CRL, canon, 0, cert + u, u_end - u))
-                      meta_emit(a, i, MK_CRL, iss, exp_hour, u, u_end - u);
+    uint32_t uo[META_MAX_URIS], ul[META_MAX_URIS], nu = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < META_MAX_URIS; k++) uo[k] = ul[k] = 0;
+    uint32_t p = cs;
+    while (ok && p < e) {
+      uint32_t t1, f, f_end;
+      rd_hdr(g, L, p, e, ok, t1, f, f_end);
+      ok = ok && t1 == 0x30u;
+      while (ok && f < f_end) {
+        uint32_t t2, n, n_end;
+        rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
+        if (ok && t2 == 0xa0u) {
+          while (ok && n < n_end) {
+            uint32_t t3, q, q_end;
+            rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
+            if (ok && t3 == 0xa0u) {
+              while (ok && q < q_end) {
+                uint32_t t4, u, u_end;
+                rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
+                if (ok && t4 == 0x86u) {
+                  if (u_end - u > META_MAX_BYTES || nu >= META_MAX_URIS) host = true;
+#pragma unroll
+                  for (uint32_t k = 0; k < META_MAX_URIS; k++) {  // register array: no dynamic indexing
+                    uo[k] = k == nu ? u : uo[k];
+                    ul[k] = k == nu ? u_end - u : ul[k];
                   }
-                  q = u_end;
+                  nu++;
                 }
+                q = u_end;
               }
-              n = q_end;
             }
+            n = q_end;
           }
-          f = n_end;
         }
-        p = f_end;
+        f = n_end;
       }
+      p = f_end;
+    }
+    if (ok && !host) {
+#pragma unroll
+      for (uint32_t k = 0; k < META_MAX_URIS; k++)
+        if (k < nu && meta_upsert(a, MK_CRL, canon, 0, cert + uo[k], ul[k])) meta_emit(a, i, MK_CRL, iss, exp_hour, uo[k], ul[k]);
     }
   }
+  // knownIssuerDNs (:97,:130-135): keyed by the Name's DER bytes (Issuer.String() is a function of them)
+  if (!host && meta_upsert(a, MK_DN, canon, 0, cert + dn_off, dn_len)) meta_emit(a, i, MK_DN, iss, exp_hour, dn_off, dn_len);
   if (host) meta_emit(a, i, MK_HOST, iss, exp_hour, 0, L);
+}
+
+// ------------------------------------------------------------------ whole-certificate SHA-256 (auxiliary)
+// NOT on the reference's path — it never hashes a leaf certificate (the only SHA-256 is Issuer.ID's,
+// storage/types.go:155-159).  This is the kernel BASELINE.json's north_star names literally ("one-cert-per-lane
+// SHA-256 with round constants in LDS"): the fingerprint CT tooling identifies certificates by.  VALU-bound
+// (≈2 000 instructions per 64-byte block), not HBM-bound: reported against its own roofline.
+// Full blocks are fetched as four unaligned 16-byte loads per lane; the padded tail goes through the byte path.
+__global__ void __launch_bounds__(256) k_fingerprint(const uint8_t* payload, const uint64_t* offsets,
+                                                     const uint64_t* ends, uint64_t n, uint32_t* digests) {
+  __shared__ uint32_t kc[64];
+  if (threadIdx.x < 64) kc[threadIdx.x] = K256[threadIdx.x];
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t lo, hi;
+  cert_range(offsets, ends, i, lo, hi);
+  const uint64_t len64 = hi - lo;
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  const uint8_t* p = payload + lo;
+  const uint64_t full = len64 >> 6;
+  for (uint64_t b = 0; b < full; b++) {
+    uint32_t w[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const U16 v = *(const U16*)(p + b * 64 + q * 16);
+      w[4 * q] = __builtin_bswap32(v.a); w[4 * q + 1] = __builtin_bswap32(v.b);
+      w[4 * q + 2] = __builtin_bswap32(v.c); w[4 * q + 3] = __builtin_bswap32(v.d);
+    }
+    sha256_compress(h, w, kc);
+  }
+  // tail: 0..63 message bytes, 0x80, zeros, 64-bit bit length — one or two blocks
+  const uint32_t rem = (uint32_t)(len64 & 63u);
+  const uint32_t nt = rem + 9 > 64 ? 2u : 1u;
+  const uint8_t* t = p + full * 64;
+  for (uint32_t b = 0; b < nt; b++) {
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t pos = b * 64 + k * 4;
+      uint32_t v = 0;
+      if (pos + 4 <= rem) {
+        v = __builtin_bswap32(((const U4*)(t + pos))->a);
+      } else if (pos <= rem) {
+        const uint32_t r = rem - pos;  // 0..3 message bytes in this word
+        const uint32_t raw = r ? ((const U4*)(t + pos))->a : 0u;  // ≤ 3 bytes past the certificate: CTMR_PAYLOAD_PAD
+        const uint32_t m = r ? (raw & (0xffffffffu >> (8 * (4 - r)))) : 0u;
+        v = __builtin_bswap32(m | (0x80u << (8 * r)));
+      }
+      w[k] = v;
+    }
+    if (b == nt - 1) {
+      w[14] = (uint32_t)((len64 * 8ull) >> 32);
+      w[15] = (uint32_t)(len64 * 8ull);
+    }
+    sha256_compress(h, w, kc);
+  }
+  uint4* out = (uint4*)(digests + i * 8);  // big-endian digest bytes
+  out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+  out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
 }
 
 // ------------------------------------------------------------------ RemoteCache point ops

@@ -269,6 +269,15 @@ class Engine:
     def meta_reset(self):
         self._ck(self._lib.ctmr_meta_reset(self._h))
 
+    # ---- whole-certificate SHA-256 (auxiliary: not on the reference's path)
+    def fingerprint_device(self, d_payload, d_offsets, d_ends, n, d_digests) -> float:
+        """n × 32-byte SHA-256 digests of the certificates into d_digests; returns the kernel time in ms."""
+        ms = C.c_float(0)
+        self._ck(self._lib.ctmr_fingerprint_device(self._h, C.c_void_p(d_payload), C.c_void_p(d_offsets),
+                                                   C.c_void_p(d_ends) if d_ends else None, n, C.c_void_p(d_digests),
+                                                   C.byref(ms)))
+        return ms.value
+
     # ---- PEM write-back (N1): pem.EncodeToMemory of the newly unknown certificates, on the GPU
     def pem_new(self):
         """PEM blocks (bytes) of every WAS_UNKNOWN entry of the last map_batch(), ascending entry order."""

@@ -84,10 +84,12 @@ typedef struct {
   uint32_t max_issuers;       /* 0 = 65536 */
   uint32_t certs_per_tile;    /* map-kernel tuning; 0 = default */
   uint32_t lds_tile_bytes;    /* map-kernel tuning; 0 = default */
-  uint32_t map_variant;       /* 0 = default (14); DESIGN.md §5: 1 = whole-cert LDS tile, 2 = direct global,
+  uint32_t map_variant;       /* 0 = default (15); DESIGN.md §5: 1 = whole-cert LDS tile, 2 = direct global,
                                  3/4/5/6 = per-lane 256/128/192/224-B LDS window, 7-9 = window + pinned tail,
                                  10-12 = line-trimmed windows, 13 = 256-B window with wave-cooperative fills,
-                                 14 = 13 fused with pass 1 of the known-certificate insert */
+                                 14 = 13 fused with pass 1 of the known-certificate insert,
+                                 15 = 14 with window-only reads (no per-access global fallback; a certificate whose
+                                      walk leaves the window is repeated with the exact global reader) */
   uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
   uint32_t collect_meta;      /* 1 = the map also records where each certificate's issuer Name and
                                  cRLDistributionPoints lie (8 B per entry) so that ctmr_meta_new* can run */
@@ -309,6 +311,14 @@ int ctmr_meta_new_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_
 int ctmr_meta_new(ctmr_engine* e, ctmr_meta_item* items, uint64_t items_cap, uint8_t* bytes, size_t bytes_cap,
                   uint64_t* n_items, size_t* bytes_need);
 int ctmr_meta_reset(ctmr_engine* e);
+
+/* ---- whole-certificate SHA-256 fingerprints (auxiliary; NOT on the reference's path, which never hashes a leaf —
+ *      SURVEY.md D2; this is the one-certificate-per-lane SHA-256 kernel BASELINE.json's north_star names).
+ *      d_digests receives n × 32 bytes (the digest as crypto/sha256.Sum256 prints it); certificate i is
+ *      [d_offsets[i], d_offsets[i+1]) of d_payload, or [d_offsets[i], d_ends[i]) when d_ends != NULL (entry view).
+ *      VALU-bound, not HBM-bound: priced against its own roofline in DESIGN.md §5. ---- */
+int ctmr_fingerprint_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                            const uint64_t* d_ends, uint64_t n, uint8_t* d_digests, float* ms);
 
 /* ---- benchmark / test input generator (SURVEY.md §8(d) synthetic CT batch); not part of the
  *      reference's surface.  Deterministic in (seed, index); host and device emit identical bytes. */

@@ -10,7 +10,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format cs
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c -d $OUT/$c -o pmc --output-format csv -- $CMD --no-cpu > $OUT/$c.log 2>&1
 done
-python $R/scripts/make_traffic.py $OUT $E ${V/#0/14} > $OUT/traffic.json 2> $OUT/traffic.err
+python $R/scripts/make_traffic.py $OUT $E ${V/#0/15} > $OUT/traffic.json 2> $OUT/traffic.err
 python $R/scripts/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -size +1M -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete
 timeout 600 $CMD --traffic-file $OUT/traffic.json > $OUT/bench.json 2> $OUT/bench.err

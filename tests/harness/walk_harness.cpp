@@ -13,6 +13,7 @@ struct PaddedReader {
     memcpy(&v, p + pos, 4);
     return v;
   }
+  uint32_t ldg(uint32_t pos) const { return ld4(pos); }
   void touch(uint32_t, uint32_t) const {}
   void touch_tail(uint32_t, uint32_t) const {}
 };

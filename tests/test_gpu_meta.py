@@ -44,7 +44,8 @@ def expected_first_sightings(certs, issuer_canon, new_idx, exp_hours):
         assert meta is not None
         name, uris, m = meta
         c = issuer_canon[i]
-        host = m.n_crl_ext > 1 or len(name) > 4096 or any(len(u) > 4096 for u in uris) or len(certs[i]) > 0xfffe
+        host = (m.n_crl_ext > 1 or len(name) > 4096 or any(len(u) > 4096 for u in uris) or m.n_crl > 4
+                or len(certs[i]) > 0xfffe)
         items = [(N.MK_EXPDATE, c, int(exp_hours[i]), b"")]
         if host:
             out.add((N.MK_HOST, i))
@@ -119,8 +120,11 @@ def test_crl_and_dn_edge_cases():
         D.cert(serial=b"\x08", issuer=n1),                                                                           # no extensions
         D.cert(serial=b"\x09", issuer=n1, exts=[dp_ext(dp(uri(b"")))]),                                              # empty URI
         D.cert(serial=b"\x0a", issuer=n1, exts=[dp_ext(dp(uri(b"u" * 300)))]),
+        D.cert(serial=b"\x0b", issuer=n2, exts=[dp_ext(dp(*[uri(b"http://many.example/%d" % k) for k in range(5)]))]),  # 5 URIs → host
+        D.cert(serial=b"\x0c", issuer=n1, exts=[dp_ext(dp(uri(b"http://a.example/" + b"y" * 5000)))]),                 # 5 KB URI → host
+        D.cert(serial=b"\x0d", issuer=n1, exts=[dp_ext(dp(*[uri(b"http://four.example/%d" % k) for k in range(4)]))]),
     ]
-    idx = [0, 0, 0, 1, 0, 0, 0, 1, 0, 1]
+    idx = [0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 0, 0]
     eng = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10, collect_meta=True)
     eng.add_issuers([iss_cert, other])
     eng.set_filter(b"", True, 0)
@@ -129,7 +133,8 @@ def test_crl_and_dn_edge_cases():
     exp = expected_first_sightings(certs, idx, list(range(len(certs))), res.records["exp_hour"])
     got = got_first_sightings(eng, eng.meta_new())
     assert got == exp
-    assert (N.MK_HOST, 5) in got and (N.MK_HOST, 6) in got
+    assert {(N.MK_HOST, 5), (N.MK_HOST, 6), (N.MK_HOST, 10), (N.MK_HOST, 11)} <= got
+    assert (N.MK_CRL, 0, 0, b"http://four.example/3") in got
     assert (N.MK_CRL, 0, 0, u2) in got and (N.MK_CRL, 0, 0, ldap) in got and (N.MK_CRL, 0, 0, b"") in got
     assert not any(k[0] == N.MK_CRL and k[3].startswith(b"\x86") for k in got)
     eng.close()

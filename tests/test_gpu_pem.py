@@ -59,3 +59,34 @@ def test_pem_device_every_length_and_padding_case():
         eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), len(idx), d_pem.data_ptr(),
                               total - 1, d_po.data_ptr())
     eng.close()
+
+
+def test_fingerprint_matches_hashlib():
+    """Auxiliary whole-certificate SHA-256 (not on the reference's path): every length 0..300 covers
+    all block/padding cases (55/56/63/64-byte boundaries), plus typical DER sizes; packed and ranged addressing."""
+    import hashlib
+    import torch
+    rng = np.random.default_rng(9)
+    lens = list(range(0, 301)) + [717, 1297, 1523, 1536, 2000, 4095, 70000]
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+    offs = np.zeros(len(blobs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in blobs])
+    payload = np.frombuffer(b"".join(blobs) + bytes(64), np.uint8)
+    dev = torch.device("cuda:0")
+    d_pay = torch.from_numpy(payload.copy()).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_dg = torch.zeros(len(blobs) * 32, dtype=torch.uint8, device=dev)
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+    eng.fingerprint_device(d_pay.data_ptr(), d_off.data_ptr(), 0, len(blobs), d_dg.data_ptr())
+    got = d_dg.cpu().numpy().tobytes()
+    for k, b in enumerate(blobs):
+        assert got[32 * k:32 * k + 32] == hashlib.sha256(b).digest(), lens[k]
+    # ranged form: [start, end) pairs, here every certificate without its last byte
+    d_start = torch.from_numpy(offs[:-1].astype(np.int64)).to(dev)
+    ends = np.maximum(offs[1:].astype(np.int64) - 1, offs[:-1].astype(np.int64))
+    d_end = torch.from_numpy(ends).to(dev)
+    eng.fingerprint_device(d_pay.data_ptr(), d_start.data_ptr(), d_end.data_ptr(), len(blobs), d_dg.data_ptr())
+    got = d_dg.cpu().numpy().tobytes()
+    for k, b in enumerate(blobs):
+        assert got[32 * k:32 * k + 32] == hashlib.sha256(b[:-1]).digest(), lens[k]
+    eng.close()
