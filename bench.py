@@ -168,6 +168,11 @@ def main():
                     help="BASELINE config 5 on one GPU: stream TOTAL entries with 10%% duplicates through one engine in "
                          "waves of --entries (default 50M), the known-certificate table persisting across waves; "
                          "checks n_new / n_dup of every wave against the generator's duplicate structure")
+    ap.add_argument("--global-dedup", action="store_true",
+                    help="BASELINE config 5's cross-GPU form: every step runs the owner-computes key exchange "
+                         "(distributed.run_global_dedup: export → all-to-all over RCCL → owner insert → flags back → apply) "
+                         "instead of the shard-local reduce; at N=1 the exchange is local and this measures the three "
+                         "exchange-mode kernels")
     ap.add_argument("--raw", action="store_true",
                     help="feed raw get-entries blobs (leaf_input ‖ extra_data, ≈3.06 KB per entry): adds the "
                          "LogEntryFromLeaf decode and the Chain[0] → issuer match in front of the map (SURVEY §8(f) N2); "
@@ -259,6 +264,10 @@ def main():
     t_gen = time.perf_counter() - t_gen
     counts_dev = torch.zeros(len(issuers), dtype=torch.int64, device=dev)
 
+    gd_rank = None
+    if args.global_dedup:
+        from ct_mapreduce_amd.distributed import GlobalDedupRank, run_global_dedup
+        gd_rank = GlobalDedupRank(eng, rank, world, dev)
     dstats = []
     meta_ms, meta_items = [], []
     d_items = torch.empty(32 * (1 << 22), dtype=torch.uint8, device=dev) if args.meta else None
@@ -269,6 +278,9 @@ def main():
             st, ds = eng.map_entries_device(d_pay.data_ptr(), d_off.data_ptr(), E, d_rec.data_ptr(), d_new.data_ptr(),
                                             d_iss.data_ptr())
             dstats.append(ds)
+        elif gd_rank is not None:
+            st = run_global_dedup(gd_rank, d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
+                                  d_rec.data_ptr(), d_new.data_ptr())
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
                                       E, d_rec.data_ptr(), d_new.data_ptr())
@@ -320,6 +332,8 @@ def main():
             pass
 
     n_total = E * world
+    if gd_rank is not None:     # exchange mode has no per-kernel events: the map time is not separable
+        ms_map = [dt / args.steps * 1e3]
     value = n_total * args.steps / dt
     alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E     # raw mode: payload_bytes is the whole blob — see "raw"
     if (args.variant or DEFAULT_VARIANT) in FUSED:
@@ -350,6 +364,10 @@ def main():
                       "compact": stats.ms_compact, "total": stats.ms_total},
         "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},
     }
+    if gd_rank is not None:
+        out["config"]["parallelism"] = f"log-index shards x{world} + owner-computes key exchange (global dedup)"
+        out["roofline"]["kernel"] = "whole exchange-mode step (export + all-to-all + owner insert + apply)"
+        out["roofline"]["note"] = "avg_launch_ms is the wall time of the whole step, not one kernel"
     if args.fingerprint and not args.raw:
         d_dg = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         fp_ms = [eng.fingerprint_device(d_pay.data_ptr(), d_off.data_ptr(), 0, E, d_dg.data_ptr()) for _ in range(3)]

@@ -131,6 +131,11 @@ def run_global_dedup(rank_obj: GlobalDedupRank, d_payload, d_offsets, d_iss, d_e
     recv = torch.empty(max(sum(recv_counts), 1) * K, dtype=torch.uint8, device=dev)
     ops, off = [], 0
     for s in range(world):                      # exchange A: key partitions
+        if s == rank:                           # own partition: a local copy, no self send/recv
+            if recv_counts[s]:
+                recv[off * K:(off + recv_counts[s]) * K].copy_(rank_obj.partition(s))
+            off += recv_counts[s]
+            continue
         if recv_counts[s]:
             ops.append(dist.P2POp(dist.irecv, recv[off * K:(off + recv_counts[s]) * K], s))
         off += recv_counts[s]
@@ -142,6 +147,11 @@ def run_global_dedup(rank_obj: GlobalDedupRank, d_payload, d_offsets, d_iss, d_e
     flags_mine = torch.zeros(max(sum(send_counts), 1), dtype=torch.uint8, device=dev)
     ops, off = [], 0
     for s in range(world):                      # exchange B: flags back, export order = owner-major
+        if s == rank:
+            if send_counts[s]:
+                flags_mine[off:off + send_counts[s]].copy_(rank_obj.flags_for(s))
+            off += send_counts[s]
+            continue
         if send_counts[s]:
             ops.append(dist.P2POp(dist.irecv, flags_mine[off:off + send_counts[s]], s))
         off += send_counts[s]
