@@ -168,6 +168,9 @@ def main():
                     help="BASELINE config 5 on one GPU: stream TOTAL entries with 10%% duplicates through one engine in "
                          "waves of --entries (default 50M), the known-certificate table persisting across waves; "
                          "checks n_new / n_dup of every wave against the generator's duplicate structure")
+    ap.add_argument("--pem", action="store_true",
+                    help="also time the PEM write-back kernels (k_pem_len + scan + k_pem_encode, SURVEY §8(f) N1) over "
+                         "the first 16M entries of the NEW list")
     ap.add_argument("--global-dedup", action="store_true",
                     help="BASELINE config 5's cross-GPU form: every step runs the owner-computes key exchange "
                          "(distributed.run_global_dedup: export → all-to-all over RCCL → owner insert → flags back → apply) "
@@ -364,6 +367,27 @@ def main():
                       "compact": stats.ms_compact, "total": stats.ms_total},
         "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},
     }
+    if args.pem and not args.raw:
+        m = min(int(stats.n_new), 16_000_000)
+        d_po = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        total = eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_new.data_ptr(), m, 0, 0, d_po.data_ptr())
+        d_pem = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+        t_p = []
+        for _ in range(3):
+            t0p = time.perf_counter()
+            eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_new.data_ptr(), m, d_pem.data_ptr(), total + 64,
+                                  d_po.data_ptr())
+            t_p.append(time.perf_counter() - t0p)
+        from oracle import oracle as orc
+        po = d_po[:3].cpu().numpy()
+        first = int(d_new[0].item())
+        o2 = d_off[first:first + 2].cpu().numpy()
+        der = d_pay[int(o2[0]):int(o2[1])].cpu().numpy().tobytes()
+        ok_pem = d_pem[int(po[0]):int(po[1])].cpu().numpy().tobytes() == orc.pem_encode(der)
+        in_bytes = int((d_off[d_new[:m] + 1] - d_off[d_new[:m]]).sum().item())
+        out["pem"] = {"certificates": m, "pem_bytes": int(total), "der_bytes": in_bytes, "ms_wall": min(t_p) * 1e3,
+                      "certs_per_s": m / min(t_p), "GBps_read_plus_written": (in_bytes + total) / min(t_p) / 1e9,
+                      "first_block_matches_oracle": bool(ok_pem)}
     if gd_rank is not None:
         out["config"]["parallelism"] = f"log-index shards x{world} + owner-computes key exchange (global dedup)"
         out["roofline"]["kernel"] = "whole exchange-mode step (export + all-to-all + owner insert + apply)"

@@ -1,0 +1,109 @@
+"""-m gpu: BASELINE.json's configs[1] and configs[2] at their full sizes.
+
+configs[1]  1 M synthetic ~1.5 KB certificates, single issuer, known-certificate dedup — bit-exact against the oracle on
+            every entry (the batch is generated in HBM and copied back for the CPU run).
+configs[2]  10 M certificates, 256 issuers, issuerCN prefix filter + per-issuer unique counts — too large for the
+            oracle inside a test, so checked through size-independent properties of the generator and of set insertion:
+            new ⇔ PASS ∧ first carrier of its key, per-issuer counts = histogram of the new entries, idempotent replay,
+            checksum of the NEW list.
+(configs[3]/[4] — 100 M-entry batch, 1 B-entry stream — run in bench.py / bench.py --stream with the same checks.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import synth, _native as N
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import synth_is_dup  # noqa: E402  (numpy restatement of the generator's duplicate structure)
+
+NOW = synth.BASE_TIME
+
+
+def device_batch(eng, cfg, first, n, dev):
+    d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    total = eng.synth_device(cfg, first, n, d_off.data_ptr(), 0, 0, 0, 0)
+    d_pay = torch.empty(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+    d_iss = torch.empty(n, dtype=torch.int32, device=dev)
+    d_et = torch.empty(n, dtype=torch.uint8, device=dev)
+    eng.synth_device(cfg, first, n, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_iss.data_ptr(), d_et.data_ptr())
+    return d_off, d_pay, d_iss, d_et, total
+
+
+def test_config1_one_million_single_issuer_bit_exact():
+    n, dev = 1_000_000, torch.device("cuda:0")
+    cfg = synth.config(seed=20260921 + 1, n_issuers=1, dup_permille=50)
+    issuers = synth.issuers(cfg)
+    eng = ctmr.Engine(device=0, table_slots=1 << 21, pair_slots=1 << 16)
+    eng.add_issuers(issuers)
+    eng.set_filter(b"", False, NOW)
+    d_off, d_pay, d_iss, d_et, total = device_batch(eng, cfg, 0, n, dev)
+    d_rec = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    d_new = torch.empty(n, dtype=torch.int64, device=dev)
+    st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
+                              d_rec.data_ptr(), d_new.data_ptr())
+    # the reference loop on the same bytes
+    o = orc.Engine(b"", False, NOW)
+    io = np.array([0, len(issuers[0])], np.uint64)
+    ost, ounk, oeh = o.batch(d_pay.cpu().numpy(), d_off.cpu().numpy().astype(np.uint64),
+                             d_iss.cpu().numpy().astype(np.uint32), np.frombuffer(issuers[0], np.uint8), io)
+    rec = d_rec.cpu().numpy().view(ctmr.engine.RECORD_DTYPE)
+    assert (rec["status"] == ost).all()
+    assert (((rec["flags"] & 2) != 0) == (ounk != 0)).all()
+    assert (rec["exp_hour"][ost != orc.ST_PARSE_ERROR] == oeh[ost != orc.ST_PARSE_ERROR]).all()
+    assert (d_new[:st.n_new].cpu().numpy() == np.nonzero(ounk)[0]).all()
+    assert st.n_new == int(ounk.sum()) == o.total_count() == eng.total_count()
+    assert int(eng.issuer_counts()[0]) == o.issuer_count(eng.issuer_id(0))
+    assert sorted(eng.keys(b"serials::*")) == [k for k in o.keys() if k.startswith(b"serials::")]
+    assert 0 < st.n_dup < st.n_new
+    eng.close()
+
+
+def test_config2_ten_million_256_issuers_properties():
+    n, dev = 10_000_000, torch.device("cuda:0")
+    cfg = synth.config(seed=20260921 + 2, n_issuers=256, zipf=1, dup_permille=100, ca_permille=10, expired_permille=10)
+    eng = ctmr.Engine(device=0, table_slots=1 << 25, pair_slots=1 << 22)
+    eng.add_issuers(synth.issuers(cfg))
+    eng.set_filter(b"Synth Issuer 0,Synth Issuer 1", False, NOW)        # passes issuers 000-199
+    d_off, d_pay, d_iss, d_et, total = device_batch(eng, cfg, 0, n, dev)
+    d_rec = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    d_new = torch.empty(n, dtype=torch.int64, device=dev)
+    st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
+                              d_rec.data_ptr(), d_new.data_ptr())
+    rec = d_rec.view(-1, 32)
+    status = rec[:, 0].cpu().numpy()
+    flags = rec[:, 1].cpu().numpy()
+    iss = d_iss.cpu().numpy()
+    # filter semantics: CN filter ⇔ issuer index ≥ 200 (unless an earlier filter fired), nothing fails to parse
+    assert (status != N.ST_PARSE_ERROR).all() and st.by_status[N.ST_PARSE_ERROR] == 0
+    cn = status == N.ST_FILTERED_CN
+    assert (iss[cn] >= 200).all() and (iss[status == N.ST_PASS] < 200).all()
+    # dedup: an entry is new ⇔ it reached Store and is the first carrier of its key (the generator re-emits an
+    # EARLIER entry's key exactly for the entries synth_is_dup marks)
+    dup = synth_is_dup(cfg.seed, 0, n, 100, np)
+    new = (flags & N.FL_WAS_UNKNOWN) != 0
+    assert (new == ((status == N.ST_PASS) & ~dup)).all()
+    assert st.n_new == int(new.sum()) and st.n_dup == int(((status == N.ST_PASS) & dup).sum())
+    new_idx = d_new[:st.n_new].cpu().numpy()
+    assert (new_idx == np.nonzero(new)[0]).all()                         # ascending, complete: checksum-free equality
+    # per-issuer unique counts (storage-statistics.go:44-53) = histogram of the new entries' issuers
+    counts = eng.issuer_counts().astype(np.int64)
+    assert (counts == np.bincount(iss[new], minlength=256)).all() and counts[200:].sum() == 0
+    assert eng.total_count() == st.n_new
+    # Σ SCARD over the keys of one issuer = its count (the statistics tool's own arithmetic)
+    k0 = [k for k in eng.keys(b"serials::*::" + eng.issuer_id(7).encode())]
+    assert sum(eng.set_cardinality(k) for k in k0) == int(counts[7])
+    # idempotence: replaying the batch finds every stored entry known
+    st2 = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
+                               d_rec.data_ptr(), d_new.data_ptr())
+    assert st2.n_new == 0 and st2.n_dup == int((status == N.ST_PASS).sum())
+    assert (eng.issuer_counts().astype(np.int64) == counts).all()
+    eng.close()
