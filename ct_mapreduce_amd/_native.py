@@ -75,6 +75,8 @@ SIGNATURES = {
     "ctmr_last_error": (C.c_char_p, [_P]),
     "ctmr_set_stream": (C.c_int, [_P, _P]),
     "ctmr_synchronize": (C.c_int, [_P]),
+    "ctmr_alloc_pinned": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "ctmr_free_pinned": (C.c_int, [_P, _P]),
     "ctmr_add_issuers": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ctmr_sha256": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p]),
     "ctmr_issuer_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),

@@ -155,11 +155,9 @@ struct ctmr_engine {
   size_t idb_cap = 0, idb_used = 0;
   uint64_t* d_idb_off = nullptr;
   uint32_t* d_idb_len = nullptr;
-  unsigned long long* d_idb_qh = nullptr;
-  uint32_t* d_idb_ht = nullptr;
+  unsigned long long* d_idb_ht = nullptr;  // (candidate hash & ~0xffffffff) | (issuer index + 1)
   uint32_t idb_ht_size = 0;
-  std::vector<uint32_t> h_idb_ht;
-  std::vector<unsigned long long> h_idb_qh;
+  std::vector<unsigned long long> h_idb_ht;
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
   unsigned long long* d_pend = nullptr;    // PEND_SLOTS claim words
   uint32_t* d_unreg = nullptr;             // UNREG_CAP entry indices
@@ -432,8 +430,7 @@ int ctmr_create(const ctmr_config* cfg, ctmr_engine** out) {
   e->idb_ht_size = (uint32_t)pow2_at_least((uint64_t)e->max_issuers * 4 < 1024 ? 1024 : (uint64_t)e->max_issuers * 4);
   CK(hipMalloc(&e->d_idb_off, (size_t)e->max_issuers * 8));
   CK(hipMalloc(&e->d_idb_len, (size_t)e->max_issuers * 4));
-  CK(hipMalloc(&e->d_idb_qh, (size_t)e->max_issuers * 8));
-  CK(hipMalloc(&e->d_idb_ht, (size_t)e->idb_ht_size * 4));
+  CK(hipMalloc(&e->d_idb_ht, (size_t)e->idb_ht_size * 8));
   CK(hipMalloc(&e->d_pend, (size_t)PEND_SLOTS * 8));
   CK(hipMalloc(&e->d_unreg, (size_t)UNREG_CAP * 4));
   CK(hipMalloc(&e->d_dcount, 64));
@@ -446,8 +443,8 @@ int ctmr_create(const ctmr_config* cfg, ctmr_engine** out) {
     CK(hipMemsetAsync(e->d_meta_slots, 0, e->n_meta_slots * sizeof(MetaSlot), e->stream));
     CK(hipMemsetAsync(e->d_mcount, 0, 64, e->stream));
   }
-  CK(hipMemsetAsync(e->d_idb_ht, 0, (size_t)e->idb_ht_size * 4, e->stream));
-  e->h_idb_ht.assign(e->idb_ht_size, 0u);
+  CK(hipMemsetAsync(e->d_idb_ht, 0, (size_t)e->idb_ht_size * 8, e->stream));
+  e->h_idb_ht.assign(e->idb_ht_size, 0ull);
   CK(hipMemsetAsync(e->table, 0, e->nslots * sizeof(Slot), e->stream));
   CK(hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
   CK(hipMemsetAsync(e->issuer_counts, 0, (size_t)e->max_issuers * 8, e->stream));
@@ -470,7 +467,7 @@ void ctmr_destroy(ctmr_engine* e) {
   (void)hipFree(e->table); (void)hipFree(e->pairs); (void)hipFree(e->issuer_counts);
   (void)hipFree(e->d_issuer_valid); (void)hipFree(e->d_canon); (void)hipFree(e->d_filter);
   (void)hipFree(e->d_stats); (void)hipFree(e->d_result); (void)hipFree(e->d_count);
-  (void)hipFree(e->d_idb_der); (void)hipFree(e->d_idb_off); (void)hipFree(e->d_idb_len); (void)hipFree(e->d_idb_qh);
+  (void)hipFree(e->d_idb_der); (void)hipFree(e->d_idb_off); (void)hipFree(e->d_idb_len);
   (void)hipFree(e->d_idb_ht); (void)hipFree(e->d_pend); (void)hipFree(e->d_unreg); (void)hipFree(e->d_dcount);
   (void)hipFree(e->d_meta_slots); (void)hipFree(e->d_meta_arena); (void)hipFree(e->d_mcount);
   for (auto p : e->d_scratch) if (p) (void)hipFree(p);
@@ -566,28 +563,41 @@ static int add_issuers_locked(ctmr_engine* e, const uint8_t* der, const uint64_t
       e->d_idb_der = nb;
       e->idb_cap = cap;
     }
-    e->h_idb_qh.resize(first + n);
     bool ht_dirty = false;
     for (uint32_t i = 0; i < n; i++) {
       const uint8_t* c = der + offsets[i];
       if (len[i]) HIPCHK(e, hipMemcpyAsync(e->d_idb_der + off[i], c, len[i], hipMemcpyHostToDevice, e->stream));
       const unsigned long long qh = cert_quick_hash(HostBytes{c}, 0, len[i]);
-      e->h_idb_qh[first + i] = qh;
       if (len[i] && e->der_to_idx.emplace(std::string((const char*)c, len[i]), first + i).second) {
         uint32_t j = (uint32_t)qh & (e->idb_ht_size - 1);
         while (e->h_idb_ht[j]) j = (j + 1) & (e->idb_ht_size - 1);
-        e->h_idb_ht[j] = first + i + 1;
+        e->h_idb_ht[j] = (qh & 0xffffffff00000000ull) | (unsigned long long)(first + i + 1);
         ht_dirty = true;
       }
     }
     e->idb_used = need;
     HIPCHK(e, hipMemcpyAsync(e->d_idb_off + first, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_idb_len + first, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_idb_qh + first, e->h_idb_qh.data() + first, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
     if (ht_dirty)
-      HIPCHK(e, hipMemcpyAsync(e->d_idb_ht, e->h_idb_ht.data(), (size_t)e->idb_ht_size * 4, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(e, hipMemcpyAsync(e->d_idb_ht, e->h_idb_ht.data(), (size_t)e->idb_ht_size * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
   }
+  return CTMR_OK;
+}
+
+int ctmr_alloc_pinned(ctmr_engine* e, size_t bytes, void** out) {
+  if (!e || !out) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  *out = nullptr;
+  HIPCHK(e, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return CTMR_OK;
+}
+
+int ctmr_free_pinned(ctmr_engine* e, void* p) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  if (p) HIPCHK(e, hipHostFree(p));
   return CTMR_OK;
 }
 
@@ -937,7 +947,7 @@ static int decode_locked(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* 
   uint64_t added = 0;
   unsigned long long hc[8];
   for (int round = 0;; round++) {
-    ma.idb_der = e->d_idb_der; ma.idb_off = e->d_idb_off; ma.idb_len = e->d_idb_len; ma.idb_qh = e->d_idb_qh;
+    ma.idb_der = e->d_idb_der; ma.idb_off = e->d_idb_off; ma.idb_len = e->d_idb_len;
     ma.ht = e->d_idb_ht;
     hipLaunchKernelGGL(k_chain0_match, dim3(blocks), dim3(256), 0, e->stream, ma);
     if (round == 0 && prof) HIPCHK(e, hipEventRecord(e->ev[7], e->stream));
@@ -1250,8 +1260,8 @@ static int pem_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   if (pem_bytes) *pem_bytes = total;
   if (!d_pem) return CTMR_OK;  // size query
   if (total > pem_cap) return fail(e, CTMR_E_RANGE, "PEM buffer too small: need %llu bytes", (unsigned long long)total);
-  hipLaunchKernelGGL(k_pem_encode, dim3((unsigned)n_idx), dim3(128), 0, e->stream, d_payload, d_offsets, d_ends, d_idx,
-                     (const uint64_t*)d_pem_offsets, d_pem);
+  hipLaunchKernelGGL(k_pem_encode, dim3((unsigned)((n_idx + PEM_PER_BLOCK - 1) / PEM_PER_BLOCK)), dim3(128), 0, e->stream,
+                     d_payload, d_offsets, d_ends, d_idx, n_idx, (const uint64_t*)d_pem_offsets, d_pem);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipGetLastError());
   return CTMR_OK;

@@ -1349,14 +1349,27 @@ __global__ void __launch_bounds__(1024) k_keys_resolve(const KeyRec* keys, uint6
 __global__ void __launch_bounds__(256) k_apply_flags(const KeyRec* sent, const uint8_t* flags, uint64_t n_keys,
                                                      ctmr_record* records, uint32_t* blk_new) {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= n_keys || !flags[k]) return;
-  const uint32_t src = sent[k].src;
-  uint8_t* fl = (uint8_t*)(records + src) + 1;
-  *fl = (uint8_t)(*fl | CTMR_FL_WAS_UNKNOWN);
-  atomicAdd(&blk_new[src >> 10], 1u);
+  const bool is_new = k < n_keys && flags[k] != 0;
+  uint32_t src = 0;
+  if (is_new) {
+    src = sent[k].src;
+    uint8_t* fl = (uint8_t*)(records + src) + 1;
+    *fl = (uint8_t)(*fl | CTMR_FL_WAS_UNKNOWN);
+  }
+  // per-1024-entry NEW counts for the compaction: keys of one partition are in ascending log order, so the lanes
+  // of a wave nearly always share one counter — one atomic per distinct counter per wave (the per-lane form spent
+  // 7.6 ms per 47 M keys serialising on single words)
+  unsigned long long todo = __ballot(is_new);
+  const uint32_t blk = src >> 10;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t b = __shfl(blk, leader);
+    const unsigned long long same = __ballot(is_new && blk == b) & todo;
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&blk_new[b], (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
 }
 
-// status histogram of a record array (exchange mode has no local resolve pass)
 __global__ void __launch_bounds__(1024) k_status_hist(const ctmr_record* records, uint64_t n, uint64_t nb,
                                                       DevStats* stats) {
   __shared__ uint32_t hist[CTMR_ST__COUNT + 1];
@@ -1407,6 +1420,7 @@ __global__ void __launch_bounds__(256) k_pem_len(const uint64_t* offsets, const 
   pem_off[r] = pem_len(hi - lo);
 }
 
+constexpr uint32_t PEM_PER_BLOCK = 8;
 struct __attribute__((packed, aligned(1))) U12 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };
 
@@ -1430,9 +1444,13 @@ __device__ __forceinline__ uint32_t b64_group(uint32_t w) {
 // adjacent lanes read adjacent 12-byte pieces and write adjacent 16-byte pieces (unaligned
 // dwordx3 / dwordx4 accesses; gfx950 runs with unaligned access mode).
 __global__ void __launch_bounds__(128) k_pem_encode(const uint8_t* payload, const uint64_t* offsets,
-                                                    const uint64_t* ends, const uint64_t* idx,
+                                                    const uint64_t* ends, const uint64_t* idx, uint64_t n_idx,
                                                     const uint64_t* pem_off, uint8_t* out) {
-  const uint64_t r = blockIdx.x;
+  // PEM_PER_BLOCK certificates per workgroup: a 1.5 KB certificate is exactly one task per thread, and one
+  // workgroup per certificate was bound by the workgroup launch rate (16 M workgroups in 20 ms)
+  for (uint32_t cc = 0; cc < PEM_PER_BLOCK; cc++) {
+  const uint64_t r = (uint64_t)blockIdx.x * PEM_PER_BLOCK + cc;
+  if (r >= n_idx) return;
   uint64_t lo, hi;
   cert_range(offsets, ends, idx[r], lo, hi);
   const uint64_t L = hi - lo;
@@ -1476,6 +1494,7 @@ __global__ void __launch_bounds__(128) k_pem_encode(const uint8_t* payload, cons
       }
       q[c] = (uint8_t)'\n';
     }
+  }
   }
 }
 
@@ -1566,8 +1585,7 @@ struct MatchArgs {
   const uint8_t* idb_der;       // registered certificates, each at a 16-byte aligned offset, zero padded
   const uint64_t* idb_off;      // per issuer: offset into idb_der
   const uint32_t* idb_len;
-  const unsigned long long* idb_qh;
-  const uint32_t* ht;           // open addressing: issuer index + 1, 0 = empty
+  const unsigned long long* ht; // open addressing: (candidate hash & ~0xffffffff) | (issuer index + 1), 0 = empty
   uint32_t ht_mask;
   uint32_t retry;
   // unregistered report
@@ -1621,19 +1639,27 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
   }
   bool searching = need;
   while (__ballot(searching)) {
-    // next candidate of every searching lane
+    // next candidate of every searching lane: one table word carries the issuer index and the upper half of its
+    // hash; length and store offset come with one more (parallel) pair of loads — no dependent load is left for
+    // the cooperative phase
     uint32_t cand = 0xffffffffu;
+    uint64_t db_off = 0;
     if (searching) {
       for (;;) {
-        const uint32_t v = a.ht[j];
-        if (v == 0u) {
+        const unsigned long long v = a.ht[j];
+        if (v == 0ull) {
           searching = false;
           break;
         }
         j = (j + 1u) & a.ht_mask;
-        if (a.idb_qh[v - 1u] == qh && a.idb_len[v - 1u] == len) {
-          cand = v - 1u;
-          break;
+        if ((v ^ qh) >> 32 == 0ull) {
+          const uint32_t c = (uint32_t)v - 1u;
+          const uint32_t clen = a.idb_len[c];
+          db_off = a.idb_off[c];
+          if (clen == len) {
+            cand = c;
+            break;
+          }
         }
       }
     }
@@ -1654,8 +1680,7 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
         if (src[u] < 0) continue;  // wave-uniform
         const uint64_t s_lo = __shfl(lo, src[u]);
         const uint32_t s_len = __shfl(len, src[u]);
-        const uint32_t s_c = __shfl(cand, src[u]);
-        const uint8_t* db = a.idb_der + a.idb_off[s_c];
+        const uint8_t* db = a.idb_der + __shfl(db_off, src[u]);
         const uint32_t off0 = lane * 16u, off1 = off0 + 1024u;
         if (off0 < s_len) {
           const U16 x = *(const U16*)(a.blob + s_lo + off0);  // ≤ 15 bytes past Chain[0]: CTMR_PAYLOAD_PAD
@@ -1769,14 +1794,11 @@ struct MetaArgs {
   uint32_t epoch;  // launch number (≥ 1): slots of earlier launches are immutable and read through the caches
 };
 
-// k-th 16-byte chunk of an item, bytes past its end zeroed (one unaligned dwordx4 load; ≤ 15 bytes past the item,
-// which lies inside a certificate inside the payload + CTMR_PAYLOAD_PAD).  Items are hashed and compared in these
-// chunks: the first version of this kernel used dwords and was bound by L2 REQUESTS (1.46 G for 18.8 M new
-// certificates, 76 % of its L1 accesses missing — profiles/r01/s4/pmc_meta_20m_dword_version.txt).
-__device__ __forceinline__ uint4 meta_chunk(const uint8_t* p, uint32_t len, uint32_t k) {
-  const U16 v = *(const U16*)(p + 16u * k);
-  const uint32_t rem = len - 16u * k;  // > 0
-  uint32_t w[4] = {v.a, v.b, v.c, v.d};
+// 16-byte chunks of an item, bytes past its end zeroed.  Items are hashed and compared in these chunks: the first
+// version of this kernel used dwords and was bound by L2 REQUESTS (1.46 G for 18.8 M new certificates, 76 % of its
+// L1 accesses missing — profiles/r01/s4/pmc_meta_20m_dword_version.txt).
+__device__ __forceinline__ uint4 mask_chunk(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rem) {
+  uint32_t w[4] = {w0, w1, w2, w3};
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const uint32_t have = rem > 4u * q ? rem - 4u * q : 0u;
@@ -1784,6 +1806,25 @@ __device__ __forceinline__ uint4 meta_chunk(const uint8_t* p, uint32_t len, uint
   }
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
+struct GlobalSrc {  // straight from the certificate in HBM: one unaligned dwordx4 load per chunk (≤ 15 bytes past the
+  const uint8_t* p; //  item, which lies inside a certificate inside the payload + CTMR_PAYLOAD_PAD)
+  uint32_t len;
+  __device__ __forceinline__ uint4 chunk(uint32_t k) const {
+    const U16 v = *(const U16*)(p + 16u * k);
+    return mask_chunk(v.a, v.b, v.c, v.d, len - 16u * k);
+  }
+};
+struct LdsSrc {  // from this lane's staging area in LDS, at any byte offset (5 dwords, 4 alignbytes)
+  const uint32_t* w;  // dword-aligned lane area
+  uint32_t off;       // byte offset of the item inside it
+  uint32_t len;
+  __device__ __forceinline__ uint4 chunk(uint32_t k) const {
+    const uint32_t at = off + 16u * k, i = at >> 2, sh = at & 3u;
+    const uint32_t d0 = w[i], d1 = w[i + 1], d2 = w[i + 2], d3 = w[i + 3], d4 = w[i + 4];
+    return mask_chunk(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                      __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh), len - 16u * k);
+  }
+};
 
 // Plain (cacheable) load the compiler may not merge or hoist: wavefront-scope atomic.  Used for memo slots of EARLIER
 // launches, which are immutable — the steady state, where the same few hundred DN/CRL slots are read by every new
@@ -1792,14 +1833,15 @@ __device__ __forceinline__ unsigned long long ld_wave(const unsigned long long* 
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-// true = first sighting of (kind, issuer, key2, bytes)
+// true = first sighting of (kind, issuer, key2, bytes); the bytes come through a chunk source
+template <class S>
 __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, uint32_t issuer, uint32_t key2,
-                                            const uint8_t* p, uint32_t len) {
+                                            const S& src, uint32_t len) {
   const uint32_t nc = (len + 15u) >> 4;
   unsigned long long h = mixk(((unsigned long long)issuer << 32 | key2) + 0x9e3779b97f4a7c15ull * (kind + 1u));
   h = mixk(h ^ len);
   for (uint32_t k = 0; k < nc; k++) {
-    const uint4 c = meta_chunk(p, len, k);
+    const uint4 c = src.chunk(k);
     h = mixk(h ^ (((unsigned long long)c.y << 32 | c.x) + 0x9e3779b97f4a7c15ull * (2u * k + 2u)));
     h = mixk(h ^ (((unsigned long long)c.w << 32 | c.z) + 0x9e3779b97f4a7c15ull * (2u * k + 3u)));
   }
@@ -1823,7 +1865,7 @@ __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, ui
         } else {
           unsigned long long* dst = (unsigned long long*)(a.arena + at);
           for (uint32_t k = 0; k < nc; k++) {
-            const uint4 c = meta_chunk(p, len, k);
+            const uint4 c = src.chunk(k);
             st_agent(dst + 2 * k, (unsigned long long)c.y << 32 | c.x);
             st_agent(dst + 2 * k + 1, (unsigned long long)c.w << 32 | c.z);
           }
@@ -1847,17 +1889,17 @@ __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, ui
       bool eq = ((m >> 60) & 3ull) == kind && ((m >> 40) & 0xfffffull) == len &&
                 (settled ? ld_wave(&sl->w[2]) : ld_agent(&sl->w[2])) == w2;
       if (eq) {
-        const unsigned long long* src = (const unsigned long long*)(a.arena + ((m & 0xffffffffffull) << 3));
+        const unsigned long long* asrc = (const unsigned long long*)(a.arena + ((m & 0xffffffffffull) << 3));
         for (uint32_t k = 0; (k < nc) & eq; k++) {
-          const uint4 c = meta_chunk(p, len, k);
+          const uint4 c = src.chunk(k);
           unsigned long long s0, s1;
           if (settled) {
-            const uint4 v = *(const uint4*)(src + 2 * k);  // immutable: plain 16-byte load
+            const uint4 v = *(const uint4*)(asrc + 2 * k);  // immutable: plain 16-byte load
             s0 = (unsigned long long)v.y << 32 | v.x;
             s1 = (unsigned long long)v.w << 32 | v.z;
           } else {
-            s0 = ld_agent(src + 2 * k);
-            s1 = ld_agent(src + 2 * k + 1);
+            s0 = ld_agent(asrc + 2 * k);
+            s1 = ld_agent(asrc + 2 * k + 1);
           }
           eq = s0 == ((unsigned long long)c.y << 32 | c.x) && s1 == ((unsigned long long)c.w << 32 | c.z);
         }
@@ -1877,7 +1919,68 @@ __device__ __forceinline__ void meta_emit(const MetaArgs& a, uint64_t entry, uin
   if (at < a.items_cap) a.items[at] = MetaItem{entry, kind, issuer_idx, exp_hour, off, len, 0u};
 }
 
+// Per-lane LDS staging: the issuer Name (≤ META_LDS_DN bytes) and the cRLDistributionPoints value (≤ META_LDS_CRL) of
+// the lane's certificate are fetched with up to 12 independent 16-byte loads issued together — ONE memory latency —
+// and everything after that (the DistributionPoint walk, hashing, comparing) reads LDS.  The dependent chain per
+// certificate drops from ≈35 global round trips to the three memo probes.  Longer items take the global path.
+constexpr uint32_t META_LDS_DN = 128, META_LDS_CRL = 64, META_LDS_STRIDE = META_LDS_DN + META_LDS_CRL + 16;
+
+struct LdsTlvReader {  // rd_hdr over the staged cRLDistributionPoints value: positions are certificate offsets
+  const uint32_t* w;   // lane area (dwords) of the value
+  uint32_t s;          // certificate offset of its first byte
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - s;  // callers stay within [s, e + 3]; the area has 16 bytes of slack
+    const uint32_t i = rel >> 2;
+    return __builtin_amdgcn_alignbyte(w[i + 1], w[i], rel & 3u);
+  }
+};
+
+// DistributionPoint walk (RFC 5280 §4.2.1.13) over [cs, e): collects up to META_MAX_URIS URI ranges (certificate
+// offsets); returns false when the value is malformed.  `host` is set when a URI is too long or there are too many.
+template <class R>
+__device__ __forceinline__ bool walk_crl_dps(const R& g, uint32_t L, uint32_t cs, uint32_t e, uint32_t uo[META_MAX_URIS],
+                                             uint32_t ul[META_MAX_URIS], uint32_t& nu, bool& host) {
+  bool ok = true;
+  uint32_t p = cs;
+  while (ok && p < e) {
+    uint32_t t1, f, f_end;
+    rd_hdr(g, L, p, e, ok, t1, f, f_end);
+    ok = ok && t1 == 0x30u;
+    while (ok && f < f_end) {
+      uint32_t t2, n, n_end;
+      rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
+      if (ok && t2 == 0xa0u) {
+        while (ok && n < n_end) {
+          uint32_t t3, q, q_end;
+          rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
+          if (ok && t3 == 0xa0u) {
+            while (ok && q < q_end) {
+              uint32_t t4, u, u_end;
+              rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
+              if (ok && t4 == 0x86u) {
+                if (u_end - u > META_MAX_BYTES || nu >= META_MAX_URIS) host = true;
+#pragma unroll
+                for (uint32_t k = 0; k < META_MAX_URIS; k++) {  // register array: no dynamic indexing
+                  uo[k] = k == nu ? u : uo[k];
+                  ul[k] = k == nu ? u_end - u : ul[k];
+                }
+                nu++;
+              }
+              q = u_end;
+            }
+          }
+          n = q_end;
+        }
+      }
+      f = n_end;
+    }
+    p = f_end;
+  }
+  return ok;
+}
+
 __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[256 * META_LDS_STRIDE];
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n_new) return;
   const uint64_t i = a.new_idx[r];
@@ -1889,71 +1992,76 @@ __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
   const uint32_t L = (uint32_t)(hi - lo);
   const uint8_t* cert = a.payload + lo;
   const uint2 ml = a.meta_loc[i];
-  // knownExpDates → seenExpDateBefore (issuermetadata.go:96-108)
-  if (meta_upsert(a, MK_EXPDATE, canon, (uint32_t)exp_hour, cert, 0)) meta_emit(a, i, MK_EXPDATE, iss, exp_hour, 0, 0);
   bool host = ml.x == META_HOST || ml.y == META_HOST || ml.x == META_NONE;
-  uint32_t dn_off = 0, dn_len = 0;
+  uint32_t dn_off = 0, dn_len = 0, cr_s = 0, cr_len = 0;
   if (!host) {
     dn_off = ml.x & 0xffffu;
     dn_len = ml.x >> 16;
     host = dn_len > META_MAX_BYTES || dn_off + dn_len > L;
+    if (ml.y != META_NONE) {
+      cr_s = ml.y & 0xffffu;
+      cr_len = ml.y >> 16;
+      host = host || cr_s + cr_len > L;
+    }
   }
+  // ---- stage: every load of this lane is in flight before the first one is needed
+  uint8_t* my = stage + threadIdx.x * META_LDS_STRIDE;
+  const bool dn_lds = !host && dn_len <= META_LDS_DN, cr_lds = !host && cr_len != 0u && cr_len <= META_LDS_CRL;
+  {
+    U16 d[META_LDS_DN / 16], c[META_LDS_CRL / 16];
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_DN / 16; k++)
+      if (dn_lds && 16u * k < dn_len) d[k] = *(const U16*)(cert + dn_off + 16u * k);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_CRL / 16; k++)
+      if (cr_lds && 16u * k < cr_len) c[k] = *(const U16*)(cert + cr_s + 16u * k);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_DN / 16; k++)
+      if (dn_lds && 16u * k < dn_len) *(uint4*)(my + 16u * k) = make_uint4(d[k].a, d[k].b, d[k].c, d[k].d);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_CRL / 16; k++)
+      if (cr_lds && 16u * k < cr_len) *(uint4*)(my + META_LDS_DN + 16u * k) = make_uint4(c[k].a, c[k].b, c[k].c, c[k].d);
+  }
+  // knownExpDates → seenExpDateBefore (issuermetadata.go:96-108): no bytes, probes while the loads fly
+  if (meta_upsert(a, MK_EXPDATE, canon, (uint32_t)exp_hour, GlobalSrc{cert, 0}, 0)) meta_emit(a, i, MK_EXPDATE, iss, exp_hour, 0, 0);
   // knownCrlDPs (:111-127): CRLDistributionPoints ::= SEQUENCE OF DistributionPoint { [0] { [0] GeneralNames { [6] URI }}}
   // One validating pass collects the URI ranges (a malformed value yields NO URIs, as the oracle defines; more than
   // META_MAX_URIS → host), then the memo is consulted.
-  if (!host && ml.y != META_NONE) {
-    ByteReader g{cert};
-    const uint32_t s = ml.y & 0xffffu, e = s + (ml.y >> 16);
-    bool ok = e <= L;
-    uint32_t tag, cs, ce;
-    rd_hdr(g, L, s, e, ok, tag, cs, ce);
-    ok = ok && tag == 0x30u && ce == e;
+  if (!host && cr_len != 0u) {
+    const uint32_t e = cr_s + cr_len;
     uint32_t uo[META_MAX_URIS], ul[META_MAX_URIS], nu = 0;
 #pragma unroll
     for (uint32_t k = 0; k < META_MAX_URIS; k++) uo[k] = ul[k] = 0;
-    uint32_t p = cs;
-    while (ok && p < e) {
-      uint32_t t1, f, f_end;
-      rd_hdr(g, L, p, e, ok, t1, f, f_end);
-      ok = ok && t1 == 0x30u;
-      while (ok && f < f_end) {
-        uint32_t t2, n, n_end;
-        rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
-        if (ok && t2 == 0xa0u) {
-          while (ok && n < n_end) {
-            uint32_t t3, q, q_end;
-            rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
-            if (ok && t3 == 0xa0u) {
-              while (ok && q < q_end) {
-                uint32_t t4, u, u_end;
-                rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
-                if (ok && t4 == 0x86u) {
-                  if (u_end - u > META_MAX_BYTES || nu >= META_MAX_URIS) host = true;
-#pragma unroll
-                  for (uint32_t k = 0; k < META_MAX_URIS; k++) {  // register array: no dynamic indexing
-                    uo[k] = k == nu ? u : uo[k];
-                    ul[k] = k == nu ? u_end - u : ul[k];
-                  }
-                  nu++;
-                }
-                q = u_end;
-              }
-            }
-            n = q_end;
-          }
-        }
-        f = n_end;
-      }
-      p = f_end;
+    bool ok = true;
+    uint32_t tag, cs, ce;
+    const uint32_t* cw = (const uint32_t*)(my + META_LDS_DN);
+    if (cr_lds) {
+      LdsTlvReader g{cw, cr_s};
+      rd_hdr(g, e, cr_s, e, ok, tag, cs, ce);  // L = e: reads clamp to the staged value, not to the certificate
+      ok = ok && tag == 0x30u && ce == e;
+      ok = ok && walk_crl_dps(g, e, cs, e, uo, ul, nu, host);
+    } else {
+      ByteReader g{cert};
+      rd_hdr(g, L, cr_s, e, ok, tag, cs, ce);
+      ok = ok && tag == 0x30u && ce == e;
+      ok = ok && walk_crl_dps(g, L, cs, e, uo, ul, nu, host);
     }
     if (ok && !host) {
 #pragma unroll
-      for (uint32_t k = 0; k < META_MAX_URIS; k++)
-        if (k < nu && meta_upsert(a, MK_CRL, canon, 0, cert + uo[k], ul[k])) meta_emit(a, i, MK_CRL, iss, exp_hour, uo[k], ul[k]);
+      for (uint32_t k = 0; k < META_MAX_URIS; k++) {
+        if (k >= nu) continue;
+        const bool first = cr_lds ? meta_upsert(a, MK_CRL, canon, 0, LdsSrc{cw, uo[k] - cr_s, ul[k]}, ul[k])
+                                  : meta_upsert(a, MK_CRL, canon, 0, GlobalSrc{cert + uo[k], ul[k]}, ul[k]);
+        if (first) meta_emit(a, i, MK_CRL, iss, exp_hour, uo[k], ul[k]);
+      }
     }
   }
   // knownIssuerDNs (:97,:130-135): keyed by the Name's DER bytes (Issuer.String() is a function of them)
-  if (!host && meta_upsert(a, MK_DN, canon, 0, cert + dn_off, dn_len)) meta_emit(a, i, MK_DN, iss, exp_hour, dn_off, dn_len);
+  if (!host) {
+    const bool first = dn_lds ? meta_upsert(a, MK_DN, canon, 0, LdsSrc{(const uint32_t*)my, 0u, dn_len}, dn_len)
+                              : meta_upsert(a, MK_DN, canon, 0, GlobalSrc{cert + dn_off, dn_len}, dn_len);
+    if (first) meta_emit(a, i, MK_DN, iss, exp_hour, dn_off, dn_len);
+  }
   if (host) meta_emit(a, i, MK_HOST, iss, exp_hour, 0, L);
 }
 

@@ -111,6 +111,7 @@ class Engine:
     # ---- lifecycle
     def close(self):
         if getattr(self, "_h", None):
+            self.free_pinned()
             self._lib.ctmr_destroy(self._h)
             self._h = None
 
@@ -133,6 +134,22 @@ class Engine:
 
     def synchronize(self):
         self._ck(self._lib.ctmr_synchronize(self._h))
+
+    # ---- page-locked host buffers for the host-buffer entry points
+    def pinned_array(self, nbytes):
+        """uint8 numpy array over hipHostMalloc memory (freed when the array's owner object is collected)."""
+        p = C.c_void_p()
+        self._ck(self._lib.ctmr_alloc_pinned(self._h, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        return arr
+
+    def free_pinned(self):
+        for p in getattr(self, "_pinned", []):
+            self._lib.ctmr_free_pinned(self._h, C.c_void_p(p))
+        self._pinned = []
 
     # ---- issuers / filter
     def add_issuers(self, certs):

@@ -126,6 +126,12 @@ const char* ctmr_last_error(const ctmr_engine* e);
 int ctmr_set_stream(ctmr_engine* e, void* hip_stream);
 int ctmr_synchronize(ctmr_engine* e);
 
+/* Page-locked host memory for the host-buffer entry points (ctmr_map_batch, ctmr_map_entries, ctmr_add_issuers):
+ * buffers obtained here are copied to HBM by DMA at full PCIe rate without the driver's bounce copy.  A cgo host
+ * fills them through unsafe.Slice; they are C memory, so the "no Go pointer is retained" rule is not involved. */
+int ctmr_alloc_pinned(ctmr_engine* e, size_t bytes, void** out);
+int ctmr_free_pinned(ctmr_engine* e, void* p);
+
 /* ---- issuer table: replaces x509.ParseCertificate(Chain[0]) + NewIssuer + Issuer.ID()
  *      (ct-fetch.go:221; storage/types.go:109-130,155-159).  Appends n issuer certificates
  *      (DER blob + n+1 offsets); *first_idx receives the index of the first one. ---- */
