@@ -19,6 +19,8 @@
 
 namespace ctmr {
 
+struct __attribute__((packed, aligned(1))) U16t { uint32_t a, b, c, d; };  // unaligned 16-byte access
+
 // ------------------------------------------------------------------ byte readers
 // 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
 struct LdsReader {
@@ -137,6 +139,11 @@ struct WinReaderC : WinReader<WCH> {
 template <int WCH>
 struct WinReaderS : WinReaderC<WCH> {
   mutable uint32_t miss;
+  // The 32 bytes behind the TBSCertificate (signatureAlgorithm, the signatureValue header, its pad octet), fetched
+  // by touch_tail() TOGETHER with the extension-block refill: the three ldg() reads at the end of the walk were
+  // three dependent, uncoalesced global round trips per wave; now they are register selects.
+  uint32_t tl[8];
+  uint32_t tl_pos;  // certificate offset of tl[0]'s first byte; 0x80000000 = not fetched (positions are < 2^31)
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     uint32_t rel = pos - (uint32_t)this->grel;
     constexpr uint32_t LAST = WinReader<WCH>::WBYTES - 8u;
@@ -144,6 +151,29 @@ struct WinReaderS : WinReaderC<WCH> {
     rel = rel > LAST ? LAST : rel;
     const uint32_t i = rel >> 2;
     return __builtin_amdgcn_alignbyte(this->win[i + 1], this->win[i], rel & 3u);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t tail) {
+    const uint64_t ta = this->base + tail;
+    const bool have = ta + 32u <= this->limit;
+    const uint8_t* tp = (const uint8_t*)this->g32 + (have ? ta : 0ull);
+    const U16t a = *(const U16t*)tp, b = *(const U16t*)(tp + 16);  // in flight with the refill below
+    WinReaderC<WCH>::touch_tail(pos, tail);
+    tl[0] = a.a; tl[1] = a.b; tl[2] = a.c; tl[3] = a.d;
+    tl[4] = b.a; tl[5] = b.b; tl[6] = b.c; tl[7] = b.d;
+    tl_pos = have ? tail : 0x80000000u;
+  }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {
+    const uint32_t off = pos - tl_pos;
+    const uint32_t wi = off >> 2;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 7; k++) {
+      lo = wi == k ? tl[k] : lo;
+      hi = wi == k ? tl[k + 1] : hi;
+    }
+    uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+    if (off > 27u) v = WinReader<WCH>::ldg(pos);  // a long AlgorithmIdentifier, or no prefetch: the real load
+    return v;
   }
 };
 
@@ -974,7 +1004,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   if (live) {
     if constexpr (STRICT) {
       WinReaderS<WCH> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
-                          (int32_t)(int64_t)(g_me - lo)}}, 0u};
+                          (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
       map_one(r, hi - lo, i, a, o0, o1);
       if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
         GlobalReader g{(const uint32_t*)a.payload, lo};
