@@ -41,12 +41,15 @@ __host__ __device__ inline unsigned long long mixk(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
   return z ^ (z >> 31);
 }
-// 64-bit hash of (meta, serial words)
+// 64-bit hash of (meta, serial words): three multiply-mix rounds (a 64-bit multiply is four quarter-rate 32-bit
+// multiplies on CDNA: the six-round version was ≈ 8 % of the map kernel's VALU time).  Equal keys always compare in
+// full, so the hash only has to spread; serial words are folded in rotated so that swapped words do not cancel.
+__host__ __device__ inline unsigned long long rotl64(unsigned long long x, int r) { return (x << r) | (x >> (64 - r)); }
 __host__ __device__ inline unsigned long long key_hash(unsigned long long meta,
                                                         const unsigned long long s[5]) {
   unsigned long long h = mixk(meta + 0x9e3779b97f4a7c15ull);
-#pragma unroll
-  for (int i = 0; i < 5; i++) h = mixk(h ^ (s[i] + 0x9e3779b97f4a7c15ull * (i + 2)));
+  h = mixk(h ^ s[0] ^ rotl64(s[1], 29) ^ 0x3c6ef372fe94f82bull);
+  h = mixk(h ^ s[2] ^ rotl64(s[3], 29) ^ rotl64(s[4], 47));
   return h;
 }
 __host__ __device__ inline uint32_t key_tag(unsigned long long h) {

@@ -51,6 +51,19 @@ struct FilterView {
   const uint32_t* words;       // piece bytes, zero padded to 4-byte multiples
 };
 
+// Readers whose ld4 is memory-safe at ANY position (the window-only reader clamps into its LDS window) declare
+// `static constexpr bool kNoClamp = true`; for all others a read position is clamped to the certificate length
+// first.  Either way a read at or past L returns bytes the checks around it never accept.
+template <class R>
+constexpr auto reader_no_clamp(int) -> decltype(R::kNoClamp, bool()) { return R::kNoClamp; }
+template <class R>
+constexpr bool reader_no_clamp(...) { return false; }
+template <class R>
+CTMR_HD uint32_t ldc(const R& r, uint32_t p, uint32_t L) {
+  if constexpr (reader_no_clamp<R>(0)) return r.ld4(p);
+  else return r.ld4(p < L ? p : L);
+}
+
 // certIsFilteredOut filter (3): strings.HasPrefix(Issuer.CommonName, piece) for some piece
 // (ct-fetch.go:57-69).  Pieces are wave-uniform, the CN bytes per lane.
 template <class R>
@@ -65,7 +78,7 @@ CTMR_HD bool cn_prefix_match(const R& r, uint32_t L, uint32_t cn_off, uint32_t c
       const uint32_t rem = pl - k;
       const uint32_t mask = rem >= 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - rem)));
       const uint32_t at = cn_off + k;
-      eq = ((r.ld4(at < L ? at : L) ^ pw[k >> 2]) & mask) == 0;
+      eq = ((ldc(r, at, L) ^ pw[k >> 2]) & mask) == 0;
     }
     if (eq) return true;
   }
@@ -84,38 +97,35 @@ CTMR_HD bool cn_prefix_match(const R& r, uint32_t L, uint32_t cn_off, uint32_t c
 template <class R>
 CTMR_HD void rd_hdr(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& tag,
                     uint32_t& cs, uint32_t& ce) {
-  const uint32_t w = r.ld4(p < L ? p : L);
+  const uint32_t w = ldc(r, p, L);
   tag = w & 0xffu;
-  const uint32_t b = (w >> 8) & 0xffu, b2 = (w >> 16) & 0xffu, b3 = w >> 24;
+  const uint32_t b = (w >> 8) & 0xffu;
   const uint32_t n = b & 0x7fu;
   const bool lng = b >= 0x80u;
-  uint32_t len = lng ? (n == 1 ? b2 : ((b2 << 8) | b3)) : b;
+  const uint32_t len2 = __builtin_bswap32(w) & 0xffffu;  // the two octets behind the length octet, big endian
+  const uint32_t len1 = len2 >> 8;
+  // short form | 0x81 vv (vv >= 0x80) | 0x82 hh ll (hh != 0): minimal, no leading zero.  For the long forms with
+  // one or two length octets "minimal" is one comparison: value >= 0x40 << n (0x80, 0x100).
+  uint32_t len = lng ? (n == 1u ? len1 : len2) : b;
   const uint32_t hl = lng ? 2u + n : 2u;
-  // short form | 0x81 vv (vv >= 0x80) | 0x82 hh ll (hh != 0): minimal, no leading zero
-  bool good = ((tag & 0x1fu) != 0x1fu) & (!lng | (n == 1 ? b2 >= 0x80u : b2 != 0u)) & (!lng | (n != 0u));
+  bool good = !lng | (((n - 1u) <= 1u) & (len >= (0x40u << (n & 3u))));
   if (lng & (n > 2u)) {  // > 64 KiB contents: rare
     const uint32_t q = p + 2u;
-    const uint32_t x = r.ld4(q < L ? q : L);  // the n length bytes, big endian
+    const uint32_t x = ldc(r, q, L);  // the n length bytes, big endian
     const uint32_t be = __builtin_bswap32(x);
-    len = n == 3 ? (be >> 8) : be;
-    good = good & (n <= 4u) & ((x & 0xffu) != 0u) & (len <= 0x7fffffffu);
+    len = n == 3u ? (be >> 8) : be;
+    good = (n <= 4u) & ((x & 0xffu) != 0u) & (len <= 0x7fffffffu);
   }
-  const uint32_t c = p + hl;              // p <= 2^31, hl <= 6: no wrap
-  good = good & (p <= end) & (c <= end);  // header bytes inside [p, end)
-  good = good & (len <= end - c);         // (end - c wraps only when good is already false)
-  ok = ok & good;
+  good = good & ((tag & 0x1fu) != 0x1fu);
+  const uint32_t c = p + hl;  // p <= 2^31, hl <= 6: no wrap
   cs = c;
-  ce = c + len;
+  ce = c + len;               // len < 2^31: no wrap; ce >= c >= p, so ONE comparison bounds header and contents
+  ok = ok & good & (ce <= end);
 }
 
-CTMR_HD bool digits4(uint32_t w) {  // four ASCII digits?
-  bool ok = true;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint32_t c = (w >> (8 * i)) & 0xffu;
-    ok = ok & ((c - 0x30u) <= 9u);
-  }
-  return ok;
+CTMR_HD bool digits4(uint32_t w) {  // four ASCII digits?  (SWAR: every byte ^ 0x30 must be <= 9)
+  const uint32_t t = w ^ 0x30303030u;
+  return ((((t & 0x7f7f7f7fu) + 0x76767676u) | t) & 0x80808080u) == 0u;
 }
 
 CTMR_HD uint32_t d2(uint32_t w, int sh) {  // two digits at bit offset sh of w → value
@@ -168,7 +178,7 @@ CTMR_HD void rd_time(const R& r, uint32_t L, uint32_t c, uint32_t tag, uint32_t 
 // Go asn1 checkInteger on content [c, c+len): non-empty and minimally encoded.
 template <class R>
 CTMR_HD bool int_ok(const R& r, uint32_t L, uint32_t c, uint32_t len) {
-  const uint32_t w = r.ld4(c < L ? c : L);
+  const uint32_t w = ldc(r, c, L);
   const uint32_t b0 = w & 0xffu, b1 = (w >> 8) & 0xffu;
   const bool pad0 = (b0 == 0x00u) & ((b1 & 0x80u) == 0u);
   const bool padf = (b0 == 0xffu) & ((b1 & 0x80u) != 0u);
@@ -218,7 +228,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   const uint32_t tbs_end = ce;
   uint32_t q = cs;
   // version [0] EXPLICIT INTEGER
-  if ((q < tbs_end) & ((r.ld4(q < L ? q : L) & 0xffu) == 0xa0u)) {
+  if ((q < tbs_end) & ((ldc(r, q, L) & 0xffu) == 0xa0u)) {
     uint32_t vs, ve, t2, is_, ie;
     rd_hdr(r, L, q, tbs_end, ok, tag, vs, ve);
     rd_hdr(r, L, vs, ve, ok, t2, is_, ie);
@@ -267,7 +277,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         uint32_t to, co, eo, tv, cv, ev;
         rd_hdr(r, L, a, a_end, ok, t1, c1, e1);      // AttributeTypeAndValue
         rd_hdr(r, L, c1, e1, ok, to, co, eo);        // type OID
-        const uint32_t oidw = r.ld4(co < L ? co : L);
+        const uint32_t oidw = ldc(r, co, L);
         rd_hdr(r, L, eo, e1, ok, tv, cv, ev);        // value
         ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co);
         const bool is_cn = (eo - co == 3u) & ((oidw & 0xffffffu) == 0x030455u) & string_tag(tv);
@@ -305,16 +315,16 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // a two-region reader fetches them in one burst
   r.touch_tail(q, tbs_end);
   // [1] issuerUniqueID, [2] subjectUniqueID: skipped
-  uint32_t nt = (ok & (q < tbs_end)) ? (r.ld4(q < L ? q : L) & 0xffu) : 0u;
+  uint32_t nt = (ok & (q < tbs_end)) ? (ldc(r, q, L) & 0xffu) : 0u;
   if (nt == 0x81u) {
     rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
     q = ce;
-    nt = (ok & (q < tbs_end)) ? (r.ld4(q < L ? q : L) & 0xffu) : 0u;
+    nt = (ok & (q < tbs_end)) ? (ldc(r, q, L) & 0xffu) : 0u;
   }
   if (nt == 0x82u) {
     rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
     q = ce;
-    nt = (ok & (q < tbs_end)) ? (r.ld4(q < L ? q : L) & 0xffu) : 0u;
+    nt = (ok & (q < tbs_end)) ? (ldc(r, q, L) & 0xffu) : 0u;
   }
   // [3] EXPLICIT Extensions
   if (nt == 0xa3u) {
@@ -328,11 +338,11 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
       r.touch(e, 48);
       rd_hdr(r, L, e, e_end, ok, t1, x, x_end);   // Extension
       rd_hdr(r, L, x, x_end, ok, to, co, eo);     // extnID
-      const uint32_t oidw = r.ld4(co < L ? co : L);
+      const uint32_t oidw = ldc(r, co, L);
       rd_hdr(r, L, eo, x_end, ok, tv, cv, ev);    // critical or extnValue
       ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co);
       if (tv == 0x01u) {  // critical BOOLEAN
-        const uint32_t bv = r.ld4(cv < L ? cv : L) & 0xffu;
+        const uint32_t bv = ldc(r, cv, L) & 0xffu;
         ok = ok & (ev - cv == 1u) & ((bv == 0x00u) | (bv == 0xffu));
         rd_hdr(r, L, ev, x_end, ok, tv, cv, ev);
       }
@@ -351,7 +361,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         if (ok & (c < c_end)) {
           rd_hdr(r, L, c, c_end, ok, tf, cf, ef);
           if (tf == 0x01u) {
-            const uint32_t bv = r.ld4(cf < L ? cf : L) & 0xffu;
+            const uint32_t bv = ldc(r, cf, L) & 0xffu;
             ok = ok & (ef - cf == 1u) & ((bv == 0x00u) | (bv == 0xffu));
             ca = bv == 0xffu;
             c = ef;
@@ -372,11 +382,11 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   rd_hdr(tv, L, ce, L, ok, tag, cs, ce);
   ok = ok & (tag == 0x03u) & (ce != cs);
   {
-    const uint32_t pad = tv.ld4(cs < L ? cs : L) & 0xffu;
+    const uint32_t pad = ldc(tv, cs, L) & 0xffu;
     ok = ok & (pad <= 7u) & ((ce - cs != 1u) | (pad == 0u));
     if (ok & (pad != 0u)) {  // padding bits must be zero: only then is the last octet needed
       const uint32_t lastp = ce - 1u;
-      const uint32_t last = tv.ld4(lastp < L ? lastp : L) & 0xffu;
+      const uint32_t last = ldc(tv, lastp, L) & 0xffu;
       ok = (last & ((1u << (pad & 7u)) - 1u)) == 0u;
     }
   }

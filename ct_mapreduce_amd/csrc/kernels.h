@@ -138,6 +138,7 @@ struct WinReaderC : WinReader<WCH> {
 // misses in 200 000 certificates once the three reads behind the TBS go through ldg()).
 template <int WCH>
 struct WinReaderS : WinReaderC<WCH> {
+  static constexpr bool kNoClamp = true;  // ld4 clamps into the window itself
   mutable uint32_t miss;
   // The 32 bytes behind the TBSCertificate (signatureAlgorithm, the signatureValue header, its pad octet), fetched
   // by touch_tail() TOGETHER with the extension-block refill: the three ldg() reads at the end of the walk were
