@@ -1488,13 +1488,14 @@ __global__ void __launch_bounds__(128) k_pem_encode(const uint8_t* payload, cons
   const uint8_t* in = payload + lo;
   uint8_t* o = out + pem_off[r];
   const uint64_t b64 = 4 * ((L + 2) / 3), nlines = (b64 + 63) / 64;
-  if (threadIdx.x == 0) {
-    const char* h = "-----BEGIN CERTIFICATE-----\n";
-    for (int k = 0; k < 28; k++) o[k] = (uint8_t)h[k];
-  } else if (threadIdx.x == 64) {
-    const char* f = "-----END CERTIFICATE-----\n";
+  // framing lines as a handful of wide unaligned stores (they were 54 single-byte stores on two threads)
+  if (threadIdx.x == 0) {         // "-----BEGIN CERTIFICATE-----\n" = 16 + 12 bytes
+    *(U16*)o = U16{0x2d2d2d2du, 0x4745422du, 0x43204e49u, 0x49545245u};
+    *(U12*)(o + 16) = U12{0x41434946u, 0x2d2d4554u, 0x0a2d2d2du};
+  } else if (threadIdx.x == 64) { // "-----END CERTIFICATE-----\n" = 26 bytes: 16 + 12 overlapping by two
     uint8_t* e = o + 28 + b64 + nlines;
-    for (int k = 0; k < 26; k++) e[k] = (uint8_t)f[k];
+    *(U16*)e = U16{0x2d2d2d2du, 0x444e452du, 0x52454320u, 0x49464954u};
+    *(U12*)(e + 14) = U12{0x41434946u, 0x2d2d4554u, 0x0a2d2d2du};  // bytes 14..25 (two bytes overlap the store above)
   }
   const uint64_t nq = (L + 11) / 12;
   for (uint64_t k = threadIdx.x; k < nq; k += 128) {
