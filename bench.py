@@ -194,14 +194,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local %= max(torch.cuda.device_count(), 1)      # (CTMR_DIST_BACKEND=gloo lets two test ranks share one GPU)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if args.gpus > 1 or world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        backend = os.environ.get("CTMR_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        try:
+            dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
+        except TypeError:                                           # older torch: no device_id argument
+            dist.init_process_group(backend)
         world, rank = dist.get_world_size(), dist.get_rank()
     else:
         dist = None
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     filt = b"Synth Issuer 0,Synth Issuer 1"      # BASELINE config 3: passes issuers 000-199
     cfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=0,
