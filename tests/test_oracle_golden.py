@@ -194,3 +194,14 @@ def test_pem_encode_line_breaking_edges():
         exp = b"-----BEGIN CERTIFICATE-----\n" + b"".join(l.encode() + b"\n" for l in lines) + \
               b"-----END CERTIFICATE-----\n"
         assert orc.pem_encode(der) == exp, n
+
+
+def test_golden_files_are_current():
+    """The committed fixtures equal what tests/golden/make_golden.py produces (PEM literals of the reference's tests
+    when /root/reference is present; the frozen synthetic batch always)."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "golden", "make_golden.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
