@@ -1605,6 +1605,10 @@ __global__ void __launch_bounds__(256) k_entry_decode(DecodeArgs a) {
 // (pend[] claims) for the host to register; `retry` re-examines only entries still marked unregistered.
 constexpr uint32_t ISS_UNREGISTERED = 0xfffffffeu;
 constexpr uint32_t PEND_SLOTS = 8192;  // distinct unknown Chain[0] hashes remembered per launch
+#ifndef CTMR_MATCH_PER_STEP
+#define CTMR_MATCH_PER_STEP 4
+#endif
+constexpr uint32_t MATCH_PER_STEP = CTMR_MATCH_PER_STEP;  // candidates whose loads are in flight together (4 and 8 both measure 9.2–9.3 ms per 40 M entries: the kernel is near the HBM rate once partial lines are counted)
 
 struct MatchArgs {
   const uint8_t* blob;
@@ -1695,20 +1699,20 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
         }
       }
     }
-    // cooperative bytewise verification, four candidates per step so that their loads are in flight together
+    // cooperative bytewise verification, MATCH_PER_STEP candidates per step so that their loads are in flight together
     // (a step costs one memory latency; certificates up to 2 KiB need no inner loop)
     unsigned long long todo = __ballot(cand != 0xffffffffu);
     while (todo) {
-      int src[4];
-      bool eq[4];
+      int src[MATCH_PER_STEP];
+      bool eq[MATCH_PER_STEP];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < (int)MATCH_PER_STEP; u++) {
         src[u] = todo ? __ffsll((long long)todo) - 1 : -1;
         todo &= todo - 1ull;  // 0 stays 0
         eq[u] = true;
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < (int)MATCH_PER_STEP; u++) {
         if (src[u] < 0) continue;  // wave-uniform
         const uint64_t s_lo = __shfl(lo, src[u]);
         const uint32_t s_len = __shfl(len, src[u]);
@@ -1731,7 +1735,7 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < (int)MATCH_PER_STEP; u++) {
         if (src[u] < 0) continue;
         const bool all = __ballot(!eq[u]) == 0ull;
         if ((int)lane == src[u] && all) {
