@@ -778,7 +778,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   InsertArgs ia;
   ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.ends = d_ends; ia.canon = e->d_canon;
   ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = d_slot; ia.ent = d_ent; ia.n = n; ia.epoch = e->epoch;
-  const bool fused = e->cfg.map_variant == 14 || e->cfg.map_variant == 15 || e->cfg.map_variant == 0;
+  const bool fused = e->cfg.map_variant == 0 || e->cfg.map_variant == 14 || e->cfg.map_variant == 15;
   if (prof) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
   if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, true, fused ? &ia : nullptr,
                       d_ends, blob_bytes + CTMR_PAYLOAD_PAD))) return r;

@@ -1030,6 +1030,10 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
 }
 
+// (Tried and dropped, session 4: a software-pipelined form — one wave walks 2 or 4 batches of 64 certificates and
+// fetches the next batch's front windows into registers while walking the current one.  256 VGPRs → 8 waves per CU,
+// and the first vector load inside the walk (the issuerCN filter words) waits on vmcnt for the prefetch issued just
+// before it, so the overlap never materialises: 26.0 ms against 23.1 ms, profiles/r01/s4/sweep_pipe.txt.)
 // Wave-aggregated add: one atomic per distinct key per wave (the "match-any" loop).
 __device__ __forceinline__ void wave_agg_add(bool active, uint32_t key, unsigned long long* arr) {
   unsigned long long todo = __ballot(active);
