@@ -243,3 +243,34 @@ def test_device_generator_matches_host_and_large_properties(variant):
     assert st2.n_new == 0 and st2.n_dup == st.by_status[0] and eng.total_count() == st.n_new
     assert st.ms_map > 0
     eng.close()
+
+
+def test_real_world_roots_as_issuers_and_leaves():
+    """The CA bundles shipped in the image (RSA/EC keys, UTCTime/GeneralizedTime, names without CN, v1 certificates):
+    issuer IDs computed on the GPU ≡ hashlib over OpenSSL's SPKI; as leaves, every record field ≡ oracle."""
+    import base64
+    import hashlib
+    from tests import harness
+    from tests.test_real_certs_cpu import bundle_ders
+    ders = bundle_ders()
+    if len(ders) < 50:
+        pytest.skip("no CA bundle in this image")
+    eng = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10)
+    eng.add_issuers(ders)
+    for k, d in enumerate(ders):
+        o = harness.ossl_extract(d)
+        want = base64.urlsafe_b64encode(hashlib.sha256(bytes(o.spki[:o.spki_len])).digest()).decode()
+        info = eng.issuer_info(k)
+        assert info.valid and info.issuer_id.decode() == want, k
+    for log_expired, now in ((True, NOW), (False, NOW), (False, 0)):
+        eng.reset_known()
+        eng.set_filter(b"", log_expired, now)
+        batch = Batch.from_certs(ders, list(range(len(ders))))
+        batch.payload = np.concatenate([batch.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+        res = eng.map_batch(batch)
+        o, st, unk, eh = run_oracle(batch, ders, b"", log_expired, now)
+        assert_records_equal(res, batch, st, unk, eh)
+        assert_state_equal(eng, o, len(ders))
+    # every certificate of the bundle is a CA (or expired): certIsFilteredOut stops them all, nothing reaches Store
+    assert ((st == orc.ST_FILTERED_CA) | (st == orc.ST_FILTERED_EXPIRED)).all() and eng.total_count() == 0
+    eng.close()
