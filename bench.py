@@ -214,9 +214,11 @@ def main():
     now = synth.BASE_TIME
     issuers = synth.issuers(cfg)
 
+    raw_view = {}
+
     def setup_raw(E):
         eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
-                          map_variant=args.variant, profile=True)
+                          map_variant=args.variant, profile=True, collect_meta=args.meta)
         eng.set_filter(filt, False, now)              # no add_issuers: Chain[0] certificates register themselves
         first = rank * E
         d_bounds = torch.empty(2 * E + 1, dtype=torch.int64, device=dev)
@@ -226,6 +228,15 @@ def main():
         d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         d_new = torch.empty(E, dtype=torch.int64, device=dev)
         d_ts = torch.empty(E, dtype=torch.int64, device=dev)
+        # caller-owned entry view: the decode fills it, map / meta / PEM read certificates through it
+        raw_view["start"] = torch.empty(E, dtype=torch.int64, device=dev)
+        raw_view["end"] = torch.empty(E, dtype=torch.int64, device=dev)
+        raw_view["iss"] = torch.empty(E, dtype=torch.int32, device=dev)
+        raw_view["et"] = torch.empty(E, dtype=torch.uint8, device=dev)
+        raw_view["view"] = N.EntryView(cert_start=raw_view["start"].data_ptr(), cert_end=raw_view["end"].data_ptr(),
+                                       issuer_idx=raw_view["iss"].data_ptr(), entry_type=raw_view["et"].data_ptr(),
+                                       timestamp=d_ts.data_ptr(), chain0_start=None, chain0_len=None)
+        raw_view["blob_bytes"] = total
         torch.cuda.synchronize()
         return eng, d_bounds, d_blob, d_ts, None, d_rec, d_new
 
@@ -283,8 +294,9 @@ def main():
     def step():
         eng.reset_known()
         if args.raw:   # d_off = bounds, d_pay = blob, d_iss = timestamps
-            st, ds = eng.map_entries_device(d_pay.data_ptr(), d_off.data_ptr(), E, d_rec.data_ptr(), d_new.data_ptr(),
-                                            d_iss.data_ptr())
+            ds = eng.decode_entries_device(d_pay.data_ptr(), d_off.data_ptr(), E, raw_view["view"])
+            st = eng.map_view_device(d_pay.data_ptr(), raw_view["blob_bytes"], raw_view["view"], E, d_rec.data_ptr(),
+                                     d_new.data_ptr())
             dstats.append(ds)
         elif gd_rank is not None:
             st = run_global_dedup(gd_rank, d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
@@ -292,9 +304,11 @@ def main():
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
                                       E, d_rec.data_ptr(), d_new.data_ptr())
-        if args.meta and not args.raw:
+        if args.meta:
             t_m = time.perf_counter()
-            meta_items.append(eng.meta_new_device(d_pay.data_ptr(), d_off.data_ptr(), 0, d_rec.data_ptr(),
+            offs_p = raw_view["start"].data_ptr() if args.raw else d_off.data_ptr()
+            ends_p = raw_view["end"].data_ptr() if args.raw else 0
+            meta_items.append(eng.meta_new_device(d_pay.data_ptr(), offs_p, ends_p, d_rec.data_ptr(),
                                                   d_new.data_ptr(), int(st.n_new), d_items.data_ptr(), 1 << 22))
             meta_ms.append((time.perf_counter() - t_m) * 1e3)
         if dist is not None:
@@ -372,24 +386,31 @@ def main():
                       "compact": stats.ms_compact, "total": stats.ms_total},
         "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},
     }
-    if args.pem and not args.raw:
+    if args.pem:
         m = min(int(stats.n_new), 16_000_000)
         d_po = torch.empty(m + 1, dtype=torch.int64, device=dev)
-        total = eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_new.data_ptr(), m, 0, 0, d_po.data_ptr())
+
+        def pem_call(d_pem_ptr, cap):
+            if args.raw:
+                return eng.pem_encode_view_device(d_pay.data_ptr(), raw_view["view"], d_new.data_ptr(), m, d_pem_ptr, cap,
+                                                  d_po.data_ptr())
+            return eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_new.data_ptr(), m, d_pem_ptr, cap,
+                                         d_po.data_ptr())
+        total = pem_call(0, 0)
         d_pem = torch.empty(total + 64, dtype=torch.uint8, device=dev)
         t_p = []
         for _ in range(3):
             t0p = time.perf_counter()
-            eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_new.data_ptr(), m, d_pem.data_ptr(), total + 64,
-                                  d_po.data_ptr())
+            pem_call(d_pem.data_ptr(), total + 64)
             t_p.append(time.perf_counter() - t0p)
         from oracle import oracle as orc
         po = d_po[:3].cpu().numpy()
         first = int(d_new[0].item())
-        o2 = d_off[first:first + 2].cpu().numpy()
-        der = d_pay[int(o2[0]):int(o2[1])].cpu().numpy().tobytes()
+        starts_t = raw_view["start"] if args.raw else d_off[:-1]
+        ends_t = raw_view["end"] if args.raw else d_off[1:]
+        der = d_pay[int(starts_t[first].item()):int(ends_t[first].item())].cpu().numpy().tobytes()
         ok_pem = d_pem[int(po[0]):int(po[1])].cpu().numpy().tobytes() == orc.pem_encode(der)
-        in_bytes = int((d_off[d_new[:m] + 1] - d_off[d_new[:m]]).sum().item())
+        in_bytes = int((ends_t[d_new[:m]] - starts_t[d_new[:m]]).sum().item())
         out["pem"] = {"certificates": m, "pem_bytes": int(total), "der_bytes": in_bytes, "ms_wall": min(t_p) * 1e3,
                       "certs_per_s": m / min(t_p), "GBps_read_plus_written": (in_bytes + total) / min(t_p) / 1e9,
                       "first_block_matches_oracle": bool(ok_pem)}

@@ -1275,6 +1275,14 @@ int ctmr_pem_encode_device(ctmr_engine* e, const uint8_t* d_payload, const uint6
   return pem_device_locked(e, d_payload, d_offsets, d_idx, n_idx, d_pem, pem_cap, d_pem_offsets, pem_bytes);
 }
 
+int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* v,
+                                const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,
+                                uint64_t* d_pem_offsets, uint64_t* pem_bytes) {
+  if (!e || !v || !d_pem_offsets || (n_idx && (!d_blob || !v->cert_start || !v->cert_end || !d_idx))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return pem_device_locked(e, d_blob, v->cert_start, d_idx, n_idx, d_pem, pem_cap, d_pem_offsets, pem_bytes, v->cert_end);
+}
+
 int ctmr_pem_new(ctmr_engine* e, uint8_t* out, size_t cap, uint64_t* pem_offsets, size_t* need, uint64_t* count) {
   if (!e) return CTMR_E_INVAL;
   std::lock_guard<std::mutex> g(e->mu);

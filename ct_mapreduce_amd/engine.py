@@ -318,6 +318,13 @@ class Engine:
             C.c_void_p(d_pem) if d_pem else None, pem_cap, C.c_void_p(d_pem_offsets), C.byref(total)))
         return int(total.value)
 
+    def pem_encode_view_device(self, d_blob, view: N.EntryView, d_idx, n_idx, d_pem, pem_cap, d_pem_offsets) -> int:
+        total = C.c_uint64(0)
+        self._ck(self._lib.ctmr_pem_encode_view_device(
+            self._h, C.c_void_p(d_blob), C.byref(view), C.c_void_p(d_idx), n_idx,
+            C.c_void_p(d_pem) if d_pem else None, pem_cap, C.c_void_p(d_pem_offsets), C.byref(total)))
+        return int(total.value)
+
     # ---- cross-GPU key exchange (global dedup), device pointers as ints
     KEY_BYTES = 64
 

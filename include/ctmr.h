@@ -238,6 +238,8 @@ int ctmr_pem_encode_device(ctmr_engine* e, const uint8_t* d_payload, const uint6
                            const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,
                            uint64_t* d_pem_offsets, uint64_t* pem_bytes);
 int ctmr_pem_new(ctmr_engine* e, uint8_t* out, size_t cap, uint64_t* pem_offsets, size_t* need, uint64_t* count);
+/* The device variant over an entry view (raw get-entries batches): certificate i is [cert_start[i], cert_end[i]) of
+ * d_blob.  Declared behind ctmr_entry_view below. */
 
 /* ---- CT get-entries leaf decode: replaces ct.LogEntryFromLeaf
  *      (cmd/ct-fetch/ct-fetch.go:452; RFC 6962 §3.4 MerkleTreeLeaf, §4.6 extra_data) and insertCTWorker's choice of
@@ -282,6 +284,10 @@ int ctmr_map_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_
                             ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
 int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n, ctmr_record* records,
                      uint64_t* new_idx, uint64_t* timestamp, ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
+/* ctmr_pem_encode_device for an entry view: PEM of the certificates d_idx[0..n_idx) names, straight out of the blob. */
+int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* d_view,
+                                const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,
+                                uint64_t* d_pem_offsets, uint64_t* pem_bytes);
 
 /* ---- IssuerMetadata on device: replaces the per-new-certificate part of
  *      IssuerMetadata.Accumulate (storage/issuermetadata.go:92-138) — its three per-issuer memo maps knownExpDates,

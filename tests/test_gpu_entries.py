@@ -166,3 +166,35 @@ def test_device_generator_and_device_path_match_the_host_path():
 def _spki(der):
     c = orc.parse_cert(der)
     return der[c.spki_off:c.spki_off + c.spki_len]
+
+
+def test_pem_over_entry_view_device():
+    """N1 over N2: PEM of the new certificates straight out of the raw blob through a caller-owned entry view."""
+    cfg = synth.config(seed=31, n_issuers=4, dup_permille=100)
+    n = 3000
+    dev = torch.device("cuda:0")
+    raw = synth.host_entries(cfg, 0, n)
+    b = synth.host_batch(cfg, 0, n)
+    eng = ctmr.Engine(device=0, table_slots=1 << 14, pair_slots=1 << 12)
+    eng.set_filter(b"", True, NOW)
+    d_blob = torch.from_numpy(raw.blob.copy()).to(dev)
+    d_bounds = torch.from_numpy(raw.bounds.astype(np.int64)).to(dev)
+    v_start = torch.zeros(n, dtype=torch.int64, device=dev)
+    v_end = torch.zeros(n, dtype=torch.int64, device=dev)
+    v_iss = torch.zeros(n, dtype=torch.int32, device=dev)
+    v_et = torch.zeros(n, dtype=torch.uint8, device=dev)
+    view = N.EntryView(cert_start=v_start.data_ptr(), cert_end=v_end.data_ptr(), issuer_idx=v_iss.data_ptr(),
+                       entry_type=v_et.data_ptr(), timestamp=None, chain0_start=None, chain0_len=None)
+    eng.decode_entries_device(d_blob.data_ptr(), d_bounds.data_ptr(), n, view)
+    d_rec = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+    d_new = torch.zeros(n, dtype=torch.int64, device=dev)
+    st = eng.map_view_device(d_blob.data_ptr(), int(raw.bounds[-1]), view, n, d_rec.data_ptr(), d_new.data_ptr())
+    m = int(st.n_new)
+    d_po = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    total = eng.pem_encode_view_device(d_blob.data_ptr(), view, d_new.data_ptr(), m, 0, 0, d_po.data_ptr())
+    d_pem = torch.zeros(total, dtype=torch.uint8, device=dev)
+    eng.pem_encode_view_device(d_blob.data_ptr(), view, d_new.data_ptr(), m, d_pem.data_ptr(), total, d_po.data_ptr())
+    po, pem, new = d_po.cpu().numpy(), d_pem.cpu().numpy().tobytes(), d_new[:m].cpu().numpy()
+    for k in range(0, m, 41):
+        assert pem[po[k]:po[k + 1]] == orc.pem_encode(b.cert(int(new[k])))
+    eng.close()
