@@ -1260,7 +1260,7 @@ static int pem_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   if (pem_bytes) *pem_bytes = total;
   if (!d_pem) return CTMR_OK;  // size query
   if (total > pem_cap) return fail(e, CTMR_E_RANGE, "PEM buffer too small: need %llu bytes", (unsigned long long)total);
-  hipLaunchKernelGGL(k_pem_encode, dim3((unsigned)((n_idx + PEM_PER_BLOCK - 1) / PEM_PER_BLOCK)), dim3(128), 0, e->stream,
+  hipLaunchKernelGGL(k_pem_encode, dim3((unsigned)((n_idx + 4 * PEM_PER_WAVE - 1) / (4 * PEM_PER_WAVE))), dim3(256), 0, e->stream,
                      d_payload, d_offsets, d_ends, d_idx, n_idx, (const uint64_t*)d_pem_offsets, d_pem);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipGetLastError());

@@ -1455,7 +1455,7 @@ __global__ void __launch_bounds__(256) k_pem_len(const uint64_t* offsets, const 
   pem_off[r] = pem_len(hi - lo);
 }
 
-constexpr uint32_t PEM_PER_BLOCK = 8;
+constexpr uint32_t PEM_PER_WAVE = 16;
 struct __attribute__((packed, aligned(1))) U12 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };
 
@@ -1478,31 +1478,43 @@ __device__ __forceinline__ uint32_t b64_group(uint32_t w) {
 // One workgroup per certificate; one task = 12 input bytes → 16 characters (a quarter line), so
 // adjacent lanes read adjacent 12-byte pieces and write adjacent 16-byte pieces (unaligned
 // dwordx3 / dwordx4 accesses; gfx950 runs with unaligned access mode).
-__global__ void __launch_bounds__(128) k_pem_encode(const uint8_t* payload, const uint64_t* offsets,
+__global__ void __launch_bounds__(256) k_pem_encode(const uint8_t* payload, const uint64_t* offsets,
                                                     const uint64_t* ends, const uint64_t* idx, uint64_t n_idx,
                                                     const uint64_t* pem_off, uint8_t* out) {
-  // PEM_PER_BLOCK certificates per workgroup: a 1.5 KB certificate is exactly one task per thread, and one
-  // workgroup per certificate was bound by the workgroup launch rate (16 M workgroups in 20 ms)
-  for (uint32_t cc = 0; cc < PEM_PER_BLOCK; cc++) {
-  const uint64_t r = (uint64_t)blockIdx.x * PEM_PER_BLOCK + cc;
+  // One WAVE per certificate (no workgroup-level cooperation is needed), PEM_PER_WAVE certificates per wave in turn:
+  // every wave follows its own idx → offsets → bytes chain, so a CU has 32 certificates in flight instead of 16
+  // two-wave workgroups' worth, and the chain of the next certificate is not behind a workgroup's slowest wave.
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+  // the idx → offsets → pem_off chains of all PEM_PER_WAVE certificates of this wave in ONE round: lane c fetches
+  // certificate c's, the loop below broadcasts them
+  uint64_t m_lo = 0, m_hi = 0, m_po = 0;
+  {
+    const uint64_t rr = wave * PEM_PER_WAVE + lane;
+    if (lane < PEM_PER_WAVE && rr < n_idx) {
+      cert_range(offsets, ends, idx[rr], m_lo, m_hi);
+      m_po = pem_off[rr];
+    }
+  }
+  for (uint32_t cc = 0; cc < PEM_PER_WAVE; cc++) {
+  const uint64_t r = wave * PEM_PER_WAVE + cc;
   if (r >= n_idx) return;
-  uint64_t lo, hi;
-  cert_range(offsets, ends, idx[r], lo, hi);
+  const uint64_t lo = __shfl(m_lo, (int)cc), hi = __shfl(m_hi, (int)cc);
   const uint64_t L = hi - lo;
   const uint8_t* in = payload + lo;
-  uint8_t* o = out + pem_off[r];
+  uint8_t* o = out + __shfl(m_po, (int)cc);
   const uint64_t b64 = 4 * ((L + 2) / 3), nlines = (b64 + 63) / 64;
   // framing lines as a handful of wide unaligned stores (they were 54 single-byte stores on two threads)
-  if (threadIdx.x == 0) {         // "-----BEGIN CERTIFICATE-----\n" = 16 + 12 bytes
+  if (lane == 0) {         // "-----BEGIN CERTIFICATE-----\n" = 16 + 12 bytes
     *(U16*)o = U16{0x2d2d2d2du, 0x4745422du, 0x43204e49u, 0x49545245u};
     *(U12*)(o + 16) = U12{0x41434946u, 0x2d2d4554u, 0x0a2d2d2du};
-  } else if (threadIdx.x == 64) { // "-----END CERTIFICATE-----\n" = 26 bytes: 16 + 12 overlapping by two
+  } else if (lane == 32) { // "-----END CERTIFICATE-----\n" = 26 bytes: 16 + 12 overlapping by two
     uint8_t* e = o + 28 + b64 + nlines;
     *(U16*)e = U16{0x2d2d2d2du, 0x444e452du, 0x52454320u, 0x49464954u};
     *(U12*)(e + 14) = U12{0x41434946u, 0x2d2d4554u, 0x0a2d2d2du};  // bytes 14..25 (two bytes overlap the store above)
   }
   const uint64_t nq = (L + 11) / 12;
-  for (uint64_t k = threadIdx.x; k < nq; k += 128) {
+  for (uint64_t k = lane; k < nq; k += 64) {
     const uint64_t ip = 12 * k;
     const uint32_t nin = (uint32_t)(L - ip < 12 ? L - ip : 12);
     const U12 v = *(const U12*)(in + ip);  // may read ≤ 11 bytes past the certificate: CTMR_PAYLOAD_PAD
