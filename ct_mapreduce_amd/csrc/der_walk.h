@@ -321,7 +321,9 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
   q = ce;
-  // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo)
+  // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo).  A long subject (OV/EV certificates) puts this
+  // header past the front window: say so, instead of leaving a window-only reader to its slow exact path.
+  r.touch(q, 8);
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
   o.spki_off = q;

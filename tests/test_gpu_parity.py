@@ -274,3 +274,40 @@ def test_real_world_roots_as_issuers_and_leaves():
     # every certificate of the bundle is a CA (or expired): certIsFilteredOut stops them all, nothing reaches Store
     assert ((st == orc.ST_FILTERED_CA) | (st == orc.ST_FILTERED_EXPIRED)).all() and eng.total_count() == 0
     eng.close()
+
+
+def test_long_names_and_mixed_keys(variant):
+    """OV/EV-like certificates: issuer and subject names of up to several hundred bytes push the SPKI header and
+    the extension block past the front window (refills, not the slow path), EC and RSA keys mixed in one wave."""
+    rng = random.Random(31337)
+
+    def long_name(n_attrs, width):
+        return D.name(*[D.rdn(a, bytes(rng.choice(b"abcdefghij KLMNOP") for _ in range(width)))
+                        for a in ([6, 8, 7, 10, 11, 3] * 3)[:n_attrs]])
+    rsa_spki = bytes.fromhex("30820122300d06092a864886f70d01010105000382010f003082010a0282010100") + \
+        bytes(rng.randrange(256) for _ in range(256)) + bytes.fromhex("0203010001")
+    cfg = synth.config(seed=8, n_issuers=3)
+    issuers = synth.issuers(cfg)
+    certs, iss = [], []
+    for k in range(700):
+        exts = [D.ext(0x0f, D.tlv(0x03, b"\x05\xa0"), True), D.BC_NOT_CA if k % 7 else D.BC_CA,
+                D.ext(0x0e, D.tlv(0x04, bytes(20))),
+                D.ext(0x1f, D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa0, D.tlv(0x86, b"http://crl.example.com/x.crl")))))),
+                D.ext(0x11, D.seq(*[D.tlv(0x82, b"host%d.example.com" % j) for j in range(rng.randrange(1, 40))]))]
+        certs.append(D.cert(serial=bytes([1] + [rng.randrange(256) for _ in range(rng.randrange(1, 19))]),
+                            issuer=long_name(rng.randrange(1, 7), rng.randrange(4, 60)),
+                            subject=long_name(rng.randrange(1, 10), rng.randrange(4, 70)),
+                            spki=rsa_spki if k % 2 else D.EC_SPKI, exts=exts if k % 11 else None,
+                            not_after=D.gentime("20300101000000Z") if k % 5 == 0 else None))
+        iss.append(k % 3)
+    batch = Batch.from_certs(certs, iss)
+    batch.payload = np.concatenate([batch.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    eng = make_engine(variant)
+    eng.add_issuers(issuers)
+    eng.set_filter(b"a,b,c,d,e,f,g,h,i,j,K,L", False, NOW)          # CommonName first letters: about half pass
+    res = eng.map_batch(batch)
+    o, st, unk, eh = run_oracle(batch, issuers, b"a,b,c,d,e,f,g,h,i,j,K,L", False, NOW)
+    assert (st == 0).sum() > 40 and (st == orc.ST_FILTERED_CN).sum() > 50 and (st == orc.ST_FILTERED_CA).sum() > 50
+    assert_records_equal(res, batch, st, unk, eh)
+    assert_state_equal(eng, o, len(issuers))
+    eng.close()
