@@ -168,6 +168,10 @@ def main():
                     help="BASELINE config 5 on one GPU: stream TOTAL entries with 10%% duplicates through one engine in "
                          "waves of --entries (default 50M), the known-certificate table persisting across waves; "
                          "checks n_new / n_dup of every wave against the generator's duplicate structure")
+    ap.add_argument("--mixed", action="store_true",
+                    help="the mixed synthetic corpus (half EC P-256 keys, 40%% OV-like subjects of 120-260 bytes, longer "
+                         "issuer names, one GeneralizedTime in four) instead of the SURVEY §8(d) corpus: how the map "
+                         "behaves when the lanes of a wave do not walk identical layouts; not the default workload")
     ap.add_argument("--pem", action="store_true",
                     help="also time the PEM write-back kernels (k_pem_len + scan + k_pem_encode, SURVEY §8(f) N1) over "
                          "the first 16M entries of the NEW list")
@@ -210,7 +214,7 @@ def main():
 
     filt = b"Synth Issuer 0,Synth Issuer 1"      # BASELINE config 3: passes issuers 000-199
     cfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=0,
-                       ca_permille=10, expired_permille=10)
+                       ca_permille=10, expired_permille=10, profile=1 if args.mixed else 0)
     now = synth.BASE_TIME
     issuers = synth.issuers(cfg)
 
@@ -434,6 +438,8 @@ def main():
                               "bound": "valu", "blocks_per_s": (stats.payload_bytes / 64 + 1.5 * E) / (ms_fp * 1e-3),
                               "matches_hashlib_on_first_1000": bool(okfp),
                               "note": "auxiliary op, not on the reference's path (SURVEY D2); VALU roofline in DESIGN.md §5"}
+    if args.mixed:
+        out["config"]["workload"] = "MIXED corpus (EC/RSA keys, OV-like subjects, GeneralizedTime): " + out["config"]["workload"]
     if args.meta and meta_ms:
         out["kernel_ms"]["meta_new_cold_wall"] = meta_ms[0]
         out["kernel_ms"]["meta_new_warm_wall"] = sum(meta_ms[1:]) / max(len(meta_ms) - 1, 1)

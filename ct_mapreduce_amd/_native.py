@@ -63,7 +63,8 @@ class IssuerInfo(C.Structure):
 class SynthConfig(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_issuers", C.c_uint32), ("zipf", C.c_uint32),
                 ("dup_permille", C.c_uint32), ("ca_permille", C.c_uint32),
-                ("expired_permille", C.c_uint32), ("mean_len", C.c_uint32), ("base_time", C.c_int64)]
+                ("expired_permille", C.c_uint32), ("mean_len", C.c_uint32), ("base_time", C.c_int64),
+                ("profile", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # name → (restype, argtypes); must list every function include/ctmr.h declares

@@ -379,6 +379,7 @@ SynthCfg to_synth(const ctmr_synth_config* c, const uint32_t* cdf) {
   s.mean_len = c->mean_len ? c->mean_len : 1536;
   s.base_time = c->base_time ? c->base_time : 1767225600ll;  // 2026-01-01T00:00:00Z
   s.zipf_cdf = cdf;
+  s.profile = c->profile;
   return s;
 }
 

@@ -17,6 +17,7 @@ struct SynthCfg {
   uint32_t n_issuers, zipf, dup_permille, ca_permille, expired_permille, mean_len;
   int64_t base_time;
   const uint32_t* zipf_cdf;  // n_issuers thresholds in [0,2^32): issuer = first k with u < cdf[k]
+  uint32_t profile;          // 0 = SURVEY §8(d) corpus (RSA-2048, short names, UTCTime); 1 = mixed (see synth_leaf_emit)
 };
 
 CTMR_HD uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
@@ -160,7 +161,7 @@ CTMR_HD void close_rdn(BackWriter& w, uint8_t attr, uint8_t strtag, uint32_t end
 }
 
 // issuer DN: C=US, O=Synth CA Org, CN=Synth Issuer NNN  (written backward: CN first)
-CTMR_HD void put_issuer_name(BackWriter& w, uint32_t k) {
+CTMR_HD void put_issuer_name(BackWriter& w, uint32_t k, uint32_t profile = 0) {
   const uint32_t end = w.pos;
   {
     const uint32_t e = w.pos;
@@ -168,8 +169,14 @@ CTMR_HD void put_issuer_name(BackWriter& w, uint32_t k) {
     w.str("Synth Issuer ", 13);
     close_rdn(w, 0x03, 0x0c, e);
   }
+  if (profile == 1 && k % 3u != 0) {  // mixed corpus: OU, and a long O for one issuer in three
+    const uint32_t e = w.pos;
+    w.str("Synth Trust Services Division", 29);
+    close_rdn(w, 0x0b, 0x13, e);
+  }
   {
     const uint32_t e = w.pos;
+    if (profile == 1 && k % 3u == 2) w.str(" Certification Authority Holdings Incorporated", 46);
     w.str("Synth CA Org", 12);
     close_rdn(w, 0x0a, 0x0c, e);
   }
@@ -202,6 +209,45 @@ CTMR_HD void put_rsa_spki(BackWriter& w, Rng& r) {
                                   0xf7, 0x0d, 0x01, 0x01, 0x01, 0x05, 0x00};
   w.bytes(alg, 15);
   w.hdr(0x30, end);
+}
+
+CTMR_HD void put_ec_spki(BackWriter& w, Rng& r) {  // id-ecPublicKey, prime256v1, uncompressed point: 91 bytes
+  const uint32_t end = w.pos;
+  w.random(r, 64);
+  w.put(0x04);
+  w.put(0x00);
+  w.hdr(0x03, end);
+  const uint8_t alg[21] = {0x30, 0x13, 0x06, 0x07, 0x2a, 0x86, 0x48, 0xce, 0x3d, 0x02, 0x01,
+                           0x06, 0x08, 0x2a, 0x86, 0x48, 0xce, 0x3d, 0x03, 0x01, 0x07};
+  w.bytes(alg, 21);
+  w.hdr(0x30, end);
+}
+
+// GeneralizedTime "YYYYMMDDHHMMSSZ" TLV, written backward
+CTMR_HD void put_gentime(BackWriter& w, int64_t t) {
+  int64_t days = t / 86400;
+  int64_t rem = t % 86400;
+  if (rem < 0) {
+    rem += 86400;
+    days -= 1;
+  }
+  int32_t y;
+  uint32_t mo, d;
+  civil_from_days(days, y, mo, d);
+  const uint32_t hh = (uint32_t)rem / 3600u, mi = ((uint32_t)rem % 3600u) / 60u, ss = (uint32_t)rem % 60u;
+  const uint32_t end = w.pos;
+  w.put('Z');
+  w.put('0' + ss % 10); w.put('0' + ss / 10);
+  w.put('0' + mi % 10); w.put('0' + mi / 10);
+  w.put('0' + hh % 10); w.put('0' + hh / 10);
+  w.put('0' + d % 10);  w.put('0' + d / 10);
+  w.put('0' + mo % 10); w.put('0' + mo / 10);
+  uint32_t yy = (uint32_t)y;
+  for (int k = 0; k < 4; k++) {
+    w.put('0' + yy % 10);
+    yy /= 10;
+  }
+  w.hdr(0x18, end);
 }
 
 CTMR_HD void put_sig(BackWriter& w, Rng& r) {  // sha256WithRSAEncryption + 256-byte signature
@@ -381,26 +427,46 @@ CTMR_HD void synth_leaf_emit(const SynthCfg& c, uint64_t i, BackWriter& w, uint3
   }
   w.hdr(0x30, ext_end);
   w.hdr(0xa3, ext_end);
-  // ---- subjectPublicKeyInfo
-  put_rsa_spki(w, br);
-  // ---- subject: CN=host-%016x.example
+  // ---- subjectPublicKeyInfo (mixed corpus: half the keys are EC P-256, 91 instead of 294 bytes)
+  const bool mixed = c.profile == 1;
+  if (mixed && (subj & 1u)) put_ec_spki(w, br); else put_rsa_spki(w, br);
+  // ---- subject: CN=host-%016x.example; mixed corpus: 40 % of the subjects are OV-like
+  //      (C, ST, L, O of 8…71 characters, OU) — 120…260 bytes instead of 38
   {
     const uint32_t end = w.pos;
-    const uint32_t e = w.pos;
-    w.str(".example", 8);
-    put_hex(w, subj, 16);
-    w.str("host-", 5);
-    close_rdn(w, 0x03, 0x0c, e);
+    {
+      const uint32_t e = w.pos;
+      w.str(".example", 8);
+      put_hex(w, subj, 16);
+      w.str("host-", 5);
+      close_rdn(w, 0x03, 0x0c, e);
+    }
+    if (mixed && ((subj >> 8) % 5u) < 2u) {
+      { const uint32_t e = w.pos; w.str("Platform Engineering", 20); close_rdn(w, 0x0b, 0x0c, e); }
+      {
+        const uint32_t e = w.pos;
+        const uint32_t ol = 8u + (uint32_t)((subj >> 16) & 63u);
+        uint64_t v = subj;
+        for (uint32_t k = 0; k < ol; k++) {
+          w.put((uint8_t)('a' + (v & 0xf)));
+          v = (v >> 4) | (v << 60);
+        }
+        close_rdn(w, 0x0a, 0x0c, e);
+      }
+      { const uint32_t e = w.pos; w.str("San Francisco", 13); close_rdn(w, 0x07, 0x0c, e); }
+      { const uint32_t e = w.pos; w.str("California", 10); close_rdn(w, 0x08, 0x0c, e); }
+      { const uint32_t e = w.pos; w.str("US", 2); close_rdn(w, 0x06, 0x13, e); }
+    }
     w.hdr(0x30, end);
   }
-  // ---- validity
+  // ---- validity (mixed corpus: one notAfter in four is a GeneralizedTime)
   {
     const uint32_t end = w.pos;
-    put_utctime(w, not_after);
+    if (mixed && ((subj >> 12) & 3u) == 0u) put_gentime(w, not_after); else put_utctime(w, not_after);
     put_utctime(w, not_before);
     w.hdr(0x30, end);
   }
-  put_issuer_name(w, issuer);
+  put_issuer_name(w, issuer, c.profile);
   put_sigalg(w);
   {  // serialNumber: positive, DER-minimal (leading 00 when the top bit is set)
     const uint32_t e = w.pos;
@@ -444,14 +510,14 @@ CTMR_HD void synth_issuer_emit(const SynthCfg& c, uint32_t k, BackWriter& w) {
   w.hdr(0x30, ext_end);
   w.hdr(0xa3, ext_end);
   put_rsa_spki(w, r);
-  put_issuer_name(w, k);  // subject
+  put_issuer_name(w, k, c.profile);  // subject
   {
     const uint32_t end = w.pos;
     put_utctime(w, c.base_time + 3650ll * 86400);
     put_utctime(w, c.base_time - 365ll * 86400);
     w.hdr(0x30, end);
   }
-  put_issuer_name(w, k);  // issuer (self-issued)
+  put_issuer_name(w, k, c.profile);  // issuer (self-issued)
   put_sigalg(w);
   {
     const uint32_t e = w.pos;

@@ -10,10 +10,11 @@ BASE_TIME = 1767225600  # 2026-01-01T00:00:00Z
 
 
 def config(seed=20260921, n_issuers=1, zipf=1, dup_permille=0, ca_permille=10, expired_permille=10,
-           mean_len=1536, base_time=BASE_TIME):
+           mean_len=1536, base_time=BASE_TIME, profile=0):
+    """profile 0: the SURVEY §8(d) corpus; 1: mixed keys (EC/RSA), long OV-like subjects, GeneralizedTime."""
     return N.SynthConfig(seed=seed, n_issuers=n_issuers, zipf=zipf, dup_permille=dup_permille,
                          ca_permille=ca_permille, expired_permille=expired_permille,
-                         mean_len=mean_len, base_time=base_time)
+                         mean_len=mean_len, base_time=base_time, profile=profile, reserved=0)
 
 
 def leaf(cfg, i):

@@ -343,6 +343,10 @@ typedef struct {
   uint32_t expired_permille; /* notAfter < base time (filter 2 when now == base) */
   uint32_t mean_len;       /* 0 = 1536 */
   int64_t base_time;       /* 0 = 2026-01-01T00:00:00Z */
+  uint32_t profile;        /* 0 = the SURVEY §8(d) corpus (RSA-2048 keys, 38-byte subjects, UTCTime);
+                              1 = mixed: half the keys EC P-256, 40 % OV-like subjects of 120…260 bytes, longer issuer
+                                  names for two issuers in three, one GeneralizedTime notAfter in four */
+  uint32_t reserved;
 } ctmr_synth_config;
 
 /* Length of synthetic leaf i / issuer certificate k, and their bytes (host side). */

@@ -311,3 +311,21 @@ def test_long_names_and_mixed_keys(variant):
     assert_records_equal(res, batch, st, unk, eh)
     assert_state_equal(eng, o, len(issuers))
     eng.close()
+
+
+def test_mixed_synthetic_corpus_bit_exact(variant):
+    """The mixed corpus (profile=1): lanes of one wave walk EC and RSA certificates, 38-byte and 250-byte subjects,
+    UTCTime and GeneralizedTime side by side."""
+    cfg = synth.config(seed=20260921 + 9, n_issuers=64, dup_permille=100, ca_permille=10, expired_permille=10, profile=1)
+    batch = synth.host_batch(cfg, 0, 20000)
+    issuers = synth.issuers(cfg)
+    filt = b"Synth Issuer 00,Synth Issuer 01,Synth Issuer 02"
+    eng = make_engine(variant)
+    eng.add_issuers(issuers)
+    eng.set_filter(filt, False, NOW)
+    res = eng.map_batch(batch)
+    o, st, unk, eh = run_oracle(batch, issuers, filt, False, NOW)
+    assert (st == 0).sum() > 5000 and 0 < unk.sum() < (st == 0).sum()
+    assert_records_equal(res, batch, st, unk, eh)
+    assert_state_equal(eng, o, len(issuers))
+    eng.close()

@@ -166,3 +166,25 @@ def test_time_forms(golden_certs, t, ok, exp):
     if ok:
         assert o.not_after == exp
     assert same(der2) == ok
+
+
+def test_mixed_synthetic_corpus_against_openssl():
+    """profile=1: EC P-256 and RSA keys, OV-like subjects, longer issuer names, GeneralizedTime — oracle, product
+    walk (host build) and OpenSSL agree, and the corpus really is mixed."""
+    cfg = synth.config(seed=21, n_issuers=9, profile=1, ca_permille=30, expired_permille=30)
+    n_ec = n_gt = n_ov = 0
+    for i in range(600):
+        der, iss, et = synth.leaf(cfg, i)
+        assert same(der)
+        c = orc.parse_cert(der)
+        o = harness.ossl_extract(der)
+        assert c.ok and o is not None
+        assert (c.not_before, c.not_after) == (o.not_before, o.not_after)
+        assert der[c.cn_off:c.cn_off + c.cn_len] == bytes(o.cn[:o.cn_len]) == b"Synth Issuer %03d" % iss
+        assert der[c.spki_off:c.spki_off + c.spki_len] == bytes(o.spki[:o.spki_len])
+        n_ec += c.spki_len == 91
+        n_gt += b"\x18\x0f20" in der
+        n_ov += b"San Francisco" in der
+    assert n_ec > 200 and n_gt > 80 and n_ov > 150
+    for k in range(9):
+        assert same(synth.issuer(cfg, k))
