@@ -188,6 +188,7 @@ struct ctmr_engine {
   uint64_t last_n = 0, last_n_new = 0;
   size_t last_o_off = 0, last_o_new = 0;
   hipEvent_t ev[8] = {};
+  std::vector<uint64_t> h_rel;  // host staging of the rebased offsets of ctmr_map_batch
   // host-side store: non-table keys + members with serials longer than CTMR_MAX_SERIAL
   std::map<std::string, std::set<std::string>> hstore;
   std::map<std::string, int64_t> expiry;          // explicit ExpireAt overrides / host keys
@@ -750,7 +751,8 @@ static int launch_map(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* 
 static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                              const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
                              ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats,
-                             const uint64_t* d_ends = nullptr, uint64_t blob_bytes = 0) {
+                             const uint64_t* d_ends = nullptr, uint64_t blob_bytes = 0,
+                             uint64_t payload_bytes_known = ~0ull) {
   HIPCHK(e, hipSetDevice(e->device));
   if (stats) memset(stats, 0, sizeof *stats);
   if (n == 0) return CTMR_OK;
@@ -793,14 +795,29 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   ra.ent = d_ent; ra.issuer_counts = e->issuer_counts; ra.stats = e->d_stats; ra.blk_new = d_blk_new; ra.n = n;
   hipLaunchKernelGGL(k_resolve, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(1024), 0, e->stream, ra, nb);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[3], e->stream));
+  // ---- compaction of the NEW list, queued right behind the resolve: the common case needs ONE synchronisation per
+  //      batch (a host that feeds 1 001-entry batches — one get-entries response — pays for every extra round trip)
+  auto compact = [&]() {
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records, (const uint32_t*)d_ent, n, (const uint64_t*)d_blk_base, d_new_idx);
+  };
+  if (d_new_idx) compact();
+  if (prof) HIPCHK(e, hipEventRecord(e->ev[4], e->stream));
   DevStats hs;
+  uint64_t ends[2] = {0, blob_bytes};
   HIPCHK(e, hipMemcpyAsync(&hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
+  if (!d_ends && payload_bytes_known == ~0ull) {
+    HIPCHK(e, hipMemcpyAsync(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost, e->stream));
+  } else if (!d_ends) {
+    ends[1] = payload_bytes_known;
+  }
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipGetLastError());
   if (hs.n_full) return fail(e, CTMR_E_FULL, "known-certificate table full (%llu slots): %llu entries dropped",
                              (unsigned long long)e->nslots, hs.n_full);
 
-  // ---- serials longer than CTMR_MAX_SERIAL: exact host-side set, in log order
+  // ---- serials longer than CTMR_MAX_SERIAL: exact host-side set, in log order (rare: the NEW list is rebuilt)
   uint64_t host_new = 0;
   if (hs.n_host) {
     std::vector<uint32_t> ent(n);
@@ -833,26 +850,18 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
         HIPCHK(e, hipMemcpy(d_blk_new + i / 1024, &bn, 4, hipMemcpyHostToDevice));
       }
     }
+    if (host_new && d_new_idx) {
+      compact();
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      HIPCHK(e, hipGetLastError());
+    }
   }
-  // ---- compaction of the NEW list
-  if (d_new_idx) {
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records, (const uint32_t*)d_ent, n, (const uint64_t*)d_blk_base, d_new_idx);
-  }
-  if (prof) HIPCHK(e, hipEventRecord(e->ev[4], e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  HIPCHK(e, hipGetLastError());
   if (stats) {
     stats->n = n;
     for (int k = 0; k < CTMR_ST__COUNT; k++) stats->by_status[k] = hs.by_status[k];
     stats->n_new = hs.n_new + host_new;
     stats->n_dup = hs.n_dup + (hs.n_host - host_new);
     stats->n_host_set = hs.n_host;
-    uint64_t ends[2] = {0, blob_bytes};
-    if (!d_ends) {
-      HIPCHK(e, hipMemcpy(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost));
-      HIPCHK(e, hipMemcpy(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost));
-    }
     stats->payload_bytes = ends[1] - ends[0];  // entry view: the whole blob (leaf_input + extra_data)
     stats->map_launches = 1;
     if (prof) {
@@ -891,20 +900,23 @@ int ctmr_map_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offse
   const size_t o_off = 0, o_iss = (n + 1) * 8, o_et = o_iss + n * 4, o_new = (o_et + n + 15) & ~(size_t)15;
   if ((r = ensure(e, SC_STAGE_B, o_new + n * 8))) return r;
   uint8_t* B = (uint8_t*)e->d_scratch[SC_STAGE_B];
-  std::vector<uint64_t> rel(n + 1);
+  // rel[] lives in the engine: the uploads are ordered before the kernels on the stream and every caller buffer
+  // is consumed before this call returns (the call ends with a synchronisation), so no sync is needed here
+  std::vector<uint64_t>& rel = e->h_rel;
+  rel.resize(n + 1);
   for (uint64_t i = 0; i <= n; i++) rel[i] = offsets[i] - base;
   HIPCHK(e, hipMemcpyAsync(e->d_scratch[SC_STAGE_A], payload + base, bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync(B + o_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync(B + o_iss, issuer_idx, n * 4, hipMemcpyHostToDevice, e->stream));
   if (entry_type) HIPCHK(e, hipMemcpyAsync(B + o_et, entry_type, n, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));  // rel[] is a local
   ctmr_batch_stats st;
   r = map_device_locked(e, (const uint8_t*)e->d_scratch[SC_STAGE_A], (const uint64_t*)(B + o_off),
                         (const uint32_t*)(B + o_iss), entry_type ? B + o_et : nullptr, n, nullptr,
-                        new_idx ? (uint64_t*)(B + o_new) : nullptr, &st);
+                        new_idx ? (uint64_t*)(B + o_new) : nullptr, &st, nullptr, 0, bytes);
   if (r) return r;
-  if (records) HIPCHK(e, hipMemcpy(records, e->d_scratch[SC_RECORDS], n * sizeof(ctmr_record), hipMemcpyDeviceToHost));
-  if (new_idx && st.n_new) HIPCHK(e, hipMemcpy(new_idx, B + o_new, st.n_new * 8, hipMemcpyDeviceToHost));
+  if (records) HIPCHK(e, hipMemcpyAsync(records, e->d_scratch[SC_RECORDS], n * sizeof(ctmr_record), hipMemcpyDeviceToHost, e->stream));
+  if (new_idx && st.n_new) HIPCHK(e, hipMemcpyAsync(new_idx, B + o_new, st.n_new * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
   if (stats) *stats = st;
   e->last_n = n; e->last_n_new = new_idx ? st.n_new : 0; e->last_o_off = o_off; e->last_o_new = o_new;
   e->last_is_view = false;
