@@ -72,3 +72,49 @@ def test_pinned_buffers_round_trip():
     got = eng.map_batch(Batch(p, b.offsets, b.issuer_idx, b.entry_type)).records
     assert (got == want).all()
     eng.close()
+
+
+def test_concurrent_callers_share_one_engine():
+    """RemoteCache methods are called from numThreads goroutines at once (ct-fetch.go:140-145): every entry point
+    takes the engine mutex.  Four host threads map disjoint windows of one stream and hammer the point operations;
+    the final state equals the single-threaded oracle's."""
+    import threading
+    from oracle import oracle as orc
+    cfg = synth.config(seed=3, n_issuers=4, dup_permille=0)
+    issuers = synth.issuers(cfg)
+    eng = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 15)   # 90 d × 24 h × 4 issuers of (expDate, issuer) pairs
+    eng.add_issuers(issuers)
+    eng.set_filter(b"", True, NOW)
+    batches = [synth.host_batch(cfg, k * 3000, 3000) for k in range(8)]
+    errors, news = [], [0] * 4
+
+    def worker(t):
+        try:
+            for k in (t, t + 4):
+                news[t] += eng.map_batch(batches[k]).stats.n_new
+                for j in range(50):
+                    m = bytes([1 + t, j, k])
+                    assert eng.set_insert(b"crl::thread%d" % t, m) and eng.set_contains(b"crl::thread%d" % t, m)
+                eng.issuer_counts()
+                eng.keys(b"crl::*")
+        except Exception as ex:          # noqa: BLE001
+            errors.append(ex)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    o = orc.Engine(b"", True, NOW)
+    io = np.zeros(len(issuers) + 1, np.uint64)
+    io[1:] = np.cumsum([len(x) for x in issuers])
+    blob = np.frombuffer(b"".join(issuers), np.uint8)
+    want = 0
+    for b in batches:
+        st, unk, eh = o.batch(b.payload, b.offsets, b.issuer_idx, blob, io)
+        want += int(unk.sum())
+    assert sum(news) == want == eng.total_count() == o.total_count()
+    assert sorted(eng.keys(b"serials::*")) == [k for k in o.keys() if k.startswith(b"serials::")]
+    for t in range(4):
+        assert eng.set_cardinality(b"crl::thread%d" % t) == 100
+    eng.close()
