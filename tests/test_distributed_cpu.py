@@ -51,6 +51,7 @@ def _worker(rank, world, port, n_total, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
 def test_two_rank_gloo_counts_match_single_process(tmp_path):
     from ct_mapreduce_amd import synth
     from oracle import oracle as orc
@@ -152,6 +153,7 @@ def _exchange_worker(rank, world, port, n_total, outdir):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
 def test_three_rank_gloo_key_exchange_matches_single_process(tmp_path):
     from ct_mapreduce_amd import synth
     from oracle import oracle as orc
