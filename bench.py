@@ -224,6 +224,10 @@ def main():
         eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
                           map_variant=args.variant, profile=True, collect_meta=args.meta)
         eng.set_filter(filt, False, now)              # no add_issuers: Chain[0] certificates register themselves
+        if world > 1:
+            # … in shard order, so issuer index k would name different issuers on different ranks and the count
+            # all-reduce would add apples to oranges: with several ranks, register the same list up front
+            eng.add_issuers(issuers)
         first = rank * E
         d_bounds = torch.empty(2 * E + 1, dtype=torch.int64, device=dev)
         total = eng.synth_entries_device(cfg, first, E, d_bounds.data_ptr(), 0, 0)
