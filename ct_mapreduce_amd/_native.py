@@ -106,6 +106,10 @@ SIGNATURES = {
     "ctmr_exchange_apply_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
                                              C.POINTER(BatchStats)]),
     "ctmr_pem_encode_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
+    "ctmr_set_issuer_autoregister": (C.c_int, [_P, C.c_int]),
+    "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "ctmr_exchange_export_view_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(EntryView), C.c_uint64, _P, C.c_uint32,
+                                                   _P, C.POINTER(C.c_uint64)]),
     "ctmr_pem_encode_view_device": (C.c_int, [_P, _P, C.POINTER(EntryView), _P, C.c_uint64, _P, C.c_uint64, _P,
                                               C.POINTER(C.c_uint64)]),
     "ctmr_pem_new": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),

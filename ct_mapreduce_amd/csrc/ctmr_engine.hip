@@ -159,6 +159,8 @@ struct ctmr_engine {
   uint32_t idb_ht_size = 0;
   std::vector<unsigned long long> h_idb_ht;
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
+  bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
+  std::vector<std::string> pending_issuers;  // auto_register off: what the last decode found unregistered
   unsigned long long* d_pend = nullptr;    // PEND_SLOTS claim words
   uint32_t* d_unreg = nullptr;             // UNREG_CAP entry indices
   unsigned long long* d_dcount = nullptr;  // 8 counters of the decode / match kernels
@@ -929,6 +931,7 @@ static int decode_locked(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* 
                          const ctmr_entry_view* v, ctmr_decode_stats* stats) {
   HIPCHK(e, hipSetDevice(e->device));
   if (stats) memset(stats, 0, sizeof *stats);
+  e->pending_issuers.clear();
   if (n == 0) return CTMR_OK;
   if (n >= 0xfffffff0ull) return fail(e, CTMR_E_INVAL, "batch too large (n < 2^32-16)");
   if (!v->cert_start || !v->cert_end || !v->issuer_idx || !v->entry_type)
@@ -990,6 +993,13 @@ static int decode_locked(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* 
     }
     const uint32_t fresh = (uint32_t)off.size() - 1;
     if (fresh == 0) return fail(e, CTMR_E_HIP, "Chain[0] match reported unregistered certificates but none is new");
+    if (!e->auto_register) {
+      e->pending_issuers.clear();
+      for (uint32_t k = 0; k < fresh; k++)
+        e->pending_issuers.emplace_back((const char*)blob.data() + off[k], (size_t)(off[k + 1] - off[k]));
+      return fail(e, CTMR_E_NOTFOUND, "%u Chain[0] certificate(s) are not registered (issuer auto-registration is off: "
+                  "ctmr_pending_issuers, ctmr_add_issuers, then call again)", fresh);
+    }
     blob.resize(blob.size() + CTMR_PAYLOAD_PAD);
     if ((r = add_issuers_locked(e, blob.data(), off.data(), fresh, nullptr))) return r;
     added += fresh;
@@ -1114,6 +1124,21 @@ int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds
   e->last_o_start = (size_t)((uint8_t*)v.cert_start - (uint8_t*)e->d_scratch[SC_VIEW]);
   e->last_o_end = (size_t)((uint8_t*)v.cert_end - (uint8_t*)e->d_scratch[SC_VIEW]);
   return CTMR_OK;
+}
+
+int ctmr_set_issuer_autoregister(ctmr_engine* e, int on) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  e->auto_register = on != 0;
+  return CTMR_OK;
+}
+
+int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need, uint64_t* count) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  int rc = CTMR_OK;
+  serialise(e->pending_issuers, out, cap, need, count, &rc);
+  return rc;
 }
 
 // ------------------------------------------------------------------ IssuerMetadata on device (N3)
@@ -1330,20 +1355,17 @@ int ctmr_pem_new(ctmr_engine* e, uint8_t* out, size_t cap, uint64_t* pem_offsets
 
 // ------------------------------------------------------------------ cross-GPU key exchange
 
-int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
-                                const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
-                                ctmr_record* d_records, uint32_t world, void* d_keys_out,
-                                uint64_t* counts) {
-  if (!e || !d_records || !d_keys_out || !counts || world == 0 || world > MAX_WORLD ||
-      (n && (!d_payload || !d_offsets || !d_issuer_idx)))
-    return CTMR_E_INVAL;
-  std::lock_guard<std::mutex> g(e->mu);
+static int exchange_export_locked(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                                  const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                                  ctmr_record* d_records, uint32_t world, void* d_keys_out, uint64_t* counts,
+                                  const uint64_t* d_ends, uint64_t blob_bytes) {
   HIPCHK(e, hipSetDevice(e->device));
   for (uint32_t w = 0; w < world; w++) counts[w] = 0;
   if (n == 0) return CTMR_OK;
   if (n >= 0xfffffff0ull) return fail(e, CTMR_E_INVAL, "batch too large (n < 2^32-16)");
   int r;
-  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, false))) return r;
+  if ((r = launch_map(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, false, nullptr, d_ends,
+                      blob_bytes + CTMR_PAYLOAD_PAD))) return r;
   const uint64_t nb = (n + 1023) / 1024;
   const uint64_t ncnt = (uint64_t)world * nb;
   if ((r = ensure(e, SC_SLOTID, n))) return r;                 // owner byte per entry
@@ -1353,7 +1375,7 @@ int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const 
   uint32_t* d_cnt = (uint32_t*)e->d_scratch[SC_BLKNEW];
   uint64_t* d_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
   InsertArgs ia;
-  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.ends = nullptr; ia.canon = e->d_canon;
+  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.ends = d_ends; ia.canon = e->d_canon;
   ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = nullptr; ia.n = n; ia.epoch = e->epoch;
   HIPCHK(e, hipMemsetAsync(d_cnt, 0, (ncnt + 1) * 4, e->stream));
   hipLaunchKernelGGL(k_key_count, dim3((unsigned)nb), dim3(1024), 0, e->stream, ia, world, nb, d_owner, d_cnt);
@@ -1367,6 +1389,29 @@ int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const 
   HIPCHK(e, hipGetLastError());
   for (uint32_t w = 0; w < world; w++) counts[w] = base[w + 1] - base[w];
   return CTMR_OK;
+}
+
+int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                                const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
+                                ctmr_record* d_records, uint32_t world, void* d_keys_out,
+                                uint64_t* counts) {
+  if (!e || !d_records || !d_keys_out || !counts || world == 0 || world > MAX_WORLD ||
+      (n && (!d_payload || !d_offsets || !d_issuer_idx)))
+    return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return exchange_export_locked(e, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, world, d_keys_out,
+                                counts, nullptr, 0);
+}
+
+int ctmr_exchange_export_view_device(ctmr_engine* e, const uint8_t* d_blob, uint64_t blob_bytes,
+                                     const ctmr_entry_view* v, uint64_t n, ctmr_record* d_records,
+                                     uint32_t world, void* d_keys_out, uint64_t* counts) {
+  if (!e || !v || !d_records || !d_keys_out || !counts || world == 0 || world > MAX_WORLD ||
+      (n && (!d_blob || !v->cert_start || !v->cert_end || !v->issuer_idx)))
+    return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  return exchange_export_locked(e, d_blob, v->cert_start, v->issuer_idx, v->entry_type, n, d_records, world, d_keys_out,
+                                counts, v->cert_end, blob_bytes);
 }
 
 int ctmr_exchange_insert_device(ctmr_engine* e, const void* d_keys, uint64_t n_keys, uint8_t* d_flags,

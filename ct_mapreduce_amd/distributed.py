@@ -178,3 +178,52 @@ def run_simulated(rank_objs, shards, new_idx_ptrs=None):
         out.append(r.apply(torch.cat(fl) if world > 1 else fl[0],
                            new_idx_ptrs[k] if new_idx_ptrs else 0))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Raw get-entries shards + global dedup: the key records carry issuer INDICES, so every rank's issuer table must
+# list the same certificates in the same order.  Engines run with issuer auto-registration off; a decode that meets
+# unregistered Chain[0] certificates fails with E_NOTFOUND and lists them; the lists of all ranks are gathered and
+# the union is registered everywhere in one agreed order (bytewise), then the decode is repeated.  New issuers are
+# rare (hundreds per log), so the extra round is too.
+def union_in_agreed_order(pending_lists):
+    """Deterministic registration order for the union of the ranks' pending lists."""
+    return sorted(set(d for lst in pending_lists for d in lst))
+
+
+def decode_synchronised(engines_or_engine, decode_calls, gather=None):
+    """decode_calls[r]() runs rank r's decode (it may raise CtmrError E_NOTFOUND); gather(list) → list of every
+    rank's list (default: torch.distributed.all_gather_object).  With a list of engines (tests: several ranks in one
+    process) no collective is used.  Returns each call's result."""
+    from . import _native as N
+    from .engine import CtmrError
+    single = not isinstance(engines_or_engine, (list, tuple))
+    engines = [engines_or_engine] if single else list(engines_or_engine)
+    calls = [decode_calls] if single else list(decode_calls)
+    for _ in range(64):
+        results, pending = [], []
+        for eng, call in zip(engines, calls):
+            try:
+                results.append(call())
+                pending.append([])
+            except CtmrError as ex:
+                if ex.code != N.E_NOTFOUND:
+                    raise
+                results.append(None)
+                pending.append(eng.pending_issuers())
+        if single:
+            if gather is None:
+                import torch.distributed as dist
+                box = [None] * dist.get_world_size()
+                dist.all_gather_object(box, pending[0])
+                everyone = box
+            else:
+                everyone = gather(pending[0])
+        else:
+            everyone = pending
+        fresh = union_in_agreed_order(everyone)
+        if not fresh:
+            return results[0] if single else results
+        for eng in engines:
+            eng.add_issuers(fresh)
+    raise RuntimeError("issuer synchronisation does not converge")

@@ -337,6 +337,33 @@ class Engine:
             C.c_void_p(d_keys_out), counts))
         return [int(c) for c in counts]
 
+    def exchange_export_view(self, d_blob, blob_bytes, view: N.EntryView, n, d_records, world, d_keys_out):
+        counts = (C.c_uint64 * world)()
+        self._ck(self._lib.ctmr_exchange_export_view_device(
+            self._h, C.c_void_p(d_blob), blob_bytes, C.byref(view), n, C.c_void_p(d_records), world,
+            C.c_void_p(d_keys_out), counts))
+        return [int(c) for c in counts]
+
+    def set_issuer_autoregister(self, on: bool):
+        self._ck(self._lib.ctmr_set_issuer_autoregister(self._h, int(bool(on))))
+
+    def pending_issuers(self):
+        """Distinct Chain[0] certificates the last raw-entry call found unregistered (auto-registration off)."""
+        need, cnt = C.c_size_t(), C.c_uint64()
+        rc = self._lib.ctmr_pending_issuers(self._h, None, 0, C.byref(need), C.byref(cnt))
+        if rc not in (0, N.E_RANGE):
+            self._ck(rc)
+        if cnt.value == 0:
+            return []
+        buf = (C.c_uint8 * need.value)()
+        self._ck(self._lib.ctmr_pending_issuers(self._h, buf, need.value, C.byref(need), C.byref(cnt)))
+        raw, out, o = bytes(buf), [], 0
+        while o < len(raw):
+            l = int.from_bytes(raw[o:o + 4], "little")
+            out.append(raw[o + 4:o + 4 + l])
+            o += 4 + l
+        return out
+
     def exchange_insert(self, d_keys, n_keys, d_flags) -> int:
         out = C.c_uint64()
         self._ck(self._lib.ctmr_exchange_insert_device(self._h, C.c_void_p(d_keys), n_keys,

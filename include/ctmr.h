@@ -284,6 +284,18 @@ int ctmr_map_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_
                             ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
 int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n, ctmr_record* records,
                      uint64_t* new_idx, uint64_t* timestamp, ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
+/* Issuer registration policy of the raw-entry calls.  on = 1 (default): a Chain[0] certificate met for the first time
+ * is registered by the call.  on = 0: nothing is registered; when a batch contains unregistered Chain[0]
+ * certificates the decode fails with CTMR_E_NOTFOUND and ctmr_pending_issuers lists them (distinct, [u32 len][DER]…,
+ * ascending log index of first appearance) — for hosts that must keep the issuer tables of several engines
+ * identical (multi-GPU key exchange: DESIGN.md §8): gather the pending lists of all ranks, register the union in
+ * one agreed order with ctmr_add_issuers on every rank, call again. */
+int ctmr_set_issuer_autoregister(ctmr_engine* e, int on);
+int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need, uint64_t* count);
+/* ctmr_exchange_export_device over an entry view (raw get-entries batches; same contract). */
+int ctmr_exchange_export_view_device(ctmr_engine* e, const uint8_t* d_blob, uint64_t blob_bytes,
+                                     const ctmr_entry_view* d_view, uint64_t n, ctmr_record* d_records,
+                                     uint32_t world, void* d_keys_out, uint64_t* counts);
 /* ctmr_pem_encode_device for an entry view: PEM of the certificates d_idx[0..n_idx) names, straight out of the blob. */
 int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* d_view,
                                 const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,

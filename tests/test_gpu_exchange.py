@@ -104,3 +104,70 @@ def test_global_path_equals_local_path_on_one_gpu():
     assert st_glob.n_new == st_local.n_new and list(st_glob.by_status) == list(st_local.by_status)
     assert (e1.issuer_counts() == e2.issuer_counts()).all()
     e1.close(); e2.close()
+
+
+def test_raw_shards_with_synchronised_issuer_registration():
+    """Global dedup fed by RAW get-entries shards: two "ranks" (engines) see the issuers in different orders; with
+    auto-registration off and the pending lists merged in an agreed order their tables stay index-identical, and the
+    key exchange over entry views reproduces the single-stream oracle."""
+    from ct_mapreduce_amd.distributed import decode_synchronised
+    from oracle import oracle as orc
+    world = 2
+    cfg = synth.config(seed=57, n_issuers=24, dup_permille=300, ca_permille=30, expired_permille=30)
+    n_total = 5000
+    whole = synth.host_entries(cfg, 0, n_total)
+    o = orc.Engine(FILT, False, NOW)
+    st, unk, eh, ts = o.raw_batch(whole.blob, whole.bounds)
+    assert 0 < unk.sum() < (st == 0).sum()
+    engines = []
+    for _ in range(world):
+        e = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12)
+        e.set_filter(FILT, False, NOW)
+        e.set_issuer_autoregister(False)
+        engines.append(e)
+    ranks = [GlobalDedupRank(engines[r], r, world, DEV) for r in range(world)]
+    keep, calls, ranges = [], [], []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        raw = synth.host_entries(cfg, lo, hi - lo)
+        n = raw.n
+        d_blob = torch.from_numpy(raw.blob.copy()).to(DEV)
+        d_bounds = torch.from_numpy(raw.bounds.astype(np.int64)).to(DEV)
+        t = {k: torch.zeros(n, dtype=dt, device=DEV) for k, dt in
+             (("start", torch.int64), ("end", torch.int64), ("iss", torch.int32), ("et", torch.uint8))}
+        view = N.EntryView(cert_start=t["start"].data_ptr(), cert_end=t["end"].data_ptr(), issuer_idx=t["iss"].data_ptr(),
+                           entry_type=t["et"].data_ptr(), timestamp=None, chain0_start=None, chain0_len=None)
+        rec = torch.zeros(n * 32, dtype=torch.uint8, device=DEV)
+        new = torch.zeros(n, dtype=torch.int64, device=DEV)
+        keep.append((d_blob, d_bounds, t, view, rec, new, n, int(raw.bounds[-1])))
+        calls.append(lambda e=engines[r], b=d_blob, bd=d_bounds, n=n, v=view: e.decode_entries_device(b.data_ptr(), bd.data_ptr(), n, v))
+        ranges.append((lo, hi))
+    with pytest.raises(ctmr.CtmrError) as ei:                   # nothing is registered silently
+        calls[0]()
+    assert ei.value.code == N.E_NOTFOUND and len(engines[0].pending_issuers()) > 0
+    decode_synchronised(engines, calls)
+    assert engines[0].issuer_count() == engines[1].issuer_count() > 0
+    for k in range(engines[0].issuer_count()):                  # index-identical issuer tables
+        assert engines[0].issuer_id(k) == engines[1].issuer_id(k)
+    # key exchange over the views (same data movement as run_simulated, export through the view entry point)
+    counts = []
+    for r in range(world):
+        d_blob, _, _, view, rec, _, n, nbytes = keep[r]
+        ranks[r].n, ranks[r].d_records = n, rec.data_ptr()
+        ranks[r].keys = torch.empty(max(n, 1) * 64, dtype=torch.uint8, device=DEV)
+        ranks[r].send_counts = engines[r].exchange_export_view(d_blob.data_ptr(), nbytes, view, n, rec.data_ptr(), world,
+                                                               ranks[r].keys.data_ptr())
+        ranks[r].n_keys = sum(ranks[r].send_counts)
+        counts.append(ranks[r].send_counts)
+    for ow, rk in enumerate(ranks):
+        rk.insert(torch.cat([ranks[s].partition(ow) for s in range(world)]), [counts[s][ow] for s in range(world)])
+    for r, rk in enumerate(ranks):
+        stats = rk.apply(torch.cat([ranks[ow].flags_for(r) for ow in range(world)]), keep[r][5].data_ptr())
+        lo, hi = ranges[r]
+        rec = keep[r][4].cpu().numpy().view(RECORD_DTYPE)
+        assert (rec["status"] == st[lo:hi]).all()
+        assert (((rec["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all()
+        assert stats.n_new == int(unk[lo:hi].sum())
+    assert sum(e.total_count() for e in engines) == o.total_count()
+    for e in engines:
+        e.close()
