@@ -1385,12 +1385,11 @@ class FilesystemDatabase {  // storage/filesystemdatabase.go
     const uint64_t n = raw.size();
     BatchResult res;
     if (n == 0) return res;
-    std::string blob = raw.blob;
-    blob.append(CTMR_PAYLOAD_PAD + 16, '\0');
     res.records.resize(n);
     res.new_idx.resize(n);
     res.timestamps.resize(n);
-    engine_->ck(ctmr_map_entries(engine_->handle(), (const uint8_t*)blob.data(), raw.bounds.data(), n, res.records.data(),
+    // host variant: the library stages the blob itself and pads the device copy — no copy, no padding here
+    engine_->ck(ctmr_map_entries(engine_->handle(), (const uint8_t*)raw.blob.data(), raw.bounds.data(), n, res.records.data(),
                                  res.new_idx.data(), res.timestamps.data(), &res.decode, &res.stats));
     res.new_idx.resize(res.stats.n_new);
     afterMap(res, [&](uint64_t i) { return raw.Certificate(i); });
