@@ -175,11 +175,14 @@ def main():
     ap.add_argument("--pem", action="store_true",
                     help="also time the PEM write-back kernels (k_pem_len + scan + k_pem_encode, SURVEY §8(f) N1) over "
                          "the first 16M entries of the NEW list")
-    ap.add_argument("--global-dedup", action="store_true",
-                    help="BASELINE config 5's cross-GPU form: every step runs the owner-computes key exchange "
-                         "(distributed.run_global_dedup: export → all-to-all over RCCL → owner insert → flags back → apply) "
-                         "instead of the shard-local reduce; at N=1 the exchange is local and this measures the three "
-                         "exchange-mode kernels")
+    ap.add_argument("--global-dedup", nargs="?", const="owner", default=None, choices=["owner", "bloom"],
+                    help="BASELINE config 5's cross-GPU form instead of the shard-local reduce.  owner (default): the "
+                         "owner-computes key exchange (distributed.run_global_dedup: export → all-to-all over RCCL → "
+                         "owner insert → flags back → apply); at N=1 the exchange is local and this measures the three "
+                         "exchange-mode kernels.  bloom: the north_star's all-gather of per-GPU Bloom filters as an exact "
+                         "pre-filter (distributed.run_bloom_dedup: local insert → filter all-gather → probe → exact "
+                         "lookup at the peers whose filter matched → apply); at N=1 this measures the add/probe/apply "
+                         "kernels on top of the ordinary reduce")
     ap.add_argument("--raw", action="store_true",
                     help="feed raw get-entries blobs (leaf_input ‖ extra_data, ≈3.06 KB per entry): adds the "
                          "LogEntryFromLeaf decode and the Chain[0] → issuer match in front of the map (SURVEY §8(f) N2); "
@@ -213,7 +216,10 @@ def main():
         dist = None
 
     filt = b"Synth Issuer 0,Synth Issuer 1"      # BASELINE config 3: passes issuers 000-199
-    cfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=0,
+    # the global-dedup modes run BASELINE config 5's corpus: 10 % of the entries repeat an earlier entry's key —
+    # anywhere earlier in the stream, i.e. usually in another rank's shard
+    dup_permille = 100 if args.global_dedup else 0
+    cfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
                        ca_permille=10, expired_permille=10, profile=1 if args.mixed else 0)
     now = synth.BASE_TIME
     issuers = synth.issuers(cfg)
@@ -292,9 +298,13 @@ def main():
     counts_dev = torch.zeros(len(issuers), dtype=torch.int64, device=dev)
 
     gd_rank = None
-    if args.global_dedup:
+    bloom_rank = None
+    if args.global_dedup == "owner":
         from ct_mapreduce_amd.distributed import GlobalDedupRank, run_global_dedup
         gd_rank = GlobalDedupRank(eng, rank, world, dev)
+    elif args.global_dedup == "bloom":
+        from ct_mapreduce_amd.distributed import BloomDedupRank, run_bloom_dedup
+        bloom_rank = BloomDedupRank(eng, rank, world, dev, pow2_at_least(16 * E))   # ≈16 filter bits per key held
     dstats = []
     meta_ms, meta_items = [], []
     d_items = torch.empty(32 * (1 << 22), dtype=torch.uint8, device=dev) if args.meta else None
@@ -309,6 +319,9 @@ def main():
         elif gd_rank is not None:
             st = run_global_dedup(gd_rank, d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
                                   d_rec.data_ptr(), d_new.data_ptr())
+        elif bloom_rank is not None:
+            st = run_bloom_dedup(bloom_rank, d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
+                                 d_rec.data_ptr(), d_new.data_ptr(), order_base=rank * E)
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
                                       E, d_rec.data_ptr(), d_new.data_ptr())
@@ -362,7 +375,7 @@ def main():
             pass
 
     n_total = E * world
-    if gd_rank is not None:     # exchange mode has no per-kernel events: the map time is not separable
+    if gd_rank is not None or bloom_rank is not None:   # no per-kernel events here: the map time is not separable
         ms_map = [dt / args.steps * 1e3]
     value = n_total * args.steps / dt
     alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E     # raw mode: payload_bytes is the whole blob — see "raw"
@@ -422,7 +435,29 @@ def main():
         out["pem"] = {"certificates": m, "pem_bytes": int(total), "der_bytes": in_bytes, "ms_wall": min(t_p) * 1e3,
                       "certs_per_s": m / min(t_p), "GBps_read_plus_written": (in_bytes + total) / min(t_p) / 1e9,
                       "first_block_matches_oracle": bool(ok_pem)}
+    if args.global_dedup:
+        # exactness of the GLOBAL dedup against the generator's structure: entry i repeats an earlier entry's key iff
+        # synth_is_dup(i), wherever that earlier entry lives — so this rank's NEW entries are its PASS ∧ ¬dup ones
+        status = d_rec.view(-1, 32)[:E, 0].cpu().numpy()
+        is_new = (d_rec.view(-1, 32)[:E, 1].cpu().numpy() & 2) != 0
+        dup = synth_is_dup(cfg.seed, rank * E, E, dup_permille, np)
+        bad = int((is_new != ((status == 0) & ~dup)).sum()) + int(int(stats.n_new) != int(is_new.sum()))
+        if dist is not None:
+            t = torch.tensor([bad, int(stats.n_new)], dtype=torch.int64, device=dev)
+            dist.all_reduce(t)
+            bad, n_new_all = int(t[0].item()), int(t[1].item())
+        else:
+            n_new_all = int(stats.n_new)
+        out["result"]["global_dedup"] = {"mode": args.global_dedup, "n_new_all_ranks": n_new_all,
+                                         "entries_disagreeing_with_generator": bad}
+    if bloom_rank is not None:
+        out["config"]["parallelism"] = f"log-index shards x{world} + Bloom-filter all-gather pre-filter + exact lookup (global dedup)"
+        out["roofline"]["kernel"] = "whole Bloom-mode step (map + insert + filter add + all-gather + probe + lookup + apply)"
+        out["roofline"]["note"] = "avg_launch_ms is the wall time of the whole step, not one kernel"
+        out["result"]["global_dedup"].update({"filter_bytes_per_rank": bloom_rank.n_words * 8,
+                                              "key_records_sent_by_rank0": int(bloom_rank.n_keys)})
     if gd_rank is not None:
+        out["result"]["global_dedup"]["key_records_sent_by_rank0"] = int(gd_rank.n_keys)
         out["config"]["parallelism"] = f"log-index shards x{world} + owner-computes key exchange (global dedup)"
         out["roofline"]["kernel"] = "whole exchange-mode step (export + all-to-all + owner insert + apply)"
         out["roofline"]["note"] = "avg_launch_ms is the wall time of the whole step, not one kernel"

@@ -105,6 +105,13 @@ SIGNATURES = {
     "ctmr_exchange_insert_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "ctmr_exchange_apply_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
                                              C.POINTER(BatchStats)]),
+    "ctmr_bloom_config": (C.c_int, [_P, C.c_uint64, _P]),
+    "ctmr_bloom_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "ctmr_bloom_add_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
+    "ctmr_bloom_probe_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, C.c_uint64,
+                                          _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ctmr_bloom_lookup_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),
+    "ctmr_bloom_apply_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P, C.POINTER(BatchStats)]),
     "ctmr_pem_encode_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "ctmr_set_issuer_autoregister": (C.c_int, [_P, C.c_int]),
     "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),

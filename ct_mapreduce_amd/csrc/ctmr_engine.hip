@@ -172,6 +172,11 @@ struct ctmr_engine {
   unsigned long long* d_mcount = nullptr;  // [0] arena used [1] items [2] overflow events
   uint64_t meta_n = 0;                     // entries the SC_META scratch describes (the last map call)
   uint32_t meta_epoch = 0;                 // k_meta_new launches so far
+  // Bloom-variant global dedup: cumulative filter of the keys this rank found locally new
+  unsigned long long* d_bloom = nullptr;
+  uint64_t bloom_words = 0;
+  bool bloom_owned = false;                // false: the filter lives in a caller-owned buffer
+  uint32_t bloom_round_epoch = 0;          // epoch of the batch of the current round (0 = empty batch)
   bool last_meta_valid = false;            // SC_ITEMS holds the items of the last host batch
   uint64_t last_meta_items = 0;
   // the last ctmr_map_entries (host variant): ctmr_pem_new encodes from its view
@@ -474,6 +479,7 @@ void ctmr_destroy(ctmr_engine* e) {
   (void)hipFree(e->d_idb_der); (void)hipFree(e->d_idb_off); (void)hipFree(e->d_idb_len);
   (void)hipFree(e->d_idb_ht); (void)hipFree(e->d_pend); (void)hipFree(e->d_unreg); (void)hipFree(e->d_dcount);
   (void)hipFree(e->d_meta_slots); (void)hipFree(e->d_meta_arena); (void)hipFree(e->d_mcount);
+  if (e->bloom_owned) (void)hipFree(e->d_bloom);
   for (auto p : e->d_scratch) if (p) (void)hipFree(p);
   for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1489,6 +1495,180 @@ int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t 
   return CTMR_OK;
 }
 
+// ------------------------------------------------------------------ cross-GPU dedup, Bloom pre-filter variant
+
+int ctmr_bloom_config(ctmr_engine* e, uint64_t bits, void* d_words) {
+  if (!e) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (bits < 4096 || bits > (1ull << 40) || (bits & (bits - 1)))
+    return fail(e, CTMR_E_INVAL, "Bloom filter size must be a power of two in [2^12, 2^40] bits");
+  if ((uintptr_t)d_words & 7) return fail(e, CTMR_E_INVAL, "Bloom filter buffer must be 8-byte aligned");
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (e->d_bloom && e->bloom_owned) (void)hipFree(e->d_bloom);
+  e->d_bloom = nullptr;
+  e->bloom_words = 0;
+  if (d_words) {
+    e->d_bloom = (unsigned long long*)d_words;
+    e->bloom_owned = false;
+  } else {
+    if (hipMalloc(&e->d_bloom, bits / 8) != hipSuccess) {
+      (void)hipGetLastError();
+      e->d_bloom = nullptr;
+      return fail(e, CTMR_E_NOMEM, "Bloom filter: %llu bytes", (unsigned long long)(bits / 8));
+    }
+    e->bloom_owned = true;
+  }
+  e->bloom_words = bits / 64;
+  e->bloom_round_epoch = 0;
+  HIPCHK(e, hipMemsetAsync(e->d_bloom, 0, bits / 8, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return CTMR_OK;
+}
+
+int ctmr_bloom_device(ctmr_engine* e, void** d_words, uint64_t* n_words) {
+  if (!e || !d_words) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  if (!e->d_bloom) return fail(e, CTMR_E_INVAL, "ctmr_bloom_config has not been called");
+  *d_words = e->d_bloom;
+  if (n_words) *n_words = e->bloom_words;
+  return CTMR_OK;
+}
+
+static void bloom_args(ctmr_engine* e, InsertArgs& ia, const uint8_t* d_payload, const uint64_t* d_offsets,
+                       const uint64_t* d_ends, uint64_t n, const ctmr_record* d_records) {
+  ia.records = d_records; ia.payload = d_payload; ia.offsets = d_offsets; ia.ends = d_ends; ia.canon = e->d_canon;
+  ia.table = e->table; ia.mask = e->nslots - 1; ia.slot_id = nullptr; ia.ent = nullptr; ia.n = n; ia.epoch = e->epoch;
+}
+
+int ctmr_bloom_add_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets, const uint64_t* d_ends,
+                          uint64_t n, const ctmr_record* d_records) {
+  if (!e || (n && (!d_payload || !d_offsets))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->d_bloom) return fail(e, CTMR_E_INVAL, "ctmr_bloom_config has not been called");
+  e->bloom_round_epoch = n ? e->epoch : 0;
+  if (n == 0) return CTMR_OK;
+  if (!d_records) d_records = (const ctmr_record*)e->d_scratch[SC_RECORDS];
+  if (!d_records) return fail(e, CTMR_E_INVAL, "no records: run ctmr_map_*_device on this batch first");
+  InsertArgs ia;
+  bloom_args(e, ia, d_payload, d_offsets, d_ends, n, d_records);
+  hipLaunchKernelGGL(k_bloom_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia, e->d_bloom,
+                     e->bloom_words - 1);
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller all-gathers the filter on its own stream next
+  HIPCHK(e, hipGetLastError());
+  return CTMR_OK;
+}
+
+int ctmr_bloom_probe_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                            const uint64_t* d_ends, uint64_t n, const ctmr_record* d_records, const void* d_filters,
+                            uint32_t world, uint32_t rank, uint64_t order_base, void* d_keys_out, uint64_t keys_cap,
+                            uint64_t* counts) {
+  if (!e || !counts || !d_filters || world == 0 || world > MAX_WORLD || rank >= world ||
+      (n && (!d_payload || !d_offsets)) || (keys_cap && !d_keys_out))
+    return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->d_bloom) return fail(e, CTMR_E_INVAL, "ctmr_bloom_config has not been called");
+  for (uint32_t w = 0; w < world; w++) counts[w] = 0;
+  if (n == 0) return CTMR_OK;
+  if (!d_records) d_records = (const ctmr_record*)e->d_scratch[SC_RECORDS];
+  if (!d_records) return fail(e, CTMR_E_INVAL, "no records: run ctmr_map_*_device on this batch first");
+  const uint64_t nb = (n + 1023) / 1024;
+  const uint64_t ncnt = (uint64_t)world * nb;
+  int r;
+  if ((r = ensure(e, SC_SLOTID, n * 4))) return r;              // hit mask u16 per entry
+  if ((r = ensure(e, SC_BLKNEW, (ncnt + 1) * 4))) return r;
+  if ((r = ensure(e, SC_BLKBASE, (ncnt + 1) * 8))) return r;
+  uint16_t* d_hit = (uint16_t*)e->d_scratch[SC_SLOTID];
+  uint32_t* d_cnt = (uint32_t*)e->d_scratch[SC_BLKNEW];
+  uint64_t* d_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
+  InsertArgs ia;
+  bloom_args(e, ia, d_payload, d_offsets, d_ends, n, d_records);
+  HIPCHK(e, hipMemsetAsync(d_cnt, 0, (ncnt + 1) * 4, e->stream));
+  hipLaunchKernelGGL(k_bloom_probe, dim3((unsigned)nb), dim3(1024), 0, e->stream, ia,
+                     (const unsigned long long*)d_filters, e->bloom_words, world, rank, nb, d_hit, d_cnt);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_cnt, ncnt + 1, d_base);
+  std::vector<uint64_t> base(world + 1);
+  for (uint32_t w = 0; w <= world; w++)
+    HIPCHK(e, hipMemcpyAsync(&base[w], d_base + (uint64_t)w * nb, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  for (uint32_t w = 0; w < world; w++) counts[w] = base[w + 1] - base[w];
+  if (base[world] > keys_cap)
+    return fail(e, CTMR_E_RANGE, "key buffer too small: %llu records needed", (unsigned long long)base[world]);
+  if (base[world] == 0) return CTMR_OK;
+  hipLaunchKernelGGL(k_bloom_scatter, dim3((unsigned)nb), dim3(1024), 0, e->stream, ia, world, nb,
+                     (const uint16_t*)d_hit, (const uint64_t*)d_base, (unsigned long long)order_base,
+                     (KeyRec*)d_keys_out);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  return CTMR_OK;
+}
+
+int ctmr_bloom_lookup_device(ctmr_engine* e, const void* d_keys, uint64_t n_keys, uint64_t order_base,
+                             uint8_t* d_flags) {
+  if (!e || (n_keys && (!d_keys || !d_flags))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (n_keys == 0) return CTMR_OK;
+  hipLaunchKernelGGL(k_keys_lookup, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, e->stream,
+                     (const KeyRec*)d_keys, n_keys, (const Slot*)e->table, e->nslots - 1, e->bloom_round_epoch,
+                     (unsigned long long)order_base, d_flags);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  return CTMR_OK;
+}
+
+int ctmr_bloom_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, const void* d_keys_sent,
+                            const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx, ctmr_batch_stats* stats) {
+  if (!e || (n_keys && (!d_keys_sent || !d_flags))) return CTMR_E_INVAL;
+  std::lock_guard<std::mutex> g(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (n == 0) return CTMR_OK;
+  if (!d_records) d_records = (ctmr_record*)e->d_scratch[SC_RECORDS];
+  if (!d_records) return fail(e, CTMR_E_INVAL, "no records: run ctmr_map_*_device on this batch first");
+  const uint64_t nb = (n + 1023) / 1024;
+  int r;
+  if ((r = ensure(e, SC_BLKNEW, nb * 4))) return r;
+  if ((r = ensure(e, SC_BLKBASE, nb * 8))) return r;
+  uint32_t* d_blk_new = (uint32_t*)e->d_scratch[SC_BLKNEW];
+  uint64_t* d_blk_base = (uint64_t*)e->d_scratch[SC_BLKBASE];
+  HIPCHK(e, hipMemsetAsync(e->d_stats, 0, sizeof(DevStats), e->stream));
+  if (n_keys) {
+    e->pairs_dirty = true;
+    hipLaunchKernelGGL(k_bloom_apply, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, e->stream,
+                       (const KeyRec*)d_keys_sent, d_flags, n_keys, d_records, e->table, e->nslots - 1,
+                       e->issuer_counts);
+  }
+  hipLaunchKernelGGL(k_count_new_flags, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records, n,
+                     d_blk_new);
+  hipLaunchKernelGGL(k_status_hist, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(1024), 0, e->stream,
+                     (const ctmr_record*)d_records, n, nb, e->d_stats);
+  if (d_new_idx) {
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records,
+                       (const uint32_t*)nullptr, n, (const uint64_t*)d_blk_base, d_new_idx);
+  }
+  DevStats hs;
+  HIPCHK(e, hipMemcpyAsync(&hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
+  std::vector<uint32_t> bn(nb);
+  HIPCHK(e, hipMemcpyAsync(bn.data(), d_blk_new, nb * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipGetLastError());
+  if (stats) {
+    stats->n = n;
+    for (int k = 0; k < CTMR_ST__COUNT; k++) stats->by_status[k] = hs.by_status[k];
+    uint64_t nn = 0;
+    for (auto v : bn) nn += v;
+    stats->n_new = nn;                 // long-serial entries that were new in the host-side set keep their flag
+    stats->n_host_set = hs.n_host;
+    stats->n_dup = hs.by_status[CTMR_ST_PASS] - nn;
+  }
+  return CTMR_OK;
+}
+
 // ------------------------------------------------------------------ RemoteCache set methods
 
 int ctmr_set_insert(ctmr_engine* e, const char* key, size_t kl, const uint8_t* m, size_t ml, int* was_new) {
@@ -1733,6 +1913,8 @@ int ctmr_reset_known(ctmr_engine* e) {
   for (auto it = e->hstore.begin(); it != e->hstore.end();)
     it = it->first.compare(0, 9, "serials::") == 0 ? e->hstore.erase(it) : std::next(it);
   e->host_issuer_counts.clear();
+  if (e->d_bloom) HIPCHK(e, hipMemsetAsync(e->d_bloom, 0, e->bloom_words * 8, e->stream));
+  e->bloom_round_epoch = 0;
   return CTMR_OK;
 }
 

@@ -1433,6 +1433,191 @@ __global__ void __launch_bounds__(1024) k_status_hist(const ctmr_record* records
     atomicAdd(&stats->n_host, (unsigned long long)hist[CTMR_ST__COUNT]);
 }
 
+// ------------------------------------------------------------------ cross-GPU dedup, Bloom pre-filter variant
+// The all-gather of per-GPU Bloom fingerprints `north_star` names, made exact.  Every rank keeps
+// its OWN known-certificate table (the ordinary fused map + insert runs unchanged) and a cumulative Bloom filter of
+// every key it ever found locally new.  Per round: the filters are all-gathered; a rank probes its locally-new keys
+// against the other ranks' filters — a Bloom filter has no false negatives, so a key that hits no peer filter exists
+// on no other rank and needs no exchange at all; a key that hits peer p's filter (a real cross-rank duplicate or a
+// false positive) is sent to p, which looks it up EXACTLY in its table and answers "known here before you": found
+// with an older epoch, or found in this round under a lower global order (= lower log index).  Exactly one rank — the
+// lowest log index — keeps WasUnknown for each key.  The asker then clears the flag, takes the key out of its
+// per-issuer count and marks its slot SHADOW (known for dedup, not counted or listed: the sets of the ranks stay
+// disjoint, so Σ over ranks of SCARD / per-issuer counts is the global value, as in the owner-computes variant).
+//
+// Filter: blocked Bloom, one 64-bit word per key, 4 bits inside it — one 8-byte atomicOr to add, one 8-byte load per
+// peer to probe.  At 16 filter bits per key the false-positive rate is ≈ 0.5 % (only extra key traffic, never a wrong
+// answer).
+constexpr unsigned long long SLOT_SHADOW = 1ull << 63;  // Slot.w[2]: key is counted by another rank
+
+__host__ __device__ inline void bloom_pos(unsigned long long h, uint64_t wmask, uint64_t& word,
+                                          unsigned long long& bits) {
+  const unsigned long long g = mixk(h ^ 0xa0761d6478bd642full);
+  word = g & wmask;
+  bits = (1ull << ((g >> 40) & 63)) | (1ull << ((g >> 46) & 63)) | (1ull << ((g >> 52) & 63)) |
+         (1ull << ((g >> 58) & 63));
+}
+
+// key of entry i when it is a locally-new member of the device set (long serials stay shard-local on the host)
+__device__ __forceinline__ bool entry_new_key(const InsertArgs& a, uint64_t i, unsigned long long& meta,
+                                              unsigned long long s[5]) {
+  const uint32_t head = *(const uint32_t*)(a.records + i);
+  if ((head & 0xffu) != CTMR_ST_PASS || !((head >> 8) & CTMR_FL_WAS_UNKNOWN)) return false;
+  return entry_key(a, i, meta, s);
+}
+
+__global__ void __launch_bounds__(256) k_bloom_add(InsertArgs a, unsigned long long* words, uint64_t wmask) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  unsigned long long meta, s[5];
+  if (!entry_new_key(a, i, meta, s)) return;
+  uint64_t word;
+  unsigned long long bits;
+  bloom_pos(key_hash(meta, s), wmask, word, bits);
+  if ((ld_agent(&words[word]) & bits) != bits) atomicOr(&words[word], bits);
+}
+
+// pass A: peers whose filter holds the key (bit p of hit_out[i]) + per-(peer, 1024-entry block) counts
+__global__ void __launch_bounds__(1024) k_bloom_probe(InsertArgs a, const unsigned long long* filters,
+                                                      uint64_t n_words, uint32_t world, uint32_t rank, uint64_t nb,
+                                                      uint16_t* hit_out, uint32_t* cnt) {
+  __shared__ uint32_t c[MAX_WORLD];
+  if (threadIdx.x < MAX_WORLD) c[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  uint32_t hit = 0;
+  if (i < a.n) {
+    unsigned long long meta, s[5];
+    if (entry_new_key(a, i, meta, s)) {
+      uint64_t word;
+      unsigned long long bits;
+      bloom_pos(key_hash(meta, s), n_words - 1, word, bits);
+      for (uint32_t p = 0; p < world; p++)
+        if (p != rank && (filters[(uint64_t)p * n_words + word] & bits) == bits) hit |= 1u << p;
+    }
+    hit_out[i] = (uint16_t)hit;
+  }
+  for (uint32_t w = 0; w < world; w++) {
+    const unsigned long long m = __ballot((hit >> w) & 1u);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[w], (uint32_t)__popcll(m));
+  }
+  __syncthreads();
+  if (threadIdx.x < world) cnt[(uint64_t)threadIdx.x * nb + blockIdx.x] = c[threadIdx.x];
+}
+
+// pass B: stable scatter of the key records into the per-peer partitions (a key goes to every peer it hit);
+// KeyRec.owner = destination, KeyRec.pad = global order of the entry (order_base + batch index)
+__global__ void __launch_bounds__(1024) k_bloom_scatter(InsertArgs a, uint32_t world, uint64_t nb,
+                                                        const uint16_t* hit_in, const uint64_t* base,
+                                                        unsigned long long order_base, KeyRec* out) {
+  __shared__ uint32_t wc[16][MAX_WORLD];
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t hit = i < a.n ? hit_in[i] : 0u;
+  uint32_t my_rank[MAX_WORLD];
+  for (uint32_t w = 0; w < world; w++) {
+    const unsigned long long m = __ballot((hit >> w) & 1u);
+    if (lane == 0) wc[wv][w] = (uint32_t)__popcll(m);
+    my_rank[w] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (hit) {
+    unsigned long long meta, s[5];
+    entry_key(a, i, meta, s);
+    const unsigned long long order = order_base + i;
+    for (uint32_t w = 0; w < world; w++) {
+      if (!((hit >> w) & 1u)) continue;
+      uint32_t before = 0;
+      for (uint32_t k = 0; k < wv; k++) before += wc[k][w];
+      uint4* q = (uint4*)(out + base[(uint64_t)w * nb + blockIdx.x] + before + my_rank[w]);
+      q[0] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+      q[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+      q[2] = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+      q[3] = make_uint4((uint32_t)i, w, (uint32_t)order, (uint32_t)(order >> 32));
+    }
+  }
+}
+
+// read-only find (the batch that filled the table has completed: plain loads)
+__device__ __forceinline__ uint32_t table_find(const Slot* table, uint64_t mask, unsigned long long meta,
+                                               const unsigned long long s[5]) {
+  const unsigned long long h = key_hash(meta, s);
+  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  uint64_t j = h & mask;
+  for (uint64_t probes = 0; probes <= mask; probes++) {
+    const Slot* sl = table + j;
+    const unsigned long long w0 = sl->w[0];
+    if (w0 == 0ull) return SID_NONE;
+    if ((w0 & 0xffffffff00000000ull) == tagw && w0 != SLOT_TOMB) {
+      bool eq = sl->w[1] == meta;
+#pragma unroll
+      for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+      if (eq) return (uint32_t)j;
+    }
+    j = (j + 1) & mask;
+  }
+  return SID_NONE;
+}
+
+// Peer side: flags[k] = 1 when the key is known here before the asker's entry — since an earlier round, or since
+// this round under a lower global order.
+__global__ void __launch_bounds__(256) k_keys_lookup(const KeyRec* keys, uint64_t n, const Slot* table, uint64_t mask,
+                                                     uint32_t round_epoch, unsigned long long order_base,
+                                                     uint8_t* flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const KeyRec k = keys[i];
+  const uint32_t sid = table_find(table, mask, k.meta, k.s);
+  uint8_t f = 0;
+  if (sid != SID_NONE) {
+    const unsigned long long w0 = table[sid].w[0], w2 = table[sid].w[2];
+    f = (uint32_t)w2 != round_epoch || order_base + (uint32_t)w0 < k.pad;
+  }
+  flags[i] = f;
+}
+
+// Asker side: a flagged key loses WasUnknown (once, however many peers flagged it), leaves the per-issuer count and
+// its slot becomes SHADOW.
+__global__ void __launch_bounds__(256) k_bloom_apply(const KeyRec* sent, const uint8_t* flags, uint64_t n_keys,
+                                                     ctmr_record* records, Slot* table, uint64_t mask,
+                                                     unsigned long long* issuer_counts) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool lost = false;
+  uint32_t canon = 0;
+  if (k < n_keys && flags[k] != 0) {
+    const KeyRec kr = sent[k];
+    const uint32_t old = atomicAnd((uint32_t*)(records + kr.src), ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8));
+    if ((old >> 8) & CTMR_FL_WAS_UNKNOWN) {
+      lost = true;
+      canon = (uint32_t)(kr.meta >> 32) & 0xffffffu;
+      const uint32_t sid = table_find(table, mask, kr.meta, kr.s);
+      if (sid != SID_NONE) atomicOr(&table[sid].w[2], SLOT_SHADOW);
+    }
+  }
+  unsigned long long todo = __ballot(lost);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t c = __shfl(canon, leader);
+    const unsigned long long same = __ballot(lost && canon == c) & todo;
+    if ((int)(threadIdx.x & 63) == leader)
+      atomicAdd(&issuer_counts[c], (unsigned long long)(-(long long)__popcll(same)));
+    todo &= ~same;
+  }
+}
+
+// NEW count per 1024-entry block from the record flags (compaction after k_bloom_apply)
+__global__ void __launch_bounds__(1024) k_count_new_flags(const ctmr_record* records, uint64_t n, uint32_t* blk_new) {
+  __shared__ uint32_t c;
+  if (threadIdx.x == 0) c = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  const bool is_new = i < n && (((const uint8_t*)(records + i))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
+  const unsigned long long m = __ballot(is_new);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c, (uint32_t)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0) blk_new[blockIdx.x] = c;
+}
+
 // ------------------------------------------------------------------ PEM write-back
 // pem.EncodeToMemory(&pem.Block{Type: "CERTIFICATE", Bytes: aCert.Raw}) of every newly unknown
 // certificate (storage/filesystemdatabase.go:167-175,196-200): "-----BEGIN CERTIFICATE-----\n",
@@ -2199,9 +2384,10 @@ __global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, un
   } else if (op == 1) {
     result[0] = sid != SID_NONE;
   } else if (sid != SID_NONE) {
+    const bool shadow = (table[sid].w[2] & SLOT_SHADOW) != 0;  // counted by another rank: nothing to take off here
     table[sid].w[0] = SLOT_TOMB;
     table[sid].w[1] = 0;
-    atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
+    if (!shadow) atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
     result[0] = 1;
   }
 }
@@ -2220,8 +2406,10 @@ __global__ void __launch_bounds__(256) k_sweep(Slot* table, uint64_t nslots, int
   const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
   const bool hit = any_key ? ((long long)eh * 3600 <= now) : ((uint32_t)eh == exp_hour_key && canon == canon_key);
   if (!hit) return;
+  const bool shadow = (table[j].w[2] & SLOT_SHADOW) != 0;  // counted by another rank (Bloom-variant global dedup)
   table[j].w[0] = SLOT_TOMB;
   table[j].w[1] = 0;
+  if (shadow) return;
   atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
   atomicAdd(removed, 1ull);
 }
@@ -2233,7 +2421,7 @@ __global__ void __launch_bounds__(256) k_build_pairs(const Slot* table, uint64_t
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= nslots) return;
   const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
-  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID) || (table[j].w[2] & SLOT_SHADOW)) return;
   const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
   if (!pair_add(pairs, pmask, ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1, 1)) atomicAdd(full, 1ull);
 }
@@ -2246,7 +2434,7 @@ __global__ void __launch_bounds__(256) k_list(const Slot* table, uint64_t nslots
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= nslots) return;
   const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
-  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID) || (table[j].w[2] & SLOT_SHADOW)) return;
   if ((uint32_t)w1 != exp_hour_key || ((uint32_t)(w1 >> 32) & 0xffffffu) != canon_key) return;
   const unsigned long long k = atomicAdd(count, 1ull);
   if (k >= cap) return;

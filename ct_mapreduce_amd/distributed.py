@@ -73,16 +73,40 @@ def run_sharded(n_total: int, n_issuers: int, make_batch, map_fn, counts_fn, dev
 # (tests/test_gpu_exchange.py: two engines on one GPU); run_global_dedup() drives one rank over
 # torch.distributed.
 
-class GlobalDedupRank:
+def _share_stream(engine, torch_device):
+    """Run the engine's kernels on torch's current stream of that device: the buffers torch allocates/zeroes and the
+    collectives' waits are ordered on that stream, so the engine's reads and writes of them must be too."""
+    if getattr(torch_device, "type", "cpu") == "cuda" and hasattr(engine, "set_stream"):
+        import torch
+        engine.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
+
+
+class _Buffers:
+    """Grow-only byte buffers kept across rounds (a fresh multi-GB torch.empty per round would put allocator work and
+    first-touch page faults inside every step)."""
+
+    def _buf(self, name, nbytes):
+        import torch
+        have = getattr(self, "_b_" + name, None)
+        if have is None or have.numel() < nbytes:
+            have = None
+            setattr(self, "_b_" + name, None)              # release before growing
+            have = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.dev)
+            setattr(self, "_b_" + name, have)
+        return have[:max(nbytes, 1)]
+
+
+class GlobalDedupRank(_Buffers):
     KEY = 64
 
     def __init__(self, engine, rank, world, torch_device):
         self.eng, self.rank, self.world, self.dev = engine, rank, world, torch_device
+        _share_stream(engine, torch_device)
 
     def export(self, d_payload, d_offsets, d_iss, d_et, n, d_records):
         import torch
         self.n, self.d_records = n, d_records
-        self.keys = torch.empty(max(n, 1) * self.KEY, dtype=torch.uint8, device=self.dev)
+        self.keys = self._buf("keys", max(n, 1) * self.KEY)
         self.send_counts = self.eng.exchange_export(d_payload, d_offsets, d_iss, d_et, n, d_records,
                                                     self.world, self.keys.data_ptr())
         self.n_keys = sum(self.send_counts)
@@ -98,7 +122,7 @@ class GlobalDedupRank:
         import torch
         self.recv_counts = list(recv_counts)
         nrecv = sum(recv_counts)
-        self.flags_out = torch.zeros(max(nrecv, 1), dtype=torch.uint8, device=self.dev)
+        self.flags_out = self._buf("flags_out", nrecv)       # the insert writes every byte
         self.n_new_owned = self.eng.exchange_insert(received.data_ptr(), nrecv, self.flags_out.data_ptr()) \
             if nrecv else 0
         return self.flags_out
@@ -128,7 +152,7 @@ def run_global_dedup(rank_obj: GlobalDedupRank, d_payload, d_offsets, d_iss, d_e
     dist.all_gather(allc, sc)
     recv_counts = [int(allc[s][rank].item()) for s in range(world)]
     K = GlobalDedupRank.KEY
-    recv = torch.empty(max(sum(recv_counts), 1) * K, dtype=torch.uint8, device=dev)
+    recv = rank_obj._buf("recv", sum(recv_counts) * K)
     ops, off = [], 0
     for s in range(world):                      # exchange A: key partitions
         if s == rank:                           # own partition: a local copy, no self send/recv
@@ -144,7 +168,7 @@ def run_global_dedup(rank_obj: GlobalDedupRank, d_payload, d_offsets, d_iss, d_e
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
     rank_obj.insert(recv, recv_counts)
-    flags_mine = torch.zeros(max(sum(send_counts), 1), dtype=torch.uint8, device=dev)
+    flags_mine = rank_obj._buf("flags_mine", sum(send_counts))
     ops, off = [], 0
     for s in range(world):                      # exchange B: flags back, export order = owner-major
         if s == rank:
@@ -177,6 +201,175 @@ def run_simulated(rank_objs, shards, new_idx_ptrs=None):
         fl = [rank_objs[o].flags_for(k) for o in range(world)]
         out.append(r.apply(torch.cat(fl) if world > 1 else fl[0],
                            new_idx_ptrs[k] if new_idx_ptrs else 0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Global dedup across GPUs, Bloom pre-filter variant (BASELINE north_star "all-gather of per-GPU Bloom fingerprints",
+# SURVEY.md §8(e)(i)) — exact, identical results to the owner-computes exchange above.
+#
+#   phase 1  map      the ordinary fused map + insert into the rank's OWN table     (Engine.map_batch_device)
+#   phase 2  add      locally-new keys → this rank's cumulative Bloom filter        (Engine.bloom_add)
+#   all-gather        the filters (n_words × 8 bytes per rank) — the only traffic for keys no other rank holds
+#   phase 3  probe    locally-new keys × the other ranks' filters → one key record per (key, peer that may hold it)
+#                                                                                   (Engine.bloom_probe)
+#   exchange A        key records → those peers
+#   phase 4  lookup   exact, read-only: "known here before you" byte per record     (Engine.bloom_lookup)
+#   exchange B        bytes → askers
+#   phase 5  apply    flagged entries lose WasUnknown and leave the per-issuer count (Engine.bloom_apply)
+#   counts            per-issuer counters all-reduced as in the shard-local mode
+#
+# Against the owner-computes exchange: every key record travels there (64 B × (G−1)/G of all PASS entries); here the
+# filters travel (2 B per key held, to each of the G−1 peers) plus records for cross-rank duplicates and ≈0.5 % false
+# positives per peer.  Fewer bytes for big single rounds and the first rounds of a stream; a long stream's cumulative
+# filter outgrows the per-round key traffic after about three equal rounds (DESIGN.md §8 has the arithmetic).
+
+class BloomDedupRank(_Buffers):
+    KEY = 64
+
+    def __init__(self, engine, rank, world, torch_device, bloom_bits):
+        import torch
+        self.eng, self.rank, self.world, self.dev = engine, rank, world, torch_device
+        _share_stream(engine, torch_device)
+        self.n_words = bloom_bits // 64
+        # all-gather buffer, rank-major; this rank's filter IS row `rank` (caller-owned filter memory)
+        self.filters = torch.zeros((world, self.n_words), dtype=torch.int64, device=torch_device)
+        engine.bloom_config(bloom_bits, self.filters[rank].data_ptr())
+
+    def own_filter(self):
+        return self.filters[self.rank]
+
+    def map(self, d_payload, d_offsets, d_iss, d_et, n, d_records, d_ends=0, order_base=0, view=None,
+            blob_bytes=0):
+        """Phases 1 + 2.  Packed batch, or an entry view (view = N.EntryView over d_payload = the blob)."""
+        self.batch = (d_payload, d_offsets, d_ends, n, d_records)
+        self.order_base = order_base
+        if view is not None:
+            st = self.eng.map_view_device(d_payload, blob_bytes, view, n, d_records)
+        elif n:
+            st = self.eng.map_batch_device(d_payload, d_offsets, d_iss, d_et, n, d_records)
+        else:
+            st = None
+        self.eng.bloom_add(d_payload, d_offsets, d_ends, n, d_records)
+        return st
+
+    def probe(self):
+        """Phase 3 (after the all-gather filled self.filters) → counts per peer."""
+        import torch
+        d_payload, d_offsets, d_ends, n, d_records = self.batch
+        cap = max(1024, n // 4, getattr(self, "_cap", 0))
+        while True:
+            self.keys = self._buf("keys", cap * self.KEY)
+            counts, fits = self.eng.bloom_probe(d_payload, d_offsets, d_ends, n, d_records,
+                                                self.filters.data_ptr(), self.world, self.rank, self.order_base,
+                                                self.keys.data_ptr(), cap)
+            if fits:
+                break
+            cap = sum(counts)
+        self._cap = cap
+        self.send_counts = counts
+        self.n_keys = sum(counts)
+        return counts
+
+    def partition(self, peer):
+        lo = sum(self.send_counts[:peer]) * self.KEY
+        return self.keys[lo:lo + self.send_counts[peer] * self.KEY]
+
+    def lookup(self, received, recv_counts):
+        """Phase 4.  received: key records concatenated in asker-rank order."""
+        import torch
+        self.recv_counts = list(recv_counts)
+        nrecv = sum(recv_counts)
+        self.flags_out = self._buf("flags_out", nrecv)       # the lookup writes every byte
+        if nrecv:
+            self.eng.bloom_lookup(received.data_ptr(), nrecv, self.order_base, self.flags_out.data_ptr())
+        return self.flags_out
+
+    def flags_for(self, asker):
+        lo = sum(self.recv_counts[:asker])
+        return self.flags_out[lo:lo + self.recv_counts[asker]]
+
+    def apply(self, flags_mine, d_new_idx=0):
+        """Phase 5.  flags_mine: one byte per exported record, in export (peer-major) order."""
+        _, _, _, n, d_records = self.batch
+        return self.eng.bloom_apply(d_records, n, self.keys.data_ptr(), flags_mine.data_ptr(), self.n_keys,
+                                    d_new_idx)
+
+
+def _all_to_all_v(rank, world, part_fn, send_counts, recv_counts, out, unit):
+    """part_fn(p) → tensor for peer p (send_counts[p] × unit bytes); out ← what the peers sent, sender-rank order."""
+    import torch.distributed as dist
+    ops, off = [], 0
+    for s in range(world):
+        if s == rank:                               # own partition: a local copy, no self send/recv
+            if recv_counts[s]:
+                out[off * unit:(off + recv_counts[s]) * unit].copy_(part_fn(s))
+            off += recv_counts[s]
+            continue
+        if recv_counts[s]:
+            ops.append(dist.P2POp(dist.irecv, out[off * unit:(off + recv_counts[s]) * unit], s))
+        off += recv_counts[s]
+        if send_counts[s]:
+            ops.append(dist.P2POp(dist.isend, part_fn(s), s))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+
+
+def run_bloom_dedup(rank_obj: BloomDedupRank, d_payload, d_offsets, d_iss, d_et, n, d_records, d_new_idx=0,
+                    order_base=0, d_ends=0, view=None, blob_bytes=0):
+    """One rank's round over torch.distributed (backend nccl = RCCL; gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    world, rank, dev = rank_obj.world, rank_obj.rank, rank_obj.dev
+    rank_obj.map(d_payload, d_offsets, d_iss, d_et, n, d_records, d_ends, order_base, view, blob_bytes)
+    if world > 1:                                   # the Bloom all-gather
+        mine = rank_obj.own_filter().clone()
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(rank_obj.filters, mine)
+        else:
+            rows = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(rows, mine)
+            for p in range(world):
+                if p != rank:
+                    rank_obj.filters[p].copy_(rows[p])
+    send_counts = rank_obj.probe()
+    if world == 1:
+        return rank_obj.apply(rank_obj._buf("flags_mine", 1), d_new_idx)
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    allc = [torch.empty_like(sc) for _ in range(world)]
+    dist.all_gather(allc, sc)
+    recv_counts = [int(allc[s][rank].item()) for s in range(world)]
+    K = BloomDedupRank.KEY
+    recv = rank_obj._buf("recv", sum(recv_counts) * K)
+    _all_to_all_v(rank, world, rank_obj.partition, send_counts, recv_counts, recv, K)      # exchange A
+    rank_obj.lookup(recv, recv_counts)
+    flags_mine = rank_obj._buf("flags_mine", sum(send_counts))
+    _all_to_all_v(rank, world, rank_obj.flags_for, recv_counts, send_counts, flags_mine, 1)  # exchange B
+    return rank_obj.apply(flags_mine, d_new_idx)
+
+
+def run_simulated_bloom(rank_objs, shards, new_idx_ptrs=None, order_bases=None):
+    """All ranks of a world inside ONE process (tests): shards[r] = (d_payload, d_offsets, d_iss, d_et, n,
+    d_records).  Same data movement as run_bloom_dedup with tensor copies instead of collectives."""
+    import torch
+    world = len(rank_objs)
+    for k, r in enumerate(rank_objs):
+        r.map(*shards[k], order_base=order_bases[k] if order_bases else 0)
+    for r in rank_objs:                             # "all-gather"
+        for p, q in enumerate(rank_objs):
+            if q is not r:
+                r.filters[p].copy_(q.own_filter())
+    counts = [r.probe() for r in rank_objs]
+    for o, r in enumerate(rank_objs):
+        parts = [rank_objs[s].partition(o) for s in range(world)]
+        r.lookup(torch.cat(parts) if world > 1 else parts[0], [counts[s][o] for s in range(world)])
+    out = []
+    for k, r in enumerate(rank_objs):
+        fl = [rank_objs[o].flags_for(k) for o in range(world)]
+        fl = torch.cat(fl) if world > 1 else fl[0]
+        if fl.numel() == 0:
+            fl = torch.zeros(1, dtype=torch.uint8, device=r.dev)
+        out.append(r.apply(fl, new_idx_ptrs[k] if new_idx_ptrs else 0))
     return out
 
 

@@ -378,6 +378,48 @@ class Engine:
             C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
         return st
 
+    # ---- cross-GPU global dedup, Bloom pre-filter variant (ctmr.h: ctmr_bloom_*), device pointers as ints
+    def bloom_config(self, bits: int, d_words=0):
+        """d_words: caller-owned device buffer of bits/8 bytes (0 = the library allocates the filter)."""
+        self._ck(self._lib.ctmr_bloom_config(self._h, bits, C.c_void_p(d_words) if d_words else None))
+
+    def bloom_device(self):
+        """(device pointer, n_words) of this rank's cumulative filter (u64 words)."""
+        p, nw = C.c_void_p(), C.c_uint64()
+        self._ck(self._lib.ctmr_bloom_device(self._h, C.byref(p), C.byref(nw)))
+        return int(p.value), int(nw.value)
+
+    def bloom_add(self, d_payload, d_offsets, d_ends, n, d_records=0):
+        self._ck(self._lib.ctmr_bloom_add_device(
+            self._h, C.c_void_p(d_payload) if n else None, C.c_void_p(d_offsets) if n else None,
+            C.c_void_p(d_ends) if d_ends else None, n, C.c_void_p(d_records) if d_records else None))
+
+    def bloom_probe(self, d_payload, d_offsets, d_ends, n, d_records, d_filters, world, rank, order_base,
+                    d_keys_out, keys_cap):
+        """→ (counts per peer, fits): fits False = keys_cap too small, nothing written, call again."""
+        counts = (C.c_uint64 * world)()
+        rc = self._lib.ctmr_bloom_probe_device(
+            self._h, C.c_void_p(d_payload) if n else None, C.c_void_p(d_offsets) if n else None,
+            C.c_void_p(d_ends) if d_ends else None, n, C.c_void_p(d_records) if d_records else None,
+            C.c_void_p(d_filters), world, rank, order_base, C.c_void_p(d_keys_out) if keys_cap else None,
+            keys_cap, counts)
+        if rc == N.E_RANGE:
+            return [int(c) for c in counts], False
+        self._ck(rc)
+        return [int(c) for c in counts], True
+
+    def bloom_lookup(self, d_keys, n_keys, order_base, d_flags):
+        self._ck(self._lib.ctmr_bloom_lookup_device(self._h, C.c_void_p(d_keys) if n_keys else None, n_keys,
+                                                    order_base, C.c_void_p(d_flags) if n_keys else None))
+
+    def bloom_apply(self, d_records, n, d_keys_sent, d_flags, n_keys, d_new_idx=0) -> N.BatchStats:
+        st = N.BatchStats()
+        self._ck(self._lib.ctmr_bloom_apply_device(
+            self._h, C.c_void_p(d_records) if d_records else None, n,
+            C.c_void_p(d_keys_sent) if n_keys else None, C.c_void_p(d_flags) if n_keys else None, n_keys,
+            C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
+        return st
+
     # ---- storage.RemoteCache set methods (storage/types.go:83-102)
     @staticmethod
     def _b(x):

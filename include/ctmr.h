@@ -225,6 +225,44 @@ int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t 
                                const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx,
                                ctmr_batch_stats* stats);
 
+/* ---- cross-GPU global dedup, Bloom pre-filter variant (the "all-gather of per-GPU Bloom fingerprints" of
+ *      BASELINE.json's north_star) — exact, same results as the owner-computes exchange above.
+ *      Every rank keeps its own known-certificate table (plain ctmr_map_*_device calls) plus a cumulative Bloom
+ *      filter of the keys it found locally new.  One round = one map call per rank, then:
+ *   add:    sets the filter bits of the batch's CTMR_FL_WAS_UNKNOWN keys.  The host all-gathers the filters
+ *           (ctmr_bloom_device gives the pointer; n_words × 8 bytes per rank, rank-major in the gathered buffer).
+ *   probe:  tests the batch's locally-new keys against the OTHER ranks' filters and writes one 64-byte key record per
+ *           (key, peer whose filter holds it) into d_keys_out, partitioned by peer, ascending log index inside a
+ *           partition; counts[p] (host) = records for peer p.  A key that hits no peer filter is on no other rank and
+ *           is not exchanged at all.  order_base = global order of entry 0 of this rank's batch (its log index):
+ *           between ranks that meet the same key in the same round the LOWEST order keeps WasUnknown.  When more
+ *           than keys_cap records are needed: CTMR_E_RANGE, counts[] filled, nothing written — call again.
+ *   lookup: the peer looks the received records up in its table (exact, read-only) and writes one byte per record:
+ *           1 = known here before the asker's entry (since an earlier round, or this round under a lower order).
+ *           order_base as given to this rank's own probe.
+ *   apply:  the asker clears CTMR_FL_WAS_UNKNOWN of every flagged entry (once per entry), takes it out of its
+ *           per-issuer count, marks the key's slot as counted elsewhere (it stays known for dedup, but is left out of
+ *           SetCardinality / SetList / the per-issuer counts, so that sums over ranks are the global values),
+ *           compacts new_idx and fills stats.
+ *   d_ends NULL = packed batch (d_offsets has n+1 entries); otherwise entry-view ranges (ctmr_entry_view).
+ *   d_records NULL = the engine's own records of the last map call.  Same issuers in the same order on every rank.
+ *   Serials longer than CTMR_MAX_SERIAL stay shard-local on the host side, as above. ---- */
+/* bits: power of two, 2^12..2^40, ≈16 per key this rank will ever hold.  d_words NULL: the library allocates the
+ * filter; otherwise a caller-owned device buffer of bits/8 bytes (e.g. this rank's row of the all-gather buffer),
+ * zeroed by the call, which must outlive the engine's use of it.  Same size on every rank. */
+int ctmr_bloom_config(ctmr_engine* e, uint64_t bits, void* d_words);
+int ctmr_bloom_device(ctmr_engine* e, void** d_words, uint64_t* n_words);
+int ctmr_bloom_add_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets, const uint64_t* d_ends,
+                          uint64_t n, const ctmr_record* d_records);
+int ctmr_bloom_probe_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
+                            const uint64_t* d_ends, uint64_t n, const ctmr_record* d_records, const void* d_filters,
+                            uint32_t world, uint32_t rank, uint64_t order_base, void* d_keys_out, uint64_t keys_cap,
+                            uint64_t* counts);
+int ctmr_bloom_lookup_device(ctmr_engine* e, const void* d_keys, uint64_t n_keys, uint64_t order_base,
+                             uint8_t* d_flags);
+int ctmr_bloom_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, const void* d_keys_sent,
+                            const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx, ctmr_batch_stats* stats);
+
 /* ---- PEM write-back: replaces pem.EncodeToMemory(&pem.Block{Type: "CERTIFICATE",
  *      Bytes: aCert.Raw}) of FilesystemDatabase.Store (storage/filesystemdatabase.go:167-175,196-200); the host
  *      hands each PEM to StorageBackend.StoreCertificatePEM (storage/localdiskbackend.go:194-199).
