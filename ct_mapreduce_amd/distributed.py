@@ -324,7 +324,7 @@ def run_bloom_dedup(rank_obj: BloomDedupRank, d_payload, d_offsets, d_iss, d_et,
     rank_obj.map(d_payload, d_offsets, d_iss, d_et, n, d_records, d_ends, order_base, view, blob_bytes)
     if world > 1:                                   # the Bloom all-gather
         mine = rank_obj.own_filter().clone()
-        if dist.get_backend() == "nccl":
+        if "nccl" in str(dist.get_backend()):
             dist.all_gather_into_tensor(rank_obj.filters, mine)
         else:
             rows = [torch.empty_like(mine) for _ in range(world)]
