@@ -61,6 +61,26 @@ def cpu_baseline(batch_arrays, issuers, filt, now, sample):
             "host_cores_available": os.cpu_count()}, (st, unk)
 
 
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup quota when there is one (a 256-thread box may be shared out in
+    16-CPU pods), else the affinity mask."""
+    aff = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if q != "max":
+            return min(aff, max(1, -(-int(q) // int(per)))), int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return min(aff, max(1, -(-q // per))), q / per
+    except (OSError, ValueError):
+        pass
+    return aff, None
+
+
 def cpu_baseline_threads(batch_arrays, issuers, filt, now, sample, threads):
     """The same restatement on `threads` host threads: contiguous slices of the sample, one oracle engine (its own
     in-process sets) per thread — T reference processes with -offset/-limit, minus the Redis they would share, so
@@ -197,8 +217,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=6_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="host threads of the all-core cpu_baseline leg (0 = every core this process may run on; 1 = "
-                         "only the one-core leg)")
+                    help="host threads of the all-core cpu_baseline leg (0 = the CPUs this process may use at once: the "
+                         "cgroup quota if there is one, else the affinity mask; 1 = only the one-core leg)")
     ap.add_argument("--cpu-sample-mt", type=int, default=0,
                     help="entries of the all-core leg (default ≈100 k per thread, at most 16 M)")
     ap.add_argument("--meta", action="store_true",
@@ -550,9 +570,10 @@ def main():
                       d_iss[:sample].cpu().numpy().astype(np.uint32))
             base, (ost, ounk) = cpu_baseline(arrays, issuers, filt, now, sample)
             out["cpu_baseline"] = base
-            threads = args.cpu_threads or len(os.sched_getaffinity(0))
+            quota_threads, quota = cpu_quota()
+            threads = args.cpu_threads or quota_threads
             if threads > 1:
-                # … and on every host core of the box: a larger sample of the same batch (≈100 k entries per thread)
+                # … and on every host CPU this process may use: a larger sample of the same batch (≈100 k entries per thread)
                 sample_mt = min(E, args.cpu_sample_mt or min(100_000 * threads, 16_000_000))
                 offs_mt = d_off[: sample_mt + 1].cpu().numpy().astype(np.uint64)
                 nb_mt = int(offs_mt[-1])
@@ -570,7 +591,8 @@ def main():
                     "sample": f"first {sample_mt} entries of the same synthetic batch in {threads} contiguous slices, one "
                               f"oracle/ctmr_oracle.c engine per thread (per-thread in-process sets stand in for the "
                               f"shared Redis; not the Go binary), best of 3, {best[1]:.2f} s",
-                    "host_cores_available": os.cpu_count(), "pass_count_matches_gpu": bool(ok_mt),
+                    "host_cores_available": os.cpu_count(), "cgroup_cpu_quota": quota,
+                    "pass_count_matches_gpu": bool(ok_mt),
                     "one_core": {"value": base["value"], "sample": base["sample"]}}
             # the bench doubles as a parity check on that sample
             rec = d_rec[: sample * 32].cpu().numpy().view(ctmr.engine.RECORD_DTYPE)
