@@ -7,8 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libctmr.so")
 SOURCES = ["ctmr_engine.hip"]
-DEPS = ["ctmr_engine.hip", "kernels.h", "ctmr_dev.h", "der_walk.h", "synth.h",
-        os.path.join("..", "..", "include", "ctmr.h")]
+
+
+def deps():
+    """Every source the library is compiled from: csrc/ (recursively) and the public header."""
+    out = [os.path.join(HERE, "..", "include", "ctmr.h")]
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".hip"))]
+    return out
 
 
 def hipcc():
@@ -22,7 +28,7 @@ def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force=False, verbose=False):

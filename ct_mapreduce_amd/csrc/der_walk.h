@@ -2,7 +2,7 @@
 //
 // One function, walk_cert<Reader>(), written for one-certificate-per-lane execution on
 // CDNA4: every byte access goes through Reader::ld4(pos), a 4-byte little-endian window at an
-// arbitrary byte position (LDS tile or global memory — kernels.hip supplies both), so one
+// arbitrary byte position (LDS tile or global memory — kernels/readers.h supplies both), so one
 // TLV header (tag, length byte, up to two long-form length bytes) costs a single load.
 //
 // It replaces, for the fields the reference path consumes, the call

@@ -1,0 +1,259 @@
+// kernels/entries.h — CT get-entries decode and Chain[0] → issuer match.
+// gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
+#pragma once
+#include "pem.h"
+
+namespace ctmr {
+
+// ------------------------------------------------------------------ CT get-entries decode
+struct __attribute__((packed, aligned(1))) U4 { uint32_t a; };
+struct DevBytes {  // arbitrary byte positions of the blob (gfx950 runs with unaligned access mode)
+  const uint8_t* p;
+  __device__ __forceinline__ uint32_t le32(uint64_t pos) const { return ((const U4*)(p + pos))->a; }
+  __device__ __forceinline__ void le128(uint64_t pos, uint32_t out[4]) const {
+    const U16 v = *(const U16*)(p + pos);
+    out[0] = v.a; out[1] = v.b; out[2] = v.c; out[3] = v.d;
+  }
+  __device__ __forceinline__ uint32_t u8(uint64_t pos) const { return p[pos]; }
+  __device__ __forceinline__ uint32_t be(uint64_t pos, int k) const {  // reads ≤ 3 bytes past pos+k: CTMR_PAYLOAD_PAD
+    return __builtin_bswap32(le32(pos)) >> (32 - 8 * k);
+  }
+};
+
+struct DecodeArgs {
+  const uint8_t* blob;
+  const uint64_t* bounds;  // 2n+1
+  uint64_t n;
+  uint64_t* cert_start;
+  uint64_t* cert_end;
+  uint8_t* entry_type;
+  uint64_t* timestamp;     // may be null
+  uint64_t* chain0_start;
+  uint32_t* chain0_len;
+  unsigned long long* counters;  // [0] x509 [1] precert [2] decode error [3] len(Chain) < 1
+};
+
+// ct.LogEntryFromLeaf, one raw entry per lane (entry_decode.h).  Reads ≈ 5 scattered header words per entry
+// (leaf header, extensions length behind the certificate, the chain headers); the certificates themselves
+// are skipped by length.
+constexpr uint32_t DECODE_PER_BLOCK = 2048;  // entries per workgroup: counters reach global memory once per 2048 entries
+__global__ void __launch_bounds__(256) k_entry_decode(DecodeArgs a) {
+  __shared__ uint32_t cnt[4];
+  if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const uint64_t base = (uint64_t)blockIdx.x * DECODE_PER_BLOCK;
+  DevBytes b{a.blob};
+#pragma unroll 2
+  for (uint32_t k = 0; k < DECODE_PER_BLOCK / 256; k++) {
+    const uint64_t i = base + k * 256u + threadIdx.x;
+    if (i >= a.n) break;
+    EntryDec d;
+    decode_entry(b, a.bounds[2 * i], a.bounds[2 * i + 1], a.bounds[2 * i + 2], d);
+    a.cert_start[i] = d.ok ? d.cert_lo : 0ull;
+    a.cert_end[i] = d.ok ? d.cert_hi : 0ull;
+    a.entry_type[i] = d.ok ? (uint8_t)d.entry_type : (uint8_t)CTMR_ENTRY_INVALID;
+    if (a.timestamp) a.timestamp[i] = d.ok ? d.timestamp : 0ull;
+    a.chain0_start[i] = d.ok ? d.chain0_lo : 0ull;
+    a.chain0_len[i] = d.ok ? d.chain0_len : 0u;
+    c0 += d.ok && d.entry_type == 0;
+    c1 += d.ok && d.entry_type == 1;
+    c2 += !d.ok;
+    c3 += d.ok && d.n_chain == 0;
+  }
+  // hundreds of thousands of device atomics on one cache line serialise at the memory side (measured: 12 of the
+  // 15 ms of the first version of this kernel at 40 M entries): LDS first, then four atomics per workgroup
+  if (c0) atomicAdd(&cnt[0], c0);
+  if (c1) atomicAdd(&cnt[1], c1);
+  if (c2) atomicAdd(&cnt[2], c2);
+  if (c3) atomicAdd(&cnt[3], c3);
+  __syncthreads();
+  if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(&a.counters[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+
+// Chain[0] → issuer table index: replaces, per entry, x509.ParseCertificate(Chain[0]) + NewIssuer
+// (ct-fetch.go:221; storage/types.go:109-115) by a bytewise match against the issuer certificates registered so
+// far (each of which went through exactly that parse once, k_issuer_ids).  Phase 1, per lane: candidate from a
+// small hash table keyed by cert_quick_hash.  Phase 2, wave-cooperative: the 64 lanes stream the candidate's
+// bytes (16 B per lane per step, 1 KiB per instruction) against the registered copy — every byte of Chain[0]
+// is compared, so equal means identical.  Unregistered certificates are reported once per distinct hash
+// (pend[] claims) for the host to register; `retry` re-examines only entries still marked unregistered.
+constexpr uint32_t ISS_UNREGISTERED = 0xfffffffeu;
+constexpr uint32_t PEND_SLOTS = 8192;  // distinct unknown Chain[0] hashes remembered per launch
+#ifndef CTMR_MATCH_PER_STEP
+#define CTMR_MATCH_PER_STEP 4
+#endif
+constexpr uint32_t MATCH_PER_STEP = CTMR_MATCH_PER_STEP;  // candidates whose loads are in flight together (4 and 8 both measure 9.2–9.3 ms per 40 M entries: the kernel is near the HBM rate once partial lines are counted)
+
+struct MatchArgs {
+  const uint8_t* blob;
+  const uint64_t* chain0_start;
+  const uint32_t* chain0_len;
+  const uint8_t* entry_type;
+  uint32_t* issuer_idx;
+  uint64_t n;
+  // issuer certificate store
+  const uint8_t* idb_der;       // registered certificates, each at a 16-byte aligned offset, zero padded
+  const uint64_t* idb_off;      // per issuer: offset into idb_der
+  const uint32_t* idb_len;
+  const unsigned long long* ht; // open addressing: (candidate hash & ~0xffffffff) | (issuer index + 1), 0 = empty
+  uint32_t ht_mask;
+  uint32_t retry;
+  // unregistered report
+  unsigned long long* pend;     // PEND_SLOTS claim words (zeroed by the host)
+  uint32_t* unreg_list;         // entry indices, one per distinct hash
+  uint32_t unreg_cap;
+  unsigned long long* counters; // [0] entries left unregistered, [1] list entries, [2] pend overflow
+};
+
+__device__ __forceinline__ bool eq16_prefix(const U16& x, const uint4& y, uint32_t rem) {  // first min(rem,16) bytes equal
+  const uint32_t d[4] = {x.a ^ y.x, x.b ^ y.y, x.c ^ y.z, x.d ^ y.w};
+  bool eq = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t have = rem > 4u * k ? rem - 4u * k : 0u;
+    const uint32_t mask = have >= 4u ? 0xffffffffu : (have ? (0xffffffffu >> (8 * (4 - have))) : 0u);
+    eq = eq && (d[k] & mask) == 0u;
+  }
+  return eq;
+}
+
+__global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < a.n;
+  uint64_t lo = 0;
+  uint32_t len = 0;
+  bool need = false;
+  uint32_t result = CTMR_NO_ISSUER;
+  if (live) {
+    if (a.retry) {
+      result = a.issuer_idx[i];
+      need = result == ISS_UNREGISTERED;
+    } else {
+      need = a.entry_type[i] != CTMR_ENTRY_INVALID;
+    }
+    if (need) {
+      lo = a.chain0_start[i];
+      len = a.chain0_len[i];
+      need = len != 0u;
+      if (!need) result = CTMR_NO_ISSUER;
+    }
+  }
+  DevBytes b{a.blob};
+  unsigned long long qh = 0;
+  uint32_t j = 0;
+  if (need) {
+    qh = cert_quick_hash(b, lo, len);
+    j = (uint32_t)qh & a.ht_mask;
+    result = ISS_UNREGISTERED;
+  }
+  bool searching = need;
+  while (__ballot(searching)) {
+    // next candidate of every searching lane: one table word carries the issuer index and the upper half of its
+    // hash; length and store offset come with one more (parallel) pair of loads — no dependent load is left for
+    // the cooperative phase
+    uint32_t cand = 0xffffffffu;
+    uint64_t db_off = 0;
+    if (searching) {
+      for (;;) {
+        const unsigned long long v = a.ht[j];
+        if (v == 0ull) {
+          searching = false;
+          break;
+        }
+        j = (j + 1u) & a.ht_mask;
+        if ((v ^ qh) >> 32 == 0ull) {
+          const uint32_t c = (uint32_t)v - 1u;
+          const uint32_t clen = a.idb_len[c];
+          db_off = a.idb_off[c];
+          if (clen == len) {
+            cand = c;
+            break;
+          }
+        }
+      }
+    }
+    // cooperative bytewise verification, MATCH_PER_STEP candidates per step so that their loads are in flight together
+    // (a step costs one memory latency; certificates up to 2 KiB need no inner loop)
+    unsigned long long todo = __ballot(cand != 0xffffffffu);
+    while (todo) {
+      int src[MATCH_PER_STEP];
+      bool eq[MATCH_PER_STEP];
+#pragma unroll
+      for (int u = 0; u < (int)MATCH_PER_STEP; u++) {
+        src[u] = todo ? __ffsll((long long)todo) - 1 : -1;
+        todo &= todo - 1ull;  // 0 stays 0
+        eq[u] = true;
+      }
+#pragma unroll
+      for (int u = 0; u < (int)MATCH_PER_STEP; u++) {
+        if (src[u] < 0) continue;  // wave-uniform
+        const uint64_t s_lo = __shfl(lo, src[u]);
+        const uint32_t s_len = __shfl(len, src[u]);
+        const uint8_t* db = a.idb_der + __shfl(db_off, src[u]);
+        const uint32_t off0 = lane * 16u, off1 = off0 + 1024u;
+        if (off0 < s_len) {
+          const U16 x = *(const U16*)(a.blob + s_lo + off0);  // ≤ 15 bytes past Chain[0]: CTMR_PAYLOAD_PAD
+          const uint4 y = *(const uint4*)(db + off0);
+          eq[u] = eq16_prefix(x, y, s_len - off0);
+        }
+        if (off1 < s_len) {
+          const U16 x = *(const U16*)(a.blob + s_lo + off1);
+          const uint4 y = *(const uint4*)(db + off1);
+          eq[u] = eq[u] && eq16_prefix(x, y, s_len - off1);
+        }
+        for (uint32_t off = off0 + 2048u; off < s_len; off += 1024u) {  // > 2 KiB: rare
+          const U16 x = *(const U16*)(a.blob + s_lo + off);
+          const uint4 y = *(const uint4*)(db + off);
+          eq[u] = eq[u] && eq16_prefix(x, y, s_len - off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < (int)MATCH_PER_STEP; u++) {
+        if (src[u] < 0) continue;
+        const bool all = __ballot(!eq[u]) == 0ull;
+        if ((int)lane == src[u] && all) {
+          result = cand;
+          searching = false;
+        }
+      }
+    }
+  }
+  if (live) a.issuer_idx[i] = result;
+  // report unregistered certificates, once per distinct hash
+  const bool unreg = live && result == ISS_UNREGISTERED;
+  const unsigned long long mu = __ballot(unreg);
+  if (lane == 0 && mu) atomicAdd(&a.counters[0], (unsigned long long)__popcll(mu));
+  // one claim per distinct hash per wave (a cold start has every lane here)
+  unsigned long long todo_u = mu;
+  while (todo_u) {
+    const int leader = __ffsll((long long)todo_u) - 1;
+    const unsigned long long lq = __shfl(qh, leader);
+    const unsigned long long same = __ballot(unreg && qh == lq) & todo_u;
+    todo_u &= ~same;
+    if ((int)lane != leader) continue;
+    uint32_t k = (uint32_t)(qh >> 32) & (PEND_SLOTS - 1u);
+    bool first = false, placed = false;
+    for (uint32_t probes = 0; probes < 64u && !placed; probes++) {
+      const unsigned long long old = atomicCAS(&a.pend[k], 0ull, qh);
+      if (old == 0ull) {
+        first = true;
+        placed = true;
+      } else if (old == qh) {
+        placed = true;
+      }
+      k = (k + 1u) & (PEND_SLOTS - 1u);
+    }
+    if (!placed) {
+      atomicAdd(&a.counters[2], 1ull);
+      first = true;  // overflow: report it anyway (the host dedups by bytes)
+    }
+    if (first) {
+      const unsigned long long at = atomicAdd(&a.counters[1], 1ull);
+      if (at < a.unreg_cap) a.unreg_list[at] = (uint32_t)i;
+    }
+  }
+}
+
+}  // namespace ctmr

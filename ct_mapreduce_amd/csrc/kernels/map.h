@@ -1,0 +1,284 @@
+// kernels/map.h — the map: one certificate per lane — TBSCertificate walk, the three filters, the 32-byte record.
+// gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
+#pragma once
+#include "sha256.h"
+
+namespace ctmr {
+
+// ------------------------------------------------------------------ the map
+struct MapArgs {
+  const uint8_t* payload;
+  const uint64_t* offsets;    // packed batch: n+1 offsets; entry view (ends != null): n range starts
+  const uint64_t* ends;       // null = packed batch; else certificate i is [offsets[i], ends[i]) (ctmr_entry_view)
+  uint64_t limit;             // entry view: readable bytes of payload (blob bytes + CTMR_PAYLOAD_PAD)
+  const uint32_t* issuer_idx;
+  const uint8_t* entry_type;  // may be null
+  ctmr_record* records;
+  const uint8_t* issuer_valid;
+  const FilterDev* filt;
+  uint64_t n;
+  uint32_t n_issuers;
+  uint32_t certs_per_tile;
+  uint32_t lds_bytes;  // dynamic LDS size of the launch
+  uint2* meta_loc;          // null, or per entry (Walk.meta_issuer, Walk.meta_crl) for k_meta_new (config.collect_meta)
+  uint32_t optimistic_new;  // 1: PASS records leave the map with CTMR_FL_WAS_UNKNOWN already set — the
+                            // reduce only CLEARS it for the (rare) duplicates, so the common case costs
+                            // no second scattered write into the record array
+};
+
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+// Byte range of certificate i and the readable size of the payload, for both input forms.
+__device__ __forceinline__ void cert_range(const uint64_t* offsets, const uint64_t* ends, uint64_t i, uint64_t& lo,
+                                           uint64_t& hi) {
+  lo = offsets[i];
+  hi = ends ? ends[i] : offsets[i + 1];
+  if (hi < lo) hi = lo;
+}
+__device__ __forceinline__ uint64_t map_limit(const MapArgs& a) {
+  return a.ends ? a.limit : a.offsets[a.n] + CTMR_PAYLOAD_PAD;
+}
+
+// Everything after the bytes are addressable: walk, filters, record.
+template <class R>
+__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, uint4& o0,
+                                        uint4& o1) {
+  Walk w;
+  const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
+  const FilterDev* f = a.filt;
+  const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
+  const bool ok = walk_cert(r, L, w, f->active != 0u, fv);  // L > 2^31-1 is rejected inside, without divergence
+  const uint32_t iss = a.issuer_idx[idx];
+  const uint32_t et = a.entry_type ? a.entry_type[idx] : 0u;
+  uint32_t status;
+  if (et == CTMR_ENTRY_INVALID) {
+    status = CTMR_ST_ENTRY_DECODE_ERROR;  // never reached entryChan (ct-fetch.go:452-459)
+  } else if (!ok) {
+    status = CTMR_ST_PARSE_ERROR;
+  } else if (w.bc_valid && w.is_ca) {
+    status = CTMR_ST_FILTERED_CA;
+  } else if (w.not_after < f->now && !f->log_expired) {
+    status = CTMR_ST_FILTERED_EXPIRED;
+  } else if (!w.cn_match) {
+    status = CTMR_ST_FILTERED_CN;
+  } else if (iss == CTMR_NO_ISSUER || iss >= a.n_issuers) {
+    status = CTMR_ST_NO_ISSUER;
+  } else if (!a.issuer_valid[iss]) {
+    status = CTMR_ST_ISSUER_PARSE_ERROR;
+  } else {
+    status = CTMR_ST_PASS;
+  }
+  uint32_t flags = et == 1u ? CTMR_FL_PRECERT : 0u;
+  if (a.optimistic_new && status == CTMR_ST_PASS) flags |= CTMR_FL_WAS_UNKNOWN;
+  uint32_t slen = 0, s[5] = {0, 0, 0, 0, 0};
+  int32_t exp_hour = 0;
+  if (ok) {
+    // NewExpDateFromTime: Truncate(time.Hour) = floor (storage/types.go:339-346)
+    long long q = w.not_after / 3600;
+    if (w.not_after % 3600 < 0) q -= 1;
+    exp_hour = (int32_t)q;
+    slen = w.serial_len > 0xffffu ? 0xffffu : w.serial_len;
+    if (w.serial_len > 20) flags |= CTMR_FL_LONG_SERIAL;
+#pragma unroll
+    for (int k = 0; k < 5; k++) s[k] = w.serial_w[k];
+  }
+  o0 = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
+  o1 = make_uint4(s[1], s[2], s[3], s[4]);
+  if (a.meta_loc) a.meta_loc[idx] = make_uint2(ok ? w.meta_issuer : META_NONE, ok ? w.meta_crl : META_NONE);
+}
+
+template <class R>
+__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a) {
+  uint4 o0, o1;
+  map_one(r, len64, idx, a, o0, o1);
+  uint4* out = (uint4*)(a.records + idx);
+  out[0] = o0;
+  out[1] = o1;
+}
+
+// Record store for the one-wave-per-workgroup window kernels: the 64 records of the wave (2 KiB,
+// contiguous) are transposed through LDS so that each of the two store instructions writes 1 KiB of
+// consecutive bytes (whole 64-B sectors) instead of 64 half-sectors 32 B apart.  The window area is
+// free by now: every lane of the wave has finished its walk.
+__device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t first, bool live, const uint4& o0,
+                                                   const uint4& o1) {
+  uint4* t = (uint4*)smem;
+  const uint32_t lane = threadIdx.x;
+  __builtin_amdgcn_wave_barrier();
+  if (live) {
+    t[2 * lane] = o0;
+    t[2 * lane + 1] = o1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t rem = a.n - first;  // records of this wave
+  const uint32_t nvec = rem >= 64 ? 128u : (uint32_t)rem * 2u;
+  uint4* out = (uint4*)(a.records + first);
+  if (lane < nvec) out[lane] = t[lane];
+  if (64u + lane < nvec) out[64 + lane] = t[64 + lane];
+}
+
+// LDS-tile map.  One wave per workgroup, one tile of `certs_per_tile` consecutive
+// certificates per workgroup: the tile's byte range [offsets[first], offsets[last+1]) is
+// contiguous in the packed payload, so it is copied with perfectly coalesced 16-B/lane loads
+// (1 KiB per wave instruction) into LDS; then lane l walks certificate first+l out of LDS.
+
+__global__ void __launch_bounds__(64) k_map_tile(MapArgs a) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t C = a.certs_per_tile;
+  const uint64_t first = (uint64_t)blockIdx.x * C;
+  if (first >= a.n) return;
+  const uint32_t cnt = (uint32_t)((a.n - first) < C ? (a.n - first) : C);
+  uint64_t my_lo = 0, my_hi = 0;
+  if (lane < cnt) {
+    my_lo = a.offsets[first + lane];
+    my_hi = a.offsets[first + lane + 1];
+  }
+  const uint64_t tile_lo = __shfl(my_lo, 0);
+  const uint64_t tile_hi = __shfl(my_hi, cnt - 1);
+  const uint64_t a_lo = tile_lo & ~15ull;
+  const uint64_t span = tile_hi - a_lo;
+  if (tile_hi < tile_lo || span + 48 > a.lds_bytes) {
+    // oversize (or malformed offsets): walk straight from global memory
+    if (lane < cnt) {
+      if (my_hi < my_lo) my_hi = my_lo;
+      GlobalReader r{(const uint32_t*)a.payload, my_lo};
+      map_one(r, my_hi - my_lo, first + lane, a);
+    }
+    return;
+  }
+  // ---- stage the tile: global → VGPR → LDS, 8 × 1 KiB in flight per wave
+  {
+    const uint4* src = (const uint4*)(a.payload + a_lo);
+    uint4* dst = (uint4*)smem;
+    const uint32_t nvec = (uint32_t)((span + 15) >> 4);
+    for (uint32_t base = 0; base < nvec; base += 8 * 64) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t i = base + k * 64 + lane;
+        if (i < nvec) v[k] = src[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t i = base + k * 64 + lane;
+        if (i < nvec) dst[i] = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < cnt) {
+    if (my_hi < my_lo) my_hi = my_lo;
+    LdsReader r{(const uint32_t*)smem, (uint32_t)(my_lo - a_lo)};
+    map_one(r, my_hi - my_lo, first + lane, a);
+  }
+}
+
+// Direct map: one certificate per lane straight from global memory.
+__global__ void __launch_bounds__(256) k_map_direct(MapArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  uint64_t lo, hi;
+  cert_range(a.offsets, a.ends, i, lo, hi);
+  GlobalReader r{(const uint32_t*)a.payload, lo};
+  map_one(r, hi - lo, i, a);
+}
+
+// Window map: one certificate per lane, all 64 lanes busy, DER stays in global memory and is
+// pulled through a per-lane LDS window (WinReader).  One wave per workgroup, so LDS (not the
+// 256-thread granule) sets the occupancy: 64 × (WCH·16+16) bytes per wave.
+template <int WCH>
+__global__ void __launch_bounds__(64) k_map_win(MapArgs a) {
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint64_t i = first + threadIdx.x;
+  const bool live = i < a.n;
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
+    constexpr uint32_t STRIDE = WCH * 16 + 16;
+    WinReader<WCH> r{(const uint32_t*)a.payload, lo, map_limit(a),
+                     (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
+    r.refill(0);
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
+}
+
+// Window map with a wave-cooperative first fill: instead of every lane issuing 16 loads of ITS certificate
+// (64 uncoalesced 16-byte requests per instruction), 16 adjacent lanes fetch the 16 chunks of one
+// certificate's front window, 4 certificates per instruction — the texture addresser sees 8 lanes per
+// 128-byte line — and each lane parks its chunk directly in the owning lane's LDS window.
+template <int WCH>
+__global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
+  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t i = first + lane;
+  const bool live = i < a.n;
+  constexpr uint32_t STRIDE = WCH * 16 + 16;
+  const uint64_t limit = map_limit(a);
+  uint64_t lo = 0, hi = 0;
+  if (live) cert_range(a.offsets, a.ends, i, lo, hi);
+  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
+  {
+    uint4 v[16];
+    const uint32_t sub = lane & 15u;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+      const uint64_t at = g + 16u * sub;
+      v[it] = (g != ~0ull && at + 16u <= limit) ? *(const uint4*)(a.payload + at) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                       (int32_t)(int64_t)(g_me - lo)}};
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
+}
+
+// Line-trimmed window map (WinReaderT).
+template <int WCH, int NF, int NE>
+__global__ void __launch_bounds__(64) k_map_wint(MapArgs a) {
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint64_t i = first + threadIdx.x;
+  const bool live = i < a.n;
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
+    constexpr uint32_t STRIDE = WCH * 16 + 16;
+    WinReaderT<WCH, NF, NE> r{(const uint32_t*)a.payload, lo, map_limit(a),
+                              (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0};
+    r.refill(0, NF);
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
+}
+
+// Two-region window map (WinReader2): same walk, 2 dependent HBM round trips per certificate.
+template <int WCH>
+__global__ void __launch_bounds__(64) k_map_win2(MapArgs a) {
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint64_t i = first + threadIdx.x;
+  const bool live = i < a.n;
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  if (live) {
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
+    constexpr uint32_t STRIDE = (WCH + 3) * 16;
+    WinReader2<WCH> r{(const uint32_t*)a.payload, lo, map_limit(a),
+                      (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0x7fffff00};
+    r.refill(0);
+    map_one(r, hi - lo, i, a, o0, o1);
+  }
+  store_records_wave(a, first, live, o0, o1);
+}
+
+}  // namespace ctmr

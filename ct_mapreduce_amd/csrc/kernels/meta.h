@@ -1,0 +1,328 @@
+// kernels/meta.h — IssuerMetadata memo on the device.
+// gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
+#pragma once
+#include "entries.h"
+
+namespace ctmr {
+
+// ------------------------------------------------------------------ IssuerMetadata on device
+// IssuerMetadata.Accumulate (storage/issuermetadata.go:92-138) runs for every newly unknown certificate but changes
+// state only the first time an issuer meets an (expDate), a CRL distribution point or an issuer DN: its three
+// per-issuer memo maps (knownExpDates :96, knownCrlDPs :113, knownIssuerDNs :97) live here as ONE device hash set of
+// (kind, issuer, bytes).  k_meta_new walks the NEW list of a batch, and appends an item only for first sightings —
+// the host then formats/inserts those few (addCRL :48-73, addIssuerDN :75-87, AllocateExpDateAndIssuer
+// filesystemdatabase.go:189-195) instead of parsing every new certificate.
+// Set semantics are exact: a slot is claimed by CAS on the 64-bit hash, its bytes are copied into an arena and
+// published (write-through payload, drained, then the VALID word — the table_upsert recipe); equal hash is
+// followed by a full comparison, so a hash collision only costs a probe.
+struct MetaSlot {
+  unsigned long long w[4];  // w0 hash (claim, never 0) | w1 VALID(63) kind(61..60) len(59..40) arena_off/8(39..0)
+};                          // w2 issuer << 32 | key2 | w3 launch number that created the slot
+constexpr unsigned long long META_VALID = 1ull << 63;
+constexpr uint32_t MK_EXPDATE = 0, MK_CRL = 1, MK_DN = 2, MK_HOST = 3;  // item kinds; MK_HOST = parse this one on the host
+constexpr uint32_t META_MAX_BYTES = 4096;
+constexpr uint32_t META_MAX_URIS = 4;  // CRL distribution point URIs per certificate on the device path; more → host
+struct ByteReader {  // one unaligned dword per access (k_meta_new's TLV reads)
+  const uint8_t* p;
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const { return ((const U4*)(p + pos))->a; }
+};
+
+struct MetaItem {  // 32 bytes, = ctmr_meta_item
+  uint64_t entry;
+  uint32_t kind, issuer_idx;
+  int32_t exp_hour;
+  uint32_t off, len, pad;
+};
+static_assert(sizeof(MetaItem) == 32, "MetaItem");
+
+struct MetaArgs {
+  const uint8_t* payload;
+  const uint64_t* offsets;
+  const uint64_t* ends;
+  const ctmr_record* records;
+  const uint32_t* canon;
+  const uint2* meta_loc;
+  const uint64_t* new_idx;
+  uint64_t n_new;
+  MetaSlot* slots;
+  uint64_t mask;
+  uint8_t* arena;
+  uint64_t arena_cap;
+  unsigned long long* counters;  // [0] arena bytes used [1] items appended [2] set/arena overflow events
+  MetaItem* items;
+  uint64_t items_cap;
+  uint32_t epoch;  // launch number (≥ 1): slots of earlier launches are immutable and read through the caches
+};
+
+// 16-byte chunks of an item, bytes past its end zeroed.  Items are hashed and compared in these chunks: the first
+// version of this kernel used dwords and was bound by L2 REQUESTS (1.46 G for 18.8 M new certificates, 76 % of its
+// L1 accesses missing — profiles/r01/s4/pmc_meta_20m_dword_version.txt).
+__device__ __forceinline__ uint4 mask_chunk(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rem) {
+  uint32_t w[4] = {w0, w1, w2, w3};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t have = rem > 4u * q ? rem - 4u * q : 0u;
+    w[q] = have >= 4u ? w[q] : (have ? (w[q] & (0xffffffffu >> (8u * (4u - have)))) : 0u);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+struct GlobalSrc {  // straight from the certificate in HBM: one unaligned dwordx4 load per chunk (≤ 15 bytes past the
+  const uint8_t* p; //  item, which lies inside a certificate inside the payload + CTMR_PAYLOAD_PAD)
+  uint32_t len;
+  __device__ __forceinline__ uint4 chunk(uint32_t k) const {
+    const U16 v = *(const U16*)(p + 16u * k);
+    return mask_chunk(v.a, v.b, v.c, v.d, len - 16u * k);
+  }
+};
+struct LdsSrc {  // from this lane's staging area in LDS, at any byte offset (5 dwords, 4 alignbytes)
+  const uint32_t* w;  // dword-aligned lane area
+  uint32_t off;       // byte offset of the item inside it
+  uint32_t len;
+  __device__ __forceinline__ uint4 chunk(uint32_t k) const {
+    const uint32_t at = off + 16u * k, i = at >> 2, sh = at & 3u;
+    const uint32_t d0 = w[i], d1 = w[i + 1], d2 = w[i + 2], d3 = w[i + 3], d4 = w[i + 4];
+    return mask_chunk(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                      __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh), len - 16u * k);
+  }
+};
+
+// Plain (cacheable) load the compiler may not merge or hoist: wavefront-scope atomic.  Used for memo slots of EARLIER
+// launches, which are immutable — the steady state, where the same few hundred DN/CRL slots are read by every new
+// certificate and should come out of L1/L2 instead of device-coherent loads.
+__device__ __forceinline__ unsigned long long ld_wave(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// true = first sighting of (kind, issuer, key2, bytes); the bytes come through a chunk source
+template <class S>
+__device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, uint32_t issuer, uint32_t key2,
+                                            const S& src, uint32_t len) {
+  const uint32_t nc = (len + 15u) >> 4;
+  unsigned long long h = mixk(((unsigned long long)issuer << 32 | key2) + 0x9e3779b97f4a7c15ull * (kind + 1u));
+  h = mixk(h ^ len);
+  for (uint32_t k = 0; k < nc; k++) {
+    const uint4 c = src.chunk(k);
+    h = mixk(h ^ (((unsigned long long)c.y << 32 | c.x) + 0x9e3779b97f4a7c15ull * (2u * k + 2u)));
+    h = mixk(h ^ (((unsigned long long)c.w << 32 | c.z) + 0x9e3779b97f4a7c15ull * (2u * k + 3u)));
+  }
+  if (h == 0ull) h = 1ull;
+  const unsigned long long w2 = ((unsigned long long)issuer << 32) | key2;
+  uint64_t j = h & a.mask;
+  uint64_t probes = 0;
+  for (;;) {
+    MetaSlot* sl = a.slots + j;
+    unsigned long long w0 = ld_wave(&sl->w[0]);  // a stale 0 only sends us to the CAS, which tells the truth
+    if (w0 == 0ull) {
+      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, h);
+      if (old == 0ull) {  // claimed: copy the bytes, publish
+        const unsigned long long need = (unsigned long long)nc * 16ull;
+        unsigned long long at = need ? atomicAdd(&a.counters[0], need) : 0ull;
+        uint32_t pk = kind;
+        if (at + need > a.arena_cap) {  // arena exhausted: a dead slot (never equal to anything); always "new"
+          atomicAdd(&a.counters[2], 1ull);
+          pk = MK_HOST;
+          at = 0;
+        } else {
+          unsigned long long* dst = (unsigned long long*)(a.arena + at);
+          for (uint32_t k = 0; k < nc; k++) {
+            const uint4 c = src.chunk(k);
+            st_agent(dst + 2 * k, (unsigned long long)c.y << 32 | c.x);
+            st_agent(dst + 2 * k + 1, (unsigned long long)c.w << 32 | c.z);
+          }
+        }
+        st_agent(&sl->w[2], w2);
+        st_agent(&sl->w[3], (unsigned long long)a.epoch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(&sl->w[1], META_VALID | ((unsigned long long)pk << 60) | ((unsigned long long)len << 40) | (at >> 3));
+        return true;
+      }
+      w0 = old;
+    }
+    if (w0 == h) {
+      unsigned long long m = ld_wave(&sl->w[1]);
+      const unsigned long long ep = ld_wave(&sl->w[3]);
+      const bool settled = (m & META_VALID) && ep != 0ull && ep < a.epoch;  // published by an earlier launch: immutable
+      if (!settled) {
+        m = ld_agent(&sl->w[1]);
+        if (!(m & META_VALID)) continue;  // the claimer has not published yet: poll again (as table_upsert does)
+      }
+      bool eq = ((m >> 60) & 3ull) == kind && ((m >> 40) & 0xfffffull) == len &&
+                (settled ? ld_wave(&sl->w[2]) : ld_agent(&sl->w[2])) == w2;
+      if (eq) {
+        const unsigned long long* asrc = (const unsigned long long*)(a.arena + ((m & 0xffffffffffull) << 3));
+        for (uint32_t k = 0; (k < nc) & eq; k++) {
+          const uint4 c = src.chunk(k);
+          unsigned long long s0, s1;
+          if (settled) {
+            const uint4 v = *(const uint4*)(asrc + 2 * k);  // immutable: plain 16-byte load
+            s0 = (unsigned long long)v.y << 32 | v.x;
+            s1 = (unsigned long long)v.w << 32 | v.z;
+          } else {
+            s0 = ld_agent(asrc + 2 * k);
+            s1 = ld_agent(asrc + 2 * k + 1);
+          }
+          eq = s0 == ((unsigned long long)c.y << 32 | c.x) && s1 == ((unsigned long long)c.w << 32 | c.z);
+        }
+      }
+      if (eq) return false;
+    }
+    j = (j + 1) & a.mask;
+    if (++probes > a.mask) break;
+  }
+  atomicAdd(&a.counters[2], 1ull);  // set full: report every time (the host's sets dedup)
+  return true;
+}
+
+__device__ __forceinline__ void meta_emit(const MetaArgs& a, uint64_t entry, uint32_t kind, uint32_t issuer_idx,
+                                          int32_t exp_hour, uint32_t off, uint32_t len) {
+  const unsigned long long at = atomicAdd(&a.counters[1], 1ull);
+  if (at < a.items_cap) a.items[at] = MetaItem{entry, kind, issuer_idx, exp_hour, off, len, 0u};
+}
+
+// Per-lane LDS staging: the issuer Name (≤ META_LDS_DN bytes) and the cRLDistributionPoints value (≤ META_LDS_CRL) of
+// the lane's certificate are fetched with up to 12 independent 16-byte loads issued together — ONE memory latency —
+// and everything after that (the DistributionPoint walk, hashing, comparing) reads LDS.  The dependent chain per
+// certificate drops from ≈35 global round trips to the three memo probes.  Longer items take the global path.
+constexpr uint32_t META_LDS_DN = 128, META_LDS_CRL = 64, META_LDS_STRIDE = META_LDS_DN + META_LDS_CRL + 16;
+
+struct LdsTlvReader {  // rd_hdr over the staged cRLDistributionPoints value: positions are certificate offsets
+  const uint32_t* w;   // lane area (dwords) of the value
+  uint32_t s;          // certificate offset of its first byte
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - s;  // callers stay within [s, e + 3]; the area has 16 bytes of slack
+    const uint32_t i = rel >> 2;
+    return __builtin_amdgcn_alignbyte(w[i + 1], w[i], rel & 3u);
+  }
+};
+
+// DistributionPoint walk (RFC 5280 §4.2.1.13) over [cs, e): collects up to META_MAX_URIS URI ranges (certificate
+// offsets); returns false when the value is malformed.  `host` is set when a URI is too long or there are too many.
+template <class R>
+__device__ __forceinline__ bool walk_crl_dps(const R& g, uint32_t L, uint32_t cs, uint32_t e, uint32_t uo[META_MAX_URIS],
+                                             uint32_t ul[META_MAX_URIS], uint32_t& nu, bool& host) {
+  bool ok = true;
+  uint32_t p = cs;
+  while (ok && p < e) {
+    uint32_t t1, f, f_end;
+    rd_hdr(g, L, p, e, ok, t1, f, f_end);
+    ok = ok && t1 == 0x30u;
+    while (ok && f < f_end) {
+      uint32_t t2, n, n_end;
+      rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
+      if (ok && t2 == 0xa0u) {
+        while (ok && n < n_end) {
+          uint32_t t3, q, q_end;
+          rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
+          if (ok && t3 == 0xa0u) {
+            while (ok && q < q_end) {
+              uint32_t t4, u, u_end;
+              rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
+              if (ok && t4 == 0x86u) {
+                if (u_end - u > META_MAX_BYTES || nu >= META_MAX_URIS) host = true;
+#pragma unroll
+                for (uint32_t k = 0; k < META_MAX_URIS; k++) {  // register array: no dynamic indexing
+                  uo[k] = k == nu ? u : uo[k];
+                  ul[k] = k == nu ? u_end - u : ul[k];
+                }
+                nu++;
+              }
+              q = u_end;
+            }
+          }
+          n = q_end;
+        }
+      }
+      f = n_end;
+    }
+    p = f_end;
+  }
+  return ok;
+}
+
+__global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[256 * META_LDS_STRIDE];
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n_new) return;
+  const uint64_t i = a.new_idx[r];
+  const uint4 r0 = *(const uint4*)(a.records + i);
+  const int32_t exp_hour = (int32_t)r0.y;
+  const uint32_t iss = r0.z, canon = a.canon[iss];
+  uint64_t lo, hi;
+  cert_range(a.offsets, a.ends, i, lo, hi);
+  const uint32_t L = (uint32_t)(hi - lo);
+  const uint8_t* cert = a.payload + lo;
+  const uint2 ml = a.meta_loc[i];
+  bool host = ml.x == META_HOST || ml.y == META_HOST || ml.x == META_NONE;
+  uint32_t dn_off = 0, dn_len = 0, cr_s = 0, cr_len = 0;
+  if (!host) {
+    dn_off = ml.x & 0xffffu;
+    dn_len = ml.x >> 16;
+    host = dn_len > META_MAX_BYTES || dn_off + dn_len > L;
+    if (ml.y != META_NONE) {
+      cr_s = ml.y & 0xffffu;
+      cr_len = ml.y >> 16;
+      host = host || cr_s + cr_len > L;
+    }
+  }
+  // ---- stage: every load of this lane is in flight before the first one is needed
+  uint8_t* my = stage + threadIdx.x * META_LDS_STRIDE;
+  const bool dn_lds = !host && dn_len <= META_LDS_DN, cr_lds = !host && cr_len != 0u && cr_len <= META_LDS_CRL;
+  {
+    U16 d[META_LDS_DN / 16], c[META_LDS_CRL / 16];
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_DN / 16; k++)
+      if (dn_lds && 16u * k < dn_len) d[k] = *(const U16*)(cert + dn_off + 16u * k);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_CRL / 16; k++)
+      if (cr_lds && 16u * k < cr_len) c[k] = *(const U16*)(cert + cr_s + 16u * k);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_DN / 16; k++)
+      if (dn_lds && 16u * k < dn_len) *(uint4*)(my + 16u * k) = make_uint4(d[k].a, d[k].b, d[k].c, d[k].d);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_CRL / 16; k++)
+      if (cr_lds && 16u * k < cr_len) *(uint4*)(my + META_LDS_DN + 16u * k) = make_uint4(c[k].a, c[k].b, c[k].c, c[k].d);
+  }
+  // knownExpDates → seenExpDateBefore (issuermetadata.go:96-108): no bytes, probes while the loads fly
+  if (meta_upsert(a, MK_EXPDATE, canon, (uint32_t)exp_hour, GlobalSrc{cert, 0}, 0)) meta_emit(a, i, MK_EXPDATE, iss, exp_hour, 0, 0);
+  // knownCrlDPs (:111-127): CRLDistributionPoints ::= SEQUENCE OF DistributionPoint { [0] { [0] GeneralNames { [6] URI }}}
+  // One validating pass collects the URI ranges (a malformed value yields NO URIs, as the oracle defines; more than
+  // META_MAX_URIS → host), then the memo is consulted.
+  if (!host && cr_len != 0u) {
+    const uint32_t e = cr_s + cr_len;
+    uint32_t uo[META_MAX_URIS], ul[META_MAX_URIS], nu = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < META_MAX_URIS; k++) uo[k] = ul[k] = 0;
+    bool ok = true;
+    uint32_t tag, cs, ce;
+    const uint32_t* cw = (const uint32_t*)(my + META_LDS_DN);
+    if (cr_lds) {
+      LdsTlvReader g{cw, cr_s};
+      rd_hdr(g, e, cr_s, e, ok, tag, cs, ce);  // L = e: reads clamp to the staged value, not to the certificate
+      ok = ok && tag == 0x30u && ce == e;
+      ok = ok && walk_crl_dps(g, e, cs, e, uo, ul, nu, host);
+    } else {
+      ByteReader g{cert};
+      rd_hdr(g, L, cr_s, e, ok, tag, cs, ce);
+      ok = ok && tag == 0x30u && ce == e;
+      ok = ok && walk_crl_dps(g, L, cs, e, uo, ul, nu, host);
+    }
+    if (ok && !host) {
+#pragma unroll
+      for (uint32_t k = 0; k < META_MAX_URIS; k++) {
+        if (k >= nu) continue;
+        const bool first = cr_lds ? meta_upsert(a, MK_CRL, canon, 0, LdsSrc{cw, uo[k] - cr_s, ul[k]}, ul[k])
+                                  : meta_upsert(a, MK_CRL, canon, 0, GlobalSrc{cert + uo[k], ul[k]}, ul[k]);
+        if (first) meta_emit(a, i, MK_CRL, iss, exp_hour, uo[k], ul[k]);
+      }
+    }
+  }
+  // knownIssuerDNs (:97,:130-135): keyed by the Name's DER bytes (Issuer.String() is a function of them)
+  if (!host) {
+    const bool first = dn_lds ? meta_upsert(a, MK_DN, canon, 0, LdsSrc{(const uint32_t*)my, 0u, dn_len}, dn_len)
+                              : meta_upsert(a, MK_DN, canon, 0, GlobalSrc{cert + dn_off, dn_len}, dn_len);
+    if (first) meta_emit(a, i, MK_DN, iss, exp_hour, dn_off, dn_len);
+  }
+  if (host) meta_emit(a, i, MK_HOST, iss, exp_hour, 0, L);
+}
+
+}  // namespace ctmr

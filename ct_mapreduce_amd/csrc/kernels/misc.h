@@ -1,0 +1,212 @@
+// kernels/misc.h — auxiliary kernels: whole-certificate SHA-256, RemoteCache point ops and scans, the synthetic generator.
+// gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
+#pragma once
+#include "meta.h"
+
+namespace ctmr {
+
+// ------------------------------------------------------------------ whole-certificate SHA-256 (auxiliary)
+// NOT on the reference's path — it never hashes a leaf certificate (the only SHA-256 is Issuer.ID's,
+// storage/types.go:155-159).  This is the kernel BASELINE.json's north_star names literally ("one-cert-per-lane
+// SHA-256 with round constants in LDS"): the fingerprint CT tooling identifies certificates by.  VALU-bound
+// (≈2 000 instructions per 64-byte block), not HBM-bound: reported against its own roofline.
+// Full blocks are fetched as four unaligned 16-byte loads per lane; the padded tail goes through the byte path.
+__global__ void __launch_bounds__(256) k_fingerprint(const uint8_t* payload, const uint64_t* offsets,
+                                                     const uint64_t* ends, uint64_t n, uint32_t* digests) {
+  __shared__ uint32_t kc[64];
+  if (threadIdx.x < 64) kc[threadIdx.x] = K256[threadIdx.x];
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t lo, hi;
+  cert_range(offsets, ends, i, lo, hi);
+  const uint64_t len64 = hi - lo;
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  const uint8_t* p = payload + lo;
+  const uint64_t full = len64 >> 6;
+  for (uint64_t b = 0; b < full; b++) {
+    uint32_t w[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const U16 v = *(const U16*)(p + b * 64 + q * 16);
+      w[4 * q] = __builtin_bswap32(v.a); w[4 * q + 1] = __builtin_bswap32(v.b);
+      w[4 * q + 2] = __builtin_bswap32(v.c); w[4 * q + 3] = __builtin_bswap32(v.d);
+    }
+    sha256_compress(h, w, kc);
+  }
+  // tail: 0..63 message bytes, 0x80, zeros, 64-bit bit length — one or two blocks
+  const uint32_t rem = (uint32_t)(len64 & 63u);
+  const uint32_t nt = rem + 9 > 64 ? 2u : 1u;
+  const uint8_t* t = p + full * 64;
+  for (uint32_t b = 0; b < nt; b++) {
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t pos = b * 64 + k * 4;
+      uint32_t v = 0;
+      if (pos + 4 <= rem) {
+        v = __builtin_bswap32(((const U4*)(t + pos))->a);
+      } else if (pos <= rem) {
+        const uint32_t r = rem - pos;  // 0..3 message bytes in this word
+        const uint32_t raw = r ? ((const U4*)(t + pos))->a : 0u;  // ≤ 3 bytes past the certificate: CTMR_PAYLOAD_PAD
+        const uint32_t m = r ? (raw & (0xffffffffu >> (8 * (4 - r)))) : 0u;
+        v = __builtin_bswap32(m | (0x80u << (8 * r)));
+      }
+      w[k] = v;
+    }
+    if (b == nt - 1) {
+      w[14] = (uint32_t)((len64 * 8ull) >> 32);
+      w[15] = (uint32_t)(len64 * 8ull);
+    }
+    sha256_compress(h, w, kc);
+  }
+  uint4* out = (uint4*)(digests + i * 8);  // big-endian digest bytes
+  out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+  out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+}
+
+// ------------------------------------------------------------------ RemoteCache point ops
+// op: 0 = SetInsert, 1 = SetContains, 2 = SetRemove.  result[0] = 1 when inserted / present /
+// removed; result[1] = SID_FULL marker on a full table.
+__global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, unsigned long long s0,
+                         unsigned long long s1, unsigned long long s2, unsigned long long s3,
+                         unsigned long long s4, int op, uint32_t epoch,
+                         unsigned long long* issuer_counts, PairSlot* pairs, uint64_t pmask,
+                         uint32_t* result) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long s[5] = {s0, s1, s2, s3, s4};
+  bool created = false;
+  const uint32_t sid = table_upsert(table, mask, meta, s, 0xffffffffu, epoch, op == 0, &created);
+  result[0] = 0;
+  result[1] = sid == SID_FULL;
+  if (sid == SID_FULL) return;
+  const uint32_t canon = (uint32_t)(meta >> 32) & 0xffffffu;
+  if (op == 0) {
+    result[0] = created;
+    if (created) atomicAdd(&issuer_counts[canon], 1ull);
+  } else if (op == 1) {
+    result[0] = sid != SID_NONE;
+  } else if (sid != SID_NONE) {
+    const bool shadow = (table[sid].w[2] & SLOT_SHADOW) != 0;  // counted by another rank: nothing to take off here
+    table[sid].w[0] = SLOT_TOMB;
+    table[sid].w[1] = 0;
+    if (!shadow) atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
+    result[0] = 1;
+  }
+}
+
+// Drop every member whose (exp_hour, canonical issuer) matches, or — with any_key — every
+// member with exp_hour*3600 <= now (Redis EXPIREAT set by knowncertificates.go:98-104).
+__global__ void __launch_bounds__(256) k_sweep(Slot* table, uint64_t nslots, int any_key,
+                                               long long now, uint32_t exp_hour_key, uint32_t canon_key,
+                                               unsigned long long* issuer_counts, PairSlot* pairs,
+                                               uint64_t pmask, unsigned long long* removed) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nslots) return;
+  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  const int32_t eh = (int32_t)(uint32_t)w1;
+  const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+  const bool hit = any_key ? ((long long)eh * 3600 <= now) : ((uint32_t)eh == exp_hour_key && canon == canon_key);
+  if (!hit) return;
+  const bool shadow = (table[j].w[2] & SLOT_SHADOW) != 0;  // counted by another rank (Bloom-variant global dedup)
+  table[j].w[0] = SLOT_TOMB;
+  table[j].w[1] = 0;
+  if (shadow) return;
+  atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
+  atomicAdd(removed, 1ull);
+}
+
+// Rebuild the (expDate, issuer) → SCARD table from the known-certificate table (lazy: only the
+// statistics-style queries SetCardinality / Exists / KeysToChan need it).
+__global__ void __launch_bounds__(256) k_build_pairs(const Slot* table, uint64_t nslots, PairSlot* pairs,
+                                                     uint64_t pmask, unsigned long long* full) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nslots) return;
+  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID) || (table[j].w[2] & SLOT_SHADOW)) return;
+  const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+  if (!pair_add(pairs, pmask, ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1, 1)) atomicAdd(full, 1ull);
+}
+
+// SetList / SetToChan: gather the serials of one set.  out entries are 48 bytes:
+// [u32 len][40 bytes serial][u32 pad].
+__global__ void __launch_bounds__(256) k_list(const Slot* table, uint64_t nslots, uint32_t exp_hour_key,
+                                              uint32_t canon_key, uint8_t* out, uint64_t cap,
+                                              unsigned long long* count) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nslots) return;
+  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID) || (table[j].w[2] & SLOT_SHADOW)) return;
+  if ((uint32_t)w1 != exp_hour_key || ((uint32_t)(w1 >> 32) & 0xffffffu) != canon_key) return;
+  const unsigned long long k = atomicAdd(count, 1ull);
+  if (k >= cap) return;
+  unsigned long long* o = (unsigned long long*)(out + k * 48);
+  o[0] = (w1 >> 56) & 0x7full;
+#pragma unroll
+  for (int q = 0; q < 5; q++) o[1 + q] = table[j].w[3 + q];
+}
+
+// KeysToChan: dump the non-empty (expDate, issuer) pairs.
+__global__ void __launch_bounds__(256) k_pairs(const PairSlot* pairs, uint64_t npairs,
+                                               unsigned long long* out, uint64_t cap,
+                                               unsigned long long* count) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= npairs) return;
+  const unsigned long long k = pairs[j].key, c = pairs[j].count;
+  if (k == 0ull || c == 0ull) return;
+  const unsigned long long at = atomicAdd(count, 1ull);
+  if (at >= cap) return;
+  out[2 * at] = k;
+  out[2 * at + 1] = c;
+}
+
+// ------------------------------------------------------------------ synthetic generator
+__global__ void __launch_bounds__(256) k_synth_len(SynthCfg c, uint64_t first, uint64_t n,
+                                                   uint64_t* offsets) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  BackWriter w{nullptr, SYNTH_MAX_LEN};
+  uint32_t iss;
+  uint8_t et;
+  synth_leaf_emit(c, first + i, w, iss, et);
+  offsets[i + 1] = SYNTH_MAX_LEN - w.pos;
+  if (i == 0) offsets[0] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_synth_emit(SynthCfg c, uint64_t first, uint64_t n,
+                                                    const uint64_t* offsets, uint8_t* payload,
+                                                    uint32_t* issuer_idx, uint8_t* entry_type) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+  BackWriter w{payload + offsets[i], len};
+  uint32_t iss;
+  uint8_t et;
+  synth_leaf_emit(c, first + i, w, iss, et);
+  issuer_idx[i] = iss;
+  entry_type[i] = et;
+}
+
+
+// raw get-entries form: lens[2i] = leaf_input bytes, lens[2i+1] = extra_data bytes (scanned into bounds by the host)
+__global__ void __launch_bounds__(256) k_synth_entries_len(SynthCfg c, uint64_t first, uint64_t n, uint64_t* bounds) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  BackWriter w{nullptr, SYNTH_ENTRY_MAX};
+  const uint32_t leaf = synth_entry_emit(c, first + i, w);
+  bounds[2 * i + 1] = leaf;
+  bounds[2 * i + 2] = SYNTH_ENTRY_MAX - w.pos - leaf;
+  if (i == 0) bounds[0] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_synth_entries_emit(SynthCfg c, uint64_t first, uint64_t n,
+                                                            const uint64_t* bounds, uint8_t* blob) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = (uint32_t)(bounds[2 * i + 2] - bounds[2 * i]);
+  BackWriter w{blob + bounds[2 * i], len};
+  synth_entry_emit(c, first + i, w);
+}
+
+}  // namespace ctmr

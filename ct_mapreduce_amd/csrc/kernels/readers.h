@@ -1,0 +1,293 @@
+// kernels/readers.h — byte readers: how one lane gets at the bytes of its certificate (global memory, an LDS tile, a per-lane LDS window with wave-cooperative fills).
+// gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
+#pragma once
+#include "../ctmr_dev.h"
+#include "../entry_decode.h"
+#include "../synth.h"
+
+namespace ctmr {
+
+struct __attribute__((packed, aligned(1))) U16t { uint32_t a, b, c, d; };  // unaligned 16-byte access
+
+// ------------------------------------------------------------------ byte readers
+// 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
+struct LdsReader {
+  const uint32_t* lds;  // tile words (LDS)
+  uint32_t base;        // byte offset of this certificate inside the tile
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t a = base + pos;
+    const uint32_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(lds[i + 1], lds[i], a & 3u);
+  }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
+  __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void touch_tail(uint32_t, uint32_t) const {}
+};
+
+struct GlobalReader {
+  const uint32_t* words;  // 4-byte aligned base of the buffer (kernel argument: global address space)
+  uint64_t base;          // byte offset of this certificate inside the buffer
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(words[i + 1], words[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
+  __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void touch_tail(uint32_t, uint32_t) const {}
+};
+
+// Per-lane LDS window ("software cache") over a certificate that stays in global memory.
+// Each lane owns WCH 16-byte chunks of LDS (lane stride WCH*16+16 bytes: 16-B aligned for
+// ds_write_b128, and ≤4-way bank conflicts on the dword reads).  touch(pos, need) refills the
+// window with WCH independent global_load_dwordx4 (one burst, one memory latency) when the next
+// `need` bytes are not resident; ld4 hits LDS inside the window and falls back to a plain global
+// load outside it — so correctness never depends on where the window is.  The walk touches the
+// front of the certificate and the extension block; SPKI body, SAN body and signature are
+// skipped by length and therefore never fetched from HBM.
+template <int WCH>
+struct WinReader {
+  const uint32_t* g32;  // payload, dword view (global)
+  uint64_t base;        // certificate start (byte offset into payload)
+  uint64_t limit;       // readable bytes of payload (offsets[n] + CTMR_PAYLOAD_PAD)
+  uint32_t* win;        // this lane's window words in LDS
+  int32_t grel;         // window start relative to the certificate start; (base+grel) % 16 == 0
+  static constexpr uint32_t WBYTES = WCH * 16;
+
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel <= WBYTES - 8u) {
+      const uint32_t i = rel >> 2;
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
+    }
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {  // straight from global memory
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ void refill(uint32_t pos) {
+    const uint64_t g = (base + pos) & ~15ull;
+    grel = (int32_t)(int64_t)(g - base);
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    uint4 v[WCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++)
+      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+  }
+  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
+    if (need > WBYTES - 16u) need = WBYTES - 16u;  // the window start is 16-B aligned in HBM
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel > WBYTES - need) refill(pos);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, 256); }
+};
+
+// WinReader whose touch_tail() (the one refill every lane of the wave reaches at the same program point,
+// right behind the SubjectPublicKeyInfo header) is wave-cooperative like the first fill of k_map_winc:
+// 16 adjacent lanes fetch the 16 chunks of one certificate's window, 4 certificates per load
+// instruction.  Falls back to the per-lane refill when some lane of the wave is not at that point.
+template <int WCH>
+struct WinReaderC : WinReader<WCH> {
+  static constexpr uint32_t STRIDE = WCH * 16 + 16;
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) {
+    if (__ballot(1) != ~0ull) {
+      this->refill(pos);
+      return;
+    }
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 15u;
+    const uint64_t g_me = (this->base + pos) & ~15ull;
+    this->grel = (int32_t)(int64_t)(g_me - this->base);
+    uint8_t* lds0 = (uint8_t*)this->win - lane * STRIDE;
+    uint4 v[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+      const uint64_t at = g + 16u * sub;
+      v[it] = (at + 16u <= this->limit) ? *((const uint4*)this->g32 + (at >> 4)) : make_uint4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      *(uint4*)(lds0 + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+// WinReaderC whose ld4() is served by the LDS window ALONE: no per-access "outside the window → global load"
+// branch (88 ld4 per certificate, each of which used to carry its own exec-mask dance).  An access that does fall
+// outside is clamped and remembered in `miss`; the kernel then repeats that certificate with the exact GlobalReader.
+// On well-formed certificates the walk's touch() hints keep every ld4 inside (measured on the synthetic corpus: 0
+// misses in 200 000 certificates once the three reads behind the TBS go through ldg()).
+template <int WCH>
+struct WinReaderS : WinReaderC<WCH> {
+  static constexpr bool kNoClamp = true;  // ld4 clamps into the window itself
+  mutable uint32_t miss;
+  // The 32 bytes behind the TBSCertificate (signatureAlgorithm, the signatureValue header, its pad octet), fetched
+  // by touch_tail() TOGETHER with the extension-block refill: the three ldg() reads at the end of the walk were
+  // three dependent, uncoalesced global round trips per wave; now they are register selects.
+  uint32_t tl[8];
+  uint32_t tl_pos;  // certificate offset of tl[0]'s first byte; 0x80000000 = not fetched (positions are < 2^31)
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    uint32_t rel = pos - (uint32_t)this->grel;
+    constexpr uint32_t LAST = WinReader<WCH>::WBYTES - 8u;
+    miss |= (uint32_t)(rel > LAST);
+    rel = rel > LAST ? LAST : rel;
+    const uint32_t i = rel >> 2;
+    return __builtin_amdgcn_alignbyte(this->win[i + 1], this->win[i], rel & 3u);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t tail) {
+    const uint64_t ta = this->base + tail;
+    const bool have = ta + 32u <= this->limit;
+    const uint8_t* tp = (const uint8_t*)this->g32 + (have ? ta : 0ull);
+    const U16t a = *(const U16t*)tp, b = *(const U16t*)(tp + 16);  // in flight with the refill below
+    WinReaderC<WCH>::touch_tail(pos, tail);
+    tl[0] = a.a; tl[1] = a.b; tl[2] = a.c; tl[3] = a.d;
+    tl[4] = b.a; tl[5] = b.b; tl[6] = b.c; tl[7] = b.d;
+    tl_pos = have ? tail : 0x80000000u;
+  }
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {
+    const uint32_t off = pos - tl_pos;
+    const uint32_t wi = off >> 2;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 7; k++) {
+      lo = wi == k ? tl[k] : lo;
+      hi = wi == k ? tl[k + 1] : hi;
+    }
+    uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+    if (off > 27u) v = WinReader<WCH>::ldg(pos);  // a long AlgorithmIdentifier, or no prefetch: the real load
+    return v;
+  }
+};
+
+// Line-trimmed window.  HBM is fetched in 128-byte lines (scripts/calib_fetch.hip: FETCH_SIZE x2 equals
+// the unique 128-B lines of every window pattern tried), so a refill that ends in the middle of a line
+// pays for the whole line and keeps only part of it.  This reader ends every refill at the end of the
+// line that holds byte pos+N-1 (N = bytes the walk is expected to need from there: NF for the front of
+// the certificate, NE for the extension block and on-demand refills), capped at WCH chunks: a 256-byte
+// refill at a random 16-byte phase touches 2.875 lines on average, a trimmed one 2.4.  Shorter windows
+// only ever cost an extra refill — ld4 falls back to global loads outside the window as before.
+template <int WCH, int NF, int NE>
+struct WinReaderT {
+  const uint32_t* g32;
+  uint64_t base;
+  uint64_t limit;
+  uint32_t* win;
+  int32_t grel;
+  uint32_t wlen;  // valid bytes in the window (multiple of 16)
+
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel + 8u <= wlen && rel < 0x7fffffffu) {
+      const uint32_t i = rel >> 2;
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
+    }
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ void refill(uint32_t pos, uint32_t n) {
+    const uint64_t p = base + pos;
+    const uint64_t g = p & ~15ull;
+    const uint64_t end = ((p + n - 1u) | 127ull) + 1ull;
+    grel = (int32_t)(int64_t)(g - base);
+    uint32_t cnt = (uint32_t)((end - g) >> 4);
+    cnt = cnt < (uint32_t)WCH ? cnt : (uint32_t)WCH;
+    const uint64_t room = limit > g ? (limit - g) >> 4 : 0ull;
+    cnt = room < cnt ? (uint32_t)room : cnt;
+    wlen = cnt * 16u;
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    uint4 v[WCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++) v[k] = (uint32_t)k < cnt ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+  }
+  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
+    if (need > (uint32_t)NE) need = NE;
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel + need > wlen || rel >= 0x7fffffffu) refill(pos, NE);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, NE); }
+};
+
+// Two-region window: MAIN (WCH chunks, moves with the walk) + TAIL (3 chunks pinned at the end of
+// the TBSCertificate: signatureAlgorithm and the BIT STRING header of signatureValue).  The walk
+// knows both addresses as soon as it has decoded the SubjectPublicKeyInfo header — the extension
+// block starts right behind the key, the tail at tbs_end — so touch_tail() fetches both regions
+// in ONE burst of WCH+3 independent global_load_dwordx4: the dependent HBM round trips per
+// certificate drop from ≈8 (front, [3] tag, extensions, sigalg header, BIT STRING header, pad
+// byte, last byte, …) to 2 (front; extensions + tail).  Lane stride (WCH+3)·16 B with WCH even:
+// an odd number of 16-B chunks keeps the dword reads at ≤4-way bank conflicts without a pad chunk.
+template <int WCH>
+struct WinReader2 {
+  static constexpr int TCH = 3;
+  static constexpr uint32_t WBYTES = WCH * 16, TBYTES = TCH * 16;
+  const uint32_t* g32;
+  uint64_t base;
+  uint64_t limit;
+  uint32_t* win;  // main window words; the tail window follows at win + WCH*4
+  int32_t grel;   // main window start relative to the certificate start
+  int32_t trel;   // tail window start (0x7fffff00 = not loaded)
+
+  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
+  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel <= WBYTES - 8u) {
+      const uint32_t i = rel >> 2;
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
+    }
+    const uint32_t rel2 = pos - (uint32_t)trel;
+    if (rel2 <= TBYTES - 8u) {
+      const uint32_t i = WCH * 4 + (rel2 >> 2);
+      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel2 & 3u);
+    }
+    const uint64_t a = base + pos;
+    const uint64_t i = a >> 2;
+    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
+  }
+  __device__ __forceinline__ void refill(uint32_t pos) {
+    const uint64_t g = (base + pos) & ~15ull;
+    grel = (int32_t)(int64_t)(g - base);
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    uint4 v[WCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++)
+      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+  }
+  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
+    if (need > WBYTES - 16u) need = WBYTES - 16u;
+    const uint32_t rel = pos - (uint32_t)grel;
+    if (rel > WBYTES - need) refill(pos);
+  }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t tailpos) {
+    const uint64_t g = (base + pos) & ~15ull;
+    const uint64_t t = (base + tailpos) & ~15ull;
+    grel = (int32_t)(int64_t)(g - base);
+    trel = (int32_t)(int64_t)(t - base);
+    const uint4* src = (const uint4*)g32 + (g >> 4);
+    const uint4* tsrc = (const uint4*)g32 + (t >> 4);
+    uint4 v[WCH], u[TCH];
+#pragma unroll
+    for (int k = 0; k < WCH; k++)
+      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < TCH; k++)
+      u[k] = (t + 16u * k + 16u <= limit) ? tsrc[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+#pragma unroll
+    for (int k = 0; k < TCH; k++) ((uint4*)win)[WCH + k] = u[k];
+  }
+};
+
+}  // namespace ctmr

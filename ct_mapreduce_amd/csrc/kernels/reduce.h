@@ -1,0 +1,514 @@
+// kernels/reduce.h — the reduce: known-certificate table insert (fused into the map kernel by default), WasUnknown, per-issuer counts, compaction of the NEW list.
+// gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
+#pragma once
+#include "map.h"
+
+namespace ctmr {
+
+// ------------------------------------------------------------------ the reduce
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, AGENT);
+}
+
+// Find-or-insert one key.  Returns the slot index (or SID_FULL); *created tells whether this
+// call claimed the slot.  idx32 = batch index merged with atomicMin (pass 0xffffffff for
+// point operations).  Visibility: payload words are written through (agent-scope atomic
+// stores), drained with s_waitcnt vmcnt(0), then w[1] is published; readers poll w[1] with
+// agent-scope loads (MI355X_MICROARCH.md "handoff-flag": write-through payload + drained flag).
+__device__ __forceinline__ uint32_t table_upsert(Slot* table, uint64_t mask, unsigned long long meta,
+                                                 const unsigned long long s[5], uint32_t idx32,
+                                                 uint32_t epoch, bool insert, bool* created,
+                                                 unsigned long long* prev_w0 = nullptr) {
+  const unsigned long long h = key_hash(meta, s);
+  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  uint64_t j = h & mask;
+  *created = false;
+  uint64_t probes = 0;
+  for (;;) {
+    Slot* sl = table + j;
+    unsigned long long w0 = ld_agent(&sl->w[0]);
+    if (w0 == 0ull) {
+      if (!insert) return SID_NONE;
+      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | idx32);
+      if (old == 0ull) {
+        st_agent(&sl->w[2], (unsigned long long)epoch);
+#pragma unroll
+        for (int k = 0; k < 5; k++) st_agent(&sl->w[3 + k], s[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(&sl->w[1], meta);
+        *created = true;
+        return (uint32_t)j;
+      }
+      w0 = old;
+    }
+    if ((w0 & 0xffffffff00000000ull) == tagw && w0 != SLOT_TOMB) {
+      const unsigned long long m = ld_agent(&sl->w[1]);
+      if (!(m & SLOT_VALID)) continue;  // creator has not published yet: poll again
+      bool eq = m == meta;
+#pragma unroll
+      for (int k = 0; k < 5; k++) eq = eq && ld_agent(&sl->w[3 + k]) == s[k];
+      if (eq) {
+        if (insert && idx32 != 0xffffffffu) {
+          const unsigned long long old = atomicMin(&sl->w[0], tagw | idx32);
+          if (prev_w0) *prev_w0 = old;
+        }
+        return (uint32_t)j;
+      }
+    }
+    j = (j + 1) & mask;
+    if (++probes > mask) return SID_FULL;
+  }
+}
+
+struct InsertArgs {
+  const ctmr_record* records;
+  const uint8_t* payload;  // for serials longer than the 20 octets a record carries
+  const uint64_t* offsets;
+  const uint64_t* ends;    // null = packed batch (MapArgs)
+  const uint32_t* canon;   // issuer_idx → canonical issuer
+  Slot* table;
+  uint64_t mask;
+  uint32_t* slot_id;       // candidate slot of DEFER entries (written for those only)
+  uint32_t* ent;           // per entry: status(0..2) | state(3..5) | canonical issuer << 8
+  uint64_t n;
+  uint32_t epoch;
+};
+
+// Per-entry state of the reduce (bits 3..5 of ent[i]); the low 3 bits carry record.status.
+enum : uint32_t {
+  ES_NONE = 0,     // did not reach the set (filtered / parse error / no issuer)
+  ES_CLAIMED = 1,  // claimed an empty slot: WasUnknown unless a lower log index of the same key marks it
+  ES_DEFER = 2,    // met a same-tag slot of this batch: decided in pass 2; WasUnknown unless marked
+  ES_DUP = 3,      // known: since an earlier batch, or a lower log index of this batch holds the key
+  ES_HOST = 4,     // serial longer than CTMR_MAX_SERIAL: exact host-side set
+  ES_FULL = 5      // table full
+};
+__device__ __forceinline__ uint32_t ent_pack(uint32_t status, uint32_t state, uint32_t canon) {
+  return (status & 7u) | (state << 3) | (canon << 8);
+}
+__device__ __forceinline__ uint32_t ent_state(uint32_t e) { return (e >> 3) & 7u; }
+__device__ __forceinline__ bool ent_is_new(uint32_t e) {
+  const uint32_t st = ent_state(e);
+  return (st == ES_CLAIMED) | (st == ES_DEFER);
+}
+// a PASS entry lost to a lower log index of the same key: its ent byte 0 and its record flag
+__device__ __forceinline__ void mark_dup(uint32_t* ent, ctmr_record* records, uint32_t loser) {
+  ((uint8_t*)(ent + loser))[0] = (uint8_t)(CTMR_ST_PASS | (ES_DUP << 3));
+  uint8_t* fl = (uint8_t*)(records + loser) + 1;
+  *fl = (uint8_t)(*fl & ~CTMR_FL_WAS_UNKNOWN);
+}
+
+// Offset of the serialNumber content octets (certificate already accepted by the map).
+__device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, uint32_t L) {
+  bool ok = true;
+  uint32_t tag, cs, ce;
+  rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+  rd_hdr(r, L, cs, L, ok, tag, cs, ce);
+  uint32_t q = cs;
+  if ((r.ld4(q) & 0xffu) == 0xa0u) {
+    rd_hdr(r, L, q, L, ok, tag, cs, ce);
+    q = ce;
+  }
+  rd_hdr(r, L, q, L, ok, tag, cs, ce);
+  return cs;
+}
+
+__device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, const uint4& r0,
+                                           const uint4& r1, unsigned long long s[5]) {
+  const uint32_t slen = r0.x >> 16;
+  s[0] = (unsigned long long)r0.w | ((unsigned long long)r1.x << 32);
+  s[1] = (unsigned long long)r1.y | ((unsigned long long)r1.z << 32);
+  s[2] = (unsigned long long)r1.w;
+  s[3] = 0;
+  s[4] = 0;
+  if (slen > 20) {
+    // octets 20..slen-1 come from the certificate itself
+    uint64_t lo, hi;
+    cert_range(a.offsets, a.ends, i, lo, hi);
+    GlobalReader g{(const uint32_t*)a.payload, lo};
+    const uint32_t so = serial_content_off(g, (uint32_t)(hi - lo));
+    uint32_t x[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const uint32_t pos = 20u + 4u * k;
+      if (pos < slen) {
+        const uint32_t rem = slen - pos;
+        const uint32_t v = g.ld4(so + pos);
+        x[k] = rem >= 4 ? v : (v & (0xffffffffu >> (8 * (4 - rem))));
+      }
+    }
+    s[2] |= (unsigned long long)x[0] << 32;
+    s[3] = (unsigned long long)x[1] | ((unsigned long long)x[2] << 32);
+    s[4] = (unsigned long long)x[3] | ((unsigned long long)x[4] << 32);
+  }
+}
+
+// KnownCertificates.WasUnknown → RemoteCache.SetInsert (knowncertificates.go:38-55) for every
+// PASS entry, against the in-HBM table.  PASS 1 (this kernel) never reads anything another lane
+// of the same launch wrote except the CAS word itself:
+//   empty slot      → one atomicCAS claims it (state CLAIMED); the 64-byte slot image is written
+//                     after the probe loop, four lanes per slot, so that one store instruction emits
+//                     whole 64-byte slots (one memory transaction each) instead of four partial ones
+//   same tag, slot of an OLDER batch (epoch in [1, cur)) → fully visible: compare now (state DUP)
+//   same tag, slot of THIS batch (epoch 0 = not written yet, or cur) → remember the slot (state
+//                     DEFER), decide in pass 2 after the kernel boundary made every pass-1 store visible
+// Records arrive with WAS_UNKNOWN set optimistically by the map; it is cleared here / in pass 2
+// for duplicates only.  The reduce's later passes read the 4-byte ent[] word, never the table.
+// Pass-1 set insert of one PASS record held in registers (r0, r1 = the two 16-byte halves of the record).
+// On a claim the 64-byte slot image is returned in q0..q3 and `claimed` is the slot index; the caller
+// stores it cooperatively (store_slots_wave).  Returns the ES_* state.
+__device__ __forceinline__ uint32_t insert_probe(const InsertArgs& a, uint64_t i, const uint4& r0, const uint4& r1,
+                                                 uint32_t canon, uint64_t& claimed, uint4& q0, uint4& q1, uint4& q2,
+                                                 uint4& q3) {
+  const uint32_t slen = r0.x >> 16;
+  if (slen > CTMR_MAX_SERIAL) return ES_HOST;
+  unsigned long long s[5];
+  record_key(a, i, r0, r1, s);
+  const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
+  const unsigned long long h = key_hash(meta, s);
+  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  uint64_t j = h & a.mask;
+  for (uint64_t probes = 0; probes <= a.mask; probes++) {
+    Slot* sl = a.table + j;
+    const unsigned long long w0 = tagw | (uint32_t)i;
+    const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
+    if (old == 0ull) {  // claimed
+      q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)meta, (uint32_t)(meta >> 32));
+      q1 = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+      q2 = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+      q3 = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+      claimed = j;
+      return ES_CLAIMED;
+    }
+    if ((old & 0xffffffff00000000ull) == tagw) {
+      const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
+      if (ep != 0u && ep != a.epoch) {  // older batch: complete and visible
+        bool eq = sl->w[1] == meta;
+#pragma unroll
+        for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+        if (eq) return ES_DUP;
+      } else {
+        a.slot_id[i] = (uint32_t)j;
+        return ES_DEFER;
+      }
+    }
+    j = (j + 1) & a.mask;
+  }
+  return ES_FULL;
+}
+
+// Cooperative slot write of one wave: lane L parks its 64-byte image at img[L*4 .. L*4+3]; store
+// instruction r then has lane L write quarter L%4 of the slot of lane 16r + L/4, so four adjacent
+// lanes emit one whole slot.  (w[0] is rewritten with the value the CAS stored: concurrent CAS
+// attempts of this pass see a non-zero word either way; atomicMin only runs in pass 2.)
+__device__ __forceinline__ void store_slots_wave(Slot* table, uint4* img, uint32_t lane, uint64_t claimed,
+                                                 const uint4& q0, const uint4& q1, const uint4& q2, const uint4& q3) {
+  uint4* my = img + lane * 4;
+  my[0] = q0; my[1] = q1; my[2] = q2; my[3] = q3;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t src = 16u * r + (lane >> 2);
+    const uint64_t sj = __shfl(claimed, src);
+    if (sj != ~0ull) {
+      const uint4 v = img[r * 64 + lane];
+      ((uint4*)(table + sj))[lane & 3u] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 slot images
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t state = ES_NONE, status = CTMR_ST__COUNT, canon = 0;
+  uint64_t claimed = ~0ull;  // slot index when this lane claimed one
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  if (i < a.n) {
+    const uint4* rp = (const uint4*)(a.records + i);
+    const uint4 r0 = rp[0];
+    status = r0.x & 0xffu;
+    if (status == CTMR_ST_PASS) {
+      canon = a.canon[r0.z];
+      const uint4 r1 = rp[1];
+      state = insert_probe(a, i, r0, r1, canon, claimed, q0, q1, q2, q3);
+      if (state != ES_CLAIMED && state != ES_DEFER) {  // not (yet) unknown: drop the optimistic flag
+        uint8_t* fl = (uint8_t*)(a.records + i) + 1;
+        *fl = (uint8_t)((r0.x >> 8) & ~CTMR_FL_WAS_UNKNOWN);
+      }
+    }
+    a.ent[i] = ent_pack(status, state, canon);
+  }
+  store_slots_wave(a.table, img[wv], lane, claimed, q0, q1, q2, q3);
+}
+
+// PASS 2: DEFER entries — their candidate slot was created by this batch and is complete now.
+// Equal key → atomicMin the batch index into w[0]; the RETURNED previous minimum tells who loses:
+// whichever of (previous holder, me) has the higher log index is marked DUP, so after this pass
+// exactly the lowest log index of every new key is still CLAIMED/DEFER — nobody has to re-read the
+// table to find out.  A 32-bit tag collision between different keys (≈2^-32 per probe) falls back
+// to the fully synchronised upsert, which is also safe against other pass-2 lanes inserting the
+// same key concurrently.
+__global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* records) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const uint32_t e = a.ent[i];
+  if (ent_state(e) != ES_DEFER) return;
+  const uint32_t sid = a.slot_id[i];
+  const uint4* rp = (const uint4*)(a.records + i);
+  const uint4 r0 = rp[0], r1 = rp[1];
+  unsigned long long s[5];
+  record_key(a, i, r0, r1, s);
+  const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
+  Slot* sl = a.table + sid;
+  bool eq = sl->w[1] == meta;
+#pragma unroll
+  for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+  unsigned long long prev = ~0ull;
+  if (eq) {
+    const unsigned long long tagw = (unsigned long long)key_tag(key_hash(meta, s)) << 32;
+    prev = atomicMin(&sl->w[0], tagw | (uint32_t)i);
+  } else {
+    bool created;
+    const uint32_t r = table_upsert(a.table, a.mask, meta, s, (uint32_t)i, a.epoch, true, &created, &prev);
+    if (r == SID_FULL) {
+      ((uint8_t*)(a.ent + i))[0] = (uint8_t)(CTMR_ST_PASS | (ES_FULL << 3));
+      return;
+    }
+    if (created) return;  // stays DEFER = unknown unless a lower index joins and marks it
+  }
+  const uint32_t other = (uint32_t)prev;
+  mark_dup(a.ent, records, other < (uint32_t)i ? (uint32_t)i : other);
+}
+
+// Fused map + pass-1 insert (variant 14): the lane that just finished walking a certificate probes the
+// known-certificate table straight from its registers — the 32-byte record is not re-read (−3.2 GB per
+// 100 M entries), the WAS_UNKNOWN flag is final before the record is stored (no second scattered write for
+// old-batch duplicates) and the random-access latency of the CAS hides behind the walks of the other
+// waves of the CU instead of being a kernel of its own.  Pass 2 (k_insert2) is unchanged.
+// (Tried and dropped: loading the slot's claim word early, when the key is known but the extension block
+// is still in flight, so that the CAS finds the line on-die — +0.6 ms at 100 M entries: the kernel is bound
+// by memory transactions, not by the latency of the probe.)
+template <int WCH, bool STRICT>
+__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
+  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t i = first + lane;
+  const bool live = i < a.n;
+  constexpr uint32_t STRIDE = WCH * 16 + 16;
+  const uint64_t limit = map_limit(a);
+  uint64_t lo = 0, hi = 0;
+  if (live) cert_range(a.offsets, a.ends, i, lo, hi);
+  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
+  {
+    uint4 v[16];
+    const uint32_t sub = lane & 15u;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+      const uint64_t at = g + 16u * sub;
+      v[it] = (g != ~0ull && at + 16u <= limit) ? *(const uint4*)(a.payload + at) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+  uint64_t claimed = ~0ull;
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  if (live) {
+    if constexpr (STRICT) {
+      WinReaderS<WCH> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                          (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
+      map_one(r, hi - lo, i, a, o0, o1);
+      if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
+        GlobalReader g{(const uint32_t*)a.payload, lo};
+        map_one(g, hi - lo, i, a, o0, o1);
+      }
+    } else {
+      WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                         (int32_t)(int64_t)(g_me - lo)}};
+      map_one(r, hi - lo, i, a, o0, o1);
+    }
+    const uint32_t status = o0.x & 0xffu;
+    uint32_t state = ES_NONE, canon = 0;
+    if (status == CTMR_ST_PASS) {
+      canon = ia.canon[o0.z];
+      state = insert_probe(ia, i, o0, o1, canon, claimed, q0, q1, q2, q3);
+      if (state != ES_CLAIMED && state != ES_DEFER) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
+    }
+    ia.ent[i] = ent_pack(status, state, canon);
+  }
+  store_records_wave(a, first, live, o0, o1);
+  __builtin_amdgcn_wave_barrier();
+  store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
+}
+
+// (Tried and dropped, session 4: a software-pipelined form — one wave walks 2 or 4 batches of 64 certificates and
+// fetches the next batch's front windows into registers while walking the current one.  256 VGPRs → 8 waves per CU,
+// and the first vector load inside the walk (the issuerCN filter words) waits on vmcnt for the prefetch issued just
+// before it, so the overlap never materialises: 26.0 ms against 23.1 ms, profiles/r01/s4/sweep_pipe.txt.)
+// Wave-aggregated add: one atomic per distinct key per wave (the "match-any" loop).
+__device__ __forceinline__ void wave_agg_add(bool active, uint32_t key, unsigned long long* arr) {
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k = __shfl(key, leader);
+    const unsigned long long same = __ballot(active && key == k) & todo;
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&arr[k], (unsigned long long)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+__device__ __forceinline__ bool pair_add(PairSlot* pairs, uint64_t pmask, unsigned long long key,
+                                         long long delta) {
+  uint64_t j = mixk(key) & pmask;
+  for (uint64_t probes = 0; probes <= pmask; probes++) {
+    unsigned long long k = ld_agent(&pairs[j].key);
+    if (k == 0ull) {
+      const unsigned long long old = atomicCAS(&pairs[j].key, 0ull, key);
+      k = old == 0ull ? key : old;
+    }
+    if (k == key) {
+      atomicAdd(&pairs[j].count, (unsigned long long)delta);
+      return true;
+    }
+    j = (j + 1) & pmask;
+  }
+  return false;
+}
+
+struct ResolveArgs {
+  const uint32_t* ent;
+  unsigned long long* issuer_counts;  // per canonical issuer
+  DevStats* stats;
+  uint32_t* blk_new;  // NEW count per 1024-entry block
+  uint64_t n;
+};
+
+// One streaming pass over ent[] (4 bytes per entry; no table or record access): per-issuer unique
+// counts of the entries that WERE unknown (Σ_expDate SCARD, storage-statistics.go:44-53), status
+// histogram, NEW count per 1024-entry block for the compaction.
+// Persistent blocks: per-issuer counts are first accumulated in an LDS histogram (issuers
+// below RES_LDS_ISSUERS) and flushed with ONE global atomic per non-empty bin per block —
+// hundreds of thousands of device atomics on the few cache lines of the hot issuers serialise
+// at the memory side otherwise.  Issuers beyond the LDS bins use wave-aggregated global atomics.
+constexpr uint32_t RES_LDS_ISSUERS = 4096;
+
+__global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
+  __shared__ uint32_t hist[CTMR_ST__COUNT + 4];
+  __shared__ uint32_t ih[RES_LDS_ISSUERS];
+  __shared__ uint32_t blk_cnt;
+  if (threadIdx.x < CTMR_ST__COUNT + 4) hist[threadIdx.x] = 0;
+  for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024) ih[k] = 0;
+  __syncthreads();
+  for (uint64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+    if (threadIdx.x == 0) blk_cnt = 0;
+    __syncthreads();
+    const uint64_t i = blk * 1024 + threadIdx.x;
+    bool is_new = false, is_dup = false, is_host = false, is_full = false;
+    uint32_t status = CTMR_ST__COUNT, canon = 0;
+    if (i < a.n) {
+      const uint32_t e = a.ent[i];
+      status = e & 7u;
+      const uint32_t st = ent_state(e);
+      canon = e >> 8;
+      is_new = (st == ES_CLAIMED) | (st == ES_DEFER);
+      is_dup = st == ES_DUP;
+      is_host = st == ES_HOST;
+      is_full = st == ES_FULL;
+    }
+    if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
+    wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, a.issuer_counts);
+    // (the per-(expDate, issuer) cardinalities are rebuilt lazily by k_build_pairs on the first
+    //  SetCardinality/KeysToChan after a mutation — they are statistics, not hot-path state)
+    const unsigned long long m_new = __ballot(is_new), m_dup = __ballot(is_dup),
+                             m_host = __ballot(is_host), m_full = __ballot(is_full);
+    if ((threadIdx.x & 63) == 0) {
+      if (m_new) {
+        atomicAdd(&blk_cnt, (uint32_t)__popcll(m_new));
+        atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(m_new));
+      }
+      if (m_dup) atomicAdd(&hist[CTMR_ST__COUNT + 1], (uint32_t)__popcll(m_dup));
+      if (m_host) atomicAdd(&hist[CTMR_ST__COUNT + 2], (uint32_t)__popcll(m_host));
+      if (m_full) atomicAdd(&hist[CTMR_ST__COUNT + 3], (uint32_t)__popcll(m_full));
+    }
+#pragma unroll
+    for (uint32_t st = 0; st < CTMR_ST__COUNT; st++) {
+      const unsigned long long m = __ballot(status == st);
+      if ((threadIdx.x & 63) == 0 && m) atomicAdd(&hist[st], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.blk_new[blk] = blk_cnt;
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024)
+    if (ih[k]) atomicAdd(&a.issuer_counts[k], (unsigned long long)ih[k]);
+  if (threadIdx.x < CTMR_ST__COUNT) {
+    if (hist[threadIdx.x]) atomicAdd(&a.stats->by_status[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+  } else if (threadIdx.x == CTMR_ST__COUNT) {
+    if (hist[CTMR_ST__COUNT]) atomicAdd(&a.stats->n_new, (unsigned long long)hist[CTMR_ST__COUNT]);
+  } else if (threadIdx.x == CTMR_ST__COUNT + 1) {
+    if (hist[CTMR_ST__COUNT + 1]) atomicAdd(&a.stats->n_dup, (unsigned long long)hist[CTMR_ST__COUNT + 1]);
+  } else if (threadIdx.x == CTMR_ST__COUNT + 2) {
+    if (hist[CTMR_ST__COUNT + 2]) atomicAdd(&a.stats->n_host, (unsigned long long)hist[CTMR_ST__COUNT + 2]);
+  } else if (threadIdx.x == CTMR_ST__COUNT + 3) {
+    if (hist[CTMR_ST__COUNT + 3]) atomicAdd(&a.stats->n_full, (unsigned long long)hist[CTMR_ST__COUNT + 3]);
+  }
+}
+
+// Stream compaction of the NEW entries, ascending: wave ballot + popcount prefix inside a
+// 1024-entry block, block bases from the exclusive scan of blk_new.  The NEW predicate comes
+// from ent[] (local reduce) or from the record flag (exchange mode, ent == nullptr).
+__global__ void __launch_bounds__(1024) k_compact(const ctmr_record* records, const uint32_t* ent, uint64_t n,
+                                                  const uint64_t* blk_base, uint64_t* new_idx) {
+  __shared__ uint32_t wave_cnt[16];
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  bool is_new = false;
+  if (i < n)
+    is_new = ent ? ent_is_new(ent[i]) : (((const uint8_t*)(records + i))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
+  const unsigned long long m = __ballot(is_new);
+  if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (is_new) {
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < wv; k++) before += wave_cnt[k];
+    const uint32_t rank = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    new_idx[blk_base[blockIdx.x] + rank] = i;
+  }
+}
+
+// exclusive scan of blk_new (u32) into blk_base (u64): single workgroup, chunked
+__global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* blk_new, uint64_t nb,
+                                                      uint64_t* blk_base) {
+  __shared__ unsigned long long part[1024];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < nb; base += 1024) {
+    const uint64_t i = base + threadIdx.x;
+    const unsigned long long v = i < nb ? blk_new[i] : 0ull;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      const unsigned long long t = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) blk_base[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+}
+
+}  // namespace ctmr
