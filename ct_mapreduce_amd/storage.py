@@ -852,3 +852,77 @@ def storage_statistics(db: FilesystemDatabase):
         totalCRLs += len(crls)
         out[issuerObj.Issuer.ID()] = (len(issuerObj.ExpDates), count, sorted(crls), sorted(dns))
     return out, totalSerials, totalCRLs
+
+
+# ------------------------------------------------------------------------------------------------
+# N4, second half: the sets as a Redis protocol stream.  `redis-cli --pipe < dump` loads them into the Redis of a
+# reference deployment (or a scratch one), so that a real ct-fetch run elsewhere and this engine can be diffed with
+# the reference's own tools (storage-statistics, SCARD/SMEMBERS); redis_load() is the way back.
+_SET_PATTERNS = ("%s::*" % kSerials, "%s::*" % kCrls, "%s::*" % kIssuers)
+
+
+def _resp(*args) -> bytes:
+    out = [b"*%d\r\n" % len(args)]
+    for a in args:
+        a = _b(a)
+        out.append(b"$%d\r\n" % len(a) + a + b"\r\n")
+    return b"".join(out)
+
+
+def redis_dump(cache: RemoteCache, out, patterns=_SET_PATTERNS, members_per_command=512) -> dict:
+    """Writes SADD commands for every set matching `patterns` (members are raw bytes — serials contain NULs, which
+    RESP bulk strings carry unchanged) and, for the known-certificate sets, the EXPIREAT the reference puts on them:
+    the expDate of the key (KnownCertificates.setExpiryFlag, storage/knowncertificates.go:98-104).  → counts."""
+    n_keys = n_members = 0
+    prefix = (kSerials + "::").encode()
+    for pat in patterns:
+        for key in sorted(cache.KeysToChan(pat)):
+            key = _b(key)
+            members = sorted(set(cache.SetToChan(key)))       # SetToChan may repeat members (knowncertificates.go:80-93)
+            for i in range(0, len(members), members_per_command):
+                out.write(_resp(b"SADD", key, *members[i:i + members_per_command]))
+            if key.startswith(prefix):
+                exp = ExpDate.Parse(key[len(prefix):].split(b"::", 1)[0].decode())
+                out.write(_resp(b"EXPIREAT", key, str(exp.ExpireTime())))
+            n_keys += 1
+            n_members += len(members)
+    return {"keys": n_keys, "members": n_members}
+
+
+def redis_load(cache: RemoteCache, stream) -> dict:
+    """Applies a redis_dump() stream (RESP arrays of bulk strings; SADD and EXPIREAT) to `cache`."""
+    data = stream.read()
+    pos, n_cmd, n_new = 0, 0, 0
+
+    def line():
+        nonlocal pos
+        e = data.index(b"\r\n", pos)
+        v = data[pos:e]
+        pos = e + 2
+        return v
+
+    while pos < len(data):
+        head = line()
+        if head[:1] != b"*":
+            raise ValueError("not a RESP array at byte %d" % (pos - len(head) - 2))
+        args = []
+        for _ in range(int(head[1:])):
+            ln = line()
+            if ln[:1] != b"$":
+                raise ValueError("not a bulk string at byte %d" % (pos - len(ln) - 2))
+            n = int(ln[1:])
+            args.append(data[pos:pos + n])
+            if data[pos + n:pos + n + 2] != b"\r\n":
+                raise ValueError("bulk string not terminated at byte %d" % (pos + n))
+            pos += n + 2
+        cmd = args[0].upper()
+        if cmd == b"SADD":
+            for m in args[2:]:
+                n_new += bool(cache.SetInsert(args[1], m))
+        elif cmd == b"EXPIREAT":
+            cache.ExpireAt(args[1], int(args[2]))
+        else:
+            raise ValueError("unsupported command %r" % cmd)
+        n_cmd += 1
+    return {"commands": n_cmd, "inserted": n_new}
+

@@ -238,3 +238,34 @@ def test_pem_encode_matches_reference_fixture(golden_certs, golden_dir):
     for n, der in golden_certs.items():
         want = open(os.path.join(golden_dir, n + ".pem"), "rb").read().strip() + b"\n"
         assert S.pem_encode(der) == want
+
+
+def test_redis_dump_is_exact_resp_and_round_trips():
+    """N4: the sets as a Redis protocol stream (SADD + the EXPIREAT of knowncertificates.go:98-104) and back."""
+    import io
+    c = S.MockRemoteCache()
+    c.SetInsert("serials::2020-02-05-00::iss", b"\x00\xaa")            # the raw serial octets of kLeadingZeroes
+    c.SetInsert("serials::2020-02-05-00::iss", b"\x01")
+    c.SetInsert("crl::iss", b"http://a/b.crl")
+    buf = io.BytesIO()
+    assert S.redis_dump(c, buf) == {"keys": 2, "members": 3}
+    key = b"serials::2020-02-05-00::iss"
+    assert buf.getvalue() == (
+        b"*4\r\n$4\r\nSADD\r\n$%d\r\n%s\r\n$2\r\n\x00\xaa\r\n$1\r\n\x01\r\n" % (len(key), key) +
+        b"*3\r\n$8\r\nEXPIREAT\r\n$%d\r\n%s\r\n$10\r\n%d\r\n" % (len(key), key, utc(2020, 2, 5)) +
+        b"*3\r\n$4\r\nSADD\r\n$8\r\ncrl::iss\r\n$14\r\nhttp://a/b.crl\r\n")
+    d = S.MockRemoteCache()
+    assert S.redis_load(d, io.BytesIO(buf.getvalue())) == {"commands": 3, "inserted": 3}
+    assert d.Data == c.Data and d.Expirations == {key: utc(2020, 2, 5)}
+    # many members: several SADD commands per key, nothing lost, members with CR/LF survive
+    big = S.MockRemoteCache()
+    for i in range(1300):
+        big.SetInsert("issuer::x", b"\r\n%d\r\n" % i)
+    buf = io.BytesIO()
+    S.redis_dump(big, buf, members_per_command=512)
+    assert buf.getvalue().count(b"SADD") == 3
+    back = S.MockRemoteCache()
+    S.redis_load(back, io.BytesIO(buf.getvalue()))
+    assert back.Data == big.Data
+    with pytest.raises(ValueError):
+        S.redis_load(back, io.BytesIO(b"*1\r\n$4\r\nPING\r\n"))

@@ -132,3 +132,38 @@ def test_StoreBatch_end_to_end(tmp_path, mode):
     days = {orc.day_id(orc.parse_cert(leafs[j]).not_after) for j in range(n) if status[j] == 0}
     assert {d for d in os.listdir(tmp_path) if os.path.exists(tmp_path / d / "dirty")} == days
     eng.close()
+
+
+def test_redis_dump_of_the_gpu_sets_equals_the_oracle_and_restores(engine):
+    """N4: dump the HBM-resident sets as a Redis protocol stream, load it into a mock cache and into a second
+    engine: keys, members, cardinalities and expiry times are the oracle's."""
+    import io
+    cfg = synth.config(seed=91, n_issuers=6, dup_permille=200, ca_permille=20, expired_permille=20)
+    issuers = synth.issuers(cfg)
+    now = synth.BASE_TIME
+    engine.add_issuers(issuers)
+    engine.set_filter(b"", False, now)
+    b = synth.host_batch(cfg, 0, 3000)
+    engine.map_batch(b)
+    o = orc.Engine(b"", False, now)
+    for i in range(b.n):
+        o.entry(b.cert(i), issuers[int(b.issuer_idx[i])])
+    okeys = [k for k in o.keys() if k.startswith(b"serials::")]
+    buf = io.BytesIO()
+    n = S.redis_dump(S.GpuRemoteCache(engine), buf)
+    assert n == {"keys": len(okeys), "members": o.total_count()}
+    mock = S.MockRemoteCache()
+    S.redis_load(mock, io.BytesIO(buf.getvalue()))
+    assert sorted(mock.Data) == okeys
+    for k in okeys:
+        assert mock.Data[k] == sorted(o.members(k))
+        assert mock.Expirations[k] == o.key_expiry(k)
+    e2 = ctmr.Engine(device=0, table_slots=1 << 14, pair_slots=1 << 12)
+    e2.add_issuers(issuers)
+    res = S.redis_load(S.GpuRemoteCache(e2), io.BytesIO(buf.getvalue()))
+    assert res["inserted"] == o.total_count()
+    assert sorted(e2.keys(b"serials::*")) == okeys
+    assert (e2.issuer_counts() == engine.issuer_counts()).all()
+    for k in okeys[::7]:
+        assert e2.set_list(k) == sorted(o.members(k))
+    e2.close()
