@@ -796,7 +796,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   if (prof) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
   // ---- insert (pass 1 ran inside the map kernel when fused)
   if (!fused) hipLaunchKernelGGL(k_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia);
-  hipLaunchKernelGGL(k_insert2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, ia, d_records);
+  hipLaunchKernelGGL(k_insert2, dim3((unsigned)((n + INSERT2_PER_BLOCK - 1) / INSERT2_PER_BLOCK)), dim3(256), 0, e->stream, ia, d_records);
   if (prof) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
   // ---- resolve
   ResolveArgs ra;
@@ -807,7 +807,7 @@ static int map_device_locked(ctmr_engine* e, const uint8_t* d_payload, const uin
   //      batch (a host that feeds 1 001-entry batches — one get-entries response — pays for every extra round trip)
   auto compact = [&]() {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records, (const uint32_t*)d_ent, n, (const uint64_t*)d_blk_base, d_new_idx);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, e->stream, (const ctmr_record*)d_records, (const uint32_t*)d_ent, n, (const uint64_t*)d_blk_base, d_new_idx);
   };
   if (d_new_idx) compact();
   if (prof) HIPCHK(e, hipEventRecord(e->ev[4], e->stream));
@@ -1473,7 +1473,7 @@ int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t 
                      (const ctmr_record*)d_records, n, nb, e->d_stats);
   if (d_new_idx) {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records,
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, e->stream, (const ctmr_record*)d_records,
                        (const uint32_t*)nullptr, n, (const uint64_t*)d_blk_base, d_new_idx);
   }
   DevStats hs;
@@ -1648,7 +1648,7 @@ int ctmr_bloom_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, 
                      (const ctmr_record*)d_records, n, nb, e->d_stats);
   if (d_new_idx) {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, d_blk_new, nb, d_blk_base);
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(1024), 0, e->stream, (const ctmr_record*)d_records,
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, e->stream, (const ctmr_record*)d_records,
                        (const uint32_t*)nullptr, n, (const uint64_t*)d_blk_base, d_new_idx);
   }
   DevStats hs;

@@ -254,11 +254,7 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
 // table to find out.  A 32-bit tag collision between different keys (≈2^-32 per probe) falls back
 // to the fully synchronised upsert, which is also safe against other pass-2 lanes inserting the
 // same key concurrently.
-__global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* records) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  const uint32_t e = a.ent[i];
-  if (ent_state(e) != ES_DEFER) return;
+__device__ __forceinline__ void insert2_one(const InsertArgs& a, ctmr_record* records, uint64_t i, uint32_t e) {
   const uint32_t sid = a.slot_id[i];
   const uint4* rp = (const uint4*)(a.records + i);
   const uint4 r0 = rp[0], r1 = rp[1];
@@ -284,6 +280,24 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
   }
   const uint32_t other = (uint32_t)prev;
   mark_dup(a.ent, records, other < (uint32_t)i ? (uint32_t)i : other);
+}
+
+// Four entries per thread, one 16-byte load of ent[]: nearly every entry is not DEFER, so the kernel is a scan of
+// ent[] — with one entry per thread it was bound by launching 1.5 M near-empty waves per 100 M entries (1.4 ms).
+constexpr uint32_t INSERT2_PER_BLOCK = 1024;
+__global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* records) {
+  const uint64_t i0 = (uint64_t)blockIdx.x * INSERT2_PER_BLOCK + threadIdx.x * 4u;
+  if (i0 >= a.n) return;
+  uint32_t e[4] = {0u, 0u, 0u, 0u};
+  if (i0 + 4 <= a.n) {
+    const uint4 v = *(const uint4*)(a.ent + i0);
+    e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+  } else {
+    for (uint32_t k = 0; i0 + k < a.n; k++) e[k] = a.ent[i0 + k];
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++)
+    if (ent_state(e[k]) == ES_DEFER) insert2_one(a, records, i0 + k, e[k]);
 }
 
 // Fused map + pass-1 insert (variant 14): the lane that just finished walking a certificate probes the
@@ -467,47 +481,64 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
 // Stream compaction of the NEW entries, ascending: wave ballot + popcount prefix inside a
 // 1024-entry block, block bases from the exclusive scan of blk_new.  The NEW predicate comes
 // from ent[] (local reduce) or from the record flag (exchange mode, ent == nullptr).
-__global__ void __launch_bounds__(1024) k_compact(const ctmr_record* records, const uint32_t* ent, uint64_t n,
-                                                  const uint64_t* blk_base, uint64_t* new_idx) {
-  __shared__ uint32_t wave_cnt[16];
-  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+// Four entries per thread (256 threads per 1024-entry block): the per-thread counts 0..4 are prefix-summed over the
+// wave with three ballots (one per bit of the count).
+__global__ void __launch_bounds__(256) k_compact(const ctmr_record* records, const uint32_t* ent, uint64_t n,
+                                                 const uint64_t* blk_base, uint64_t* new_idx) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint64_t i0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4u;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  bool is_new = false;
-  if (i < n)
-    is_new = ent ? ent_is_new(ent[i]) : (((const uint8_t*)(records + i))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
-  const unsigned long long m = __ballot(is_new);
-  if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+  bool f[4] = {false, false, false, false};
+  if (ent) {
+    if (i0 + 4 <= n) {
+      const uint4 v = *(const uint4*)(ent + i0);
+      f[0] = ent_is_new(v.x); f[1] = ent_is_new(v.y); f[2] = ent_is_new(v.z); f[3] = ent_is_new(v.w);
+    } else {
+      for (uint32_t k = 0; k < 4 && i0 + k < n; k++) f[k] = ent_is_new(ent[i0 + k]);
+    }
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (i0 + k < n) f[k] = (((const uint8_t*)(records + i0 + k))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
+  }
+  const uint32_t c = (uint32_t)f[0] + f[1] + f[2] + f[3];
+  const unsigned long long m0 = __ballot(c & 1u), m1 = __ballot(c & 2u), m2 = __ballot(c & 4u);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t pre = (uint32_t)__popcll(m0 & lt) + 2u * (uint32_t)__popcll(m1 & lt) + 4u * (uint32_t)__popcll(m2 & lt);
+  if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m0) + 2u * (uint32_t)__popcll(m1) + 4u * (uint32_t)__popcll(m2);
   __syncthreads();
-  if (is_new) {
-    uint32_t before = 0;
-    for (uint32_t k = 0; k < wv; k++) before += wave_cnt[k];
-    const uint32_t rank = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    new_idx[blk_base[blockIdx.x] + rank] = i;
+  if (c) {
+    for (uint32_t k = 0; k < wv; k++) pre += wave_cnt[k];
+    uint64_t at = blk_base[blockIdx.x] + pre;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (f[k]) new_idx[at++] = i0 + k;
   }
 }
 
-// exclusive scan of blk_new (u32) into blk_base (u64): single workgroup, chunked
+// exclusive scan of blk_new (u32) into blk_base (u64): single workgroup
 __global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* blk_new, uint64_t nb,
                                                       uint64_t* blk_base) {
+  // every thread sums a contiguous chunk, ONE block-wide scan of the 1024 sums, every thread writes its chunk's
+  // prefixes (the chunked 10-step scan of before took 0.2 ms per 100 M entries, all of it on the critical path)
   __shared__ unsigned long long part[1024];
-  __shared__ unsigned long long carry;
-  if (threadIdx.x == 0) carry = 0;
+  const uint64_t per = (nb + 1023) / 1024;
+  const uint64_t lo = (uint64_t)threadIdx.x * per < nb ? (uint64_t)threadIdx.x * per : nb;
+  const uint64_t hi = lo + per < nb ? lo + per : nb;
+  unsigned long long sum = 0;
+  for (uint64_t i = lo; i < hi; i++) sum += blk_new[i];
+  part[threadIdx.x] = sum;
   __syncthreads();
-  for (uint64_t base = 0; base < nb; base += 1024) {
-    const uint64_t i = base + threadIdx.x;
-    const unsigned long long v = i < nb ? blk_new[i] : 0ull;
-    part[threadIdx.x] = v;
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const unsigned long long t = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-      const unsigned long long t = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
-      __syncthreads();
-      part[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nb) blk_base[i] = carry + part[threadIdx.x] - v;
+    part[threadIdx.x] += t;
     __syncthreads();
-    if (threadIdx.x == 1023) carry += part[1023];
-    __syncthreads();
+  }
+  unsigned long long run = part[threadIdx.x] - sum;
+  for (uint64_t i = lo; i < hi; i++) {
+    blk_base[i] = run;
+    run += blk_new[i];
   }
 }
 
