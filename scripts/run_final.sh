@@ -1,9 +1,19 @@
 #!/bin/bash
-# what the driver does at round end: build check, GPU tests, smoke, default bench
+# what the driver does at round end (build check, smoke, GPU tests, default bench) + the profiled run of the same command
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/s4; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; mkdir -p $OUT
 cd $R
 timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -3
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_final.log 2>&1; tail -3 $OUT/pytest_final.log
-timeout 600 python bench.py --pem > $OUT/bench_final.json 2> $OUT/bench_final.err; python -c "
-import json; d=json.load(open('$OUT/bench_final.json')); print(d['value'], d['roofline']['frac'], d['roofline']['frac_physical'], d['kernel_ms'], d['cpu_baseline']['value'], d['parity_vs_oracle_on_sample']); print('pem', d.get('pem'))"; tail -2 $OUT/bench_final.err
+timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_final.log 2>&1; tail -3 $OUT/pytest_final.log
+timeout 900 python bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err; python -c "
+import json; d=json.loads([l for l in open('$OUT/bench_final.json').read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['frac_physical'], d['kernel_ms'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['parity_vs_oracle_on_sample'])"; tail -2 $OUT/bench_final.err
+( cd /tmp; export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o final --output-format csv -- python $R/bench.py --no-cpu > $OUT/bench_final_profiled.json 2> $OUT/bench_final_profiled.err
+  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/rocprofv3_kernel_stats_final.csv; head -8 "$f" | cut -c1-160
+  find $OUT/prof -name "*.csv" -size +1M -delete )
+python -c "
+import json; d=json.loads([l for l in open('$OUT/bench_final_profiled.json').read().splitlines() if l.startswith('{')][-1]); print('profiled run:', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['kernel_ms'])"
+timeout 900 python bench.py --raw --meta --no-cpu > $OUT/bench_raw_meta.json 2> $OUT/bench_raw_meta.err; python -c "
+import json; d=json.loads([l for l in open('$OUT/bench_raw_meta.json').read().splitlines() if l.startswith('{')][-1]); print('raw+meta', d['value'], d['ms_per_step'], d['kernel_ms'], d.get('meta'))"
+timeout 900 python bench.py --stream 1000000000 --no-cpu > $OUT/bench_stream.json 2> $OUT/bench_stream.err; python -c "
+import json; d=json.loads([l for l in open('$OUT/bench_stream.json').read().splitlines() if l.startswith('{')][-1]); print('stream', d['value'], d['ms_per_step'], d['result'])"
