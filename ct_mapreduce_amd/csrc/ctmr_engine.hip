@@ -169,6 +169,8 @@ struct ctmr_engine {
   uint64_t n_meta_slots = 0;
   uint8_t* d_meta_arena = nullptr;
   uint64_t meta_arena_cap = 0;
+  std::vector<uint32_t*> meta_hour_pages;  // knownExpDates bitmaps, META_HOUR_PAGE issuers each
+  uint32_t** d_meta_hour_pages = nullptr;  // device copy of the page pointers
   unsigned long long* d_mcount = nullptr;  // [0] arena used [1] items [2] overflow events
   uint64_t meta_n = 0;                     // entries the SC_META scratch describes (the last map call)
   uint32_t meta_epoch = 0;                 // k_meta_new launches so far
@@ -444,7 +446,7 @@ int ctmr_create(const ctmr_config* cfg, ctmr_engine** out) {
   CK(hipMalloc(&e->d_unreg, (size_t)UNREG_CAP * 4));
   CK(hipMalloc(&e->d_dcount, 64));
   if (cfg->collect_meta) {
-    e->n_meta_slots = 1ull << 20;
+    e->n_meta_slots = 1ull << 22;  // 128 MB: a load factor near 0.1 keeps nearly every item at the home position of its hash (k_meta_new's fast path)
     e->meta_arena_cap = 64ull << 20;
     CK(hipMalloc(&e->d_meta_slots, e->n_meta_slots * sizeof(MetaSlot)));
     CK(hipMalloc(&e->d_meta_arena, e->meta_arena_cap));
@@ -479,6 +481,8 @@ void ctmr_destroy(ctmr_engine* e) {
   (void)hipFree(e->d_idb_der); (void)hipFree(e->d_idb_off); (void)hipFree(e->d_idb_len);
   (void)hipFree(e->d_idb_ht); (void)hipFree(e->d_pend); (void)hipFree(e->d_unreg); (void)hipFree(e->d_dcount);
   (void)hipFree(e->d_meta_slots); (void)hipFree(e->d_meta_arena); (void)hipFree(e->d_mcount);
+  for (auto p : e->meta_hour_pages) (void)hipFree(p);
+  (void)hipFree(e->d_meta_hour_pages);
   if (e->bloom_owned) (void)hipFree(e->d_bloom);
   for (auto p : e->d_scratch) if (p) (void)hipFree(p);
   for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1149,9 +1153,38 @@ int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need,
 
 // ------------------------------------------------------------------ IssuerMetadata on device (N3)
 
+constexpr size_t META_HOUR_PAGE_BYTES = (size_t)META_HOUR_PAGE * (META_HOUR_BITS / 8);
+
+// one (issuer, hour) bitmap page per META_HOUR_PAGE registered issuers
+static int meta_hour_pages_locked(ctmr_engine* e) {
+  const size_t need = (e->issuers.size() + META_HOUR_PAGE - 1) / META_HOUR_PAGE;
+  if (e->meta_hour_pages.size() >= need) return CTMR_OK;
+  if (!e->d_meta_hour_pages) {
+    const size_t cap = ((size_t)e->max_issuers + META_HOUR_PAGE - 1) / META_HOUR_PAGE;
+    if (hipMalloc(&e->d_meta_hour_pages, cap * sizeof(uint32_t*)) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e, CTMR_E_NOMEM, "expDate bitmap page table");
+    }
+  }
+  while (e->meta_hour_pages.size() < need) {
+    uint32_t* p = nullptr;
+    if (hipMalloc(&p, META_HOUR_PAGE_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e, CTMR_E_NOMEM, "expDate bitmap page (%zu bytes)", META_HOUR_PAGE_BYTES);
+    }
+    HIPCHK(e, hipMemsetAsync(p, 0, META_HOUR_PAGE_BYTES, e->stream));
+    e->meta_hour_pages.push_back(p);
+  }
+  HIPCHK(e, hipMemcpyAsync(e->d_meta_hour_pages, e->meta_hour_pages.data(), e->meta_hour_pages.size() * sizeof(uint32_t*),
+                           hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // the vector may move before the copy has read it
+  return CTMR_OK;
+}
+
 static int meta_reset_locked(ctmr_engine* e) {
   if (!e->d_meta_slots) return CTMR_OK;
   HIPCHK(e, hipMemsetAsync(e->d_meta_slots, 0, e->n_meta_slots * sizeof(MetaSlot), e->stream));
+  for (auto p : e->meta_hour_pages) HIPCHK(e, hipMemsetAsync(p, 0, META_HOUR_PAGE_BYTES, e->stream));
   HIPCHK(e, hipMemsetAsync(e->d_mcount, 0, 64, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->last_meta_valid = false;
@@ -1172,6 +1205,9 @@ static int meta_device_locked(ctmr_engine* e, const uint8_t* d_payload, const ui
   a.slots = e->d_meta_slots; a.mask = e->n_meta_slots - 1; a.arena = e->d_meta_arena; a.arena_cap = e->meta_arena_cap;
   a.counters = e->d_mcount; a.items = (MetaItem*)d_items; a.items_cap = items_cap;
   a.epoch = ++e->meta_epoch;
+  int rp = meta_hour_pages_locked(e);
+  if (rp) return rp;
+  a.hour_pages = e->d_meta_hour_pages; a.n_hour_pages = (uint32_t)e->meta_hour_pages.size();
   HIPCHK(e, hipMemsetAsync(e->d_mcount + 1, 0, 8, e->stream));
   hipLaunchKernelGGL(k_meta_new, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, e->stream, a);
   unsigned long long hc[3];

@@ -52,12 +52,23 @@ struct MetaArgs {
   MetaItem* items;
   uint64_t items_cap;
   uint32_t epoch;  // launch number (≥ 1): slots of earlier launches are immutable and read through the caches
+  uint32_t* const* hour_pages;  // knownExpDates as bitmaps: page c (META_HOUR_PAGE issuers) → one bit per (issuer, hour)
+  uint32_t n_hour_pages;
 };
+
+// knownExpDates (issuermetadata.go:96-108) is a set of (issuer, expDate hour): small dense integers.  One bit per pair —
+// META_HOUR_BITS hours (1970 … 2089) per canonical issuer, pages of META_HOUR_PAGE issuers allocated as issuers are
+// registered — decides "seen before" with one cached load, and a first sighting with one atomicOr whose return value
+// names the single lane that reports it.  (As entries of the hash set below, the ≈ 2 000 hours of every issuer were 99 %
+// of its population: they pushed DN/CRL items off their home slots and, a few lanes per wave at a time, kept nearly
+// every wave in the probe loop.)  Hours outside the bitmap's range take the hash-set path.
+constexpr uint32_t META_HOUR_BITS = 1u << 20, META_HOUR_PAGE = 64;
 
 // 16-byte chunks of an item, bytes past its end zeroed.  Items are hashed and compared in these chunks: the first
 // version of this kernel used dwords and was bound by L2 REQUESTS (1.46 G for 18.8 M new certificates, 76 % of its
 // L1 accesses missing — profiles/r01/s4/pmc_meta_20m_dword_version.txt).
 __device__ __forceinline__ uint4 mask_chunk(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rem) {
+  if (rem >= 16u) return make_uint4(w0, w1, w2, w3);  // only an item's last chunk has bytes to clear
   uint32_t w[4] = {w0, w1, w2, w3};
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -94,18 +105,43 @@ __device__ __forceinline__ unsigned long long ld_wave(const unsigned long long* 
 }
 
 // true = first sighting of (kind, issuer, key2, bytes); the bytes come through a chunk source
+// Item hash: add-rotate-xor over the 16-byte chunks (12 full-rate VALU operations per chunk), one multiply-mix at each
+// end.  The first version ran two mixk() — four 64-bit multiplies, quarter-rate on CDNA — per chunk: ≈ 2 700 VALU
+// instructions per wave of certificates, half of the kernel's time (pmc_meta, session 5).  Equal hashes are always
+// followed by a full comparison, so the hash only has to spread.
+struct MetaHashState {
+  uint32_t a, b;
+};
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
+__device__ __forceinline__ MetaHashState meta_hash_begin(uint32_t kind, uint32_t issuer, uint32_t key2, uint32_t len) {
+  const unsigned long long h =
+      mixk((((unsigned long long)issuer << 32 | key2) + 0x9e3779b97f4a7c15ull * (kind + 1u)) ^ ((unsigned long long)len << 24));
+  return MetaHashState{(uint32_t)h, (uint32_t)(h >> 32)};
+}
+__device__ __forceinline__ void meta_hash_chunk(MetaHashState& s, const uint4& c) {
+  s.a = rotl32(s.a, 5) ^ c.x;  s.a += s.b;
+  s.b = rotl32(s.b, 11) ^ c.y; s.b += s.a;
+  s.a = rotl32(s.a, 7) ^ c.z;  s.a += s.b;
+  s.b = rotl32(s.b, 13) ^ c.w; s.b += s.a;
+}
+__device__ __forceinline__ unsigned long long meta_hash_end(const MetaHashState& s) {
+  const unsigned long long h = mixk((unsigned long long)s.b << 32 | s.a);
+  return h ? h : 1ull;
+}
+template <class S>
+__device__ __forceinline__ unsigned long long meta_hash(uint32_t kind, uint32_t issuer, uint32_t key2, const S& src,
+                                                        uint32_t len) {
+  const uint32_t nc = (len + 15u) >> 4;
+  MetaHashState st = meta_hash_begin(kind, issuer, key2, len);
+  for (uint32_t k = 0; k < nc; k++) meta_hash_chunk(st, src.chunk(k));
+  return meta_hash_end(st);
+}
+
 template <class S>
 __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, uint32_t issuer, uint32_t key2,
                                             const S& src, uint32_t len) {
   const uint32_t nc = (len + 15u) >> 4;
-  unsigned long long h = mixk(((unsigned long long)issuer << 32 | key2) + 0x9e3779b97f4a7c15ull * (kind + 1u));
-  h = mixk(h ^ len);
-  for (uint32_t k = 0; k < nc; k++) {
-    const uint4 c = src.chunk(k);
-    h = mixk(h ^ (((unsigned long long)c.y << 32 | c.x) + 0x9e3779b97f4a7c15ull * (2u * k + 2u)));
-    h = mixk(h ^ (((unsigned long long)c.w << 32 | c.z) + 0x9e3779b97f4a7c15ull * (2u * k + 3u)));
-  }
-  if (h == 0ull) h = 1ull;
+  const unsigned long long h = meta_hash(kind, issuer, key2, src, len);
   const unsigned long long w2 = ((unsigned long long)issuer << 32) | key2;
   uint64_t j = h & a.mask;
   uint64_t probes = 0;
@@ -239,6 +275,38 @@ __device__ __forceinline__ bool walk_crl_dps(const R& g, uint32_t L, uint32_t cs
   return ok;
 }
 
+// The steady state of the memo — the item was published by an EARLIER launch and sits at the home position of its
+// hash — decided without the probe loop.  k_meta_new issues the home-slot loads of all of a certificate's items
+// together and then the arena loads of all of them together: two memory latencies for the three lookups instead of
+// the five or six of three sequential meta_upsert calls (slot, then arena, item after item).  Plain cacheable loads
+// are enough: a slot an earlier launch published never changes again, and anything else (empty, claimed in this
+// launch, another key) is left to meta_upsert, whose atomics tell the truth.
+struct MetaHome {
+  uint4 lo, hi;  // the 32-byte slot: w0 | w1 , w2 | w3
+  __device__ __forceinline__ unsigned long long w(int k) const {
+    const uint4& v = k < 2 ? lo : hi;
+    return (k & 1) ? ((unsigned long long)v.w << 32 | v.z) : ((unsigned long long)v.y << 32 | v.x);
+  }
+};
+__device__ __forceinline__ MetaHome meta_home_load(const MetaArgs& a, unsigned long long h, bool want) {
+  MetaHome m{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  if (want) {
+    const uint4* sl = (const uint4*)(a.slots + (h & a.mask));
+    m.lo = sl[0];
+    m.hi = sl[1];
+  }
+  return m;
+}
+// the home slot holds exactly (kind, issuer, key2, len) under hash h, published by an earlier launch → its arena
+// offset; ~0 otherwise
+__device__ __forceinline__ uint64_t meta_home_match(const MetaArgs& a, const MetaHome& m, unsigned long long h,
+                                                    uint32_t kind, unsigned long long w2, uint32_t len) {
+  const unsigned long long w1 = m.w(1), ep = m.w(3);
+  const bool hit = m.w(0) == h && (w1 & META_VALID) && ep != 0ull && ep < a.epoch && ((w1 >> 60) & 3ull) == kind &&
+                   ((w1 >> 40) & 0xfffffull) == len && m.w(2) == w2;
+  return hit ? (w1 & 0xffffffffffull) << 3 : ~0ull;
+}
+
 __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[256 * META_LDS_STRIDE];
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -282,19 +350,19 @@ __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
     for (uint32_t k = 0; k < META_LDS_CRL / 16; k++)
       if (cr_lds && 16u * k < cr_len) *(uint4*)(my + META_LDS_DN + 16u * k) = make_uint4(c[k].a, c[k].b, c[k].c, c[k].d);
   }
-  // knownExpDates → seenExpDateBefore (issuermetadata.go:96-108): no bytes, probes while the loads fly
-  if (meta_upsert(a, MK_EXPDATE, canon, (uint32_t)exp_hour, GlobalSrc{cert, 0}, 0)) meta_emit(a, i, MK_EXPDATE, iss, exp_hour, 0, 0);
+  // ---- what this certificate contributes: (issuer, expDate), its CRL distribution point URIs, its issuer Name.
   // knownCrlDPs (:111-127): CRLDistributionPoints ::= SEQUENCE OF DistributionPoint { [0] { [0] GeneralNames { [6] URI }}}
   // One validating pass collects the URI ranges (a malformed value yields NO URIs, as the oracle defines; more than
-  // META_MAX_URIS → host), then the memo is consulted.
+  // META_MAX_URIS → host).
+  uint32_t uo[META_MAX_URIS], ul[META_MAX_URIS], nu = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < META_MAX_URIS; k++) uo[k] = ul[k] = 0;
+  const uint32_t* cw = (const uint32_t*)(my + META_LDS_DN);
+  bool crl_ok = false;
   if (!host && cr_len != 0u) {
     const uint32_t e = cr_s + cr_len;
-    uint32_t uo[META_MAX_URIS], ul[META_MAX_URIS], nu = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < META_MAX_URIS; k++) uo[k] = ul[k] = 0;
     bool ok = true;
     uint32_t tag, cs, ce;
-    const uint32_t* cw = (const uint32_t*)(my + META_LDS_DN);
     if (cr_lds) {
       LdsTlvReader g{cw, cr_s};
       rd_hdr(g, e, cr_s, e, ok, tag, cs, ce);  // L = e: reads clamp to the staged value, not to the certificate
@@ -306,18 +374,87 @@ __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
       ok = ok && tag == 0x30u && ce == e;
       ok = ok && walk_crl_dps(g, L, cs, e, uo, ul, nu, host);
     }
-    if (ok && !host) {
+    crl_ok = ok && !host;
+  }
+  // ---- fast path: home slots of (expDate | first URI | Name) loaded together, then their arena bytes together
+  const bool f_crl = crl_ok && cr_lds && nu >= 1u && ul[0] <= META_LDS_CRL;
+  const bool f_dn = dn_lds;
+  const LdsSrc s_crl{cw, f_crl ? uo[0] - cr_s : 0u, f_crl ? ul[0] : 0u};
+  const LdsSrc s_dn{(const uint32_t*)my, 0u, f_dn ? dn_len : 0u};
+  const unsigned long long w2_it = (unsigned long long)canon << 32;
+  uint4 cc[META_LDS_CRL / 16], cd[META_LDS_DN / 16];  // the items' chunks, extracted from LDS once
+  const uint32_t nc_crl = f_crl ? (ul[0] + 15u) >> 4 : 0u, nc_dn = f_dn ? (dn_len + 15u) >> 4 : 0u;
+  MetaHashState st_crl = meta_hash_begin(MK_CRL, canon, 0, s_crl.len), st_dn = meta_hash_begin(MK_DN, canon, 0, s_dn.len);
 #pragma unroll
-      for (uint32_t k = 0; k < META_MAX_URIS; k++) {
-        if (k >= nu) continue;
-        const bool first = cr_lds ? meta_upsert(a, MK_CRL, canon, 0, LdsSrc{cw, uo[k] - cr_s, ul[k]}, ul[k])
-                                  : meta_upsert(a, MK_CRL, canon, 0, GlobalSrc{cert + uo[k], ul[k]}, ul[k]);
-        if (first) meta_emit(a, i, MK_CRL, iss, exp_hour, uo[k], ul[k]);
-      }
+  for (uint32_t k = 0; k < META_LDS_CRL / 16; k++) {
+    cc[k] = make_uint4(0, 0, 0, 0);
+    if (k < nc_crl) {
+      cc[k] = s_crl.chunk(k);
+      meta_hash_chunk(st_crl, cc[k]);
+    }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < META_LDS_DN / 16; k++) {
+    cd[k] = make_uint4(0, 0, 0, 0);
+    if (k < nc_dn) {
+      cd[k] = s_dn.chunk(k);
+      meta_hash_chunk(st_dn, cd[k]);
+    }
+  }
+  const unsigned long long h_crl = meta_hash_end(st_crl), h_dn = meta_hash_end(st_dn);
+  // knownExpDates: the (issuer, hour) bit
+  const bool exp_bit = (uint32_t)exp_hour < META_HOUR_BITS && canon / META_HOUR_PAGE < a.n_hour_pages;
+  uint32_t* exp_word = nullptr;
+  uint32_t exp_have = 0;
+  if (exp_bit) {
+    exp_word = a.hour_pages[canon / META_HOUR_PAGE] + (uint64_t)(canon % META_HOUR_PAGE) * (META_HOUR_BITS / 32) +
+               ((uint32_t)exp_hour >> 5);
+    exp_have = __hip_atomic_load(exp_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // cacheable; a stale 0 → atomicOr
+  }
+  const MetaHome m_crl = meta_home_load(a, h_crl, f_crl), m_dn = meta_home_load(a, h_dn, f_dn);
+  bool seen_exp = exp_bit && ((exp_have >> ((uint32_t)exp_hour & 31u)) & 1u);
+  const uint64_t at_crl = f_crl ? meta_home_match(a, m_crl, h_crl, MK_CRL, w2_it, ul[0]) : ~0ull;
+  const uint64_t at_dn = f_dn ? meta_home_match(a, m_dn, h_dn, MK_DN, w2_it, dn_len) : ~0ull;
+  bool seen_crl = at_crl != ~0ull, seen_dn = at_dn != ~0ull;
+  {
+    uint4 ac[META_LDS_CRL / 16], ad[META_LDS_DN / 16];
+    const uint32_t lc = seen_crl ? nc_crl : 0u, ld = seen_dn ? nc_dn : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_CRL / 16; k++)
+      ac[k] = k < lc ? *(const uint4*)(a.arena + at_crl + 16u * k) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_DN / 16; k++)
+      ad[k] = k < ld ? *(const uint4*)(a.arena + at_dn + 16u * k) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_CRL / 16; k++)
+      if (k < lc) seen_crl = seen_crl && cc[k].x == ac[k].x && cc[k].y == ac[k].y && cc[k].z == ac[k].z && cc[k].w == ac[k].w;
+#pragma unroll
+    for (uint32_t k = 0; k < META_LDS_DN / 16; k++)
+      if (k < ld) seen_dn = seen_dn && cd[k].x == ad[k].x && cd[k].y == ad[k].y && cd[k].z == ad[k].z && cd[k].w == ad[k].w;
+  }
+  // ---- everything the fast path did not settle goes through the exact upsert
+  // knownExpDates → seenExpDateBefore (issuermetadata.go:96-108): no bytes
+  if (!seen_exp) {
+    bool first;
+    if (exp_bit) {
+      const uint32_t bit = 1u << ((uint32_t)exp_hour & 31u);
+      first = !(atomicOr(exp_word, bit) & bit);
+    } else {
+      first = meta_upsert(a, MK_EXPDATE, canon, (uint32_t)exp_hour, GlobalSrc{cert, 0}, 0);
+    }
+    if (first) meta_emit(a, i, MK_EXPDATE, iss, exp_hour, 0, 0);
+  }
+  if (crl_ok) {
+#pragma unroll
+    for (uint32_t k = 0; k < META_MAX_URIS; k++) {
+      if (k >= nu || (k == 0 && seen_crl)) continue;
+      const bool first = cr_lds ? meta_upsert(a, MK_CRL, canon, 0, LdsSrc{cw, uo[k] - cr_s, ul[k]}, ul[k])
+                                : meta_upsert(a, MK_CRL, canon, 0, GlobalSrc{cert + uo[k], ul[k]}, ul[k]);
+      if (first) meta_emit(a, i, MK_CRL, iss, exp_hour, uo[k], ul[k]);
     }
   }
   // knownIssuerDNs (:97,:130-135): keyed by the Name's DER bytes (Issuer.String() is a function of them)
-  if (!host) {
+  if (!host && !seen_dn) {
     const bool first = dn_lds ? meta_upsert(a, MK_DN, canon, 0, LdsSrc{(const uint32_t*)my, 0u, dn_len}, dn_len)
                               : meta_upsert(a, MK_DN, canon, 0, GlobalSrc{cert + dn_off, dn_len}, dn_len);
     if (first) meta_emit(a, i, MK_DN, iss, exp_hour, dn_off, dn_len);

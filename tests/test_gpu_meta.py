@@ -123,20 +123,32 @@ def test_crl_and_dn_edge_cases():
         D.cert(serial=b"\x0b", issuer=n2, exts=[dp_ext(dp(*[uri(b"http://many.example/%d" % k) for k in range(5)]))]),  # 5 URIs → host
         D.cert(serial=b"\x0c", issuer=n1, exts=[dp_ext(dp(uri(b"http://a.example/" + b"y" * 5000)))]),                 # 5 KB URI → host
         D.cert(serial=b"\x0d", issuer=n1, exts=[dp_ext(dp(*[uri(b"http://four.example/%d" % k) for k in range(4)]))]),
+        # expDate hours outside the (issuer, hour) bitmap's 1970–2089 range take the hash-set path: first and repeat
+        D.cert(serial=b"\x0e", issuer=n1, not_after=D.gentime("21500601120000Z")),
+        D.cert(serial=b"\x0f", issuer=n1, not_after=D.gentime("21500601123000Z")),
+        D.cert(serial=b"\x10", issuer=n1, not_before=D.gentime("19600101000000Z"), not_after=D.gentime("19650601120000Z")),
+        D.cert(serial=b"\x11", issuer=n1, not_before=D.gentime("19600101000000Z"), not_after=D.gentime("19650601125959Z")),
     ]
-    idx = [0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 0, 0]
+    idx = [0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0]
     eng = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10, collect_meta=True)
     eng.add_issuers([iss_cert, other])
     eng.set_filter(b"", True, 0)
     res = eng.map_batch(Batch.from_certs(certs, idx))
     assert (res.records["status"] == 0).all() and res.stats.n_new == len(certs)
     exp = expected_first_sightings(certs, idx, list(range(len(certs))), res.records["exp_hour"])
-    got = got_first_sightings(eng, eng.meta_new())
+    raw_items = eng.meta_new()
+    got = got_first_sightings(eng, raw_items)
     assert got == exp
     assert {(N.MK_HOST, 5), (N.MK_HOST, 6), (N.MK_HOST, 10), (N.MK_HOST, 11)} <= got
     assert (N.MK_CRL, 0, 0, b"http://four.example/3") in got
     assert (N.MK_CRL, 0, 0, u2) in got and (N.MK_CRL, 0, 0, ldap) in got and (N.MK_CRL, 0, 0, b"") in got
     assert not any(k[0] == N.MK_CRL and k[3].startswith(b"\x86") for k in got)
+    hours = res.records["exp_hour"]
+    assert hours[13] == hours[14] > (1 << 20) and hours[15] == hours[16] < 0
+    far = [it for it in raw_items if it[0] == N.MK_EXPDATE and it[3] in (int(hours[13]), int(hours[15]))]
+    assert len(far) == 2                                       # ONE first sighting per out-of-range hour
+    near = [it for it in raw_items if it[0] == N.MK_EXPDATE and it[3] == int(hours[0])]
+    assert len(near) == 2                                      # … and per (issuer, hour) bit: two issuers share hours[0]
     eng.close()
 
 
