@@ -13,7 +13,11 @@ import json; d=json.loads([l for l in open('$OUT/bench_final.json').read().split
   find $OUT/prof -name "*.csv" -size +1M -delete )
 python -c "
 import json; d=json.loads([l for l in open('$OUT/bench_final_profiled.json').read().splitlines() if l.startswith('{')][-1]); print('profiled run:', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['kernel_ms'])"
-timeout 900 python bench.py --raw --meta --no-cpu > $OUT/bench_raw_meta.json 2> $OUT/bench_raw_meta.err; python -c "
-import json; d=json.loads([l for l in open('$OUT/bench_raw_meta.json').read().splitlines() if l.startswith('{')][-1]); print('raw+meta', d['value'], d['ms_per_step'], d['kernel_ms'], d.get('meta'))"
+timeout 900 python bench.py --raw --meta --pem --no-cpu > $OUT/bench_raw_meta.json 2> $OUT/bench_raw_meta.err; python -c "
+import json; d=json.loads([l for l in open('$OUT/bench_raw_meta.json').read().splitlines() if l.startswith('{')][-1]); print('raw+meta+pem', d['value'], d['ms_per_step'], d['kernel_ms'], d.get('meta'), d.get('pem'))"
 timeout 900 python bench.py --stream 1000000000 --no-cpu > $OUT/bench_stream.json 2> $OUT/bench_stream.err; python -c "
 import json; d=json.loads([l for l in open('$OUT/bench_stream.json').read().splitlines() if l.startswith('{')][-1]); print('stream', d['value'], d['ms_per_step'], d['result'])"
+( cd /tmp; export TMPDIR=/tmp   # HBM bytes of k_meta_new (PMC pass of its own, no trace flags)
+  timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_meta_fetch -o f --output-format csv -- python $R/bench.py --meta --entries 20000000 --steps 2 --warmup 1 --no-cpu > $OUT/pmc_meta_fetch.log 2>&1
+  python $R/scripts/pmc_summary.py $OUT/pmc_meta_fetch 2>/dev/null | grep -E "k_meta_new" | tee $OUT/pmc_meta_fetch_summary.txt
+  find $OUT/pmc_meta_fetch -name "*.csv" -size +1M -delete )
