@@ -86,6 +86,8 @@ __global__ void __launch_bounds__(256) k_pem_encode(const uint8_t* payload, cons
     *(U12*)(e + 14) = U12{0x41434946u, 0x2d2d4554u, 0x0a2d2d2du};  // bytes 14..25 (two bytes overlap the store above)
   }
   const uint64_t nq = (L + 11) / 12;
+  // (tried, session 5: two tasks per lane per round with both loads issued first — 19.1 ms against 16.2 ms per 16 M
+  //  certificates; the kernel is not waiting on these loads)
   for (uint64_t k = lane; k < nq; k += 64) {
     const uint64_t ip = 12 * k;
     const uint32_t nin = (uint32_t)(L - ip < 12 ? L - ip : 12);
