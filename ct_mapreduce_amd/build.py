@@ -13,7 +13,7 @@ def deps():
     """Every source the library is compiled from: csrc/ (recursively) and the public header."""
     out = [os.path.join(HERE, "..", "include", "ctmr.h")]
     for d, _, files in os.walk(CSRC):
-        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".hip"))]
+        out += [os.path.join(d, f) for f in files if f.endswith((".h", ".hip", ".inc"))]
     return out
 
 
