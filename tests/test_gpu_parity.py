@@ -329,3 +329,22 @@ def test_mixed_synthetic_corpus_bit_exact(variant):
     assert_records_equal(res, batch, st, unk, eh)
     assert_state_equal(eng, o, len(issuers))
     eng.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2047, 4093, 4099])
+def test_batch_sizes_around_the_reduce_tail_boundaries(n):
+    """k_insert2 / k_compact handle four entries per thread and 1 024 per block: every size class around those
+    boundaries, with in-batch duplicates (DEFER entries) and a second batch of pure duplicates."""
+    cfg = synth.config(seed=777 + n, n_issuers=4, dup_permille=300, ca_permille=50, expired_permille=50)
+    issuers = synth.issuers(cfg)
+    eng = make_engine((15, 0, 0), table_slots=1 << 15, pair_slots=1 << 15)
+    eng.add_issuers(issuers)
+    eng.set_filter(b"", False, NOW)
+    o = None
+    for first in (0, 0, n):                       # the batch, the same batch again (all known), the next entries
+        b = synth.host_batch(cfg, first, n)
+        res = eng.map_batch(b)
+        o, st, unk, eh = run_oracle(b, issuers, b"", False, NOW, engine=o)
+        assert_records_equal(res, b, st, unk, eh)
+    assert_state_equal(eng, o, len(issuers))
+    eng.close()
