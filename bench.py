@@ -487,17 +487,20 @@ def main():
             t0p = time.perf_counter()
             pem_call(d_pem.data_ptr(), total + 64)
             t_p.append(time.perf_counter() - t0p)
-        from oracle import oracle as orc
+        import base64
         po = d_po[:3].cpu().numpy()
         first = int(d_new[0].item())
         starts_t = raw_view["start"] if args.raw else d_off[:-1]
         ends_t = raw_view["end"] if args.raw else d_off[1:]
         der = d_pay[int(starts_t[first].item()):int(ends_t[first].item())].cpu().numpy().tobytes()
-        ok_pem = d_pem[int(po[0]):int(po[1])].cpu().numpy().tobytes() == orc.pem_encode(der)
+        b64 = base64.b64encode(der)                  # pem.EncodeToMemory: 64-column base64 between the two marker lines
+        want = (b"-----BEGIN CERTIFICATE-----\n" + b"".join(b64[k:k + 64] + b"\n" for k in range(0, len(b64), 64)) +
+                b"-----END CERTIFICATE-----\n")
+        ok_pem = d_pem[int(po[0]):int(po[1])].cpu().numpy().tobytes() == want
         in_bytes = int((ends_t[d_new[:m]] - starts_t[d_new[:m]]).sum().item())
         out["pem"] = {"certificates": m, "pem_bytes": int(total), "der_bytes": in_bytes, "ms_wall": min(t_p) * 1e3,
                       "certs_per_s": m / min(t_p), "GBps_read_plus_written": (in_bytes + total) / min(t_p) / 1e9,
-                      "first_block_matches_oracle": bool(ok_pem)}
+                      "first_block_matches_stdlib_base64": bool(ok_pem)}
     if args.global_dedup:
         # exactness of the GLOBAL dedup against the generator's structure: entry i repeats an earlier entry's key iff
         # synth_is_dup(i), wherever that earlier entry lives — so this rank's NEW entries are its PASS ∧ ¬dup ones
