@@ -220,7 +220,7 @@ def main():
                     help="host threads of the all-core cpu_baseline leg (0 = the CPUs this process may use at once: the "
                          "cgroup quota if there is one, else the affinity mask; 1 = only the one-core leg)")
     ap.add_argument("--cpu-sample-mt", type=int, default=0,
-                    help="entries of the all-core leg (default ≈100 k per thread, at most 16 M)")
+                    help="entries of the all-core leg (default ≈400 k per thread, at most 16 M)")
     ap.add_argument("--meta", action="store_true",
                     help="also run the IssuerMetadata memo kernel (k_meta_new, SURVEY §8(f) N3) over the NEW list of "
                          "every step (engine created with collect_meta) and report its time")
@@ -576,8 +576,9 @@ def main():
             quota_threads, quota = cpu_quota()
             threads = args.cpu_threads or quota_threads
             if threads > 1:
-                # … and on every host CPU this process may use: a larger sample of the same batch (≈100 k entries per thread)
-                sample_mt = min(E, args.cpu_sample_mt or min(100_000 * threads, 16_000_000))
+                # … and on every host CPU this process may use: a larger sample of the same batch (≈400 k entries per thread)
+                del arrays                               # the one-core sample's host copy
+                sample_mt = min(E, args.cpu_sample_mt or min(400_000 * threads, 16_000_000))
                 offs_mt = d_off[: sample_mt + 1].cpu().numpy().astype(np.uint64)
                 nb_mt = int(offs_mt[-1])
                 pay_mt = torch.zeros(nb_mt + N.PAYLOAD_PAD, dtype=torch.uint8)
