@@ -1,0 +1,100 @@
+"""One-off fuzz campaign on the GPU box: mutated certificates through the default map kernel (strict LDS window +
+miss fallback) against the oracle, every observable compared.  Not a test (minutes, not seconds):
+    gpurun -- 'python scripts/fuzz_gpu.py 400000'
+"""
+import glob
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402,F401
+
+import ct_mapreduce_amd as ctmr  # noqa: E402
+from ct_mapreduce_amd import synth, _native as N  # noqa: E402
+from ct_mapreduce_amd.engine import Batch  # noqa: E402
+from tests import der as D  # noqa: E402
+from tests.gpu_common import run_oracle, expected_records  # noqa: E402
+from tests.test_walk_cpu import mutate  # noqa: E402
+
+
+def pem_certs(path):
+    import base64
+    out, cur = [], None
+    for line in open(path, "rb"):
+        if line.startswith(b"-----BEGIN CERTIFICATE"):
+            cur = []
+        elif line.startswith(b"-----END CERTIFICATE") and cur is not None:
+            out.append(base64.b64decode(b"".join(cur)))
+            cur = None
+        elif cur is not None:
+            cur.append(line.strip())
+    return out
+
+
+def main():
+    total = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+    chunk = 50_000
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20260923)
+    now = synth.BASE_TIME
+    cfg = synth.config(seed=11, n_issuers=8, ca_permille=100, expired_permille=100)
+    cfgm = synth.config(seed=12, n_issuers=8, ca_permille=100, expired_permille=100, profile=1)
+    issuers = synth.issuers(cfg)
+    seeds = []
+    for f in glob.glob(os.path.join(ROOT, "tests", "golden", "*.pem")):
+        seeds += pem_certs(f)
+    seeds += [synth.leaf(cfg, i)[0] for i in range(60)] + [synth.leaf(cfgm, i)[0] for i in range(60)]
+    for bundle in ("/etc/ssl/certs/ca-certificates.crt",):
+        if os.path.exists(bundle):
+            seeds += pem_certs(bundle)[:80]
+    n1 = D.name(D.rdn(6, b"US", 0x13), D.rdn(10, b"Edge Org"), D.rdn(3, b"Synth Issuer 000"))
+    seeds += [D.cert(serial=bytes([k + 1]) * (k + 1), issuer=n1,
+                     exts=[D.BC_NOT_CA, D.ext(0x1f, D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa0, D.tlv(0x86, b"http://c.example/%d" % k))))))])
+              for k in range(24)]
+    print("seeds", len(seeds), flush=True)
+    bad = 0
+    done = 0
+    t0 = time.time()
+    while done < total:
+        certs, iss, ets = [], [], []
+        for r in range(chunk):
+            s = seeds[rng.randrange(len(seeds))]
+            m = mutate(rng, s) if rng.randrange(8) else s
+            if rng.randrange(4) == 0 and len(m) > 1:
+                m = mutate(rng, m)
+            certs.append(m); iss.append(rng.randrange(len(issuers))); ets.append(rng.randrange(2))
+        batch = Batch.from_certs(certs, iss, ets)
+        batch.payload = np.concatenate([batch.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+        filt, log_exp = rng.choice(((b"", False), (b"Synth Issuer 00,Test", False), (b"zz,", True), (b"Synth", True)))
+        eng = ctmr.Engine(device=0, table_slots=1 << 18, pair_slots=1 << 18, collect_meta=True)
+        eng.add_issuers(issuers)
+        eng.set_filter(filt, log_exp, now)
+        res = eng.map_batch(batch)
+        o, st, unk, eh = run_oracle(batch, issuers, filt, log_exp, now)
+        flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh)
+        r = res.records
+        diff = ((r["status"] != st) | (r["flags"] != flags) | (r["serial_len"] != serial_len) | (r["exp_hour"] != exp_hour) |
+                (r["serial"] != serial).any(axis=1))
+        nb = int(diff.sum()) + int(not np.array_equal(res.new_idx, np.nonzero(unk)[0]))
+        if nb:
+            bad += nb
+            for i in np.nonzero(diff)[0][:5]:
+                print("MISMATCH", i, "gpu", int(r["status"][i]), int(r["flags"][i]), "oracle", int(st[i]), int(flags[i]),
+                      batch.cert(int(i)).hex()[:200], flush=True)
+        eng.meta_new()                                   # the memo kernel must survive hostile NEW certificates
+        okeys = [k for k in o.keys() if k.startswith(b"serials::")]
+        if sorted(eng.keys(b"serials::*")) != okeys or eng.total_count() != o.total_count():
+            bad += 1
+            print("STATE MISMATCH", flush=True)
+        eng.close()
+        done += chunk
+        print(f"{done} certificates, {int((st == 0).sum())} PASS in the last chunk, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print("FUZZ", "OK" if bad == 0 else "FAILED", done, bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
