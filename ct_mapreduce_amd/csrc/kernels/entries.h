@@ -103,6 +103,7 @@ struct MatchArgs {
   unsigned long long* pend;     // PEND_SLOTS claim words (zeroed by the host)
   uint32_t* unreg_list;         // entry indices, one per distinct hash
   uint32_t unreg_cap;
+  uint32_t report_all;          // 1 = list EVERY unregistered entry (no per-hash claim): see the note at the report
   unsigned long long* counters; // [0] entries left unregistered, [1] list entries, [2] pend overflow
 };
 
@@ -225,6 +226,21 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
   const bool unreg = live && result == ISS_UNREGISTERED;
   const unsigned long long mu = __ballot(unreg);
   if (lane == 0 && mu) atomicAdd(&a.counters[0], (unsigned long long)__popcll(mu));
+  // The per-hash claim below reports ONE certificate per candidate hash (length, first and last 16 bytes) per round:
+  // right for real chains, where distinct certificates differ there, but a batch with many distinct certificates that
+  // agree in those 36 bytes (a hostile or corrupted log: the same issuer certificate damaged in hundreds of places)
+  // would register one of them per round.  When registration has not converged after two rounds the host switches
+  // to report_all: every unregistered entry goes on the list (up to its capacity) and the host dedups by content.
+  if (a.report_all) {
+    if (mu) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&a.counters[1], (unsigned long long)__popcll(mu));
+      base = __shfl(base, 0);
+      const unsigned long long at = base + (unsigned long long)__popcll(mu & ((1ull << lane) - 1ull));
+      if (unreg && at < a.unreg_cap) a.unreg_list[at] = (uint32_t)i;
+    }
+    return;
+  }
   // one claim per distinct hash per wave (a cold start has every lane here)
   unsigned long long todo_u = mu;
   while (todo_u) {

@@ -198,3 +198,28 @@ def test_pem_over_entry_view_device():
     for k in range(0, m, 41):
         assert pem[po[k]:po[k + 1]] == orc.pem_encode(b.cert(int(new[k])))
     eng.close()
+
+
+def test_many_chain0_certificates_sharing_length_head_and_tail_register_in_few_rounds():
+    """Chain[0] candidates are selected by (length, first 16, last 16 bytes) and unregistered certificates are reported
+    once per such hash per round — 300 DISTINCT issuer certificates that agree in all of that (the same certificate
+    damaged in the middle: a corrupted or hostile log) used to need one registration round each and failed with
+    "does not converge"; now the engine lists every unregistered entry once the first rounds did not settle it."""
+    cfg = synth.config(seed=31, n_issuers=2)
+    iss = synth.issuer(cfg, 0)
+    cert = synth.leaf(cfg, 5)[0]
+    pairs = []
+    for k in range(300):
+        bad = bytearray(iss)
+        bad[200 + k] ^= 0x5a                        # inside the certificate, away from both ends
+        pairs.append((x509_leaf(cert), chain([bytes(bad)])))
+    pairs += [(x509_leaf(synth.leaf(cfg, 6 + k)[0]), chain([iss])) for k in range(50)]
+    raw = RawEntries.from_pairs(pairs)
+    raw.blob = np.concatenate([raw.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    eng = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10)
+    eng.set_filter(b"", True, NOW)
+    res = eng.map_entries(raw)
+    o = orc.Engine(b"", True, NOW)
+    check_against_oracle(eng, raw, o, res)
+    assert eng.issuer_count() == 301 and res.decode.n_issuers_added == 301
+    eng.close()
