@@ -19,6 +19,7 @@ from ct_mapreduce_amd.engine import Batch  # noqa: E402
 from tests import der as D  # noqa: E402
 from tests.gpu_common import run_oracle, expected_records  # noqa: E402
 from tests.test_walk_cpu import mutate  # noqa: E402
+from tests.test_gpu_meta import expected_first_sightings, got_first_sightings  # noqa: E402
 
 
 def pem_certs(path):
@@ -84,7 +85,13 @@ def main():
             for i in np.nonzero(diff)[0][:5]:
                 print("MISMATCH", i, "gpu", int(r["status"][i]), int(r["flags"][i]), "oracle", int(st[i]), int(flags[i]),
                       batch.cert(int(i)).hex()[:200], flush=True)
-        eng.meta_new()                                   # the memo kernel must survive hostile NEW certificates
+        # the IssuerMetadata memo over the hostile NEW certificates: first sightings as the reference's memo defines them
+        canon = [eng.issuer_info(k).canonical_idx for k in range(len(issuers))]
+        exp_meta = expected_first_sightings(certs, [canon[k] for k in iss], [int(k) for k in res.new_idx], r["exp_hour"])
+        got_meta = got_first_sightings(eng, eng.meta_new())
+        if got_meta != exp_meta:
+            bad += 1
+            print("META MISMATCH", sorted(got_meta ^ exp_meta, key=repr)[:4], flush=True)
         okeys = [k for k in o.keys() if k.startswith(b"serials::")]
         if sorted(eng.keys(b"serials::*")) != okeys or eng.total_count() != o.total_count():
             bad += 1
