@@ -21,6 +21,8 @@ struct MapArgs {
   uint32_t certs_per_tile;
   uint32_t lds_bytes;  // dynamic LDS size of the launch
   uint2* meta_loc;          // null, or per entry (Walk.meta_issuer, Walk.meta_crl) for k_meta_new (config.collect_meta)
+  uint32_t xcd_blocks;      // 1: workgroup w takes batch block (w % 8)·(blocks/8) + w/8 — each XCD streams its own
+                            // contiguous eighth of the batch (variant 16; the hardware deals workgroups round-robin over the XCDs)
   uint32_t optimistic_new;  // 1: PASS records leave the map with CTMR_FL_WAS_UNKNOWN already set — the
                             // reduce only CLEARS it for the (rare) duplicates, so the common case costs
                             // no second scattered write into the record array

@@ -311,7 +311,12 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 template <int WCH, bool STRICT>
 __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
-  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  uint64_t blk = blockIdx.x;
+  if (a.xcd_blocks) {
+    const uint64_t per = gridDim.x / 8u;
+    if (blk < per * 8u) blk = (blk % 8u) * per + blk / 8u;
+  }
+  const uint64_t first = blk * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
   const bool live = i < a.n;

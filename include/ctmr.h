@@ -89,7 +89,8 @@ typedef struct {
                                  10-12 = line-trimmed windows, 13 = 256-B window with wave-cooperative fills,
                                  14 = 13 fused with pass 1 of the known-certificate insert,
                                  15 = 14 with window-only reads (no per-access global fallback; a certificate whose
-                                      walk leaves the window is repeated with the exact global reader) */
+                                      walk leaves the window is repeated with the exact global reader),
+                                 16 = 15 with XCD-contiguous workgroup → block mapping (measured slower: DESIGN.md §7) */
   uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
   uint32_t collect_meta;      /* 1 = the map also records where each certificate's issuer Name and
                                  cRLDistributionPoints lie (8 B per entry) so that ctmr_meta_new* can run */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: run_sweep.sh TAG "v1 v2 ..." — parity tests, then the default bench per map variant (no CPU leg)
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/s4; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/sweep; mkdir -p $OUT
 cd $R
 TAG=$1; VARS=$2
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_$TAG.log 2>&1; tail -3 $OUT/pytest_$TAG.log
