@@ -502,6 +502,9 @@ def main():
                       "certs_per_s": m / min(t_p), "GBps_read_plus_written": (in_bytes + total) / min(t_p) / 1e9,
                       "first_block_matches_stdlib_base64": bool(ok_pem)}
     if args.global_dedup:
+        out["config"]["workload"] = out["config"]["workload"].replace(
+            "(BASELINE configs[2]/[3] shape)", "with 10 % duplicates of earlier entries, mostly in other ranks' shards "
+            "(BASELINE configs[4] corpus, one round)")
         # exactness of the GLOBAL dedup against the generator's structure: entry i repeats an earlier entry's key iff
         # synth_is_dup(i), wherever that earlier entry lives — so this rank's NEW entries are its PASS ∧ ¬dup ones
         status = d_rec.view(-1, 32)[:E, 0].cpu().numpy()
