@@ -283,7 +283,7 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
   if (op != 1) e->pairs_dirty = true;
   hipLaunchKernelGGL(k_set_op, dim3(1), dim3(64), 0, e->stream, e->table, e->nslots - 1, meta, s[0],
                      s[1], s[2], s[3], s[4], op, e->epoch, e->issuer_counts, e->pairs,
-                     e->npairs - 1, e->d_result);
+                     e->npairs - 1, e->d_bloom, e->bloom_words ? e->bloom_words - 1 : 0, e->d_result);
   uint32_t res[2];
   HIPCHK(e, hipMemcpyAsync(res, e->d_result, 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));

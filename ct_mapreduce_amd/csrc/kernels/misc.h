@@ -72,7 +72,7 @@ __global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, un
                          unsigned long long s1, unsigned long long s2, unsigned long long s3,
                          unsigned long long s4, int op, uint32_t epoch,
                          unsigned long long* issuer_counts, PairSlot* pairs, uint64_t pmask,
-                         uint32_t* result) {
+                         unsigned long long* bloom, uint64_t bloom_wmask, uint32_t* result) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const unsigned long long s[5] = {s0, s1, s2, s3, s4};
   bool created = false;
@@ -84,6 +84,12 @@ __global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, un
   if (op == 0) {
     result[0] = created;
     if (created) atomicAdd(&issuer_counts[canon], 1ull);
+    if (bloom) {  // Bloom-variant global dedup: every key this rank holds is in its filter, point inserts included
+      uint64_t word;
+      unsigned long long bits;
+      bloom_pos(key_hash(meta, s), bloom_wmask, word, bits);
+      atomicOr(&bloom[word], bits);
+    }
   } else if (op == 1) {
     result[0] = sid != SID_NONE;
   } else if (sid != SID_NONE) {

@@ -230,7 +230,8 @@ int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t 
  *      BASELINE.json's north_star) — exact, same results as the owner-computes exchange above.
  *      Every rank keeps its own known-certificate table (plain ctmr_map_*_device calls) plus a cumulative Bloom
  *      filter of the keys it found locally new.  One round = one map call per rank, then:
- *   add:    sets the filter bits of the batch's CTMR_FL_WAS_UNKNOWN keys.  The host all-gathers the filters
+ *   add:    sets the filter bits of the batch's CTMR_FL_WAS_UNKNOWN keys (ctmr_set_insert sets the bits of its member
+ *           too, once a filter is configured: every key a rank holds is in its filter).  The host all-gathers the filters
  *           (ctmr_bloom_device gives the pointer; n_words × 8 bytes per rank, rank-major in the gathered buffer).
  *   probe:  tests the batch's locally-new keys against the OTHER ranks' filters and writes one 64-byte key record per
  *           (key, peer whose filter holds it) into d_keys_out, partitioned by peer, ascending log index inside a

@@ -15,6 +15,7 @@ from ct_mapreduce_amd import synth, _native as N
 from ct_mapreduce_amd.distributed import (BloomDedupRank, GlobalDedupRank, run_bloom_dedup, run_simulated,
                                           run_simulated_bloom, shard_range)
 from ct_mapreduce_amd.engine import RECORD_DTYPE
+from oracle import oracle as orc
 from tests.gpu_common import run_oracle
 from tests.test_gpu_exchange import to_dev, make_engine, FILT, NOW, DEV
 
@@ -233,3 +234,32 @@ def test_bloom_config_errors():
     assert p != 0 and nw == 64
     e.bloom_add(0, 0, 0, 0)                      # empty batch: fine
     e.close()
+
+
+def test_point_inserted_keys_are_in_the_filter():
+    """A member added with SetInsert on one rank (ctmr_set_insert) is known to the others: the point insert sets the
+    filter bits too, so the batch entry of another rank is sent over, found and loses WasUnknown."""
+    world = 2
+    cfg = synth.config(seed=67, n_issuers=2)
+    issuers = synth.issuers(cfg)
+    engines, ranks = build_world(world, issuers, 1 << 14)
+    b = synth.host_batch(cfg, 0, 200)
+    o, st, unk, eh = run_oracle(b, issuers, FILT, False, NOW)
+    i = int(np.nonzero(unk)[0][3])                               # some new, passing entry of rank 0's batch
+    c = orc.parse_cert(b.cert(i))
+    key = b"serials::%s::%s" % (orc.exp_date_id(int(eh[i])).encode(), engines[1].issuer_id(int(b.issuer_idx[i])).encode())
+    assert engines[1].set_insert(key, b.cert(i)[c.serial_off:c.serial_off + c.serial_len]) is True
+    t = to_dev(b)
+    empty = to_dev(synth.host_batch(cfg, 1000, 0))
+    shards = [(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), b.n, t[4].data_ptr()),
+              (empty[0].data_ptr(), empty[1].data_ptr(), empty[2].data_ptr(), empty[3].data_ptr(), 0, empty[4].data_ptr())]
+    stats = run_simulated_bloom(ranks, shards, [t[5].data_ptr(), empty[5].data_ptr()], [0, 1000])
+    rec = t[4].cpu().numpy().view(RECORD_DTYPE)
+    got = (rec["flags"] & 2) != 0
+    want = unk != 0
+    want[i] = False                                              # known on rank 1 since before this round
+    assert (got == want).all()
+    assert stats[0].n_new == int(want.sum()) and sum(ranks[0].send_counts) >= 1
+    assert sum(e.total_count() for e in engines) == int(unk.sum())      # counted once, on rank 1
+    for e in engines:
+        e.close()
