@@ -323,6 +323,8 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   q = ce;
   // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo).  A long subject (OV/EV certificates) puts this
   // header past the front window: say so, instead of leaving a window-only reader to its slow exact path.
+  // (A wave-cooperative form of this refill — the lanes in need served 16 lanes per certificate, as touch_tail does —
+  //  measured no gain on the mixed corpus: 25.45 ms against 25.3 ms per 100 M, session 5.)
   r.touch(q, 8);
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
