@@ -1,0 +1,50 @@
+"""bench.py's own checkers, pinned without a GPU: the numpy restatement of the generator's duplicate structure (what
+`--stream` and `--global-dedup` compare the engine against) and the CPU quota probe of the all-core baseline leg."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from ct_mapreduce_amd import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def test_synth_is_dup_describes_the_generators_duplicates():
+    cfg = synth.config(seed=20260921 + 5, n_issuers=16, zipf=1, dup_permille=100, ca_permille=10, expired_permille=10)
+    issuers = synth.issuers(cfg)
+    n = 20000
+    b = synth.host_batch(cfg, 0, n)
+    io = np.zeros(len(issuers) + 1, np.uint64)
+    io[1:] = np.cumsum([len(x) for x in issuers])
+    o = orc.Engine(b"", False, synth.BASE_TIME)
+    st, unk, eh = o.batch(b.payload, b.offsets, b.issuer_idx, np.frombuffer(b"".join(issuers), np.uint8), io)
+    dup = bench.synth_is_dup(cfg.seed, 0, n, 100, np)
+    assert 0.05 * n < dup.sum() < 0.15 * n
+    passed = st == 0
+    assert (unk[passed & ~dup] == 1).all()          # a non-duplicate that passes the filters is new …
+    assert (unk[passed & dup] == 0).all()           # … and a duplicate repeats the key of an earlier entry
+    # the same predicate for a later window of the stream (what the waves of --stream use)
+    dup2 = bench.synth_is_dup(cfg.seed, 5000, 1000, 100, np)
+    assert (dup2 == dup[5000:6000]).all()
+
+
+def test_cpu_quota_is_sane():
+    threads, quota = bench.cpu_quota()
+    assert 1 <= threads <= len(os.sched_getaffinity(0))
+    assert quota is None or quota > 0
+
+
+def test_cpu_baseline_threads_counts_every_entry_once():
+    cfg = synth.config(seed=9, n_issuers=4, dup_permille=0, ca_permille=100, expired_permille=100)
+    issuers = synth.issuers(cfg)
+    n = 3001
+    b = synth.host_batch(cfg, 0, n)
+    pay = np.concatenate([b.payload, np.zeros(64, np.uint8)])
+    arrays = (pay, b.offsets.astype(np.uint64), b.issuer_idx.astype(np.uint32))
+    one = bench.cpu_baseline_threads(arrays, issuers, b"", synth.BASE_TIME, n, 1)
+    four = bench.cpu_baseline_threads(arrays, issuers, b"", synth.BASE_TIME, n, 4)
+    assert one[2] == four[2] > 0                    # same PASS count whatever the slicing
