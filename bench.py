@@ -464,6 +464,8 @@ def main():
                      # the walk skips key, SAN body and signature: fewer bytes move than the algorithmic
                      # figure, so frac can exceed 1; frac_physical = measured traffic / time / peak
                      "frac_physical": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                     # … and against what a plain float4 copy reaches on this part (MI355X_MICROARCH.md: 6.29 TB/s)
+                     "frac_physical_of_streaming_ceiling": (traffic / (avg_ms * 1e-3) / 1e9 / 6290.0) if traffic else None,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                      "alg_bytes_formula": "sum(L_i) + 45*E" + (" + 64*PASS (table probe)" if (args.variant or DEFAULT_VARIANT) in FUSED else "")},
         "kernel_ms": {"map": stats.ms_map, "insert": stats.ms_insert, "resolve": stats.ms_resolve,
