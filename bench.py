@@ -26,12 +26,9 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32
 
 
-MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 3: "k_map_win<16>", 4: "k_map_win<8>", 5: "k_map_win<12>",
-               6: "k_map_win<14>", 7: "k_map_win2<16>", 8: "k_map_win2<14>", 9: "k_map_win2<12>", 10: "k_map_wint<16,192,208>",
-               11: "k_map_wint<16,208,224>", 12: "k_map_wint<16,176,192>", 13: "k_map_winc<16>", 14: "k_map_fused<16>",
-               15: "k_map_fused<16, true>", 16: "k_map_fused<16, true> (XCD-contiguous blocks)"}
+MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16>", 15: "k_map_fused<16>"}   # 1, 2: sweep build only
 DEFAULT_VARIANT = 15
-FUSED = (14, 15, 16)          # map kernels that also do pass 1 of the known-certificate insert
+FUSED = (15,)          # map kernels that also do pass 1 of the known-certificate insert
 ALG_BYTES_PROBE = 64   # per PASS entry: 32 B slot read + 32 B slot write — fused kernels only
 
 

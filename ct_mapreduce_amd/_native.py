@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libctmr.so")
+# CTMR_LIB: scripts/sweep.py points this at libctmr_sweep.so (the product + the two baseline map designs)
+LIB_PATH = os.environ.get("CTMR_LIB") or os.path.join(HERE, "libctmr.so")
 
 ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
     ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)

@@ -6,6 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libctmr.so")
+SWEEP_LIB = os.path.join(HERE, "libctmr_sweep.so")   # + the two baseline map designs (scripts/sweep.py); never shipped
 SOURCES = ["ctmr_engine.hip"]
 
 
@@ -24,23 +25,25 @@ def hipcc():
     return "hipcc"
 
 
-def stale():
-    if not os.path.exists(LIB):
+def stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in deps())
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
+def build(force=False, verbose=False, sweep=False):
+    lib = SWEEP_LIB if sweep else LIB
+    if not force and not stale(lib):
+        return lib
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+           "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"] + (["-DCTMR_SWEEP"] if sweep else []) + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", lib]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, sweep="--sweep" in sys.argv)

@@ -135,6 +135,7 @@ struct ctmr_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   ctmr_config cfg{};
+  bool tile_attr_set = false;  // CTMR_SWEEP builds: k_map_tile's dynamic-LDS attribute is set on this engine's device
   // known-certificate table
   Slot* table = nullptr;
   uint64_t nslots = 0;

@@ -1,9 +1,10 @@
 // kernels.h — the hand-written HIP kernels of the library, gfx950 (CDNA4, wave64) only.  No MFMA anywhere: this path
 // is byte/integer scan + hash work bounded by HBM bandwidth.
 //
-//   kernels/readers.h   LdsReader, GlobalReader, WinReader… — per-lane 256-byte LDS windows, wave-cooperative fills
+//   kernels/readers.h   GlobalReader, WinReader/C/S — per-lane 256-byte LDS windows, wave-cooperative fills
 //   kernels/sha256.h    k_issuer_ids (issuer table: walk Chain[0], SHA-256(RawSubjectPublicKeyInfo)), k_sha256_one
-//   kernels/map.h       the map — k_map_tile / k_map_direct / k_map_win* (earlier variants, kept selectable)
+//   kernels/map.h       the map — map_one (walk + filters + record), k_map_winc (the map without the fused insert)
+//   kernels/map_sweep.h k_map_tile / k_map_direct: the two baseline designs, CTMR_SWEEP builds only (libctmr_sweep.so)
 //   kernels/reduce.h    table_upsert, k_insert / k_insert2, k_map_fused (THE dominant kernel: walk + filters + pass 1 of
 //                       the insert from the walking lane's registers; the default), k_resolve, k_scan_blocks, k_compact
 //   kernels/exchange.h  k_key_count / k_key_scatter / k_keys_insert* / k_keys_resolve / k_apply_flags (owner-computes
@@ -16,6 +17,9 @@
 #include "kernels/readers.h"
 #include "kernels/sha256.h"
 #include "kernels/map.h"
+#ifdef CTMR_SWEEP
+#include "kernels/map_sweep.h"
+#endif
 #include "kernels/reduce.h"
 #include "kernels/exchange.h"
 #include "kernels/pem.h"

@@ -18,11 +18,9 @@ struct MapArgs {
   const FilterDev* filt;
   uint64_t n;
   uint32_t n_issuers;
-  uint32_t certs_per_tile;
-  uint32_t lds_bytes;  // dynamic LDS size of the launch
+  uint32_t certs_per_tile;  // CTMR_SWEEP builds only (k_map_tile)
+  uint32_t lds_bytes;       // dynamic LDS size of the launch (k_map_tile)
   uint2* meta_loc;          // null, or per entry (Walk.meta_issuer, Walk.meta_crl) for k_meta_new (config.collect_meta)
-  uint32_t xcd_blocks;      // 1: workgroup w takes batch block (w % 8)·(blocks/8) + w/8 — each XCD streams its own
-                            // contiguous eighth of the batch (variant 16; the hardware deals workgroups round-robin over the XCDs)
   uint32_t optimistic_new;  // 1: PASS records leave the map with CTMR_FL_WAS_UNKNOWN already set — the
                             // reduce only CLEARS it for the (rare) duplicates, so the common case costs
                             // no second scattered write into the record array
@@ -119,97 +117,13 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
   if (64u + lane < nvec) out[64 + lane] = t[64 + lane];
 }
 
-// LDS-tile map.  One wave per workgroup, one tile of `certs_per_tile` consecutive
-// certificates per workgroup: the tile's byte range [offsets[first], offsets[last+1]) is
-// contiguous in the packed payload, so it is copied with perfectly coalesced 16-B/lane loads
-// (1 KiB per wave instruction) into LDS; then lane l walks certificate first+l out of LDS.
-
-__global__ void __launch_bounds__(64) k_map_tile(MapArgs a) {
-  const uint32_t lane = threadIdx.x;
-  const uint32_t C = a.certs_per_tile;
-  const uint64_t first = (uint64_t)blockIdx.x * C;
-  if (first >= a.n) return;
-  const uint32_t cnt = (uint32_t)((a.n - first) < C ? (a.n - first) : C);
-  uint64_t my_lo = 0, my_hi = 0;
-  if (lane < cnt) {
-    my_lo = a.offsets[first + lane];
-    my_hi = a.offsets[first + lane + 1];
-  }
-  const uint64_t tile_lo = __shfl(my_lo, 0);
-  const uint64_t tile_hi = __shfl(my_hi, cnt - 1);
-  const uint64_t a_lo = tile_lo & ~15ull;
-  const uint64_t span = tile_hi - a_lo;
-  if (tile_hi < tile_lo || span + 48 > a.lds_bytes) {
-    // oversize (or malformed offsets): walk straight from global memory
-    if (lane < cnt) {
-      if (my_hi < my_lo) my_hi = my_lo;
-      GlobalReader r{(const uint32_t*)a.payload, my_lo};
-      map_one(r, my_hi - my_lo, first + lane, a);
-    }
-    return;
-  }
-  // ---- stage the tile: global → VGPR → LDS, 8 × 1 KiB in flight per wave
-  {
-    const uint4* src = (const uint4*)(a.payload + a_lo);
-    uint4* dst = (uint4*)smem;
-    const uint32_t nvec = (uint32_t)((span + 15) >> 4);
-    for (uint32_t base = 0; base < nvec; base += 8 * 64) {
-      uint4 v[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const uint32_t i = base + k * 64 + lane;
-        if (i < nvec) v[k] = src[i];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const uint32_t i = base + k * 64 + lane;
-        if (i < nvec) dst[i] = v[k];
-      }
-    }
-  }
-  __syncthreads();
-  if (lane < cnt) {
-    if (my_hi < my_lo) my_hi = my_lo;
-    LdsReader r{(const uint32_t*)smem, (uint32_t)(my_lo - a_lo)};
-    map_one(r, my_hi - my_lo, first + lane, a);
-  }
-}
-
-// Direct map: one certificate per lane straight from global memory.
-__global__ void __launch_bounds__(256) k_map_direct(MapArgs a) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  uint64_t lo, hi;
-  cert_range(a.offsets, a.ends, i, lo, hi);
-  GlobalReader r{(const uint32_t*)a.payload, lo};
-  map_one(r, hi - lo, i, a);
-}
-
-// Window map: one certificate per lane, all 64 lanes busy, DER stays in global memory and is
-// pulled through a per-lane LDS window (WinReader).  One wave per workgroup, so LDS (not the
-// 256-thread granule) sets the occupancy: 64 × (WCH·16+16) bytes per wave.
-template <int WCH>
-__global__ void __launch_bounds__(64) k_map_win(MapArgs a) {
-  const uint64_t first = (uint64_t)blockIdx.x * 64;
-  const uint64_t i = first + threadIdx.x;
-  const bool live = i < a.n;
-  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-  if (live) {
-    uint64_t lo, hi;
-    cert_range(a.offsets, a.ends, i, lo, hi);
-    constexpr uint32_t STRIDE = WCH * 16 + 16;
-    WinReader<WCH> r{(const uint32_t*)a.payload, lo, map_limit(a),
-                     (uint32_t*)(smem + threadIdx.x * STRIDE), 0};
-    r.refill(0);
-    map_one(r, hi - lo, i, a, o0, o1);
-  }
-  store_records_wave(a, first, live, o0, o1);
-}
-
-// Window map with a wave-cooperative first fill: instead of every lane issuing 16 loads of ITS certificate
-// (64 uncoalesced 16-byte requests per instruction), 16 adjacent lanes fetch the 16 chunks of one
-// certificate's front window, 4 certificates per instruction — the texture addresser sees 8 lanes per
-// 128-byte line — and each lane parks its chunk directly in the owning lane's LDS window.
+// Window map (variant 13; the exchange modes and `map_variant = 13` use it, the default is k_map_fused in reduce.h):
+// one certificate per lane, all 64 lanes busy, DER stays in global memory and is pulled through a per-lane LDS
+// window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: 64 × (16·16+16) bytes per
+// wave.  The first fill is wave-cooperative: instead of every lane issuing 16 loads of ITS certificate (64
+// uncoalesced 16-byte requests per instruction), 16 adjacent lanes fetch the 16 chunks of one certificate's front
+// window, 4 certificates per instruction — the texture addresser sees 8 lanes per 128-byte line — and each lane
+// parks its chunk directly in the owning lane's LDS window.
 template <int WCH>
 __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
@@ -240,44 +154,6 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   if (live) {
     WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
                        (int32_t)(int64_t)(g_me - lo)}};
-    map_one(r, hi - lo, i, a, o0, o1);
-  }
-  store_records_wave(a, first, live, o0, o1);
-}
-
-// Line-trimmed window map (WinReaderT).
-template <int WCH, int NF, int NE>
-__global__ void __launch_bounds__(64) k_map_wint(MapArgs a) {
-  const uint64_t first = (uint64_t)blockIdx.x * 64;
-  const uint64_t i = first + threadIdx.x;
-  const bool live = i < a.n;
-  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-  if (live) {
-    uint64_t lo, hi;
-    cert_range(a.offsets, a.ends, i, lo, hi);
-    constexpr uint32_t STRIDE = WCH * 16 + 16;
-    WinReaderT<WCH, NF, NE> r{(const uint32_t*)a.payload, lo, map_limit(a),
-                              (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0};
-    r.refill(0, NF);
-    map_one(r, hi - lo, i, a, o0, o1);
-  }
-  store_records_wave(a, first, live, o0, o1);
-}
-
-// Two-region window map (WinReader2): same walk, 2 dependent HBM round trips per certificate.
-template <int WCH>
-__global__ void __launch_bounds__(64) k_map_win2(MapArgs a) {
-  const uint64_t first = (uint64_t)blockIdx.x * 64;
-  const uint64_t i = first + threadIdx.x;
-  const bool live = i < a.n;
-  uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-  if (live) {
-    uint64_t lo, hi;
-    cert_range(a.offsets, a.ends, i, lo, hi);
-    constexpr uint32_t STRIDE = (WCH + 3) * 16;
-    WinReader2<WCH> r{(const uint32_t*)a.payload, lo, map_limit(a),
-                      (uint32_t*)(smem + threadIdx.x * STRIDE), 0, 0x7fffff00};
-    r.refill(0);
     map_one(r, hi - lo, i, a, o0, o1);
   }
   store_records_wave(a, first, live, o0, o1);

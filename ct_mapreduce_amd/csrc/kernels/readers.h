@@ -1,4 +1,4 @@
-// kernels/readers.h — byte readers: how one lane gets at the bytes of its certificate (global memory, an LDS tile, a per-lane LDS window with wave-cooperative fills).
+// kernels/readers.h — byte readers: how one lane gets at the bytes of its certificate (global memory, or a per-lane LDS window with wave-cooperative fills).
 // gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
 #pragma once
 #include "../ctmr_dev.h"
@@ -10,20 +10,7 @@ namespace ctmr {
 struct __attribute__((packed, aligned(1))) U16t { uint32_t a, b, c, d; };  // unaligned 16-byte access
 
 // ------------------------------------------------------------------ byte readers
-// 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
-struct LdsReader {
-  const uint32_t* lds;  // tile words (LDS)
-  uint32_t base;        // byte offset of this certificate inside the tile
-  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
-    const uint32_t a = base + pos;
-    const uint32_t i = a >> 2;
-    return __builtin_amdgcn_alignbyte(lds[i + 1], lds[i], a & 3u);
-  }
-  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
-  __device__ __forceinline__ void touch(uint32_t, uint32_t) const {}
-  __device__ __forceinline__ void touch_tail(uint32_t, uint32_t) const {}
-};
-
+// ld4(pos): 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
 struct GlobalReader {
   const uint32_t* words;  // 4-byte aligned base of the buffer (kernel argument: global address space)
   uint64_t base;          // byte offset of this certificate inside the buffer
@@ -163,130 +150,6 @@ struct WinReaderS : WinReaderC<WCH> {
     uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
     if (off > 27u) v = WinReader<WCH>::ldg(pos);  // a long AlgorithmIdentifier, or no prefetch: the real load
     return v;
-  }
-};
-
-// Line-trimmed window.  HBM is fetched in 128-byte lines (scripts/calib_fetch.hip: FETCH_SIZE x2 equals
-// the unique 128-B lines of every window pattern tried), so a refill that ends in the middle of a line
-// pays for the whole line and keeps only part of it.  This reader ends every refill at the end of the
-// line that holds byte pos+N-1 (N = bytes the walk is expected to need from there: NF for the front of
-// the certificate, NE for the extension block and on-demand refills), capped at WCH chunks: a 256-byte
-// refill at a random 16-byte phase touches 2.875 lines on average, a trimmed one 2.4.  Shorter windows
-// only ever cost an extra refill — ld4 falls back to global loads outside the window as before.
-template <int WCH, int NF, int NE>
-struct WinReaderT {
-  const uint32_t* g32;
-  uint64_t base;
-  uint64_t limit;
-  uint32_t* win;
-  int32_t grel;
-  uint32_t wlen;  // valid bytes in the window (multiple of 16)
-
-  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
-  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
-    const uint32_t rel = pos - (uint32_t)grel;
-    if (rel + 8u <= wlen && rel < 0x7fffffffu) {
-      const uint32_t i = rel >> 2;
-      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
-    }
-    const uint64_t a = base + pos;
-    const uint64_t i = a >> 2;
-    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
-  }
-  __device__ __forceinline__ void refill(uint32_t pos, uint32_t n) {
-    const uint64_t p = base + pos;
-    const uint64_t g = p & ~15ull;
-    const uint64_t end = ((p + n - 1u) | 127ull) + 1ull;
-    grel = (int32_t)(int64_t)(g - base);
-    uint32_t cnt = (uint32_t)((end - g) >> 4);
-    cnt = cnt < (uint32_t)WCH ? cnt : (uint32_t)WCH;
-    const uint64_t room = limit > g ? (limit - g) >> 4 : 0ull;
-    cnt = room < cnt ? (uint32_t)room : cnt;
-    wlen = cnt * 16u;
-    const uint4* src = (const uint4*)g32 + (g >> 4);
-    uint4 v[WCH];
-#pragma unroll
-    for (int k = 0; k < WCH; k++) v[k] = (uint32_t)k < cnt ? src[k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
-  }
-  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
-    if (need > (uint32_t)NE) need = NE;
-    const uint32_t rel = pos - (uint32_t)grel;
-    if (rel + need > wlen || rel >= 0x7fffffffu) refill(pos, NE);
-  }
-  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, NE); }
-};
-
-// Two-region window: MAIN (WCH chunks, moves with the walk) + TAIL (3 chunks pinned at the end of
-// the TBSCertificate: signatureAlgorithm and the BIT STRING header of signatureValue).  The walk
-// knows both addresses as soon as it has decoded the SubjectPublicKeyInfo header — the extension
-// block starts right behind the key, the tail at tbs_end — so touch_tail() fetches both regions
-// in ONE burst of WCH+3 independent global_load_dwordx4: the dependent HBM round trips per
-// certificate drop from ≈8 (front, [3] tag, extensions, sigalg header, BIT STRING header, pad
-// byte, last byte, …) to 2 (front; extensions + tail).  Lane stride (WCH+3)·16 B with WCH even:
-// an odd number of 16-B chunks keeps the dword reads at ≤4-way bank conflicts without a pad chunk.
-template <int WCH>
-struct WinReader2 {
-  static constexpr int TCH = 3;
-  static constexpr uint32_t WBYTES = WCH * 16, TBYTES = TCH * 16;
-  const uint32_t* g32;
-  uint64_t base;
-  uint64_t limit;
-  uint32_t* win;  // main window words; the tail window follows at win + WCH*4
-  int32_t grel;   // main window start relative to the certificate start
-  int32_t trel;   // tail window start (0x7fffff00 = not loaded)
-
-  __device__ __forceinline__ uint32_t ldg(uint32_t pos) const { return ld4(pos); }
-  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
-    const uint32_t rel = pos - (uint32_t)grel;
-    if (rel <= WBYTES - 8u) {
-      const uint32_t i = rel >> 2;
-      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
-    }
-    const uint32_t rel2 = pos - (uint32_t)trel;
-    if (rel2 <= TBYTES - 8u) {
-      const uint32_t i = WCH * 4 + (rel2 >> 2);
-      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel2 & 3u);
-    }
-    const uint64_t a = base + pos;
-    const uint64_t i = a >> 2;
-    return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
-  }
-  __device__ __forceinline__ void refill(uint32_t pos) {
-    const uint64_t g = (base + pos) & ~15ull;
-    grel = (int32_t)(int64_t)(g - base);
-    const uint4* src = (const uint4*)g32 + (g >> 4);
-    uint4 v[WCH];
-#pragma unroll
-    for (int k = 0; k < WCH; k++)
-      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
-  }
-  __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
-    if (need > WBYTES - 16u) need = WBYTES - 16u;
-    const uint32_t rel = pos - (uint32_t)grel;
-    if (rel > WBYTES - need) refill(pos);
-  }
-  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t tailpos) {
-    const uint64_t g = (base + pos) & ~15ull;
-    const uint64_t t = (base + tailpos) & ~15ull;
-    grel = (int32_t)(int64_t)(g - base);
-    trel = (int32_t)(int64_t)(t - base);
-    const uint4* src = (const uint4*)g32 + (g >> 4);
-    const uint4* tsrc = (const uint4*)g32 + (t >> 4);
-    uint4 v[WCH], u[TCH];
-#pragma unroll
-    for (int k = 0; k < WCH; k++)
-      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < TCH; k++)
-      u[k] = (t + 16u * k + 16u <= limit) ? tsrc[k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
-#pragma unroll
-    for (int k = 0; k < TCH; k++) ((uint4*)win)[WCH + k] = u[k];
   }
 };
 

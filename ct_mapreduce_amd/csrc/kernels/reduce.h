@@ -300,23 +300,22 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
     if (ent_state(e[k]) == ES_DEFER) insert2_one(a, records, i0 + k, e[k]);
 }
 
-// Fused map + pass-1 insert (variant 14): the lane that just finished walking a certificate probes the
+// Fused map + pass-1 insert (the default, variant 15): the lane that just finished walking a certificate probes the
 // known-certificate table straight from its registers — the 32-byte record is not re-read (−3.2 GB per
 // 100 M entries), the WAS_UNKNOWN flag is final before the record is stored (no second scattered write for
 // old-batch duplicates) and the random-access latency of the CAS hides behind the walks of the other
 // waves of the CU instead of being a kernel of its own.  Pass 2 (k_insert2) is unchanged.
+// Every ld4 of the walk is served by the LDS window alone (WinReaderS); a certificate whose walk leaves the window
+// is repeated with the exact global reader.
 // (Tried and dropped: loading the slot's claim word early, when the key is known but the extension block
 // is still in flight, so that the CAS finds the line on-die — +0.6 ms at 100 M entries: the kernel is bound
-// by memory transactions, not by the latency of the probe.)
-template <int WCH, bool STRICT>
+// by memory transactions, not by the latency of the probe.  An XCD-contiguous workgroup → block mapping: 23.87 ms
+// against 23.44 ms, profiles/r01/s5/sweep_xcd_contiguous_blocks_not_default.txt.  The same kernel with the per-access
+// global fallback inside ld4 instead of the window-only reader: 0.9–2.5 ms slower, profiles/r01/s4.)
+template <int WCH>
 __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
-  uint64_t blk = blockIdx.x;
-  if (a.xcd_blocks) {
-    const uint64_t per = gridDim.x / 8u;
-    if (blk < per * 8u) blk = (blk % 8u) * per + blk / 8u;
-  }
-  const uint64_t first = blk * 64;
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
   const bool live = i < a.n;
@@ -343,18 +342,12 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   uint64_t claimed = ~0ull;
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
   if (live) {
-    if constexpr (STRICT) {
-      WinReaderS<WCH> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
-                          (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
-      map_one(r, hi - lo, i, a, o0, o1);
-      if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
-        GlobalReader g{(const uint32_t*)a.payload, lo};
-        map_one(g, hi - lo, i, a, o0, o1);
-      }
-    } else {
-      WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
-                         (int32_t)(int64_t)(g_me - lo)}};
-      map_one(r, hi - lo, i, a, o0, o1);
+    WinReaderS<WCH> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                        (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
+    map_one(r, hi - lo, i, a, o0, o1);
+    if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
+      GlobalReader g{(const uint32_t*)a.payload, lo};
+      map_one(g, hi - lo, i, a, o0, o1);
     }
     const uint32_t status = o0.x & 0xffu;
     uint32_t state = ES_NONE, canon = 0;

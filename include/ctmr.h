@@ -82,15 +82,12 @@ typedef struct {
   uint64_t table_slots;       /* known-certificate table capacity (64-B slots; rounded up to 2^k); 0 = 2^24 */
   uint64_t pair_slots;        /* (expDate,issuer) cardinality table capacity; 0 = 2^22 */
   uint32_t max_issuers;       /* 0 = 65536 */
-  uint32_t certs_per_tile;    /* map-kernel tuning; 0 = default */
-  uint32_t lds_tile_bytes;    /* map-kernel tuning; 0 = default */
-  uint32_t map_variant;       /* 0 = default (15); DESIGN.md §5: 1 = whole-cert LDS tile, 2 = direct global,
-                                 3/4/5/6 = per-lane 256/128/192/224-B LDS window, 7-9 = window + pinned tail,
-                                 10-12 = line-trimmed windows, 13 = 256-B window with wave-cooperative fills,
-                                 14 = 13 fused with pass 1 of the known-certificate insert,
-                                 15 = 14 with window-only reads (no per-access global fallback; a certificate whose
-                                      walk leaves the window is repeated with the exact global reader),
-                                 16 = 15 with XCD-contiguous workgroup → block mapping (measured slower: DESIGN.md §7) */
+  uint32_t certs_per_tile;    /* sweep build only (variant 1); 0 = default */
+  uint32_t lds_tile_bytes;    /* sweep build only (variant 1); 0 = default */
+  uint32_t map_variant;       /* 0 = default (15).  15 = k_map_fused: the map fused with pass 1 of the known-certificate
+                                 insert; 13 = k_map_winc + k_insert: the same map and insert as separate kernels.  Any other
+                                 value: CTMR_E_INVAL (the baseline designs 1 = whole-certificate LDS tile and 2 = direct
+                                 global loads exist only in the sweep build, scripts/sweep.py) */
   uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
   uint32_t collect_meta;      /* 1 = the map also records where each certificate's issuer Name and
                                  cRLDistributionPoints lie (8 B per entry) so that ctmr_meta_new* can run */

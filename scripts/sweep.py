@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """GPU tuning sweep: one resident synthetic batch, many map-kernel configurations.
-usage: sweep.py ENTRIES "variant:certs_per_tile:lds_bytes,..." [issuers]"""
+usage: sweep.py ENTRIES "variant:certs_per_tile:lds_bytes,..." [issuers]
+Runs against libctmr_sweep.so (the product + the baseline designs 1 = LDS tile, 2 = direct; built here if stale)."""
 import json
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ct_mapreduce_amd import build as _b
+os.environ["CTMR_LIB"] = _b.build(sweep=True)
 import torch
 import ct_mapreduce_amd as ctmr
 from ct_mapreduce_amd import synth, _native as N
