@@ -39,9 +39,9 @@ def pow2_at_least(v):
     return p
 
 
-def cpu_baseline(batch_arrays, issuers, filt, now, sample):
-    """The oracle's restatement of the reference loop, timed on one host core (kind "port").  The sample is the
-    first `sample` entries of the SAME batch the GPU processed, copied back from HBM (payload, offsets, issuer_idx)."""
+def cpu_baseline(batch_arrays, issuers, filt, now, sample, entry_type=None):
+    """The oracle's restatement of the reference loop, timed on one host core (kind "port"), over `sample` entries of
+    the SAME batch the GPU processed (payload, offsets, issuer_idx[, entry_type])."""
     import numpy as np
     from oracle import oracle as orc
     payload, offsets, issuer_idx = batch_arrays
@@ -50,10 +50,10 @@ def cpu_baseline(batch_arrays, issuers, filt, now, sample):
     blob = np.frombuffer(b"".join(issuers), np.uint8)
     o = orc.Engine(filt, False, now)
     t0 = time.perf_counter()
-    st, unk, eh = o.batch(payload, offsets, issuer_idx, blob, io)
+    st, unk, eh = o.batch(payload, offsets, issuer_idx, blob, io, entry_type=entry_type)
     dt = time.perf_counter() - t0
     return {"value": sample / dt, "unit": "certificates/sec", "cores": 1, "kind": "port",
-            "sample": f"first {sample} entries of the same synthetic batch, oracle/ctmr_oracle.c "
+            "sample": f"{sample} entries, oracle/ctmr_oracle.c "
                       f"(in-process hash set stands in for Redis; not the Go binary), {dt:.1f} s",
             "host_cores_available": os.cpu_count()}, (st, unk)
 
@@ -130,6 +130,128 @@ def synth_is_dup(seed, first, n, dup_permille, np):
         base = _mix64(np.uint64(seed) ^ np.uint64((1 * 0xd6e8feb86659fd93) & 0xffffffffffffffff), np)
         h = _mix64(base + i, np)
         return (i > 0) & ((h % np.uint64(1000)) < np.uint64(dup_permille))
+
+
+def lib_hash():
+    """sha256 of the library the kernels come from: traffic measured on another build is refused."""
+    import hashlib
+    from ct_mapreduce_amd import _native as N
+    return hashlib.sha256(open(N.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def parse_pmc_csv(outdir, counter, kernel_substr):
+    """Average per-launch value of one rocprofv3 --pmc counter over the launches of one kernel."""
+    import csv
+    import glob
+    vals = []
+    for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                vals.append(float(row["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def measure_traffic(args, entries, kernel_substr):
+    """HBM traffic of the map kernel, measured NOW on this build: re-executes this script on a smaller batch of the same
+    corpus under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace flags:
+    MI355X_MICROARCH.md §HBM / §rocprofv3 PMC slots) and returns bytes per certificate.  gfx950 correction: FETCH_SIZE
+    tallies 128-byte requests at 64 bytes — x2 (calibrated on this access pattern too: scripts/calib_fetch.hip,
+    profiles/r01/s2); WRITE_SIZE as is.  Both are reported in KiB by rocprofv3."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="ctmr_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, CTMR_BENCH_CHILD="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    child = [sys.executable, os.path.abspath(__file__), "--entries", str(entries), "--steps", "2", "--warmup", "1",
+             "--no-cpu", "--traffic", "off", "--issuers", str(args.issuers), "--variant", str(args.variant),
+             "--dup-permille", str(args.dup_permille)] + (["--mixed"] if args.mixed else [])
+    out = {"entries": entries}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(tmp, c)
+        try:
+            r = subprocess.run([exe, "--pmc", c, "-d", d, "-o", "pmc", "--output-format", "csv", "--"] + child,
+                               cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {c} pass timed out"
+        v, n = parse_pmc_csv(d, c, kernel_substr)
+        if v is None:
+            return None, f"rocprofv3 --pmc {c}: no rows for {kernel_substr} (rc {r.returncode}): " + r.stdout.decode(errors="replace")[-300:]
+        out[c + "_KB_per_launch"] = v
+        out["launches"] = n
+    shutil.rmtree(tmp, ignore_errors=True)
+    out["fetch_bytes_per_cert"] = 2.0 * out["FETCH_SIZE_KB_per_launch"] * 1024.0 / entries
+    out["write_bytes_per_cert"] = out["WRITE_SIZE_KB_per_launch"] * 1024.0 / entries
+    out["traffic_bytes_per_cert"] = out["fetch_bytes_per_cert"] + out["write_bytes_per_cert"]
+    out["lib_sha256_16"] = lib_hash()
+    return out, None
+
+
+def needed_bytes_per_cert(certs, starts, filt):
+    """What the walk READS of a certificate (the product's walk compiled for the host with a marking reader,
+    tests/harness): bytes covered by its reads, and the distinct 128-byte HBM lines they lie in at the certificate's
+    real position in the payload — the floor of the map kernel's fetch traffic at line granularity."""
+    from tests import harness
+    nb = nl = 0
+    for der, st in zip(certs, starts):
+        _, b, l = harness.walk_touched(der, int(st) & 127, filt)
+        nb += b
+        nl += l
+    return nb / len(certs), nl * 128.0 / len(certs)
+
+
+def strided_sample(E, slices, per_slice):
+    """[lo, hi) ranges of `slices` equally spaced slices of `per_slice` entries over [0, E)."""
+    per_slice = min(per_slice, max(1, E // slices))
+    return [(k * (E // slices), k * (E // slices) + per_slice) for k in range(slices)]
+
+
+def gather_sample(d_off, d_pay, d_iss, d_et, ranges, extra_idx, extra_certs, pad, np):
+    """One host batch = the sampled slices copied back from HBM + `extra` single entries (index → (der, issuer_idx,
+    entry_type)), all in ascending log-index order.  Returns (payload, offsets, issuer_idx, entry_type, global_index)."""
+    pieces = []          # (first_index, payload u8, lens u64, iss u32, et u8)
+    for lo, hi in ranges:
+        offs = d_off[lo:hi + 1].cpu().numpy().astype(np.uint64)
+        pay = d_pay[int(offs[0]):int(offs[-1])].cpu().numpy()
+        pieces.append((lo, pay, np.diff(offs), d_iss[lo:hi].cpu().numpy().astype(np.uint32),
+                       d_et[lo:hi].cpu().numpy().astype(np.uint8), np.arange(lo, hi, dtype=np.uint64)))
+    for i, (der, iss, et) in zip(extra_idx, extra_certs):
+        pieces.append((int(i), np.frombuffer(der, np.uint8), np.array([len(der)], np.uint64),
+                       np.array([iss], np.uint32), np.array([et], np.uint8), np.array([i], np.uint64)))
+    pieces.sort(key=lambda t: t[0])
+    payload = np.concatenate([t[1] for t in pieces] + [np.zeros(pad, np.uint8)])
+    lens = np.concatenate([t[2] for t in pieces])
+    offsets = np.zeros(len(lens) + 1, np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    return (payload, offsets, np.concatenate([t[3] for t in pieces]), np.concatenate([t[4] for t in pieces]),
+            np.concatenate([t[5] for t in pieces]))
+
+
+def synth_src(seed, idx, dup_permille, np):
+    """numpy restatement of csrc/synth.h synth_src: the entry whose key entry i repeats (i itself if it is no duplicate)."""
+    with np.errstate(over="ignore"):
+        idx = np.asarray(idx, dtype=np.uint64)
+        src = idx.copy()
+        dup = synth_is_dup_at(seed, idx, dup_permille, np)
+        base = _mix64(np.uint64(seed) ^ np.uint64((2 * 0xd6e8feb86659fd93) & 0xffffffffffffffff), np)
+        j = _mix64(base + idx[dup], np) % idx[dup]
+        while True:                                  # walk down to the nearest entry that is no duplicate itself
+            d = synth_is_dup_at(seed, j, dup_permille, np)
+            if not d.any():
+                break
+            j = np.where(d, j - np.uint64(1), j)
+        src[dup] = j
+        return src, dup
+
+
+def synth_is_dup_at(seed, idx, dup_permille, np):
+    with np.errstate(over="ignore"):
+        idx = np.asarray(idx, dtype=np.uint64)
+        base = _mix64(np.uint64(seed) ^ np.uint64((1 * 0xd6e8feb86659fd93) & 0xffffffffffffffff), np)
+        h = _mix64(base + idx, np)
+        return (idx > 0) & ((h % np.uint64(1000)) < np.uint64(dup_permille))
 
 
 def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers):
@@ -247,10 +369,23 @@ def main():
                     help="feed raw get-entries blobs (leaf_input ‖ extra_data, ≈3.06 KB per entry): adds the "
                          "LogEntryFromLeaf decode and the Chain[0] → issuer match in front of the map (SURVEY §8(f) N2); "
                          "not the default workload")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "off"],
+                    help="auto (default, N=1 only): after the timed steps re-execute this script on --traffic-entries "
+                         "entries of the same corpus under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate "
+                         "passes) and report the map kernel's measured HBM traffic; off: roofline.traffic = null")
+    ap.add_argument("--traffic-entries", type=int, default=10_000_000)
     ap.add_argument("--traffic-file", default=None,
-                    help="JSON written by scripts/make_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / "
-                         "WRITE_SIZE passes of this command (default: profiles/traffic_map.json when it was "
-                         "measured on the same entries/variant)")
+                    help="use this earlier measurement (the JSON this script writes to gpurun_out/traffic_map.json) instead "
+                         "of measuring; refused unless it was taken on the same build of libctmr.so")
+    ap.add_argument("--dup-permille", type=int, default=20,
+                    help="entries that repeat an earlier entry's (issuer, serial, notAfter) — anywhere earlier in the "
+                         "batch — so that the DEFER / duplicate paths of the insert run at headline scale (default 2 %%)")
+    ap.add_argument("--sample-slices", type=int, default=60,
+                    help="the oracle-checked sample (= the one-core cpu_baseline leg) is this many equally spaced slices "
+                         "of the batch …")
+    ap.add_argument("--sample-per-slice", type=int, default=0,
+                    help="… of this many entries each (default: --cpu-sample / --sample-slices), plus every entry "
+                         "outside the slices whose key a sampled duplicate repeats")
     args = ap.parse_args()
 
     import numpy as np
@@ -278,7 +413,7 @@ def main():
     filt = b"Synth Issuer 0,Synth Issuer 1"      # BASELINE config 3: passes issuers 000-199
     # the global-dedup modes run BASELINE config 5's corpus: 10 % of the entries repeat an earlier entry's key —
     # anywhere earlier in the stream, i.e. usually in another rank's shard
-    dup_permille = 100 if args.global_dedup else 0
+    dup_permille = 100 if args.global_dedup else args.dup_permille
     cfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
                        ca_permille=10, expired_permille=10, profile=1 if args.mixed else 0)
     now = synth.BASE_TIME
@@ -420,19 +555,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # HBM traffic of the map kernel per launch: PMC counters can only be collected under rocprofv3, in their
-    # own passes; the committed measurement of the same command is reported when workload and kernel match.
-    traffic = None
-    traffic_src = None
-    tf = args.traffic_file or os.path.join(ROOT, "profiles", "traffic_map.json")
-    if os.path.exists(tf):
-        try:
-            t = json.load(open(tf))
-            if int(t.get("entries", -1)) == E and int(t.get("map_variant", -1)) == (args.variant or DEFAULT_VARIANT):
-                traffic = t.get("traffic_bytes")
-                traffic_src = os.path.relpath(tf, ROOT)
-        except (ValueError, OSError):
-            pass
+    # HBM traffic of the map kernel per launch: PMC counters can only be collected under rocprofv3, in their own
+    # passes — this script re-executes itself under the profiler on a smaller batch of the same corpus (bytes per
+    # certificate do not depend on the batch size: every launch streams ≫ the 256 MB of on-die cache) and scales.
+    traffic = traffic_info = traffic_err = None
+    kname = MAP_KERNELS[args.variant or DEFAULT_VARIANT].split("<")[0]
+    plain = not (args.raw or args.global_dedup or args.meta)
+    if rank == 0 and world == 1 and plain and not os.environ.get("CTMR_BENCH_CHILD"):
+        if args.traffic_file:
+            try:
+                t = json.load(open(args.traffic_file))
+                if t.get("lib_sha256_16") == lib_hash() and "traffic_bytes_per_cert" in t:
+                    traffic_info = dict(t, source=os.path.relpath(args.traffic_file, ROOT))
+                else:
+                    traffic_err = "traffic file refused: taken on another build of libctmr.so"
+            except (ValueError, OSError) as ex:
+                traffic_err = f"traffic file unreadable: {ex}"
+        elif args.traffic == "auto":
+            t_tr = time.perf_counter()
+            traffic_info, traffic_err = measure_traffic(args, min(E, args.traffic_entries), kname)
+            if traffic_info:
+                traffic_info["source"] = "measured by this run (rocprofv3 --pmc, two passes)"
+                traffic_info["seconds"] = round(time.perf_counter() - t_tr, 1)
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    json.dump(traffic_info, open(os.path.join(ROOT, "gpurun_out", "traffic_map.json"), "w"))
+                except OSError:
+                    pass
+        if traffic_info:
+            traffic = traffic_info["traffic_bytes_per_cert"] * E
 
     n_total = E * world
     if gd_rank is not None or bloom_rank is not None:   # no per-kernel events here: the map time is not separable
@@ -449,25 +600,31 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{E} synthetic ~1.5 KB DER CT entries per GPU, {args.issuers} issuers (Zipf), "
+                               f"{dup_permille / 10:g} % duplicates of earlier entries, "
                                "issuerCN prefix filter + known-certificate dedup + per-issuer unique counts "
                                "(BASELINE configs[2]/[3] shape)",
                    "entries_per_gpu": E, "mean_der_bytes": stats.payload_bytes / E,
                    "parallelism": f"log-index shards x{world}", "map_variant": args.variant or DEFAULT_VARIANT,
                    "gen_seconds": round(t_gen, 2)},
+        # roofline of the dominant kernel.  `frac` is PHYSICAL when the traffic was measured: HBM bytes the kernel moved
+        # (PMC counters) ÷ its average launch time ÷ peak.  The walk skips key, SAN body and signature by length, so the
+        # SURVEY §8(d) algorithmic figure (every certificate byte "read once") counts bytes that never move:
+        # `frac_algorithmic` is kept beside it, never instead of it.
         "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or DEFAULT_VARIANT],
-                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_source": traffic_src,
-                     # the walk skips key, SAN body and signature: fewer bytes move than the algorithmic
-                     # figure, so frac can exceed 1; frac_physical = measured traffic / time / peak
-                     "frac_physical": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                     # … and against what a plain float4 copy reaches on this part (MI355X_MICROARCH.md: 6.29 TB/s)
-                     "frac_physical_of_streaming_ceiling": (traffic / (avg_ms * 1e-3) / 1e9 / 6290.0) if traffic else None,
+                     "achieved": (traffic if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9,
+                     "achieved_basis": "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE) / avg launch time" if traffic
+                                       else "ALGORITHMIC bytes / avg launch time (no PMC measurement in this run"
+                                            + (": " + traffic_err if traffic_err else "") + ")",
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": (traffic if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": traffic, "traffic_measurement": traffic_info,
+                     "frac_of_streaming_ceiling": (traffic / (avg_ms * 1e-3) / 1e9 / 6290.0) if traffic else None,
+                     "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                      "alg_bytes_formula": "sum(L_i) + 45*E" + (" + 64*PASS (table probe)" if (args.variant or DEFAULT_VARIANT) in FUSED else "")},
         "kernel_ms": {"map": stats.ms_map, "insert": stats.ms_insert, "resolve": stats.ms_resolve,
                       "compact": stats.ms_compact, "total": stats.ms_total},
-        "result": {"n_new": int(stats.n_new), "by_status": [int(x) for x in stats.by_status]},
+        "result": {"n_new": int(stats.n_new), "n_dup": int(stats.n_dup), "by_status": [int(x) for x in stats.by_status]},
     }
     if args.pem:
         m = min(int(stats.n_new), 16_000_000)
@@ -502,7 +659,7 @@ def main():
                       "first_block_matches_stdlib_base64": bool(ok_pem)}
     if args.global_dedup:
         out["config"]["workload"] = out["config"]["workload"].replace(
-            "(BASELINE configs[2]/[3] shape)", "with 10 % duplicates of earlier entries, mostly in other ranks' shards "
+            "(BASELINE configs[2]/[3] shape)", "— mostly in other ranks' shards "
             "(BASELINE configs[4] corpus, one round)")
         # exactness of the GLOBAL dedup against the generator's structure: entry i repeats an earlier entry's key iff
         # synth_is_dup(i), wherever that earlier entry lives — so this rank's NEW entries are its PASS ∧ ¬dup ones
@@ -568,18 +725,55 @@ def main():
         out["kernel_ms"]["match"] = ds.ms_match
     if rank == 0:
         if world == 1 and not args.no_cpu and not args.raw:
-            sample = min(args.cpu_sample, E)
-            offs = d_off[: sample + 1].cpu().numpy().astype(np.uint64)
-            nbytes = int(offs[-1])
-            arrays = (np.concatenate([d_pay[:nbytes].cpu().numpy(), np.zeros(N.PAYLOAD_PAD, np.uint8)]), offs,
-                      d_iss[:sample].cpu().numpy().astype(np.uint32))
-            base, (ost, ounk) = cpu_baseline(arrays, issuers, filt, now, sample)
+            # ---- the oracle-checked sample = the one-core cpu_baseline leg: equally spaced slices over the WHOLE batch,
+            # copied back from HBM, plus — generated on the host, byte-identical to the device generator
+            # (tests/test_gpu_parity.py) — every entry outside the slices whose key a sampled duplicate repeats, all in
+            # log order.  The generator repeats keys of NON-duplicate entries only (csrc/synth.h synth_src), so the
+            # oracle's WasUnknown over this closed set is the whole batch's answer for every entry in it.
+            per = args.sample_per_slice or max(1, min(args.cpu_sample, E) // args.sample_slices)
+            ranges = strided_sample(E, args.sample_slices, per)
+            in_sample = np.concatenate([np.arange(lo, hi, dtype=np.uint64) for lo, hi in ranges])
+            src, isdup = synth_src(cfg.seed, in_sample, dup_permille, np)
+            extra = np.setdiff1d(src[isdup], in_sample)
+            extra_certs = [synth.leaf(cfg, int(i)) for i in extra]
+            arrays = gather_sample(d_off, d_pay, d_iss, d_et, ranges, extra, extra_certs, N.PAYLOAD_PAD, np)
+            sample = len(arrays[4])
+            base, (ost, ounk) = cpu_baseline(arrays[:3], issuers, filt, now, sample, arrays[3])
+            base["sample"] = (f"{args.sample_slices} equally spaced slices of {per} entries of the same synthetic batch, copied "
+                              f"back from HBM, + the {len(extra)} entries outside them whose keys sampled duplicates repeat; "
+                              + base["sample"])
             out["cpu_baseline"] = base
+            gidx = torch.from_numpy(arrays[4].astype(np.int64)).to(dev)
+            rec = d_rec.view(-1, 32)[gidx].cpu().numpy().reshape(-1).view(ctmr.engine.RECORD_DTYPE)
+            gnew = (rec["flags"] & 2) != 0
+            out["parity_vs_oracle_on_sample"] = bool((rec["status"] == ost).all() and (gnew == (ounk != 0)).all())
+            out["parity_sample"] = {"entries": int(sample), "slices": args.sample_slices, "entries_per_slice": per,
+                                    "sources_outside_the_slices": int(len(extra)),
+                                    "pass": int((ost == 0).sum()), "was_unknown": int((ounk != 0).sum()),
+                                    "known_duplicates": int(((ost == 0) & (ounk == 0)).sum()),
+                                    "status_mismatches": int((rec["status"] != ost).sum()),
+                                    "was_unknown_mismatches": int((gnew != (ounk != 0)).sum())}
+            # what the walk must read of these certificates, against the measured traffic
+            k = min(20000, per)
+            offs_k = arrays[1][:k + 1]
+            certs_k = [arrays[0][int(offs_k[i]):int(offs_k[i + 1])].tobytes() for i in range(k)]
+            starts_k = d_off[ranges[0][0]:ranges[0][0] + k].cpu().numpy()
+            nb, nl = needed_bytes_per_cert(certs_k, starts_k, filt)
+            n_pass = int(stats.by_status[0])
+            fixed = ALG_BYTES_FIXED * E + 4 * E + ALG_BYTES_PROBE * n_pass      # arrays + record + ent[] word; slot read + write
+            out["roofline"]["needed_bytes"] = nb * E + fixed
+            out["roofline"]["needed_line_bytes"] = nl * E + fixed + 64 * n_pass   # … when every touched 128-B line moves whole (slot lines too)
+            out["roofline"]["needed_note"] = (f"per certificate the walk's reads cover {nb:.0f} bytes lying in {nl / 128:.2f} lines of 128 B "
+                                              f"(product walk on the host with a marking reader, first {k} sampled certificates); "
+                                              "+ 45 B arrays/record + 4 B reduce state per entry + the 64-B slot (a 128-B line) per PASS entry")
+            if traffic:
+                out["roofline"]["over_fetch_vs_needed_bytes"] = traffic / out["roofline"]["needed_bytes"]
+                out["roofline"]["over_fetch_vs_needed_lines"] = traffic / out["roofline"]["needed_line_bytes"]
             quota_threads, quota = cpu_quota()
             threads = args.cpu_threads or quota_threads
             if threads > 1:
-                # … and on every host CPU this process may use: a larger sample of the same batch (≈400 k entries per thread)
-                del arrays                               # the one-core sample's host copy
+                # … and on every host CPU this process may use: a contiguous sample of the same batch (≈400 k entries per thread)
+                del arrays
                 sample_mt = min(E, args.cpu_sample_mt or min(400_000 * threads, 16_000_000))
                 offs_mt = d_off[: sample_mt + 1].cpu().numpy().astype(np.uint64)
                 nb_mt = int(offs_mt[-1])
@@ -600,10 +794,6 @@ def main():
                     "host_cores_available": os.cpu_count(), "cgroup_cpu_quota": quota,
                     "pass_count_matches_gpu": bool(ok_mt),
                     "one_core": {"value": base["value"], "sample": base["sample"]}}
-            # the bench doubles as a parity check on that sample
-            rec = d_rec[: sample * 32].cpu().numpy().view(ctmr.engine.RECORD_DTYPE)
-            out["parity_vs_oracle_on_sample"] = bool((rec["status"] == ost).all() and
-                                                     (((rec["flags"] & 2) != 0) == (ounk != 0)).all())
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -29,6 +29,11 @@ struct Walk {
   uint32_t cn_off, cn_len;
   uint32_t spki_off, spki_len;
   bool bc_valid, is_ca;
+  // findings certificate-transparency-go reports as x509.NonFatalErrors (WALK_NF_*): the certificate is handed out
+  // all the same.  The reference keeps it when it is an X509 entry (ct.LogEntryFromLeaf drops an entry only on
+  // x509.IsFatal errors, cmd/ct-fetch/ct-fetch.go:452-459) and drops it when it is a precertificate or a Chain[0]
+  // issuer (any err: :202-209, :221-225) — map_one / k_issuer_ids apply that.
+  uint32_t nonfatal;
   // captured while the bytes are at hand (a windowed reader may have moved on afterwards):
   uint32_t serial_w[5];  // first min(20, serial_len) serial octets, little-endian words, zero padded
   bool cn_match;         // some issuerCNFilter piece is a byte prefix of the CommonName
@@ -36,6 +41,9 @@ struct Walk {
   // (meta_pack): the issuer Name TLV, and the OCTET STRING content of extension 2.5.29.31
   uint32_t meta_issuer, meta_crl;
 };
+
+constexpr uint32_t WALK_NF_NEGATIVE_SERIAL = 1u;  // "x509: negative serial number"
+constexpr uint32_t WALK_NF_LAX_INTEGER = 2u;      // an INTEGER only CT-go's lax asn1 re-parse accepts (not minimal)
 
 constexpr uint32_t META_NONE = 0u;           // no such element
 constexpr uint32_t META_HOST = 0xffffffffu;  // does not fit 16+16 bits, or the extension occurs twice: host parse
@@ -92,13 +100,36 @@ CTMR_HD bool cn_prefix_match(const R& r, uint32_t L, uint32_t cn_off, uint32_t c
 // `ok`), and only the final `ok` is observable.  This keeps the exec-mask bookkeeping down to
 // the loops and the few optional elements.
 
-// TLV header at p, which must lie wholly inside [p, end): tag, content start, content end.
-// Go encoding/asn1 parseTagAndLength rules: single-byte tags, definite minimal lengths < 2^31.
-template <class R>
+// TLV header at p: tag (the identifier octet), content start, content end.  Go encoding/asn1 parseTagAndLength rules:
+// definite minimal lengths < 2^31; the high-tag-number form is allowed (minimal, < 2^31) — it can only ever match an
+// ANY position, every expected tag on this path is a low one.  FIT = true: header and contents must lie inside
+// [p, end) (Go: "data truncated").  FIT = false: only the header must (an OPTIONAL field that does not match is
+// skipped, but parseTagAndLength has run on it; an EXPLICIT wrapper's own length is never checked).
+template <bool FIT = true, class R>
 CTMR_HD void rd_hdr(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& tag,
                     uint32_t& cs, uint32_t& ce) {
-  const uint32_t w = ldc(r, p, L);
+  uint32_t w = ldc(r, p, L);
   tag = w & 0xffu;
+  uint32_t lp = p;  // the length octet is at lp + 1
+  bool tag_ok = true;
+  if ((tag & 0x1fu) == 0x1fu) {  // high-tag-number form (rare): parseBase128Int, <= 5 octets, first != 0x80, value in [31, 2^31)
+    const uint32_t x = ldc(r, p + 1u, L), y = ldc(r, p + 5u, L) & 0xffu;
+    uint32_t k = 5u;
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int i = 4; i >= 0; i--) {  // k = index of the first octet without the continuation bit
+      const uint32_t bt = i < 4 ? (x >> (8 * i)) & 0xffu : y;
+      k = (bt & 0x80u) ? k : (uint32_t)i;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const uint32_t bt = i < 4 ? (x >> (8 * i)) & 0xffu : y;
+      if ((uint32_t)i <= k) v = (v << 7) | (bt & 0x7fu);
+    }
+    tag_ok = (k < 5u) & ((x & 0xffu) != 0x80u) & (v <= 0x7fffffffull) & (v >= 0x1full);
+    lp = p + 1u + (k < 5u ? k : 0u);
+    w = ldc(r, lp, L);
+  }
   const uint32_t b = (w >> 8) & 0xffu;
   const uint32_t n = b & 0x7fu;
   const bool lng = b >= 0x80u;
@@ -107,20 +138,20 @@ CTMR_HD void rd_hdr(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, 
   // short form | 0x81 vv (vv >= 0x80) | 0x82 hh ll (hh != 0): minimal, no leading zero.  For the long forms with
   // one or two length octets "minimal" is one comparison: value >= 0x40 << n (0x80, 0x100).
   uint32_t len = lng ? (n == 1u ? len1 : len2) : b;
-  const uint32_t hl = lng ? 2u + n : 2u;
+  const uint32_t hl = (lp - p) + (lng ? 2u + n : 2u);
   bool good = !lng | (((n - 1u) <= 1u) & (len >= (0x40u << (n & 3u))));
   if (lng & (n > 2u)) {  // > 64 KiB contents: rare
-    const uint32_t q = p + 2u;
+    const uint32_t q = lp + 2u;
     const uint32_t x = ldc(r, q, L);  // the n length bytes, big endian
     const uint32_t be = __builtin_bswap32(x);
     len = n == 3u ? (be >> 8) : be;
     good = (n <= 4u) & ((x & 0xffu) != 0u) & (len <= 0x7fffffffu);
   }
-  good = good & ((tag & 0x1fu) != 0x1fu);
-  const uint32_t c = p + hl;  // p <= 2^31, hl <= 6: no wrap
+  good = good & tag_ok;
+  const uint32_t c = p + hl;  // p <= 2^31, hl <= 11: no wrap
   cs = c;
   ce = c + len;               // len < 2^31: no wrap; ce >= c >= p, so ONE comparison bounds header and contents
-  ok = ok & good & (ce <= end);
+  ok = ok & good & ((FIT ? ce : cs) <= end);
 }
 
 CTMR_HD bool digits4(uint32_t w) {  // four ASCII digits?  (SWAR: every byte ^ 0x30 must be <= 9)
@@ -141,29 +172,54 @@ CTMR_HD int64_t days_from_civil(int32_t y, uint32_t m, uint32_t d) {
   return (int64_t)era * 146097 + (int64_t)doe - 719468;
 }
 
-// UTCTime "YYMMDDHHMM[SS]Z" (tag 0x17, len 11/13) or GeneralizedTime "YYYYMMDDHHMMSSZ"
-// (tag 0x18, len 15) at content offset c.  Only the Z forms are in the profile.
+// UTCTime "YYMMDDHHMM[SS]" + zone (tag 0x17) or GeneralizedTime "YYYYMMDDHHMMSS" + zone (tag 0x18) at content offset
+// c; zone = 'Z' or a NON-ZERO numeric offset ±hhmm with mm <= 59.  Go asn1 parseUTCTime / parseGeneralizedTime:
+// time.Parse with the layouts "0601021504Z0700" (tried first), "060102150405Z0700", "20060102150405Z0700", then the
+// result must serialise back to the input — so ±0000 is out (offset 0 prints as "Z"), mm = 60..99 is out (prints as
+// the next hour), fractions are out; hh is any two digits (the Go 1.13 toolchain the reference pins does not
+// range-check it, and Format prints it back).  UTCTime years: yy < 50 → 20yy, else 19yy (time.Parse's 69 pivot
+// plus parseUTCTime's "year >= 2050 → −100").
 template <class R>
 CTMR_HD void rd_time(const R& r, uint32_t L, uint32_t c, uint32_t tag, uint32_t len, bool& ok,
                      int64_t& out) {
   const uint32_t cc = c < L ? c : L;
-  uint32_t w0 = r.ld4(cc), w1 = r.ld4(cc + 4), w2 = r.ld4(cc + 8), w3 = r.ld4(cc + 12);
+  uint32_t w0 = r.ld4(cc), w1 = r.ld4(cc + 4), w2 = r.ld4(cc + 8), w3 = r.ld4(cc + 12), w4 = 0u;
+  if (len > 16u) w4 = r.ld4(cc + 16);  // only a numeric zone reaches this far: rare
   const bool gt = tag == 0x18u;
-  bool good = gt ? (len == 15u) : ((tag == 0x17u) & ((len == 13u) | (len == 11u)));
+  bool good = gt | (tag == 0x17u);
   uint32_t century = 0;
+  uint32_t dl = len;  // length from the two-digit year on
   if (gt) {
     good = good & digits4(w0);
     century = d2(w0, 0);
-    // drop the century: shift the 16-byte window down by two bytes → "YYMMDDHHMMSSZ"
+    // drop the century: shift the 20-byte window down by two bytes → "YYMMDDHHMMSS" + zone
     w0 = (w0 >> 16) | (w1 << 16);
     w1 = (w1 >> 16) | (w2 << 16);
     w2 = (w2 >> 16) | (w3 << 16);
-    w3 = w3 >> 16;
+    w3 = (w3 >> 16) | (w4 << 16);
+    w4 = w4 >> 16;
+    dl = len - 2u;
   }
-  const bool short_form = !gt & (len == 11u);  // "YYMMDDHHMMZ": seconds = 00
-  const uint32_t z = short_form ? (w2 >> 16) : w3;
-  if (short_form) w2 = (w2 & 0xffffu) | 0x30300000u;
-  good = good & digits4(w0) & digits4(w1) & digits4(w2) & ((z & 0xffu) == (uint32_t)'Z');
+  // seconds are there iff the 11th character is a digit (the layout without seconds is tried first and fails on it)
+  const uint32_t c10 = (w2 >> 16) & 0xffu;
+  const bool secs = (c10 - 0x30u) <= 9u;
+  good = good & (secs | !gt);
+  const uint32_t zw = secs ? w3 : ((w2 >> 16) | (w3 << 16));     // zone characters 0..3
+  const uint32_t z4 = secs ? (w4 & 0xffu) : ((w3 >> 16) & 0xffu);  // zone character 4
+  const uint32_t zl = dl - (secs ? 12u : 10u);                     // wraps for short strings: neither 1 nor 5
+  if (!secs) w2 = (w2 & 0xffffu) | 0x30300000u;                    // seconds = "00"
+  good = good & digits4(w0) & digits4(w1) & digits4(w2);
+  const uint32_t z0 = zw & 0xffu;
+  int32_t zoff = 0;
+  bool zone_ok = (zl == 1u) & (z0 == (uint32_t)'Z');
+  if (zl == 5u) {  // rare
+    const uint32_t dg = (zw >> 8) | (z4 << 24);  // "hhmm"
+    const uint32_t zh = d2(dg, 0), zm = d2(dg, 16);
+    zone_ok = ((z0 == (uint32_t)'+') | (z0 == (uint32_t)'-')) & digits4(dg) & (zm <= 59u) & ((zh | zm) != 0u);
+    zoff = (int32_t)(zh * 3600u + zm * 60u);
+    zoff = z0 == (uint32_t)'-' ? -zoff : zoff;
+  }
+  good = good & zone_ok;
   const uint32_t yy = d2(w0, 0);
   const int32_t year = gt ? (int32_t)(century * 100u + yy) : (int32_t)(yy < 50u ? 2000u + yy : 1900u + yy);
   const uint32_t mon = d2(w0, 16), day = d2(w1, 0), hh = d2(w1, 16), mm = d2(w2, 0), ss = d2(w2, 16);
@@ -172,17 +228,71 @@ CTMR_HD void rd_time(const R& r, uint32_t L, uint32_t c, uint32_t tag, uint32_t 
   dim = mon == 2u ? (leap ? 29u : 28u) : dim;
   good = good & (mon >= 1u) & (mon <= 12u) & (day >= 1u) & (day <= dim) & (hh <= 23u) & (mm <= 59u) & (ss <= 59u);
   ok = ok & good;
-  out = days_from_civil(year, mon, day) * 86400 + (int64_t)(hh * 3600u + mm * 60u + ss);
+  out = days_from_civil(year, mon, day) * 86400 + (int64_t)(hh * 3600u + mm * 60u + ss) - (int64_t)zoff;
 }
 
-// Go asn1 checkInteger on content [c, c+len): non-empty and minimally encoded.
+// Go asn1 checkInteger on content [c, c+len): non-empty (else fatal) and minimally encoded (else a finding only
+// CT-go's lax re-parse tolerates: WALK_NF_LAX_INTEGER).  neg: the sign bit of the first content octet.
 template <class R>
-CTMR_HD bool int_ok(const R& r, uint32_t L, uint32_t c, uint32_t len) {
+CTMR_HD void int_check(const R& r, uint32_t L, uint32_t c, uint32_t len, bool& ok, uint32_t& nf, bool& neg) {
   const uint32_t w = ldc(r, c, L);
   const uint32_t b0 = w & 0xffu, b1 = (w >> 8) & 0xffu;
   const bool pad0 = (b0 == 0x00u) & ((b1 & 0x80u) == 0u);
   const bool padf = (b0 == 0xffu) & ((b1 & 0x80u) != 0u);
-  return (len != 0u) & ((len == 1u) | !(pad0 | padf));
+  ok = ok & (len != 0u);
+  nf = ((len > 1u) & (pad0 | padf)) ? (nf | WALK_NF_LAX_INTEGER) : nf;
+  neg = (b0 & 0x80u) != 0u;
+}
+
+// An `int` field (Version, MaxPathLen): parseInt32 = checkInteger, at most 8 octets, the value fits int32.  A
+// minimal encoding fits iff it has at most 4 octets; a non-minimal one (lax) is decoded.
+template <class R>
+CTMR_HD void int32_check(const R& r, uint32_t L, uint32_t c, uint32_t len, bool& ok, uint32_t& nf) {
+  const uint32_t w = ldc(r, c, L);
+  const uint32_t b0 = w & 0xffu, b1 = (w >> 8) & 0xffu;
+  const bool pad0 = (b0 == 0x00u) & ((b1 & 0x80u) == 0u);
+  const bool padf = (b0 == 0xffu) & ((b1 & 0x80u) != 0u);
+  const bool nonmin = (len > 1u) & (pad0 | padf);
+  bool good = (len != 0u) & (len <= (nonmin ? 8u : 4u));
+  if (nonmin & good) {  // rare
+    const uint32_t w1 = ldc(r, c + 4u, L);
+    const unsigned long long be = ((unsigned long long)__builtin_bswap32(w) << 32) | __builtin_bswap32(w1);
+    const long long v = (long long)be >> (8u * (8u - len));  // the first len octets, sign-extended
+    good = v == (long long)(int32_t)v;
+    nf |= WALK_NF_LAX_INTEGER;
+  }
+  ok = ok & good;
+}
+
+// Go asn1 parseBitString on content [c, c+len): non-empty, pad <= 7, no pad bits in an empty string, pad bits zero
+// (only then is the last octet read — it may be far away).
+template <class R>
+CTMR_HD void bit_string_check(const R& r, uint32_t L, uint32_t c, uint32_t len, bool& ok) {
+  const uint32_t pad = ldc(r, c, L) & 0xffu;
+  ok = ok & (len != 0u) & (pad <= 7u) & ((len != 1u) | (pad == 0u));
+  if (ok & (pad != 0u)) {
+    const uint32_t lastp = c + len - 1u;
+    const uint32_t last = ldc(r, lastp, L) & 0xffu;
+    ok = (last & ((1u << (pad & 7u)) - 1u)) == 0u;
+  }
+}
+
+// pkix.AlgorithmIdentifier ::= SEQUENCE { algorithm OBJECT IDENTIFIER, parameters ANY OPTIONAL } at p, inside [p, end):
+// the OID must be there, non-empty and end on an octet without the continuation bit (parseObjectIdentifier, as far as
+// it is modelled); parameters, when present, must be one well-formed TLV that fits; anything behind is ignored.
+template <class R>
+CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& after) {
+  uint32_t tag, cs, ce, to, co, eo;
+  rd_hdr(r, L, p, end, ok, tag, cs, ce);
+  rd_hdr(r, L, cs, ce, ok, to, co, eo);
+  const uint32_t lastp = eo - 1u;
+  const uint32_t last = ldc(r, lastp, L);
+  ok = ok & (tag == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
+  if (ok & (eo < ce)) {
+    uint32_t tp, cp, ep;
+    rd_hdr(r, L, eo, ce, ok, tp, cp, ep);
+  }
+  after = ce;
 }
 
 CTMR_HD bool string_tag(uint32_t t) {
@@ -199,11 +309,77 @@ struct TailView {
   CTMR_HD uint32_t ld4(uint32_t pos) const { return r.ldg(pos); }
 };
 
+// pkix.RDNSequence at q (asn1.RawValue in the tbsCertificate, then asn1.Unmarshal into pkix.RDNSequence): SEQUENCE OF
+// SET OF SEQUENCE { type OID, value ANY }; bytes behind the value inside an AttributeTypeAndValue are ignored.
+// CN = true: also finds the last attribute with OID 2.5.4.3 whose value is a string type (the types Go decodes to a
+// `string`; pkix.Name.FillFromRDNSequence).  One flattened loop: each iteration decodes either a SET (RDN) header or
+// one AttributeTypeAndValue.  Returns the end of the Name.
+template <bool CN, class R>
+CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool& ok, uint32_t& cn_off, uint32_t& cn_len) {
+  uint32_t tag, cs, ce;
+  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+  ok = ok & (tag == 0x30u);
+  const uint32_t s_end = ce;
+  uint32_t a = cs, a_end = cs;
+  while (ok & (a < s_end)) {
+    uint32_t t1, c1, e1;
+    r.touch(a, 32);
+    if (a == a_end) {  // next RDN
+      // Fast form: the 12 bytes at a hold SET hdr, AttributeTypeAndValue hdr, a 3-byte OID with its hdr, and the
+      // value hdr — when every length is short form (the usual 2.5.4.x attribute).  One independent 12-byte
+      // read replaces five dependent header reads; each header read is an LDS round trip on the critical path.
+      const uint32_t w0 = ldc(r, a, L), w1 = ldc(r, a + 4u, L), w2 = ldc(r, a + 8u, L);
+      const bool fast = ((w0 & 0x80ff80ffu) == 0x00300031u) & ((w1 & 0xffffu) == 0x0306u) &
+                        ((w2 & 0x800080u) == 0u) & ((w2 & 0x1f00u) != 0x1f00u);  // short value length, OID ends, low value tag
+      if (fast) {
+        const uint32_t set_end = a + 2u + ((w0 >> 8) & 0xffu), atv_end = a + 4u + (w0 >> 24);
+        const uint32_t tv = (w2 >> 8) & 0xffu, cv = a + 11u, ev = cv + ((w2 >> 16) & 0xffu);
+        ok = ok & (set_end <= s_end) & (atv_end <= set_end) & (ev <= atv_end);
+        if constexpr (CN) {
+          const bool is_cn = (((w1 >> 16) | ((w2 & 0xffu) << 16)) == 0x030455u) & string_tag(tv);
+          cn_off = is_cn ? cv : cn_off;
+          cn_len = is_cn ? ev - cv : cn_len;
+        }
+        a = atv_end;
+        a_end = set_end;
+      } else {
+        rd_hdr(r, L, a, s_end, ok, t1, c1, e1);
+        ok = ok & (t1 == 0x31u);
+        a = c1;
+        a_end = e1;
+      }
+    } else {
+      uint32_t to, co, eo, tv, cv, ev;
+      rd_hdr(r, L, a, a_end, ok, t1, c1, e1);      // AttributeTypeAndValue
+      rd_hdr(r, L, c1, e1, ok, to, co, eo);        // type OID
+      const uint32_t oidw = ldc(r, co, L);
+      const uint32_t lastp = eo - 1u;
+      const uint32_t last = ldc(r, lastp, L);
+      rd_hdr(r, L, eo, e1, ok, tv, cv, ev);        // value
+      ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
+      if constexpr (CN) {
+        const bool is_cn = (eo - co == 3u) & ((oidw & 0xffffffu) == 0x030455u) & string_tag(tv);
+        cn_off = is_cn ? cv : cn_off;
+        cn_len = is_cn ? ev - cv : cn_len;
+      }
+      a = e1;
+    }
+  }
+  return ce;
+}
+
 // `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
 // windowed reader that about `need` bytes from pos are read next; r.touch_tail(pos, tail) that the
 // bytes from pos AND the bytes at `tail` are read next; other readers ignore both.
 // The filter view is passed BY VALUE (use_filter + fv): a pointer that is either &local or null makes
 // the compiler materialise the view in scratch memory — 28 bytes of HBM writes per certificate.
+//
+// The accept/reject rules are Go's encoding/asn1 struct-unmarshalling rules applied to crypto/x509's `certificate`,
+// `tbsCertificate`, `publicKeyInfo`, `pkix.AlgorithmIdentifier`, `pkix.RDNSequence`, `pkix.Extension` and
+// `basicConstraints` definitions, as far as the bytes are ones this path reads anyway (DESIGN.md §3.1 lists what is
+// left out): a field must match its tag and lie inside the enclosing contents; bytes behind the last field of a
+// SEQUENCE are ignored; an OPTIONAL field with another tag is skipped, but its header must parse; parsing resumes
+// behind the INNER element of an EXPLICIT wrapper, whatever the wrapper's own length says.
 template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv) {
   o.serial_off = o.serial_len = 0;
@@ -214,6 +390,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   o.cn_off = o.cn_len = 0;
   o.spki_off = o.spki_len = 0;
   o.bc_valid = o.is_ca = false;
+  o.nonfatal = 0u;
   o.meta_issuer = o.meta_crl = META_NONE;
   bool ok = L <= 0x7fffffffu;
   L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
@@ -227,17 +404,25 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   ok = ok & (tag == 0x30u);
   const uint32_t tbs_end = ce;
   uint32_t q = cs;
-  // version [0] EXPLICIT INTEGER
+  // Version int `asn1:"optional,explicit,default:0,tag:0"`: an empty wrapper is an error ("zero length explicit tag
+  // was not an asn1.Flag"); otherwise the inner INTEGER is parsed against the TBSCertificate and parsing resumes
+  // behind IT.
   if ((q < tbs_end) & ((ldc(r, q, L) & 0xffu) == 0xa0u)) {
     uint32_t vs, ve, t2, is_, ie;
-    rd_hdr(r, L, q, tbs_end, ok, tag, vs, ve);
-    rd_hdr(r, L, vs, ve, ok, t2, is_, ie);
-    ok = ok & (t2 == 0x02u) & (ie == ve) & (ie - is_ <= 4u) & int_ok(r, L, is_, ie - is_);
-    q = ve;
+    rd_hdr<false>(r, L, q, tbs_end, ok, tag, vs, ve);
+    rd_hdr(r, L, vs, tbs_end, ok, t2, is_, ie);
+    ok = ok & (ve != vs) & (t2 == 0x02u);
+    int32_check(r, L, is_, ie - is_, ok, o.nonfatal);
+    q = ie;
   }
   // serialNumber: raw content octets
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
-  ok = ok & (tag == 0x02u) & int_ok(r, L, cs, ce - cs);
+  ok = ok & (tag == 0x02u);
+  {
+    bool neg;
+    int_check(r, L, cs, ce - cs, ok, o.nonfatal, neg);
+    o.nonfatal = neg ? (o.nonfatal | WALK_NF_NEGATIVE_SERIAL) : o.nonfatal;
+  }
   o.serial_off = cs;
   o.serial_len = ce - cs;
   {
@@ -254,59 +439,16 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   }
   q = ce;
   // signature AlgorithmIdentifier
-  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
-  ok = ok & (tag == 0x30u);
-  q = ce;
-  // issuer Name → last string-typed CommonName.  One flattened loop: each iteration decodes
-  // either a SET (RDN) header or one AttributeTypeAndValue.
-  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
-  ok = ok & (tag == 0x30u);
-  o.meta_issuer = meta_pack(q, ce - q);
+  alg_id(r, L, q, tbs_end, ok, q);
+  // issuer Name → last string-typed CommonName
   {
-    const uint32_t s_end = ce;
-    uint32_t a = cs, a_end = cs;
-    while (ok & (a < s_end)) {
-      uint32_t t1, c1, e1;
-      r.touch(a, 32);
-      if (a == a_end) {  // next RDN
-        // Fast form: the 12 bytes at a hold SET hdr, AttributeTypeAndValue hdr, a 3-byte OID with its hdr, and the
-        // value hdr — when every length is short form (the usual 2.5.4.x attribute).  One independent 12-byte
-        // read replaces five dependent header reads; each header read is an LDS round trip on the critical path.
-        const uint32_t w0 = ldc(r, a, L), w1 = ldc(r, a + 4u, L), w2 = ldc(r, a + 8u, L);
-        const bool fast = ((w0 & 0x80ff80ffu) == 0x00300031u) & ((w1 & 0xffffu) == 0x0306u) & ((w2 & 0x800000u) == 0u);
-        if (fast) {
-          const uint32_t set_end = a + 2u + ((w0 >> 8) & 0xffu), atv_end = a + 4u + (w0 >> 24);
-          const uint32_t tv = (w2 >> 8) & 0xffu, cv = a + 11u, ev = cv + ((w2 >> 16) & 0xffu);
-          ok = ok & (set_end <= s_end) & (atv_end <= set_end) & (ev <= atv_end) & ((tv & 0x1fu) != 0x1fu);
-          const bool is_cn = (((w1 >> 16) | ((w2 & 0xffu) << 16)) == 0x030455u) & string_tag(tv);
-          o.cn_off = is_cn ? cv : o.cn_off;
-          o.cn_len = is_cn ? ev - cv : o.cn_len;
-          a = atv_end;
-          a_end = set_end;
-        } else {
-          rd_hdr(r, L, a, s_end, ok, t1, c1, e1);
-          ok = ok & (t1 == 0x31u);
-          a = c1;
-          a_end = e1;
-        }
-      } else {
-        uint32_t to, co, eo, tv, cv, ev;
-        rd_hdr(r, L, a, a_end, ok, t1, c1, e1);      // AttributeTypeAndValue
-        rd_hdr(r, L, c1, e1, ok, to, co, eo);        // type OID
-        const uint32_t oidw = ldc(r, co, L);
-        rd_hdr(r, L, eo, e1, ok, tv, cv, ev);        // value
-        ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co);
-        const bool is_cn = (eo - co == 3u) & ((oidw & 0xffffffu) == 0x030455u) & string_tag(tv);
-        o.cn_off = is_cn ? cv : o.cn_off;
-        o.cn_len = is_cn ? ev - cv : o.cn_len;
-        a = e1;
-      }
-    }
+    const uint32_t n0 = q;
+    q = walk_name<true>(r, L, q, tbs_end, ok, o.cn_off, o.cn_len);
+    o.meta_issuer = meta_pack(n0, q - n0);
     if (use_filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, fv) : false;
   }
-  q = ce;
   r.touch(q, 48);
-  // validity
+  // validity: two Times; anything behind them is ignored
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
   {
@@ -317,49 +459,76 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     rd_time(r, L, c1, t1, e1 - c1, ok, o.not_after);
   }
   q = ce;
-  // subject
-  rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
-  ok = ok & (tag == 0x30u);
-  q = ce;
-  // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo).  A long subject (OV/EV certificates) puts this
-  // header past the front window: say so, instead of leaving a window-only reader to its slow exact path.
+  // subject Name: same structure, nothing of it is consumed
+  {
+    uint32_t d0 = 0, d1 = 0;
+    q = walk_name<false>(r, L, q, tbs_end, ok, d0, d1);
+  }
+  // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo): publicKeyInfo ::= SEQUENCE { AlgorithmIdentifier,
+  // BIT STRING }; the key bits themselves are skipped by length.  A long subject (OV/EV certificates) puts this header
+  // past the front window: say so, instead of leaving a window-only reader to its slow exact path.
   // (A wave-cooperative form of this refill — the lanes in need served 16 lanes per certificate, as touch_tail does —
   //  measured no gain on the mixed corpus: 25.45 ms against 25.3 ms per 100 M, session 5.)
-  r.touch(q, 8);
+  r.touch(q, 40);
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
   o.spki_off = q;
   o.spki_len = ce - q;
+  {
+    uint32_t k, tk, ck, ek;
+    alg_id(r, L, cs, ce, ok, k);
+    rd_hdr(r, L, k, ce, ok, tk, ck, ek);
+    ok = ok & (tk == 0x03u);
+    bit_string_check(r, L, ck, ek - ck, ok);
+  }
   q = ce;
   // what follows the key (unique ids, extensions) and the tail behind the TBS are both known now:
   // a two-region reader fetches them in one burst
   r.touch_tail(q, tbs_end);
-  // [1] issuerUniqueID, [2] subjectUniqueID: skipped
-  uint32_t nt = (ok & (q < tbs_end)) ? (ldc(r, q, L) & 0xffu) : 0u;
+  // UniqueId, SubjectUniqueId asn1.BitString `optional,tag:1|2`, Extensions `optional,explicit,tag:3`: each parses the
+  // header at the current position (which must be a valid header) and skips itself when the tag is not its own;
+  // whatever is left in the TBSCertificate after the three is ignored.
+  uint32_t nt = 0u;
+  if (ok & (q < tbs_end)) {
+    rd_hdr<false>(r, L, q, tbs_end, ok, tag, cs, ce);
+    nt = ok ? tag : 0u;
+  }
   if (nt == 0x81u) {
-    rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+    ok = ok & (ce <= tbs_end);
+    bit_string_check(r, L, cs, ce - cs, ok);
     q = ce;
-    nt = (ok & (q < tbs_end)) ? (ldc(r, q, L) & 0xffu) : 0u;
+    nt = 0u;
+    if (ok & (q < tbs_end)) {
+      rd_hdr<false>(r, L, q, tbs_end, ok, tag, cs, ce);
+      nt = ok ? tag : 0u;
+    }
   }
   if (nt == 0x82u) {
-    rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+    ok = ok & (ce <= tbs_end);
+    bit_string_check(r, L, cs, ce - cs, ok);
     q = ce;
-    nt = (ok & (q < tbs_end)) ? (ldc(r, q, L) & 0xffu) : 0u;
+    nt = 0u;
+    if (ok & (q < tbs_end)) {
+      rd_hdr<false>(r, L, q, tbs_end, ok, tag, cs, ce);
+      nt = ok ? tag : 0u;
+    }
   }
-  // [3] EXPLICIT Extensions
-  if (nt == 0xa3u) {
+  // [3] matches when constructed or empty, and empty is an error
+  if ((nt == 0xa3u) | (nt == 0x83u)) ok = ok & (ce != cs);
+  if (ok & (nt == 0xa3u)) {
     uint32_t e, e_end;
     r.touch(q, 48);
-    rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
-    rd_hdr(r, L, cs, ce, ok, tag, e, e_end);
-    ok = ok & (tag == 0x30u);
+    rd_hdr<false>(r, L, cs, tbs_end, ok, tag, e, e_end);
+    // an inner element that is not a SEQUENCE leaves the optional field unset: no extensions at all
+    ok = ok & ((tag != 0x30u) | (e_end <= tbs_end));
+    e_end = tag == 0x30u ? e_end : e;
     while (ok & (e < e_end)) {
       uint32_t t1, x, x_end, to, co, eo, tv, cv, ev, oidw;
       r.touch(e, 48);
       // Fast form: Extension hdr, a 3-byte extnID with its hdr, optional critical BOOLEAN and the extnValue hdr
       // lie in the 12 bytes at e when every length is short form (every 2.5.29.x extension under 128 bytes).
       const uint32_t w0 = ldc(r, e, L), w1 = ldc(r, e + 4u, L), w2 = ldc(r, e + 8u, L);
-      const bool p0 = (w0 & 0xffff80ffu) == 0x03060030u;
+      const bool p0 = ((w0 & 0xffff80ffu) == 0x03060030u) & ((w1 & 0x800000u) == 0u);
       const uint32_t b7 = w1 >> 24, b9 = (w2 >> 8) & 0xffu;
       const bool nc = p0 & (b7 == 0x04u) & ((w2 & 0x80u) == 0u);
       const bool cr = p0 & (b7 == 0x01u) & ((w2 & 0x80ff00ffu) == 0x00040001u) & ((b9 == 0x00u) | (b9 == 0xffu));
@@ -375,8 +544,10 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         rd_hdr(r, L, e, e_end, ok, t1, x, x_end);   // Extension
         rd_hdr(r, L, x, x_end, ok, to, co, eo);     // extnID
         oidw = ldc(r, co, L);
+        const uint32_t lastp = eo - 1u;
+        const uint32_t last = ldc(r, lastp, L);
         rd_hdr(r, L, eo, x_end, ok, tv, cv, ev);    // critical or extnValue
-        ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co);
+        ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
         if (tv == 0x01u) {  // critical BOOLEAN
           const uint32_t bv = ldc(r, cv, L) & 0xffu;
           ok = ok & (ev - cv == 1u) & ((bv == 0x00u) | (bv == 0xffu));
@@ -390,21 +561,27 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         o.meta_crl = is_crl ? pk : o.meta_crl;
       }
       if (ok & (eo - co == 3u) & ((oidw & 0xffffffu) == 0x131d55u)) {
-        // basicConstraints ::= SEQUENCE { cA BOOLEAN DEFAULT FALSE, pathLen INTEGER OPTIONAL }
-        uint32_t tb, c, c_end, tf, cf, ef;
+        // basicConstraints struct { IsCA bool `optional`; MaxPathLen int `optional,default:-1` } must be the whole
+        // OCTET STRING ("x509: trailing data after X.509 BasicConstraints"); inside the SEQUENCE an element of
+        // another type leaves the optional field at its default and whatever follows is ignored
+        uint32_t tb, c, c_end, tf = 0u, cf = 0u, ef = 0u;
         rd_hdr(r, L, cv, ev, ok, tb, c, c_end);
         ok = ok & (tb == 0x30u) & (c_end == ev);
         bool ca = false;
         if (ok & (c < c_end)) {
-          rd_hdr(r, L, c, c_end, ok, tf, cf, ef);
+          rd_hdr<false>(r, L, c, c_end, ok, tf, cf, ef);
           if (tf == 0x01u) {
             const uint32_t bv = ldc(r, cf, L) & 0xffu;
-            ok = ok & (ef - cf == 1u) & ((bv == 0x00u) | (bv == 0xffu));
+            ok = ok & (ef <= c_end) & (ef - cf == 1u) & ((bv == 0x00u) | (bv == 0xffu));
             ca = bv == 0xffu;
             c = ef;
-            if (ok & (c < c_end)) rd_hdr(r, L, c, c_end, ok, tf, cf, ef);
+            tf = 0u;
+            if (ok & (c < c_end)) rd_hdr<false>(r, L, c, c_end, ok, tf, cf, ef);
           }
-          if (ok & (c < c_end)) ok = ok & (tf == 0x02u) & int_ok(r, L, cf, ef - cf);
+          if (ok & (c < c_end) & (tf == 0x02u)) {  // pathLenConstraint
+            ok = ok & (ef <= c_end);
+            int32_check(r, L, cf, ef - cf, ok, o.nonfatal);
+          }
         }
         o.bc_valid = true;
         o.is_ca = ca;
@@ -412,21 +589,13 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
       e = x_end;
     }
   }
-  // signatureAlgorithm, signatureValue BIT STRING (Go asn1 parseBitString)
+  // signatureAlgorithm, signatureValue BIT STRING (Go asn1 parseBitString); bytes behind them are ignored
   const TailView<R> tv{r};
-  rd_hdr(tv, L, tbs_end, L, ok, tag, cs, ce);
-  ok = ok & (tag == 0x30u);
-  rd_hdr(tv, L, ce, L, ok, tag, cs, ce);
-  ok = ok & (tag == 0x03u) & (ce != cs);
-  {
-    const uint32_t pad = ldc(tv, cs, L) & 0xffu;
-    ok = ok & (pad <= 7u) & ((ce - cs != 1u) | (pad == 0u));
-    if (ok & (pad != 0u)) {  // padding bits must be zero: only then is the last octet needed
-      const uint32_t lastp = ce - 1u;
-      const uint32_t last = ldc(tv, lastp, L) & 0xffu;
-      ok = (last & ((1u << (pad & 7u)) - 1u)) == 0u;
-    }
-  }
+  uint32_t sq;
+  alg_id(tv, L, tbs_end, L, ok, sq);
+  rd_hdr(tv, L, sq, L, ok, tag, cs, ce);
+  ok = ok & (tag == 0x03u);
+  bit_string_check(tv, L, cs, ce - cs, ok);
   return ok;
 }
 

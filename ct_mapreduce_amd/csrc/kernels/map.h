@@ -47,9 +47,13 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
   const FilterDev* f = a.filt;
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
-  const bool ok = walk_cert(r, L, w, f->active != 0u, fv);  // L > 2^31-1 is rejected inside, without divergence
+  bool ok = walk_cert(r, L, w, f->active != 0u, fv);  // L > 2^31-1 is rejected inside, without divergence
   const uint32_t iss = a.issuer_idx[idx];
   const uint32_t et = a.entry_type ? a.entry_type[idx] : 0u;
+  // An X509 entry's certificate was parsed by ct.LogEntryFromLeaf, which keeps it unless the error is fatal
+  // (ct-fetch.go:452-459); a precertificate is parsed in insertCTWorker and dropped on ANY error, CT-go's
+  // x509.NonFatalErrors included (:202-209).  Fields of a dropped certificate are not reported.
+  ok = ok & !((et == 1u) & (w.nonfatal != 0u));
   uint32_t status;
   if (et == CTMR_ENTRY_INVALID) {
     status = CTMR_ST_ENTRY_DECODE_ERROR;  // never reached entryChan (ct-fetch.go:452-459)

@@ -103,7 +103,8 @@ __device__ __forceinline__ void mark_dup(uint32_t* ent, ctmr_record* records, ui
   *fl = (uint8_t)(*fl & ~CTMR_FL_WAS_UNKNOWN);
 }
 
-// Offset of the serialNumber content octets (certificate already accepted by the map).
+// Offset of the serialNumber content octets (certificate already accepted by the map): behind the INNER element of
+// the optional [0] version wrapper, as walk_cert resumes there.
 __device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, uint32_t L) {
   bool ok = true;
   uint32_t tag, cs, ce;
@@ -111,7 +112,8 @@ __device__ __forceinline__ uint32_t serial_content_off(const GlobalReader& r, ui
   rd_hdr(r, L, cs, L, ok, tag, cs, ce);
   uint32_t q = cs;
   if ((r.ld4(q) & 0xffu) == 0xa0u) {
-    rd_hdr(r, L, q, L, ok, tag, cs, ce);
+    rd_hdr<false>(r, L, q, L, ok, tag, cs, ce);
+    rd_hdr(r, L, cs, L, ok, tag, cs, ce);
     q = ce;
   }
   rd_hdr(r, L, q, L, ok, tag, cs, ce);

@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(64) k_issuer_ids(const uint8_t* der, const uin
   GlobalReader r{(const uint32_t*)der, offsets[i]};
   const uint32_t L = (uint32_t)(offsets[i + 1] - offsets[i]);
   Walk w;
-  const bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w);
+  // any err of x509.ParseCertificate(Chain[0]) skips the entry, non-fatal findings included (ct-fetch.go:221-225)
+  const bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w) && w.nonfatal == 0u;
   valid[i] = ok ? 1 : 0;
   uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (ok) sha256_lane(r, w.spki_off, w.spki_len, kc, dg);

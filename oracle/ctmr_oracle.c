@@ -15,39 +15,81 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* ------------------------------------------------------------------ DER walk */
+/* ------------------------------------------------------------------ DER walk
+ *
+ * What "x509.ParseCertificate succeeded" means here.  The parser itself is third-party
+ * (certificate-transparency-go v1.1.0, a fork of Go's crypto/x509 + encoding/asn1; absent from this machine), so this
+ * restates Go's encoding/asn1 *struct-unmarshalling rules* applied to the x509 `certificate` / `tbsCertificate` /
+ * `pkix.*` struct definitions, for every element whose bytes the path reads anyway:
+ *   - parseTagAndLength: definite minimal lengths < 2^31, high-tag-number form allowed (minimal, < 2^31);
+ *   - a struct field must match its universal tag, lie inside the enclosing contents ("data truncated"), and
+ *     *bytes left over at the end of a SEQUENCE are ignored* ("adding elements to the end has been used in X.509");
+ *   - an OPTIONAL field whose tag does not match is skipped — but its header must still be a valid header;
+ *   - an EXPLICIT wrapper's own length is never checked against its inner element: parsing resumes right behind
+ *     the INNER element ([0] version, [3] extensions);
+ *   - UTCTime / GeneralizedTime go through time.Parse("0601021504Z0700" | "060102150405Z0700" |
+ *     "20060102150405Z0700") and must serialise back to the same string: 'Z' or a NON-ZERO numeric offset ±hhmm with
+ *     mm <= 59 (hh is not range-checked by the Go 1.13 toolchain the reference pins; go.mod:24);
+ *   - INTEGERs must be non-empty and minimal (checkInteger); int fields must fit int32.
+ * CT-go returns some findings as x509.NonFatalErrors instead of failing: the certificate is still handed out.  The
+ * reference keeps such a certificate when it arrives as an X509 entry (ct.LogEntryFromLeaf only drops the entry on
+ * x509.IsFatal errors, cmd/ct-fetch/ct-fetch.go:452-459) and drops it when it is a precertificate or a Chain[0]
+ * issuer (any err, :202-209, :221-225).  The findings modelled as non-fatal — recalled, not verifiable here — are in
+ * ORC_NF_*: a negative serialNumber, and INTEGERs that only the "lax" re-parse accepts (not minimally encoded).
+ * NOT checked (needs bytes the path never reads, or CT-go's source): the public key itself, extension bodies other
+ * than basicConstraints, string character sets, attribute values of non-string types, OID arcs >= 2^31.
+ */
 
 typedef struct {
-  uint8_t tag;
+  uint8_t tag;  /* identifier octet (class | constructed | number; number == 0x1f: high-tag-number form) */
   uint32_t hl;  /* header length */
   uint32_t len; /* content length */
 } tlv;
 
-/* One TLV header at p, which must lie wholly (header + content) inside [p, end).
- * Length rules as Go encoding/asn1 parseTagAndLength: no high-tag-number form on this
- * path, no indefinite length, long form without leading zero byte, minimal, < 2^31. */
-static int rd_tlv(const uint8_t* d, uint64_t p, uint64_t end, tlv* t) {
-  if (p + 2 > end) return 0;
-  t->tag = d[p];
-  if ((t->tag & 0x1f) == 0x1f) return 0;
-  uint8_t b = d[p + 1];
+/* Go encoding/asn1 parseTagAndLength at p, reading no byte at or past `end`: the header only. */
+static int rd_hdr(const uint8_t* d, uint64_t p, uint64_t end, tlv* t) {
+  if (p >= end) return 0;
+  uint64_t o = p;
+  t->tag = d[o++];
+  if ((t->tag & 0x1f) == 0x1f) { /* parseBase128Int: <= 5 octets, minimal, value in [0x1f, 2^31) */
+    uint64_t v = 0;
+    int k = 0;
+    for (;;) {
+      if (o >= end) return 0;      /* truncated base 128 integer */
+      if (k == 5) return 0;        /* base 128 integer too large */
+      uint8_t b = d[o++];
+      if (k == 0 && b == 0x80) return 0; /* integer is not minimally encoded */
+      v = (v << 7) | (b & 0x7f);
+      k++;
+      if (!(b & 0x80)) break;
+    }
+    if (v > 0x7fffffffu) return 0;
+    if (v < 0x1f) return 0;        /* non-minimal tag */
+  }
+  if (o >= end) return 0;          /* truncated tag or length */
+  uint8_t b = d[o++];
   if (b < 0x80) {
-    t->hl = 2;
     t->len = b;
   } else {
     uint32_t n = b & 0x7f;
-    if (n == 0 || n > 4) return 0;
-    if (p + 2 + n > end) return 0;
-    if (d[p + 2] == 0) return 0; /* superfluous leading zeros */
+    if (n == 0 || n > 4) return 0; /* indefinite length; length too large */
+    if (o + n > end) return 0;
+    if (d[o] == 0) return 0;       /* superfluous leading zeros in length */
     uint64_t v = 0;
-    for (uint32_t i = 0; i < n; i++) v = (v << 8) | d[p + 2 + i];
-    if (v < 0x80) return 0;       /* non-minimal */
+    for (uint32_t i = 0; i < n; i++) v = (v << 8) | d[o + i];
+    o += n;
+    if (v < 0x80) return 0;        /* non-minimal length */
     if (v > 0x7fffffffu) return 0; /* length too large */
-    t->hl = 2 + n;
     t->len = (uint32_t)v;
   }
-  if (p + t->hl + (uint64_t)t->len > end) return 0;
+  t->hl = (uint32_t)(o - p);
   return 1;
+}
+
+/* header + contents inside [p, end) (Go: invalidLength → "data truncated") */
+static int rd_tlv(const uint8_t* d, uint64_t p, uint64_t end, tlv* t) {
+  if (!rd_hdr(d, p, end, t)) return 0;
+  return p + t->hl + (uint64_t)t->len <= end;
 }
 
 static int is_digit(uint8_t c) { return c >= '0' && c <= '9'; }
@@ -72,31 +114,55 @@ static int days_in_month(int64_t y, int m) {
   return dm[m - 1];
 }
 
-/* UTCTime (tag 0x17) "YYMMDDHHMMZ" / "YYMMDDHHMMSSZ", GeneralizedTime (0x18)
- * "YYYYMMDDHHMMSSZ". Go asn1 parseUTCTime/parseGeneralizedTime; only the 'Z' zone forms
- * are in the profile (numeric offsets → parse error; documented divergence). */
+/* The "Z0700" element of the three layouts: 'Z', or sign hh mm.  Accepted iff the parsed time serialises back to
+ * the input (asn1.parseUTCTime / parseGeneralizedTime): digits only, mm <= 59 (60 would print as the next hour),
+ * and not ±0000 (offset 0 prints as "Z").  hh: any two digits — time.Parse of Go 1.13 does not range-check it and
+ * Format prints offset/60/60 with two digits.  *off = seconds east of UTC. */
+static int parse_zone(const uint8_t* s, uint32_t n, int64_t* off) {
+  if (n == 1 && s[0] == 'Z') {
+    *off = 0;
+    return 1;
+  }
+  if (n != 5 || (s[0] != '+' && s[0] != '-')) return 0;
+  for (int i = 1; i < 5; i++)
+    if (!is_digit(s[i])) return 0;
+  int hh = two(s + 1), mm = two(s + 3);
+  if (mm > 59 || (hh == 0 && mm == 0)) return 0;
+  *off = (int64_t)(hh * 3600 + mm * 60) * (s[0] == '-' ? -1 : 1);
+  return 1;
+}
+
+/* UTCTime (tag 0x17) "YYMMDDHHMM[SS]" + zone, GeneralizedTime (0x18) "YYYYMMDDHHMMSS" + zone.
+ * UTCTime years: time.Parse maps yy >= 69 to 19yy, else 20yy; parseUTCTime then subtracts a century when the year
+ * (in the time's own zone) is >= 2050 — together: yy < 50 → 20yy, else 19yy. */
 static int parse_time(const uint8_t* d, const tlv* t, uint64_t content, int64_t* out) {
   const uint8_t* s = d + content;
-  int64_t year;
+  int64_t year, off = 0;
   int mon, day, hh, mm, ss = 0;
   uint32_t n = t->len;
   if (t->tag == 0x17) {
-    if (n != 11 && n != 13) return 0;
-    for (uint32_t i = 0; i + 1 < n; i++)
+    /* 10 digits, then either the zone (layout without seconds, tried first) or 2 more digits and the zone */
+    if (n < 11) return 0;
+    for (uint32_t i = 0; i < 10; i++)
       if (!is_digit(s[i])) return 0;
-    if (s[n - 1] != 'Z') return 0;
+    uint32_t z = 10;
+    if (is_digit(s[10])) {
+      if (n < 13 || !is_digit(s[11])) return 0;
+      ss = two(s + 10);
+      z = 12;
+    }
+    if (!parse_zone(s + z, n - z, &off)) return 0;
     int yy = two(s);
     year = yy < 50 ? 2000 + yy : 1900 + yy;
     mon = two(s + 2);
     day = two(s + 4);
     hh = two(s + 6);
     mm = two(s + 8);
-    if (n == 13) ss = two(s + 10);
   } else if (t->tag == 0x18) {
-    if (n != 15) return 0;
+    if (n < 15) return 0;
     for (uint32_t i = 0; i < 14; i++)
       if (!is_digit(s[i])) return 0;
-    if (s[14] != 'Z') return 0;
+    if (!parse_zone(s + 14, n - 14, &off)) return 0;
     year = two(s) * 100 + two(s + 2);
     mon = two(s + 4);
     day = two(s + 6);
@@ -109,16 +175,43 @@ static int parse_time(const uint8_t* d, const tlv* t, uint64_t content, int64_t*
   if (mon < 1 || mon > 12) return 0;
   if (day < 1 || day > days_in_month(year, mon)) return 0;
   if (hh > 23 || mm > 59 || ss > 59) return 0;
-  *out = days_from_civil(year, mon, day) * 86400 + hh * 3600 + mm * 60 + ss;
+  *out = days_from_civil(year, mon, day) * 86400 + hh * 3600 + mm * 60 + ss - off;
   return 1;
 }
 
-/* Go asn1 checkInteger: non-empty, minimally encoded. */
+/* Go asn1 checkInteger: non-empty, minimally encoded.  Returns 1 = ok, 0 = empty (an error even for the lax
+ * re-parse), -1 = not minimal (strict parse fails, CT-go's lax re-parse accepts: a non-fatal finding). */
 static int check_integer(const uint8_t* d, uint64_t content, uint32_t len) {
   if (len == 0) return 0;
   if (len == 1) return 1;
-  if (d[content] == 0x00 && (d[content + 1] & 0x80) == 0) return 0;
-  if (d[content] == 0xff && (d[content + 1] & 0x80) == 0x80) return 0;
+  if (d[content] == 0x00 && (d[content + 1] & 0x80) == 0) return -1;
+  if (d[content] == 0xff && (d[content + 1] & 0x80) == 0x80) return -1;
+  return 1;
+}
+
+/* An `int` field (Version, MaxPathLen): parseInt32 = checkInteger, at most 8 octets, value fits int32.
+ * Same three-way result. */
+static int check_int32(const uint8_t* d, uint64_t content, uint32_t len) {
+  int c = check_integer(d, content, len);
+  if (c == 0) return 0;
+  if (len > 8) return 0;
+  int64_t v = (d[content] & 0x80) ? -1 : 0;
+  for (uint32_t i = 0; i < len; i++) v = (int64_t)(((uint64_t)v << 8) | d[content + i]);
+  if (v != (int64_t)(int32_t)v) return 0;
+  return c;
+}
+
+/* parseObjectIdentifier, as far as it is modelled: non-empty and the last octet ends an arc. */
+static int oid_ok(const uint8_t* d, uint64_t content, uint32_t len) {
+  return len != 0 && (d[content + len - 1] & 0x80) == 0;
+}
+
+/* parseBitString on contents [c, c+len) */
+static int bit_string_ok(const uint8_t* d, uint64_t c, uint32_t len) {
+  if (len == 0) return 0;
+  uint8_t pad = d[c];
+  if (pad > 7 || (len == 1 && pad > 0)) return 0;
+  if (pad > 0 && (d[c + len - 1] & ((1u << pad) - 1)) != 0) return 0;
   return 1;
 }
 
@@ -134,10 +227,56 @@ static int is_string_tag(uint8_t tag) {
     out->err_site = (site); \
     return;                 \
   } while (0)
+#define FAIL0(site)         \
+  do {                      \
+    *site_out = (site);     \
+    return 0;               \
+  } while (0)
+
+/* pkix.AlgorithmIdentifier ::= SEQUENCE { algorithm OBJECT IDENTIFIER, parameters ANY OPTIONAL } at p */
+static int alg_id(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, int* site_out, int site) {
+  if (!rd_tlv(d, p, end, t) || t->tag != 0x30) FAIL0(site);
+  uint64_t a = p + t->hl, a_end = a + t->len;
+  tlv o;
+  if (!rd_tlv(d, a, a_end, &o) || o.tag != 0x06 || !oid_ok(d, a + o.hl, o.len)) FAIL0(site + 1);
+  a += o.hl + o.len;
+  if (a < a_end && !rd_tlv(d, a, a_end, &o)) FAIL0(site + 2); /* parameters asn1.RawValue `optional` */
+  return 1;
+}
+
+/* pkix.RDNSequence at p: SEQUENCE OF SET OF SEQUENCE { type OID, value ANY }.  cn: the last AttributeTypeAndValue
+ * with OID 2.5.4.3 whose value is a string type (pkix.Name.FillFromRDNSequence), or NULL. */
+static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint32_t* cn_off, uint32_t* cn_len,
+                        int* site_out, int site) {
+  if (!rd_tlv(d, p, end, t) || t->tag != 0x30) FAIL0(site);
+  uint64_t r = p + t->hl, r_end = r + t->len;
+  while (r < r_end) {
+    tlv set;
+    if (!rd_tlv(d, r, r_end, &set) || set.tag != 0x31) FAIL0(site + 1);
+    uint64_t a = r + set.hl, a_end = a + set.len;
+    while (a < a_end) {
+      tlv atv, oid, val;
+      if (!rd_tlv(d, a, a_end, &atv) || atv.tag != 0x30) FAIL0(site + 2);
+      uint64_t b = a + atv.hl, b_end = b + atv.len;
+      if (!rd_tlv(d, b, b_end, &oid) || oid.tag != 0x06 || !oid_ok(d, b + oid.hl, oid.len)) FAIL0(site + 3);
+      uint64_t vpos = b + oid.hl + oid.len;
+      if (!rd_tlv(d, vpos, b_end, &val)) FAIL0(site + 4);  /* ANY: must be there and fit; anything behind it is ignored */
+      if (cn_off && oid.len == 3 && d[b + oid.hl] == 0x55 && d[b + oid.hl + 1] == 0x04 &&
+          d[b + oid.hl + 2] == 0x03 && is_string_tag(val.tag)) {
+        *cn_off = (uint32_t)(vpos + val.hl);
+        *cn_len = val.len;
+      }
+      a += atv.hl + atv.len;
+    }
+    r += set.hl + set.len;
+  }
+  return 1;
+}
 
 void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
   memset(out, 0, sizeof(*out));
   tlv t;
+  int site = 0;
   if (L > 0x7fffffffu) FAIL(1);
   /* Certificate ::= SEQUENCE, no trailing data (x509.ParseCertificate) */
   if (!rd_tlv(d, 0, L, &t) || t.tag != 0x30) FAIL(2);
@@ -150,51 +289,35 @@ void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
   out->tbs_len = t.hl + t.len;
   uint64_t tbs_end = p + t.hl + t.len;
   uint64_t q = p + t.hl;
-  /* version [0] EXPLICIT INTEGER DEFAULT v1 */
+  /* Version int `asn1:"optional,explicit,default:0,tag:0"`.  Go resumes behind the INNER integer; the wrapper's
+   * length is only used to tell "empty" (an error: not an asn1.Flag) from "has an element". */
   if (q < tbs_end && d[q] == 0xa0) {
-    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(5);
+    if (!rd_hdr(d, q, tbs_end, &t)) FAIL(5);
+    if (t.len == 0) FAIL(5);
     tlv v;
     uint64_t vq = q + t.hl;
-    if (!rd_tlv(d, vq, vq + t.len, &v) || v.tag != 0x02) FAIL(6);
-    if ((uint64_t)v.hl + v.len != t.len) FAIL(7);
-    if (v.len > 4 || !check_integer(d, vq + v.hl, v.len)) FAIL(8);
-    q += t.hl + t.len;
+    if (!rd_tlv(d, vq, tbs_end, &v) || v.tag != 0x02) FAIL(6);
+    int ci = check_int32(d, vq + v.hl, v.len);
+    if (ci == 0) FAIL(8);
+    if (ci < 0) out->nonfatal |= ORC_NF_LAX_INTEGER;
+    q = vq + v.hl + v.len;
   }
   /* serialNumber INTEGER: raw content octets kept verbatim (types.go:165-178) */
   if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x02) FAIL(9);
-  if (!check_integer(d, q + t.hl, t.len)) FAIL(10);
+  {
+    int ci = check_integer(d, q + t.hl, t.len);
+    if (ci == 0) FAIL(10);
+    if (ci < 0) out->nonfatal |= ORC_NF_LAX_INTEGER;
+    if (d[q + t.hl] & 0x80) out->nonfatal |= ORC_NF_NEGATIVE_SERIAL; /* CT-go: "x509: negative serial number", non-fatal */
+  }
   out->serial_off = (uint32_t)(q + t.hl);
   out->serial_len = t.len;
   q += t.hl + t.len;
-  /* signature AlgorithmIdentifier: skipped */
-  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(11);
+  /* signature AlgorithmIdentifier */
+  if (!alg_id(d, q, tbs_end, &t, &site, 11)) FAIL(site);
   q += t.hl + t.len;
-  /* issuer Name: RDNSequence; CommonName = last AttributeTypeAndValue with OID 2.5.4.3 whose
-   * value is a string type (pkix.Name.FillFromRDNSequence) */
-  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(12);
-  {
-    uint64_t r = q + t.hl, r_end = q + t.hl + t.len;
-    while (r < r_end) {
-      tlv set;
-      if (!rd_tlv(d, r, r_end, &set) || set.tag != 0x31) FAIL(13);
-      uint64_t a = r + set.hl, a_end = r + set.hl + set.len;
-      while (a < a_end) {
-        tlv atv, oid, val;
-        if (!rd_tlv(d, a, a_end, &atv) || atv.tag != 0x30) FAIL(14);
-        uint64_t b = a + atv.hl, b_end = a + atv.hl + atv.len;
-        if (!rd_tlv(d, b, b_end, &oid) || oid.tag != 0x06 || oid.len == 0) FAIL(15);
-        uint64_t vpos = b + oid.hl + oid.len;
-        if (!rd_tlv(d, vpos, b_end, &val)) FAIL(16);
-        if (oid.len == 3 && d[b + oid.hl] == 0x55 && d[b + oid.hl + 1] == 0x04 &&
-            d[b + oid.hl + 2] == 0x03 && is_string_tag(val.tag)) {
-          out->cn_off = (uint32_t)(vpos + val.hl);
-          out->cn_len = val.len;
-        }
-        a += atv.hl + atv.len;
-      }
-      r += set.hl + set.len;
-    }
-  }
+  /* issuer Name (asn1.RawValue, then asn1.Unmarshal into pkix.RDNSequence) */
+  if (!rdn_sequence(d, q, tbs_end, &t, &out->cn_off, &out->cn_len, &site, 50)) FAIL(site);
   q += t.hl + t.len;
   /* validity SEQUENCE { notBefore Time, notAfter Time } */
   if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(17);
@@ -208,90 +331,112 @@ void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
     if (!parse_time(d, &tm, v + tm.hl, &out->not_after)) FAIL(21);
   }
   q += t.hl + t.len;
-  /* subject Name: skipped */
-  if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(22);
+  /* subject Name: same structure; no field of it is consumed */
+  if (!rdn_sequence(d, q, tbs_end, &t, NULL, NULL, &site, 60)) FAIL(site);
   q += t.hl + t.len;
-  /* subjectPublicKeyInfo: full TLV = RawSubjectPublicKeyInfo (types.go:109-115) */
+  /* subjectPublicKeyInfo: full TLV = RawSubjectPublicKeyInfo (types.go:109-115);
+   * publicKeyInfo ::= SEQUENCE { algorithm AlgorithmIdentifier, publicKey BIT STRING } */
   if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(23);
   out->spki_off = (uint32_t)q;
   out->spki_len = t.hl + t.len;
+  {
+    uint64_t k = q + t.hl, k_end = k + t.len;
+    tlv a;
+    if (!alg_id(d, k, k_end, &a, &site, 70)) FAIL(site);
+    k += a.hl + a.len;
+    if (!rd_tlv(d, k, k_end, &a) || a.tag != 0x03 || !bit_string_ok(d, k + a.hl, a.len)) FAIL(73);
+  }
   q += t.hl + t.len;
-  /* issuerUniqueID [1], subjectUniqueID [2] IMPLICIT BIT STRING OPTIONAL: skipped */
-  if (q < tbs_end && d[q] == 0x81) {
-    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(24);
-    q += t.hl + t.len;
-  }
-  if (q < tbs_end && d[q] == 0x82) {
-    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(25);
-    q += t.hl + t.len;
-  }
-  /* extensions [3] EXPLICIT SEQUENCE OF Extension */
-  if (q < tbs_end && d[q] == 0xa3) {
-    if (!rd_tlv(d, q, tbs_end, &t)) FAIL(26);
-    tlv seq;
-    uint64_t e0 = q + t.hl;
-    if (!rd_tlv(d, e0, e0 + t.len, &seq) || seq.tag != 0x30) FAIL(27);
-    uint64_t e = e0 + seq.hl, e_end = e0 + seq.hl + seq.len;
-    while (e < e_end) {
-      tlv ext, oid, val;
-      if (!rd_tlv(d, e, e_end, &ext) || ext.tag != 0x30) FAIL(28);
-      uint64_t x = e + ext.hl, x_end = e + ext.hl + ext.len;
-      if (!rd_tlv(d, x, x_end, &oid) || oid.tag != 0x06 || oid.len == 0) FAIL(29);
-      uint64_t oid_c = x + oid.hl;
-      x += oid.hl + oid.len;
-      if (!rd_tlv(d, x, x_end, &val)) FAIL(30);
-      if (val.tag == 0x01) { /* critical BOOLEAN DEFAULT FALSE */
-        if (val.len != 1) FAIL(31);
-        uint8_t bv = d[x + val.hl];
-        if (bv != 0x00 && bv != 0xff) FAIL(32);
-        x += val.hl + val.len;
-        if (!rd_tlv(d, x, x_end, &val)) FAIL(33);
-      }
-      if (val.tag != 0x04) FAIL(34);
-      if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x13) {
-        /* basicConstraints ::= SEQUENCE { cA BOOLEAN DEFAULT FALSE, pathLen INTEGER OPTIONAL };
-         * must fill the OCTET STRING (x509: trailing data after X.509 BasicConstraints) */
-        tlv bc;
-        uint64_t o = x + val.hl, o_end = x + val.hl + val.len;
-        if (!rd_tlv(d, o, o_end, &bc) || bc.tag != 0x30) FAIL(35);
-        if ((uint64_t)bc.hl + bc.len != val.len) FAIL(36);
-        uint64_t c = o + bc.hl, c_end = o + bc.hl + bc.len;
-        int ca = 0;
-        if (c < c_end) {
-          tlv f;
-          if (!rd_tlv(d, c, c_end, &f)) FAIL(37);
-          if (f.tag == 0x01) {
-            if (f.len != 1) FAIL(38);
-            uint8_t bv = d[c + f.hl];
-            if (bv != 0x00 && bv != 0xff) FAIL(39);
-            ca = bv == 0xff;
-            c += f.hl + f.len;
-            if (c < c_end) {
-              if (!rd_tlv(d, c, c_end, &f)) FAIL(40);
-            }
-          }
-          if (c < c_end) { /* pathLenConstraint */
-            if (f.tag != 0x02 || !check_integer(d, c + f.hl, f.len)) FAIL(41);
-          }
-        }
-        out->bc_valid = 1;
-        out->is_ca = ca; /* a repeated extension overwrites (last wins) */
-      }
-      e += ext.hl + ext.len;
+  /* UniqueId, SubjectUniqueId asn1.BitString `optional,tag:1|2`; Extensions `optional,explicit,tag:3`.  Each
+   * optional field parses the header at the current position (which must therefore be a valid header) and skips
+   * itself when the tag is not its own; whatever is left in the TBSCertificate after the three is ignored. */
+  if (q < tbs_end) {
+    if (!rd_hdr(d, q, tbs_end, &t)) FAIL(24);
+    if (t.tag == 0x81) {
+      if (q + t.hl + (uint64_t)t.len > tbs_end || !bit_string_ok(d, q + t.hl, t.len)) FAIL(24);
+      q += t.hl + t.len;
     }
   }
-  /* signatureAlgorithm, signatureValue BIT STRING */
-  p = tbs_end;
-  if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x30) FAIL(42);
-  p += t.hl + t.len;
-  if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x03) FAIL(43);
-  {
-    /* Go asn1 parseBitString */
-    if (t.len == 0) FAIL(44);
-    uint8_t pad = d[p + t.hl];
-    if (pad > 7 || (t.len == 1 && pad > 0)) FAIL(45);
-    if (pad > 0 && (d[p + t.hl + t.len - 1] & ((1u << pad) - 1)) != 0) FAIL(46);
+  if (q < tbs_end) {
+    if (!rd_hdr(d, q, tbs_end, &t)) FAIL(25);
+    if (t.tag == 0x82) {
+      if (q + t.hl + (uint64_t)t.len > tbs_end || !bit_string_ok(d, q + t.hl, t.len)) FAIL(25);
+      q += t.hl + t.len;
+    }
   }
+  if (q < tbs_end) {
+    if (!rd_hdr(d, q, tbs_end, &t)) FAIL(26);
+    /* [3] matches when constructed or empty; empty is an error ("zero length explicit tag was not an asn1.Flag") */
+    if ((t.tag == 0xa3 || t.tag == 0x83) && t.len == 0) FAIL(26);
+  }
+  if (q < tbs_end && t.tag == 0xa3) {
+    tlv seq;
+    uint64_t e0 = q + t.hl;
+    if (!rd_hdr(d, e0, tbs_end, &seq)) FAIL(27);
+    /* an inner element that is not a SEQUENCE leaves the optional field unset: no extensions at all */
+    if (seq.tag == 0x30) {
+      if (e0 + seq.hl + (uint64_t)seq.len > tbs_end) FAIL(27);
+      uint64_t e = e0 + seq.hl, e_end = e0 + seq.hl + seq.len;
+      while (e < e_end) {
+        tlv ext, oid, val;
+        if (!rd_tlv(d, e, e_end, &ext) || ext.tag != 0x30) FAIL(28);
+        uint64_t x = e + ext.hl, x_end = e + ext.hl + ext.len;
+        if (!rd_tlv(d, x, x_end, &oid) || oid.tag != 0x06 || !oid_ok(d, x + oid.hl, oid.len)) FAIL(29);
+        uint64_t oid_c = x + oid.hl;
+        x += oid.hl + oid.len;
+        if (!rd_hdr(d, x, x_end, &val)) FAIL(30);
+        if (val.tag == 0x01) { /* critical BOOLEAN DEFAULT FALSE */
+          if (x + val.hl + (uint64_t)val.len > x_end) FAIL(30);
+          if (val.len != 1) FAIL(31);
+          uint8_t bv = d[x + val.hl];
+          if (bv != 0x00 && bv != 0xff) FAIL(32);
+          x += val.hl + val.len;
+          if (!rd_hdr(d, x, x_end, &val)) FAIL(33);
+        }
+        if (val.tag != 0x04) FAIL(34);
+        if (x + val.hl + (uint64_t)val.len > x_end) FAIL(34);
+        if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x13) {
+          /* basicConstraints struct { IsCA bool `optional`; MaxPathLen int `optional,default:-1` } must be the
+           * whole OCTET STRING ("x509: trailing data after X.509 BasicConstraints"); inside the SEQUENCE an
+           * element of another type leaves the optional field at its default, and trailing elements are ignored */
+          tlv bc;
+          uint64_t o = x + val.hl, o_end = x + val.hl + val.len;
+          if (!rd_tlv(d, o, o_end, &bc) || bc.tag != 0x30) FAIL(35);
+          if ((uint64_t)bc.hl + bc.len != val.len) FAIL(36);
+          uint64_t c = o + bc.hl, c_end = o + bc.hl + bc.len;
+          int ca = 0;
+          if (c < c_end) {
+            tlv f;
+            if (!rd_hdr(d, c, c_end, &f)) FAIL(37);
+            if (f.tag == 0x01) {
+              if (c + f.hl + (uint64_t)f.len > c_end) FAIL(37);
+              if (f.len != 1) FAIL(38);
+              uint8_t bv = d[c + f.hl];
+              if (bv != 0x00 && bv != 0xff) FAIL(39);
+              ca = bv == 0xff;
+              c += f.hl + f.len;
+              if (c < c_end && !rd_hdr(d, c, c_end, &f)) FAIL(40);
+            }
+            if (c < c_end && f.tag == 0x02) { /* pathLenConstraint */
+              if (c + f.hl + (uint64_t)f.len > c_end) FAIL(41);
+              int ci = check_int32(d, c + f.hl, f.len);
+              if (ci == 0) FAIL(41);
+              if (ci < 0) out->nonfatal |= ORC_NF_LAX_INTEGER;
+            }
+          }
+          out->bc_valid = 1;
+          out->is_ca = ca; /* a repeated extension overwrites (last wins) */
+        }
+        e += ext.hl + ext.len;
+      }
+    }
+  }
+  /* signatureAlgorithm, signatureValue BIT STRING; whatever follows inside the Certificate is ignored */
+  p = tbs_end;
+  if (!alg_id(d, p, cert_end, &t, &site, 42)) FAIL(site);
+  p += t.hl + t.len;
+  if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x03) FAIL(45);
+  if (!bit_string_ok(d, p + t.hl, t.len)) FAIL(46);
   out->ok = 1;
 }
 
@@ -800,13 +945,15 @@ int64_t orc_inserted(orc_engine* e) { return e->inserted; }
 
 /* One pass of insertCTWorker's loop body + FilesystemDatabase.Store.
  * ct-fetch.go:191-235; filesystemdatabase.go:158-211; knowncertificates.go:28-55. */
-int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, const uint8_t* issuer_der,
+int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int entry_type, const uint8_t* issuer_der,
                      size_t issuer_len, int* was_unknown, int32_t* exp_hour,
                      const uint8_t** serial, uint32_t* serial_len) {
   orc_cert c;
   if (was_unknown) *was_unknown = 0;
   orc_parse_cert(leaf, leaf_len, &c); /* :198-204 */
-  if (!c.ok) return ORC_ST_PARSE_ERROR; /* :206-209 */
+  /* X509 entry: the certificate LogEntryFromLeaf parsed, kept unless the error was fatal (:452-459);
+   * precertificate: parsed here, dropped on ANY error, x509.NonFatalErrors included (:202-209) */
+  if (!c.ok || (entry_type == 1 && c.nonfatal)) return ORC_ST_PARSE_ERROR; /* :206-209 */
   if (exp_hour) *exp_hour = orc_exp_hour(c.not_after);
   if (serial) *serial = leaf + c.serial_off;
   if (serial_len) *serial_len = c.serial_len;
@@ -815,7 +962,7 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, const 
   if (!issuer_der) return ORC_ST_NO_ISSUER; /* :215-219 */
   orc_cert ic;
   orc_parse_cert(issuer_der, issuer_len, &ic); /* :221 */
-  if (!ic.ok) return ORC_ST_ISSUER_PARSE_ERROR; /* :222-225 */
+  if (!ic.ok || ic.nonfatal) return ORC_ST_ISSUER_PARSE_ERROR; /* any err :222-225 */
   /* Store: filesystemdatabase.go:158-211 */
   int32_t eh = orc_exp_hour(c.not_after);           /* :160 */
   char issuer_id[45];
@@ -837,7 +984,7 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, const 
 }
 
 void orc_engine_batch(orc_engine* e, const uint8_t* payload, const uint64_t* offsets,
-                      const uint32_t* issuer_idx, uint64_t n, const uint8_t* issuer_payload,
+                      const uint32_t* issuer_idx, const uint8_t* entry_type, uint64_t n, const uint8_t* issuer_payload,
                       const uint64_t* issuer_offsets, uint32_t n_issuers, uint8_t* out_status,
                       uint8_t* out_unknown, int32_t* out_exp_hour) {
   for (uint64_t i = 0; i < n; i++) {
@@ -852,7 +999,7 @@ void orc_engine_batch(orc_engine* e, const uint8_t* payload, const uint64_t* off
     }
     int unk = 0;
     int32_t eh = 0;
-    int st = orc_engine_entry(e, leaf, ll, idr, il, &unk, &eh, NULL, NULL);
+    int st = orc_engine_entry(e, leaf, ll, entry_type ? entry_type[i] : 0, idr, il, &unk, &eh, NULL, NULL);
     if (out_status) out_status[i] = (uint8_t)st;
     if (out_unknown) out_unknown[i] = (uint8_t)unk;
     if (out_exp_hour) out_exp_hour[i] = eh;
@@ -972,7 +1119,7 @@ void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bo
     if (d.ok) {
       /* ct-fetch.go:198-204 the certificate; :215 len(Chain) < 1; :221 Chain[0] */
       const uint8_t* c = (d.cert_in_extra ? extra : leaf) + d.cert_off;
-      st = orc_engine_entry(e, c, d.cert_len, d.n_chain ? extra + d.chain0_off : NULL, d.chain0_len, &unk, &eh,
+      st = orc_engine_entry(e, c, d.cert_len, d.entry_type, d.n_chain ? extra + d.chain0_off : NULL, d.chain0_len, &unk, &eh,
                             NULL, NULL);
     }
     if (out_status) out_status[i] = (uint8_t)st;

@@ -20,8 +20,9 @@
  *   github.com/google/certificate-transparency-go v1.1.0 (go.mod:10), absent from
  *   /root/reference and from this machine; no Go toolchain exists here.  The fields
  *   Issuer.CommonName, NotAfter, IsCA/BasicConstraintsValid and every accept/reject
- *   decision follow RFC 5280 DER + the "DER walk profile" written down in DESIGN.md §3,
- *   cross-checked against OpenSSL 3 (tests/test_oracle_openssl.py) but NOT against Go.
+ *   decision follow Go's encoding/asn1 struct-unmarshalling rules applied to the x509 struct definitions (the
+ *   "DER walk profile" written down in DESIGN.md §3), cross-checked against OpenSSL 3 on well-formed
+ *   certificates (tests/test_walk_cpu.py) but NOT against Go.
  */
 #ifndef CTMR_ORACLE_H
 #define CTMR_ORACLE_H
@@ -59,7 +60,12 @@ typedef struct {
   int32_t is_ca;
   uint32_t spki_off, spki_len;       /* RawSubjectPublicKeyInfo: full TLV */
   uint32_t tbs_off, tbs_len;         /* RawTBSCertificate: full TLV */
+  int32_t nonfatal;      /* ORC_NF_*: findings CT-go reports as x509.NonFatalErrors — the certificate is handed out
+                            all the same; kept for X509 entries, dropped for precertificates and Chain[0] issuers */
 } orc_cert;
+
+#define ORC_NF_NEGATIVE_SERIAL 1 /* "x509: negative serial number" */
+#define ORC_NF_LAX_INTEGER 2     /* an INTEGER only CT-go's lax asn1 re-parse accepts: not minimally encoded */
 
 void orc_parse_cert(const uint8_t* der, size_t len, orc_cert* out);
 
@@ -94,7 +100,7 @@ void orc_engine_free(orc_engine*);
 /* One iteration of insertCTWorker's loop body.  issuer_der==NULL ⇔ len(Chain)<1.
  * Returns the status; *was_unknown = knownCerts.WasUnknown(serial) when status==PASS.
  * exp_hour/serial are filled whenever the leaf parsed. */
-int orc_engine_entry(orc_engine*, const uint8_t* leaf, size_t leaf_len, const uint8_t* issuer_der,
+int orc_engine_entry(orc_engine*, const uint8_t* leaf, size_t leaf_len, int entry_type, const uint8_t* issuer_der,
                      size_t issuer_len, int* was_unknown, int32_t* exp_hour,
                      const uint8_t** serial, uint32_t* serial_len);
 
@@ -121,8 +127,10 @@ int64_t orc_inserted(orc_engine*);
 /* Batch driver over the packed layout: the same loop, used for the
  * cpu_baseline timing and for bulk parity.  issuer_idx[i]==0xFFFFFFFF ⇔ no chain.
  * out_status[n], out_unknown[n], out_exp_hour[n] may be NULL. */
+/* entry_type[n]: 0 X509LogEntryType, 1 PrecertLogEntryType (decides what happens to non-fatal parse findings);
+ * NULL = all X509. */
 void orc_engine_batch(orc_engine*, const uint8_t* payload, const uint64_t* offsets,
-                      const uint32_t* issuer_idx, uint64_t n, const uint8_t* issuer_payload,
+                      const uint32_t* issuer_idx, const uint8_t* entry_type, uint64_t n, const uint8_t* issuer_payload,
                       const uint64_t* issuer_offsets, uint32_t n_issuers, uint8_t* out_status,
                       uint8_t* out_unknown, int32_t* out_exp_hour);
 

@@ -34,7 +34,10 @@ class Cert(C.Structure):
                 ("cn_off", C.c_uint32), ("cn_len", C.c_uint32),
                 ("bc_valid", C.c_int32), ("is_ca", C.c_int32),
                 ("spki_off", C.c_uint32), ("spki_len", C.c_uint32),
-                ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32)]
+                ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32), ("nonfatal", C.c_int32)]
+
+
+NF_NEGATIVE_SERIAL, NF_LAX_INTEGER = 1, 2
 
 
 def pem_encode(der: bytes) -> bytes:
@@ -70,7 +73,7 @@ def lib():
         L.orc_engine_new.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int64]
         L.orc_engine_new.restype = C.c_void_p
         L.orc_engine_free.argtypes = [C.c_void_p]
-        L.orc_engine_entry.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+        L.orc_engine_entry.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.orc_set_insert.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
@@ -90,7 +93,7 @@ def lib():
         L.orc_total_count.restype = C.c_int64
         L.orc_inserted.argtypes = [C.c_void_p]
         L.orc_inserted.restype = C.c_int64
-        L.orc_engine_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+        L.orc_engine_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
         L.orc_cert_meta.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Meta)]
@@ -174,17 +177,18 @@ class Engine:
     def __del__(self):
         self.close()
 
-    def entry(self, leaf: bytes, issuer_der):
+    def entry(self, leaf: bytes, issuer_der, entry_type: int = 0):
         unk = C.c_int(0)
         eh = C.c_int32(0)
         sp = C.c_void_p()
         sl = C.c_uint32(0)
-        st = lib().orc_engine_entry(self._h, leaf, len(leaf), issuer_der,
+        st = lib().orc_engine_entry(self._h, leaf, len(leaf), entry_type, issuer_der,
                                     len(issuer_der) if issuer_der is not None else 0,
                                     C.byref(unk), C.byref(eh), C.byref(sp), C.byref(sl))
         return st, bool(unk.value), eh.value
 
-    def batch(self, payload, offsets, issuer_idx, issuer_payload, issuer_offsets):
+    def batch(self, payload, offsets, issuer_idx, issuer_payload, issuer_offsets, entry_type=None):
+        """entry_type: u8[n] (0 X509, 1 precert) or None = all X509 entries."""
         import numpy as np
         n = len(offsets) - 1
         status = np.zeros(n, dtype=np.uint8)
@@ -195,8 +199,11 @@ class Engine:
         issuer_idx = np.ascontiguousarray(issuer_idx, dtype=np.uint32)
         issuer_payload = np.ascontiguousarray(issuer_payload, dtype=np.uint8)
         issuer_offsets = np.ascontiguousarray(issuer_offsets, dtype=np.uint64)
+        if entry_type is not None:
+            entry_type = np.ascontiguousarray(entry_type, dtype=np.uint8)
         lib().orc_engine_batch(self._h, payload.ctypes.data, offsets.ctypes.data,
-                               issuer_idx.ctypes.data, n, issuer_payload.ctypes.data,
+                               issuer_idx.ctypes.data, entry_type.ctypes.data if entry_type is not None else None,
+                               n, issuer_payload.ctypes.data,
                                issuer_offsets.ctypes.data, len(issuer_offsets) - 1,
                                status.ctypes.data, unknown.ctypes.data, exp.ctypes.data)
         return status, unknown, exp

@@ -48,19 +48,22 @@ def ext(oid_last, value, critical=None):
 
 
 def cert(serial=b"\x01", issuer=None, not_before=None, not_after=None, subject=None, spki=EC_SPKI,
-         exts=None, version=True, sig=b"\x00" + b"\x5a" * 64, extra_tbs=b""):
+         exts=None, version=True, sig=b"\x00" + b"\x5a" * 64, extra_tbs=b"", tbs_sigalg=SIGALG, outer_sigalg=SIGALG):
+    """version: True = [0]{INTEGER 2}, False = absent, bytes = those bytes verbatim."""
     issuer = issuer if issuer is not None else name(rdn(3, b"Test CA"))
     subject = subject if subject is not None else name(rdn(3, b"leaf"))
     not_before = not_before or utctime("250101000000Z")
     not_after = not_after or utctime("270101000000Z")
     tbs = b""
-    if version:
+    if isinstance(version, bytes):
+        tbs += version
+    elif version:
         tbs += tlv(0xa0, tlv(0x02, b"\x02"))
-    tbs += tlv(0x02, serial) + SIGALG + issuer + seq(not_before, not_after) + subject + spki
+    tbs += tlv(0x02, serial) + tbs_sigalg + issuer + seq(not_before, not_after) + subject + spki
     if exts is not None:
         tbs += tlv(0xa3, seq(*exts))
     tbs += extra_tbs
-    return seq(tlv(0x30, tbs), SIGALG, tlv(0x03, sig))
+    return seq(tlv(0x30, tbs), outer_sigalg, tlv(0x03, sig))
 
 
 BC_CA = ext(0x13, seq(tlv(0x01, b"\xff")), critical=True)

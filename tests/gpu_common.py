@@ -12,7 +12,7 @@ def run_oracle(batch, issuers, filt=b"", log_expired=False, now=0, engine=None):
         io[1:] = np.cumsum([len(x) for x in issuers])
     blob = np.frombuffer(b"".join(issuers), np.uint8) if issuers else np.zeros(1, np.uint8)
     st, unk, eh = o.batch(batch.payload if len(batch.payload) else np.zeros(1, np.uint8), batch.offsets,
-                          batch.issuer_idx, blob, io)
+                          batch.issuer_idx, blob, io, entry_type=batch.entry_type)
     return o, st, unk, eh
 
 
@@ -28,7 +28,7 @@ def expected_records(batch, st, unk, eh):
         c = orc.parse_cert(der)
         if batch.entry_type[i] == 1:
             flags[i] |= 1
-        if not c.ok:
+        if not c.ok or (batch.entry_type[i] == 1 and c.nonfatal):   # a dropped certificate reports no fields
             continue
         exp_hour[i] = eh[i]
         serial_len[i] = min(c.serial_len, 0xffff)

@@ -22,7 +22,7 @@ class HarnessOut(C.Structure):
                 ("not_before", C.c_int64), ("not_after", C.c_int64), ("cn_off", C.c_uint32),
                 ("cn_len", C.c_uint32), ("bc_valid", C.c_int32), ("is_ca", C.c_int32),
                 ("spki_off", C.c_uint32), ("spki_len", C.c_uint32), ("serial_w", C.c_uint32 * 5),
-                ("cn_match", C.c_int32)]
+                ("cn_match", C.c_int32), ("nonfatal", C.c_int32)]
 
 
 class OsslOut(C.Structure):
@@ -73,6 +73,18 @@ def product_walk(der: bytes, fill=0xA5, cn_filter=None) -> HarnessOut:
     f = cn_filter if cn_filter is not None else b""
     _walk.harness_walk_f(der, len(der), fill, f, len(f), int(cn_filter is not None), C.byref(o))
     return o
+
+
+def walk_touched(der: bytes, phase: int = 0, cn_filter: bytes = b""):
+    """(accepted, bytes the walk's reads cover, distinct 128-byte lines they lie in when the certificate starts at
+    byte `phase` of a line) — bench.py's needed_bytes accounting."""
+    product_walk(b"\x30\x00")          # builds / loads the library
+    fn = _walk.harness_walk_touched
+    fn.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32),
+                   C.POINTER(C.c_uint32)]
+    nb, nl = C.c_uint32(0), C.c_uint32(0)
+    ok = fn(der, len(der), phase & 127, cn_filter, len(cn_filter), C.byref(nb), C.byref(nl))
+    return bool(ok), nb.value, nl.value
 
 
 def ossl_extract(der: bytes):

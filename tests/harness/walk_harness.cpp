@@ -27,6 +27,7 @@ struct HarnessOut {
   uint32_t spki_off, spki_len;
   uint32_t serial_w[5];
   int32_t cn_match;
+  int32_t nonfatal;
 };
 
 extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, const char* filter,
@@ -68,4 +69,57 @@ extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, c
   out->spki_off = w.spki_off; out->spki_len = w.spki_len;
   memcpy(out->serial_w, w.serial_w, 20);
   out->cn_match = w.cn_match;
+  out->nonfatal = (int32_t)w.nonfatal;
+}
+
+// What the walk READS: every ld4/ldg marks its four bytes.  Used by bench.py's "needed_bytes" accounting (the bytes and
+// the distinct 128-byte HBM lines a certificate's walk covers when the certificate starts at byte `phase` of a line),
+// against which the measured traffic of the map kernel is an over-fetch ratio.
+struct CountingReader {
+  const uint8_t* p;
+  std::vector<uint8_t>* mark;
+  uint32_t ld4(uint32_t pos) const {
+    for (uint32_t k = 0; k < 4; k++)
+      if (pos + k < mark->size()) (*mark)[pos + k] = 1;
+    uint32_t v;
+    memcpy(&v, p + pos, 4);
+    return v;
+  }
+  uint32_t ldg(uint32_t pos) const { return ld4(pos); }
+  void touch(uint32_t, uint32_t) const {}
+  void touch_tail(uint32_t, uint32_t) const {}
+};
+
+extern "C" int harness_walk_touched(const uint8_t* der, uint32_t len, uint32_t phase, const char* filter, uint32_t flen,
+                                    uint32_t* bytes, uint32_t* lines128) {
+  uint32_t piece_len[64], piece_word[64], words[1024] = {0}, np = 0, nw = 0;
+  for (uint32_t s = 0;;) {
+    uint32_t t = s;
+    while (t < flen && filter[t] != ',') t++;
+    piece_len[np] = t - s;
+    piece_word[np] = nw;
+    memcpy((uint8_t*)(words + nw), filter + s, t - s);
+    nw += (t - s + 3) / 4;
+    np++;
+    if (t >= flen) break;
+    s = t + 1;
+  }
+  ctmr::FilterView fv{np, piece_len, piece_word, words};
+  std::vector<uint8_t> buf((size_t)len + 64, 0);
+  memcpy(buf.data(), der, len);
+  std::vector<uint8_t> mark(len, 0);
+  CountingReader r{buf.data(), &mark};
+  ctmr::Walk w;
+  const bool ok = ctmr::walk_cert(r, len, w, flen ? &fv : nullptr);
+  uint32_t nb = 0, nl = 0;
+  int64_t last_line = -1;
+  for (uint32_t i = 0; i < len; i++)
+    if (mark[i]) {
+      nb++;
+      const int64_t line = (int64_t)((phase + i) >> 7);
+      if (line != last_line) { nl++; last_line = line; }
+    }
+  *bytes = nb;
+  *lines128 = nl;
+  return ok;
 }

@@ -48,3 +48,41 @@ def test_cpu_baseline_threads_counts_every_entry_once():
     one = bench.cpu_baseline_threads(arrays, issuers, b"", synth.BASE_TIME, n, 1)
     four = bench.cpu_baseline_threads(arrays, issuers, b"", synth.BASE_TIME, n, 4)
     assert one[2] == four[2] > 0                    # same PASS count whatever the slicing
+
+
+def test_strided_sample_closure_gives_the_whole_batch_answer():
+    """bench.py's parity leg: the oracle over (sampled slices + the sources of sampled duplicates), in log order, must
+    say for every one of those entries what the oracle over the WHOLE batch says — here the whole batch is small enough
+    to run, at 100 M entries only the closed sample is."""
+    import torch
+    cfg = synth.config(seed=20260925, n_issuers=16, zipf=1, dup_permille=150, ca_permille=10, expired_permille=10)
+    E = 30000
+    b = synth.host_batch(cfg, 0, E)
+    issuers = synth.issuers(cfg)
+    filt = b"Synth Issuer 00"
+    io = np.zeros(len(issuers) + 1, np.uint64)
+    io[1:] = np.cumsum([len(x) for x in issuers])
+    blob = np.frombuffer(b"".join(issuers), np.uint8)
+    whole = orc.Engine(filt, False, synth.BASE_TIME)
+    st_w, unk_w, _ = whole.batch(np.concatenate([b.payload, np.zeros(32, np.uint8)]), b.offsets, b.issuer_idx, blob, io,
+                                 entry_type=b.entry_type)
+    ranges = bench.strided_sample(E, 12, 500)
+    assert len(ranges) == 12 and ranges[1][0] == E // 12 and all(hi - lo == 500 for lo, hi in ranges)
+    in_sample = np.concatenate([np.arange(lo, hi, dtype=np.uint64) for lo, hi in ranges])
+    src, isdup = bench.synth_src(cfg.seed, in_sample, 150, np)
+    assert (isdup == bench.synth_is_dup_at(cfg.seed, in_sample, 150, np)).all() and isdup.sum() > 500
+    extra = np.setdiff1d(src[isdup], in_sample)
+    assert len(extra) > 300                                      # most sources lie outside the slices
+    extra_certs = [synth.leaf(cfg, int(i)) for i in extra]
+    d_off = torch.from_numpy(b.offsets.astype(np.int64))
+    arrays = bench.gather_sample(d_off, torch.from_numpy(b.payload), torch.from_numpy(b.issuer_idx.astype(np.int32)),
+                                 torch.from_numpy(b.entry_type), ranges, extra, extra_certs, 32, np)
+    gidx = arrays[4].astype(np.int64)
+    assert (np.diff(gidx) > 0).all() and len(gidx) == len(in_sample) + len(extra)
+    for k in (0, 17, len(gidx) - 1):                             # the gathered bytes are the batch's bytes
+        assert arrays[0][int(arrays[1][k]):int(arrays[1][k + 1])].tobytes() == b.cert(int(gidx[k]))
+    part = orc.Engine(filt, False, synth.BASE_TIME)
+    st_s, unk_s, _ = part.batch(arrays[0], arrays[1], arrays[2], blob, io, entry_type=arrays[3])
+    assert (st_s == st_w[gidx]).all()
+    assert (unk_s == unk_w[gidx]).all()
+    assert ((st_s == 0) & (unk_s == 0)).sum() > 300              # known duplicates are in the sample

@@ -14,7 +14,7 @@ from ct_mapreduce_amd.engine import Batch
 from oracle import oracle as orc
 from tests import der as D
 from tests.gpu_common import run_oracle, assert_records_equal, assert_state_equal
-from tests.test_walk_cpu import mutate
+from tests.test_walk_cpu import mutate, edge_seeds
 
 NOW = synth.BASE_TIME
 
@@ -104,7 +104,8 @@ def test_golden_entry_through_gpu(golden_certs, variant):
 def test_edge_cases_and_fuzz(golden_certs, variant):
     rng = random.Random(99)
     cfg = synth.config(seed=5, n_issuers=4, ca_permille=100, expired_permille=100)
-    issuers = synth.issuers(cfg) + [b"\x30\x03\x02\x01\x00", synth.issuer(cfg, 1)]   # 4 invalid, 5 dup SPKI of 1
+    issuers = synth.issuers(cfg) + [b"\x30\x03\x02\x01\x00", synth.issuer(cfg, 1),   # 4 invalid, 5 dup SPKI of 1
+                                    D.cert(serial=b"\x00\x01", exts=[D.BC_CA])]         # 6: a non-fatal finding is an err for Chain[0]
     certs, iss, ets = [], [], []
 
     def add(c, i=0, et=0):
@@ -113,6 +114,14 @@ def test_edge_cases_and_fuzz(golden_certs, variant):
     seeds = list(golden_certs.values()) + [synth.leaf(cfg, i)[0] for i in range(20)]
     for r in range(3000):
         add(mutate(rng, seeds[r % len(seeds)]), rng.randrange(4), rng.randrange(2))
+    # the Go-specific rules (numeric zones, lax INTEGERs and negative serials — kept for X509 entries, dropped for
+    # precertificates —, unique ids, high tag numbers, wrappers that lie about their length), plain and mutated
+    edges = edge_seeds()
+    for c in edges:
+        add(c, 0, 0); add(c, 0, 1)
+    for r in range(3000):
+        c = mutate(rng, edges[r % len(edges)])
+        add(mutate(rng, c) if r % 3 == 0 and len(c) > 1 else c, rng.randrange(4), rng.randrange(2))
     add(b"")                                            # empty record
     add(b"\x30")
     add(synth.leaf(cfg, 1)[0], N.NO_ISSUER)             # chain empty
@@ -120,6 +129,7 @@ def test_edge_cases_and_fuzz(golden_certs, variant):
     add(synth.leaf(cfg, 3)[0], 77)                      # out-of-range index behaves as no issuer
     a = synth.leaf(cfg, 6)[0]
     add(a, 1); add(a, 5)                                # same SPKI through two issuer entries → duplicate
+    add(synth.leaf(cfg, 7)[0], 6)                       # issuer certificate with a lax INTEGER: ISSUER_PARSE_ERROR
     for s in (b"\x00\xaa", bytes(range(1, 21)), bytes(range(1, 22)), bytes(range(1, 31)),
               bytes(range(1, 41)), bytes(range(1, 42)), b"\x05" * 45, b"\x06" * 300, bytes(range(1, 31)),
               b"\x05" * 45):

@@ -9,7 +9,7 @@ from ct_mapreduce_amd import synth
 from oracle import oracle as orc
 from tests import harness
 
-FIELDS = ("serial_off", "serial_len", "not_before", "not_after", "cn_off", "cn_len", "bc_valid",
+FIELDS = ("nonfatal", "serial_off", "serial_len", "not_before", "not_after", "cn_off", "cn_len", "bc_valid",
           "is_ca", "spki_off", "spki_len")
 
 
@@ -139,7 +139,12 @@ def test_product_walk_equals_oracle_on_mutations(golden_certs):
     (b"\x17\x0d" + b"260101000060Z", False, 0),
     (b"\x17\x0d" + b"26010100000 Z", False, 0),
     (b"\x17\x0d" + b"260101000000+", False, 0),
-    (b"\x17\x11" + b"260101000000+0100", False, 0),   # numeric zone: outside the profile
+    (b"\x17\x11" + b"260101000000+0100", True, 1767225600 - 3600),   # numeric zones: Go's "Z0700" layout element
+    (b"\x17\x0f" + b"2601010000-0530", True, 1767225600 + 19800),
+    (b"\x18\x13" + b"20260101000000-0800", True, 1767225600 + 28800),
+    (b"\x17\x11" + b"260101000000+0000", False, 0),   # offset 0 prints back as "Z": rejected
+    (b"\x17\x11" + b"260101000000+0060", False, 0),   # prints back as +0100
+    (b"\x18\x13" + b"20260101000000+00:3", False, 0),
     (b"\x18\x0d" + b"260101000000Z", False, 0),
     (b"\x16\x0d" + b"260101000000Z", False, 0),
 ])
@@ -188,3 +193,40 @@ def test_mixed_synthetic_corpus_against_openssl():
     assert n_ec > 200 and n_gt > 80 and n_ov > 150
     for k in range(9):
         assert same(synth.issuer(cfg, k))
+
+
+def edge_seeds():
+    """Small hand-built certificates that sit on the Go-specific rules (numeric zones, lax INTEGERs, unique ids,
+    high tag numbers, odd basicConstraints, explicit wrappers that lie about their length): mutations of these land on
+    headers far more often than mutations of a 1.5 KB certificate do."""
+    from tests import der as D
+    ec = D.seq(D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 2, 1), D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 3, 1, 7))
+    hi = D.seq(D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), b"\x5f\x28\x01x")), D.rdn(3, b"cn"), D.rdn(10, b"o", tag=0x13))
+    return [
+        D.cert(exts=[D.BC_NOT_CA]),
+        D.cert(not_after=D.utctime("270101010000+0100"), not_before=D.gentime("20250101000000-0800"), exts=[D.BC_CA]),
+        D.cert(not_after=D.utctime("2701010100+0100"), serial=b"\x00\x7f", version=D.tlv(0xa0, D.tlv(0x02, b"\x00\x02"))),
+        D.cert(serial=b"\xff\x80", issuer=hi, subject=hi, exts=[D.ext(0x13, D.seq(D.tlv(0x02, b"\x00\x05")))]),
+        D.cert(extra_tbs=D.tlv(0x81, b"\x01\x02") + D.tlv(0x82, b"\x00\x02") + D.tlv(0xa3, D.seq(D.BC_CA) + b"\xff")),
+        D.cert(extra_tbs=b"\xa3\x01" + D.seq(D.ext(0x13, D.seq(D.tlv(0x01, b"\xff"), D.tlv(0x05, b""), b"\x05\x7f")))),
+        D.cert(version=b"\xa0\x05" + D.tlv(0x02, b"\x02"), spki=D.seq(ec, D.tlv(0x03, b"\x03" + bytes(31) + b"\xf8"), D.tlv(0x05, b"")),
+               tbs_sigalg=D.seq(D.oid(0x2a, 3)), outer_sigalg=D.seq(D.oid(0x2a, 3), D.tlv(0x30, b""), D.tlv(0x05, b""))),
+        D.cert(extra_tbs=D.tlv(0x1f, b"")[:1] + b"\x28\x00" + b"\x05\x00", version=False, sig=b"\x07\x80"),
+        D.cert(exts=[D.seq(D.oid(0x2b, 6, 1, 4, 1, 0x82, 0x37), D.tlv(0x01, b"\xff"), D.tlv(0x04, b"abc")), D.BC_CA, D.BC_NOT_CA],
+               issuer=D.seq(D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), D.tlv(0x13, b"a")) + D.seq(D.oid(0x55, 4, 3), D.tlv(0x16, b"b"), D.tlv(0x05, b"")))),
+               subject=D.seq(D.tlv(0x31, b""))),
+    ]
+
+
+def test_product_walk_equals_oracle_on_mutated_edge_certificates():
+    rng = random.Random(20260923)
+    seeds = edge_seeds()
+    accepted = 0
+    for der in seeds:
+        assert same(der), der.hex()
+    for r in range(12000):
+        der = mutate(rng, seeds[r % len(seeds)])
+        if rng.randrange(3) == 0 and len(der) > 1:
+            der = mutate(rng, der)
+        accepted += same(der)
+    assert 1000 < accepted < 11000
