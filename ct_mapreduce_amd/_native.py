@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CTMR_LIB") or os.path.join(HERE, "libctmr.so")
 ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
     ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
 ST_COUNT = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 ENTRY_INVALID = 0xFF
 FL_PRECERT, FL_WAS_UNKNOWN, FL_LONG_SERIAL = 1, 2, 4
 NO_ISSUER = 0xFFFFFFFF
@@ -26,7 +26,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_slots", C.c_uint64),
                 ("pair_slots", C.c_uint64), ("max_issuers", C.c_uint32), ("certs_per_tile", C.c_uint32),
                 ("lds_tile_bytes", C.c_uint32), ("map_variant", C.c_uint32), ("profile", C.c_uint32),
-                ("collect_meta", C.c_uint32)]
+                ("collect_meta", C.c_uint32), ("max_table_slots", C.c_uint64)]
 
 
 class BatchStats(C.Structure):

@@ -139,6 +139,9 @@ struct ctmr_engine {
   // known-certificate table
   Slot* table = nullptr;
   uint64_t nslots = 0;
+  uint64_t max_slots = 0;   // growth limit (config.max_table_slots; at most 2^31: slot ids are 32-bit)
+  uint64_t occupied = 0;    // slots claimed since the table was last (re)built: live members + tombstones
+  uint32_t rebuilds = 0;
   PairSlot* pairs = nullptr;
   uint64_t npairs = 0;
   unsigned long long* issuer_counts = nullptr;
@@ -275,12 +278,18 @@ int upload_filter(ctmr_engine* e) {
   return CTMR_OK;
 }
 
+int ensure_capacity(ctmr_engine* e, uint64_t incoming);
+
 int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uint8_t* m, size_t n,
              int* out) {
   unsigned long long s[5];
   pack_serial(m, n, s);
   const unsigned long long meta = key_meta(exp_hour, canon, (uint32_t)n);
-  if (op == 0) e->epoch++;
+  if (op == 0) {
+    int rc = ensure_capacity(e, 1);
+    if (rc) return rc;
+    e->epoch++;
+  }
   if (op != 1) e->pairs_dirty = true;
   hipLaunchKernelGGL(k_set_op, dim3(1), dim3(64), 0, e->stream, e->table, e->nslots - 1, meta, s[0],
                      s[1], s[2], s[3], s[4], op, e->epoch, e->issuer_counts, e->pairs,
@@ -289,8 +298,52 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
   HIPCHK(e, hipMemcpyAsync(res, e->d_result, 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   if (res[1]) return fail(e, CTMR_E_FULL, "known-certificate or pair table is full");
+  if (op == 0 && res[0]) e->occupied++;
   *out = (int)res[0];
   return CTMR_OK;
+}
+
+// Known-certificate table capacity (what Redis does by growing until OOM, storage/rediscache.go:57-65): before a call
+// that may claim up to `incoming` slots, make sure the load stays under 3/4 afterwards.  If it would not, the table is
+// rebuilt on the GPU (k_rehash) into the smallest power of two that holds (live + incoming) at load <= 1/2 — larger
+// when members were added, the SAME size when the slots were eaten by tombstones (expiry sweeps, SetRemove), which a
+// rebuild leaves behind.  When even max_slots cannot hold the batch the call fails with CTMR_E_FULL BEFORE anything
+// was inserted: a batch is applied completely or not at all.
+int ensure_capacity(ctmr_engine* e, uint64_t incoming) {
+  if ((e->occupied + incoming) * 4 <= e->nslots * 3) return CTMR_OK;
+  // how many members are alive decides the new size: count them with the rebuild itself when tombstones may exist
+  uint64_t want = pow2_at_least((e->occupied + incoming) * 2);
+  if (want > e->max_slots) want = e->max_slots;
+  if (want < e->nslots) want = e->nslots;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    Slot* nt = nullptr;
+    if (hipMalloc(&nt, want * sizeof(Slot)) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e, CTMR_E_NOMEM, "known-certificate table: cannot allocate %llu slots for the rebuild",
+                  (unsigned long long)want);
+    }
+    HIPCHK(e, hipMemsetAsync(nt, 0, want * sizeof(Slot), e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+    hipLaunchKernelGGL(k_rehash, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream,
+                       (const Slot*)e->table, e->nslots, nt, want - 1, e->d_count);
+    unsigned long long live = 0;
+    HIPCHK(e, hipMemcpyAsync(&live, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipGetLastError());
+    (void)hipFree(e->table);
+    e->table = nt;
+    e->nslots = want;
+    e->occupied = live;
+    e->rebuilds++;
+    if ((e->occupied + incoming) * 4 <= e->nslots * 3) return CTMR_OK;
+    // the rebuild found fewer tombstones than hoped for and the size was capped: one more try at the cap, else full
+    if (want >= e->max_slots) break;
+    want = pow2_at_least((e->occupied + incoming) * 2);
+    if (want > e->max_slots) want = e->max_slots;
+  }
+  return fail(e, CTMR_E_FULL, "known-certificate table full: %llu members + %llu incoming do not fit %llu slots "
+              "(max_table_slots); nothing of this call was applied", (unsigned long long)e->occupied,
+              (unsigned long long)incoming, (unsigned long long)e->nslots);
 }
 
 int ensure_pairs(ctmr_engine* e) {

@@ -123,6 +123,34 @@ __global__ void __launch_bounds__(256) k_sweep(Slot* table, uint64_t nslots, int
   atomicAdd(removed, 1ull);
 }
 
+// Table growth / compaction: every live member of the old table is re-inserted into the new (zeroed) one — the
+// keys are distinct, so one CAS claims the slot and plain stores fill it (the kernel boundary publishes them).  The
+// slot image moves verbatim: the tag half of w[0] is a function of the key hash, not of the table size; w[2] keeps
+// the creating batch's epoch and the SHADOW bit.  Tombstones stay behind, which is how their slots are recovered.
+__global__ void __launch_bounds__(256) k_rehash(const Slot* old_table, uint64_t old_slots, Slot* table, uint64_t mask,
+                                                unsigned long long* moved) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= old_slots) return;
+  const Slot* o = old_table + j;
+  const unsigned long long w0 = o->w[0], w1 = o->w[1];
+  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  unsigned long long s[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) s[k] = o->w[3 + k];
+  const unsigned long long w2 = o->w[2];
+  uint64_t q = key_hash(w1, s) & mask;
+  for (;;) {  // the new table holds at most half as many members as it has slots: this terminates
+    if (atomicCAS(&table[q].w[0], 0ull, w0) == 0ull) break;
+    q = (q + 1) & mask;
+  }
+  Slot* d = table + q;
+  d->w[1] = w1;
+  d->w[2] = w2;
+#pragma unroll
+  for (int k = 0; k < 5; k++) d->w[3 + k] = s[k];
+  atomicAdd(moved, 1ull);
+}
+
 // Rebuild the (expDate, issuer) → SCARD table from the known-certificate table (lazy: only the
 // statistics-style queries SetCardinality / Exists / KeysToChan need it).
 __global__ void __launch_bounds__(256) k_build_pairs(const Slot* table, uint64_t nslots, PairSlot* pairs,

@@ -95,12 +95,12 @@ class BatchResult:
 
 class Engine:
     def __init__(self, device=0, table_slots=0, pair_slots=0, max_issuers=0, certs_per_tile=0,
-                 lds_tile_bytes=0, map_variant=0, profile=False, collect_meta=False):
+                 lds_tile_bytes=0, map_variant=0, profile=False, collect_meta=False, max_table_slots=0):
         self._lib = N.lib()
         cfg = N.Config(struct_size=C.sizeof(N.Config), device=device, table_slots=table_slots,
                        pair_slots=pair_slots, max_issuers=max_issuers, certs_per_tile=certs_per_tile,
                        lds_tile_bytes=lds_tile_bytes, map_variant=map_variant, profile=int(profile),
-                       collect_meta=int(collect_meta))
+                       collect_meta=int(collect_meta), max_table_slots=max_table_slots)
         h = C.c_void_p()
         rc = self._lib.ctmr_create(C.byref(cfg), C.byref(h))
         if rc != 0:

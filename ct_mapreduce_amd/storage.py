@@ -19,7 +19,6 @@ import hashlib
 import json
 import os
 import time as _time
-from urllib.parse import urlsplit
 
 import numpy as np
 
@@ -478,30 +477,85 @@ def name_atvs(name_der: bytes):
     return out
 
 
+_GO_STRING_TAGS = (0x0c, 0x12, 0x13, 0x14, 0x16)     # UTF8, Numeric, Printable, T61, IA5: what Go's asn1 decodes to a `string`
+
+
 def name_string(atvs) -> str:
-    """pkix.Name.String(): RDNs of ToRDNSequence() reversed, multi-values joined with '+'."""
-    if True:
-        named, extra = {}, []
-        for oid, vt, val in atvs:
-            s = val.decode("utf-8", "replace")
-            if len(oid) == 3 and oid[:2] == b"\x55\x04" and oid[2] in _ATTR_NAMES:
-                named.setdefault(oid[2], []).append(s)
-            else:
-                extra.append((oid, s))
-        rdns = []
-        for oid, s in extra:
-            arcs = [oid[0] // 40, oid[0] % 40]
-            v = 0
-            for b in oid[1:]:
-                v = (v << 7) | (b & 0x7f)
-                if not b & 0x80:
-                    arcs.append(v)
-                    v = 0
-            rdns.append(".".join(map(str, arcs)) + "=" + _escape_rdn_value(s))
-        for a in _ORDER:
-            if a in named:
-                rdns.append("+".join(_ATTR_NAMES[a] + "=" + _escape_rdn_value(x) for x in named[a]))
-        return ",".join(reversed(rdns))
+    """pkix.Name.String() of certificate-transparency-go v1.1.0 (go.mod:10) = ToRDNSequence().String(): the Name is
+    rebuilt from the nine typed fields FillFromRDNSequence fills (C, ST, L, STREET, POSTALCODE, O, OU, CN,
+    SERIALNUMBER; string-typed values only) plus ExtraNames, which a parsed certificate never has — every other
+    attribute type (DC, emailAddress, organizationIdentifier, jurisdiction*, …) is DROPPED.  (Go >= 1.15's
+    crypto/x509/pkix appends them as `oid=#hex`; the pinned fork predates that.)  RDNs are printed in reverse, the
+    values of one type joined with '+'."""
+    named = {}
+    for oid, vt, val in atvs:
+        if len(oid) == 3 and oid[:2] == b"\x55\x04" and oid[2] in _ATTR_NAMES and vt in _GO_STRING_TAGS:
+            named.setdefault(oid[2], []).append(val.decode("utf-8", "replace"))
+    rdns = []
+    for a in _ORDER:
+        if a in named:
+            rdns.append("+".join(_ATTR_NAMES[a] + "=" + _escape_rdn_value(x) for x in named[a]))
+    return ",".join(reversed(rdns))
+
+
+def go_url_normalise(raw: str):
+    """url.Parse(strings.TrimSpace(s)) + url.String() for the shapes a CRL distribution point takes — the same rules
+    as go_url_normalise in include/ctmr_storage.hpp (one set of vectors pins both: tests/test_storage_cpu.py,
+    tests/host/test_storage.cpp): scheme lower-cased; control characters, malformed %-escapes and a non-numeric port
+    are parse errors; path and fragment bytes outside Go's unescaped set are %XX-escaped by String().
+    Returns (ok, scheme, normalised)."""
+    s = raw.strip(" \t\n\v\f\r")
+    b = s.encode("utf-8", "surrogateescape")
+    if any(c < 0x20 or c == 0x7f for c in b):
+        return False, "", ""
+    i = 0
+    while i < len(s):
+        c = s[i]
+        if c.isascii() and (c.isalpha() or (i > 0 and (c.isdigit() or c in "+-."))):
+            i += 1
+            continue
+        break
+    if i == 0 or i >= len(s) or s[i] != ":":
+        return True, "", s                                     # no scheme
+    scheme = s[:i].lower()
+    rest, frag, query = s[i + 1:], None, None
+    if "#" in rest:
+        rest, frag = rest.split("#", 1)
+    if "?" in rest:
+        rest, query = rest.split("?", 1)
+
+    def bad_escape(t):
+        hexd = "0123456789abcdefABCDEF"
+        return any(t[k] == "%" and (k + 2 >= len(t) or t[k + 1] not in hexd or t[k + 2] not in hexd)
+                   for k in range(len(t)))
+    if bad_escape(rest) or bad_escape(frag or ""):
+        return False, "", ""
+    authority, path = None, rest
+    if rest.startswith("//"):
+        sl = rest.find("/", 2)
+        authority = rest[2:] if sl < 0 else rest[2:sl]
+        path = "" if sl < 0 else rest[sl:]
+        host = authority.rsplit("@", 1)[-1]
+        if not host.startswith("["):                           # validOptionalPort on what follows the last ':'
+            if ":" in host and not all("0" <= ch <= "9" for ch in host.rsplit(":", 1)[1]):
+                return False, "", ""
+
+    def esc(t, is_path):
+        out = []
+        for c in t.encode("utf-8", "surrogateescape"):
+            ch = chr(c)
+            keep = (c < 0x80 and ch.isalnum()) or (c != 0 and ch in "-_.~$&+,/:;=@%!*'()") or (not is_path and ch == "?")
+            out.append(ch if keep else "%%%02X" % c)
+        return "".join(out)
+    norm = scheme + ":"
+    if authority is not None:
+        norm += "//" + authority
+    norm += esc(path, True)
+    if query is not None:
+        norm += "?" + query
+    if frag is not None:
+        norm += "#" + esc(frag, False)
+    return True, scheme, norm
 
 
 class IssuerMetadata:
@@ -516,15 +570,14 @@ class IssuerMetadata:
     def issuersId(self): return "%s::%s" % (kIssuers, self.id())
 
     def addCRL(self, aCRL: str):                               # :48-73
-        try:
-            u = urlsplit(aCRL.strip())
-        except ValueError:
+        ok, scheme, norm = go_url_normalise(aCRL)
+        if not ok:
+            return                                             # "Not a valid CRL DP URL"
+        if scheme in ("ldap", "ldaps"):
             return
-        if u.scheme in ("ldap", "ldaps"):
-            return
-        if u.scheme not in ("http", "https"):
-            return
-        self.cache.SetInsert(self.crlId(), u.geturl())
+        if scheme not in ("http", "https"):
+            return                                             # "Ignoring unknown CRL scheme"
+        self.cache.SetInsert(self.crlId(), norm)
 
     def addIssuerDN(self, dn: str):                            # :75-87
         self.cache.SetInsert(self.issuersId(), dn)

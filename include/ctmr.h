@@ -29,14 +29,15 @@
 extern "C" {
 #endif
 
-#define CTMR_ABI_VERSION 2
+#define CTMR_ABI_VERSION 3
 
 enum {
   CTMR_OK = 0,
   CTMR_E_INVAL = -1,     /* bad argument */
   CTMR_E_HIP = -2,       /* HIP runtime error (message has the hipError string) */
   CTMR_E_NOMEM = -3,     /* device or host allocation failed */
-  CTMR_E_FULL = -4,      /* known-certificate table / issuer table / pair table is full */
+  CTMR_E_FULL = -4,      /* known-certificate table (at max_table_slots) / issuer table / pair table is full; a map /
+                            insert call that returns it has not been applied (no slot claimed, no counter changed) */
   CTMR_E_NOTFOUND = -5,
   CTMR_E_RANGE = -6      /* caller buffer too small; *need tells the size */
 };
@@ -91,6 +92,12 @@ typedef struct {
   uint32_t profile;           /* 1 = bracket every kernel with hipEvents (ctmr_batch_stats.ms_*) */
   uint32_t collect_meta;      /* 1 = the map also records where each certificate's issuer Name and
                                  cRLDistributionPoints lie (8 B per entry) so that ctmr_meta_new* can run */
+  uint64_t max_table_slots;   /* growth limit of the known-certificate table; 0 = 2^31.  Redis grows until OOM
+                                 (storage/rediscache.go:57-65); here, before a call that may claim more slots than keep
+                                 the load under 3/4, the table is rebuilt on the GPU into the power of two that holds
+                                 (live members + incoming) at load <= 1/2 — tombstones (expiry sweeps, SetRemove) are
+                                 dropped by the rebuild.  When even this limit cannot hold the call, it fails with
+                                 CTMR_E_FULL BEFORE anything is inserted: a batch is applied completely or not at all. */
 } ctmr_config;
 
 typedef struct {

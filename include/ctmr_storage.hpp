@@ -857,9 +857,12 @@ class HostCert {
   std::vector<ATV> issuer_atvs;
   std::vector<std::string> crlDistributionPoints;
 
-  // pkix.Name.String(): known attribute types in ToRDNSequence() order (C, ST, L, STREET, POSTALCODE, O, OU, CN,
-  // SERIALNUMBER — Go ≥ 1.10; same order as the Python mirror), unknown ones first as dotted OIDs, the whole
-  // sequence reversed, multi-values joined by '+'
+  // pkix.Name.String() of certificate-transparency-go v1.1.0 (go.mod:10) = ToRDNSequence().String(): the Name is
+  // rebuilt from the nine typed fields FillFromRDNSequence fills (C, ST, L, STREET, POSTALCODE, O, OU, CN,
+  // SERIALNUMBER; values of the types Go's asn1 decodes to a `string` only) plus ExtraNames, which a parsed certificate
+  // never has — every other attribute type (DC, emailAddress, organizationIdentifier, jurisdiction*, …) is DROPPED.
+  // (Go >= 1.15's crypto/x509/pkix appends them as `oid=#hex`; the pinned fork predates that.)  The sequence is
+  // printed reversed, the values of one type joined by '+'.
   std::string IssuerString() const {
     static const std::map<uint8_t, const char*> names = {{6, "C"}, {10, "O"}, {11, "OU"}, {3, "CN"}, {5, "SERIALNUMBER"},
                                                          {7, "L"}, {8, "ST"}, {9, "STREET"}, {17, "POSTALCODE"}};
@@ -867,17 +870,9 @@ class HostCert {
     std::map<uint8_t, std::vector<std::string>> named;
     std::vector<std::string> rdns;
     for (auto& a : issuer_atvs) {
-      if (a.oid.size() == 3 && a.oid[0] == 0x55 && a.oid[1] == 0x04 && names.count((uint8_t)a.oid[2])) {
+      const bool go_string = a.tag == 0x0c || a.tag == 0x12 || a.tag == 0x13 || a.tag == 0x14 || a.tag == 0x16;
+      if (a.oid.size() == 3 && a.oid[0] == 0x55 && a.oid[1] == 0x04 && names.count((uint8_t)a.oid[2]) && go_string)
         named[(uint8_t)a.oid[2]].push_back(a.value);
-      } else {
-        std::string dotted = std::to_string((uint8_t)a.oid[0] / 40) + "." + std::to_string((uint8_t)a.oid[0] % 40);
-        uint64_t v = 0;
-        for (size_t i = 1; i < a.oid.size(); i++) {
-          v = (v << 7) | ((uint8_t)a.oid[i] & 0x7f);
-          if (!((uint8_t)a.oid[i] & 0x80)) { dotted += "." + std::to_string(v); v = 0; }
-        }
-        rdns.push_back(dotted + "=" + escape(a.value));
-      }
     }
     for (uint8_t t : order) {
       auto f = named.find(t);

@@ -235,6 +235,14 @@ static void Test_HostCert() {
   const std::string name = tlv(0x30, rdn(3, 0x0c, "a,b+c \"q\"") + rdn(10, 0x0c, " x "));
   const std::string esc_cert = make_cert(byte1(1), name, "010101000000Z");
   CHECK_EQ(HostCert(esc_cert).IssuerString(), std::string("CN=a\\,b\\+c \\\"q\\\",O=\\ x\\ "));
+  // attribute types outside the nine FillFromRDNSequence knows (DC, emailAddress) and values that are no Go string
+  // (BMPString) are dropped by the pinned CT-go's Name.String()
+  {
+    const std::string dc = tlv(0x31, tlv(0x30, tlv(0x06, std::string("\x09\x92\x26\x89\x93\xf2\x2c\x64\x01\x19", 10)) + tlv(0x16, "example")));
+    const std::string mail = tlv(0x31, tlv(0x30, tlv(0x06, std::string("\x2a\x86\x48\x86\xf7\x0d\x01\x09\x01", 9)) + tlv(0x16, "ca@example.org")));
+    const std::string odd = tlv(0x30, dc + rdn(6, 0x13, "DE") + rdn(10, 0x1e, std::string("\0O\0r\0g", 6)) + rdn(10, 0x0c, "Org") + mail + rdn(3, 0x0c, "The CA"));
+    CHECK_EQ(HostCert(make_cert(byte1(1), odd, "010101000000Z")).IssuerString(), std::string("CN=The CA,O=Org,C=DE"));
+  }
   // a synthetic leaf of the benchmark corpus
   ctmr_synth_config cfg;
   memset(&cfg, 0, sizeof cfg);

@@ -7,6 +7,7 @@ pytestmark = pytest.mark.gpu
 import torch  # noqa: E402,F401
 
 import ct_mapreduce_amd as ctmr
+from oracle import oracle as orc
 from ct_mapreduce_amd import synth, _native as N
 from ct_mapreduce_amd.engine import Batch, RawEntries
 
@@ -19,12 +20,105 @@ def code(fn):
     return ei.value.code
 
 
-def test_known_certificate_table_full_is_reported():
+def test_table_full_fails_before_anything_is_applied():
+    """max_table_slots caps the growth; a batch that cannot fit is refused BEFORE any insert (a partially
+    applied batch lost its new certificates' write-back): the sets, the counters and a retry with a smaller batch are
+    what they would be had the failed call never happened."""
     cfg = synth.config(seed=1, n_issuers=2)
-    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
-    eng.add_issuers(synth.issuers(cfg))
+    issuers = synth.issuers(cfg)
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10, max_table_slots=1 << 10)
+    eng.add_issuers(issuers)
     eng.set_filter(b"", True, NOW)
-    assert code(lambda: eng.map_batch(synth.host_batch(cfg, 0, 3000))) == N.E_FULL       # 3 000 keys, 1 024 slots
+    small = synth.host_batch(cfg, 0, 300)
+    r1 = eng.map_batch(small)
+    keys_before, total_before = sorted(eng.keys(b"serials::*")), eng.total_count()
+    assert code(lambda: eng.map_batch(synth.host_batch(cfg, 300, 3000))) == N.E_FULL     # 3 000 keys, 1 024 slots
+    assert sorted(eng.keys(b"serials::*")) == keys_before and eng.total_count() == total_before == r1.stats.n_new
+    nxt = synth.host_batch(cfg, 300, 300)
+    r2 = eng.map_batch(nxt)                                                            # … and the engine still works
+    o = orc.Engine(b"", True, NOW)
+    io = np.zeros(len(issuers) + 1, np.uint64)
+    io[1:] = np.cumsum([len(x) for x in issuers])
+    blob = np.frombuffer(b"".join(issuers), np.uint8)
+    o.batch(small.payload, small.offsets, small.issuer_idx, blob, io, entry_type=small.entry_type)
+    st, unk, _ = o.batch(nxt.payload, nxt.offsets, nxt.issuer_idx, blob, io, entry_type=nxt.entry_type)
+    assert (((r2.records["flags"] & 2) != 0) == (unk != 0)).all() and eng.total_count() == o.total_count()
+    assert code(lambda: eng.set_insert(b"serials::2030-01-01-00::" + eng.issuer_id(0).encode(), b"\x01" * 3) or
+                [eng.set_insert(b"serials::2030-01-01-00::" + eng.issuer_id(0).encode(), bytes([k >> 8, k & 255, 7]))
+                 for k in range(2000)]) == N.E_FULL
+    eng.close()
+
+
+def test_table_grows_and_recovers_tombstones():
+    """Redis grows until OOM (storage/rediscache.go:57-65): the table is rebuilt on the GPU (k_rehash) when a batch
+    could push the load past 3/4 — larger when members were added, the same size when expiry sweeps left tombstones."""
+    cfg = synth.config(seed=3, n_issuers=8, dup_permille=200)
+    issuers = synth.issuers(cfg)
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 14)
+    eng.add_issuers(issuers)
+    eng.set_filter(b"", True, NOW)
+    o = orc.Engine(b"", True, NOW)
+    io = np.zeros(len(issuers) + 1, np.uint64)
+    io[1:] = np.cumsum([len(x) for x in issuers])
+    blob = np.frombuffer(b"".join(issuers), np.uint8)
+    first = 0
+    for n in (500, 700, 3000, 20000, 1000):          # 1 024 slots → 65 536: several rebuilds, duplicates across them
+        b = synth.host_batch(cfg, first, n)
+        res = eng.map_batch(b)
+        st, unk, _ = o.batch(b.payload, b.offsets, b.issuer_idx, blob, io, entry_type=b.entry_type)
+        assert (((res.records["flags"] & 2) != 0) == (unk != 0)).all(), n
+        first += n - 100                              # overlap: the old members must still be found after a rebuild
+    assert eng.total_count() == o.total_count()
+    assert sorted(eng.keys(b"serials::*")) == [k for k in o.keys() if k.startswith(b"serials::")]
+    counts = eng.issuer_counts()
+    for k in range(len(issuers)):
+        assert int(counts[k]) == o.issuer_count(eng.issuer_id(k))
+    key = sorted(eng.keys(b"serials::*"))[len(o.keys()) // 2]
+    assert eng.set_list(key) == o.members(key)
+    # tombstones: expire everything, then fill again and again under a cap that only holds one round
+    eng2 = ctmr.Engine(device=0, table_slots=1 << 13, pair_slots=1 << 14, max_table_slots=1 << 13)
+    eng2.add_issuers(issuers)
+    eng2.set_filter(b"", True, NOW)
+    for rnd in range(6):                              # 6 × 4 000 members through 8 192 slots
+        b = synth.host_batch(cfg, 100000 + rnd * 5000, 5000)
+        res = eng2.map_batch(b)
+        assert res.stats.n_new == eng2.total_count() > 3500
+        assert eng2.expire_sweep(NOW + 400 * 86400) == res.stats.n_new and eng2.total_count() == 0
+    eng2.close()
+    eng.close()
+
+
+def test_members_inserted_before_their_issuer_is_registered_are_migrated():
+    """a Redis restore (storage.redis_load) or a RemoteCache.SetInsert ahead of add_issuers put
+    `serials::` members of a not-yet-registered issuer ID into the host-side store, where the map's dedup never
+    looked.  Registration now moves them into the table."""
+    cfg = synth.config(seed=9, n_issuers=3, dup_permille=0)
+    issuers = synth.issuers(cfg)
+    b = synth.host_batch(cfg, 0, 400)
+    ref = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 12)
+    ref.add_issuers(issuers)
+    ref.set_filter(b"", True, NOW)
+    ref.map_batch(b)
+    dump = {k: ref.set_list(k) for k in ref.keys(b"serials::*")}
+    eng = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 12)
+    eng.set_filter(b"", True, NOW)
+    long_member = bytes(range(1, 60))                 # > CTMR_MAX_SERIAL: stays host-side, but starts to count
+    some_key = sorted(dump)[0]
+    for k, members in dump.items():                   # restore BEFORE any issuer is known
+        for m in members:
+            assert eng.set_insert(k, m)
+    assert eng.set_insert(some_key, long_member)
+    assert sorted(eng.keys(b"serials::*")) == sorted(dump) and eng.total_count() == 0      # no issuer yet: nothing to count under
+    eng.add_issuers(issuers)
+    assert eng.total_count() == ref.total_count() + 1
+    assert (eng.issuer_counts()[:3].sum() == ref.issuer_counts()[:3].sum() + 1)
+    for k, members in dump.items():
+        assert eng.set_list(k) == sorted(members + ([long_member] if k == some_key else []))
+        assert eng.set_cardinality(k) == len(members) + (k == some_key)
+    res = eng.map_batch(b)                            # the restored certificates are KNOWN to the map now
+    assert res.stats.n_new == 0 and res.stats.n_dup == int(res.stats.by_status[0])
+    assert not eng.set_insert(some_key, dump[some_key][0])
+    ref.close()
     eng.close()
 
 

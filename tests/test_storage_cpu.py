@@ -112,6 +112,15 @@ def duplicate_crls_suite(cache):                               # :16-60
     for v in ("http://::1/file.crl", "http://::1/file.crl ", " http://::1/file.crl ", " http://::1/file.crl   "):
         meta.addCRL(v)
         assert len(meta.CRLs()) == 1
+    # url.String(): the same vectors as Suite_DuplicateCRLs in tests/host/test_storage.cpp — both mirrors produce the
+    # same set members
+    meta.addCRL("HTTP://Example.com/a b.crl")                  # scheme lower-cased, path escaped
+    assert sorted(meta.CRLs()) == ["http://::1/file.crl", "http://Example.com/a%20b.crl"]
+    meta.addCRL("http://host:bad/x.crl")                       # invalid port: url.Parse error, ignored
+    meta.addCRL("http://host/%zz")                             # invalid escape, ignored
+    meta.addCRL("http://host/a\tb.crl")                        # control character inside: url.Parse error
+    meta.addCRL("no-scheme/file.crl")
+    assert len(meta.CRLs()) == 2
 
 
 def accumulate_suite(cache):                                   # :100-136
@@ -147,6 +156,13 @@ def test_issuer_dn_string_and_crl_extraction(golden_certs):
                                     "OU=International,O=WISeKey,C=CH")
     assert S.HostCert(D.cert(issuer=D.name(D.rdn(3, b'a,b+c "q"'), D.rdn(10, b" x "))))\
         .issuer_string() == 'CN=a\\,b\\+c \\"q\\",O=\\ x\\ '
+    # attribute types outside the nine FillFromRDNSequence knows (DC, emailAddress) and values that are no Go string
+    # (BMPString) are DROPPED by the pinned CT-go's Name.String(): the issuer:: set member
+    # of a reference deployment does not show them
+    dc = D.tlv(0x31, D.seq(D.oid(0x09, 0x92, 0x26, 0x89, 0x93, 0xf2, 0x2c, 0x64, 0x01, 0x19), D.tlv(0x16, b"example")))
+    mail = D.tlv(0x31, D.seq(D.oid(0x2a, 0x86, 0x48, 0x86, 0xf7, 0x0d, 0x01, 0x09, 0x01), D.tlv(0x16, b"ca@example.org")))
+    odd = D.name(dc, D.rdn(6, b"DE", tag=0x13), D.rdn(10, b"\x00O\x00r\x00g", tag=0x1e), D.rdn(10, b"Org"), mail, D.rdn(3, b"The CA"))
+    assert S.HostCert(D.cert(issuer=odd)).issuer_string() == "CN=The CA,O=Org,C=DE"
 
 
 # ---- filesystemdatabase_test.go (cache-facing parts) --------------------------------------------------
