@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_sizes_match_the_header():
-    assert C.sizeof(N.Config) == 48
+    assert C.sizeof(N.Config) == 56
     assert C.sizeof(N.IssuerInfo) == 4 + 4 + 32 + 48
     assert C.sizeof(N.SynthConfig) == 8 + 6 * 4 + 8 + 8
     assert C.sizeof(N.BatchStats) == 8 + 8 * 8 + 4 * 8 + 5 * 4 + 4     # by_status[CTMR_ST__COUNT = 8]
