@@ -11,7 +11,8 @@ timed step, so every step does the same "first sighting" work.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: the entry stream is sharded by log-index range (rank r owns [r·E, (r+1)·E), weak scaling);
-the only data-path collective is the RCCL all-reduce of the per-issuer count vector.
+the only data-path collective of the default mode is the RCCL all-reduce of the per-issuer count vector, issued by
+the library itself (ctmr_group_issuer_counts); torch.distributed only carries the 128-byte group id at start-up.
 """
 import argparse
 import json
@@ -254,6 +255,21 @@ def synth_is_dup_at(seed, idx, dup_permille, np):
         return (idx > 0) & ((h % np.uint64(1000)) < np.uint64(dup_permille))
 
 
+def share_group_id(dist, rank, make_id):
+    """Control path of `--gpus N`: rank 0 makes the 128-byte group id (ncclGetUniqueId through the library), every rank
+    receives it — the one thing the host carries between its processes; the data path never touches torch.distributed."""
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def max_over_ranks(dist, seconds, dev):
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers):
     """BASELINE config 5 on ONE GPU (the cross-GPU form is distributed.run_global_dedup): a long stream with 10 %
     duplicates, the known-certificate table persisting across waves."""
@@ -400,12 +416,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.gpus > 1 or world > 1:
+        # CONTROL path only: torch.distributed (gloo over 127.0.0.1, the launcher's rendezvous) carries the 128-byte
+        # group id from rank 0 to the others.  Everything on the data path — shard maps, key exchange, Bloom
+        # all-gather, the all-reduce of the per-issuer counts, the barriers and the max-over-ranks of the step time —
+        # goes through the library's own RCCL group (ctmr_group_*, csrc/engine/group.inc).
         import torch.distributed as dist
-        backend = os.environ.get("CTMR_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
-        try:
-            dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
-        except TypeError:                                           # older torch: no device_id argument
-            dist.init_process_group(backend)
+        dist.init_process_group(os.environ.get("CTMR_DIST_BACKEND", "gloo"))
         world, rank = dist.get_world_size(), dist.get_rank()
     else:
         dist = None
@@ -490,16 +506,15 @@ def main():
             torch.cuda.empty_cache()
             E //= 2
     t_gen = time.perf_counter() - t_gen
-    counts_dev = torch.zeros(len(issuers), dtype=torch.int64, device=dev)
-
-    gd_rank = None
-    bloom_rank = None
-    if args.global_dedup == "owner":
-        from ct_mapreduce_amd.distributed import GlobalDedupRank, run_global_dedup
-        gd_rank = GlobalDedupRank(eng, rank, world, dev)
-    elif args.global_dedup == "bloom":
-        from ct_mapreduce_amd.distributed import BloomDedupRank, run_bloom_dedup
-        bloom_rank = BloomDedupRank(eng, rank, world, dev, pow2_at_least(16 * E))   # ≈16 filter bits per key held
+    from ct_mapreduce_amd.distributed import Group, shard as make_shard
+    group = None
+    if dist is not None:
+        group = Group.rccl(eng, share_group_id(dist, rank, Group.unique_id), rank, world)
+    elif args.global_dedup:
+        group = Group.local([eng])          # N = 1: the exchange is local, this measures each mode's kernels
+    if args.global_dedup == "bloom":
+        group.bloom_config(pow2_at_least(16 * E))       # ≈16 filter bits per key held
+    global_counts = [None]
     dstats = []
     meta_ms, meta_items = [], []
     d_items = torch.empty(32 * (1 << 22), dtype=torch.uint8, device=dev) if args.meta else None
@@ -511,12 +526,11 @@ def main():
             st = eng.map_view_device(d_pay.data_ptr(), raw_view["blob_bytes"], raw_view["view"], E, d_rec.data_ptr(),
                                      d_new.data_ptr())
             dstats.append(ds)
-        elif gd_rank is not None:
-            st = run_global_dedup(gd_rank, d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
-                                  d_rec.data_ptr(), d_new.data_ptr())
-        elif bloom_rank is not None:
-            st = run_bloom_dedup(bloom_rank, d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
-                                 d_rec.data_ptr(), d_new.data_ptr(), order_base=rank * E)
+        elif group is not None:
+            # one native call: this rank's shard map + (owner | Bloom) exchange over RCCL (copies when N = 1)
+            st = group.map_batch(args.global_dedup or "local",
+                                 [make_shard(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
+                                             d_rec.data_ptr(), d_new.data_ptr(), order_base=rank * E)])[0]
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
                                       E, d_rec.data_ptr(), d_new.data_ptr())
@@ -527,16 +541,14 @@ def main():
             meta_items.append(eng.meta_new_device(d_pay.data_ptr(), offs_p, ends_p, d_rec.data_ptr(),
                                                   d_new.data_ptr(), int(st.n_new), d_items.data_ptr(), 1 << 22))
             meta_ms.append((time.perf_counter() - t_m) * 1e3)
-        if dist is not None:
-            # per-issuer unique counts merged over xGMI (RCCL all-reduce, 2 KiB)
-            c = torch.from_numpy(eng.issuer_counts().astype(np.int64)).to(dev)
-            dist.all_reduce(c)
-            counts_dev.copy_(c)
+        if group is not None and world > 1:
+            # per-issuer unique counts merged over xGMI: ncclAllReduce inside ctmr_group_issuer_counts (2 KiB)
+            global_counts[0] = group.issuer_counts(len(issuers))
         return st
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if group is not None and world > 1:
+            group.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -550,10 +562,8 @@ def main():
         ms_map.append(stats.ms_map)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if group is not None and world > 1:
+        dt = float(group.all_reduce_u64([int(dt * 1e9)], op_max=True)[0]) * 1e-9      # the slowest rank's time
 
     # HBM traffic of the map kernel per launch: PMC counters can only be collected under rocprofv3, in their own
     # passes — this script re-executes itself under the profiler on a smaller batch of the same corpus (bytes per
@@ -586,7 +596,7 @@ def main():
             traffic = traffic_info["traffic_bytes_per_cert"] * E
 
     n_total = E * world
-    if gd_rank is not None or bloom_rank is not None:   # no per-kernel events here: the map time is not separable
+    if args.global_dedup:   # no per-kernel events here: the map time is not separable
         ms_map = [dt / args.steps * 1e3]
     value = n_total * args.steps / dt
     alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E     # raw mode: payload_bytes is the whole blob — see "raw"
@@ -624,7 +634,8 @@ def main():
                      "alg_bytes_formula": "sum(L_i) + 45*E" + (" + 64*PASS (table probe)" if (args.variant or DEFAULT_VARIANT) in FUSED else "")},
         "kernel_ms": {"map": stats.ms_map, "insert": stats.ms_insert, "resolve": stats.ms_resolve,
                       "compact": stats.ms_compact, "total": stats.ms_total},
-        "result": {"n_new": int(stats.n_new), "n_dup": int(stats.n_dup), "by_status": [int(x) for x in stats.by_status]},
+        "result": {"n_new": int(stats.n_new), "n_dup": int(stats.n_dup), "by_status": [int(x) for x in stats.by_status],
+                   "issuer_counts_all_ranks_sum": int(global_counts[0].sum()) if global_counts[0] is not None else None},
     }
     if args.pem:
         m = min(int(stats.n_new), 16_000_000)
@@ -667,25 +678,21 @@ def main():
         is_new = (d_rec.view(-1, 32)[:E, 1].cpu().numpy() & 2) != 0
         dup = synth_is_dup(cfg.seed, rank * E, E, dup_permille, np)
         bad = int((is_new != ((status == 0) & ~dup)).sum()) + int(int(stats.n_new) != int(is_new.sum()))
-        if dist is not None:
-            t = torch.tensor([bad, int(stats.n_new)], dtype=torch.int64, device=dev)
-            dist.all_reduce(t)
-            bad, n_new_all = int(t[0].item()), int(t[1].item())
-        else:
-            n_new_all = int(stats.n_new)
+        bad, n_new_all = (int(v) for v in group.all_reduce_u64([bad, int(stats.n_new)]))
+        gi = group.info()
         out["result"]["global_dedup"] = {"mode": args.global_dedup, "n_new_all_ranks": n_new_all,
-                                         "entries_disagreeing_with_generator": bad}
-    if bloom_rank is not None:
-        out["config"]["parallelism"] = f"log-index shards x{world} + Bloom-filter all-gather pre-filter + exact lookup (global dedup)"
-        out["roofline"]["kernel"] = "whole Bloom-mode step (map + insert + filter add + all-gather + probe + lookup + apply)"
+                                         "entries_disagreeing_with_generator": bad,
+                                         "transport": "rccl" if gi.transport else "local (one rank: copies)",
+                                         "key_records_sent_by_rank0": int(gi.keys_sent),
+                                         "filter_bytes_received_by_rank0": int(gi.filter_bytes_received)}
         out["roofline"]["note"] = "avg_launch_ms is the wall time of the whole step, not one kernel"
-        out["result"]["global_dedup"].update({"filter_bytes_per_rank": bloom_rank.n_words * 8,
-                                              "key_records_sent_by_rank0": int(bloom_rank.n_keys)})
-    if gd_rank is not None:
-        out["result"]["global_dedup"]["key_records_sent_by_rank0"] = int(gd_rank.n_keys)
-        out["config"]["parallelism"] = f"log-index shards x{world} + owner-computes key exchange (global dedup)"
-        out["roofline"]["kernel"] = "whole exchange-mode step (export + all-to-all + owner insert + apply)"
-        out["roofline"]["note"] = "avg_launch_ms is the wall time of the whole step, not one kernel"
+        out["roofline"]["achieved"] = out["roofline"]["frac"] = None      # no single kernel to price: see kernel_ms of the default mode
+        if args.global_dedup == "bloom":
+            out["config"]["parallelism"] = f"log-index shards x{world} + Bloom-filter all-gather pre-filter + exact lookup (global dedup)"
+            out["roofline"]["kernel"] = "whole Bloom-mode step (map + insert + filter add + all-gather + probe + lookup + apply)"
+        else:
+            out["config"]["parallelism"] = f"log-index shards x{world} + owner-computes key exchange (global dedup)"
+            out["roofline"]["kernel"] = "whole exchange-mode step (export + all-to-all + owner insert + apply)"
     if args.fingerprint and not args.raw:
         d_dg = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         fp_ms = [eng.fingerprint_device(d_pay.data_ptr(), d_off.data_ptr(), 0, E, d_dg.data_ptr()) for _ in range(3)]
@@ -795,6 +802,8 @@ def main():
                     "pass_count_matches_gpu": bool(ok_mt),
                     "one_core": {"value": base["value"], "sample": base["sample"]}}
         print(json.dumps(out))
+    if group is not None:
+        group.close()
     if dist is not None:
         dist.destroy_process_group()
     eng.close()

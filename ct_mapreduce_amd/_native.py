@@ -49,6 +49,22 @@ class DecodeStats(C.Structure):
 
 
 MK_EXPDATE, MK_CRL, MK_DN, MK_HOST = range(4)
+DEDUP_LOCAL, DEDUP_OWNER, DEDUP_BLOOM = range(3)
+TRANSPORT_LOCAL, TRANSPORT_RCCL = range(2)
+GROUP_ID_BYTES = 128
+
+
+class Shard(C.Structure):
+    _fields_ = [("d_payload", C.c_void_p), ("d_offsets", C.c_void_p), ("d_ends", C.c_void_p),
+                ("d_issuer_idx", C.c_void_p), ("d_entry_type", C.c_void_p), ("n", C.c_uint64),
+                ("blob_bytes", C.c_uint64), ("order_base", C.c_uint64), ("d_records", C.c_void_p),
+                ("d_new_idx", C.c_void_p)]
+
+
+class GroupStats(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("n_local", C.c_uint32), ("transport", C.c_uint32),
+                ("first_local_rank", C.c_uint32), ("keys_sent", C.c_uint64), ("keys_received", C.c_uint64),
+                ("filter_bytes_received", C.c_uint64)]
 
 
 class MetaItem(C.Structure):
@@ -113,6 +129,18 @@ SIGNATURES = {
                                           _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "ctmr_bloom_lookup_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),
     "ctmr_bloom_apply_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P, C.POINTER(BatchStats)]),
+    "ctmr_group_create_local": (C.c_int, [C.POINTER(_P), C.c_uint32, C.POINTER(_P)]),
+    "ctmr_group_unique_id": (C.c_int, [C.c_char_p]),
+    "ctmr_group_create_rccl": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "ctmr_group_destroy": (None, [_P]),
+    "ctmr_group_last_error": (C.c_char_p, [_P]),
+    "ctmr_group_info": (C.c_int, [_P, C.POINTER(GroupStats)]),
+    "ctmr_group_bloom_config": (C.c_int, [_P, C.c_uint64]),
+    "ctmr_group_map_batch": (C.c_int, [_P, C.c_int, C.POINTER(Shard), C.POINTER(BatchStats)]),
+    "ctmr_group_issuer_counts": (C.c_int, [_P, _P, C.c_uint32]),
+    "ctmr_group_total_count": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ctmr_group_all_reduce_u64": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
+    "ctmr_group_barrier": (C.c_int, [_P]),
     "ctmr_pem_encode_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "ctmr_set_issuer_autoregister": (C.c_int, [_P, C.c_int]),
     "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),

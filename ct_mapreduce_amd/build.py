@@ -38,7 +38,7 @@ def build(force=False, verbose=False, sweep=False):
         return lib
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"] + (["-DCTMR_SWEEP"] if sweep else []) + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", lib]
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", lib]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

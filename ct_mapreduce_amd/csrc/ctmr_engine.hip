@@ -6,6 +6,8 @@
 // issuer registry.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -468,6 +470,7 @@ extern "C" {
 #include "engine/pem.inc"
 #include "engine/exchange.inc"
 #include "engine/sets.inc"
+#include "engine/group.inc"
 #include "engine/synth.inc"
 
 }  // extern "C"

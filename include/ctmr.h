@@ -269,6 +269,72 @@ int ctmr_bloom_lookup_device(ctmr_engine* e, const void* d_keys, uint64_t n_keys
 int ctmr_bloom_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, const void* d_keys_sent,
                             const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx, ctmr_batch_stats* stats);
 
+/* ---- multi-GPU groups: the shared set service of a sharded deployment, natively behind this ABI.  Replaces what one
+ *      Redis server gives N ct-fetch processes that split a log by -offset/-limit (cmd/ct-fetch/ct-fetch.go:288-305;
+ *      storage/rediscache.go:21-65: SADD answers "was new" for all of them).  A group has `world` ranks, each an
+ *      engine on one GPU that maps the entries of its log-index shard; one ctmr_group_map_batch call per round runs the
+ *      shard maps AND the exchange that makes the dedup global; ctmr_group_issuer_counts is the all-reduce of the
+ *      per-issuer counts.  Two transports, the same per-rank kernels in the same order:
+ *        ctmr_group_create_local  every rank lives in this process (one engine per device — a single host process
+ *                                 driving the node's GPUs — or several engines on one device): device-to-device copies
+ *        ctmr_group_create_rccl   one process per GPU: RCCL over xGMI (ncclSend/ncclRecv all-to-all, ncclAllGather of
+ *                                 the Bloom filters, ncclAllReduce of the counts); librccl is loaded on demand.
+ *                                 id = the bytes ctmr_group_unique_id produced on one rank, handed to the others by the
+ *                                 host over any channel it has.
+ *      Engines must have registered the same issuers in the same order (key records carry canonical issuer indices);
+ *      they stay usable on their own; destroy the group before its engines.
+ *   modes   CTMR_DEDUP_LOCAL  shard-local dedup only (exact when no key spans two shards: BASELINE config 4)
+ *           CTMR_DEDUP_OWNER  owner-computes key exchange (ctmr_exchange_* above): export → all-to-all → owner insert
+ *                             → flags back → apply.  Every key is stored once, on rank hash(key) mod world.
+ *           CTMR_DEDUP_BLOOM  all-gather of per-GPU Bloom filters as an exact pre-filter (ctmr_bloom_* above; needs
+ *                             ctmr_group_bloom_config): local insert → filter all-gather → probe → key records only to
+ *                             the peers whose filter matched → exact lookup → flags back → apply
+ *   shards  one ctmr_shard per LOCAL rank (rank order), device pointers on that rank's GPU, as ctmr_map_batch_device
+ *           takes them; d_ends != NULL: an entry view (d_offsets = cert_start, d_ends = cert_end, blob_bytes set).
+ *           order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown).
+ *           d_records is required in the OWNER and BLOOM modes.  stats: one per local rank (may be NULL). ---- */
+typedef struct ctmr_group ctmr_group;
+#define CTMR_GROUP_ID_BYTES 128
+enum { CTMR_DEDUP_LOCAL = 0, CTMR_DEDUP_OWNER = 1, CTMR_DEDUP_BLOOM = 2 };
+enum { CTMR_TRANSPORT_LOCAL = 0, CTMR_TRANSPORT_RCCL = 1 };
+typedef struct {
+  const uint8_t* d_payload;
+  const uint64_t* d_offsets;
+  const uint64_t* d_ends;       /* NULL = packed batch */
+  const uint32_t* d_issuer_idx;
+  const uint8_t* d_entry_type;  /* may be NULL */
+  uint64_t n;
+  uint64_t blob_bytes;          /* entry view only */
+  uint64_t order_base;
+  ctmr_record* d_records;
+  uint64_t* d_new_idx;          /* may be NULL */
+} ctmr_shard;
+typedef struct {
+  uint32_t world, n_local, transport, first_local_rank;
+  /* what the last ctmr_group_map_batch moved between ranks, summed over the local ranks */
+  uint64_t keys_sent, keys_received;   /* 64-byte key records to / from OTHER ranks */
+  uint64_t filter_bytes_received;      /* Bloom mode: the peers' filters, per local rank */
+} ctmr_group_stats;
+int ctmr_group_create_local(ctmr_engine* const* engines, uint32_t n, ctmr_group** out);
+int ctmr_group_unique_id(uint8_t id[CTMR_GROUP_ID_BYTES]);
+int ctmr_group_create_rccl(ctmr_engine* engine, const uint8_t id[CTMR_GROUP_ID_BYTES], uint32_t rank, uint32_t world,
+                           ctmr_group** out);
+void ctmr_group_destroy(ctmr_group* g);
+const char* ctmr_group_last_error(const ctmr_group* g);
+int ctmr_group_info(ctmr_group* g, ctmr_group_stats* out);
+/* bits per rank: power of two, ≈16 per key a rank will ever hold; same on every rank. */
+int ctmr_group_bloom_config(ctmr_group* g, uint64_t bits);
+int ctmr_group_map_batch(ctmr_group* g, int mode, const ctmr_shard* shards, ctmr_batch_stats* stats);
+/* Σ over ALL ranks of ctmr_issuer_counts / ctmr_total_count (storage-statistics.go:44-53 over the whole deployment):
+ * the ncclAllReduce of the per-issuer count vector in the RCCL transport. */
+int ctmr_group_issuer_counts(ctmr_group* g, uint64_t* out, uint32_t n);
+int ctmr_group_total_count(ctmr_group* g, uint64_t* out);
+/* Sum (op_max = 0) or maximum (1) over the ranks of n host-side u64 values, in place, and a barrier: what a
+ * multi-process host needs besides the data path (the round's global NEW count, the slowest rank's time) without a
+ * second communication library.  No-ops for a local group (the caller holds every rank's values). */
+int ctmr_group_all_reduce_u64(ctmr_group* g, uint64_t* values, uint32_t n, int op_max);
+int ctmr_group_barrier(ctmr_group* g);
+
 /* ---- PEM write-back: replaces pem.EncodeToMemory(&pem.Block{Type: "CERTIFICATE",
  *      Bytes: aCert.Raw}) of FilesystemDatabase.Store (storage/filesystemdatabase.go:167-175,196-200); the host
  *      hands each PEM to StorageBackend.StoreCertificatePEM (storage/localdiskbackend.go:194-199).

@@ -1,6 +1,9 @@
-"""world_size-2 gloo test of the multi-GPU host logic (shard ranges + count all-reduce).
-The per-rank map is the ORACLE here (tests may use it as the checker/stand-in); on GPUs the same
-driver is fed Engine.map_batch (bench.py --gpus N)."""
+"""CPU side of the multi-GPU path.  The data path (shard maps, key exchange, Bloom all-gather, count all-reduce) is
+native and needs GPUs (tests/test_gpu_exchange.py, test_gpu_bloom.py drive it through a local group); what is left
+for the host — and tested here, with world_size-2 `gloo` processes — is the shard arithmetic, carrying the 128-byte
+group id from one rank to all (bench.py's control path) and the property the shard-local mode rests on: per-issuer
+counts of log-index shards add up to the single-process counts when no key spans two shards (BASELINE config 4).
+The per-rank map is the ORACLE here (a stand-in for the engine, as the checker may be)."""
 import os
 import sys
 
@@ -8,7 +11,9 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from ct_mapreduce_amd.distributed import shard_range
+from ct_mapreduce_amd.distributed import shard_range, union_in_agreed_order, decode_synchronised
+from ct_mapreduce_amd.engine import CtmrError
+from ct_mapreduce_amd import _native as N
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -24,13 +29,22 @@ def test_shard_ranges_partition_the_stream():
 
 def _worker(rank, world, port, n_total, out):
     sys.path.insert(0, ROOT)
+    import torch
     import torch.distributed as dist
+    import bench
     from ct_mapreduce_amd import synth
-    from ct_mapreduce_amd.distributed import run_sharded
     from oracle import oracle as orc
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py's control path: rank 0 makes the group id, every rank ends up with the same 128 bytes
+    gid = bench.share_group_id(dist, rank, lambda: bytes([7]) * 100 + os.urandom(28))
+    assert len(gid) == 128 and gid[:100] == bytes([7]) * 100
+    box = [None] * world
+    dist.all_gather_object(box, gid)
+    assert all(b == box[0] for b in box)
+    assert bench.max_over_ranks(dist, 1.0 + rank, torch.device("cpu")) == float(world)
+    # the shard-local mode: rank r maps [lo, hi) with its own known-certificate sets; counts are summed
     cfg = synth.config(seed=77, n_issuers=8, dup_permille=0, ca_permille=20, expired_permille=20)
     issuers = synth.issuers(cfg)
     ids = [orc.issuer_id(d[orc.parse_cert(d).spki_off:][:orc.parse_cert(d).spki_len]) for d in issuers]
@@ -38,15 +52,13 @@ def _worker(rank, world, port, n_total, out):
     io[1:] = np.cumsum([len(x) for x in issuers])
     blob = np.frombuffer(b"".join(issuers), np.uint8)
     eng = orc.Engine(b"Synth Issuer 00", False, synth.BASE_TIME)
-
-    def map_fn(b):
-        st, unk, eh = eng.batch(b.payload, b.offsets, b.issuer_idx, blob, io)
-        return int(unk.sum())
-
-    res = run_sharded(n_total, len(issuers), lambda lo, hi: synth.host_batch(cfg, lo, hi - lo), map_fn,
-                      lambda: np.array([eng.issuer_count(i) for i in ids], dtype=np.uint64))
+    lo, hi = shard_range(n_total, rank, world)
+    b = synth.host_batch(cfg, lo, hi - lo)
+    st, unk, eh = eng.batch(b.payload, b.offsets, b.issuer_idx, blob, io, entry_type=b.entry_type)
+    t = torch.tensor([int(unk.sum())] + [eng.issuer_count(i) for i in ids], dtype=torch.int64)
+    dist.all_reduce(t)                      # what ctmr_group_issuer_counts does natively (ncclAllReduce)
     if rank == 0:
-        np.save(out, np.concatenate([[res.n_new_global], res.global_counts]))
+        np.save(out, t.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,269 +79,54 @@ def test_two_rank_gloo_counts_match_single_process(tmp_path):
     io[1:] = np.cumsum([len(x) for x in issuers])
     eng = orc.Engine(b"Synth Issuer 00", False, synth.BASE_TIME)
     b = synth.host_batch(cfg, 0, n_total)
-    st, unk, eh = eng.batch(b.payload, b.offsets, b.issuer_idx, np.frombuffer(b"".join(issuers), np.uint8), io)
+    st, unk, eh = eng.batch(b.payload, b.offsets, b.issuer_idx, np.frombuffer(b"".join(issuers), np.uint8), io,
+                            entry_type=b.entry_type)
     ids = [orc.issuer_id(d[orc.parse_cert(d).spki_off:][:orc.parse_cert(d).spki_len]) for d in issuers]
     want = [int(unk.sum())] + [eng.issuer_count(i) for i in ids]
     assert list(got) == want
 
 
-# ------------------------------------------------------------------------------------------------
-# The cross-rank key exchange driver (distributed.run_global_dedup: counts all-gather, key partitions to their
-# owners in sender-rank order, flags back in export order) under world_size-3 gloo.  The per-rank engine is a
-# CPU stand-in built on the ORACLE's field extraction with the same three calls as Engine.exchange_* — what is
-# under test is the data movement between processes, which cannot run on GPUs here (one GPU per gpurun box).
-class _FakeExchangeEngine:
-    KEY = 64
+class _FakeEngine:
+    """Issuer registry of an engine with auto-registration off: a decode lists what it has not seen registered."""
 
-    def __init__(self, filt, now):
-        from oracle import oracle as orc
-        self.orc, self.filt, self.now = orc, filt, now
-        self.known = set()
-        self.flags_by_entry = None
+    def __init__(self, needs):
+        self.needs, self.registered, self.calls = list(needs), [], 0
 
-    @staticmethod
-    def _view(ptr, nbytes):
-        import ctypes
-        return np.ctypeslib.as_array((ctypes.c_uint8 * max(nbytes, 1)).from_address(ptr))
+    def decode(self):
+        self.calls += 1
+        self._pending = [d for d in self.needs if d not in self.registered]
+        if self._pending:
+            raise CtmrError(N.E_NOTFOUND, "unregistered Chain[0] certificates")
+        return "decoded"
 
-    def exchange_export(self, batch, _o, _i, _e, n, _r, world, d_keys_out):
-        import zlib
-        orc = self.orc
-        parts = [[] for _ in range(world)]
-        for i in range(n):
-            der = batch.cert(i)
-            c = orc.parse_cert(der)
-            if not c.ok or orc.is_filtered_out(der, c, self.filt, False, self.now) != orc.ST_PASS:
-                continue
-            key = b"%d|%d|" % (orc.exp_hour(c.not_after), int(batch.issuer_idx[i])) + der[c.serial_off:c.serial_off + c.serial_len]
-            rec = i.to_bytes(8, "little") + len(key).to_bytes(2, "little") + key
-            assert len(rec) <= self.KEY
-            parts[zlib.crc32(key) % world].append(rec.ljust(self.KEY, b"\0"))
-        out = self._view(d_keys_out, n * self.KEY)
-        blob = b"".join(b"".join(p) for p in parts)
-        out[:len(blob)] = np.frombuffer(blob, np.uint8)
-        self.n = n
-        return [len(p) for p in parts]
+    def pending_issuers(self):
+        return list(self._pending)
 
-    def exchange_insert(self, d_keys, n_keys, d_flags):
-        keys, flags = self._view(d_keys, n_keys * self.KEY), self._view(d_flags, n_keys)
-        new = 0
-        for k in range(n_keys):
-            rec = keys[k * self.KEY:(k + 1) * self.KEY].tobytes()
-            key = rec[10:10 + int.from_bytes(rec[8:10], "little")]
-            flags[k] = key not in self.known
-            new += int(flags[k])
-            self.known.add(key)
-        return new
-
-    def exchange_apply(self, _records, n, d_keys_sent, d_flags, n_keys, _new_idx):
-        keys, flags = self._view(d_keys_sent, n_keys * self.KEY), self._view(d_flags, n_keys)
-        self.flags_by_entry = np.zeros(n, np.uint8)
-        for k in range(n_keys):
-            self.flags_by_entry[int.from_bytes(keys[k * self.KEY:k * self.KEY + 8].tobytes(), "little")] = flags[k]
-        return int(self.flags_by_entry.sum())
+    def add_issuers(self, ders):
+        self.registered += list(ders)
 
 
-def _exchange_worker(rank, world, port, n_total, outdir):
-    sys.path.insert(0, ROOT)
-    import torch
-    import torch.distributed as dist
-    from ct_mapreduce_amd import synth
-    from ct_mapreduce_amd.distributed import GlobalDedupRank, run_global_dedup, shard_range
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = synth.config(seed=78, n_issuers=8, dup_permille=300, ca_permille=20, expired_permille=20)
-    eng = _FakeExchangeEngine(b"Synth Issuer 00", synth.BASE_TIME)
-    ro = GlobalDedupRank(eng, rank, world, torch.device("cpu"))
-    got = []
-    for lo_all, hi_all in ((0, n_total // 2), (n_total // 2, n_total)):          # two waves: the owners' sets persist
-        lo, hi = shard_range(hi_all - lo_all, rank, world)
-        b = synth.host_batch(cfg, lo_all + lo, hi - lo)
-        run_global_dedup(ro, b, 0, 0, 0, b.n, 0)
-        got.append((lo_all + lo, eng.flags_by_entry.copy()))
-    np.save(os.path.join(outdir, f"flags_{rank}.npy"), np.array(got, dtype=object), allow_pickle=True)
-    dist.barrier()
-    dist.destroy_process_group()
+def test_issuer_tables_are_synchronised_in_an_agreed_order():
+    assert union_in_agreed_order([[b"b", b"a"], [b"c", b"a"], []]) == [b"a", b"b", b"c"]
+    e0, e1 = _FakeEngine([b"iss-2", b"iss-1"]), _FakeEngine([b"iss-3", b"iss-1"])
+    res = decode_synchronised([e0, e1], [e0.decode, e1.decode])
+    assert res == ["decoded", "decoded"]
+    assert e0.registered == e1.registered == [b"iss-1", b"iss-2", b"iss-3"]      # the same certificates, the same order
+    # one process per rank: the host supplies the gather
+    a, b = _FakeEngine([b"x"]), _FakeEngine([b"y", b"x"])
+    pend_b = [b"y", b"x"]
+    assert decode_synchronised(a, a.decode, gather=lambda mine: [mine, [d for d in pend_b if d not in a.registered]]) == "decoded"
+    assert a.registered == [b"x", b"y"]
+    with pytest.raises(ValueError):
+        decode_synchronised(a, a.decode)
 
 
-@pytest.mark.timeout(600)
-def test_three_rank_gloo_key_exchange_matches_single_process(tmp_path):
-    from ct_mapreduce_amd import synth
-    from oracle import oracle as orc
-    n_total, world = 2400, 3
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_exchange_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
-    flags = np.zeros(n_total, np.uint8)
-    for r in range(world):
-        for first, f in np.load(tmp_path / f"flags_{r}.npy", allow_pickle=True):
-            flags[first:first + len(f)] = f
-    # single process, whole stream in log order: the reference loop
-    cfg = synth.config(seed=78, n_issuers=8, dup_permille=300, ca_permille=20, expired_permille=20)
-    issuers = synth.issuers(cfg)
-    io = np.zeros(len(issuers) + 1, np.uint64)
-    io[1:] = np.cumsum([len(x) for x in issuers])
-    eng = orc.Engine(b"Synth Issuer 00", False, synth.BASE_TIME)
-    b = synth.host_batch(cfg, 0, n_total)
-    st, unk, eh = eng.batch(b.payload, b.offsets, b.issuer_idx, np.frombuffer(b"".join(issuers), np.uint8), io)
-    assert 0 < unk.sum() < (st == 0).sum()                     # there ARE cross-shard duplicates
-    assert (flags == unk).all()
-
-
-# ------------------------------------------------------------------------------------------------
-# The Bloom pre-filter variant of the global dedup (distributed.run_bloom_dedup: local insert → filter all-gather →
-# probe → key records to the peers whose filter matched → exact lookup → flags back → apply) under world_size-3 gloo,
-# three rounds.  The per-rank engine is a CPU stand-in with the same calls as Engine.map_batch_device / bloom_*,
-# built on the ORACLE's field extraction; what is under test is the protocol and the data movement between processes.
-class _FakeBloomEngine:
-    KEY = 64
-
-    def __init__(self, filt, now):
-        from oracle import oracle as orc
-        self.orc, self.filt, self.now = orc, filt, now
-        self.known = {}           # key → (epoch, batch index)
-        self.epoch = 0
-        self.exchanged = 0
-
-    _view = staticmethod(_FakeExchangeEngine._view)
-
-    @staticmethod
-    def _pos(key, n_words):
-        import hashlib
-        g = int.from_bytes(hashlib.sha256(key).digest()[:8], "little")
-        bits = 0
-        for sh in (40, 46, 52, 58):
-            bits |= 1 << ((g >> sh) & 63)
-        return g % n_words, bits
-
-    def bloom_config(self, bits, d_words):
-        import ctypes
-        self.n_words = bits // 64
-        self.words = np.ctypeslib.as_array((ctypes.c_uint64 * self.n_words).from_address(d_words))
-        self.words[:] = 0
-
-    def map_batch_device(self, batch, _o, _i, _e, n, _r):
-        orc = self.orc
-        self.epoch += 1
-        self.keys_of = [None] * n
-        self.flags_by_entry = np.zeros(n, np.uint8)
-        for i in range(n):
-            der = batch.cert(i)
-            c = orc.parse_cert(der)
-            if not c.ok or orc.is_filtered_out(der, c, self.filt, False, self.now) != orc.ST_PASS:
-                continue
-            key = b"%d|%d|" % (orc.exp_hour(c.not_after), int(batch.issuer_idx[i])) + der[c.serial_off:c.serial_off + c.serial_len]
-            if key not in self.known:
-                self.known[key] = (self.epoch, i)
-                self.keys_of[i] = key
-                self.flags_by_entry[i] = 1
-
-    def bloom_add(self, _p, _o, _e, n, _r):
-        self.round_epoch = self.epoch if n else 0
-        for i in range(n):
-            if self.keys_of[i] is not None:
-                w, bits = self._pos(self.keys_of[i], self.n_words)
-                self.words[w] |= np.uint64(bits)
-
-    def bloom_probe(self, _p, _o, _e, n, _r, d_filters, world, rank, order_base, d_keys_out, cap):
-        import ctypes
-        filters = np.ctypeslib.as_array((ctypes.c_uint64 * (world * self.n_words)).from_address(d_filters))
-        parts = [[] for _ in range(world)]
-        for i in range(n):
-            key = self.keys_of[i]
-            if key is None:
-                continue
-            w, bits = self._pos(key, self.n_words)
-            for p in range(world):
-                if p != rank and (int(filters[p * self.n_words + w]) & bits) == bits:
-                    rec = i.to_bytes(8, "little") + (order_base + i).to_bytes(8, "little") + len(key).to_bytes(2, "little") + key
-                    assert len(rec) <= self.KEY
-                    parts[p].append(rec.ljust(self.KEY, b"\0"))
-        counts = [len(p) for p in parts]
-        if sum(counts) > cap:
-            return counts, False
-        blob = b"".join(b"".join(p) for p in parts)
-        self._view(d_keys_out, cap * self.KEY)[:len(blob)] = np.frombuffer(blob, np.uint8)
-        self.exchanged += sum(counts)
-        return counts, True
-
-    def bloom_lookup(self, d_keys, n_keys, order_base, d_flags):
-        keys, flags = self._view(d_keys, n_keys * self.KEY), self._view(d_flags, n_keys)
-        for k in range(n_keys):
-            rec = keys[k * self.KEY:(k + 1) * self.KEY].tobytes()
-            order = int.from_bytes(rec[8:16], "little")
-            key = rec[18:18 + int.from_bytes(rec[16:18], "little")]
-            hit = self.known.get(key)
-            flags[k] = hit is not None and (hit[0] != self.round_epoch or order_base + hit[1] < order)
-
-    def bloom_apply(self, _records, n, d_keys_sent, d_flags, n_keys, _new_idx):
-        keys, flags = self._view(d_keys_sent, n_keys * self.KEY), self._view(d_flags, n_keys)
-        for k in range(n_keys):
-            if flags[k]:
-                self.flags_by_entry[int.from_bytes(keys[k * self.KEY:k * self.KEY + 8].tobytes(), "little")] = 0
-        return int(self.flags_by_entry.sum())
-
-
-def _bloom_worker(rank, world, port, n_total, bits, outdir):
-    sys.path.insert(0, ROOT)
-    import torch
-    import torch.distributed as dist
-    from ct_mapreduce_amd import synth
-    from ct_mapreduce_amd.distributed import BloomDedupRank, run_bloom_dedup, shard_range
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = synth.config(seed=79, n_issuers=8, dup_permille=300, ca_permille=20, expired_permille=20)
-    eng = _FakeBloomEngine(b"Synth Issuer 00", synth.BASE_TIME)
-    ro = BloomDedupRank(eng, rank, world, torch.device("cpu"), bits)
-    got = []
-    third = n_total // 3
-    for lo_all, hi_all in ((0, third), (third, 2 * third), (2 * third, n_total)):   # tables and filters persist
-        lo, hi = shard_range(hi_all - lo_all, rank, world)
-        # rank 2 sits out the second round: an empty batch must not disturb the protocol
-        n = 0 if (rank == 2 and lo_all == third) else hi - lo
-        b = synth.host_batch(cfg, lo_all + lo, n)
-        run_bloom_dedup(ro, b, 0, 0, 0, b.n, 0, order_base=lo_all + lo)
-        got.append((lo_all + lo, eng.flags_by_entry.copy() if n else np.zeros(0, np.uint8), n))
-    np.save(os.path.join(outdir, f"bloom_{rank}.npy"), np.array(got, dtype=object), allow_pickle=True)
-    with open(os.path.join(outdir, f"bloom_exchanged_{rank}.txt"), "w") as f:
-        f.write(str(eng.exchanged))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("bits", [1 << 16, 1 << 9])
-def test_three_rank_gloo_bloom_dedup_matches_single_process(tmp_path, bits):
-    from ct_mapreduce_amd import synth
-    from oracle import oracle as orc
-    n_total, world = 2400, 3
-    port = 33500 + (os.getpid() % 2000) + (1 if bits == 1 << 9 else 0)
-    mp.spawn(_bloom_worker, args=(world, port, n_total, bits, str(tmp_path)), nprocs=world, join=True)
-    flags = np.zeros(n_total, np.uint8)
-    seen = np.zeros(n_total, bool)
-    for r in range(world):
-        for first, f, n in np.load(tmp_path / f"bloom_{r}.npy", allow_pickle=True):
-            flags[first:first + n] = f
-            seen[first:first + n] = True
-    # single process, the entries the ranks saw, in log order: the reference loop
-    cfg = synth.config(seed=79, n_issuers=8, dup_permille=300, ca_permille=20, expired_permille=20)
-    issuers = synth.issuers(cfg)
-    io = np.zeros(len(issuers) + 1, np.uint64)
-    io[1:] = np.cumsum([len(x) for x in issuers])
-    eng = orc.Engine(b"Synth Issuer 00", False, synth.BASE_TIME)
-    b = synth.host_batch(cfg, 0, n_total)
-    unk = np.zeros(n_total, np.uint8)
-    idx = np.nonzero(seen)[0]
-    assert 0 < len(idx) < n_total
-    n_pass = 0
-    for i in idx:                                              # skipped entries never reach the reference loop
-        st_i, unk[i], _ = eng.entry(b.cert(int(i)), issuers[int(b.issuer_idx[i])])
-        n_pass += st_i == orc.ST_PASS
-    assert 0 < unk.sum()
-    assert (flags == unk).all(), np.nonzero(flags != unk)[0][:10]
-    exchanged = sum(int(open(tmp_path / f"bloom_exchanged_{r}.txt").read()) for r in range(world))
-    if bits == 1 << 16:
-        assert 0 < exchanged < n_pass // 2                     # most keys never leave their rank
-    else:
-        assert exchanged > n_pass // 2                         # 8-word filter, saturated: nearly everything is checked exactly
+def test_group_entry_points_reject_bad_arguments_without_a_gpu():
+    import ctypes as C
+    lib = N.lib()
+    h = C.c_void_p()
+    assert lib.ctmr_group_create_local(None, 0, C.byref(h)) == N.E_INVAL
+    assert lib.ctmr_group_create_rccl(None, b"\0" * 128, 0, 1, C.byref(h)) == N.E_INVAL
+    assert lib.ctmr_group_map_batch(None, 0, None, None) == N.E_INVAL
+    assert lib.ctmr_group_issuer_counts(None, None, 0) == N.E_INVAL
+    lib.ctmr_group_destroy(None)

@@ -1,8 +1,9 @@
 """-m gpu: cross-GPU global dedup, Bloom pre-filter variant (BASELINE north_star "all-gather of per-GPU Bloom
-fingerprints") validated on one GPU: a simulated world of 1–4 ranks (several engines on one
-device, tensor copies instead of collectives) equals the oracle over the WHOLE stream — one round, several rounds with
-duplicates across rounds and ranks, a filter so small that false positives dominate — and equals the
-owner-computes exchange."""
+fingerprints") through the NATIVE group layer on one GPU: a local group of 1–4 ranks (several
+engines on one device: the RCCL transport's phase drivers and kernels, copies where it would send) equals the oracle
+over the WHOLE stream — one round, several rounds with duplicates across rounds and ranks, a filter so small that
+false positives dominate — and equals the owner-computes exchange.  (tests/test_gpu_exchange.py runs both modes
+through the same scenarios; this file holds what is specific to the filters.)"""
 import numpy as np
 import pytest
 
@@ -12,17 +13,18 @@ import torch  # noqa: E402
 
 import ct_mapreduce_amd as ctmr
 from ct_mapreduce_amd import synth, _native as N
-from ct_mapreduce_amd.distributed import (BloomDedupRank, GlobalDedupRank, run_bloom_dedup, run_simulated,
-                                          run_simulated_bloom, shard_range)
+from ct_mapreduce_amd.distributed import Group, shard_range
 from ct_mapreduce_amd.engine import RECORD_DTYPE
 from oracle import oracle as orc
 from tests.gpu_common import run_oracle
-from tests.test_gpu_exchange import to_dev, make_engine, FILT, NOW, DEV
+from tests.test_gpu_exchange import to_dev, dev_shard, make_engine, FILT, NOW, DEV
 
 
 def build_world(world, issuers, bits):
     engines = [make_engine(issuers) for _ in range(world)]
-    return engines, [BloomDedupRank(engines[r], r, world, DEV, bits) for r in range(world)]
+    g = Group.local(engines)
+    g.bloom_config(bits)
+    return engines, g
 
 
 def load_shards(cfg, lo_all, hi_all, world):
@@ -33,7 +35,7 @@ def load_shards(cfg, lo_all, hi_all, world):
         b = synth.host_batch(cfg, lo, hi - lo)
         t = to_dev(b)
         keep.append(t)
-        shards.append((t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), b.n, t[4].data_ptr()))
+        shards.append(dev_shard(t, b.n, order_base=lo))
         ranges.append((lo, hi))
     return shards, keep, ranges
 
@@ -53,13 +55,11 @@ def check_round(keep, ranges, stats, st, unk, base=0):
             assert stats[r].by_status[k] == int((st[lo:hi] == k).sum())
 
 
-def check_state(engines, o, n_issuers):
-    total = np.zeros(n_issuers, dtype=np.uint64)
-    for e in engines:
-        total += e.issuer_counts()
+def check_state(engines, g, o, n_issuers):
+    total = g.issuer_counts(n_issuers)
     for k in range(n_issuers):
         assert int(total[k]) == o.issuer_count(engines[0].issuer_id(k)), k
-    assert sum(e.total_count() for e in engines) == o.total_count()
+    assert g.total_count() == o.total_count() == sum(e.total_count() for e in engines)
     okeys = [k for k in o.keys() if k.startswith(b"serials::")]
     assert sorted(set(sum((e.keys(b"serials::*") for e in engines), []))) == okeys
     # the ranks' sets are disjoint: cardinalities and member lists add up to the oracle's
@@ -77,20 +77,21 @@ def test_bloom_dedup_matches_oracle_over_the_whole_stream(world):
     issuers = synth.issuers(cfg)
     o, st, unk, eh = run_oracle(synth.host_batch(cfg, 0, n_total), issuers, FILT, False, NOW)
     assert 0 < unk.sum() < (st == 0).sum()
-    engines, ranks = build_world(world, issuers, 1 << 17)
+    engines, g = build_world(world, issuers, 1 << 17)
     shards, keep, ranges = load_shards(cfg, 0, n_total, world)
-    if world == 1:
-        stats = [run_bloom_dedup(ranks[0], *shards[0], keep[0][5].data_ptr())]
+    stats = g.map_batch("bloom", shards)
+    info = g.info()
+    if world > 1:
+        assert 0 < info.keys_sent < int((st == 0).sum())           # cross-rank duplicates were exchanged, most keys were not
+        assert info.filter_bytes_received == (world - 1) * (1 << 17) // 8
     else:
-        stats = run_simulated_bloom(ranks, shards, [k[5].data_ptr() for k in keep], [lo for lo, _ in ranges])
-        assert sum(sum(r.send_counts) for r in ranks) > 0            # cross-rank duplicates were exchanged …
-        assert sum(sum(r.send_counts) for r in ranks) < int((st == 0).sum())   # … and most keys were not
+        assert info.keys_sent == 0
     check_round(keep, ranges, stats, st, unk)
-    check_state(engines, o, len(issuers))
-    if world > 1:   # replay: nothing is new anywhere
-        stats2 = run_simulated_bloom(ranks, shards, None, [lo for lo, _ in ranges])
-        assert all(s.n_new == 0 for s in stats2)
-        check_state(engines, o, len(issuers))
+    check_state(engines, g, o, len(issuers))
+    stats2 = g.map_batch("bloom", shards)                            # replay: nothing is new anywhere
+    assert all(s.n_new == 0 for s in stats2)
+    check_state(engines, g, o, len(issuers))
+    g.close()
     for e in engines:
         e.close()
 
@@ -102,7 +103,7 @@ def test_bloom_dedup_stream_in_rounds(world, bits):
     grow-and-retry path runs) — the result does not change."""
     cfg = synth.config(seed=62, n_issuers=12, dup_permille=300, ca_permille=20, expired_permille=20)
     issuers = synth.issuers(cfg)
-    engines, ranks = build_world(world, issuers, bits)
+    engines, g = build_world(world, issuers, bits)
     o = None
     W = 3000
     exchanged = 0
@@ -110,14 +111,15 @@ def test_bloom_dedup_stream_in_rounds(world, bits):
         lo_all, hi_all = wave * W, (wave + 1) * W
         o, st, unk, eh = run_oracle(synth.host_batch(cfg, lo_all, W), issuers, FILT, False, NOW, engine=o)
         shards, keep, ranges = load_shards(cfg, lo_all, hi_all, world)
-        stats = run_simulated_bloom(ranks, shards, [k[5].data_ptr() for k in keep], [lo for lo, _ in ranges])
+        stats = g.map_batch("bloom", shards)
         check_round(keep, ranges, stats, st, unk, base=lo_all)
-        exchanged += sum(sum(r.send_counts) for r in ranks)
-    check_state(engines, o, len(issuers))
+        exchanged += g.info().keys_sent
+    check_state(engines, g, o, len(issuers))
     if bits == 1 << 12:
         assert exchanged > o.total_count() // 2       # 64-word filter filling up: false positives dominate
     else:
         assert 0 < exchanged < o.total_count()        # only cross-rank duplicates travel
+    g.close()
     for e in engines:
         e.close()
 
@@ -127,83 +129,21 @@ def test_bloom_and_owner_exchange_agree():
     cfg = synth.config(seed=63, n_issuers=8, dup_permille=400)
     n_total = 5000
     issuers = synth.issuers(cfg)
-    engines_b, ranks_b = build_world(world, issuers, 1 << 16)
+    engines_b, gb = build_world(world, issuers, 1 << 16)
     engines_o = [make_engine(issuers) for _ in range(world)]
-    ranks_o = [GlobalDedupRank(engines_o[r], r, world, DEV) for r in range(world)]
+    go = Group.local(engines_o)
     shards_b, keep_b, ranges = load_shards(cfg, 0, n_total, world)
     shards_o, keep_o, _ = load_shards(cfg, 0, n_total, world)
-    sb = run_simulated_bloom(ranks_b, shards_b, [k[5].data_ptr() for k in keep_b], [lo for lo, _ in ranges])
-    so = run_simulated(ranks_o, shards_o, [k[5].data_ptr() for k in keep_o])
+    sb = gb.map_batch("bloom", shards_b)
+    so = go.map_batch("owner", shards_o)
     for r in range(world):
         assert (keep_b[r][4].cpu().numpy() == keep_o[r][4].cpu().numpy()).all()
         assert sb[r].n_new == so[r].n_new and list(sb[r].by_status) == list(so[r].by_status)
         assert (keep_b[r][5][:sb[r].n_new].cpu().numpy() == keep_o[r][5][:so[r].n_new].cpu().numpy()).all()
-    tb = sum(e.issuer_counts() for e in engines_b)
-    to = sum(e.issuer_counts() for e in engines_o)
-    assert (tb == to).all()
+    assert (gb.issuer_counts(len(issuers)) == go.issuer_counts(len(issuers))).all()
+    assert gb.info().keys_sent < go.info().keys_sent                 # the filters keep most keys at home
+    gb.close(); go.close()
     for e in engines_b + engines_o:
-        e.close()
-
-
-def test_bloom_dedup_over_entry_views():
-    """Raw get-entries shards: the probe reads certificates through the entry view (d_ends)."""
-    from ct_mapreduce_amd.distributed import decode_synchronised
-    from oracle import oracle as orc
-    world = 2
-    cfg = synth.config(seed=64, n_issuers=20, dup_permille=300, ca_permille=30, expired_permille=30)
-    n_total = 4000
-    whole = synth.host_entries(cfg, 0, n_total)
-    o = orc.Engine(FILT, False, NOW)
-    st, unk, eh, ts = o.raw_batch(whole.blob, whole.bounds)
-    engines = []
-    for _ in range(world):
-        e = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12)
-        e.set_filter(FILT, False, NOW)
-        e.set_issuer_autoregister(False)
-        engines.append(e)
-    ranks = [BloomDedupRank(engines[r], r, world, DEV, 1 << 16) for r in range(world)]
-    keep, calls, ranges = [], [], []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        raw = synth.host_entries(cfg, lo, hi - lo)
-        n = raw.n
-        d_blob = torch.from_numpy(raw.blob.copy()).to(DEV)
-        d_bounds = torch.from_numpy(raw.bounds.astype(np.int64)).to(DEV)
-        t = {k: torch.zeros(n, dtype=dt, device=DEV) for k, dt in
-             (("start", torch.int64), ("end", torch.int64), ("iss", torch.int32), ("et", torch.uint8))}
-        view = N.EntryView(cert_start=t["start"].data_ptr(), cert_end=t["end"].data_ptr(),
-                           issuer_idx=t["iss"].data_ptr(), entry_type=t["et"].data_ptr(), timestamp=None,
-                           chain0_start=None, chain0_len=None)
-        rec = torch.zeros(n * 32, dtype=torch.uint8, device=DEV)
-        new = torch.zeros(n, dtype=torch.int64, device=DEV)
-        keep.append((d_blob, d_bounds, t, view, rec, new, n, len(raw.blob)))
-        calls.append(lambda e=engines[r], b=d_blob, bd=d_bounds, n=n, v=view: e.decode_entries_device(
-            b.data_ptr(), bd.data_ptr(), n, v))
-        ranges.append((lo, hi))
-    decode_synchronised(engines, calls)
-    for r, rk in enumerate(ranks):
-        d_blob, d_bounds, t, view, rec, new, n, nbytes = keep[r]
-        rk.map(d_blob.data_ptr(), t["start"].data_ptr(), 0, 0, n, rec.data_ptr(), d_ends=t["end"].data_ptr(),
-               order_base=ranges[r][0], view=view, blob_bytes=nbytes)
-    for rk in ranks:
-        for p, q in enumerate(ranks):
-            if q is not rk:
-                rk.filters[p].copy_(q.own_filter())
-    counts = [rk.probe() for rk in ranks]
-    for o_, rk in enumerate(ranks):
-        rk.lookup(torch.cat([ranks[s].partition(o_) for s in range(world)]), [counts[s][o_] for s in range(world)])
-    for k, rk in enumerate(ranks):
-        fl = torch.cat([ranks[p].flags_for(k) for p in range(world)])
-        if fl.numel() == 0:
-            fl = torch.zeros(1, dtype=torch.uint8, device=DEV)
-        stt = rk.apply(fl, keep[k][5].data_ptr())
-        lo, hi = ranges[k]
-        rec = keep[k][4].cpu().numpy().view(RECORD_DTYPE)
-        assert (rec["status"] == st[lo:hi]).all()
-        assert (((rec["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all()
-        assert stt.n_new == int(unk[lo:hi].sum())
-    assert sum(e.total_count() for e in engines) == o.total_count()
-    for e in engines:
         e.close()
 
 
@@ -211,14 +151,15 @@ def test_shadow_members_are_not_counted_twice_by_sweep_and_remove():
     world = 2
     cfg = synth.config(seed=65, n_issuers=4, dup_permille=500)
     issuers = synth.issuers(cfg)
-    engines, ranks = build_world(world, issuers, 1 << 15)
+    engines, g = build_world(world, issuers, 1 << 15)
     shards, keep, ranges = load_shards(cfg, 0, 3000, world)
-    run_simulated_bloom(ranks, shards, None, [lo for lo, _ in ranges])
-    before = sum(e.total_count() for e in engines)
+    g.map_batch("bloom", shards)
+    before = g.total_count()
     removed = sum(e.expire_sweep(NOW + 400 * 86400) for e in engines)      # everything has expired by then
     assert removed == before
-    assert sum(e.total_count() for e in engines) == 0
+    assert g.total_count() == 0
     assert all(e.keys(b"serials::*") == [] for e in engines)
+    g.close()
     for e in engines:
         e.close()
 
@@ -233,6 +174,12 @@ def test_bloom_config_errors():
     p, nw = e.bloom_device()
     assert p != 0 and nw == 64
     e.bloom_add(0, 0, 0, 0)                      # empty batch: fine
+    g = Group.local([e])
+    with pytest.raises(ctmr.CtmrError):
+        g.bloom_config(1000)
+    with pytest.raises(ctmr.CtmrError):
+        Group.local([make_engine(synth.issuers(synth.config(seed=66, n_issuers=2)))]).map_batch("bloom", [dev_shard(to_dev(synth.host_batch(synth.config(seed=66, n_issuers=2), 0, 10)), 10)])
+    g.close()
     e.close()
 
 
@@ -242,7 +189,7 @@ def test_point_inserted_keys_are_in_the_filter():
     world = 2
     cfg = synth.config(seed=67, n_issuers=2)
     issuers = synth.issuers(cfg)
-    engines, ranks = build_world(world, issuers, 1 << 14)
+    engines, g = build_world(world, issuers, 1 << 14)
     b = synth.host_batch(cfg, 0, 200)
     o, st, unk, eh = run_oracle(b, issuers, FILT, False, NOW)
     i = int(np.nonzero(unk)[0][3])                               # some new, passing entry of rank 0's batch
@@ -251,15 +198,14 @@ def test_point_inserted_keys_are_in_the_filter():
     assert engines[1].set_insert(key, b.cert(i)[c.serial_off:c.serial_off + c.serial_len]) is True
     t = to_dev(b)
     empty = to_dev(synth.host_batch(cfg, 1000, 0))
-    shards = [(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), b.n, t[4].data_ptr()),
-              (empty[0].data_ptr(), empty[1].data_ptr(), empty[2].data_ptr(), empty[3].data_ptr(), 0, empty[4].data_ptr())]
-    stats = run_simulated_bloom(ranks, shards, [t[5].data_ptr(), empty[5].data_ptr()], [0, 1000])
+    stats = g.map_batch("bloom", [dev_shard(t, b.n, order_base=0), dev_shard(empty, 0, order_base=1000)])
     rec = t[4].cpu().numpy().view(RECORD_DTYPE)
     got = (rec["flags"] & 2) != 0
     want = unk != 0
     want[i] = False                                              # known on rank 1 since before this round
     assert (got == want).all()
-    assert stats[0].n_new == int(want.sum()) and sum(ranks[0].send_counts) >= 1
-    assert sum(e.total_count() for e in engines) == int(unk.sum())      # counted once, on rank 1
+    assert stats[0].n_new == int(want.sum()) and g.info().keys_sent >= 1
+    assert g.total_count() == int(unk.sum())                     # counted once, on rank 1
+    g.close()
     for e in engines:
         e.close()

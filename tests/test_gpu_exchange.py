@@ -1,6 +1,8 @@
-"""-m gpu: cross-GPU global dedup (owner-computes key exchange) validated on one GPU —
-world=1 (self exchange) equals the local path, and a simulated world of 2 and 3 ranks (several
-engines on one device, tensors sliced instead of sent) equals the oracle over the WHOLE stream."""
+"""-m gpu: cross-GPU global dedup through the NATIVE group layer (ctmr_group_*, csrc/engine/group.inc) on one GPU:
+several engines on the one reachable device form a local group — the same phase drivers and kernels the RCCL transport
+runs, with device-to-device copies where RCCL would send — and every shard's records must equal the oracle's view of
+that slice of the WHOLE stream; world = 1 equals the plain local path; an RCCL group of world 1 exercises the
+librccl loading, communicator and collectives that exist with one rank."""
 import numpy as np
 import pytest
 
@@ -10,7 +12,7 @@ import torch  # noqa: E402
 
 import ct_mapreduce_amd as ctmr
 from ct_mapreduce_amd import synth, _native as N
-from ct_mapreduce_amd.distributed import GlobalDedupRank, run_global_dedup, run_simulated, shard_range
+from ct_mapreduce_amd.distributed import Group, shard, shard_range, decode_synchronised
 from ct_mapreduce_amd.engine import RECORD_DTYPE
 from tests.gpu_common import run_oracle
 
@@ -29,38 +31,23 @@ def to_dev(b):
     return pay, off, iss, et, rec, new
 
 
-def make_engine(issuers):
-    e = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12)
+def dev_shard(t, n, order_base=0):
+    pay, off, iss, et, rec, new = t
+    return shard(pay.data_ptr(), off.data_ptr(), iss.data_ptr(), et.data_ptr(), n, rec.data_ptr(), new.data_ptr(),
+                 order_base=order_base)
+
+
+def make_engine(issuers, **kw):
+    kw.setdefault("table_slots", 1 << 16)
+    kw.setdefault("pair_slots", 1 << 12)
+    e = ctmr.Engine(device=0, **kw)
     e.add_issuers(issuers)
     e.set_filter(FILT, False, NOW)
     return e
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_global_dedup_matches_oracle_over_the_whole_stream(world):
-    cfg = synth.config(seed=55, n_issuers=16, dup_permille=300, ca_permille=30, expired_permille=30)
-    n_total = 6000
-    issuers = synth.issuers(cfg)
-    whole = synth.host_batch(cfg, 0, n_total)
-    o, st, unk, eh = run_oracle(whole, issuers, FILT, False, NOW)
-    assert 0 < unk.sum() < (st == 0).sum()                       # duplicates exist, also across shards
-    engines = [make_engine(issuers) for _ in range(world)]
-    ranks = [GlobalDedupRank(engines[r], r, world, DEV) for r in range(world)]
-    shards, keep, ranges = [], [], []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        b = synth.host_batch(cfg, lo, hi - lo)
-        pay, off, iss, et, rec, new = to_dev(b)
-        keep.append((pay, off, iss, et, rec, new))
-        shards.append((pay.data_ptr(), off.data_ptr(), iss.data_ptr(), et.data_ptr(), b.n, rec.data_ptr()))
-        ranges.append((lo, hi))
-    if world == 1:
-        stats = [run_global_dedup(ranks[0], *shards[0], keep[0][5].data_ptr())]
-    else:
-        stats = run_simulated(ranks, shards, [k[5].data_ptr() for k in keep])
-    # every shard's records equal the oracle's view of that slice of the global stream
-    for r in range(world):
-        lo, hi = ranges[r]
+def check_shards_against_oracle(keep, stats, ranges, st, unk):
+    for r, (lo, hi) in enumerate(ranges):
         rec = keep[r][4].cpu().numpy().view(RECORD_DTYPE)
         assert (rec["status"] == st[lo:hi]).all()
         assert (((rec["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all()
@@ -69,19 +56,89 @@ def test_global_dedup_matches_oracle_over_the_whole_stream(world):
         assert (new == np.nonzero(unk[lo:hi])[0]).all()
         for k in range(7):
             assert stats[r].by_status[k] == int((st[lo:hi] == k).sum())
-    # owner-local per-issuer counters sum to the global unique counts; every key has one owner
-    total = np.zeros(len(issuers), dtype=np.uint64)
-    for e in engines:
-        total += e.issuer_counts()
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom"])
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+def test_global_dedup_matches_oracle_over_the_whole_stream(world, mode):
+    cfg = synth.config(seed=55, n_issuers=16, dup_permille=300, ca_permille=30, expired_permille=30)
+    n_total = 6000
+    issuers = synth.issuers(cfg)
+    whole = synth.host_batch(cfg, 0, n_total)
+    o, st, unk, eh = run_oracle(whole, issuers, FILT, False, NOW)
+    assert 0 < unk.sum() < (st == 0).sum()                       # duplicates exist, also across shards
+    engines = [make_engine(issuers) for _ in range(world)]
+    g = Group.local(engines)
+    if mode == "bloom":
+        g.bloom_config(1 << 16)
+    keep, shards, ranges = [], [], []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        t = to_dev(synth.host_batch(cfg, lo, hi - lo))
+        keep.append(t)
+        shards.append(dev_shard(t, hi - lo, order_base=lo))
+        ranges.append((lo, hi))
+    stats = g.map_batch(mode, shards)
+    check_shards_against_oracle(keep, stats, ranges, st, unk)
+    info = g.info()
+    assert info.world == world and info.n_local == world and info.transport == N.TRANSPORT_LOCAL
+    if world > 1:
+        assert info.keys_sent == info.keys_received > 0
+    # the ranks' per-issuer counters sum to the global unique counts (the group's all-reduce); every key counted once
+    total = g.issuer_counts(len(issuers))
     for k in range(len(issuers)):
         assert int(total[k]) == o.issuer_count(engines[0].issuer_id(k))
-    assert sum(e.total_count() for e in engines) == o.total_count()
+    assert g.total_count() == o.total_count() == sum(e.total_count() for e in engines)
     allkeys = sorted(sum((e.keys(b"serials::*") for e in engines), []))
     assert sorted(set(allkeys)) == [k for k in o.keys() if k.startswith(b"serials::")]
     # replay: nothing is new anywhere
-    if world > 1:
-        stats2 = run_simulated(ranks, shards)
-        assert all(s.n_new == 0 for s in stats2)
+    stats2 = g.map_batch(mode, shards)
+    assert all(s.n_new == 0 for s in stats2)
+    assert g.total_count() == o.total_count()
+    g.close()
+    for e in engines:
+        e.close()
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom"])
+def test_four_rounds_with_duplicates_across_rounds_and_ranks(mode):
+    world, rounds, per = 3, 4, 1500
+    cfg = synth.config(seed=58, n_issuers=8, dup_permille=350, ca_permille=20, expired_permille=20)
+    issuers = synth.issuers(cfg)
+    engines = [make_engine(issuers) for _ in range(world)]
+    g = Group.local(engines)
+    if mode == "bloom":
+        g.bloom_config(1 << 12)                                  # tiny filter: false positives dominate, results stay exact
+    o = None
+    for rnd in range(rounds):
+        base = rnd * per * world
+        keep, shards, want = [], [], []
+        for r in range(world):
+            lo, hi = shard_range(per * world, r, world)
+            if rnd == 2 and r == 1:
+                hi = lo                                          # an EMPTY shard in one round
+            b = synth.host_batch(cfg, base + lo, hi - lo)
+            o, st, unk, _ = run_oracle(b, issuers, FILT, False, NOW, engine=o)   # the stream in log order, shard by shard
+            want.append((st, unk))
+            t = to_dev(b)
+            keep.append(t)
+            shards.append(dev_shard(t, hi - lo, order_base=base + lo))
+        stats = g.map_batch(mode, shards)
+        for r in range(world):
+            st, unk = want[r]
+            rec = keep[r][4].cpu().numpy().view(RECORD_DTYPE)[:len(st)]
+            assert (rec["status"] == st).all(), (rnd, r)
+            assert (((rec["flags"] & 2) != 0) == (unk != 0)).all(), (rnd, r)
+            assert stats[r].n_new == int(unk.sum())
+            assert (keep[r][5][:stats[r].n_new].cpu().numpy() == np.nonzero(unk)[0]).all()
+    assert g.total_count() == o.total_count()
+    total = g.issuer_counts(len(issuers))
+    for k in range(len(issuers)):
+        assert int(total[k]) == o.issuer_count(engines[0].issuer_id(k))
+    # expiry sweep over every rank: the group total drops to zero (SHADOW members of the Bloom mode are not counted twice)
+    removed = sum(e.expire_sweep(NOW + 400 * 86400) for e in engines)
+    assert removed == o.total_count() and g.total_count() == 0
+    g.close()
     for e in engines:
         e.close()
 
@@ -90,27 +147,61 @@ def test_global_path_equals_local_path_on_one_gpu():
     cfg = synth.config(seed=56, n_issuers=4, dup_permille=200)
     issuers = synth.issuers(cfg)
     b = synth.host_batch(cfg, 0, 5000)
-    pay, off, iss, et, rec, new = to_dev(b)
-    e1, e2 = make_engine(issuers), make_engine(issuers)
+    t = to_dev(b)
+    pay, off, iss, et, rec, new = t
+    e1, e2, e3 = make_engine(issuers), make_engine(issuers), make_engine(issuers)
     st_local = e1.map_batch_device(pay.data_ptr(), off.data_ptr(), iss.data_ptr(), et.data_ptr(), b.n,
                                    rec.data_ptr(), new.data_ptr())
     rec_local = rec.cpu().numpy().copy()
     new_local = new[:st_local.n_new].cpu().numpy().copy()
-    rec.zero_()
-    st_glob = run_global_dedup(GlobalDedupRank(e2, 0, 1, DEV), pay.data_ptr(), off.data_ptr(), iss.data_ptr(),
-                               et.data_ptr(), b.n, rec.data_ptr(), new.data_ptr())
-    assert (rec.cpu().numpy() == rec_local).all()
-    assert (new[:st_glob.n_new].cpu().numpy() == new_local).all()
-    assert st_glob.n_new == st_local.n_new and list(st_glob.by_status) == list(st_local.by_status)
-    assert (e1.issuer_counts() == e2.issuer_counts()).all()
-    e1.close(); e2.close()
+    for eng, mode in ((e2, "owner"), (e3, "local")):
+        rec.zero_()
+        g = Group.local([eng])
+        st_glob = g.map_batch(mode, [dev_shard(t, b.n)])[0]
+        assert (rec.cpu().numpy() == rec_local).all()
+        assert (new[:st_glob.n_new].cpu().numpy() == new_local).all()
+        assert st_glob.n_new == st_local.n_new and list(st_glob.by_status) == list(st_local.by_status)
+        assert (e1.issuer_counts() == eng.issuer_counts()).all()
+        assert (g.issuer_counts(len(issuers)) == e1.issuer_counts()[:len(issuers)]).all()
+        g.close()
+    e1.close(); e2.close(); e3.close()
+
+
+@pytest.mark.parametrize("mode", ["local", "owner", "bloom"])
+def test_rccl_transport_with_one_rank(mode):
+    """The RCCL transport (librccl loaded on demand, ncclCommInitRank, ncclAllGather of the counts / filters,
+    ncclAllReduce of the per-issuer counts) with world = 1 — all that can run where one GPU is reachable; N > 1 over
+    RCCL stays unmeasured until a multi-GPU node exists."""
+    cfg = synth.config(seed=59, n_issuers=6, dup_permille=250)
+    issuers = synth.issuers(cfg)
+    b = synth.host_batch(cfg, 0, 4000)
+    t = to_dev(b)
+    e = make_engine(issuers)
+    gid = Group.unique_id()
+    assert len(gid) == N.GROUP_ID_BYTES and any(gid)
+    g = Group.rccl(e, gid, 0, 1)
+    if mode == "bloom":
+        g.bloom_config(1 << 16)
+    stats = g.map_batch(mode, [dev_shard(t, b.n)])[0]
+    o, st, unk, eh = run_oracle(b, issuers, FILT, False, NOW)
+    rec = t[4].cpu().numpy().view(RECORD_DTYPE)
+    assert (rec["status"] == st).all() and (((rec["flags"] & 2) != 0) == (unk != 0)).all()
+    assert stats.n_new == int(unk.sum()) == g.total_count()
+    info = g.info()
+    assert info.transport == N.TRANSPORT_RCCL and info.world == 1
+    counts = g.issuer_counts(len(issuers))
+    for k in range(len(issuers)):
+        assert int(counts[k]) == o.issuer_count(e.issuer_id(k))
+    assert (g.all_reduce_u64([5, 7]) == [5, 7]).all() and (g.all_reduce_u64([9], op_max=True) == [9]).all()
+    g.barrier()
+    g.close()
+    e.close()
 
 
 def test_raw_shards_with_synchronised_issuer_registration():
-    """Global dedup fed by RAW get-entries shards: two "ranks" (engines) see the issuers in different orders; with
-    auto-registration off and the pending lists merged in an agreed order their tables stay index-identical, and the
-    key exchange over entry views reproduces the single-stream oracle."""
-    from ct_mapreduce_amd.distributed import decode_synchronised
+    """Global dedup fed by RAW get-entries shards: two ranks see the issuers in different orders; with
+    auto-registration off and the pending lists merged in an agreed order their tables stay index-identical, and both
+    exchanges over entry views reproduce the single-stream oracle."""
     from oracle import oracle as orc
     world = 2
     cfg = synth.config(seed=57, n_issuers=24, dup_permille=300, ca_permille=30, expired_permille=30)
@@ -119,55 +210,49 @@ def test_raw_shards_with_synchronised_issuer_registration():
     o = orc.Engine(FILT, False, NOW)
     st, unk, eh, ts = o.raw_batch(whole.blob, whole.bounds)
     assert 0 < unk.sum() < (st == 0).sum()
-    engines = []
-    for _ in range(world):
-        e = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12)
-        e.set_filter(FILT, False, NOW)
-        e.set_issuer_autoregister(False)
-        engines.append(e)
-    ranks = [GlobalDedupRank(engines[r], r, world, DEV) for r in range(world)]
-    keep, calls, ranges = [], [], []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        raw = synth.host_entries(cfg, lo, hi - lo)
-        n = raw.n
-        d_blob = torch.from_numpy(raw.blob.copy()).to(DEV)
-        d_bounds = torch.from_numpy(raw.bounds.astype(np.int64)).to(DEV)
-        t = {k: torch.zeros(n, dtype=dt, device=DEV) for k, dt in
-             (("start", torch.int64), ("end", torch.int64), ("iss", torch.int32), ("et", torch.uint8))}
-        view = N.EntryView(cert_start=t["start"].data_ptr(), cert_end=t["end"].data_ptr(), issuer_idx=t["iss"].data_ptr(),
-                           entry_type=t["et"].data_ptr(), timestamp=None, chain0_start=None, chain0_len=None)
-        rec = torch.zeros(n * 32, dtype=torch.uint8, device=DEV)
-        new = torch.zeros(n, dtype=torch.int64, device=DEV)
-        keep.append((d_blob, d_bounds, t, view, rec, new, n, int(raw.bounds[-1])))
-        calls.append(lambda e=engines[r], b=d_blob, bd=d_bounds, n=n, v=view: e.decode_entries_device(b.data_ptr(), bd.data_ptr(), n, v))
-        ranges.append((lo, hi))
-    with pytest.raises(ctmr.CtmrError) as ei:                   # nothing is registered silently
-        calls[0]()
-    assert ei.value.code == N.E_NOTFOUND and len(engines[0].pending_issuers()) > 0
-    decode_synchronised(engines, calls)
-    assert engines[0].issuer_count() == engines[1].issuer_count() > 0
-    for k in range(engines[0].issuer_count()):                  # index-identical issuer tables
-        assert engines[0].issuer_id(k) == engines[1].issuer_id(k)
-    # key exchange over the views (same data movement as run_simulated, export through the view entry point)
-    counts = []
-    for r in range(world):
-        d_blob, _, _, view, rec, _, n, nbytes = keep[r]
-        ranks[r].n, ranks[r].d_records = n, rec.data_ptr()
-        ranks[r].keys = torch.empty(max(n, 1) * 64, dtype=torch.uint8, device=DEV)
-        ranks[r].send_counts = engines[r].exchange_export_view(d_blob.data_ptr(), nbytes, view, n, rec.data_ptr(), world,
-                                                               ranks[r].keys.data_ptr())
-        ranks[r].n_keys = sum(ranks[r].send_counts)
-        counts.append(ranks[r].send_counts)
-    for ow, rk in enumerate(ranks):
-        rk.insert(torch.cat([ranks[s].partition(ow) for s in range(world)]), [counts[s][ow] for s in range(world)])
-    for r, rk in enumerate(ranks):
-        stats = rk.apply(torch.cat([ranks[ow].flags_for(r) for ow in range(world)]), keep[r][5].data_ptr())
-        lo, hi = ranges[r]
-        rec = keep[r][4].cpu().numpy().view(RECORD_DTYPE)
-        assert (rec["status"] == st[lo:hi]).all()
-        assert (((rec["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all()
-        assert stats.n_new == int(unk[lo:hi].sum())
-    assert sum(e.total_count() for e in engines) == o.total_count()
-    for e in engines:
-        e.close()
+    for mode in ("owner", "bloom"):
+        engines = []
+        for _ in range(world):
+            e = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12)
+            e.set_filter(FILT, False, NOW)
+            e.set_issuer_autoregister(False)
+            engines.append(e)
+        g = Group.local(engines)
+        if mode == "bloom":
+            g.bloom_config(1 << 16)
+        keep, calls, ranges, shards = [], [], [], []
+        for r in range(world):
+            lo, hi = shard_range(n_total, r, world)
+            raw = synth.host_entries(cfg, lo, hi - lo)
+            n = raw.n
+            d_blob = torch.from_numpy(raw.blob.copy()).to(DEV)
+            d_bounds = torch.from_numpy(raw.bounds.astype(np.int64)).to(DEV)
+            t = {k: torch.zeros(n, dtype=dt, device=DEV) for k, dt in
+                 (("start", torch.int64), ("end", torch.int64), ("iss", torch.int32), ("et", torch.uint8))}
+            view = N.EntryView(cert_start=t["start"].data_ptr(), cert_end=t["end"].data_ptr(), issuer_idx=t["iss"].data_ptr(),
+                               entry_type=t["et"].data_ptr(), timestamp=None, chain0_start=None, chain0_len=None)
+            rec = torch.zeros(n * 32, dtype=torch.uint8, device=DEV)
+            new = torch.zeros(n, dtype=torch.int64, device=DEV)
+            keep.append((d_blob, d_bounds, t, view, rec, new, n, int(raw.bounds[-1])))
+            calls.append(lambda e=engines[r], b=d_blob, bd=d_bounds, n=n, v=view: e.decode_entries_device(b.data_ptr(), bd.data_ptr(), n, v))
+            ranges.append((lo, hi))
+            shards.append(shard(d_blob.data_ptr(), t["start"].data_ptr(), t["iss"].data_ptr(), t["et"].data_ptr(), n,
+                                rec.data_ptr(), new.data_ptr(), order_base=lo, d_ends=t["end"].data_ptr(),
+                                blob_bytes=int(raw.bounds[-1])))
+        with pytest.raises(ctmr.CtmrError) as ei:                   # nothing is registered silently
+            calls[0]()
+        assert ei.value.code == N.E_NOTFOUND and len(engines[0].pending_issuers()) > 0
+        decode_synchronised(engines, calls)
+        assert engines[0].issuer_count() == engines[1].issuer_count() > 0
+        for k in range(engines[0].issuer_count()):                  # index-identical issuer tables
+            assert engines[0].issuer_id(k) == engines[1].issuer_id(k)
+        stats = g.map_batch(mode, shards)
+        for r, (lo, hi) in enumerate(ranges):
+            rec = keep[r][4].cpu().numpy().view(RECORD_DTYPE)
+            assert (rec["status"] == st[lo:hi]).all(), mode
+            assert (((rec["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all(), mode
+            assert stats[r].n_new == int(unk[lo:hi].sum())
+        assert g.total_count() == o.total_count()
+        g.close()
+        for e in engines:
+            e.close()

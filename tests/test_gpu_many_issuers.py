@@ -11,10 +11,10 @@ import torch  # noqa: E402
 
 import ct_mapreduce_amd as ctmr
 from ct_mapreduce_amd import synth
-from ct_mapreduce_amd.distributed import GlobalDedupRank, BloomDedupRank, run_simulated, run_simulated_bloom, shard_range
+from ct_mapreduce_amd.distributed import Group, shard_range
 from ct_mapreduce_amd.engine import RECORD_DTYPE
 from tests.gpu_common import run_oracle
-from tests.test_gpu_exchange import to_dev
+from tests.test_gpu_exchange import to_dev, dev_shard
 
 DEV = torch.device("cuda:0")
 NOW = synth.BASE_TIME
@@ -71,31 +71,26 @@ def test_global_dedup_counts_with_6000_issuers(mode):
         e.add_issuers(issuers)
         e.set_filter(FILT, False, NOW)
         engines.append(e)
-    if mode == "owner":
-        ranks = [GlobalDedupRank(engines[r], r, world, DEV) for r in range(world)]
-    else:
-        ranks = [BloomDedupRank(engines[r], r, world, DEV, 1 << 20) for r in range(world)]
-    shards, keep, bases = [], [], []
+    g = Group.local(engines)
+    if mode == "bloom":
+        g.bloom_config(1 << 20)
+    shards, keep = [], []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
-        b = synth.host_batch(cfg, lo, hi - lo)
-        t = to_dev(b)
+        t = to_dev(synth.host_batch(cfg, lo, hi - lo))
         keep.append(t)
-        shards.append((t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), b.n, t[4].data_ptr()))
-        bases.append(lo)
-    if mode == "owner":
-        stats = run_simulated(ranks, shards, [k[5].data_ptr() for k in keep])
-    else:
-        stats = run_simulated_bloom(ranks, shards, [k[5].data_ptr() for k in keep], order_bases=bases)
+        shards.append(dev_shard(t, hi - lo, order_base=lo))
+    stats = g.map_batch(mode, shards)
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
         rec = keep[r][4].cpu().numpy().view(RECORD_DTYPE)
         assert (rec["status"] == st[lo:hi]).all()
         assert (((rec["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all()
         assert stats[r].n_new == int(unk[lo:hi].sum())
-    total = sum((e.issuer_counts()[:N_ISSUERS] for e in engines), np.zeros(N_ISSUERS, np.uint64))
+    total = g.issuer_counts(N_ISSUERS)
     want = expected_counts(whole, unk, N_ISSUERS)
     assert (total == want).all(), np.nonzero(total != want)[0][:10]
     assert int(want[4096:].sum()) > 5000
+    g.close()
     for e in engines:
         e.close()
