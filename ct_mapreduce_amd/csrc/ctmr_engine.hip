@@ -10,6 +10,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -130,8 +134,12 @@ bool glob_match(const char* p, size_t pn, const char* s, size_t sn) {
 
 }  // namespace
 
+struct ctmr_pipeline;
+
 struct ctmr_engine {
   std::mutex mu;
+  std::atomic<ctmr_pipeline*> pipe{nullptr};  // asynchronous host ingestion (engine/pipeline.inc), created on first use
+  std::mutex pipe_mu;
   mutable std::string err;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -460,11 +468,18 @@ const std::vector<uint32_t>& host_cdf(uint32_t n) {
 
 }  // namespace
 
+extern "C++" {
+namespace {
+void pipe_shutdown(ctmr_engine* e);  // engine/pipeline.inc
+}
+}
+
 extern "C" {
 
 #include "engine/lifecycle.inc"
 #include "engine/issuers.inc"
 #include "engine/map.inc"
+#include "engine/pipeline.inc"
 #include "engine/entries.inc"
 #include "engine/meta.inc"
 #include "engine/pem.inc"

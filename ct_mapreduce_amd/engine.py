@@ -200,6 +200,28 @@ class Engine:
             new_idx.ctypes.data if (want_new and n) else None, C.byref(st)))
         return BatchResult(records, new_idx[:st.n_new] if want_new else new_idx[:0], st)
 
+    # ---- asynchronous host ingestion (ctmr_submit_batch / ctmr_wait / ctmr_flush)
+    def submit_batch(self, payload, offsets, issuer_idx, entry_type, n) -> int:
+        """Arrays (numpy, contiguous) or raw addresses (ints: e.g. pinned buffers of alloc_pinned).  Returns the ticket.
+        The caller keeps the arrays alive — and pinned payloads untouched — until wait(ticket)."""
+        def addr(a):
+            return a.ctypes.data if hasattr(a, "ctypes") else a
+        t = C.c_uint64(0)
+        self._ck(self._lib.ctmr_submit_batch(self._h, addr(payload), addr(offsets), addr(issuer_idx),
+                                             addr(entry_type) if entry_type is not None else None, n, C.byref(t)))
+        return t.value
+
+    def flush(self):
+        self._ck(self._lib.ctmr_flush(self._h))
+
+    def wait(self, ticket: int, n: int, want_records=True, want_new=True) -> BatchResult:
+        records = np.zeros(n, dtype=RECORD_DTYPE)
+        new_idx = np.zeros(max(n, 1), dtype=np.uint64)
+        st = N.BatchStats()
+        self._ck(self._lib.ctmr_wait(self._h, ticket, records.ctypes.data if (want_records and n) else None,
+                                     new_idx.ctypes.data if (want_new and n) else None, C.byref(st)))
+        return BatchResult(records, new_idx[:st.n_new] if want_new else new_idx[:0], st)
+
     def map_batch_device(self, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records=0,
                          d_new_idx=0) -> N.BatchStats:
         """All pointers are device addresses (ints), e.g. torch tensors' data_ptr()."""

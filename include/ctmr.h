@@ -172,6 +172,28 @@ int ctmr_map_batch_device(ctmr_engine* e, const uint8_t* d_payload, const uint64
                           const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
                           ctmr_record* d_records, uint64_t* d_new_idx, ctmr_batch_stats* stats);
 
+/* ---- asynchronous host ingestion: the counterpart, in front of the GPU, of the channel between the reference's
+ *      downloader and its insertCTWorker goroutines (cmd/ct-fetch/ct-fetch.go:132,140-145,191): the downloader hands
+ *      over one get-entries response at a time, at most 1 001 entries (:417-424), and a synchronous ctmr_map_batch per
+ *      response is bound by the host↔device round trip, not by the GPU.
+ *   submit: same arguments as ctmr_map_batch; returns a ticket at once.  The DER goes to HBM with an asynchronous copy
+ *           behind the previous submit's bytes (straight DMA from buffers of ctmr_alloc_pinned — keep them untouched
+ *           until ctmr_wait; pageable memory is staged before the call returns); consecutive submits coalesce into a
+ *           super-batch that is mapped as ONE batch when it reaches 65 536 entries / 96 MB, on ctmr_flush, or when one
+ *           of its tickets is waited for — while the next one is already filling.
+ *   wait:   blocks until the ticket's super-batch is done; records / new_idx (indices relative to THIS batch, ascending)
+ *           / stats as ctmr_map_batch returns them (any may be NULL).  A ticket is collected once.
+ *      Super-batches run in submission order and entries keep their order inside one: the lowest log index of a key
+ *      wins WasUnknown across everything in flight, as in a sequence of synchronous calls.  Up to 4 super-batches may
+ *      be unfinished or uncollected; a submit that would need a fifth blocks while one is still running and fails
+ *      with CTMR_E_RANGE when all four only wait to be collected.  Thread-safe (several downloader threads may submit
+ *      and wait).  ctmr_pem_new / ctmr_meta_new refer to synchronous calls only. ---- */
+typedef uint64_t ctmr_ticket;
+int ctmr_submit_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* offsets, const uint32_t* issuer_idx,
+                      const uint8_t* entry_type, uint64_t n, ctmr_ticket* ticket);
+int ctmr_flush(ctmr_engine* e);
+int ctmr_wait(ctmr_engine* e, ctmr_ticket ticket, ctmr_record* records, uint64_t* new_idx, ctmr_batch_stats* stats);
+
 /* ---- storage.RemoteCache set methods on byte strings (storage/types.go:83-102;
  *      Redis impl storage/rediscache.go:57-120,153-169; mock storage/mockcache.go:38-166).
  *      Keys of the form "serials::<expDateID-with-hour>::<issuerID of a registered issuer>"

@@ -1,0 +1,145 @@
+"""-m gpu: asynchronous host ingestion (ctmr_submit_batch / ctmr_wait / ctmr_flush, csrc/engine/pipeline.inc) — the
+GPU-side counterpart of the reference's entryChan (cmd/ct-fetch/ct-fetch.go:132,191): get-entries-sized batches
+(≤ 1 001 entries, :417-424) submitted without waiting coalesce into super-batches and come back, ticket by ticket,
+exactly as a sequence of synchronous calls over the same stream would answer — including which duplicate is "first"
+when the two copies of a key sit in different batches that are in flight together."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402,F401
+
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import synth, _native as N
+from tests.gpu_common import run_oracle, assert_records_equal
+
+NOW = synth.BASE_TIME
+FILT = b"Synth Issuer 0,Synth Issuer 1"
+
+
+def make(issuers, **kw):
+    kw.setdefault("table_slots", 1 << 20)
+    kw.setdefault("pair_slots", 1 << 14)
+    e = ctmr.Engine(device=0, **kw)
+    e.add_issuers(issuers)
+    e.set_filter(FILT, False, NOW)
+    return e
+
+
+def arrays(b):
+    pay = np.concatenate([b.payload, np.zeros(32, np.uint8)])
+    return pay, b.offsets.astype(np.uint64), b.issuer_idx.astype(np.uint32), b.entry_type.astype(np.uint8)
+
+
+@pytest.mark.parametrize("size,count", [(1001, 150), (257, 40), (70000, 3)])
+def test_tickets_answer_like_synchronous_calls(size, count):
+    cfg = synth.config(seed=91, n_issuers=64, zipf=1, dup_permille=200, ca_permille=10, expired_permille=10)
+    issuers = synth.issuers(cfg)
+    eng = make(issuers)
+    batches = [synth.host_batch(cfg, k * size, size) for k in range(count)]
+    keep, tickets = [], []
+    for b in batches:                                  # submit everything, collect nothing yet …
+        a = arrays(b)
+        keep.append(a)
+        tickets.append(eng.submit_batch(a[0], a[1], a[2], a[3], b.n))
+        if len(tickets) - sum(1 for _ in ()) > 0 and len(tickets) % 120 == 0:
+            eng.flush()
+    o = None
+    for b, t in zip(batches, tickets):                 # … then collect in order: the oracle sees ONE stream
+        res = eng.wait(t, b.n)
+        o, st, unk, eh = run_oracle(b, issuers, FILT, False, NOW, engine=o)
+        assert_records_equal(res, b, st, unk, eh)
+        assert res.stats.n_dup == int(((st == 0) & (unk == 0)).sum())
+        assert res.stats.payload_bytes == int(b.offsets[-1])
+    assert eng.total_count() == o.total_count()
+    with pytest.raises(ctmr.CtmrError) as ei:          # a ticket is collected once
+        eng.wait(tickets[0], batches[0].n)
+    assert ei.value.code == N.E_NOTFOUND
+    # the synchronous entry point still works on the same engine, and sees what the pipeline inserted
+    again = eng.map_batch(batches[0])
+    assert again.stats.n_new == 0
+    eng.close()
+
+
+def test_out_of_order_collection_empty_batches_and_pinned_memory():
+    cfg = synth.config(seed=92, n_issuers=8, dup_permille=300)
+    issuers = synth.issuers(cfg)
+    eng = make(issuers)
+    sizes = [1001, 0, 5, 1001, 0, 300]
+    batches, first = [], 0
+    for n in sizes:
+        batches.append(synth.host_batch(cfg, first, n))
+        first += n
+    keep, tickets = [], []
+    for k, b in enumerate(batches):
+        pay, off, iss, et = arrays(b)
+        if k % 2 == 0:                                 # every other payload in page-locked memory: straight DMA
+            p = eng.pinned_array(pay.nbytes)
+            p[:] = pay
+            pay = p
+        keep.append((pay, off, iss, et))
+        tickets.append(eng.submit_batch(pay, off, iss, None if k == 2 else et, b.n))
+    # the oracle processes the stream in SUBMISSION order whatever the collection order is
+    want, o = [], None
+    for k, b in enumerate(batches):
+        if k == 2:
+            b.entry_type[:] = 0                        # submitted with entry_type = NULL: all X509
+        o, st, unk, eh = run_oracle(b, issuers, FILT, False, NOW, engine=o)
+        want.append((st, unk, eh))
+    for k in (5, 0, 3, 1, 2, 4):
+        res = eng.wait(tickets[k], batches[k].n)
+        if batches[k].n:
+            assert_records_equal(res, batches[k], *want[k])
+        else:
+            assert res.stats.n == 0 and len(res.new_idx) == 0
+    eng.close()
+
+
+def test_pipeline_full_is_reported_not_deadlocked():
+    cfg = synth.config(seed=93, n_issuers=4)
+    issuers = synth.issuers(cfg)
+    eng = make(issuers)
+    b = synth.host_batch(cfg, 0, 70000)                # one submit = one whole super-batch
+    a = arrays(b)
+    tickets = [eng.submit_batch(a[0], a[1], a[2], a[3], b.n) for _ in range(4)]
+    with pytest.raises(ctmr.CtmrError) as ei:          # four uncollected super-batches: the fifth is refused, not blocked
+        for _ in range(3):
+            eng.submit_batch(a[0], a[1], a[2], a[3], b.n)
+    assert ei.value.code == N.E_RANGE
+    r0 = eng.wait(tickets[0], b.n)
+    assert r0.stats.n_new > 60000
+    t5 = eng.submit_batch(a[0], a[1], a[2], a[3], b.n)  # a slot is free again
+    for t in tickets[1:] + [t5]:
+        assert eng.wait(t, b.n).stats.n_new == 0        # the same certificates again: all known
+    eng.close()
+
+
+def test_several_threads_submit_and_wait():
+    cfg = synth.config(seed=94, n_issuers=16, dup_permille=0)
+    issuers = synth.issuers(cfg)
+    eng = make(issuers)
+    per, rounds, T = 1001, 30, 4
+    news, errors = [0] * T, []
+
+    def worker(t):
+        try:
+            for r in range(rounds):
+                b = synth.host_batch(cfg, (t * rounds + r) * per, per)
+                a = arrays(b)
+                tk = eng.submit_batch(a[0], a[1], a[2], a[3], b.n)
+                news[t] += eng.wait(tk, b.n).stats.n_new
+        except Exception as ex:                          # noqa: BLE001
+            errors.append(ex)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    whole = synth.host_batch(cfg, 0, per * rounds * T)
+    o, st, unk, eh = run_oracle(whole, issuers, FILT, False, NOW)
+    assert sum(news) == int(unk.sum()) == eng.total_count()   # disjoint keys: the interleaving does not matter
+    eng.close()
