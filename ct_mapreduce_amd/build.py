@@ -32,12 +32,15 @@ def stale(lib=LIB):
     return any(os.path.getmtime(d) > t for d in deps())
 
 
-def build(force=False, verbose=False, sweep=False):
-    lib = SWEEP_LIB if sweep else LIB
+def build(force=False, verbose=False, sweep=False, defines=(), tag=""):
+    """defines / tag: experiment builds of the sweep library (e.g. defines=["CTMR_NT_LOADS"], tag="nt") →
+    libctmr_sweep_<tag>.so; the shipped library never takes any."""
+    lib = (SWEEP_LIB.replace(".so", "_%s.so" % tag) if tag else SWEEP_LIB) if sweep else LIB
     if not force and not stale(lib):
         return lib
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"] + (["-DCTMR_SWEEP"] if sweep else []) + \
+          ["-D" + d for d in defines] + \
           [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", lib]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -117,8 +117,8 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
   const uint64_t rem = a.n - first;  // records of this wave
   const uint32_t nvec = rem >= 64 ? 128u : (uint32_t)rem * 2u;
   uint4* out = (uint4*)(a.records + first);
-  if (lane < nvec) out[lane] = t[lane];
-  if (64u + lane < nvec) out[64 + lane] = t[64 + lane];
+  if (lane < nvec) st_stream16(out + lane, t[lane]);
+  if (64u + lane < nvec) st_stream16(out + 64 + lane, t[64 + lane]);
 }
 
 // Window map (variant 13; the exchange modes and `map_variant = 13` use it, the default is k_map_fused in reduce.h):
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
     for (int it = 0; it < 16; it++) {
       const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
       const uint64_t at = g + 16u * sub;
-      v[it] = (g != ~0ull && at + 16u <= limit) ? *(const uint4*)(a.payload + at) : make_uint4(0, 0, 0, 0);
+      v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(a.payload + at)) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < 16; it++)

@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
     for (int it = 0; it < 16; it++) {
       const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
       const uint64_t at = g + 16u * sub;
-      v[it] = (g != ~0ull && at + 16u <= limit) ? *(const uint4*)(a.payload + at) : make_uint4(0, 0, 0, 0);
+      v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(a.payload + at)) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < 16; it++)
