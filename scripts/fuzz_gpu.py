@@ -18,7 +18,7 @@ from ct_mapreduce_amd import synth, _native as N  # noqa: E402
 from ct_mapreduce_amd.engine import Batch  # noqa: E402
 from tests import der as D  # noqa: E402
 from tests.gpu_common import run_oracle, expected_records  # noqa: E402
-from tests.test_walk_cpu import mutate  # noqa: E402
+from tests.test_walk_cpu import mutate, edge_seeds  # noqa: E402
 from tests.test_gpu_meta import expected_first_sightings, got_first_sightings  # noqa: E402
 
 
@@ -55,6 +55,7 @@ def main():
     seeds += [D.cert(serial=bytes([k + 1]) * (k + 1), issuer=n1,
                      exts=[D.BC_NOT_CA, D.ext(0x1f, D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa0, D.tlv(0x86, b"http://c.example/%d" % k))))))])
               for k in range(24)]
+    seeds += edge_seeds() * 6      # the Go-specific rules (numeric zones, lax INTEGERs, unique ids, high tags, lying wrappers): weighted up
     print("seeds", len(seeds), flush=True)
     bad = 0
     done = 0
