@@ -318,6 +318,8 @@ void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
   q += t.hl + t.len;
   /* issuer Name (asn1.RawValue, then asn1.Unmarshal into pkix.RDNSequence) */
   if (!rdn_sequence(d, q, tbs_end, &t, &out->cn_off, &out->cn_len, &site, 50)) FAIL(site);
+  out->issuer_off = (uint32_t)q;
+  out->issuer_len = t.hl + t.len;
   q += t.hl + t.len;
   /* validity SEQUENCE { notBefore Time, notAfter Time } */
   if (!rd_tlv(d, q, tbs_end, &t) || t.tag != 0x30) FAIL(17);
@@ -377,6 +379,8 @@ void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
     if (seq.tag == 0x30) {
       if (e0 + seq.hl + (uint64_t)seq.len > tbs_end) FAIL(27);
       uint64_t e = e0 + seq.hl, e_end = e0 + seq.hl + seq.len;
+      out->exts_off = (uint32_t)e;
+      out->exts_end = (uint32_t)e_end;
       while (e < e_end) {
         tlv ext, oid, val;
         if (!rd_tlv(d, e, e_end, &ext) || ext.tag != 0x30) FAIL(28);
@@ -1178,45 +1182,28 @@ int orc_cert_meta(const uint8_t* d, size_t L, orc_meta* m) {
   orc_cert c;
   orc_parse_cert(d, L, &c);
   if (!c.ok) return 0;
-  /* the certificate is well formed as far as orc_parse_cert checks: walk to the two fields without re-checking */
-  tlv t;
-  uint64_t tbs_end = (uint64_t)c.tbs_off + c.tbs_len;
-  rd_tlv(d, c.tbs_off, tbs_end, &t);
-  uint64_t q = c.tbs_off + t.hl;
-  if (d[q] == 0xa0) { rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len; }
-  rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len;   /* serialNumber */
-  rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len;   /* signature */
-  rd_tlv(d, q, tbs_end, &t);                      /* issuer */
-  m->issuer_off = (uint32_t)q;
-  m->issuer_len = t.hl + t.len;
-  q = (uint64_t)c.spki_off + c.spki_len;
-  if (q < tbs_end && d[q] == 0x81) { rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len; }
-  if (q < tbs_end && d[q] == 0x82) { rd_tlv(d, q, tbs_end, &t); q += t.hl + t.len; }
-  if (q < tbs_end && d[q] == 0xa3) {
-    rd_tlv(d, q, tbs_end, &t);
-    tlv seq;
-    uint64_t e0 = q + t.hl;
-    rd_tlv(d, e0, e0 + t.len, &seq);
-    uint64_t e = e0 + seq.hl, e_end = e0 + seq.hl + seq.len;
-    while (e < e_end) {
-      tlv ext, oid, val;
-      rd_tlv(d, e, e_end, &ext);
-      uint64_t x = e + ext.hl, x_end = e + ext.hl + ext.len;
-      rd_tlv(d, x, x_end, &oid);
-      uint64_t oid_c = x + oid.hl;
-      x += oid.hl + oid.len;
-      rd_tlv(d, x, x_end, &val);
-      if (val.tag == 0x01) { x += val.hl + val.len; rd_tlv(d, x, x_end, &val); }
-      if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x1f) {
-        m->n_crl_ext++;
-        uint32_t before = m->n_crl;
-        if (!collect_dp_uris(d, x + val.hl, x + val.hl + val.len, m)) {
-          m->bad_crl = 1;
-          m->n_crl = before;
-        }
+  /* the parse located both inputs and validated every header on the way: the issuer Name, and the extension list */
+  m->issuer_off = c.issuer_off;
+  m->issuer_len = c.issuer_len;
+  uint64_t e = c.exts_off, e_end = c.exts_end;
+  while (e < e_end) {
+    tlv ext, oid, val;
+    rd_tlv(d, e, e_end, &ext);
+    uint64_t x = e + ext.hl, x_end = e + ext.hl + ext.len;
+    rd_tlv(d, x, x_end, &oid);
+    uint64_t oid_c = x + oid.hl;
+    x += oid.hl + oid.len;
+    rd_tlv(d, x, x_end, &val);
+    if (val.tag == 0x01) { x += val.hl + val.len; rd_tlv(d, x, x_end, &val); }
+    if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x1f) {
+      m->n_crl_ext++;
+      uint32_t before = m->n_crl;
+      if (!collect_dp_uris(d, x + val.hl, x + val.hl + val.len, m)) {
+        m->bad_crl = 1;
+        m->n_crl = before;
       }
-      e += ext.hl + ext.len;
     }
+    e += ext.hl + ext.len;
   }
   if (m->bad_crl) m->n_crl = 0;
   return 1;

@@ -60,6 +60,8 @@ typedef struct {
   int32_t is_ca;
   uint32_t spki_off, spki_len;       /* RawSubjectPublicKeyInfo: full TLV */
   uint32_t tbs_off, tbs_len;         /* RawTBSCertificate: full TLV */
+  uint32_t issuer_off, issuer_len;   /* the issuer Name TLV (RawIssuer) */
+  uint32_t exts_off, exts_end;       /* contents of the SEQUENCE OF Extension, 0/0 when the certificate has none */
   int32_t nonfatal;      /* ORC_NF_*: findings CT-go reports as x509.NonFatalErrors — the certificate is handed out
                             all the same; kept for X509 entries, dropped for precertificates and Chain[0] issuers */
 } orc_cert;

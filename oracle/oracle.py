@@ -34,7 +34,8 @@ class Cert(C.Structure):
                 ("cn_off", C.c_uint32), ("cn_len", C.c_uint32),
                 ("bc_valid", C.c_int32), ("is_ca", C.c_int32),
                 ("spki_off", C.c_uint32), ("spki_len", C.c_uint32),
-                ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32), ("nonfatal", C.c_int32)]
+                ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32), ("issuer_off", C.c_uint32), ("issuer_len", C.c_uint32),
+                ("exts_off", C.c_uint32), ("exts_end", C.c_uint32), ("nonfatal", C.c_int32)]
 
 
 NF_NEGATIVE_SERIAL, NF_LAX_INTEGER = 1, 2
