@@ -508,8 +508,17 @@ def main():
     t_gen = time.perf_counter() - t_gen
     from ct_mapreduce_amd.distributed import Group, shard as make_shard
     group = None
+    torch_fallback = None
     if dist is not None:
-        group = Group.rccl(eng, share_group_id(dist, rank, Group.unique_id), rank, world)
+        try:
+            group = Group.rccl(eng, share_group_id(dist, rank, Group.unique_id), rank, world)
+        except Exception as ex:          # noqa: BLE001 — librccl missing / communicator refused: say so, keep measuring
+            # the count all-reduce, barriers and the max of the step time then go over torch.distributed (the control
+            # path's process group); the line says so in config.parallelism.  The global-dedup modes need the group.
+            if args.global_dedup:
+                raise
+            torch_fallback = f"{type(ex).__name__}: {ex}"
+            sys.stderr.write(f"bench: RCCL group not available ({torch_fallback}); collectives over torch.distributed\n")
     elif args.global_dedup:
         group = Group.local([eng])          # N = 1: the exchange is local, this measures each mode's kernels
     if args.global_dedup == "bloom":
@@ -544,11 +553,17 @@ def main():
         if group is not None and world > 1:
             # per-issuer unique counts merged over xGMI: ncclAllReduce inside ctmr_group_issuer_counts (2 KiB)
             global_counts[0] = group.issuer_counts(len(issuers))
+        elif torch_fallback and world > 1:
+            c = torch.from_numpy(eng.issuer_counts()[:len(issuers)].astype(np.int64))
+            dist.all_reduce(c)
+            global_counts[0] = c.numpy().astype(np.uint64)
         return st
 
     def barrier():
         if group is not None and world > 1:
             group.barrier()
+        elif torch_fallback and world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -564,6 +579,8 @@ def main():
     dt = time.perf_counter() - t0
     if group is not None and world > 1:
         dt = float(group.all_reduce_u64([int(dt * 1e9)], op_max=True)[0]) * 1e-9      # the slowest rank's time
+    elif torch_fallback and world > 1:
+        dt = max_over_ranks(dist, dt, torch.device("cpu"))
 
     # HBM traffic of the map kernel per launch: PMC counters can only be collected under rocprofv3, in their own
     # passes — this script re-executes itself under the profiler on a smaller batch of the same corpus (bytes per
@@ -614,7 +631,10 @@ def main():
                                "issuerCN prefix filter + known-certificate dedup + per-issuer unique counts "
                                "(BASELINE configs[2]/[3] shape)",
                    "entries_per_gpu": E, "mean_der_bytes": stats.payload_bytes / E,
-                   "parallelism": f"log-index shards x{world}", "map_variant": args.variant or DEFAULT_VARIANT,
+                   "parallelism": f"log-index shards x{world}" + ("" if world == 1 else
+                                  " + per-issuer count all-reduce over RCCL inside the library (ctmr_group_issuer_counts)" if group is not None
+                                  else f" + count all-reduce over torch.distributed (RCCL group unavailable: {torch_fallback})"),
+                   "map_variant": args.variant or DEFAULT_VARIANT,
                    "gen_seconds": round(t_gen, 2)},
         # roofline of the dominant kernel.  `frac` is PHYSICAL when the traffic was measured: HBM bytes the kernel moved
         # (PMC counters) ÷ its average launch time ÷ peak.  The walk skips key, SAN body and signature by length, so the
