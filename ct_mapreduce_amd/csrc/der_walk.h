@@ -320,6 +320,9 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
   const uint32_t s_end = ce;
+  // a long Name (OV/EV subjects) that runs past the window: refill ONCE, here, where the window then covers the whole
+  // Name and the SubjectPublicKeyInfo header behind it — instead of somewhere in the middle and again at the key
+  if constexpr (!CN) r.touch(cs, ok ? (ce - cs) + 48u : 0u);
   uint32_t a = cs, a_end = cs;
   while (ok & (a < s_end)) {
     uint32_t t1, c1, e1;
@@ -461,8 +464,14 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   q = ce;
   // subject Name: same structure, nothing of it is consumed
   {
+#ifdef CTMR_EXPERIMENT_SKIP_SUBJECT  // sweep builds only: what validating the subject costs (round 1 skipped it by length)
+    rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
+    ok = ok & (tag == 0x30u);
+    q = ce;
+#else
     uint32_t d0 = 0, d1 = 0;
     q = walk_name<false>(r, L, q, tbs_end, ok, d0, d1);
+#endif
   }
   // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo): publicKeyInfo ::= SEQUENCE { AlgorithmIdentifier,
   // BIT STRING }; the key bits themselves are skipped by length.  A long subject (OV/EV certificates) puts this header

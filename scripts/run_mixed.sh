@@ -1,13 +1,11 @@
 #!/bin/bash
-# parity tests, then the default bench on the homogeneous and on the mixed corpus (no CPU leg), twice each
+# mixed-corpus map kernel time of build variants: TAGS="base nosubj ..." (tag X = libctmr_sweep_X.so)
 set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/mixed; mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
-for k in 1 2; do
-  for extra in "" "--mixed"; do
-    timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu $extra > $OUT/b.json 2>> $OUT/b.err
-    python -c "
-import json; d=json.loads([l for l in open('$OUT/b.json').read().splitlines() if l.startswith('{')][-1]); print('[$extra]', 'map_ms', round(d['kernel_ms']['map'],3), 'value', round(d['value']))" | tee -a $OUT/mixed.txt
-  done
+for tag in ${TAGS:-base}; do
+  lib=$R/ct_mapreduce_amd/libctmr.so
+  [ $tag != base ] && lib=$R/ct_mapreduce_amd/libctmr_sweep_$tag.so
+  CTMR_LIB=$lib timeout 600 python bench.py --mixed --no-cpu --traffic off --steps 6 > $OUT/bench_mixed_$tag.json 2> $OUT/bench_mixed_$tag.err; python -c "
+import json; d=json.loads([l for l in open('$OUT/bench_mixed_$tag.json').read().splitlines() if l.startswith('{')][-1]); print('$tag mixed', round(d['value']/1e9,3), round(d['ms_per_step'],2), round(d['kernel_ms']['map'],3))" | tee -a $OUT/summary.txt
 done
