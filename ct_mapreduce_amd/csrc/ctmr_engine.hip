@@ -141,6 +141,7 @@ struct ctmr_engine {
   std::atomic<ctmr_pipeline*> pipe{nullptr};  // asynchronous host ingestion (engine/pipeline.inc), created on first use
   std::mutex pipe_mu;
   mutable std::string err;
+  mutable std::mutex err_mu;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -229,7 +230,10 @@ int fail(const ctmr_engine* e, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (e) e->err = buf;
+  if (e) {
+    std::lock_guard<std::mutex> g(e->err_mu);  // a leaf lock: the ingestion pipeline reports errors outside the engine mutex
+    e->err = buf;
+  }
   return code;
 }
 

@@ -143,3 +143,29 @@ def test_several_threads_submit_and_wait():
     o, st, unk, eh = run_oracle(whole, issuers, FILT, False, NOW)
     assert sum(news) == int(unk.sum()) == eng.total_count()   # disjoint keys: the interleaving does not matter
     eng.close()
+
+
+def test_table_growth_happens_under_the_pipeline():
+    """The known-certificate table starts at 4 096 slots; the super-batches the worker runs make it grow (k_rehash)
+    between them — results stay those of the oracle over the whole stream."""
+    cfg = synth.config(seed=95, n_issuers=32, zipf=1, dup_permille=250, ca_permille=10, expired_permille=10)
+    issuers = synth.issuers(cfg)
+    eng = make(issuers, table_slots=1 << 12)
+    per, count = 1001, 120
+    batches = [synth.host_batch(cfg, k * per, per) for k in range(count)]
+    keep, tickets = [], []
+    for k, b in enumerate(batches):
+        a = arrays(b)
+        keep.append(a)
+        tickets.append(eng.submit_batch(a[0], a[1], a[2], a[3], b.n))
+        if k % 17 == 16:
+            eng.flush()                                # several small super-batches: several rebuilds
+    o = None
+    for b, t in zip(batches, tickets):
+        res = eng.wait(t, b.n)
+        o, st, unk, eh = run_oracle(b, issuers, FILT, False, NOW, engine=o)
+        assert (res.records["status"] == st).all()
+        assert (((res.records["flags"] & 2) != 0) == (unk != 0)).all()
+    assert eng.total_count() == o.total_count() > 60000
+    assert sorted(eng.keys(b"serials::*")) == [k for k in o.keys() if k.startswith(b"serials::")]
+    eng.close()
