@@ -130,7 +130,7 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
 // parks its chunk directly in the owning lane's LDS window.
 template <int WCH>
 __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
-  static_assert(WCH <= 16 && WCH >= 8, "cooperative fill: 16 adjacent lanes per certificate");
+  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   const uint64_t limit = map_limit(a);
   uint64_t lo = 0, hi = 0;
   if (live) cert_range(a.offsets, a.ends, i, lo, hi);
-  const uint64_t g_me = live ? win_start(lo) : ~0ull;
+  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
   {
     uint4 v[16];
     const uint32_t sub = lane & 15u;
@@ -147,11 +147,11 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
     for (int it = 0; it < 16; it++) {
       const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
       const uint64_t at = g + 16u * sub;
-      v[it] = (g != ~0ull && sub < (uint32_t)WCH && at + 16u <= limit) ? ld_payload16(a.payload + at) : make_uint4(0, 0, 0, 0);
+      v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(a.payload + at)) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < 16; it++)
-      if (sub < (uint32_t)WCH) *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+      *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
   }
   __builtin_amdgcn_wave_barrier();
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;

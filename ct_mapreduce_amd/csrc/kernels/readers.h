@@ -15,29 +15,9 @@ struct __attribute__((packed, aligned(1))) U16t { uint32_t a, b, c, d; };  // un
 // (profiles/r02/sweep_nontemporal.txt); loads alone 23.24, stores alone 22.83–23.31; the same hint on the per-entry
 // input words and the reduce-state word measured no further change.
 typedef uint32_t ctmr_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t ctmr_u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
-// Window geometry.  Default: 16 chunks (256 B) starting at the 16-byte boundary at or below the first byte needed.
-// -DCTMR_WCH=14 -DCTMR_WIN_EXACT (an experiment of the sweep build): 14 chunks (224 B) starting exactly AT that byte
-// (gfx950 serves unaligned dwordx4 loads) — 15 360 instead of 17 408 bytes of LDS per wave, 10 waves per CU instead of 9.
-#ifndef CTMR_WCH
-#define CTMR_WCH 16
-#endif
-#ifdef CTMR_WIN_EXACT
-constexpr bool kWinExact = true;
-#else
-constexpr bool kWinExact = false;
-#endif
-constexpr int MAP_WCH = CTMR_WCH;
-__device__ __forceinline__ uint64_t win_start(uint64_t byte_addr) { return kWinExact ? byte_addr : (byte_addr & ~15ull); }
-__device__ __forceinline__ uint4 ld_payload16(const uint8_t* p) {
-  if constexpr (kWinExact) {
-    const ctmr_u32x4_u* q = (const ctmr_u32x4_u*)p;
-    const ctmr_u32x4 t = __builtin_nontemporal_load(q);
-    return make_uint4(t.x, t.y, t.z, t.w);
-  } else {
-    const ctmr_u32x4 t = __builtin_nontemporal_load((const ctmr_u32x4*)p);
-    return make_uint4(t.x, t.y, t.z, t.w);
-  }
+__device__ __forceinline__ uint4 ld_payload16(const uint4* p) {
+  const ctmr_u32x4 t = __builtin_nontemporal_load((const ctmr_u32x4*)p);
+  return make_uint4(t.x, t.y, t.z, t.w);
 }
 __device__ __forceinline__ void st_stream16(uint4* p, const uint4& v) {
   ctmr_u32x4 t;
@@ -92,23 +72,22 @@ struct WinReader {
     return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
   }
   __device__ __forceinline__ void refill(uint32_t pos) {
-    const uint64_t g = win_start(base + pos);
+    const uint64_t g = (base + pos) & ~15ull;
     grel = (int32_t)(int64_t)(g - base);
-    const uint8_t* src = (const uint8_t*)g32 + g;
+    const uint4* src = (const uint4*)g32 + (g >> 4);
     uint4 v[WCH];
 #pragma unroll
     for (int k = 0; k < WCH; k++)
-      v[k] = (g + 16u * k + 16u <= limit) ? ld_payload16(src + 16 * k) : make_uint4(0, 0, 0, 0);
+      v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
   }
   __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
-    constexpr uint32_t SLACK = kWinExact ? 0u : 16u;  // an aligned window may start up to 15 bytes before pos
-    if (need > WBYTES - SLACK) need = WBYTES - SLACK;
+    if (need > WBYTES - 16u) need = WBYTES - 16u;  // the window start is 16-B aligned in HBM
     const uint32_t rel = pos - (uint32_t)grel;
     if (rel > WBYTES - need) refill(pos);
   }
-  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, WBYTES); }
+  __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) { touch(pos, 256); }
 };
 
 // WinReader whose touch_tail() (the one refill every lane of the wave reaches at the same program point,
@@ -124,7 +103,7 @@ struct WinReaderC : WinReader<WCH> {
       return;
     }
     const uint32_t lane = threadIdx.x & 63u, sub = lane & 15u;
-    const uint64_t g_me = win_start(this->base + pos);
+    const uint64_t g_me = (this->base + pos) & ~15ull;
     this->grel = (int32_t)(int64_t)(g_me - this->base);
     uint8_t* lds0 = (uint8_t*)this->win - lane * STRIDE;
     uint4 v[16];
@@ -132,12 +111,12 @@ struct WinReaderC : WinReader<WCH> {
     for (int it = 0; it < 16; it++) {
       const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
       const uint64_t at = g + 16u * sub;
-      v[it] = (sub < (uint32_t)WCH && at + 16u <= this->limit) ? ld_payload16((const uint8_t*)this->g32 + at) : make_uint4(0, 0, 0, 0);
+      v[it] = (at + 16u <= this->limit) ? ld_payload16((const uint4*)this->g32 + (at >> 4)) : make_uint4(0, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int it = 0; it < 16; it++)
-      if (sub < (uint32_t)WCH) *(uint4*)(lds0 + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
+      *(uint4*)(lds0 + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
     __builtin_amdgcn_wave_barrier();
   }
 };
