@@ -346,6 +346,8 @@ def main():
                     help="entries per GPU (weak scaling); default = BASELINE's 100M-entry batch "
                          "(≈152 GB of DER resident in HBM); halved automatically if it does not fit")
     ap.add_argument("--issuers", type=int, default=256)
+    ap.add_argument("--table-slots-log2", type=int, default=0,
+                    help="known-certificate table size (default: the power of two >= 2 x entries: load 0.35-0.47 when full)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--certs-per-tile", type=int, default=0)
     ap.add_argument("--lds-bytes", type=int, default=0)
@@ -468,8 +470,8 @@ def main():
     def setup(E):
         if args.raw:
             return setup_raw(E)
-        eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
-                          map_variant=args.variant, certs_per_tile=args.certs_per_tile,
+        eng = ctmr.Engine(device=local, table_slots=(1 << args.table_slots_log2) if args.table_slots_log2 else pow2_at_least(int(E * 2)),
+                          pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
                           lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
         eng.add_issuers(issuers)
         eng.set_filter(filt, False, now)

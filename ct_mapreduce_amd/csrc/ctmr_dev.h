@@ -52,6 +52,16 @@ __host__ __device__ inline unsigned long long key_hash(unsigned long long meta,
   h = mixk(h ^ s[2] ^ rotl64(s[3], 29) ^ rotl64(s[4], 47));
   return h;
 }
+// Probe sequence of the known-certificate table: linear.  (Tried in round 2: the home slot, then the OTHER slot of the
+// same 128-byte line — already on die after the first probe —, then the next line.  The map kernel does get faster with a
+// sparser table — 23.2 ms at 2^28 slots, 21.9 at 2^29, 20.9 at 2^30 for 94 M keys — but not with this sequence: 23.14–23.18
+// ms A/B/A/B against 23.14–23.17 linear, profiles/r02/sweep_probe_sequence.txt.  What a collision costs is the next
+// dependent ATOMIC round trip, whether or not its line is already in L2.)  `k` = 0-based index of the probe that failed at j.
+__host__ __device__ inline uint64_t probe_next(uint64_t j, uint64_t k, uint64_t mask) {
+  (void)k;
+  return (j + 1ull) & mask;
+}
+
 __host__ __device__ inline uint32_t key_tag(unsigned long long h) {
   uint32_t t = (uint32_t)(h >> 32);
   if (t == 0u) t = 1u;

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) k_keys_insert(const KeyRec* keys, uint64_
         break;
       }
     }
-    j = (j + 1) & mask;
+    j = probe_next(j, probes, mask);
   }
   slot_id[i] = sid;
 }
@@ -369,7 +369,7 @@ __device__ __forceinline__ uint32_t table_find(const Slot* table, uint64_t mask,
       for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
       if (eq) return (uint32_t)j;
     }
-    j = (j + 1) & mask;
+    j = probe_next(j, probes, mask);
   }
   return SID_NONE;
 }

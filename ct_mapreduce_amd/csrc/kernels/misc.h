@@ -139,9 +139,9 @@ __global__ void __launch_bounds__(256) k_rehash(const Slot* old_table, uint64_t 
   for (int k = 0; k < 5; k++) s[k] = o->w[3 + k];
   const unsigned long long w2 = o->w[2];
   uint64_t q = key_hash(w1, s) & mask;
-  for (;;) {  // the new table holds at most half as many members as it has slots: this terminates
+  for (uint64_t probes = 0;; probes++) {  // the new table holds at most half as many members as it has slots: this terminates
     if (atomicCAS(&table[q].w[0], 0ull, w0) == 0ull) break;
-    q = (q + 1) & mask;
+    q = probe_next(q, probes, mask);
   }
   Slot* d = table + q;
   d->w[1] = w1;

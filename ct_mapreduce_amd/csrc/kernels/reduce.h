@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t table_upsert(Slot* table, uint64_t mask, uns
         return (uint32_t)j;
       }
     }
-    j = (j + 1) & mask;
+    j = probe_next(j, probes, mask);
     if (++probes > mask) return SID_FULL;
   }
 }
@@ -199,7 +199,7 @@ __device__ __forceinline__ uint32_t insert_probe(const InsertArgs& a, uint64_t i
         return ES_DEFER;
       }
     }
-    j = (j + 1) & a.mask;
+    j = probe_next(j, probes, a.mask);
   }
   return ES_FULL;
 }
