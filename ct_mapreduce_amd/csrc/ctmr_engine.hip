@@ -362,14 +362,27 @@ int ensure_capacity(ctmr_engine* e, uint64_t incoming) {
 
 int ensure_pairs(ctmr_engine* e) {
   if (!e->pairs_dirty) return CTMR_OK;
-  HIPCHK(e, hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
-  HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
-  hipLaunchKernelGGL(k_build_pairs, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream,
-                     e->table, e->nslots, e->pairs, e->npairs - 1, e->d_count);
-  unsigned long long full;
-  HIPCHK(e, hipMemcpyAsync(&full, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  if (full) return fail(e, CTMR_E_FULL, "(expDate,issuer) table full (%llu slots)", (unsigned long long)e->npairs);
+  for (;;) {
+    HIPCHK(e, hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+    hipLaunchKernelGGL(k_build_pairs, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream,
+                       e->table, e->nslots, e->pairs, e->npairs - 1, e->d_count);
+    unsigned long long full;
+    HIPCHK(e, hipMemcpyAsync(&full, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (!full) break;
+    // more distinct (expDate, issuer) sets than slots: the statistics table grows like the member table does
+    if (e->npairs >= (1ull << 30))
+      return fail(e, CTMR_E_FULL, "(expDate,issuer) table full (%llu slots)", (unsigned long long)e->npairs);
+    PairSlot* np = nullptr;
+    if (hipMalloc(&np, e->npairs * 4 * sizeof(PairSlot)) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e, CTMR_E_NOMEM, "(expDate,issuer) table: cannot grow past %llu slots", (unsigned long long)e->npairs);
+    }
+    (void)hipFree(e->pairs);
+    e->pairs = np;
+    e->npairs *= 4;
+  }
   e->pairs_dirty = false;
   return CTMR_OK;
 }
