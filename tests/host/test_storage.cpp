@@ -10,6 +10,8 @@
 
 #include "ctmr_storage.hpp"
 
+#include <hip/hip_runtime_api.h>  // device buffers of the multi-GPU group test (host API only; g++ -D__HIP_PLATFORM_AMD__)
+
 using namespace ctmr::storage;
 
 static int g_fail = 0, g_checks = 0;
@@ -511,6 +513,146 @@ static void Test_StoreRawBatch_DeviceMeta_Gpu() {
   CHECK_EQ(eb.IssuerCounts().size(), (size_t)7);
 }
 
+// ---- the entry points a cgo host would add in round 2, bound from C++ as it would bind them
+// asynchronous ingestion (ctmr_submit_batch / ctmr_wait): get-entries-sized batches in flight, answers as the
+// synchronous call gives them
+static void Test_Pipeline_Gpu() {
+  GpuEngine sync_e(0, 1 << 18, 1 << 14), async_e(0, 1 << 18, 1 << 14);
+  ctmr_synth_config sc;
+  memset(&sc, 0, sizeof sc);
+  sc.seed = 4711; sc.n_issuers = 8; sc.dup_permille = 300; sc.ca_permille = 20; sc.expired_permille = 20;
+  std::string blob;
+  std::vector<uint64_t> ioff(1, 0);
+  for (uint32_t k = 0; k < 8; k++) {
+    std::string c(4096, '\0');
+    c.resize(ctmr_synth_issuer(&sc, k, (uint8_t*)&c[0], 4096));
+    blob += c;
+    ioff.push_back(blob.size());
+  }
+  for (GpuEngine* e : {&sync_e, &async_e}) {
+    uint32_t first;
+    e->ck(ctmr_add_issuers(e->handle(), (const uint8_t*)blob.data(), ioff.data(), 8, &first));
+    e->ck(ctmr_set_filter(e->handle(), "", 0, 1, 0));
+  }
+  const uint64_t per = 1001, batches = 40;
+  struct B { std::vector<uint8_t> pay; std::vector<uint64_t> off; std::vector<uint32_t> iss; std::vector<uint8_t> et; ctmr_ticket t; };
+  std::vector<B> bs(batches);
+  for (uint64_t k = 0; k < batches; k++) {
+    B& b = bs[k];
+    b.off.resize(per + 1); b.iss.resize(per); b.et.resize(per);
+    const uint64_t need = ctmr_synth_host(&sc, k * per, per, b.off.data(), nullptr, 0, b.iss.data(), b.et.data());
+    b.pay.resize(need + 64);
+    ctmr_synth_host(&sc, k * per, per, b.off.data(), b.pay.data(), need + 64, b.iss.data(), b.et.data());
+    async_e.ck(ctmr_submit_batch(async_e.handle(), b.pay.data(), b.off.data(), b.iss.data(), b.et.data(), per, &b.t));
+  }
+  uint64_t dup_total = 0;
+  for (uint64_t k = 0; k < batches; k++) {
+    B& b = bs[k];
+    std::vector<ctmr_record> ra(per), rs(per);
+    std::vector<uint64_t> na(per), ns(per);
+    ctmr_batch_stats sa, ss;
+    async_e.ck(ctmr_wait(async_e.handle(), b.t, ra.data(), na.data(), &sa));
+    sync_e.ck(ctmr_map_batch(sync_e.handle(), b.pay.data(), b.off.data(), b.iss.data(), b.et.data(), per, rs.data(), ns.data(), &ss));
+    CHECK(memcmp(ra.data(), rs.data(), per * sizeof(ctmr_record)) == 0);
+    CHECK_EQ(sa.n_new, ss.n_new);
+    CHECK_EQ(sa.n_dup, ss.n_dup);
+    CHECK(sa.n_new == 0 || memcmp(na.data(), ns.data(), sa.n_new * 8) == 0);
+    dup_total += sa.n_dup;
+  }
+  CHECK(dup_total > 1000);  // duplicates across batches that were in flight together
+  ctmr_batch_stats st;
+  CHECK_EQ(ctmr_wait(async_e.handle(), bs[0].t, nullptr, nullptr, &st), (int)CTMR_E_NOTFOUND);  // collected once
+  uint64_t ta, ts;
+  async_e.ck(ctmr_total_count(async_e.handle(), &ta));
+  sync_e.ck(ctmr_total_count(sync_e.handle(), &ts));
+  CHECK_EQ(ta, ts);
+}
+
+// multi-GPU groups (ctmr_group_*): two engines on one device as a local group; the owner-computes and the Bloom
+// exchange give the same global answer as one engine over the whole stream
+static void Test_Group_Gpu() {
+  ctmr_synth_config sc;
+  memset(&sc, 0, sizeof sc);
+  sc.seed = 4712; sc.n_issuers = 8; sc.dup_permille = 300; sc.ca_permille = 20; sc.expired_permille = 20;
+  std::string blob;
+  std::vector<uint64_t> ioff(1, 0);
+  for (uint32_t k = 0; k < 8; k++) {
+    std::string c(4096, '\0');
+    c.resize(ctmr_synth_issuer(&sc, k, (uint8_t*)&c[0], 4096));
+    blob += c;
+    ioff.push_back(blob.size());
+  }
+  const uint64_t n_total = 6000, half = n_total / 2;
+  auto setup = [&](GpuEngine& e) {
+    uint32_t first;
+    e.ck(ctmr_add_issuers(e.handle(), (const uint8_t*)blob.data(), ioff.data(), 8, &first));
+    e.ck(ctmr_set_filter(e.handle(), "", 0, 1, 0));
+  };
+  struct Dev { uint8_t* pay; uint64_t* off; uint32_t* iss; uint8_t* et; ctmr_record* rec; uint64_t* nw; uint64_t n; };
+  auto make_shard = [&](GpuEngine& e, uint64_t first, uint64_t n) {
+    Dev d;
+    d.n = n;
+    CHECK(hipMalloc((void**)&d.off, (n + 1) * 8) == hipSuccess);
+    CHECK(hipMalloc((void**)&d.iss, n * 4) == hipSuccess);
+    CHECK(hipMalloc((void**)&d.et, n) == hipSuccess);
+    CHECK(hipMalloc((void**)&d.rec, n * sizeof(ctmr_record)) == hipSuccess);
+    CHECK(hipMalloc((void**)&d.nw, n * 8) == hipSuccess);
+    uint64_t bytes = 0;
+    e.ck(ctmr_synth_device(e.handle(), &sc, first, n, d.off, nullptr, 0, nullptr, nullptr, &bytes));
+    CHECK(hipMalloc((void**)&d.pay, bytes + 64) == hipSuccess);
+    e.ck(ctmr_synth_device(e.handle(), &sc, first, n, d.off, d.pay, bytes + 64, d.iss, d.et, &bytes));
+    return d;
+  };
+  auto to_shard = [](const Dev& d, uint64_t base) {
+    ctmr_shard s;
+    memset(&s, 0, sizeof s);
+    s.d_payload = d.pay; s.d_offsets = d.off; s.d_issuer_idx = d.iss; s.d_entry_type = d.et; s.n = d.n;
+    s.order_base = base; s.d_records = d.rec; s.d_new_idx = d.nw;
+    return s;
+  };
+  // the reference answer: one engine, the whole stream
+  GpuEngine one(0, 1 << 16, 1 << 12);
+  setup(one);
+  Dev whole = make_shard(one, 0, n_total);
+  ctmr_batch_stats st_one;
+  one.ck(ctmr_map_batch_device(one.handle(), whole.pay, whole.off, whole.iss, whole.et, n_total, whole.rec, whole.nw, &st_one));
+  std::vector<ctmr_record> want(n_total);
+  CHECK(hipMemcpy(want.data(), whole.rec, n_total * sizeof(ctmr_record), hipMemcpyDeviceToHost) == hipSuccess);
+  std::vector<uint64_t> counts_one(8);
+  one.ck(ctmr_issuer_counts(one.handle(), counts_one.data(), 8));
+  for (int mode : {(int)CTMR_DEDUP_OWNER, (int)CTMR_DEDUP_BLOOM}) {
+    GpuEngine a(0, 1 << 16, 1 << 12), b(0, 1 << 16, 1 << 12);
+    setup(a); setup(b);
+    ctmr_engine* engines[2] = {a.handle(), b.handle()};
+    ctmr_group* g = nullptr;
+    CHECK_EQ(ctmr_group_create_local(engines, 2, &g), (int)CTMR_OK);
+    if (mode == CTMR_DEDUP_BLOOM) CHECK_EQ(ctmr_group_bloom_config(g, 1ull << 16), (int)CTMR_OK);
+    Dev d0 = make_shard(a, 0, half), d1 = make_shard(b, half, n_total - half);
+    ctmr_shard sh[2] = {to_shard(d0, 0), to_shard(d1, half)};
+    ctmr_batch_stats st[2];
+    const int rc = ctmr_group_map_batch(g, mode, sh, st);
+    if (rc != CTMR_OK) fprintf(stderr, "group: %s\n", ctmr_group_last_error(g));
+    CHECK_EQ(rc, (int)CTMR_OK);
+    std::vector<ctmr_record> got(n_total);
+    CHECK(hipMemcpy(got.data(), d0.rec, half * sizeof(ctmr_record), hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(hipMemcpy(got.data() + half, d1.rec, (n_total - half) * sizeof(ctmr_record), hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(memcmp(got.data(), want.data(), n_total * sizeof(ctmr_record)) == 0);   // WAS_UNKNOWN flags are global
+    CHECK_EQ(st[0].n_new + st[1].n_new, st_one.n_new);
+    std::vector<uint64_t> counts(8);
+    CHECK_EQ(ctmr_group_issuer_counts(g, counts.data(), 8), (int)CTMR_OK);
+    CHECK(counts == counts_one);
+    uint64_t total = 0;
+    CHECK_EQ(ctmr_group_total_count(g, &total), (int)CTMR_OK);
+    CHECK_EQ(total, st_one.n_new);
+    ctmr_group_stats gi;
+    CHECK_EQ(ctmr_group_info(g, &gi), (int)CTMR_OK);
+    CHECK(gi.world == 2 && gi.n_local == 2 && gi.transport == CTMR_TRANSPORT_LOCAL && gi.keys_sent > 0);
+    ctmr_group_destroy(g);
+    for (Dev* d : {&d0, &d1}) { hipFree(d->pay); hipFree(d->off); hipFree(d->iss); hipFree(d->et); hipFree(d->rec); hipFree(d->nw); }
+  }
+  hipFree(whole.pay); hipFree(whole.off); hipFree(whole.iss); hipFree(whole.et); hipFree(whole.rec); hipFree(whole.nw);
+}
+
 int main(int argc, char** argv) {
   bool gpu = false;
   for (int i = 1; i < argc; i++) {
@@ -545,6 +687,8 @@ int main(int argc, char** argv) {
       GpuEngine eng3(0, 1 << 16, 1 << 14);
       RUN(Test_StoreBatch_Gpu(eng3));
       RUN(Test_StoreRawBatch_DeviceMeta_Gpu());
+      RUN(Test_Pipeline_Gpu());
+      RUN(Test_Group_Gpu());
     } catch (const std::exception& ex) {
       fprintf(stderr, "GPU suites aborted: %s\n", ex.what());
       g_fail++;
