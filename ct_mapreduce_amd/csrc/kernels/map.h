@@ -40,16 +40,31 @@ __device__ __forceinline__ uint64_t map_limit(const MapArgs& a) {
 }
 
 // Everything after the bytes are addressable: walk, filters, record.
+// The per-entry inputs besides the certificate: issuer index, entry type, and whether that issuer's certificate parsed.
+// The fused kernel loads them BEFORE it waits for the certificate's bytes (k_map_fused), so that the two dependent
+// loads (issuer_idx → issuer_valid) are not two exposed round trips behind the walk.
+struct EntryIn {
+  uint32_t iss, et;
+  bool iss_in_range, iss_valid;
+};
+__device__ __forceinline__ EntryIn load_entry_in(const MapArgs& a, uint64_t idx) {
+  EntryIn e;
+  e.iss = a.issuer_idx[idx];
+  e.et = a.entry_type ? a.entry_type[idx] : 0u;
+  e.iss_in_range = e.iss != CTMR_NO_ISSUER && e.iss < a.n_issuers;
+  e.iss_valid = e.iss_in_range && a.issuer_valid[e.iss] != 0;
+  return e;
+}
+
 template <class R>
-__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, uint4& o0,
+__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, const EntryIn& in, uint4& o0,
                                         uint4& o1) {
   Walk w;
   const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
   const FilterDev* f = a.filt;
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
   bool ok = walk_cert(r, L, w, f->active != 0u, fv);  // L > 2^31-1 is rejected inside, without divergence
-  const uint32_t iss = a.issuer_idx[idx];
-  const uint32_t et = a.entry_type ? a.entry_type[idx] : 0u;
+  const uint32_t iss = in.iss, et = in.et;
   // An X509 entry's certificate was parsed by ct.LogEntryFromLeaf, which keeps it unless the error is fatal
   // (ct-fetch.go:452-459); a precertificate is parsed in insertCTWorker and dropped on ANY error, CT-go's
   // x509.NonFatalErrors included (:202-209).  Fields of a dropped certificate are not reported.
@@ -65,9 +80,9 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
     status = CTMR_ST_FILTERED_EXPIRED;
   } else if (!w.cn_match) {
     status = CTMR_ST_FILTERED_CN;
-  } else if (iss == CTMR_NO_ISSUER || iss >= a.n_issuers) {
+  } else if (!in.iss_in_range) {
     status = CTMR_ST_NO_ISSUER;
-  } else if (!a.issuer_valid[iss]) {
+  } else if (!in.iss_valid) {
     status = CTMR_ST_ISSUER_PARSE_ERROR;
   } else {
     status = CTMR_ST_PASS;
@@ -89,6 +104,12 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   o0 = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
   o1 = make_uint4(s[1], s[2], s[3], s[4]);
   if (a.meta_loc) a.meta_loc[idx] = make_uint2(ok ? w.meta_issuer : META_NONE, ok ? w.meta_crl : META_NONE);
+}
+
+template <class R>
+__device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, uint4& o0, uint4& o1) {
+  const EntryIn in = load_entry_in(a, idx);
+  map_one(r, len64, idx, a, in, o0, o1);
 }
 
 template <class R>

@@ -126,6 +126,14 @@ struct WinReaderC : WinReader<WCH> {
 // outside is clamped and remembered in `miss`; the kernel then repeats that certificate with the exact GlobalReader.
 // On well-formed certificates the walk's touch() hints keep every ld4 inside (measured on the synthetic corpus: 0
 // misses in 200 000 certificates once the three reads behind the TBS go through ldg()).
+// Something to do while a refill is in flight (k_map_pipe: one step of the PREVIOUS group's table probe — its atomic
+// is issued between the loads and the LDS stores that wait for them, so its round trip hides behind theirs).
+struct RefillHook {
+  void* ctx;
+  void (*issue)(void*);
+  void (*resolve)(void*);
+};
+
 template <int WCH>
 struct WinReaderS : WinReaderC<WCH> {
   static constexpr bool kNoClamp = true;  // ld4 clamps into the window itself

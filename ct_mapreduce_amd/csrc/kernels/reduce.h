@@ -325,6 +325,14 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   const uint64_t limit = map_limit(a);
   uint64_t lo = 0, hi = 0;
   if (live) cert_range(a.offsets, a.ends, i, lo, hi);
+  // the entry's other inputs and what hangs off them (issuer_idx → issuer_valid, canonical index): issued now, they
+  // return while the certificate's bytes are on their way, instead of costing dependent round trips behind the walk
+  EntryIn in{CTMR_NO_ISSUER, 0u, false, false};
+  uint32_t canon = 0;
+  if (live) {
+    in = load_entry_in(a, i);
+    canon = in.iss_in_range ? ia.canon[in.iss] : 0u;
+  }
   const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
   {
     uint4 v[16];
@@ -346,15 +354,14 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   if (live) {
     WinReaderS<WCH> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
                         (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
-    map_one(r, hi - lo, i, a, o0, o1);
+    map_one(r, hi - lo, i, a, in, o0, o1);
     if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
       GlobalReader g{(const uint32_t*)a.payload, lo};
-      map_one(g, hi - lo, i, a, o0, o1);
+      map_one(g, hi - lo, i, a, in, o0, o1);
     }
     const uint32_t status = o0.x & 0xffu;
-    uint32_t state = ES_NONE, canon = 0;
+    uint32_t state = ES_NONE;
     if (status == CTMR_ST_PASS) {
-      canon = ia.canon[o0.z];
       state = insert_probe(ia, i, o0, o1, canon, claimed, q0, q1, q2, q3);
       if (state != ES_CLAIMED && state != ES_DEFER) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
     }
