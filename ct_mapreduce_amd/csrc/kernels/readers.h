@@ -127,14 +127,14 @@ struct WinReaderC : WinReader<WCH> {
 // On well-formed certificates the walk's touch() hints keep every ld4 inside (measured on the synthetic corpus: 0
 // misses in 200 000 certificates once the three reads behind the TBS go through ldg()).
 // Something to do while a refill is in flight (k_map_pipe: one step of the PREVIOUS group's table probe — its atomic
-// is issued between the loads and the LDS stores that wait for them, so its round trip hides behind theirs).
-struct RefillHook {
-  void* ctx;
-  void (*issue)(void*);
-  void (*resolve)(void*);
+// is issued between the tail loads and the refill, and looked at once the refill's LDS stores have waited for their
+// loads, so its round trip hides behind theirs).
+struct NoRefillHook {
+  __device__ __forceinline__ void issue() {}
+  __device__ __forceinline__ void resolve() {}
 };
 
-template <int WCH>
+template <int WCH, class Hook = NoRefillHook>
 struct WinReaderS : WinReaderC<WCH> {
   static constexpr bool kNoClamp = true;  // ld4 clamps into the window itself
   mutable uint32_t miss;
@@ -143,6 +143,7 @@ struct WinReaderS : WinReaderC<WCH> {
   // three dependent, uncoalesced global round trips per wave; now they are register selects.
   uint32_t tl[8];
   uint32_t tl_pos;  // certificate offset of tl[0]'s first byte; 0x80000000 = not fetched (positions are < 2^31)
+  Hook hook{};  // by value: a pointer to state that lives across loop iterations keeps that state out of registers
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     uint32_t rel = pos - (uint32_t)this->grel;
     constexpr uint32_t LAST = WinReader<WCH>::WBYTES - 8u;
@@ -156,7 +157,9 @@ struct WinReaderS : WinReaderC<WCH> {
     const bool have = ta + 32u <= this->limit;
     const uint8_t* tp = (const uint8_t*)this->g32 + (have ? ta : 0ull);
     const U16t a = *(const U16t*)tp, b = *(const U16t*)(tp + 16);  // in flight with the refill below
+    hook.issue();
     WinReaderC<WCH>::touch_tail(pos, tail);
+    hook.resolve();
     tl[0] = a.a; tl[1] = a.b; tl[2] = a.c; tl[3] = a.d;
     tl[4] = b.a; tl[5] = b.b; tl[6] = b.c; tl[7] = b.d;
     tl_pos = have ? tail : 0x80000000u;

@@ -6,6 +6,7 @@ Names follow the reference: `Engine.map_batch` is the batched body of insertCTWo
 (storage/types.go:83-102) on byte strings.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -97,6 +98,8 @@ class Engine:
     def __init__(self, device=0, table_slots=0, pair_slots=0, max_issuers=0, certs_per_tile=0,
                  lds_tile_bytes=0, map_variant=0, profile=False, collect_meta=False, max_table_slots=0):
         self._lib = N.lib()
+        if not map_variant:   # kernel experiments (scripts/run_*.sh with a sweep build of the library): whole test suites on another variant
+            map_variant = int(os.environ.get("CTMR_MAP_VARIANT", "0"))
         cfg = N.Config(struct_size=C.sizeof(N.Config), device=device, table_slots=table_slots,
                        pair_slots=pair_slots, max_issuers=max_issuers, certs_per_tile=certs_per_tile,
                        lds_tile_bytes=lds_tile_bytes, map_variant=map_variant, profile=int(profile),
