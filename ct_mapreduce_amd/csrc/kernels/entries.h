@@ -119,28 +119,11 @@ __device__ __forceinline__ bool eq16_prefix(const U16& x, const uint4& y, uint32
   return eq;
 }
 
-__global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < a.n;
-  uint64_t lo = 0;
-  uint32_t len = 0;
-  bool need = false;
-  uint32_t result = CTMR_NO_ISSUER;
-  if (live) {
-    if (a.retry) {
-      result = a.issuer_idx[i];
-      need = result == ISS_UNREGISTERED;
-    } else {
-      need = a.entry_type[i] != CTMR_ENTRY_INVALID;
-    }
-    if (need) {
-      lo = a.chain0_start[i];
-      len = a.chain0_len[i];
-      need = len != 0u;
-      if (!need) result = CTMR_NO_ISSUER;
-    }
-  }
+// The match of one wave's 64 entries (lane = entry): `need` lanes carry Chain[0] = blob[lo, lo+len); `result` comes in
+// as what a lane that needs no match keeps (CTMR_NO_ISSUER, or the previous round's index in a retry).  Writes
+// issuer_idx[i] and the unregistered report.  Must be called by all 64 lanes.
+__device__ __forceinline__ void match_wave(const MatchArgs& a, bool need, uint64_t lo, uint32_t len, uint32_t result,
+                                           uint64_t i, bool live, uint32_t lane) {
   DevBytes b{a.blob};
   unsigned long long qh = 0;
   uint32_t j = 0;
@@ -239,7 +222,7 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
       const unsigned long long at = base + (unsigned long long)__popcll(mu & ((1ull << lane) - 1ull));
       if (unreg && at < a.unreg_cap) a.unreg_list[at] = (uint32_t)i;
     }
-    return;
+    return;  // of match_wave: wave-uniform (report_all is a kernel argument)
   }
   // one claim per distinct hash per wave (a cold start has every lane here)
   unsigned long long todo_u = mu;
@@ -270,6 +253,76 @@ __global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
       if (at < a.unreg_cap) a.unreg_list[at] = (uint32_t)i;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) k_chain0_match(MatchArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < a.n;
+  uint64_t lo = 0;
+  uint32_t len = 0;
+  bool need = false;
+  uint32_t result = CTMR_NO_ISSUER;
+  if (live) {
+    if (a.retry) {
+      result = a.issuer_idx[i];
+      need = result == ISS_UNREGISTERED;
+    } else {
+      need = a.entry_type[i] != CTMR_ENTRY_INVALID;
+    }
+    if (need) {
+      lo = a.chain0_start[i];
+      len = a.chain0_len[i];
+      need = len != 0u;
+      if (!need) result = CTMR_NO_ISSUER;
+    }
+  }
+  match_wave(a, need, lo, len, result, i, live, lane);
+}
+
+// Decode and first match round in one kernel (the default for raw input): the lane that decoded an entry's framing goes
+// straight on to the match with Chain[0]'s position in registers.  The framing words lie in the lines the match (Chain[0]
+// begins right behind the chain header) and the map (the leaf header sits in front of the certificate) fetch anyway; as a
+// kernel of its own the decode fetched ≈ 4 lines per entry for ≈ 40 bytes of use and was bound by exactly that
+// (3.7 ms per 40 M entries).  Retry rounds (a Chain[0] that had to be registered first) run k_chain0_match on the arrays
+// written here.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_decode_match(DecodeArgs a, MatchArgs m) {
+  __shared__ uint32_t cnt[4];
+  if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const uint64_t base = (uint64_t)blockIdx.x * DECODE_PER_BLOCK;
+  const uint32_t lane = threadIdx.x & 63u;
+  DevBytes b{a.blob};
+#pragma unroll 1
+  for (uint32_t k = 0; k < DECODE_PER_BLOCK / 256; k++) {
+    if (base + k * 256u >= a.n) break;  // block-uniform
+    const uint64_t i = base + k * 256u + threadIdx.x;
+    const bool live = i < a.n;
+    EntryDec d;
+    d.ok = false; d.entry_type = 0; d.chain0_lo = 0; d.chain0_len = 0; d.n_chain = 0;
+    if (live) {
+      decode_entry(b, a.bounds[2 * i], a.bounds[2 * i + 1], a.bounds[2 * i + 2], d);
+      a.cert_start[i] = d.ok ? d.cert_lo : 0ull;
+      a.cert_end[i] = d.ok ? d.cert_hi : 0ull;
+      a.entry_type[i] = d.ok ? (uint8_t)d.entry_type : (uint8_t)CTMR_ENTRY_INVALID;
+      if (a.timestamp) a.timestamp[i] = d.ok ? d.timestamp : 0ull;
+      a.chain0_start[i] = d.ok ? d.chain0_lo : 0ull;
+      a.chain0_len[i] = d.ok ? d.chain0_len : 0u;
+      c0 += d.ok && d.entry_type == 0;
+      c1 += d.ok && d.entry_type == 1;
+      c2 += !d.ok;
+      c3 += d.ok && d.n_chain == 0;
+    }
+    const bool need = live && d.ok && d.chain0_len != 0u;
+    match_wave(m, need, d.chain0_lo, d.chain0_len, CTMR_NO_ISSUER, i, live, lane);
+  }
+  if (c0) atomicAdd(&cnt[0], c0);
+  if (c1) atomicAdd(&cnt[1], c1);
+  if (c2) atomicAdd(&cnt[2], c2);
+  if (c3) atomicAdd(&cnt[3], c3);
+  __syncthreads();
+  if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(&a.counters[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
 }
 
 }  // namespace ctmr

@@ -404,7 +404,7 @@ typedef struct {
   uint64_t n_no_chain;        /* decoded entries with len(Chain) < 1 */
   uint64_t n_issuers_added;   /* distinct Chain[0] certificates this call registered */
   uint64_t blob_bytes;        /* bounds[2n] - bounds[0] */
-  float ms_decode, ms_match;  /* filled when config.profile */
+  float ms_decode, ms_match;  /* filled when config.profile; decode and the first match round run as one kernel: ms_decode = 0, ms_match = both */
 } ctmr_decode_stats;
 
 int ctmr_decode_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
