@@ -2,7 +2,7 @@
 # what the driver does at round end (build check, smoke, GPU tests, default bench) + the profiled run of the same command
 # and the secondary bench lines DESIGN.md quotes
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; mkdir -p $OUT; rm -rf $OUT/*
 cd $R
 export TMPDIR=/tmp
 timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -3
@@ -16,6 +16,7 @@ print('default', d['value'], d['ms_per_step'], 'frac', r['frac'], 'alg', r['frac
   find $OUT/prof -name "*.csv" -size +1M -delete )
 python -c "
 import json; d=json.loads([l for l in open('$OUT/bench_final_profiled.json').read().splitlines() if l.startswith('{')][-1]); print('profiled run:', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['kernel_ms'])"
+[ -n "${CORE:-}" ] && exit 0
 timeout 900 python bench.py --mixed --no-cpu > $OUT/bench_mixed.json 2> $OUT/bench_mixed.err; python -c "
 import json; d=json.loads([l for l in open('$OUT/bench_mixed.json').read().splitlines() if l.startswith('{')][-1]); print('mixed', d['value'], d['ms_per_step'], d['kernel_ms'], d['roofline']['frac'])"
 timeout 900 python bench.py --raw --meta --pem --no-cpu > $OUT/bench_raw_meta.json 2> $OUT/bench_raw_meta.err; python -c "
