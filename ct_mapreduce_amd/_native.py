@@ -14,6 +14,7 @@ ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST
     ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
 ST_COUNT = 8
 ABI_VERSION = 3
+CHAIN0_EXACT, CHAIN0_TRUSTED_LOG = 0, 1
 ENTRY_INVALID = 0xFF
 FL_PRECERT, FL_WAS_UNKNOWN, FL_LONG_SERIAL = 1, 2, 4
 NO_ISSUER = 0xFFFFFFFF
@@ -146,6 +147,7 @@ SIGNATURES = {
     "ctmr_group_barrier": (C.c_int, [_P]),
     "ctmr_pem_encode_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "ctmr_set_issuer_autoregister": (C.c_int, [_P, C.c_int]),
+    "ctmr_set_chain0_match": (C.c_int, [_P, C.c_int]),
     "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "ctmr_exchange_export_view_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(EntryView), C.c_uint64, _P, C.c_uint32,
                                                    _P, C.POINTER(C.c_uint64)]),

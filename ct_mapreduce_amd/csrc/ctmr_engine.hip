@@ -175,6 +175,8 @@ struct ctmr_engine {
   std::vector<unsigned long long> h_idb_ht;
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
   bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
+  int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
+  std::unordered_map<unsigned long long, uint32_t> qh_first;  // candidate hash → first registered certificate with it
   std::vector<std::string> pending_issuers;  // auto_register off: what the last decode found unregistered
   unsigned long long* d_pend = nullptr;    // PEND_SLOTS claim words
   uint32_t* d_unreg = nullptr;             // UNREG_CAP entry indices

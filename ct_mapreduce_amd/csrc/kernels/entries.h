@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) k_entry_decode(DecodeArgs a) {
 // is compared, so equal means identical.  Unregistered certificates are reported once per distinct hash
 // (pend[] claims) for the host to register; `retry` re-examines only entries still marked unregistered.
 constexpr uint32_t ISS_UNREGISTERED = 0xfffffffeu;
+constexpr uint32_t HT_TWIN = 0x80000000u;  // in the low word of an issuer hash-table entry (issuer indices are < 2^24)
 constexpr uint32_t PEND_SLOTS = 8192;  // distinct unknown Chain[0] hashes remembered per launch
 #ifndef CTMR_MATCH_PER_STEP
 #define CTMR_MATCH_PER_STEP 4
@@ -96,11 +97,16 @@ struct MatchArgs {
   const uint8_t* idb_der;       // registered certificates, each at a 16-byte aligned offset, zero padded
   const uint64_t* idb_off;      // per issuer: offset into idb_der
   const uint32_t* idb_len;
-  const unsigned long long* ht; // open addressing: (candidate hash & ~0xffffffff) | (issuer index + 1), 0 = empty
+  const unsigned long long* ht; // open addressing: (candidate hash & ~0xffffffff) | HT_TWIN? | (issuer index + 1), 0 = empty
   uint32_t ht_mask;
   uint32_t retry;
+  // CTMR_CHAIN0_TRUSTED_LOG: a candidate whose table word does not carry HT_TWIN is taken on its hash and length
+  // (it was parsed in full when it was registered); HT_TWIN = another registered certificate has the same candidate
+  // hash, so the bytes decide
+  uint32_t trusted;
   // unregistered report
   unsigned long long* pend;     // PEND_SLOTS claim words (zeroed by the host)
+  uint32_t* pend_min;           // per claim word: the lowest entry index with that hash (0xffffffff-filled by the host)
   uint32_t* unreg_list;         // entry indices, one per distinct hash
   uint32_t unreg_cap;
   uint32_t report_all;          // 1 = list EVERY unregistered entry (no per-hash claim): see the note at the report
@@ -148,10 +154,15 @@ __device__ __forceinline__ void match_wave(const MatchArgs& a, bool need, uint64
         }
         j = (j + 1u) & a.ht_mask;
         if ((v ^ qh) >> 32 == 0ull) {
-          const uint32_t c = (uint32_t)v - 1u;
+          const uint32_t c = ((uint32_t)v & ~HT_TWIN) - 1u;
           const uint32_t clen = a.idb_len[c];
           db_off = a.idb_off[c];
           if (clen == len) {
+            if (a.trusted && !((uint32_t)v & HT_TWIN)) {
+              result = c;  // length, first and last 16 bytes identify a certificate that was parsed when it was registered
+              searching = false;
+              break;
+            }
             cand = c;
             break;
           }
@@ -209,7 +220,8 @@ __device__ __forceinline__ void match_wave(const MatchArgs& a, bool need, uint64
   const bool unreg = live && result == ISS_UNREGISTERED;
   const unsigned long long mu = __ballot(unreg);
   if (lane == 0 && mu) atomicAdd(&a.counters[0], (unsigned long long)__popcll(mu));
-  // The per-hash claim below reports ONE certificate per candidate hash (length, first and last 16 bytes) per round:
+  // The per-hash claim below reports ONE certificate per candidate hash (length, first and last 16 bytes) per round
+  // (the host reads pend[] / pend_min[]; unreg_list carries only what overflowed the claim table):
   // right for real chains, where distinct certificates differ there, but a batch with many distinct certificates that
   // agree in those 36 bytes (a hostile or corrupted log: the same issuer certificate damaged in hundreds of places)
   // would register one of them per round.  When registration has not converged after two rounds the host switches
@@ -232,21 +244,22 @@ __device__ __forceinline__ void match_wave(const MatchArgs& a, bool need, uint64
     const unsigned long long same = __ballot(unreg && qh == lq) & todo_u;
     todo_u &= ~same;
     if ((int)lane != leader) continue;
+    // the certificate registered for a hash is the one with the LOWEST log index that carries it — whatever order the
+    // waves run in (the leader is its wave's lowest such lane): registration order, and in the trusted-log mode the
+    // certificate a hash stands for, are a function of the input alone
     uint32_t k = (uint32_t)(qh >> 32) & (PEND_SLOTS - 1u);
     bool first = false, placed = false;
     for (uint32_t probes = 0; probes < 64u && !placed; probes++) {
       const unsigned long long old = atomicCAS(&a.pend[k], 0ull, qh);
-      if (old == 0ull) {
-        first = true;
+      if (old == 0ull || old == qh) {
         placed = true;
-      } else if (old == qh) {
-        placed = true;
+        atomicMin(&a.pend_min[k], (uint32_t)i);
       }
       k = (k + 1u) & (PEND_SLOTS - 1u);
     }
     if (!placed) {
       atomicAdd(&a.counters[2], 1ull);
-      first = true;  // overflow: report it anyway (the host dedups by bytes)
+      first = true;  // claim table overflow: list the entry itself (the host dedups by bytes)
     }
     if (first) {
       const unsigned long long at = atomicAdd(&a.counters[1], 1ull);

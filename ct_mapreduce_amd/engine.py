@@ -372,6 +372,11 @@ class Engine:
     def set_issuer_autoregister(self, on: bool):
         self._ck(self._lib.ctmr_set_issuer_autoregister(self._h, int(bool(on))))
 
+    def set_chain0_match(self, mode: int):
+        """N.CHAIN0_EXACT (default: every byte of every Chain[0] compared) or N.CHAIN0_TRUSTED_LOG (compared on the
+        first sighting per call, then identified by length + first/last 16 bytes) — include/ctmr.h."""
+        self._ck(self._lib.ctmr_set_chain0_match(self._h, int(mode)))
+
     def pending_issuers(self):
         """Distinct Chain[0] certificates the last raw-entry call found unregistered (auto-registration off)."""
         need, cnt = C.c_size_t(), C.c_uint64()

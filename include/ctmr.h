@@ -424,6 +424,24 @@ int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds
  * one agreed order with ctmr_add_issuers on every rank, call again. */
 int ctmr_set_issuer_autoregister(ctmr_engine* e, int on);
 int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need, uint64_t* count);
+/* How Chain[0] is identified (cmd/ct-fetch/ct-fetch.go:221 parses it in full for every entry).
+ *   CTMR_CHAIN0_EXACT (default): every byte of every entry's Chain[0] is compared with the registered certificate —
+ *     equal means identical, whatever the log serves; the identification costs 871 B of HBM reads per entry on the
+ *     synthetic corpus and bounds the raw path.
+ *   CTMR_CHAIN0_TRUSTED_LOG: a certificate is parsed in full when it is REGISTERED (its first sighting, or
+ *     ctmr_add_issuers); afterwards an entry is attributed to it when length, first 16 and last 16 bytes (the end of
+ *     the signature) agree — no byte of Chain[0] beyond the lines the framing decode touches anyway is read.  Identical results on
+ *     everything a log that serves the chains it validated can produce (two certificates with the same last 16
+ *     signature bytes do not occur); a Chain[0] that agrees with a registered certificate in those 36 bytes but not
+ *     in between — a damaged copy — is attributed to that certificate, where the reference would parse the bytes
+ *     it was given (a parse error, or another issuer).  Which certificate a (length, head, tail) triple stands for
+ *     is decided by the lowest log index that carries it in the call that registers it — not by scheduling.  extra_data is not covered
+ *     by the log's Merkle tree and the reference verifies neither STH nor inclusion, so its own trust in the log is no
+ *     narrower; the choice is the host's.  Registered certificates that agree in those 36 bytes with another
+ *     registered certificate are always compared bytewise. */
+#define CTMR_CHAIN0_EXACT 0
+#define CTMR_CHAIN0_TRUSTED_LOG 1
+int ctmr_set_chain0_match(ctmr_engine* e, int mode);
 /* ctmr_exchange_export_device over an entry view (raw get-entries batches; same contract). */
 int ctmr_exchange_export_view_device(ctmr_engine* e, const uint8_t* d_blob, uint64_t blob_bytes,
                                      const ctmr_entry_view* d_view, uint64_t n, ctmr_record* d_records,

@@ -223,3 +223,99 @@ def test_many_chain0_certificates_sharing_length_head_and_tail_register_in_few_r
     check_against_oracle(eng, raw, o, res)
     assert eng.issuer_count() == 301 and res.decode.n_issuers_added == 301
     eng.close()
+
+
+def test_trusted_log_chain0_match():
+    """CTMR_CHAIN0_TRUSTED_LOG (include/ctmr.h): identical to the exact mode — and to the oracle — on everything a log
+    that serves the chains it validated can produce, mutated FRAMING included; the one difference is a Chain[0] that
+    copies a registered certificate except strictly between its first and last 16 bytes."""
+    rng = random.Random(7)
+    cfg = synth.config(seed=20260921 + 13, n_issuers=48, dup_permille=100, ca_permille=10, expired_permille=10)
+    raw = synth.host_entries(cfg, 0, 30000)
+    pairs = []
+    for i in range(raw.n):
+        leaf, extra = raw.leaf_input(i), raw.extra_data(i)
+        if rng.random() < 0.1:
+            leaf, extra = mutate_entry(rng, leaf, extra)          # framing damage: lengths, types, cuts, insertions
+        pairs.append((leaf, extra))
+    mixed = RawEntries.from_pairs(pairs)
+    mixed.blob = np.concatenate([mixed.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    o = orc.Engine(b"", False, NOW)
+    eng = ctmr.Engine(device=0, table_slots=1 << 17, pair_slots=1 << 16)
+    eng.set_filter(b"", False, NOW)
+    eng.set_chain0_match(N.CHAIN0_TRUSTED_LOG)
+    res = eng.map_entries(mixed)
+    check_against_oracle(eng, mixed, o, res)
+    n_iss = eng.issuer_count()
+    # a second call: every issuer is registered, none of its bytes beyond head and tail is read again
+    raw2 = synth.host_entries(cfg, 30000, 30000)
+    res2 = eng.map_entries(raw2)
+    check_against_oracle(eng, raw2, o, res2)
+    assert eng.issuer_count() >= n_iss
+    # the documented difference.  40 000 good entries of ONE issuer, then copies of that issuer certificate damaged in
+    # the middle: the exact mode gives the oracle's answer (the damaged certificate is another issuer, or does not
+    # parse); the trusted mode attributes them to the certificate registered for that (length, head, tail) — the one
+    # with the lowest log index, whatever order the waves ran in — and differs NOWHERE else.
+    cfg1 = synth.config(seed=77, n_issuers=1)
+    good = synth.host_entries(cfg1, 0, 40000)
+    iss = synth.issuer(cfg1, 0)
+    pairs = [(good.leaf_input(i), good.extra_data(i)) for i in range(good.n)]
+    n_bad = 64
+    src = [k for k in range(400) if good.leaf_input(k)[10:12] == b"\x00\x00"][:n_bad]   # x509 entries: extra_data = the chain
+    for t, k in enumerate(src):
+        dmg = bytearray(iss)
+        dmg[200 + 3 * t] ^= 0x40                                    # inside the body, far from head and tail
+        pairs.append((good.leaf_input(k), chain([bytes(dmg)])))
+    both = RawEntries.from_pairs(pairs)
+    both.blob = np.concatenate([both.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    out = {}
+    for mode in (N.CHAIN0_EXACT, N.CHAIN0_TRUSTED_LOG):
+        e2 = ctmr.Engine(device=0, table_slots=1 << 17, pair_slots=1 << 16)
+        e2.set_filter(b"", False, NOW)
+        e2.set_chain0_match(mode)
+        out[mode] = e2.map_entries(both)
+        if mode == N.CHAIN0_EXACT:
+            check_against_oracle(e2, both, orc.Engine(b"", False, NOW), out[mode])
+        e2.close()
+    ex, tr = out[N.CHAIN0_EXACT].records, out[N.CHAIN0_TRUSTED_LOG].records
+    head = slice(0, good.n)
+    for f in ("status", "flags", "serial_len", "exp_hour", "serial", "issuer_idx"):
+        assert (ex[f][head] == tr[f][head]).all(), f
+    # trusted: the damaged copies behave exactly like the entries whose leaves they repeat (0..63), as known duplicates
+    assert (tr["status"][good.n:] == tr["status"][src]).all()
+    was_pass = tr["status"][src] == orc.ST_PASS
+    assert was_pass.sum() > n_bad // 2
+    assert (tr["issuer_idx"][good.n:][was_pass] == tr["issuer_idx"][src][was_pass]).all()
+    assert ((tr["flags"][good.n:][was_pass] & 2) == 0).all()
+    # exact: wherever the leaf gets as far as the issuer, it is NOT the good certificate's
+    ex_tail = ex[good.n:][was_pass]
+    assert ((ex_tail["status"] != orc.ST_PASS) | (ex_tail["issuer_idx"] != ex["issuer_idx"][src][was_pass])).all()
+    eng.close()
+
+
+def test_trusted_log_never_trusts_registered_certificates_that_share_a_candidate_hash():
+    """Two REGISTERED certificates that agree in length, first and last 16 bytes are always compared bytewise: the
+    trusted mode then equals the exact mode even on such a pair."""
+    cfg = synth.config(seed=78, n_issuers=1)
+    good = synth.host_entries(cfg, 0, 6000)
+    iss = synth.issuer(cfg, 0)
+    twin = bytearray(iss)
+    twin[len(iss) // 2] ^= 0x01                                      # the signature no longer verifies; nobody checks it
+    twin = bytes(twin)
+    pairs = []
+    for i in range(good.n):
+        pairs.append((good.leaf_input(i), chain([twin if i % 3 == 0 else iss])))
+    raw = RawEntries.from_pairs(pairs)
+    raw.blob = np.concatenate([raw.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    recs = {}
+    for mode in (N.CHAIN0_EXACT, N.CHAIN0_TRUSTED_LOG):
+        eng = ctmr.Engine(device=0, table_slots=1 << 15, pair_slots=1 << 14)
+        eng.set_filter(b"", False, NOW)
+        eng.set_chain0_match(mode)
+        eng.add_issuers([iss, twin])
+        res = eng.map_entries(raw)
+        check_against_oracle(eng, raw, orc.Engine(b"", False, NOW), res)
+        recs[mode] = res.records
+        eng.close()
+    for f in ("status", "flags", "issuer_idx", "serial"):
+        assert (recs[N.CHAIN0_EXACT][f] == recs[N.CHAIN0_TRUSTED_LOG][f]).all(), f
