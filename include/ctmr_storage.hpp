@@ -634,6 +634,8 @@ class GpuEngine {
   void SetFilter(const std::string& issuerCNFilter, bool logExpiredEntries, int64_t now_unix) {
     ck(ctmr_set_filter(h_, issuerCNFilter.data(), issuerCNFilter.size(), logExpiredEntries ? 1 : 0, now_unix));
   }
+  // how raw-entry calls identify Chain[0] (ct-fetch.go:221): CTMR_CHAIN0_EXACT (default) | CTMR_CHAIN0_TRUSTED_LOG
+  void SetChain0Match(int mode) { ck(ctmr_set_chain0_match(h_, mode)); }
   uint32_t AddIssuer(const std::string& chain0_der) {
     const uint64_t off[2] = {0, chain0_der.size()};
     uint32_t first = 0;

@@ -448,7 +448,7 @@ static void Test_StoreBatch_Gpu(GpuEngine& eng) {
 
 // N2 + N3 through the host mirror: raw get-entries buffers + the IssuerMetadata memo on the GPU must leave the
 // cache and the backend in the same state as the packed batch with per-certificate Accumulate on the host.
-static void Test_StoreRawBatch_DeviceMeta_Gpu() {
+static void Test_StoreRawBatch_DeviceMeta_Gpu(int chain0_mode = CTMR_CHAIN0_EXACT) {
   ctmr_synth_config cfg;
   memset(&cfg, 0, sizeof cfg);
   cfg.seed = 78; cfg.n_issuers = 7; cfg.dup_permille = 150; cfg.ca_permille = 30; cfg.expired_permille = 30;
@@ -464,6 +464,7 @@ static void Test_StoreRawBatch_DeviceMeta_Gpu() {
   FilesystemDatabase da(&ba, &ca, &ea), db(&bb, &cb, &eb);
   ea.SetFilter("Synth Issuer 00", false, 1767225600ll);
   eb.SetFilter("Synth Issuer 00", false, 1767225600ll);
+  eb.SetChain0Match(chain0_mode);  // trusted-log identification of Chain[0]: the same results on what a log serves
   std::vector<uint8_t> status_a, status_b;
   uint64_t new_a = 0, new_b = 0;
   for (size_t first = 0; first < N; first += 900) {
@@ -687,6 +688,7 @@ int main(int argc, char** argv) {
       GpuEngine eng3(0, 1 << 16, 1 << 14);
       RUN(Test_StoreBatch_Gpu(eng3));
       RUN(Test_StoreRawBatch_DeviceMeta_Gpu());
+      RUN(Test_StoreRawBatch_DeviceMeta_Gpu(CTMR_CHAIN0_TRUSTED_LOG));
       RUN(Test_Pipeline_Gpu());
       RUN(Test_Group_Gpu());
     } catch (const std::exception& ex) {
