@@ -1,5 +1,5 @@
 """Host-side view of ONE raw get-entries entry, for the rare certificates the host must parse itself
-(CTMR_MK_HOST items, serials longer than a record carries).  The batch decode is the GPU's (k_entry_decode);
+(CTMR_MK_HOST items, serials longer than a record carries).  The batch decode is the GPU's (k_decode_match);
 this is RFC 6962 §3.4 / §4.6 framing only, for a single entry the GPU already accepted."""
 
 

@@ -1,4 +1,4 @@
-"""One-off fuzz campaign on the GPU box for the raw get-entries path (k_entry_decode → k_chain0_match → map/reduce):
+"""One-off fuzz campaign on the GPU box for the raw get-entries path (k_decode_match → map/reduce):
 damaged TLS framing and damaged certificate bodies against the oracle's LogEntryFromLeaf + insertCTWorker restatement.
     gpurun -- 'python scripts/fuzz_gpu_entries.py 1000000'
 """

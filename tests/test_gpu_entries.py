@@ -1,4 +1,4 @@
-"""-m gpu, N2: raw get-entries → k_entry_decode → k_chain0_match → the map/reduce, through the C
+"""-m gpu, N2: raw get-entries → k_decode_match (→ k_chain0_match for retry rounds) → the map/reduce, through the C
 ABI, bit for bit against the oracle's LogEntryFromLeaf + insertCTWorker restatement (orc_engine_raw_batch)."""
 import random
 
