@@ -106,6 +106,8 @@ SIGNATURES = {
     "ctmr_submit_batch": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "ctmr_flush": (C.c_int, [_P]),
     "ctmr_wait": (C.c_int, [_P, C.c_uint64, _P, _P, C.POINTER(BatchStats)]),
+    "ctmr_submit_entries": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ctmr_wait_entries": (C.c_int, [_P, C.c_uint64, _P, _P, _P, C.POINTER(DecodeStats), C.POINTER(BatchStats)]),
     "ctmr_set_insert": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "ctmr_set_contains": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "ctmr_set_remove": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),

@@ -498,8 +498,8 @@ extern "C" {
 #include "engine/lifecycle.inc"
 #include "engine/issuers.inc"
 #include "engine/map.inc"
-#include "engine/pipeline.inc"
 #include "engine/entries.inc"
+#include "engine/pipeline.inc"
 #include "engine/meta.inc"
 #include "engine/pem.inc"
 #include "engine/exchange.inc"

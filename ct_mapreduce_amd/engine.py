@@ -225,6 +225,24 @@ class Engine:
                                      new_idx.ctypes.data if (want_new and n) else None, C.byref(st)))
         return BatchResult(records, new_idx[:st.n_new] if want_new else new_idx[:0], st)
 
+    def submit_entries(self, blob, bounds, n) -> int:
+        """Raw get-entries form of submit_batch (ctmr_submit_entries): blob u8, bounds u64[2n+1] — arrays or addresses."""
+        def addr(a):
+            return a.ctypes.data if hasattr(a, "ctypes") else a
+        t = C.c_uint64(0)
+        self._ck(self._lib.ctmr_submit_entries(self._h, addr(blob), addr(bounds), n, C.byref(t)))
+        return t.value
+
+    def wait_entries(self, ticket: int, n: int) -> EntriesResult:
+        records = np.zeros(n, dtype=RECORD_DTYPE)
+        new_idx = np.zeros(max(n, 1), dtype=np.uint64)
+        ts = np.zeros(max(n, 1), dtype=np.uint64)
+        st, ds = N.BatchStats(), N.DecodeStats()
+        self._ck(self._lib.ctmr_wait_entries(self._h, ticket, records.ctypes.data if n else None,
+                                             new_idx.ctypes.data if n else None, ts.ctypes.data if n else None,
+                                             C.byref(ds), C.byref(st)))
+        return EntriesResult(records, new_idx[:st.n_new], ts[:n], st, ds)
+
     def map_batch_device(self, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records=0,
                          d_new_idx=0) -> N.BatchStats:
         """All pointers are device addresses (ints), e.g. torch tensors' data_ptr()."""

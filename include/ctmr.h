@@ -193,6 +193,7 @@ int ctmr_submit_batch(ctmr_engine* e, const uint8_t* payload, const uint64_t* of
                       const uint8_t* entry_type, uint64_t n, ctmr_ticket* ticket);
 int ctmr_flush(ctmr_engine* e);
 int ctmr_wait(ctmr_engine* e, ctmr_ticket ticket, ctmr_record* records, uint64_t* new_idx, ctmr_batch_stats* stats);
+/* (raw get-entries responses: ctmr_submit_entries / ctmr_wait_entries, with the raw-entry calls below) */
 
 /* ---- storage.RemoteCache set methods on byte strings (storage/types.go:83-102;
  *      Redis impl storage/rediscache.go:57-120,153-169; mock storage/mockcache.go:38-166).
@@ -416,6 +417,17 @@ int ctmr_map_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_
                             ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
 int ctmr_map_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n, ctmr_record* records,
                      uint64_t* new_idx, uint64_t* timestamp, ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
+/* Asynchronous ingestion (ctmr_submit_batch above) for RAW get-entries responses — what the reference's downloader actually holds (ct-fetch.go:446-462):
+ * blob = leaf_input_0 ‖ extra_data_0 ‖ leaf_input_1 ‖ …, bounds u64[2n+1] (ctmr_map_entries' input).  Submits of
+ * either form share the pipeline and its ordering; a super-batch holds one form (a change of form closes the open one).
+ * The super-batch is decoded, matched (Chain[0] certificates met for the first time are registered on the way, unless
+ * ctmr_set_issuer_autoregister(e, 0): then it fails with CTMR_E_NOTFOUND like ctmr_map_entries) and mapped as ONE batch.
+ * ctmr_wait_entries additionally hands out the entries' timestamps (ms, :476) and this batch's decode statistics
+ * (n_issuers_added, ms_*: of the whole super-batch); it accepts tickets of ctmr_submit_batch too (timestamps 0,
+ * dstats zeroed), and ctmr_wait accepts raw tickets. */
+int ctmr_submit_entries(ctmr_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n, ctmr_ticket* ticket);
+int ctmr_wait_entries(ctmr_engine* e, ctmr_ticket ticket, ctmr_record* records, uint64_t* new_idx, uint64_t* timestamp,
+                      ctmr_decode_stats* dstats, ctmr_batch_stats* stats);
 /* Issuer registration policy of the raw-entry calls.  on = 1 (default): a Chain[0] certificate met for the first time
  * is registered by the call.  on = 0: nothing is registered; when a batch contains unregistered Chain[0]
  * certificates the decode fails with CTMR_E_NOTFOUND and ctmr_pending_issuers lists them (distinct, [u32 len][DER]…,

@@ -10,3 +10,7 @@ import json; d=json.load(open('$OUT/ingest_1001_s$ns.json'))
 for r in d['results']: print(r['entry_point'], r['payload_memory'], r.get('tickets_in_flight'), round(r['certs_per_s']/1e6,2), 'M/s', r['payload_GBps'], 'GB/s')"
 done
 timeout 300 /tmp/ingest_bench 16384 400 > $OUT/ingest_16384.json 2> $OUT/ingest_16384.err; cat $OUT/ingest_16384.json
+# RAW get-entries responses (ctmr_map_entries against ctmr_submit_entries / ctmr_wait_entries)
+timeout 300 /tmp/ingest_bench 1001 3000 raw > $OUT/ingest_raw_1001.json 2> $OUT/ingest_raw_1001.err; tail -2 $OUT/ingest_raw_1001.err; python3 -c "
+import json; d=json.load(open('$OUT/ingest_raw_1001.json'))
+for r in d['results']: print('raw', r['entry_point'], r['payload_memory'], r.get('tickets_in_flight'), round(r['entries_per_s']/1e6,2), 'M entries/s', r['payload_GBps'], 'GB/s')"

@@ -33,6 +33,7 @@ struct HostBatch {
 int main(int argc, char** argv) {
   const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1001;
   const int calls = argc > 2 ? atoi(argv[2]) : 4000;
+  const bool raw_mode = argc > 3 && std::string(argv[3]) == "raw";
   ctmr_config cfg;
   memset(&cfg, 0, sizeof cfg);
   cfg.struct_size = sizeof cfg;
@@ -56,8 +57,80 @@ int main(int argc, char** argv) {
   }
   const char* filt = "Synth Issuer 0,Synth Issuer 1";
   CK(ctmr_set_filter(e, filt, strlen(filt), 0, 1767225600ll));
-  printf("{\"entries_per_batch\": %llu, \"batches\": %d, \"results\": [", (unsigned long long)n, calls);
+  printf("{\"entries_per_batch\": %llu, \"batches\": %d, \"form\": \"%s\", \"results\": [", (unsigned long long)n, calls,
+         raw_mode ? "raw get-entries (leaf_input + extra_data)" : "packed certificates");
   bool first_out = true;
+  if (raw_mode) {
+    // RAW get-entries responses (what the downloader holds, ct-fetch.go:446-462): ctmr_map_entries per response against
+    // ctmr_submit_entries / ctmr_wait_entries with WINDOW tickets in flight.  The engine registers the issuers itself.
+    struct RawBatch { uint8_t* blob; std::vector<uint64_t> bounds; uint64_t bytes; };
+    for (int pinned = 0; pinned < 2; pinned++) {
+      const int NB = 16;
+      std::vector<RawBatch> rb(NB);
+      for (int k = 0; k < NB; k++) {
+        RawBatch& b = rb[k];
+        b.bounds.resize(2 * n + 1);
+        b.bytes = ctmr_synth_entries_host(&sc, (uint64_t)k * n, n, b.bounds.data(), nullptr, 0);
+        if (pinned) { void* p; CK(ctmr_alloc_pinned(e, b.bytes + 64, &p)); b.blob = (uint8_t*)p; }
+        else b.blob = (uint8_t*)malloc(b.bytes + 64);
+        ctmr_synth_entries_host(&sc, (uint64_t)k * n, n, b.bounds.data(), b.blob, b.bytes + 64);
+      }
+      std::vector<ctmr_record> rec(n);
+      std::vector<uint64_t> nw(n), ts(n);
+      ctmr_batch_stats st;
+      ctmr_decode_stats ds;
+      CK(ctmr_reset_known(e));
+      CK(ctmr_map_entries(e, rb[0].blob, rb[0].bounds.data(), n, rec.data(), nw.data(), ts.data(), &ds, &st));
+      CK(ctmr_reset_known(e));
+      const int sync_calls = calls / 8 > 50 ? calls / 8 : 50;
+      double t0 = now_s();
+      for (int k = 0; k < sync_calls; k++) {
+        RawBatch& b = rb[k % NB];
+        CK(ctmr_map_entries(e, b.blob, b.bounds.data(), n, rec.data(), nw.data(), ts.data(), &ds, &st));
+      }
+      double dt = now_s() - t0;
+      printf("%s{\"entry_point\": \"ctmr_map_entries\", \"payload_memory\": \"%s\", \"us_per_batch\": %.1f, \"entries_per_s\": %.0f, \"payload_GBps\": %.2f}",
+             first_out ? "" : ", ", pinned ? "pinned" : "pageable", dt / sync_calls * 1e6, n * sync_calls / dt,
+             (double)rb[0].bytes * sync_calls / dt / 1e9);
+      first_out = false;
+      for (int window : {8, 32, 64}) {
+        // a raw super-batch closes at 96 MB ≈ 31 000 entries of 3 KB; at most 4 may be unfinished or uncollected
+        if ((uint64_t)window * rb[0].bytes > 2 * (96ull << 20)) continue;
+        CK(ctmr_reset_known(e));
+        std::deque<ctmr_ticket> fl;
+        uint64_t tot_new = 0;
+        t0 = now_s();
+        for (int k = 0; k < calls; k++) {
+          RawBatch& b = rb[k % NB];
+          ctmr_ticket t;
+          CK(ctmr_submit_entries(e, b.blob, b.bounds.data(), n, &t));
+          fl.push_back(t);
+          if ((int)fl.size() > window) {
+            CK(ctmr_wait_entries(e, fl.front(), rec.data(), nw.data(), ts.data(), &ds, &st));
+            tot_new += st.n_new;
+            fl.pop_front();
+          }
+        }
+        while (!fl.empty()) {
+          CK(ctmr_wait_entries(e, fl.front(), rec.data(), nw.data(), ts.data(), &ds, &st));
+          tot_new += st.n_new;
+          fl.pop_front();
+        }
+        dt = now_s() - t0;
+        printf(", {\"entry_point\": \"ctmr_submit_entries/ctmr_wait_entries\", \"payload_memory\": \"%s\", \"tickets_in_flight\": %d, \"us_per_batch\": %.1f, "
+               "\"entries_per_s\": %.0f, \"payload_GBps\": %.2f, \"n_new\": %llu}",
+               pinned ? "pinned" : "pageable", window, dt / calls * 1e6, n * calls / dt, (double)rb[0].bytes * calls / dt / 1e9,
+               (unsigned long long)tot_new);
+      }
+      for (auto& b : rb) {
+        if (pinned) ctmr_free_pinned(e, b.blob);
+        else free(b.blob);
+      }
+    }
+    printf("]}\n");
+    ctmr_destroy(e);
+    return 0;
+  }
   for (int pinned = 0; pinned < 2; pinned++) {
     const int NB = 16;  // distinct batches, reused round-robin (the table is reset per leg: the first pass inserts, later passes find duplicates)
     std::vector<HostBatch> hb(NB);

@@ -176,3 +176,102 @@ def test_table_growth_happens_under_the_pipeline():
     assert eng.total_count() == o.total_count() > 60000
     assert sorted(eng.keys(b"serials::*")) == [k for k in o.keys() if k.startswith(b"serials::")]
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# raw get-entries responses through the same pipeline (ctmr_submit_entries / ctmr_wait_entries)
+from oracle import oracle as orc  # noqa: E402
+
+
+def _raw_arrays(raw):
+    blob = np.concatenate([np.ascontiguousarray(raw.blob, dtype=np.uint8), np.zeros(32, np.uint8)])
+    return blob, np.ascontiguousarray(raw.bounds, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("size,count", [(1001, 90), (333, 25), (70000, 2)])
+def test_raw_tickets_answer_like_synchronous_raw_calls(size, count):
+    """Responses of `size` entries submitted without waiting; each ticket must answer like the oracle's
+    LogEntryFromLeaf + insertCTWorker over the ONE stream they form — records, NEW list, timestamps, decode statistics;
+    the engine registers the issuers on the way (no add_issuers here)."""
+    cfg = synth.config(seed=93, n_issuers=48, zipf=1, dup_permille=200, ca_permille=10, expired_permille=10)
+    eng = ctmr.Engine(device=0, table_slots=1 << 20, pair_slots=1 << 14)
+    eng.set_filter(FILT, False, NOW)
+    raws = [synth.host_entries(cfg, k * size, size) for k in range(count)]
+    keep, tickets = [], []
+    for raw in raws:
+        a = _raw_arrays(raw)
+        keep.append(a)
+        tickets.append(eng.submit_entries(a[0], a[1], raw.n))
+    o = orc.Engine(FILT, False, NOW)
+    for raw, t in zip(raws, tickets):
+        res = eng.wait_entries(t, raw.n)
+        st, unk, eh, ts = o.raw_batch(raw.blob, raw.bounds)
+        assert (res.records["status"] == st).all()
+        assert (((res.records["flags"] & 2) != 0) == (unk != 0)).all()
+        assert (res.timestamp == ts).all()
+        assert (res.new_idx == np.nonzero(unk)[0]).all()
+        assert res.decode.n == raw.n and res.decode.n_x509 + res.decode.n_precert == raw.n
+        assert res.decode.blob_bytes == int(raw.bounds[-1]) == res.stats.payload_bytes
+    assert eng.total_count() == o.total_count()
+    assert 0 < eng.issuer_count() <= 48
+    eng.close()
+
+
+def test_raw_and_packed_submits_share_the_pipeline_in_order():
+    """Alternating forms: every change of form closes the open super-batch, the order of the stream is kept — a key's
+    first copy in a packed batch makes its later copy in a raw batch a known duplicate, and the other way round."""
+    cfg = synth.config(seed=94, n_issuers=16, zipf=1, dup_permille=300)
+    issuers = synth.issuers(cfg)
+    eng = make(issuers)
+    o = orc.Engine(FILT, False, NOW)
+    size, pending, keep = 700, [], []
+
+    def collect(form, x, t):
+        if form == "packed":
+            res = eng.wait(t, x.n)
+            _, st, unk, _ = run_oracle(x, issuers, FILT, False, NOW, engine=o)
+        else:
+            res = eng.wait_entries(t, x.n)
+            st, unk, _, _ = o.raw_batch(x.blob, x.bounds)
+        assert (res.records["status"] == st).all(), form
+        assert (((res.records["flags"] & 2) != 0) == (unk != 0)).all(), form
+
+    for k in range(12):
+        if k % 2 == 0:
+            b = synth.host_batch(cfg, k * size, size)
+            a = arrays(b)
+            keep.append(a)
+            pending.append(("packed", b, eng.submit_batch(a[0], a[1], a[2], a[3], b.n)))
+        else:
+            raw = synth.host_entries(cfg, k * size, size)
+            a = _raw_arrays(raw)
+            keep.append(a)
+            pending.append(("raw", raw, eng.submit_entries(a[0], a[1], raw.n)))
+        if len(pending) == 3:          # at most four super-batches may be unfinished or uncollected
+            collect(*pending.pop(0))
+    while pending:
+        collect(*pending.pop(0))
+    assert eng.total_count() == o.total_count()
+    eng.close()
+
+
+def test_raw_submit_with_autoregistration_off_reports_the_pending_issuers():
+    cfg = synth.config(seed=95, n_issuers=5)
+    raw = synth.host_entries(cfg, 0, 2000)
+    eng = ctmr.Engine(device=0, table_slots=1 << 14, pair_slots=1 << 12)
+    eng.set_filter(b"", True, NOW)
+    eng.set_issuer_autoregister(False)
+    a = _raw_arrays(raw)
+    t = eng.submit_entries(a[0], a[1], raw.n)
+    with pytest.raises(ctmr.CtmrError) as ei:
+        eng.wait_entries(t, raw.n)
+    assert ei.value.code == N.E_NOTFOUND
+    pend = eng.pending_issuers()
+    assert sorted(pend) == sorted(set(synth.issuers(cfg)[int(i)] for i in synth.host_batch(cfg, 0, 2000).issuer_idx))
+    eng.add_issuers(sorted(pend))
+    t = eng.submit_entries(a[0], a[1], raw.n)
+    res = eng.wait_entries(t, raw.n)
+    o = orc.Engine(b"", True, NOW)
+    st, unk, _, _ = o.raw_batch(raw.blob, raw.bounds)
+    assert (res.records["status"] == st).all() and (((res.records["flags"] & 2) != 0) == (unk != 0)).all()
+    eng.close()
