@@ -176,6 +176,8 @@ struct ctmr_engine {
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
   bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
   int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
+  uint64_t meta_precheck_n = 0;            // entries of the last map call whose ent[] carries the memo pre-check (0 = none)
+  const uint32_t* meta_precheck_ent = nullptr;
   std::unordered_map<unsigned long long, uint32_t> qh_first;  // candidate hash → first registered certificate with it
   std::vector<std::string> pending_issuers;  // auto_register off: what the last decode found unregistered
   unsigned long long* d_pend = nullptr;    // PEND_SLOTS claim words
@@ -185,6 +187,7 @@ struct ctmr_engine {
   MetaSlot* d_meta_slots = nullptr;
   uint64_t n_meta_slots = 0;
   uint8_t* d_meta_arena = nullptr;
+  unsigned long long* d_meta_refs = nullptr;  // [canon] the issuer's first recorded DN, [max_issuers + canon] its first CRL DP (MetaCheck)
   uint64_t meta_arena_cap = 0;
   std::vector<uint32_t*> meta_hour_pages;  // knownExpDates bitmaps, META_HOUR_PAGE issuers each
   uint32_t** d_meta_hour_pages = nullptr;  // device copy of the page pointers

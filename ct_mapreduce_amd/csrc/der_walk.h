@@ -15,6 +15,9 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #if defined(__HIPCC__)
 #define CTMR_HD __host__ __device__ __forceinline__
 #else
@@ -383,6 +386,16 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
 // left out): a field must match its tag and lie inside the enclosing contents; bytes behind the last field of a
 // SEQUENCE are ignored; an OPTIONAL field with another tag is skipped, but its header must parse; parsing resumes
 // behind the INNER element of an EXPLICIT wrapper, whatever the wrapper's own length says.
+// r.note_issuer(pos, len), for readers that have one
+template <class R, class = void>
+struct has_note_issuer : std::false_type {};
+template <class R>
+struct has_note_issuer<R, std::void_t<decltype(std::declval<R&>().note_issuer(0u, 0u))>> : std::true_type {};
+template <class R>
+CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
+  if constexpr (has_note_issuer<R>::value) r.note_issuer(pos, len);
+}
+
 template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv) {
   o.serial_off = o.serial_len = 0;
@@ -448,6 +461,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     const uint32_t n0 = q;
     q = walk_name<true>(r, L, q, tbs_end, ok, o.cn_off, o.cn_len);
     o.meta_issuer = meta_pack(n0, q - n0);
+    note_issuer_if(r, n0, q - n0);  // readers that look the Name up while it is at hand (the map kernel's memo pre-check)
     if (use_filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, fv) : false;
   }
   r.touch(q, 48);

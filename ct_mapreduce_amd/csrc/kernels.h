@@ -3,6 +3,7 @@
 //
 //   kernels/readers.h   GlobalReader, WinReader/C/S — per-lane 256-byte LDS windows, wave-cooperative fills
 //   kernels/sha256.h    k_issuer_ids (issuer table: walk Chain[0], SHA-256(RawSubjectPublicKeyInfo)), k_sha256_one
+//   kernels/meta_core.h the read-only side of the IssuerMetadata memo (slot layout, item hash, CRL-DP walk, the map's pre-check)
 //   kernels/map.h       the map — map_one (walk + filters + record), k_map_winc (the map without the fused insert)
 //   kernels/map_sweep.h k_map_tile / k_map_direct: the two baseline designs, CTMR_SWEEP builds only (libctmr_sweep.so)
 //   kernels/reduce.h    table_upsert, k_insert / k_insert2, k_map_fused (THE dominant kernel: walk + filters + pass 1 of
@@ -10,12 +11,13 @@
 //   kernels/exchange.h  k_key_count / k_key_scatter / k_keys_insert* / k_keys_resolve / k_apply_flags (owner-computes
 //                       exchange), k_bloom_add / k_bloom_probe / k_bloom_scatter / k_keys_lookup / k_bloom_apply
 //   kernels/pem.h       k_pem_len, k_pem_encode
-//   kernels/entries.h   k_entry_decode, k_chain0_match
+//   kernels/entries.h   k_decode_match (decode + first Chain[0] match round), k_chain0_match, k_entry_decode (sweep builds)
 //   kernels/meta.h      k_meta_new
 //   kernels/misc.h      k_fingerprint, k_set_op / k_sweep / k_build_pairs / k_list / k_pairs, k_synth_*
 #pragma once
 #include "kernels/readers.h"
 #include "kernels/sha256.h"
+#include "kernels/meta_core.h"
 #include "kernels/map.h"
 #ifdef CTMR_SWEEP
 #include "kernels/map_sweep.h"

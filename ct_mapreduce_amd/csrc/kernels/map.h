@@ -58,7 +58,7 @@ __device__ __forceinline__ EntryIn load_entry_in(const MapArgs& a, uint64_t idx)
 
 template <class R>
 __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, const EntryIn& in, uint4& o0,
-                                        uint4& o1) {
+                                        uint4& o1, uint2* meta_words = nullptr) {
   Walk w;
   const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
   const FilterDev* f = a.filt;
@@ -103,7 +103,9 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   }
   o0 = make_uint4(status | (flags << 8) | (slen << 16), (uint32_t)exp_hour, iss, s[0]);
   o1 = make_uint4(s[1], s[2], s[3], s[4]);
-  if (a.meta_loc) a.meta_loc[idx] = make_uint2(ok ? w.meta_issuer : META_NONE, ok ? w.meta_crl : META_NONE);
+  const uint2 ml = make_uint2(ok ? w.meta_issuer : META_NONE, ok ? w.meta_crl : META_NONE);
+  if (a.meta_loc) a.meta_loc[idx] = ml;
+  if (meta_words) *meta_words = ml;
 }
 
 template <class R>

@@ -12,16 +12,6 @@ namespace ctmr {
 // (kind, issuer, bytes).  k_meta_new walks the NEW list of a batch, and appends an item only for first sightings —
 // the host then formats/inserts those few (addCRL :48-73, addIssuerDN :75-87, AllocateExpDateAndIssuer
 // filesystemdatabase.go:189-195) instead of parsing every new certificate.
-// Set semantics are exact: a slot is claimed by CAS on the 64-bit hash, its bytes are copied into an arena and
-// published (write-through payload, drained, then the VALID word — the table_upsert recipe); equal hash is
-// followed by a full comparison, so a hash collision only costs a probe.
-struct MetaSlot {
-  unsigned long long w[4];  // w0 hash (claim, never 0) | w1 VALID(63) kind(61..60) len(59..40) arena_off/8(39..0)
-};                          // w2 issuer << 32 | key2 | w3 launch number that created the slot
-constexpr unsigned long long META_VALID = 1ull << 63;
-constexpr uint32_t MK_EXPDATE = 0, MK_CRL = 1, MK_DN = 2, MK_HOST = 3;  // item kinds; MK_HOST = parse this one on the host
-constexpr uint32_t META_MAX_BYTES = 4096;
-constexpr uint32_t META_MAX_URIS = 4;  // CRL distribution point URIs per certificate on the device path; more → host
 struct ByteReader {  // one unaligned dword per access (k_meta_new's TLV reads)
   const uint8_t* p;
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const { return ((const U4*)(p + pos))->a; }
@@ -54,29 +44,11 @@ struct MetaArgs {
   uint32_t epoch;  // launch number (≥ 1): slots of earlier launches are immutable and read through the caches
   uint32_t* const* hour_pages;  // knownExpDates as bitmaps: page c (META_HOUR_PAGE issuers) → one bit per (issuer, hour)
   uint32_t n_hour_pages;
+  unsigned long long* refs;  // per issuer: [canon] first recorded DN, [n_refs + canon] first recorded CRL DP (as slot word w1)
+  uint32_t n_refs;
+  const uint32_t* ent;  // null, or the map kernel's pre-check (k_map_fused<…, META>): entries without ENT_META_UNSEEN are skipped
 };
 
-// knownExpDates (issuermetadata.go:96-108) is a set of (issuer, expDate hour): small dense integers.  One bit per pair —
-// META_HOUR_BITS hours (1970 … 2089) per canonical issuer, pages of META_HOUR_PAGE issuers allocated as issuers are
-// registered — decides "seen before" with one cached load, and a first sighting with one atomicOr whose return value
-// names the single lane that reports it.  (As entries of the hash set below, the ≈ 2 000 hours of every issuer were 99 %
-// of its population: they pushed DN/CRL items off their home slots and, a few lanes per wave at a time, kept nearly
-// every wave in the probe loop.)  Hours outside the bitmap's range take the hash-set path.
-constexpr uint32_t META_HOUR_BITS = 1u << 20, META_HOUR_PAGE = 64;
-
-// 16-byte chunks of an item, bytes past its end zeroed.  Items are hashed and compared in these chunks: the first
-// version of this kernel used dwords and was bound by L2 REQUESTS (1.46 G for 18.8 M new certificates, 76 % of its
-// L1 accesses missing — profiles/r01/s4/pmc_meta_20m_dword_version.txt).
-__device__ __forceinline__ uint4 mask_chunk(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rem) {
-  if (rem >= 16u) return make_uint4(w0, w1, w2, w3);  // only an item's last chunk has bytes to clear
-  uint32_t w[4] = {w0, w1, w2, w3};
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const uint32_t have = rem > 4u * q ? rem - 4u * q : 0u;
-    w[q] = have >= 4u ? w[q] : (have ? (w[q] & (0xffffffffu >> (8u * (4u - have)))) : 0u);
-  }
-  return make_uint4(w[0], w[1], w[2], w[3]);
-}
 struct GlobalSrc {  // straight from the certificate in HBM: one unaligned dwordx4 load per chunk (≤ 15 bytes past the
   const uint8_t* p; //  item, which lies inside a certificate inside the payload + CTMR_PAYLOAD_PAD)
   uint32_t len;
@@ -85,58 +57,6 @@ struct GlobalSrc {  // straight from the certificate in HBM: one unaligned dword
     return mask_chunk(v.a, v.b, v.c, v.d, len - 16u * k);
   }
 };
-struct LdsSrc {  // from this lane's staging area in LDS, at any byte offset (5 dwords, 4 alignbytes)
-  const uint32_t* w;  // dword-aligned lane area
-  uint32_t off;       // byte offset of the item inside it
-  uint32_t len;
-  __device__ __forceinline__ uint4 chunk(uint32_t k) const {
-    const uint32_t at = off + 16u * k, i = at >> 2, sh = at & 3u;
-    const uint32_t d0 = w[i], d1 = w[i + 1], d2 = w[i + 2], d3 = w[i + 3], d4 = w[i + 4];
-    return mask_chunk(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                      __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh), len - 16u * k);
-  }
-};
-
-// Plain (cacheable) load the compiler may not merge or hoist: wavefront-scope atomic.  Used for memo slots of EARLIER
-// launches, which are immutable — the steady state, where the same few hundred DN/CRL slots are read by every new
-// certificate and should come out of L1/L2 instead of device-coherent loads.
-__device__ __forceinline__ unsigned long long ld_wave(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
-// true = first sighting of (kind, issuer, key2, bytes); the bytes come through a chunk source
-// Item hash: add-rotate-xor over the 16-byte chunks (12 full-rate VALU operations per chunk), one multiply-mix at each
-// end.  The first version ran two mixk() — four 64-bit multiplies, quarter-rate on CDNA — per chunk: ≈ 2 700 VALU
-// instructions per wave of certificates, half of the kernel's time (pmc_meta, session 5).  Equal hashes are always
-// followed by a full comparison, so the hash only has to spread.
-struct MetaHashState {
-  uint32_t a, b;
-};
-__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
-__device__ __forceinline__ MetaHashState meta_hash_begin(uint32_t kind, uint32_t issuer, uint32_t key2, uint32_t len) {
-  const unsigned long long h =
-      mixk((((unsigned long long)issuer << 32 | key2) + 0x9e3779b97f4a7c15ull * (kind + 1u)) ^ ((unsigned long long)len << 24));
-  return MetaHashState{(uint32_t)h, (uint32_t)(h >> 32)};
-}
-__device__ __forceinline__ void meta_hash_chunk(MetaHashState& s, const uint4& c) {
-  s.a = rotl32(s.a, 5) ^ c.x;  s.a += s.b;
-  s.b = rotl32(s.b, 11) ^ c.y; s.b += s.a;
-  s.a = rotl32(s.a, 7) ^ c.z;  s.a += s.b;
-  s.b = rotl32(s.b, 13) ^ c.w; s.b += s.a;
-}
-__device__ __forceinline__ unsigned long long meta_hash_end(const MetaHashState& s) {
-  const unsigned long long h = mixk((unsigned long long)s.b << 32 | s.a);
-  return h ? h : 1ull;
-}
-template <class S>
-__device__ __forceinline__ unsigned long long meta_hash(uint32_t kind, uint32_t issuer, uint32_t key2, const S& src,
-                                                        uint32_t len) {
-  const uint32_t nc = (len + 15u) >> 4;
-  MetaHashState st = meta_hash_begin(kind, issuer, key2, len);
-  for (uint32_t k = 0; k < nc; k++) meta_hash_chunk(st, src.chunk(k));
-  return meta_hash_end(st);
-}
-
 template <class S>
 __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, uint32_t issuer, uint32_t key2,
                                             const S& src, uint32_t len) {
@@ -169,7 +89,14 @@ __device__ __forceinline__ bool meta_upsert(const MetaArgs& a, uint32_t kind, ui
         st_agent(&sl->w[2], w2);
         st_agent(&sl->w[3], (unsigned long long)a.epoch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_agent(&sl->w[1], META_VALID | ((unsigned long long)pk << 60) | ((unsigned long long)len << 40) | (at >> 3));
+        const unsigned long long w1 = META_VALID | ((unsigned long long)pk << 60) | ((unsigned long long)len << 40) | (at >> 3);
+        st_agent(&sl->w[1], w1);
+        // the issuer's first Name / first CRL distribution point, for the map kernel's pre-check (meta_core.h): it reads
+        // the item's bytes straight from the arena, without a hash or a slot in between.  Any published item will do.
+        if ((pk == MK_DN || pk == MK_CRL) && key2 == 0u && issuer < a.n_refs) {
+          unsigned long long* ref = a.refs + (pk == MK_CRL ? a.n_refs : 0u) + issuer;
+          if (ld_agent(ref) == 0ull) st_agent(ref, w1);
+        }
         return true;
       }
       w0 = old;
@@ -219,62 +146,6 @@ __device__ __forceinline__ void meta_emit(const MetaArgs& a, uint64_t entry, uin
 // the lane's certificate are fetched with up to 12 independent 16-byte loads issued together — ONE memory latency —
 // and everything after that (the DistributionPoint walk, hashing, comparing) reads LDS.  The dependent chain per
 // certificate drops from ≈35 global round trips to the three memo probes.  Longer items take the global path.
-constexpr uint32_t META_LDS_DN = 128, META_LDS_CRL = 64, META_LDS_STRIDE = META_LDS_DN + META_LDS_CRL + 16;
-
-struct LdsTlvReader {  // rd_hdr over the staged cRLDistributionPoints value: positions are certificate offsets
-  const uint32_t* w;   // lane area (dwords) of the value
-  uint32_t s;          // certificate offset of its first byte
-  __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
-    const uint32_t rel = pos - s;  // callers stay within [s, e + 3]; the area has 16 bytes of slack
-    const uint32_t i = rel >> 2;
-    return __builtin_amdgcn_alignbyte(w[i + 1], w[i], rel & 3u);
-  }
-};
-
-// DistributionPoint walk (RFC 5280 §4.2.1.13) over [cs, e): collects up to META_MAX_URIS URI ranges (certificate
-// offsets); returns false when the value is malformed.  `host` is set when a URI is too long or there are too many.
-template <class R>
-__device__ __forceinline__ bool walk_crl_dps(const R& g, uint32_t L, uint32_t cs, uint32_t e, uint32_t uo[META_MAX_URIS],
-                                             uint32_t ul[META_MAX_URIS], uint32_t& nu, bool& host) {
-  bool ok = true;
-  uint32_t p = cs;
-  while (ok && p < e) {
-    uint32_t t1, f, f_end;
-    rd_hdr(g, L, p, e, ok, t1, f, f_end);
-    ok = ok && t1 == 0x30u;
-    while (ok && f < f_end) {
-      uint32_t t2, n, n_end;
-      rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
-      if (ok && t2 == 0xa0u) {
-        while (ok && n < n_end) {
-          uint32_t t3, q, q_end;
-          rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
-          if (ok && t3 == 0xa0u) {
-            while (ok && q < q_end) {
-              uint32_t t4, u, u_end;
-              rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
-              if (ok && t4 == 0x86u) {
-                if (u_end - u > META_MAX_BYTES || nu >= META_MAX_URIS) host = true;
-#pragma unroll
-                for (uint32_t k = 0; k < META_MAX_URIS; k++) {  // register array: no dynamic indexing
-                  uo[k] = k == nu ? u : uo[k];
-                  ul[k] = k == nu ? u_end - u : ul[k];
-                }
-                nu++;
-              }
-              q = u_end;
-            }
-          }
-          n = q_end;
-        }
-      }
-      f = n_end;
-    }
-    p = f_end;
-  }
-  return ok;
-}
-
 // The steady state of the memo — the item was published by an EARLIER launch and sits at the home position of its
 // hash — decided without the probe loop.  k_meta_new issues the home-slot loads of all of a certificate's items
 // together and then the arena loads of all of them together: two memory latencies for the three lookups instead of
@@ -312,6 +183,9 @@ __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n_new) return;
   const uint64_t i = a.new_idx[r];
+  // the map kernel found everything this certificate contributes in the memo of earlier calls: nothing to add, nothing
+  // to read (the memo has not changed since: only this kernel writes it)
+  if (a.ent && !(a.ent[i] & ENT_META_UNSEEN)) return;
   const uint4 r0 = *(const uint4*)(a.records + i);
   const int32_t exp_hour = (int32_t)r0.y;
   const uint32_t iss = r0.z, canon = a.canon[iss];

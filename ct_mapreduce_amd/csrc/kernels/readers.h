@@ -132,6 +132,7 @@ struct WinReaderC : WinReader<WCH> {
 struct NoRefillHook {
   __device__ __forceinline__ void issue() {}
   __device__ __forceinline__ void resolve() {}
+  __device__ __forceinline__ void note_issuer(const uint32_t*, uint32_t, uint32_t, uint32_t) {}
 };
 
 template <int WCH, class Hook = NoRefillHook>
@@ -163,6 +164,10 @@ struct WinReaderS : WinReaderC<WCH> {
     tl[0] = a.a; tl[1] = a.b; tl[2] = a.c; tl[3] = a.d;
     tl[4] = b.a; tl[5] = b.b; tl[6] = b.c; tl[7] = b.d;
     tl_pos = have ? tail : 0x80000000u;
+  }
+  // der_walk.h: the issuer Name [pos, pos+len) has just been walked — the front window still holds it
+  __device__ __forceinline__ void note_issuer(uint32_t pos, uint32_t len) {
+    hook.note_issuer(this->win, pos - (uint32_t)this->grel, len, WinReader<WCH>::WBYTES - 8u);
   }
   __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {
     const uint32_t off = pos - tl_pos;

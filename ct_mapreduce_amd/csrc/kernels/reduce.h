@@ -314,8 +314,13 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 // by memory transactions, not by the latency of the probe.  An XCD-contiguous workgroup → block mapping: 23.87 ms
 // against 23.44 ms, profiles/r01/s5/sweep_xcd_contiguous_blocks_not_default.txt.  The same kernel with the per-access
 // global fallback inside ld4 instead of the window-only reader: 0.9–2.5 ms slower, profiles/r01/s4.)
-template <int WCH>
-__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
+// META (engines created with collect_meta, round 2): the memo of EARLIER ctmr_meta_new calls is looked up while the
+// bytes are in the LDS window anyway — the issuer Name from the front window (reader hook, right behind the Name), the
+// CRL distribution point from the extension window and the (issuer, expDate hour) bit at the end of the walk — and
+// ent[] bit 6 is set only for certificates that may bring a first sighting.  k_meta_new then skips everything else
+// instead of re-reading ≈ 4 lines of every new certificate (9.7 ms per 94 M new certificates in round 1).
+template <int WCH, bool META>
+__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
@@ -332,6 +337,20 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   if (live) {
     in = load_entry_in(a, i);
     canon = in.iss_in_range ? ia.canon[in.iss] : 0u;
+  }
+  // META: what the pre-check needs of this issuer's memo entries — like the entry inputs above, on their way while the
+  // window fills: the issuer's first recorded Name and CRL distribution point (arena references) and its bitmap row
+  unsigned long long dn_ref = 0, crl_ref = 0;
+  const uint32_t* hour_row = nullptr;
+  if constexpr (META) {
+    if (live && mc.enabled && in.iss_in_range) {
+      if (canon < mc.n_refs) {
+        dn_ref = mc.refs[canon];
+        crl_ref = mc.refs[mc.n_refs + canon];
+      }
+      if (canon / META_HOUR_PAGE < mc.n_hour_pages)
+        hour_row = mc.hour_pages[canon / META_HOUR_PAGE] + (uint64_t)(canon % META_HOUR_PAGE) * (META_HOUR_BITS / 32);
+    }
   }
   const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
   {
@@ -352,20 +371,43 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia) {
   uint64_t claimed = ~0ull;
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
   if (live) {
-    WinReaderS<WCH> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
-                        (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
-    map_one(r, hi - lo, i, a, in, o0, o1);
+    using Hook = typename std::conditional<META, MetaHook, NoRefillHook>::type;
+    WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+                              (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
+    if constexpr (META) {
+      r.hook.mc = mc;
+      r.hook.canon = canon;
+      r.hook.dn_ref = dn_ref;
+      r.hook.dn_seen = false;
+    }
+    uint2 ml = make_uint2(META_NONE, META_NONE);
+    map_one(r, hi - lo, i, a, in, o0, o1, &ml);
     if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
       GlobalReader g{(const uint32_t*)a.payload, lo};
       map_one(g, hi - lo, i, a, in, o0, o1);
     }
     const uint32_t status = o0.x & 0xffu;
     uint32_t state = ES_NONE;
+    // META: only a certificate that WAS unknown reaches IssuerMetadata.Accumulate; of those, only one that brings
+    // something the memo does not hold yet needs k_meta_new.  Anything not positively known to be seen counts as unseen.
+    // The lookup's loads go out before the table probe and are looked at behind it.
+    MetaTail mt;
+    bool meta_try = false;
+    if constexpr (META) {
+      meta_try = mc.enabled && status == CTMR_ST_PASS && !r.miss && ml.x != META_NONE && ml.x != META_HOST && r.hook.dn_seen;
+      if (meta_try)
+        mt = meta_tail_issue(mc, crl_ref, hour_row, (int32_t)o0.y, ml.y, r.win, r.grel, WinReader<WCH>::WBYTES - 8u);
+    }
     if (status == CTMR_ST_PASS) {
       state = insert_probe(ia, i, o0, o1, canon, claimed, q0, q1, q2, q3);
       if (state != ES_CLAIMED && state != ES_DEFER) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
     }
-    ia.ent[i] = ent_pack(status, state, canon);
+    uint32_t e = ent_pack(status, state, canon);
+    if constexpr (META) {
+      const bool seen = meta_try && meta_tail_finish(mc, canon, mt, (int32_t)o0.y, r.win);
+      e |= seen ? 0u : ENT_META_UNSEEN;
+    }
+    ia.ent[i] = e;
   }
   store_records_wave(a, first, live, o0, o1);
   __builtin_amdgcn_wave_barrier();
@@ -435,6 +477,7 @@ struct ProbeChain {
       }
     }
   }
+  __device__ __forceinline__ void note_issuer(const uint32_t*, uint32_t, uint32_t, uint32_t) {}
   __device__ __forceinline__ void issue() {
     issued = false;
     if (active) {

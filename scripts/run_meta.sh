@@ -1,10 +1,14 @@
 #!/bin/bash
-# IssuerMetadata memo kernel: parity tests, then bench --meta (packed 100 M) and --raw --meta (40 M)
+# IssuerMetadata memo pre-check inside the map kernel (k_map_fused<16, true>) against the build before it.
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/meta; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/meta; mkdir -p $OUT; rm -f $OUT/*
 cd $R
-timeout 900 python -m pytest tests/test_gpu_meta.py tests/test_storage_gpu.py tests/test_host_cpp.py -x -q -m gpu > $OUT/pytest_meta.txt 2>&1; tail -4 $OUT/pytest_meta.txt
-timeout 900 python bench.py --meta --no-cpu > $OUT/bench_meta.json 2> $OUT/bench_meta.err; python -c "
-import json; d=json.loads([l for l in open('$OUT/bench_meta.json').read().splitlines() if l.startswith('{')][-1]); print('meta', d['value'], d['ms_per_step'], d['kernel_ms'], d.get('meta'))"
-timeout 900 python bench.py --raw --meta --no-cpu > $OUT/bench_raw_meta.json 2> $OUT/bench_raw_meta.err; python -c "
-import json; d=json.loads([l for l in open('$OUT/bench_raw_meta.json').read().splitlines() if l.startswith('{')][-1]); print('raw+meta', d['value'], d['ms_per_step'], d['kernel_ms'])"
+timeout ${PYTEST_TIMEOUT:-300} python -m pytest ${PYTEST:-tests/test_gpu_meta.py tests/test_gpu_parity.py tests/test_storage_gpu.py} -m gpu -x -q -p no:cacheprovider 2>&1 | tail -12 | tee -a $OUT/summary.txt
+grep -q "failed\|error" $OUT/summary.txt && exit 1
+for tag in ${TAGS:-base before base before}; do
+  lib=$R/ct_mapreduce_amd/libctmr.so
+  [ $tag != base ] && lib=$R/ct_mapreduce_amd/libctmr_sweep_$tag.so
+  CTMR_LIB=$lib timeout 300 python bench.py --meta --no-cpu --traffic off --steps 5 --warmup 1 > $OUT/b_$tag.json 2> $OUT/b_$tag.err || { echo "$tag failed"; tail -3 $OUT/b_$tag.err; exit 1; }
+  python3 -c "
+import json; d=json.loads([l for l in open('$OUT/b_$tag.json').read().splitlines() if l.startswith('{')][-1]); print('$tag', 'certs/s', round(d['value']/1e9,3), 'ms/step', round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['kernel_ms'].items()}, d.get('meta'))" | tee -a $OUT/summary.txt
+done

@@ -1,6 +1,8 @@
 """-m gpu, N3: IssuerMetadata.Accumulate's memo on the GPU (k_meta_new) — the first sightings it
 reports are exactly those the reference's per-issuer maps (storage/issuermetadata.go:92-138) would produce from the
 newly unknown certificates, computed here with the oracle's field extraction (orc_cert_meta)."""
+import random
+
 import numpy as np
 import pytest
 
@@ -188,4 +190,71 @@ def test_device_variant_and_small_buffer():
         e2.meta_new_device(d_pay.data_ptr(), d_off.data_ptr(), 0, d_rec.data_ptr(), d_new.data_ptr(), 1,
                            d_items.data_ptr(), 10)
     e2.close()
+    eng.close()
+
+
+def test_precheck_against_a_warm_memo():
+    """Round 2: with collect_meta the map kernel looks the memo of EARLIER calls up while the bytes are in its LDS window
+    and k_meta_new skips every certificate that brings nothing new.  A warm memo, a batch of mostly-seen certificates, and
+    among them the ones that must NOT be skipped: a new expDate hour, a second CRL distribution point and another issuer
+    Name for a known issuer, two URIs, a repeated extension (host), a Name/URI longer than the fast paths — all reported
+    exactly as the reference's memo semantics say, nothing else reported."""
+    cfg = synth.config(seed=20260921 + 23, n_issuers=24, dup_permille=50)
+    issuers = synth.issuers(cfg)
+    eng = ctmr.Engine(device=0, table_slots=1 << 17, pair_slots=1 << 14, collect_meta=True)
+    eng.add_issuers(issuers)
+    eng.set_filter(b"", True, NOW)
+    seen_total = set()
+
+    def run(certs, idx):
+        b = Batch.from_certs(certs, idx)
+        res = eng.map_batch(b)
+        exp = expected_first_sightings(certs, [int(k) for k in idx], [int(i) for i in res.new_idx], res.records["exp_hour"])
+        exp -= seen_total
+        items = eng.meta_new()
+        got = got_first_sightings(eng, items)
+        assert len(items) == len(got) and got == exp
+        seen_total.update(k for k in exp if k[0] != N.MK_HOST)   # a host-routed certificate is handed over every time
+        return exp, res
+
+    b1 = synth.host_batch(cfg, 0, 20000)
+    exp1, _ = run([b1.cert(i) for i in range(b1.n)], b1.issuer_idx)
+    assert len(exp1) > 24 * 2
+    # what issuer 0's leaves look like, to build relatives of them
+    i0 = int(np.nonzero(b1.issuer_idx == 0)[0][0])
+    name0, uris0, _ = orc.cert_meta(b1.cert(i0))
+    assert len(uris0) == 1
+    other_name = D.name(D.rdn(10, b"Another Org"), D.rdn(3, b"Same key, other Name"))
+    long_name = D.name(D.rdn(10, b"o" * 150), D.rdn(3, b"long"))
+    special = [
+        D.cert(serial=b"\x51", issuer=name0, exts=[dp_ext(dp(uri(uris0[0])))]),                                  # all seen but the hour
+        D.cert(serial=b"\x52", issuer=name0, exts=[dp_ext(dp(uri(uris0[0])))], not_after=D.gentime("20440601120000Z")),
+        D.cert(serial=b"\x53", issuer=name0, exts=[dp_ext(dp(uri(b"http://crl.example/second-shard.crl")))]),      # second CRL DP of the issuer
+        D.cert(serial=b"\x54", issuer=other_name, exts=[dp_ext(dp(uri(uris0[0])))]),                             # another Name, same issuer
+        D.cert(serial=b"\x55", issuer=name0, exts=[dp_ext(dp(uri(uris0[0]), uri(b"ldap://x.example/y")))]),       # two URIs
+        D.cert(serial=b"\x56", issuer=name0, exts=[dp_ext(dp(uri(uris0[0]))), dp_ext(dp(uri(uris0[0])))]),        # extension twice → host
+        D.cert(serial=b"\x57", issuer=long_name, exts=[dp_ext(dp(uri(b"http://crl.example/" + b"p" * 90)))]),    # beyond the 128 / 64-byte fast paths
+        D.cert(serial=b"\x58", issuer=name0),                                                                    # no CRL DP at all
+        D.cert(serial=b"\x59", issuer=name0, exts=[dp_ext(dp(uri(b"http://crl.example/second-shard.crl")))]),      # … now seen (same batch)
+        D.cert(serial=b"\x5a", issuer=long_name, exts=[dp_ext(dp(uri(b"http://crl.example/" + b"p" * 90)))]),
+    ]
+    b2 = synth.host_batch(cfg, 20000, 20000)
+    certs2 = [b2.cert(i) for i in range(b2.n)]
+    idx2 = [int(k) for k in b2.issuer_idx]
+    rng = random.Random(5)
+    for c in special:                                             # scattered through the batch
+        at = rng.randrange(len(certs2))
+        certs2.insert(at, c)
+        idx2.insert(at, 0)
+    exp2, res2 = run(certs2, idx2)
+    kinds = sorted(k[0] for k in exp2)
+    assert (N.MK_CRL, 0, 0, b"http://crl.example/second-shard.crl") in exp2
+    assert (N.MK_DN, 0, 0, other_name) in exp2 and (N.MK_DN, 0, 0, long_name) in exp2
+    assert kinds.count(N.MK_HOST) == 1
+    # third pass over the same certificates after the table is cleared: every certificate is new again, nothing is a
+    # first sighting — the steady state the pre-check exists for
+    eng.reset_known()
+    exp3, res3 = run(certs2, idx2)
+    assert res3.stats.n_new >= res2.stats.n_new > 0
+    assert exp3 == {k for k in exp3 if k[0] == N.MK_HOST}         # host-routed certificates are handed over every time
     eng.close()
