@@ -602,6 +602,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 }
 #endif  // CTMR_SWEEP
 
+// (Tried and dropped, round 2: two groups of 64 certificates per wave with nothing carried across but the next group's
+// INPUTS — byte range, issuer index, entry type — requested before the current group's fill, so that the offsets →
+// addresses round trip is paid once per wave: 25.9 ms against 23.5 ms in alternating runs on one box.  The loop costs
+// registers (180 VGPRs; 168 without spills when held to three waves per SIMD) and, like k_map_pipe, runs slower than one
+// group per workgroup whatever it hides — profiles/r02/ab_two_groups_per_wave_not_kept.txt.)
 // (Tried and dropped, session 4: a software-pipelined form — one wave walks 2 or 4 batches of 64 certificates and
 // fetches the next batch's front windows into registers while walking the current one.  256 VGPRs → 8 waves per CU,
 // and the first vector load inside the walk (the issuerCN filter words) waits on vmcnt for the prefetch issued just
