@@ -569,6 +569,58 @@ static void Test_Pipeline_Gpu() {
   CHECK_EQ(ta, ts);
 }
 
+// the same pipeline fed with RAW get-entries responses (ctmr_submit_entries / ctmr_wait_entries): every ticket answers
+// like one synchronous ctmr_map_entries over the same stream — records, NEW list, timestamps, decode statistics; the
+// engines register the issuers themselves
+static void Test_PipelineRaw_Gpu() {
+  GpuEngine sync_e(0, 1 << 18, 1 << 14), async_e(0, 1 << 18, 1 << 14);
+  ctmr_synth_config sc;
+  memset(&sc, 0, sizeof sc);
+  sc.seed = 4713; sc.n_issuers = 8; sc.dup_permille = 300; sc.ca_permille = 20; sc.expired_permille = 20;
+  for (GpuEngine* e : {&sync_e, &async_e}) e->ck(ctmr_set_filter(e->handle(), "", 0, 1, 0));
+  const uint64_t per = 1001, batches = 24;
+  struct B { std::vector<uint8_t> blob; std::vector<uint64_t> bounds; ctmr_ticket t; };
+  std::vector<B> bs(batches);
+  for (uint64_t k = 0; k < batches; k++) {
+    B& b = bs[k];
+    b.bounds.resize(2 * per + 1);
+    const uint64_t need = ctmr_synth_entries_host(&sc, k * per, per, b.bounds.data(), nullptr, 0);
+    b.blob.resize(need + 64);
+    ctmr_synth_entries_host(&sc, k * per, per, b.bounds.data(), b.blob.data(), need + 64);
+    async_e.ck(ctmr_submit_entries(async_e.handle(), b.blob.data(), b.bounds.data(), per, &b.t));
+  }
+  uint64_t dup_total = 0, x509 = 0, pre = 0;
+  for (uint64_t k = 0; k < batches; k++) {
+    B& b = bs[k];
+    std::vector<ctmr_record> ra(per), rs(per);
+    std::vector<uint64_t> na(per), ns(per), ta(per), ts(per);
+    ctmr_batch_stats sa, ss;
+    ctmr_decode_stats da, ds;
+    async_e.ck(ctmr_wait_entries(async_e.handle(), b.t, ra.data(), na.data(), ta.data(), &da, &sa));
+    sync_e.ck(ctmr_map_entries(sync_e.handle(), b.blob.data(), b.bounds.data(), per, rs.data(), ns.data(), ts.data(), &ds, &ss));
+    CHECK(memcmp(ra.data(), rs.data(), per * sizeof(ctmr_record)) == 0);
+    CHECK(ta == ts);
+    CHECK_EQ(sa.n_new, ss.n_new);
+    CHECK_EQ(sa.n_dup, ss.n_dup);
+    CHECK(sa.n_new == 0 || memcmp(na.data(), ns.data(), sa.n_new * 8) == 0);
+    CHECK_EQ(da.n, ds.n);
+    CHECK_EQ(da.n_x509, ds.n_x509);
+    CHECK_EQ(da.n_precert, ds.n_precert);
+    CHECK_EQ(da.n_decode_error, ds.n_decode_error);
+    CHECK_EQ(da.blob_bytes, ds.blob_bytes);
+    dup_total += sa.n_dup; x509 += da.n_x509; pre += da.n_precert;
+  }
+  CHECK(dup_total > 500 && x509 > 1000 && pre > 1000);
+  uint32_t ia = 0, is = 0;
+  async_e.ck(ctmr_issuer_count(async_e.handle(), &ia));
+  sync_e.ck(ctmr_issuer_count(sync_e.handle(), &is));
+  CHECK(ia == is && ia > 0 && ia <= 8);
+  uint64_t ca, cs;
+  async_e.ck(ctmr_total_count(async_e.handle(), &ca));
+  sync_e.ck(ctmr_total_count(sync_e.handle(), &cs));
+  CHECK_EQ(ca, cs);
+}
+
 // multi-GPU groups (ctmr_group_*): two engines on one device as a local group; the owner-computes and the Bloom
 // exchange give the same global answer as one engine over the whole stream
 static void Test_Group_Gpu() {
@@ -690,6 +742,7 @@ int main(int argc, char** argv) {
       RUN(Test_StoreRawBatch_DeviceMeta_Gpu());
       RUN(Test_StoreRawBatch_DeviceMeta_Gpu(CTMR_CHAIN0_TRUSTED_LOG));
       RUN(Test_Pipeline_Gpu());
+      RUN(Test_PipelineRaw_Gpu());
       RUN(Test_Group_Gpu());
     } catch (const std::exception& ex) {
       fprintf(stderr, "GPU suites aborted: %s\n", ex.what());
