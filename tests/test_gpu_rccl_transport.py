@@ -1,0 +1,116 @@
+"""-m gpu: the RCCL TRANSPORT of the native group layer (csrc/engine/group.inc: grouped ncclSend/ncclRecv all-to-all,
+in-place ncclAllGather of the counts matrix and the Bloom filters, ncclAllReduce of the per-issuer counts) driven with
+a world of 2–4 ranks although only one GPU is reachable: the ranks are THREADS of one child process, each with its own
+engine and its own `ctmr_group_create_rccl` communicator, and `CTMR_RCCL_LIB` points the library at an in-process
+stand-in for librccl (tests/harness/fake_rccl.cpp) that moves the bytes with device-to-device copies.  What is under
+test is everything group.inc does around the collectives — counts, offsets, peers, in-place rules, phase order — which
+the in-process LOCAL transport (tests/test_gpu_exchange.py) does not run.  The real librccl is exercised with a world of
+one there; N > 1 over real RCCL stays unmeasured until a multi-GPU node exists."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE_SRC = os.path.join(ROOT, "tests", "harness", "fake_rccl.cpp")
+FAKE_LIB = os.path.join(ROOT, "tests", "harness", "libfake_rccl.so")
+
+CHILD = r'''
+import json, sys, threading
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import synth
+from ct_mapreduce_amd.distributed import Group, shard, shard_range
+from ct_mapreduce_amd.engine import RECORD_DTYPE
+from tests.gpu_common import run_oracle
+
+world, mode = int(sys.argv[2]), sys.argv[3]
+DEV = torch.device("cuda:0")
+NOW, FILT = synth.BASE_TIME, b"Synth Issuer 0"
+cfg = synth.config(seed=57, n_issuers=16, dup_permille=300, ca_permille=30, expired_permille=30)
+n_total = 6000
+issuers = synth.issuers(cfg)
+whole = synth.host_batch(cfg, 0, n_total)
+o, st, unk, eh = run_oracle(whole, issuers, FILT, False, NOW)
+gid = Group.unique_id()
+out, errs = [None] * world, []
+
+def rank_main(r):
+    try:
+        lo, hi = shard_range(n_total, r, world)
+        b = synth.host_batch(cfg, lo, hi - lo)
+        pay = torch.from_numpy(np.concatenate([b.payload, np.zeros(64, np.uint8)])).to(DEV)
+        off = torch.from_numpy(b.offsets.astype(np.int64)).to(DEV)
+        iss = torch.from_numpy(b.issuer_idx.astype(np.int32)).to(DEV)
+        et = torch.from_numpy(b.entry_type).to(DEV)
+        rec = torch.zeros(b.n * 32, dtype=torch.uint8, device=DEV)
+        new = torch.zeros(max(b.n, 1), dtype=torch.int64, device=DEV)
+        e = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12)
+        e.add_issuers(issuers)
+        e.set_filter(FILT, False, NOW)
+        g = Group.rccl(e, gid, r, world)                      # collective: returns when every rank has joined
+        if mode == "bloom":
+            g.bloom_config(1 << 16)
+        stats = g.map_batch(mode, [shard(pay.data_ptr(), off.data_ptr(), iss.data_ptr(), et.data_ptr(), b.n,
+                                         rec.data_ptr(), new.data_ptr(), order_base=lo)])[0]
+        counts = g.issuer_counts(len(issuers))
+        total = g.total_count()
+        mx = int(g.all_reduce_u64([r + 1], op_max=True)[0])
+        g.barrier()
+        info = g.info()
+        recs = rec.cpu().numpy().view(RECORD_DTYPE)
+        ok = bool((recs["status"] == st[lo:hi]).all() and (((recs["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all())
+        newl = new[:stats.n_new].cpu().numpy()
+        ok = ok and stats.n_new == int(unk[lo:hi].sum()) and bool((newl == np.nonzero(unk[lo:hi])[0]).all())
+        out[r] = {"ok": ok, "n_new": int(stats.n_new), "counts": [int(c) for c in counts], "total": int(total), "max": mx,
+                  "keys_sent": int(info.keys_sent), "keys_received": int(info.keys_received)}
+        g.close()
+        e.close()
+    except Exception as ex:   # noqa: BLE001
+        errs.append(f"rank {r}: {type(ex).__name__}: {ex}")
+
+ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+for t in ts: t.start()
+for t in ts: t.join(30)
+hung = [r for r, t in enumerate(ts) if t.is_alive()]
+print(json.dumps({"out": out, "errs": errs, "hung": hung, "oracle_total": int(o.total_count()),
+                  "oracle_new": int(unk.sum())}))
+sys.stdout.flush()
+import os
+os._exit(0 if not hung else 3)
+'''
+
+
+def build_fake():
+    if not os.path.exists(FAKE_LIB) or os.path.getmtime(FAKE_LIB) < os.path.getmtime(FAKE_SRC):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               FAKE_SRC, "-o", FAKE_LIB, "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
+    return FAKE_LIB
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom", "local"])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_rccl_transport_with_several_ranks_on_one_gpu(world, mode):
+    env = dict(os.environ, CTMR_RCCL_LIB=build_fake())
+    p = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(world), mode], env=env, capture_output=True, text=True,
+                       timeout=100)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert line, p.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert not res["errs"] and not res["hung"], res
+    outs = res["out"]
+    assert all(o_ is not None for o_ in outs)
+    if mode != "local":                                         # shard-local dedup is not the global answer
+        assert all(o_["ok"] for o_ in outs), outs
+        assert sum(o_["n_new"] for o_ in outs) == res["oracle_new"]
+        assert all(o_["total"] == res["oracle_total"] for o_ in outs)
+    assert all(o_["counts"] == outs[0]["counts"] for o_ in outs)   # the all-reduce gave every rank the same sums
+    assert all(o_["max"] == world for o_ in outs)
+    if mode == "owner":
+        assert sum(o_["keys_sent"] for o_ in outs) == sum(o_["keys_received"] for o_ in outs) > 0
