@@ -113,12 +113,7 @@ ncclResult_t run_p2p(ncclComm* c, std::vector<Op>& ops) {
   w->barrier();  // every copy is done: senders may reuse their buffers
   {
     std::lock_guard<std::mutex> lk(w->mu);
-    for (int d = 0; d < w->n; d++) {
-      if (w->mail[c->rank][d].set) {
-        // a send nobody received is a bug of the caller; detect it on the receiving side: the receiver clears what it took
-      }
-      w->mail[c->rank][d] = World::Msg{};
-    }
+    for (int d = 0; d < w->n; d++) w->mail[c->rank][d] = World::Msg{};  // my mailbox row is free for the next round
   }
   w->barrier();
   return rc;
