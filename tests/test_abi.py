@@ -60,3 +60,24 @@ def test_product_never_imports_the_oracle():
     import subprocess
     deps = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+def test_the_documents_quote_the_header_s_symbol_count():
+    """README / DESIGN / INTEGRATION say how many entry points the ABI has: keep them honest."""
+    n = len(declared_functions())
+    for doc in ("README.md", "DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        quoted = set(int(m) for m in re.findall(r"\b(\d+) symbols", text))
+        assert quoted == {n}, (doc, quoted, n)
+
+
+def test_an_explicit_rccl_library_is_an_error_when_it_cannot_be_loaded():
+    """CTMR_RCCL_LIB (group.inc): a named library that does not exist must fail loudly, not fall back to another one."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from ct_mapreduce_amd import _native as N; "
+            "buf = C.create_string_buffer(N.GROUP_ID_BYTES); print(N.lib().ctmr_group_unique_id(buf))" % ROOT)
+    env = dict(os.environ, CTMR_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert int(out.stdout.strip().splitlines()[-1]) != 0
