@@ -27,10 +27,9 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32
 
 
-MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16>", 15: "k_map_fused<16, false>",   # 1, 2, 17-19: sweep build only
-               17: "k_map_pipe<16, 4>", 18: "k_map_pipe<16, 2>", 19: "k_map_pipe<16, 8>"}
+MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16>", 15: "k_map_fused<16, false>"}   # 1, 2: sweep build only
 DEFAULT_VARIANT = 15
-FUSED = (15, 17, 18, 19)          # map kernels that also do pass 1 of the known-certificate insert
+FUSED = (15,)          # map kernels that also do pass 1 of the known-certificate insert
 ALG_BYTES_PROBE = 64   # per PASS entry: 32 B slot read + 32 B slot write — fused kernels only
 
 

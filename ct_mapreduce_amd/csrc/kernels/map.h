@@ -26,8 +26,6 @@ struct MapArgs {
                             // no second scattered write into the record array
 };
 
-extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-
 // Byte range of certificate i and the readable size of the payload, for both input forms.
 __device__ __forceinline__ void cert_range(const uint64_t* offsets, const uint64_t* ends, uint64_t i, uint64_t& lo,
                                            uint64_t& hi) {
@@ -146,11 +144,8 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
 
 // Window map (variant 13; the exchange modes and `map_variant = 13` use it, the default is k_map_fused in reduce.h):
 // one certificate per lane, all 64 lanes busy, DER stays in global memory and is pulled through a per-lane LDS
-// window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: 64 × (16·16+16) bytes per
-// wave.  The first fill is wave-cooperative: instead of every lane issuing 16 loads of ITS certificate (64
-// uncoalesced 16-byte requests per instruction), 16 adjacent lanes fetch the 16 chunks of one certificate's front
-// window, 4 certificates per instruction — the texture addresser sees 8 lanes per 128-byte line — and each lane
-// parks its chunk directly in the owning lane's LDS window.
+// window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: WIN_LDS_BYTES per wave.
+// The first fill is wave-cooperative (coop_fill, readers.h).
 template <int WCH>
 __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
@@ -158,28 +153,14 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
   const bool live = i < a.n;
-  constexpr uint32_t STRIDE = WCH * 16 + 16;
   const uint64_t limit = map_limit(a);
   uint64_t lo = 0, hi = 0;
   if (live) cert_range(a.offsets, a.ends, i, lo, hi);
   const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
-  {
-    uint4 v[16];
-    const uint32_t sub = lane & 15u;
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
-      const uint64_t at = g + 16u * sub;
-      v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(a.payload + at)) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < 16; it++)
-      *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
-  }
-  __builtin_amdgcn_wave_barrier();
+  coop_fill<false>(a.payload, limit, g_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   if (live) {
-    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
                        (int32_t)(int64_t)(g_me - lo)}};
     map_one(r, hi - lo, i, a, o0, o1);
   }

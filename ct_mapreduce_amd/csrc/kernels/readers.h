@@ -24,6 +24,64 @@ __device__ __forceinline__ void st_stream16(uint4* p, const uint4& v) {
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
   __builtin_nontemporal_store(t, (ctmr_u32x4*)p);
 }
+// ------------------------------------------------------------------ the per-lane LDS windows of one wave
+// One wave per workgroup; lane c owns a 256-byte window (16 chunks of 16 bytes) at smem + win_off(c).
+//   default        lane stride 272 bytes (16-B aligned for ds_write_b128, ≤ 4-way bank conflicts on equal in-window
+//                  offsets), filled through registers: 16 global_load_dwordx4 → 16 ds_write_b128 per lane
+//   CTMR_WIN_GLDS  (experiment, round 3) filled by LDS-DMA — global_load_lds_dwordx4 writes M0 + lane·16, i.e. ONE
+//                  instruction fills four whole windows that must be contiguous: groups of 4 windows (1 KiB) + 16 B
+//                  pad per group (the same 4-way conflict class as the default), no staging registers, no ds_write pass
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef CTMR_WIN_GLDS
+constexpr uint32_t WIN_GROUP = 4u * 256u + 16u;
+constexpr uint32_t WIN_LDS_BYTES = 16u * WIN_GROUP;
+__device__ __forceinline__ uint32_t win_off(uint32_t c) { return (c >> 2) * WIN_GROUP + (c & 3u) * 256u; }
+typedef __attribute__((address_space(1))) const void* ctmr_gptr;
+typedef __attribute__((address_space(3))) void* ctmr_lptr;
+#else
+constexpr uint32_t WIN_STRIDE = 16u * 16u + 16u;
+constexpr uint32_t WIN_LDS_BYTES = 64u * WIN_STRIDE;
+__device__ __forceinline__ uint32_t win_off(uint32_t c) { return c * WIN_STRIDE; }
+#endif
+
+// Wave-cooperative fill of all 64 windows: instead of every lane issuing 16 loads of ITS certificate (64 uncoalesced
+// 16-byte requests per instruction), 16 adjacent lanes fetch the 16 chunks of one certificate's window, 4 certificates
+// per instruction — the texture addresser sees 8 lanes per 128-byte line.  g_me = this lane's 16-byte aligned window
+// start in the payload (~0: no certificate); bytes at or beyond `limit` read as zero (GLDS: as whatever lies below).
+// BARRIER_BEFORE_STORES: the windows are being re-filled (every lane must be done reading the old contents).
+template <bool BARRIER_BEFORE_STORES>
+__device__ __forceinline__ void coop_fill(const uint8_t* payload, uint64_t limit, uint64_t g_me, uint32_t lane) {
+  const uint32_t sub = lane & 15u;
+#ifdef CTMR_WIN_GLDS
+  if (BARRIER_BEFORE_STORES) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my own ds_reads of the old window have returned
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+    uint64_t at = g + 16u * sub;
+    at = (g != ~0ull && at + 16u <= limit) ? at : 0ull;  // LDS-DMA cannot zero-fill: read SOMETHING readable instead
+    __builtin_amdgcn_global_load_lds((ctmr_gptr)(payload + at), (ctmr_lptr)(smem + it * WIN_GROUP), 16, 0, 2 /* nt */);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hipcc does not count LDS-DMA: the data has landed after this …
+  __builtin_amdgcn_wave_barrier();                   // … for every lane of the (single-wave) workgroup
+#else
+  uint4 v[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+    const uint64_t at = g + 16u * sub;
+    v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(payload + at)) : make_uint4(0, 0, 0, 0);
+  }
+  if (BARRIER_BEFORE_STORES) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < 16; it++)
+    *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + 16u * sub) = v[it];
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 // ------------------------------------------------------------------ byte readers
 // ld4(pos): 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
 struct GlobalReader {
@@ -96,28 +154,15 @@ struct WinReader {
 // instruction.  Falls back to the per-lane refill when some lane of the wave is not at that point.
 template <int WCH>
 struct WinReaderC : WinReader<WCH> {
-  static constexpr uint32_t STRIDE = WCH * 16 + 16;
+  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) {
     if (__ballot(1) != ~0ull) {
       this->refill(pos);
       return;
     }
-    const uint32_t lane = threadIdx.x & 63u, sub = lane & 15u;
     const uint64_t g_me = (this->base + pos) & ~15ull;
     this->grel = (int32_t)(int64_t)(g_me - this->base);
-    uint8_t* lds0 = (uint8_t*)this->win - lane * STRIDE;
-    uint4 v[16];
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
-      const uint64_t at = g + 16u * sub;
-      v[it] = (at + 16u <= this->limit) ? ld_payload16((const uint4*)this->g32 + (at >> 4)) : make_uint4(0, 0, 0, 0);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 16; it++)
-      *(uint4*)(lds0 + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
-    __builtin_amdgcn_wave_barrier();
+    coop_fill<true>((const uint8_t*)this->g32, this->limit, g_me, threadIdx.x & 63u);
   }
 };
 

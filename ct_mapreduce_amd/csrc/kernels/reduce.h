@@ -326,7 +326,6 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
   const bool live = i < a.n;
-  constexpr uint32_t STRIDE = WCH * 16 + 16;
   const uint64_t limit = map_limit(a);
   uint64_t lo = 0, hi = 0;
   if (live) cert_range(a.offsets, a.ends, i, lo, hi);
@@ -353,26 +352,13 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
     }
   }
   const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
-  {
-    uint4 v[16];
-    const uint32_t sub = lane & 15u;
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
-      const uint64_t at = g + 16u * sub;
-      v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(a.payload + at)) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < 16; it++)
-      *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
-  }
-  __builtin_amdgcn_wave_barrier();
+  coop_fill<false>(a.payload, limit, g_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   uint64_t claimed = ~0ull;
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
   if (live) {
     using Hook = typename std::conditional<META, MetaHook, NoRefillHook>::type;
-    WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
+    WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
                               (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
     if constexpr (META) {
       r.hook.mc = mc;
@@ -414,193 +400,11 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
 }
 
-#ifdef CTMR_SWEEP
-// ---- EXPERIMENT, sweep builds only (round 2, measured and NOT adopted: profiles/r02/sweep_pipelined_probe.txt) ----
-// Result at 100 M entries on one box: 26.8 / 27.1 / 27.0 ms with 4 / 2 / 8 groups per wave against 22.9 ms for
-// k_map_fused.  The number of groups per wave — i.e. the share of probe chains that are hidden, 50 % … 87.5 % — makes
-// no difference, so the chain's latency is not on the critical path (the other eight waves of the CU fill it already);
-// what the sparser-table runs measure (2^28 → 2^30 slots: 23.2 → 20.9 ms) is the number of random-access transactions,
-// not their latency.  The +4 ms is the price of carrying the pending chain through the walk: 203 VGPRs unconstrained,
-// 168 with spills when held to three waves per SIMD.
-// The pipelined form (variants 17/18/19): one wave maps G consecutive groups of 64 certificates, and the table probe of
-// group g runs INSIDE group g+1 — its first atomic is issued between the loads of g+1's front fill and the LDS stores
-// that wait for them, its second between the tail loads and the extension refill of g+1's walk — so the chain of
-// dependent random-access round trips (the wave waits for the LONGEST of its 64 chains: 4–5 steps at a load of 0.37)
-// overlaps the next group's sequential fetches instead of standing at the end of each group.  What is still unresolved
-// after g+1's walk is finished in a loop as before; records, ent[] and slot images of group g are stored then
-// (WasUnknown must be final in the record).  The last group of a wave has nobody to hide behind.
-struct ProbeChain {
-  // what the probe needs of InsertArgs (wave-uniform)
-  Slot* table;
-  uint32_t* slot_id;
-  uint64_t mask;
-  uint32_t epoch;
-  // the entry: its record (the key's serial octets 0..19 ARE record words), octets 20.. of a long serial, log index
-  uint4 o0, o1;
-  uint32_t s2h;                 // octets 20..23, 24..31, 32..39 of a long serial (zero otherwise)
-  unsigned long long s3, s4;
-  uint32_t idx;                 // batch index (n < 2^32-16)
-  uint32_t canon, state, tag, nprobes;
-  bool active, issued;
-  uint64_t j;
-  unsigned long long meta, old;
-
-  __device__ __forceinline__ void key(unsigned long long s[5]) const {
-    s[0] = (unsigned long long)o0.w | ((unsigned long long)o1.x << 32);
-    s[1] = (unsigned long long)o1.y | ((unsigned long long)o1.z << 32);
-    s[2] = (unsigned long long)o1.w | ((unsigned long long)s2h << 32);
-    s[3] = s3;
-    s[4] = s4;
-  }
-  __device__ __forceinline__ void idle() {
-    o0 = make_uint4(CTMR_ST__COUNT, 0, 0, 0); o1 = make_uint4(0, 0, 0, 0);
-    s2h = 0; s3 = s4 = 0; idx = 0; canon = 0; state = ES_NONE; tag = 0; nprobes = 0; active = false; issued = false; j = 0; meta = 0; old = 0;
-  }
-  __device__ __forceinline__ void begin(const InsertArgs& ia, uint64_t i, bool live, const uint4& r0, const uint4& r1,
-                                        uint32_t canon_) {
-    idle();
-    o0 = r0; o1 = r1; idx = (uint32_t)i; canon = canon_;
-    if (!live) o0.x = CTMR_ST__COUNT;  // status of a lane past the end: never stored
-    if (live && (r0.x & 0xffu) == CTMR_ST_PASS) {
-      const uint32_t slen = r0.x >> 16;
-      if (slen > CTMR_MAX_SERIAL) {
-        state = ES_HOST;
-      } else {
-        unsigned long long s[5];
-        record_key(ia, i, r0, r1, s);
-        s2h = (uint32_t)(s[2] >> 32); s3 = s[3]; s4 = s[4];
-        meta = key_meta((int32_t)r0.y, canon, slen);
-        const unsigned long long h = key_hash(meta, s);
-        tag = key_tag(h);
-        j = h & ia.mask;
-        active = true;
-      }
-    }
-  }
-  __device__ __forceinline__ void note_issuer(const uint32_t*, uint32_t, uint32_t, uint32_t) {}
-  __device__ __forceinline__ void issue() {
-    issued = false;
-    if (active) {
-      old = atomicCAS(&table[j].w[0], 0ull, ((unsigned long long)tag << 32) | idx);
-      issued = true;
-    }
-  }
-  __device__ __forceinline__ void resolve() {  // same decisions as insert_probe, one probe position per call
-    if (!issued) return;
-    issued = false;
-    Slot* sl = table + j;
-    if (old == 0ull) {
-      state = ES_CLAIMED; active = false;  // j stays: the slot image goes there
-      return;
-    }
-    if ((uint32_t)(old >> 32) == tag) {
-      const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
-      if (ep != 0u && ep != epoch) {
-        unsigned long long s[5];
-        key(s);
-        bool eq = sl->w[1] == meta;
-#pragma unroll
-        for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
-        if (eq) { state = ES_DUP; active = false; return; }
-      } else {
-        slot_id[idx] = (uint32_t)j; state = ES_DEFER; active = false;
-        return;
-      }
-    }
-    j = probe_next(j, (uint64_t)nprobes, mask);
-    if ((uint64_t)++nprobes > mask) { state = ES_FULL; active = false; }
-  }
-  __device__ __forceinline__ void finish() {
-    while (__ballot(active)) { issue(); resolve(); }
-  }
-  // records, ent[] and slot images of the group (the LDS windows are free: the caller is between two groups)
-  __device__ __forceinline__ void flush(const MapArgs& a, uint32_t* ent, uint64_t first, uint32_t lane) {
-    const uint32_t status = o0.x & 0xffu;
-    const bool live = status != (uint32_t)CTMR_ST__COUNT;
-    if (live) {
-      if (status == CTMR_ST_PASS && state != ES_CLAIMED && state != ES_DEFER) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
-      ent[first + lane] = ent_pack(status, state, canon);
-    }
-    store_records_wave(a, first, live, o0, o1);
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long s[5];
-    key(s);
-    const uint4 q0 = make_uint4(idx, tag, (uint32_t)meta, (uint32_t)(meta >> 32));
-    const uint4 q1 = make_uint4(epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
-    const uint4 q2 = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
-    const uint4 q3 = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
-    store_slots_wave(table, (uint4*)smem, lane, state == ES_CLAIMED ? j : ~0ull, q0, q1, q2, q3);
-    __builtin_amdgcn_wave_barrier();
-  }
-};
-
-template <int WCH, int G>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_map_pipe(MapArgs a, InsertArgs ia) {
-  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
-  const uint32_t lane = threadIdx.x;
-  constexpr uint32_t STRIDE = WCH * 16 + 16;
-  const uint64_t limit = map_limit(a);
-  ProbeChain pc;
-  pc.table = ia.table; pc.slot_id = ia.slot_id; pc.mask = ia.mask; pc.epoch = ia.epoch;
-  pc.idle();  // nothing pending: issue/resolve are no-ops
-  bool have_prev = false;
-  uint64_t prev_first = 0;
-  for (int g = 0; g < G; g++) {
-    const uint64_t first = ((uint64_t)blockIdx.x * G + g) * 64;
-    if (first >= a.n) break;  // wave-uniform
-    const uint64_t i = first + lane;
-    const bool live = i < a.n;
-    uint64_t lo = 0, hi = 0;
-    if (live) cert_range(a.offsets, a.ends, i, lo, hi);
-    EntryIn in{CTMR_NO_ISSUER, 0u, false, false};
-    uint32_t canon = 0;
-    if (live) {
-      in = load_entry_in(a, i);
-      canon = in.iss_in_range ? ia.canon[in.iss] : 0u;
-    }
-    const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
-    {
-      uint4 v[16];
-      const uint32_t sub = lane & 15u;
-#pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const uint64_t gg = __shfl(g_me, 4 * it + (int)(lane >> 4));
-        const uint64_t at = gg + 16u * sub;
-        v[it] = (gg != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(a.payload + at)) : make_uint4(0, 0, 0, 0);
-      }
-      pc.issue();
-#pragma unroll
-      for (int it = 0; it < 16; it++)
-        *(uint4*)(smem + (4 * it + (lane >> 4)) * STRIDE + 16u * sub) = v[it];
-    }
-    __builtin_amdgcn_wave_barrier();
-    pc.resolve();
-    uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-    if (live) {
-      WinReaderS<WCH, ProbeChain> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + lane * STRIDE),
-                                      (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u, pc};
-      map_one(r, hi - lo, i, a, in, o0, o1);
-      pc = r.hook;
-      if (r.miss) {
-        GlobalReader gr{(const uint32_t*)a.payload, lo};
-        map_one(gr, hi - lo, i, a, in, o0, o1);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // every lane is done with its window
-    if (have_prev) {
-      pc.finish();
-      pc.flush(a, ia.ent, prev_first, lane);
-    }
-    pc.begin(ia, i, live, o0, o1, canon);
-    have_prev = true;
-    prev_first = first;
-  }
-  if (have_prev) {
-    pc.finish();
-    pc.flush(a, ia.ent, prev_first, lane);
-  }
-}
-#endif  // CTMR_SWEEP
+// (Round-2 experiment, removed from the tree in round 3 — profiles/r02/sweep_pipelined_probe.txt: k_map_pipe let one wave
+// map 2, 4 or 8 consecutive groups and ran the table probe of group g INSIDE group g+1's fills.  26.8–27.1 ms against
+// 22.9 ms whatever share of the probe chains was hidden: the chain's latency is already covered by the CU's other
+// waves; what a sparser table saves is random-access transactions, and the pending chain's registers cost more than
+// there was to hide.)
 
 // (Tried and dropped, round 2: two groups of 64 certificates per wave with nothing carried across but the next group's
 // INPUTS — byte range, issuer index, entry type — requested before the current group's fill, so that the offsets →

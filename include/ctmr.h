@@ -126,6 +126,8 @@ typedef struct ctmr_engine ctmr_engine;
 int ctmr_abi_version(void);
 int ctmr_create(const ctmr_config* cfg, ctmr_engine** out);
 void ctmr_destroy(ctmr_engine* e);
+/* The message of the last failure on that engine, copied for the calling thread: valid until this thread's next
+ * ctmr_last_error call (other threads may fail concurrently; nobody is handed a pointer into a string in flux). */
 const char* ctmr_last_error(const ctmr_engine* e);
 /* Launch all GPU work on this hipStream_t (default: a stream the engine owns). */
 int ctmr_set_stream(ctmr_engine* e, void* hip_stream);

@@ -145,6 +145,63 @@ def test_several_threads_submit_and_wait():
     eng.close()
 
 
+def test_submitters_blocked_on_a_full_pipeline_never_orphan_a_super_batch():
+    """Back-pressure with several submitters (round-2 advisor finding): packed and raw submits alternate, so nearly every
+    submit closes the open super-batch and needs a slot of its own; four threads keep three tickets outstanding each
+    against four slots, so submitters sleep in pipe_open_for with no FREE slot and wake one after the other.  A
+    submitter that woke up and took a second slot without looking at p->open again left the first one in PS_OPEN for
+    ever — its tickets never completed.  Every ticket must come back and the union must be the oracle's."""
+    cfg = synth.config(seed=96, n_issuers=16, dup_permille=0)
+    issuers = synth.issuers(cfg)
+    eng = make(issuers)
+    per, rounds, T, keep_out = 301, 24, 4, 3
+    news, errors = [0] * T, []
+
+    def collect(t, item):
+        raw, tk, n, _keep = item
+        res = eng.wait_entries(tk, n) if raw else eng.wait(tk, n)
+        news[t] += res.stats.n_new
+
+    def worker(t):
+        raw = t % 2 == 1
+        out = []
+        try:
+            for r in range(rounds):
+                first = (t * rounds + r) * per
+                while True:
+                    try:
+                        if raw:
+                            e = synth.host_entries(cfg, first, per)
+                            item = (True, eng.submit_entries(e.blob, e.bounds, e.n), e.n, e)
+                        else:
+                            b = synth.host_batch(cfg, first, per)
+                            a = arrays(b)
+                            item = (False, eng.submit_batch(a[0], a[1], a[2], a[3], b.n), b.n, a)
+                        break
+                    except ctmr.CtmrError as ex:           # every slot holds uncollected results: collect, retry
+                        if ex.code != N.E_RANGE or not out:
+                            raise
+                        collect(t, out.pop(0))
+                out.append(item)
+                while len(out) > keep_out:
+                    collect(t, out.pop(0))
+            while out:
+                collect(t, out.pop(0))
+        except Exception as ex:                          # noqa: BLE001
+            errors.append(ex)
+    ths = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(120)
+    assert not any(th.is_alive() for th in ths), "a ticket never completed: a super-batch was orphaned"
+    assert not errors, errors
+    whole = synth.host_batch(cfg, 0, per * rounds * T)
+    o, st, unk, eh = run_oracle(whole, issuers, FILT, False, NOW)
+    assert sum(news) == int(unk.sum()) == eng.total_count()
+    eng.close()
+
+
 def test_table_growth_happens_under_the_pipeline():
     """The known-certificate table starts at 4 096 slots; the super-batches the worker runs make it grow (k_rehash)
     between them — results stay those of the oracle over the whole stream."""
