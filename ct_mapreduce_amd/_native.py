@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CTMR_LIB") or os.path.join(HERE, "libctmr.so")
 ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
     ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
 ST_COUNT = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 CHAIN0_EXACT, CHAIN0_TRUSTED_LOG = 0, 1
 ENTRY_INVALID = 0xFF
 FL_PRECERT, FL_WAS_UNKNOWN, FL_LONG_SERIAL = 1, 2, 4
@@ -65,7 +65,7 @@ class Shard(C.Structure):
 class GroupStats(C.Structure):
     _fields_ = [("world", C.c_uint32), ("n_local", C.c_uint32), ("transport", C.c_uint32),
                 ("first_local_rank", C.c_uint32), ("keys_sent", C.c_uint64), ("keys_received", C.c_uint64),
-                ("filter_bytes_received", C.c_uint64)]
+                ("filter_bytes_received", C.c_uint64), ("wire_bytes_sent", C.c_uint64), ("ms_phase", C.c_float * 8)]
 
 
 class MetaItem(C.Structure):
@@ -123,11 +123,11 @@ SIGNATURES = {
     "ctmr_total_count": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ctmr_issuer_counts_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
     "ctmr_reset_known": (C.c_int, [_P]),
-    "ctmr_exchange_export_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_uint64, _P, C.c_uint32, _P,
-                                              C.POINTER(C.c_uint64)]),
-    "ctmr_exchange_insert_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
-    "ctmr_exchange_apply_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P,
-                                             C.POINTER(BatchStats)]),
+    "ctmr_xchg_map_device": (C.c_int, [_P, C.POINTER(Shard), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64)]),
+    "ctmr_xchg_keys_device": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint64)]),
+    "ctmr_xchg_insert_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P]),
+    "ctmr_xchg_apply_device": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64, C.POINTER(BatchStats)]),
     "ctmr_bloom_config": (C.c_int, [_P, C.c_uint64, _P]),
     "ctmr_bloom_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "ctmr_bloom_add_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P]),
@@ -151,8 +151,6 @@ SIGNATURES = {
     "ctmr_set_issuer_autoregister": (C.c_int, [_P, C.c_int]),
     "ctmr_set_chain0_match": (C.c_int, [_P, C.c_int]),
     "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
-    "ctmr_exchange_export_view_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(EntryView), C.c_uint64, _P, C.c_uint32,
-                                                   _P, C.POINTER(C.c_uint64)]),
     "ctmr_pem_encode_view_device": (C.c_int, [_P, _P, C.POINTER(EntryView), _P, C.c_uint64, _P, C.c_uint64, _P,
                                               C.POINTER(C.c_uint64)]),
     "ctmr_pem_new": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),

@@ -79,6 +79,8 @@ struct PairSlot {
 struct DevStats {
   unsigned long long by_status[CTMR_ST__COUNT];
   unsigned long long n_new, n_dup, n_host, n_full, pair_full;
+  unsigned long long n_remote;  // owner-computes rounds: PASS entries whose key left for its owner (counted in n_new, optimistically)
+  unsigned long long n_xl;      // … of them with a 21..40-octet serial (they travel as 64-byte records)
 };
 
 // map-kernel filter constants (device memory; uniform reads)

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <thread>
@@ -136,6 +137,30 @@ bool glob_match(const char* p, size_t pn, const char* s, size_t sn) {
 
 struct ctmr_pipeline;
 
+// One batch of the reduce in flight or just finished (engine/map.inc: round_*; engine/exchange.inc continues it)
+struct RoundCtx {
+  bool valid = false;  // the scratch state (ent[], blk_new[]) still describes this batch
+  int mode = XM_LOCAL;
+  uint32_t world = 1, rank = 0, ord_base = 0;
+  const uint8_t* d_payload = nullptr;
+  const uint64_t* d_offsets = nullptr;
+  const uint64_t* d_ends = nullptr;
+  const uint32_t* d_issuer_idx = nullptr;
+  const uint8_t* d_entry_type = nullptr;
+  uint64_t n = 0, blob_bytes = 0, payload_bytes_known = ~0ull;
+  ctmr_record* d_records = nullptr;
+  uint64_t* d_new_idx = nullptr;
+  bool compacted = false;   // the NEW list has been written
+  DevStats hs{};            // after round_collect
+  uint64_t payload_bytes = 0, host_new = 0;
+  uint64_t lost = 0;        // entries that lost WasUnknown to another rank after the resolve (exchange / Bloom apply)
+  uint64_t remote_new = 0;  // owner-computes round: received keys that were new here
+  uint64_t n_xl = 0;        // owner-computes round: keys with 21..40-octet serials that left as 64-byte records
+  std::vector<uint64_t> counts32;
+  std::vector<KeyRec> xl;   // … those records, sorted by (owner, order)
+  bool resolved = false;    // owner-computes round: ctmr_xchg_insert_device has run
+};
+
 struct ctmr_engine {
   std::mutex mu;
   std::atomic<ctmr_pipeline*> pipe{nullptr};  // asynchronous host ingestion (engine/pipeline.inc), created on first use
@@ -211,8 +236,9 @@ struct ctmr_engine {
   DevStats* d_stats = nullptr;
   uint32_t* d_result = nullptr;        // 2 words for point ops
   unsigned long long* d_count = nullptr;
-  void* d_scratch[20] = {};            // growable buffers
-  size_t scratch_cap[20] = {};
+  void* d_scratch[28] = {};            // growable buffers
+  size_t scratch_cap[28] = {};
+  RoundCtx rd;                         // the last batch (engine/map.inc)
   // the last ctmr_map_batch (host variant): what ctmr_pem_new encodes
   uint64_t last_n = 0, last_n_new = 0;
   size_t last_o_off = 0, last_o_new = 0;
@@ -226,7 +252,8 @@ struct ctmr_engine {
 
 namespace {
 
-enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP, SC_VIEW, SC_ISS_A, SC_ISS_B, SC_ISS_C, SC_META, SC_ITEMS };
+enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP, SC_VIEW, SC_ISS_A, SC_ISS_B, SC_ISS_C, SC_META, SC_ITEMS,
+       SC_XSTAGE, SC_XWCNT, SC_XCNT, SC_XBASE, SC_XSLOT, SC_XL };  // owner-computes exchange (engine/exchange.inc)
 constexpr uint32_t UNREG_CAP = 16384;
 
 int fail(const ctmr_engine* e, int code, const char* fmt, ...) {

@@ -5,106 +5,144 @@
 
 namespace ctmr {
 
-// ------------------------------------------------------------------ cross-GPU key exchange
-// Global dedup over G GPUs: every key has one OWNER = hash(key) mod G.  A
-// rank exports the keys of its PASS entries partitioned by owner (ascending log index inside each
-// partition), the partitions are exchanged (RCCL send/recv), the owner inserts what it received
-// — concatenated in sender-rank order, which IS global log order because shards are contiguous
-// log-index ranges — and returns one "was unknown" byte per key.
-struct KeyRec {  // 64 bytes
-  unsigned long long meta;  // key_meta(exp_hour, canonical issuer, serial_len)
-  unsigned long long s[5];  // serial octets
-  uint32_t src;             // index of the entry in the sender's batch
-  uint32_t owner;
-  unsigned long long pad;
-};
-static_assert(sizeof(KeyRec) == 64, "KeyRec");
-
-constexpr uint32_t KEY_NO_OWNER = 0xffu;
+// ------------------------------------------------------------------ cross-GPU key exchange (owner-computes)
+// Global dedup over G GPUs: every key has one OWNER = key_owner_h(hash) ∈ [0, G).  Round 3 shape:
+//   sender   k_map_fused<…, XM_OWNER> inserts the keys this rank owns itself (the fused path, unchanged) and leaves the
+//            others as 32-byte records in a wave-compacted staging array; k_key_blockcount + k_scan_blocks +
+//            k_key_gather turn that into per-owner partitions, ascending log order inside a partition (what the
+//            all-to-all sends).  Serials of 21..40 octets (rare) leave as 64-byte records (k_xl_export).
+//   owner    k_keys_insert / k_keys_insert2 / k_keys_resolve: the two-pass insert of reduce.h over received records, in
+//            the SAME epoch as the owner's own shard — every w[0] carries the entry's ORDER in the round (keyrec.h), so
+//            the lowest log index wins whoever held the entry; a received record that beats an entry of the owner's own
+//            shard marks it (mark_dup_ord); one "was unknown" byte per record goes back.
+//   sender   k_apply_lost: records leave the map optimistically NEW (ES_REMOTE); only the losers are touched.
 constexpr uint32_t SID_DEFER = 0x80000000u;  // slot_id bit (owner-side kernels): candidate slot, full compare in pass 2
-constexpr uint32_t MAX_WORLD = 16;
 
-__device__ __forceinline__ bool entry_key(const InsertArgs& a, uint64_t i, unsigned long long& meta,
-                                          unsigned long long s[5]) {
+struct KeyView {
+  unsigned long long meta;
+  unsigned long long s[5];
+  uint32_t ord;
+};
+__device__ __forceinline__ KeyView load_key(const KeyRec32* keys, uint64_t i) {
+  const uint4* p = (const uint4*)(keys + i);
+  const uint4 a = p[0], b = p[1];
+  KeyView k;
+  k.meta = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+  k.s[0] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+  k.s[1] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+  k.s[2] = (unsigned long long)b.z;
+  k.s[3] = 0;
+  k.s[4] = 0;
+  k.ord = b.w;
+  return k;
+}
+__device__ __forceinline__ KeyView load_key(const KeyRec* keys, uint64_t i) {
+  const KeyRec r = keys[i];
+  KeyView k;
+  k.meta = r.meta;
+#pragma unroll
+  for (int q = 0; q < 5; q++) k.s[q] = r.s[q];
+  k.ord = (uint32_t)r.pad;
+  return k;
+}
+
+// Sender, after the fused map: records per (owner, 1024-entry block) from the per-wave counts (owner-major, as
+// k_scan_blocks and k_key_gather want them)
+__global__ void __launch_bounds__(256) k_key_blockcount(const uint8_t* wave_cnt, uint64_t n_waves, uint64_t nb,
+                                                        uint32_t world, uint32_t* cnt) {
+  const uint64_t blk = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blk >= nb) return;
+  uint32_t c[MAX_WORLD];
+#pragma unroll
+  for (uint32_t o = 0; o < MAX_WORLD; o++) c[o] = 0;
+  for (uint32_t w = 0; w < 16; w++) {
+    const uint64_t wave = blk * 16 + w;
+    if (wave >= n_waves) break;
+    const uint4 v = *(const uint4*)(wave_cnt + wave * MAX_WORLD);
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (uint32_t o = 0; o < MAX_WORLD; o++) c[o] += (x[o >> 2] >> (8 * (o & 3))) & 0xffu;
+  }
+  for (uint32_t o = 0; o < world; o++) cnt[(uint64_t)o * nb + blk] = c[o];
+}
+
+// Sender: staging array → per-owner partitions.  One 1024-thread block per 1024 entries (16 waves of the map kernel);
+// thread (w, p) moves record p of wave w's compacted group list.  Stable: ascending log order inside a partition.
+__global__ void __launch_bounds__(1024) k_key_gather(const KeyRec32* stage, const uint8_t* wave_cnt, uint64_t n_waves,
+                                                     uint64_t nb, uint32_t world, const uint64_t* base, KeyRec32* out) {
+  __shared__ uint8_t wc[16][MAX_WORLD];     // records of wave w for owner o
+  __shared__ uint16_t pre[16][MAX_WORLD];   // … of the earlier waves of this block
+  const uint32_t w = threadIdx.x >> 6, p = threadIdx.x & 63u;
+  const uint64_t wave = (uint64_t)blockIdx.x * 16 + w;
+  if (p < MAX_WORLD) wc[w][p] = wave < n_waves ? wave_cnt[wave * MAX_WORLD + p] : (uint8_t)0;
+  __syncthreads();
+  if (threadIdx.x < 16 * MAX_WORLD) {
+    const uint32_t ww = threadIdx.x / MAX_WORLD, o = threadIdx.x % MAX_WORLD;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < ww; k++) sum += wc[k][o];
+    pre[ww][o] = (uint16_t)sum;
+  }
+  __syncthreads();
+  uint32_t cum = 0, owner = KEY_NO_OWNER, rank_in = 0;
+  for (uint32_t o = 0; o < world; o++) {
+    const uint32_t c = wc[w][o];
+    if (owner == KEY_NO_OWNER && p < cum + c) {
+      owner = o;
+      rank_in = p - cum;
+    }
+    cum += c;
+  }
+  if (owner == KEY_NO_OWNER) return;
+  const uint4* src = (const uint4*)(stage + wave * 64 + p);
+  uint4* dst = (uint4*)(out + base[(uint64_t)owner * nb + blockIdx.x] + pre[w][owner] + rank_in);
+  const uint4 a = src[0], b = src[1];
+  dst[0] = a;
+  dst[1] = b;
+}
+
+// Sender, rare: the ES_REMOTE entries whose serial has 21..40 octets, as 64-byte records (unordered append; the host
+// sorts the few of them by (owner, order))
+__global__ void __launch_bounds__(256) k_xl_export(InsertArgs a, uint32_t world, KeyRec* out, uint64_t cap,
+                                                   unsigned long long* count) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  if (ent_state(a.ent[i]) != ES_REMOTE) return;
   const uint4* rp = (const uint4*)(a.records + i);
   const uint4 r0 = rp[0];
-  if ((r0.x & 0xffu) != CTMR_ST_PASS) return false;
   const uint32_t slen = r0.x >> 16;
-  if (slen > CTMR_MAX_SERIAL) return false;  // host-side set, shard-local
+  if (slen <= 20u) return;
   const uint4 r1 = rp[1];
+  unsigned long long s[5];
   record_key(a, i, r0, r1, s);
-  meta = key_meta((int32_t)r0.y, a.canon[r0.z], slen);
-  return true;
+  const unsigned long long meta = key_meta((int32_t)r0.y, a.canon[r0.z], slen);
+  const unsigned long long at = atomicAdd(count, 1ull);
+  if (at >= cap) return;
+  KeyRec k;
+  k.meta = meta;
+#pragma unroll
+  for (int q = 0; q < 5; q++) k.s[q] = s[q];
+  k.src = (uint32_t)i;
+  k.owner = key_owner_h(key_hash(meta, s), world);
+  k.pad = a.ord_base + (uint32_t)i;
+  out[at] = k;
 }
 
-__device__ __forceinline__ uint32_t key_owner(unsigned long long meta, const unsigned long long s[5],
-                                              uint32_t world) {
-  return (uint32_t)(mixk(key_hash(meta, s) ^ 0x5bd1e995u) % world);
-}
-
-// pass A: owner of every entry + per-(owner, 1024-entry block) counts (owner-major layout)
-__global__ void __launch_bounds__(1024) k_key_count(InsertArgs a, uint32_t world, uint64_t nb,
-                                                    uint8_t* owner_out, uint32_t* cnt) {
-  __shared__ uint32_t c[MAX_WORLD];
-  if (threadIdx.x < MAX_WORLD) c[threadIdx.x] = 0;
-  __syncthreads();
-  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  uint32_t owner = KEY_NO_OWNER;
-  if (i < a.n) {
-    unsigned long long meta, s[5];
-    if (entry_key(a, i, meta, s)) owner = key_owner(meta, s, world);
-    owner_out[i] = (uint8_t)owner;
-  }
-  for (uint32_t w = 0; w < world; w++) {
-    const unsigned long long m = __ballot(owner == w);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[w], (uint32_t)__popcll(m));
-  }
-  __syncthreads();
-  if (threadIdx.x < world) cnt[(uint64_t)threadIdx.x * nb + blockIdx.x] = c[threadIdx.x];
-}
-
-// pass B: stable scatter into the owner partitions
-__global__ void __launch_bounds__(1024) k_key_scatter(InsertArgs a, uint32_t world, uint64_t nb,
-                                                      const uint8_t* owner_in, const uint64_t* base,
-                                                      KeyRec* out) {
-  __shared__ uint32_t wc[16][MAX_WORLD];
-  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t owner = i < a.n ? owner_in[i] : KEY_NO_OWNER;
-  uint32_t my_rank = 0;
-  for (uint32_t w = 0; w < world; w++) {
-    const unsigned long long m = __ballot(owner == w);
-    if (lane == 0) wc[wv][w] = (uint32_t)__popcll(m);
-    if (owner == w) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  }
-  __syncthreads();
-  if (owner != KEY_NO_OWNER) {
-    uint32_t before = 0;
-    for (uint32_t k = 0; k < wv; k++) before += wc[k][owner];
-    unsigned long long meta, s[5];
-    entry_key(a, i, meta, s);
-    KeyRec* o = out + base[(uint64_t)owner * nb + blockIdx.x] + before + my_rank;
-    uint4* q = (uint4*)o;
-    q[0] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)s[0], (uint32_t)(s[0] >> 32));
-    q[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
-    q[2] = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
-    q[3] = make_uint4((uint32_t)i, owner, 0u, 0u);
-  }
-}
-
-// Owner side, pass 1 / pass 2 / resolve on received key records (same protocol as k_insert…)
-__global__ void __launch_bounds__(256) k_keys_insert(const KeyRec* keys, uint64_t n, Slot* table,
-                                                     uint64_t mask, uint32_t epoch, uint32_t* slot_id) {
+// Owner side, pass 1 / pass 2 / resolve on received key records (same protocol as the fused map's pass 1 and k_insert2).
+// `loc` describes the owner's OWN shard of the round (ent, ord_base, n; records_local): received records that beat one of
+// its entries mark it.
+template <class Rec>
+__global__ void __launch_bounds__(256) k_keys_insert(const Rec* keys, uint64_t n, Slot* table, uint64_t mask,
+                                                     uint32_t epoch, uint32_t* slot_id) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const KeyRec k = keys[i];
+  const KeyView k = load_key(keys, i);
   const unsigned long long h = key_hash(k.meta, k.s);
   const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
   uint64_t j = h & mask;
   uint32_t sid = SID_FULL;
   for (uint64_t probes = 0; probes <= mask; probes++) {
     Slot* sl = table + j;
-    const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | (uint32_t)i);
+    const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | k.ord);
     if (old == 0ull) {
       sl->w[1] = k.meta;
       uint4* q = (uint4*)&sl->w[2];
@@ -134,30 +172,37 @@ __global__ void __launch_bounds__(256) k_keys_insert(const KeyRec* keys, uint64_
   slot_id[i] = sid;
 }
 
-__global__ void __launch_bounds__(256) k_keys_insert2(const KeyRec* keys, uint64_t n, Slot* table,
-                                                      uint64_t mask, uint32_t epoch, uint32_t* slot_id) {
+template <class Rec>
+__global__ void __launch_bounds__(256) k_keys_insert2(const Rec* keys, uint64_t n, InsertArgs loc,
+                                                      ctmr_record* records_local, uint32_t* slot_id) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t sid = slot_id[i];
   if (sid >= SID_DUP_OLD || !(sid & SID_DEFER)) return;
   sid &= ~SID_DEFER;
-  const KeyRec k = keys[i];
-  Slot* sl = table + sid;
+  const KeyView k = load_key(keys, i);
+  Slot* sl = loc.table + sid;
   bool eq = sl->w[1] == k.meta;
 #pragma unroll
   for (int q = 0; q < 5; q++) eq = eq && sl->w[3 + q] == k.s[q];
+  unsigned long long prev = ~0ull;
   if (eq) {
-    atomicMin(&sl->w[0], ((unsigned long long)key_tag(key_hash(k.meta, k.s)) << 32) | (uint32_t)i);
+    prev = atomicMin(&sl->w[0], ((unsigned long long)key_tag(key_hash(k.meta, k.s)) << 32) | k.ord);
   } else {
     bool created;
-    sid = table_upsert(table, mask, k.meta, k.s, (uint32_t)i, epoch, true, &created);
+    sid = table_upsert(loc.table, loc.mask, k.meta, k.s, k.ord, loc.epoch, true, &created, &prev);
+    if (sid >= SID_DUP_OLD || created) prev = ~0ull;
   }
   slot_id[i] = sid;
+  if (prev != ~0ull) {  // whoever of (previous holder, this record) has the higher order loses; told here when it is local
+    const uint32_t other = (uint32_t)prev;
+    mark_dup_ord(loc, records_local, other < k.ord ? k.ord : other);
+  }
 }
 
-__global__ void __launch_bounds__(1024) k_keys_resolve(const KeyRec* keys, uint64_t n, uint64_t nb,
-                                                       const Slot* table, uint32_t epoch,
-                                                       const uint32_t* slot_id, uint8_t* flags,
+template <class Rec>
+__global__ void __launch_bounds__(1024) k_keys_resolve(const Rec* keys, uint64_t n, uint64_t nb, const Slot* table,
+                                                       uint32_t epoch, const uint32_t* slot_id, uint8_t* flags,
                                                        unsigned long long* issuer_counts, DevStats* stats) {
   __shared__ uint32_t ih[RES_LDS_ISSUERS];
   __shared__ uint32_t cnt[2];
@@ -175,7 +220,8 @@ __global__ void __launch_bounds__(1024) k_keys_resolve(const KeyRec* keys, uint6
       } else if (sid < SID_DUP_OLD) {
         const Slot* sl = table + sid;
         const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
-        is_new = (uint32_t)w2 == epoch && (uint32_t)w0 == (uint32_t)i;
+        const uint32_t ord = ((const uint32_t*)(keys + i))[sizeof(Rec) == 32 ? 7 : 14];  // KeyRec32.ord / low half of KeyRec.pad
+        is_new = (uint32_t)w2 == epoch && (uint32_t)w0 == ord;
         canon = (uint32_t)(w1 >> 32) & 0xffffffu;
       }
       flags[i] = is_new ? 1 : 0;
@@ -195,57 +241,25 @@ __global__ void __launch_bounds__(1024) k_keys_resolve(const KeyRec* keys, uint6
   if (threadIdx.x == 1 && cnt[1]) atomicAdd(&stats->n_full, (unsigned long long)cnt[1]);
 }
 
-// Sender side: apply the returned flags to the local records, count NEW per 1024-entry block
-__global__ void __launch_bounds__(256) k_apply_flags(const KeyRec* sent, const uint8_t* flags, uint64_t n_keys,
-                                                     ctmr_record* records, uint32_t* blk_new) {
+// Sender side: the returned bytes.  Records left the map optimistically NEW: only a record whose byte is 0 (the key
+// was known to its owner, or a lower order of this round holds it) is touched — its ent[] word and record flag, the NEW
+// count of its 1024-entry block, and the `lost` counter.
+template <class Rec>
+__global__ void __launch_bounds__(256) k_apply_lost(const Rec* sent, const uint8_t* flags, uint64_t n_keys, InsertArgs loc,
+                                                    ctmr_record* records, uint32_t* blk_new, unsigned long long* lost) {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool is_new = k < n_keys && flags[k] != 0;
-  uint32_t src = 0;
-  if (is_new) {
-    src = sent[k].src;
-    uint8_t* fl = (uint8_t*)(records + src) + 1;
-    *fl = (uint8_t)(*fl | CTMR_FL_WAS_UNKNOWN);
-  }
-  // per-1024-entry NEW counts for the compaction: keys of one partition are in ascending log order, so the lanes
-  // of a wave nearly always share one counter — one atomic per distinct counter per wave (the per-lane form spent
-  // 7.6 ms per 47 M keys serialising on single words)
-  unsigned long long todo = __ballot(is_new);
-  const uint32_t blk = src >> 10;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t b = __shfl(blk, leader);
-    const unsigned long long same = __ballot(is_new && blk == b) & todo;
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&blk_new[b], (uint32_t)__popcll(same));
-    todo &= ~same;
-  }
-}
-
-__global__ void __launch_bounds__(1024) k_status_hist(const ctmr_record* records, uint64_t n, uint64_t nb,
-                                                      DevStats* stats) {
-  __shared__ uint32_t hist[CTMR_ST__COUNT + 1];
-  if (threadIdx.x <= CTMR_ST__COUNT) hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (uint64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
-    const uint64_t i = blk * 1024 + threadIdx.x;
-    uint32_t status = CTMR_ST__COUNT, longs = 0;
-    if (i < n) {
-      const uint32_t head = *(const uint32_t*)(records + i);
-      status = head & 0xffu;
-      longs = status == CTMR_ST_PASS && (head >> 16) > CTMR_MAX_SERIAL;
+  bool lose = false;
+  if (k < n_keys && flags[k] == 0) {
+    const uint32_t ord = ((const uint32_t*)(sent + k))[sizeof(Rec) == 32 ? 7 : 14];
+    const uint32_t li = ord - loc.ord_base;
+    if ((uint64_t)li < loc.n && ent_state(loc.ent[li]) == ES_REMOTE) {
+      mark_dup(loc.ent, records, li);
+      atomicSub(&blk_new[li >> 10], 1u);
+      lose = true;
     }
-#pragma unroll
-    for (uint32_t st = 0; st < CTMR_ST__COUNT; st++) {
-      const unsigned long long m = __ballot(status == st);
-      if ((threadIdx.x & 63) == 0 && m) atomicAdd(&hist[st], (uint32_t)__popcll(m));
-    }
-    const unsigned long long ml = __ballot(longs != 0);
-    if ((threadIdx.x & 63) == 0 && ml) atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(ml));
   }
-  __syncthreads();
-  if (threadIdx.x < CTMR_ST__COUNT && hist[threadIdx.x])
-    atomicAdd(&stats->by_status[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-  if (threadIdx.x == CTMR_ST__COUNT && hist[CTMR_ST__COUNT])
-    atomicAdd(&stats->n_host, (unsigned long long)hist[CTMR_ST__COUNT]);
+  const unsigned long long m = __ballot(lose);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(lost, (unsigned long long)__popcll(m));
 }
 
 // ------------------------------------------------------------------ cross-GPU dedup, Bloom pre-filter variant
@@ -265,12 +279,17 @@ __global__ void __launch_bounds__(1024) k_status_hist(const ctmr_record* records
 // answer).
 constexpr unsigned long long SLOT_SHADOW = 1ull << 63;  // Slot.w[2]: key is counted by another rank
 
-__host__ __device__ inline void bloom_pos(unsigned long long h, uint64_t wmask, uint64_t& word,
-                                          unsigned long long& bits) {
-  const unsigned long long g = mixk(h ^ 0xa0761d6478bd642full);
-  word = g & wmask;
-  bits = (1ull << ((g >> 40) & 63)) | (1ull << ((g >> 46) & 63)) | (1ull << ((g >> 52) & 63)) |
-         (1ull << ((g >> 58) & 63));
+__device__ __forceinline__ bool entry_key(const InsertArgs& a, uint64_t i, unsigned long long& meta,
+                                          unsigned long long s[5]) {
+  const uint4* rp = (const uint4*)(a.records + i);
+  const uint4 r0 = rp[0];
+  if ((r0.x & 0xffu) != CTMR_ST_PASS) return false;
+  const uint32_t slen = r0.x >> 16;
+  if (slen > CTMR_MAX_SERIAL) return false;  // host-side set, shard-local
+  const uint4 r1 = rp[1];
+  record_key(a, i, r0, r1, s);
+  meta = key_meta((int32_t)r0.y, a.canon[r0.z], slen);
+  return true;
 }
 
 // key of entry i when it is a locally-new member of the device set (long serials stay shard-local on the host)
@@ -392,10 +411,12 @@ __global__ void __launch_bounds__(256) k_keys_lookup(const KeyRec* keys, uint64_
 }
 
 // Asker side: a flagged key loses WasUnknown (once, however many peers flagged it), leaves the per-issuer count and
-// its slot becomes SHADOW.
+// its slot becomes SHADOW; its ent[] word, the NEW count of its 1024-entry block and the `lost` counter follow, so that
+// the NEW list is compacted from ent[] as after a plain batch.
 __global__ void __launch_bounds__(256) k_bloom_apply(const KeyRec* sent, const uint8_t* flags, uint64_t n_keys,
-                                                     ctmr_record* records, Slot* table, uint64_t mask,
-                                                     unsigned long long* issuer_counts) {
+                                                     ctmr_record* records, uint32_t* ent, uint32_t* blk_new, Slot* table,
+                                                     uint64_t mask, unsigned long long* issuer_counts,
+                                                     unsigned long long* n_lost) {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool lost = false;
   uint32_t canon = 0;
@@ -407,9 +428,13 @@ __global__ void __launch_bounds__(256) k_bloom_apply(const KeyRec* sent, const u
       canon = (uint32_t)(kr.meta >> 32) & 0xffffffu;
       const uint32_t sid = table_find(table, mask, kr.meta, kr.s);
       if (sid != SID_NONE) atomicOr(&table[sid].w[2], SLOT_SHADOW);
+      ((uint8_t*)(ent + kr.src))[0] = (uint8_t)(CTMR_ST_PASS | (ES_DUP << 3));
+      atomicSub(&blk_new[kr.src >> 10], 1u);
     }
   }
-  unsigned long long todo = __ballot(lost);
+  const unsigned long long ml = __ballot(lost);
+  if (ml && (threadIdx.x & 63) == 0) atomicAdd(n_lost, (unsigned long long)__popcll(ml));
+  unsigned long long todo = ml;
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const uint32_t c = __shfl(canon, leader);
@@ -418,19 +443,6 @@ __global__ void __launch_bounds__(256) k_bloom_apply(const KeyRec* sent, const u
       atomicAdd(&issuer_counts[c], (unsigned long long)(-(long long)__popcll(same)));
     todo &= ~same;
   }
-}
-
-// NEW count per 1024-entry block from the record flags (compaction after k_bloom_apply)
-__global__ void __launch_bounds__(1024) k_count_new_flags(const ctmr_record* records, uint64_t n, uint32_t* blk_new) {
-  __shared__ uint32_t c;
-  if (threadIdx.x == 0) c = 0;
-  __syncthreads();
-  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-  const bool is_new = i < n && (((const uint8_t*)(records + i))[1] & CTMR_FL_WAS_UNKNOWN) != 0;
-  const unsigned long long m = __ballot(is_new);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c, (uint32_t)__popcll(m));
-  __syncthreads();
-  if (threadIdx.x == 0) blk_new[blockIdx.x] = c;
 }
 
 }  // namespace ctmr

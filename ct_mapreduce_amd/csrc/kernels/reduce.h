@@ -1,6 +1,7 @@
 // kernels/reduce.h — the reduce: known-certificate table insert (fused into the map kernel by default), WasUnknown, per-issuer counts, compaction of the NEW list.
 // gfx950 (CDNA4, wave64) only; part of kernels.h, which includes the pieces in dependency order.
 #pragma once
+#include "keyrec.h"
 #include "map.h"
 
 namespace ctmr {
@@ -77,6 +78,8 @@ struct InsertArgs {
   uint32_t* ent;           // per entry: status(0..2) | state(3..5) | canonical issuer << 8
   uint64_t n;
   uint32_t epoch;
+  DevStats* stats;         // n_xl (owner-computes rounds)
+  uint32_t ord_base;       // order of entry 0 in the round (keyrec.h; 0 outside a group round): w[0] carries ord_base + i
 };
 
 // Per-entry state of the reduce (bits 3..5 of ent[i]); the low 3 bits carry record.status.
@@ -86,7 +89,9 @@ enum : uint32_t {
   ES_DEFER = 2,    // met a same-tag slot of this batch: decided in pass 2; WasUnknown unless marked
   ES_DUP = 3,      // known: since an earlier batch, or a lower log index of this batch holds the key
   ES_HOST = 4,     // serial longer than CTMR_MAX_SERIAL: exact host-side set
-  ES_FULL = 5      // table full
+  ES_FULL = 5,     // table full
+  ES_REMOTE = 6    // owner-computes round: the key belongs to another rank and left as a key record; WasUnknown unless
+                   // the owner says otherwise (apply clears it) — in the NEW list, NOT in this rank's per-issuer counts
 };
 __device__ __forceinline__ uint32_t ent_pack(uint32_t status, uint32_t state, uint32_t canon) {
   return (status & 7u) | (state << 3) | (canon << 8);
@@ -94,7 +99,7 @@ __device__ __forceinline__ uint32_t ent_pack(uint32_t status, uint32_t state, ui
 __device__ __forceinline__ uint32_t ent_state(uint32_t e) { return (e >> 3) & 7u; }
 __device__ __forceinline__ bool ent_is_new(uint32_t e) {
   const uint32_t st = ent_state(e);
-  return (st == ES_CLAIMED) | (st == ES_DEFER);
+  return (st == ES_CLAIMED) | (st == ES_DEFER) | (st == ES_REMOTE);
 }
 // a PASS entry lost to a lower log index of the same key: its ent byte 0 and its record flag
 __device__ __forceinline__ void mark_dup(uint32_t* ent, ctmr_record* records, uint32_t loser) {
@@ -164,20 +169,14 @@ __device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, cons
 // Pass-1 set insert of one PASS record held in registers (r0, r1 = the two 16-byte halves of the record).
 // On a claim the 64-byte slot image is returned in q0..q3 and `claimed` is the slot index; the caller
 // stores it cooperatively (store_slots_wave).  Returns the ES_* state.
-__device__ __forceinline__ uint32_t insert_probe(const InsertArgs& a, uint64_t i, const uint4& r0, const uint4& r1,
-                                                 uint32_t canon, uint64_t& claimed, uint4& q0, uint4& q1, uint4& q2,
-                                                 uint4& q3) {
-  const uint32_t slen = r0.x >> 16;
-  if (slen > CTMR_MAX_SERIAL) return ES_HOST;
-  unsigned long long s[5];
-  record_key(a, i, r0, r1, s);
-  const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
-  const unsigned long long h = key_hash(meta, s);
+__device__ __forceinline__ uint32_t insert_probe_h(const InsertArgs& a, uint64_t i, unsigned long long meta,
+                                                   const unsigned long long s[5], unsigned long long h, uint64_t& claimed,
+                                                   uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
   const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  const unsigned long long w0 = tagw | (a.ord_base + (uint32_t)i);
   uint64_t j = h & a.mask;
   for (uint64_t probes = 0; probes <= a.mask; probes++) {
     Slot* sl = a.table + j;
-    const unsigned long long w0 = tagw | (uint32_t)i;
     const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
     if (old == 0ull) {  // claimed
       q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)meta, (uint32_t)(meta >> 32));
@@ -202,6 +201,17 @@ __device__ __forceinline__ uint32_t insert_probe(const InsertArgs& a, uint64_t i
     j = probe_next(j, probes, a.mask);
   }
   return ES_FULL;
+}
+
+__device__ __forceinline__ uint32_t insert_probe(const InsertArgs& a, uint64_t i, const uint4& r0, const uint4& r1,
+                                                 uint32_t canon, uint64_t& claimed, uint4& q0, uint4& q1, uint4& q2,
+                                                 uint4& q3) {
+  const uint32_t slen = r0.x >> 16;
+  if (slen > CTMR_MAX_SERIAL) return ES_HOST;
+  unsigned long long s[5];
+  record_key(a, i, r0, r1, s);
+  const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
+  return insert_probe_h(a, i, meta, s, key_hash(meta, s), claimed, q0, q1, q2, q3);
 }
 
 // Cooperative slot write of one wave: lane L parks its 64-byte image at img[L*4 .. L*4+3]; store
@@ -256,6 +266,13 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
 // table to find out.  A 32-bit tag collision between different keys (≈2^-32 per probe) falls back
 // to the fully synchronised upsert, which is also safe against other pass-2 lanes inserting the
 // same key concurrently.
+// Whoever loses a key of this round to a lower order: when it is an entry of THIS shard its ent[] word and its record
+// say so; an entry of another rank (owner-computes round) is told by its owner's flag byte (k_keys_resolve).
+__device__ __forceinline__ void mark_dup_ord(const InsertArgs& a, ctmr_record* records, uint32_t loser_ord) {
+  const uint32_t li = loser_ord - a.ord_base;  // wraps for lower ranks' orders: then >= n as well
+  if ((uint64_t)li < a.n) mark_dup(a.ent, records, li);
+}
+
 __device__ __forceinline__ void insert2_one(const InsertArgs& a, ctmr_record* records, uint64_t i, uint32_t e) {
   const uint32_t sid = a.slot_id[i];
   const uint4* rp = (const uint4*)(a.records + i);
@@ -263,6 +280,7 @@ __device__ __forceinline__ void insert2_one(const InsertArgs& a, ctmr_record* re
   unsigned long long s[5];
   record_key(a, i, r0, r1, s);
   const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
+  const uint32_t ord = a.ord_base + (uint32_t)i;
   Slot* sl = a.table + sid;
   bool eq = sl->w[1] == meta;
 #pragma unroll
@@ -270,18 +288,18 @@ __device__ __forceinline__ void insert2_one(const InsertArgs& a, ctmr_record* re
   unsigned long long prev = ~0ull;
   if (eq) {
     const unsigned long long tagw = (unsigned long long)key_tag(key_hash(meta, s)) << 32;
-    prev = atomicMin(&sl->w[0], tagw | (uint32_t)i);
+    prev = atomicMin(&sl->w[0], tagw | ord);
   } else {
     bool created;
-    const uint32_t r = table_upsert(a.table, a.mask, meta, s, (uint32_t)i, a.epoch, true, &created, &prev);
+    const uint32_t r = table_upsert(a.table, a.mask, meta, s, ord, a.epoch, true, &created, &prev);
     if (r == SID_FULL) {
       ((uint8_t*)(a.ent + i))[0] = (uint8_t)(CTMR_ST_PASS | (ES_FULL << 3));
       return;
     }
-    if (created) return;  // stays DEFER = unknown unless a lower index joins and marks it
+    if (created) return;  // stays DEFER = unknown unless a lower order joins and marks it
   }
   const uint32_t other = (uint32_t)prev;
-  mark_dup(a.ent, records, other < (uint32_t)i ? (uint32_t)i : other);
+  mark_dup_ord(a, records, other < ord ? ord : other);
 }
 
 // Four entries per thread, one 16-byte load of ent[]: nearly every entry is not DEFER, so the kernel is a scan of
@@ -319,8 +337,16 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 // CRL distribution point from the extension window and the (issuer, expDate hour) bit at the end of the walk — and
 // ent[] bit 6 is set only for certificates that may bring a first sighting.  k_meta_new then skips everything else
 // instead of re-reading ≈ 4 lines of every new certificate (9.7 ms per 94 M new certificates in round 1).
-template <int WCH, bool META>
-__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc) {
+// MODE (round 3: the global-dedup modes keep the fused kernel — keyrec.h):
+//   XM_OWNER  owner-computes exchange: a key owned by THIS rank is inserted here as always; a key owned by another rank is
+//             not probed at all — the walking lane has the key in registers and writes it out as a 32-byte record
+//             (state ES_REMOTE).  The records of a wave are compacted by owner with W ballots into the wave's own 2 KiB of
+//             the staging array (no atomics, no counters shared between waves); k_key_blockcount / k_key_gather turn the
+//             staging array into per-owner partitions in log order.
+//   XM_BLOOM  Bloom variant: the key of every entry that claimed or may claim a slot (CLAIMED / DEFER) is added to the
+//             rank's cumulative filter with one fire-and-forget 8-byte atomicOr — no separate pass over the records.
+template <int WCH, bool META, int MODE>
+__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
@@ -356,6 +382,9 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   uint64_t claimed = ~0ull;
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  uint32_t rem_owner = KEY_NO_OWNER;  // XM_OWNER: the rank this entry's key record goes to
+  bool rem_long = false;
+  uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
   if (live) {
     using Hook = typename std::conditional<META, MetaHook, NoRefillHook>::type;
     WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
@@ -385,8 +414,37 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
         mt = meta_tail_issue(mc, crl_ref, hour_row, (int32_t)o0.y, ml.y, r.win, r.grel, WinReader<WCH>::WBYTES - 8u);
     }
     if (status == CTMR_ST_PASS) {
-      state = insert_probe(ia, i, o0, o1, canon, claimed, q0, q1, q2, q3);
-      if (state != ES_CLAIMED && state != ES_DEFER) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
+      const uint32_t slen = o0.x >> 16;
+      if (slen > CTMR_MAX_SERIAL) {
+        state = ES_HOST;
+      } else {
+        unsigned long long s[5];
+        record_key(ia, i, o0, o1, s);
+        const unsigned long long meta = key_meta((int32_t)o0.y, canon, slen);
+        const unsigned long long h = key_hash(meta, s);
+        bool mine = true;
+        if constexpr (MODE == XM_OWNER) {
+          rem_owner = key_owner_h(h, xa.world);
+          mine = rem_owner == xa.rank;
+        }
+        if (mine) {
+          state = insert_probe_h(ia, i, meta, s, h, claimed, q0, q1, q2, q3);
+        } else {  // (XM_OWNER) the record that leaves; serials of 21..40 octets take the 64-byte path (k_xl_export)
+          state = ES_REMOTE;
+          rem_long = slen > 20u;
+          k0 = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+          k1 = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], ia.ord_base + (uint32_t)i);
+        }
+        if constexpr (MODE == XM_BLOOM) {
+          if (state == ES_CLAIMED || state == ES_DEFER) {
+            uint64_t word;
+            unsigned long long bits;
+            bloom_pos(h, xa.bloom_wmask, word, bits);
+            atomicOr(&xa.bloom[word], bits);  // result unused: a fire-and-forget atomic
+          }
+        }
+      }
+      if (state != ES_CLAIMED && state != ES_DEFER && state != ES_REMOTE) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
     }
     uint32_t e = ent_pack(status, state, canon);
     if constexpr (META) {
@@ -398,6 +456,27 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   store_records_wave(a, first, live, o0, o1);
   __builtin_amdgcn_wave_barrier();
   store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
+  if constexpr (MODE == XM_OWNER) {
+    // the wave's key records, grouped by owner: one ballot per rank gives every record its place and the per-owner counts
+    const bool rem = rem_owner != KEY_NO_OWNER && rem_owner != xa.rank && !rem_long;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t pos = 0, before = 0, mine_cnt = 0;
+    for (uint32_t o = 0; o < xa.world; o++) {
+      const unsigned long long m = __ballot(rem && rem_owner == o);
+      const uint32_t c = (uint32_t)__popcll(m);
+      if (rem && rem_owner == o) pos = before + (uint32_t)__popcll(m & lt);
+      if (lane == o) mine_cnt = c;
+      before += c;
+    }
+    if (rem) {
+      uint4* out = (uint4*)(xa.stage + first + pos);
+      out[0] = k0;
+      out[1] = k1;
+    }
+    if (lane < MAX_WORLD) xa.wave_cnt[(uint64_t)blockIdx.x * MAX_WORLD + lane] = (uint8_t)mine_cnt;
+    const unsigned long long ml = __ballot(rem_owner != KEY_NO_OWNER && rem_owner != xa.rank && rem_long);
+    if (ml && lane == 0) atomicAdd(&ia.stats->n_xl, (unsigned long long)__popcll(ml));
+  }
 }
 
 // (Round-2 experiment, removed from the tree in round 3 — profiles/r02/sweep_pipelined_probe.txt: k_map_pipe let one wave
@@ -463,17 +542,17 @@ struct ResolveArgs {
 constexpr uint32_t RES_LDS_ISSUERS = 4096;
 
 __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
-  __shared__ uint32_t hist[CTMR_ST__COUNT + 4];
+  __shared__ uint32_t hist[CTMR_ST__COUNT + 5];
   __shared__ uint32_t ih[RES_LDS_ISSUERS];
   __shared__ uint32_t blk_cnt;
-  if (threadIdx.x < CTMR_ST__COUNT + 4) hist[threadIdx.x] = 0;
+  if (threadIdx.x < CTMR_ST__COUNT + 5) hist[threadIdx.x] = 0;
   for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024) ih[k] = 0;
   __syncthreads();
   for (uint64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
     if (threadIdx.x == 0) blk_cnt = 0;
     __syncthreads();
     const uint64_t i = blk * 1024 + threadIdx.x;
-    bool is_new = false, is_dup = false, is_host = false, is_full = false;
+    bool is_new = false, is_dup = false, is_host = false, is_full = false, is_remote = false;
     uint32_t status = CTMR_ST__COUNT, canon = 0;
     if (i < a.n) {
       const uint32_t e = a.ent[i];
@@ -484,14 +563,17 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
       is_dup = st == ES_DUP;
       is_host = st == ES_HOST;
       is_full = st == ES_FULL;
+      is_remote = st == ES_REMOTE;  // counted where it is stored: by the key's owner (k_keys_resolve)
     }
     if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
     wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, a.issuer_counts);
+    is_new = is_new | is_remote;  // from here on: "in the NEW list" (optimistically, for a key that left)
     // (the per-(expDate, issuer) cardinalities are rebuilt lazily by k_build_pairs on the first
     //  SetCardinality/KeysToChan after a mutation — they are statistics, not hot-path state)
     const unsigned long long m_new = __ballot(is_new), m_dup = __ballot(is_dup),
-                             m_host = __ballot(is_host), m_full = __ballot(is_full);
+                             m_host = __ballot(is_host), m_full = __ballot(is_full), m_rem = __ballot(is_remote);
     if ((threadIdx.x & 63) == 0) {
+      if (m_rem) atomicAdd(&hist[CTMR_ST__COUNT + 4], (uint32_t)__popcll(m_rem));
       if (m_new) {
         atomicAdd(&blk_cnt, (uint32_t)__popcll(m_new));
         atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(m_new));
@@ -521,6 +603,8 @@ __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
     if (hist[CTMR_ST__COUNT + 2]) atomicAdd(&a.stats->n_host, (unsigned long long)hist[CTMR_ST__COUNT + 2]);
   } else if (threadIdx.x == CTMR_ST__COUNT + 3) {
     if (hist[CTMR_ST__COUNT + 3]) atomicAdd(&a.stats->n_full, (unsigned long long)hist[CTMR_ST__COUNT + 3]);
+  } else if (threadIdx.x == CTMR_ST__COUNT + 4) {
+    if (hist[CTMR_ST__COUNT + 4]) atomicAdd(&a.stats->n_remote, (unsigned long long)hist[CTMR_ST__COUNT + 4]);
   }
 }
 

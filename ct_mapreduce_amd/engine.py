@@ -368,24 +368,37 @@ class Engine:
             C.c_void_p(d_pem) if d_pem else None, pem_cap, C.c_void_p(d_pem_offsets), C.byref(total)))
         return int(total.value)
 
-    # ---- cross-GPU key exchange (global dedup), device pointers as ints
-    KEY_BYTES = 64
+    # ---- cross-GPU key exchange, owner-computes (ctmr.h: ctmr_xchg_*): one round on this rank, device pointers as ints.
+    # ctmr_mapreduce_amd.distributed.Group drives whole rounds natively; these are the per-rank steps for a host with a
+    # transport of its own, and for tests.
+    KEY_BYTES = 32          # a key record (serial of up to 20 octets)
+    KEY_BYTES_LONG = 64     # … of 21..40 octets
 
-    def exchange_export(self, d_payload, d_offsets, d_issuer_idx, d_entry_type, n, d_records, world,
-                        d_keys_out):
+    def xchg_map(self, shard: N.Shard, world: int, rank: int, ord_base: int):
+        """→ (records per owner, number of 64-byte records)."""
         counts = (C.c_uint64 * world)()
-        self._ck(self._lib.ctmr_exchange_export_device(
-            self._h, C.c_void_p(d_payload), C.c_void_p(d_offsets), C.c_void_p(d_issuer_idx),
-            C.c_void_p(d_entry_type) if d_entry_type else None, n, C.c_void_p(d_records), world,
-            C.c_void_p(d_keys_out), counts))
-        return [int(c) for c in counts]
+        n_long = C.c_uint64(0)
+        self._ck(self._lib.ctmr_xchg_map_device(self._h, C.byref(shard), world, rank, ord_base, counts, C.byref(n_long)))
+        return [int(c) for c in counts], int(n_long.value)
 
-    def exchange_export_view(self, d_blob, blob_bytes, view: N.EntryView, n, d_records, world, d_keys_out):
-        counts = (C.c_uint64 * world)()
-        self._ck(self._lib.ctmr_exchange_export_view_device(
-            self._h, C.c_void_p(d_blob), blob_bytes, C.byref(view), n, C.c_void_p(d_records), world,
-            C.c_void_p(d_keys_out), counts))
-        return [int(c) for c in counts]
+    def xchg_keys(self, world: int, d_keys32_out=0, d_keys64_out=0):
+        """Partitioned key records into the caller's buffers → 64-byte records per owner."""
+        counts64 = (C.c_uint64 * world)()
+        self._ck(self._lib.ctmr_xchg_keys_device(self._h, C.c_void_p(d_keys32_out) if d_keys32_out else None,
+                                                 C.c_void_p(d_keys64_out) if d_keys64_out else None, counts64))
+        return [int(c) for c in counts64]
+
+    def xchg_insert(self, d_keys32=0, n32=0, d_flags32=0, d_keys64=0, n64=0, d_flags64=0):
+        self._ck(self._lib.ctmr_xchg_insert_device(
+            self._h, C.c_void_p(d_keys32) if n32 else None, n32, C.c_void_p(d_keys64) if n64 else None, n64,
+            C.c_void_p(d_flags32) if n32 else None, C.c_void_p(d_flags64) if n64 else None))
+
+    def xchg_apply(self, d_sent32=0, d_flags32=0, n32=0, d_sent64=0, d_flags64=0, n64=0) -> N.BatchStats:
+        st = N.BatchStats()
+        self._ck(self._lib.ctmr_xchg_apply_device(
+            self._h, C.c_void_p(d_sent32) if n32 else None, C.c_void_p(d_flags32) if n32 else None, n32,
+            C.c_void_p(d_sent64) if n64 else None, C.c_void_p(d_flags64) if n64 else None, n64, C.byref(st)))
+        return st
 
     def set_issuer_autoregister(self, on: bool):
         self._ck(self._lib.ctmr_set_issuer_autoregister(self._h, int(bool(on))))
@@ -411,20 +424,6 @@ class Engine:
             out.append(raw[o + 4:o + 4 + l])
             o += 4 + l
         return out
-
-    def exchange_insert(self, d_keys, n_keys, d_flags) -> int:
-        out = C.c_uint64()
-        self._ck(self._lib.ctmr_exchange_insert_device(self._h, C.c_void_p(d_keys), n_keys,
-                                                       C.c_void_p(d_flags), C.byref(out)))
-        return out.value
-
-    def exchange_apply(self, d_records, n, d_keys_sent, d_flags, n_keys, d_new_idx=0) -> N.BatchStats:
-        st = N.BatchStats()
-        self._ck(self._lib.ctmr_exchange_apply_device(
-            self._h, C.c_void_p(d_records), n, C.c_void_p(d_keys_sent) if n_keys else None,
-            C.c_void_p(d_flags) if n_keys else None, n_keys,
-            C.c_void_p(d_new_idx) if d_new_idx else None, C.byref(st)))
-        return st
 
     # ---- cross-GPU global dedup, Bloom pre-filter variant (ctmr.h: ctmr_bloom_*), device pointers as ints
     def bloom_config(self, bits: int, d_words=0):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTMR_ABI_VERSION 3
+#define CTMR_ABI_VERSION 4
 
 enum {
   CTMR_OK = 0,
@@ -233,34 +233,55 @@ int ctmr_issuer_counts_device(ctmr_engine* e, void** d_counts, uint32_t* n);
 /* Drop every known certificate (table, pair counts, counters, host-side sets keep keys). */
 int ctmr_reset_known(ctmr_engine* e);
 
-/* ---- cross-GPU global dedup: replaces the shared Redis set service
- *      (storage/rediscache.go:57-65) between shards.  owner(key) = hash(key) mod world.
- *   export: runs the map into d_records and writes one 64-byte key record per PASS entry into
- *           d_keys_out (capacity n), partitioned by owner, ascending log index inside a partition;
- *           counts[w] (host) = keys for owner w.
- *   insert: the owner inserts the key records it received — concatenated in sender-rank order, which
- *           is global log order for contiguous log-index shards — and writes one byte per key:
- *           1 = was unknown.  Bumps the owner's per-issuer counters.
- *   apply:  the sender sets CTMR_FL_WAS_UNKNOWN in its records from the returned bytes (same order
- *           as d_keys_sent), compacts new_idx, fills stats.
- *   Every rank must have registered the same issuers in the same order.  Serials longer than
- *   CTMR_MAX_SERIAL are not exchanged (they stay shard-local on the host side). ---- */
-int ctmr_exchange_export_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
-                                const uint32_t* d_issuer_idx, const uint8_t* d_entry_type, uint64_t n,
-                                ctmr_record* d_records, uint32_t world, void* d_keys_out,
-                                uint64_t* counts);
-int ctmr_exchange_insert_device(ctmr_engine* e, const void* d_keys, uint64_t n_keys, uint8_t* d_flags,
-                                uint64_t* n_new);
-int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, const void* d_keys_sent,
-                               const uint8_t* d_flags, uint64_t n_keys, uint64_t* d_new_idx,
-                               ctmr_batch_stats* stats);
+/* One rank's input of a multi-GPU round (ctmr_group_map_batch, ctmr_xchg_map_device): device pointers on that rank's
+ * GPU, as ctmr_map_batch_device takes them; d_ends != NULL: an entry view (d_offsets = cert_start, d_ends = cert_end,
+ * blob_bytes set).  order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown). */
+typedef struct {
+  const uint8_t* d_payload;
+  const uint64_t* d_offsets;
+  const uint64_t* d_ends;       /* NULL = packed batch */
+  const uint32_t* d_issuer_idx;
+  const uint8_t* d_entry_type;  /* may be NULL */
+  uint64_t n;
+  uint64_t blob_bytes;          /* entry view only */
+  uint64_t order_base;
+  ctmr_record* d_records;
+  uint64_t* d_new_idx;          /* may be NULL */
+} ctmr_shard;
+
+/* ---- cross-GPU global dedup, owner-computes: replaces the shared Redis set service
+ *      (storage/rediscache.go:57-65: one SADD answers "was new" for every ct-fetch process) between shards.
+ *      owner(key) = a hash of the key → [0, world).  One round on one rank is four calls; a multi-process host with its
+ *      own transport puts its two all-to-alls between them (ctmr_group_map_batch does exactly that, natively):
+ *   map:    maps the shard.  A key THIS rank owns is inserted on the spot by the map kernel (the fused path of
+ *           ctmr_map_batch_device); a key another rank owns leaves as a 32-byte record (serials of 21..40 octets: a
+ *           64-byte record).  ord_base = Σ n of the lower ranks in this round: the round's global log order, < 2^32 —
+ *           among entries that bring the same new key in one round the lowest order keeps WasUnknown, as in the reference
+ *           loop over one log.  counts32[w] (host) = 32-byte records for owner w; *n_long = 64-byte records (all owners).
+ *   keys:   writes the records, partitioned by owner, ascending order inside a partition, into the caller's send
+ *           buffers (Σ counts32 × 32 bytes; n_long × 64 bytes, counts64[w] of them for owner w).
+ *   insert: the owner inserts what it received (any order of senders) in the epoch of its own shard and writes one byte
+ *           per record: 1 = was unknown.  Bumps the owner's per-issuer counters (a key is counted where it is stored).
+ *           Must be called once per round on every rank, received records or not: it also settles the rank's own shard.
+ *   apply:  the sender's records left the map with CTMR_FL_WAS_UNKNOWN set; the returned bytes (same order as the
+ *           records were sent) take it away from the entries whose key was known; compacts d_new_idx, fills stats.
+ *   Every rank must have registered the same issuers in the same order.  Serials longer than CTMR_MAX_SERIAL are not
+ *   exchanged (they stay shard-local on the host side).  shard.d_records is required. ---- */
+int ctmr_xchg_map_device(ctmr_engine* e, const ctmr_shard* shard, uint32_t world, uint32_t rank, uint32_t ord_base,
+                         uint64_t* counts32, uint64_t* n_long);
+int ctmr_xchg_keys_device(ctmr_engine* e, void* d_keys32_out, void* d_keys64_out, uint64_t* counts64);
+int ctmr_xchg_insert_device(ctmr_engine* e, const void* d_keys32, uint64_t n32, const void* d_keys64, uint64_t n64,
+                            uint8_t* d_flags32, uint8_t* d_flags64);
+int ctmr_xchg_apply_device(ctmr_engine* e, const void* d_sent32, const uint8_t* d_flags32, uint64_t n32,
+                           const void* d_sent64, const uint8_t* d_flags64, uint64_t n64, ctmr_batch_stats* stats);
 
 /* ---- cross-GPU global dedup, Bloom pre-filter variant (the "all-gather of per-GPU Bloom fingerprints" of
  *      BASELINE.json's north_star) — exact, same results as the owner-computes exchange above.
  *      Every rank keeps its own known-certificate table (plain ctmr_map_*_device calls) plus a cumulative Bloom
  *      filter of the keys it found locally new.  One round = one map call per rank, then:
- *   add:    sets the filter bits of the batch's CTMR_FL_WAS_UNKNOWN keys (ctmr_set_insert sets the bits of its member
- *           too, once a filter is configured: every key a rank holds is in its filter).  The host all-gathers the filters
+ *   add:    makes sure the filter holds the batch's CTMR_FL_WAS_UNKNOWN keys and opens the round.  Since ABI v4 an engine
+ *           with a filter adds to it INSIDE the map kernel, so for the batch the engine mapped last this costs nothing
+ *           (ctmr_set_insert sets the bits of its member too: every key a rank holds is in its filter).  The host all-gathers the filters
  *           (ctmr_bloom_device gives the pointer; n_words × 8 bytes per rank, rank-major in the gathered buffer).
  *   probe:  tests the batch's locally-new keys against the OTHER ranks' filters and writes one 64-byte key record per
  *           (key, peer whose filter holds it) into d_keys_out, partitioned by peer, ascending log index inside a
@@ -274,7 +295,8 @@ int ctmr_exchange_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t 
  *   apply:  the asker clears CTMR_FL_WAS_UNKNOWN of every flagged entry (once per entry), takes it out of its
  *           per-issuer count, marks the key's slot as counted elsewhere (it stays known for dedup, but is left out of
  *           SetCardinality / SetList / the per-issuer counts, so that sums over ranks are the global values),
- *           compacts new_idx and fills stats.
+ *           compacts new_idx and fills stats.  d_records must be the records of this engine's LAST map call (the
+ *           round continues it: only the entries that lose the flag are touched).
  *   d_ends NULL = packed batch (d_offsets has n+1 entries); otherwise entry-view ranges (ctmr_entry_view).
  *   d_records NULL = the engine's own records of the last map call.  Same issuers in the same order on every rank.
  *   Serials longer than CTMR_MAX_SERIAL stay shard-local on the host side, as above. ---- */
@@ -309,36 +331,34 @@ int ctmr_bloom_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, 
  *      Engines must have registered the same issuers in the same order (key records carry canonical issuer indices);
  *      they stay usable on their own; destroy the group before its engines.
  *   modes   CTMR_DEDUP_LOCAL  shard-local dedup only (exact when no key spans two shards: BASELINE config 4)
- *           CTMR_DEDUP_OWNER  owner-computes key exchange (ctmr_exchange_* above): export → all-to-all → owner insert
- *                             → flags back → apply.  Every key is stored once, on rank hash(key) mod world.
+ *           CTMR_DEDUP_OWNER  owner-computes key exchange (ctmr_xchg_* above): map (+ insert of the keys the rank owns)
+ *                             → key records all-to-all → owner insert → flags back → apply.  Every key is stored once,
+ *                             on its owner.
  *           CTMR_DEDUP_BLOOM  all-gather of per-GPU Bloom filters as an exact pre-filter (ctmr_bloom_* above; needs
  *                             ctmr_group_bloom_config): local insert → filter all-gather → probe → key records only to
  *                             the peers whose filter matched → exact lookup → flags back → apply
- *   shards  one ctmr_shard per LOCAL rank (rank order), device pointers on that rank's GPU, as ctmr_map_batch_device
- *           takes them; d_ends != NULL: an entry view (d_offsets = cert_start, d_ends = cert_end, blob_bytes set).
- *           order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown).
- *           d_records is required in the OWNER and BLOOM modes.  stats: one per local rank (may be NULL). ---- */
+ *   shards  one ctmr_shard (above) per LOCAL rank, rank order.  Ranks hold CONTIGUOUS log-index ranges in rank order
+ *           (rank r's entries all precede rank r+1's: ct-fetch's -offset/-limit split).  d_records is required in the
+ *           OWNER and BLOOM modes.  stats: one per local rank (may be NULL).
+ *   errors  a rank that fails inside a round keeps taking part in the round's collectives (its peers would block for
+ *           ever otherwise) and every rank's call returns the error at the end; the sets of a failed round are
+ *           unspecified — destroy the group. ---- */
 typedef struct ctmr_group ctmr_group;
 #define CTMR_GROUP_ID_BYTES 128
 enum { CTMR_DEDUP_LOCAL = 0, CTMR_DEDUP_OWNER = 1, CTMR_DEDUP_BLOOM = 2 };
 enum { CTMR_TRANSPORT_LOCAL = 0, CTMR_TRANSPORT_RCCL = 1 };
 typedef struct {
-  const uint8_t* d_payload;
-  const uint64_t* d_offsets;
-  const uint64_t* d_ends;       /* NULL = packed batch */
-  const uint32_t* d_issuer_idx;
-  const uint8_t* d_entry_type;  /* may be NULL */
-  uint64_t n;
-  uint64_t blob_bytes;          /* entry view only */
-  uint64_t order_base;
-  ctmr_record* d_records;
-  uint64_t* d_new_idx;          /* may be NULL */
-} ctmr_shard;
-typedef struct {
   uint32_t world, n_local, transport, first_local_rank;
   /* what the last ctmr_group_map_batch moved between ranks, summed over the local ranks */
-  uint64_t keys_sent, keys_received;   /* 64-byte key records to / from OTHER ranks */
+  uint64_t keys_sent, keys_received;   /* key records to / from OTHER ranks */
   uint64_t filter_bytes_received;      /* Bloom mode: the peers' filters, per local rank */
+  uint64_t wire_bytes_sent;            /* every byte handed to the transport for another rank: key records (32 B; 64 B for
+                                          Bloom candidates and 21..40-octet serials), flag bytes, filters */
+  /* wall time of the last round's phases on this process, ms (each phase ends with the ranks' streams drained):
+   * [0] map (+ the insert of locally owned keys, + filter add)  [1] key export / filter all-gather + probe
+   * [2] key records all-to-all  [3] owner insert / exact lookup (+ this shard's resolve)  [4] flags all-to-all
+   * [5] apply + NEW-list compaction  [6] the control collectives (counts, status) */
+  float ms_phase[8];
 } ctmr_group_stats;
 int ctmr_group_create_local(ctmr_engine* const* engines, uint32_t n, ctmr_group** out);
 int ctmr_group_unique_id(uint8_t id[CTMR_GROUP_ID_BYTES]);
@@ -456,10 +476,6 @@ int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need,
 #define CTMR_CHAIN0_EXACT 0
 #define CTMR_CHAIN0_TRUSTED_LOG 1
 int ctmr_set_chain0_match(ctmr_engine* e, int mode);
-/* ctmr_exchange_export_device over an entry view (raw get-entries batches; same contract). */
-int ctmr_exchange_export_view_device(ctmr_engine* e, const uint8_t* d_blob, uint64_t blob_bytes,
-                                     const ctmr_entry_view* d_view, uint64_t n, ctmr_record* d_records,
-                                     uint32_t world, void* d_keys_out, uint64_t* counts);
 /* ctmr_pem_encode_device for an entry view: PEM of the certificates d_idx[0..n_idx) names, straight out of the blob. */
 int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* d_view,
                                 const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,

@@ -100,3 +100,15 @@ def ossl_extract(der: bytes):
     if not _ossl.ossl_extract(der, len(der), C.byref(o)):
         return None
     return o
+
+
+def build_fake_rccl() -> str:
+    """The stand-in for librccl (fake_rccl.cpp: ranks as threads or processes on ONE GPU, bytes through POSIX shared
+    memory), built on demand; hand the path to the library through CTMR_RCCL_LIB."""
+    import subprocess
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    out = os.path.join(HERE, "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               src, "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-pthread", "-lrt"])
+    return out

@@ -64,7 +64,7 @@ def test_tag_collisions_take_the_synchronised_path():
         certs.append(D.cert(serial=b"\x01" + int(k).to_bytes(2, "big"), not_after=not_after,
                             issuer=D.name(D.rdn(3, b"Synth Issuer 000"))))
     certs += certs[:10]                                          # and real duplicates of colliding keys
-    # the numpy port really is the device's hash: the exchange export partitions keys by mixk(key_hash ^ c) % world
+    # the numpy port really is the device's hash: the owner-computes exchange partitions keys by a second hash of key_hash
     dev = torch.device("cuda:0")
     eng = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10)
     eng.add_issuers([issuer])
@@ -74,17 +74,23 @@ def test_tag_collisions_take_the_synchronised_path():
     d_off = torch.from_numpy(b0.offsets.astype(np.int64)).to(dev)
     d_iss = torch.zeros(b0.n, dtype=torch.int32, device=dev)
     d_rec = torch.zeros(b0.n * 32, dtype=torch.uint8, device=dev)
-    d_keys = torch.zeros(b0.n * 64, dtype=torch.uint8, device=dev)
-    eng.exchange_export(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), 0, b0.n, d_rec.data_ptr(), 16,
-                        d_keys.data_ptr())
-    recs = np.frombuffer(d_keys.cpu().numpy().tobytes(), dtype=np.dtype([("meta", "<u8"), ("s", "<u8", (5,)),
-                                                                         ("src", "<u4"), ("owner", "<u4"), ("pad", "<u8")]))
+    d_keys = torch.zeros(b0.n * 32, dtype=torch.uint8, device=dev)
+    from ct_mapreduce_amd.distributed import shard as make_shard
+    counts, n_long = eng.xchg_map(make_shard(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), 0, b0.n, d_rec.data_ptr()),
+                                  16, 15, 1000)
+    assert n_long == 0 and sum(counts) >= b0.n // 2 and counts[15] == 0     # rank 15's own keys are inserted, not exported
+    eng.xchg_keys(16, d_keys.data_ptr())
+    recs = np.frombuffer(d_keys.cpu().numpy().tobytes(), dtype=np.dtype([("meta", "<u8"), ("s0", "<u8"), ("s1", "<u8"),
+                                                                         ("s2", "<u4"), ("ord", "<u4")]))[:sum(counts)]
+    bounds = np.cumsum([0] + counts)
     with np.errstate(over="ignore"):
-        for r in recs:
-            assert r["meta"] == meta
-            hh = key_hash(U(r["meta"]), U(r["s"][0]))
-            assert int(mixk(hh ^ U(0x5bd1e995)) % U(16)) == int(r["owner"])
-            k = pairs[int(r["src"]) // 2][int(r["src"]) % 2]
+        for pos, r in enumerate(recs):
+            assert r["meta"] == meta and r["s1"] == 0 and r["s2"] == 0
+            hh = key_hash(U(r["meta"]), U(r["s0"]))
+            owner = int((int(mixk(hh ^ U(0x5bd1e995))) >> 32) * 16 >> 32)       # keyrec.h: key_owner_h
+            assert bounds[owner] <= pos < bounds[owner + 1] and owner != 15    # it lies in its owner's partition
+            src = int(r["ord"]) - 1000                                         # order in the round = ord_base + index
+            k = pairs[src // 2][src % 2]
             assert hh == h[k]                                    # and the collision search used the same values
     eng.close()
     for one_batch in (True, False):

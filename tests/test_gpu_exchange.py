@@ -256,3 +256,87 @@ def test_raw_shards_with_synchronised_issuer_registration():
         g.close()
         for e in engines:
             e.close()
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_serials_of_every_length_across_ranks(world, mode):
+    """Serial numbers of 1..45 octets, duplicated across shards.  The owner-computes exchange sends keys with serials of
+    up to 20 octets as 32-byte records and the rare 21..40-octet ones as 64-byte records on a path of their own; serials
+    beyond CTMR_MAX_SERIAL stay in the shard-local host-side set (documented).  Everything up to 40 octets must dedup
+    globally exactly like the single-stream oracle, whichever rank owns the key and whichever rank saw it first."""
+    import random
+    from ct_mapreduce_amd.engine import Batch
+    from tests import der as D
+    rng = random.Random(4242 + world)
+    issuer = synth.issuer(synth.config(n_issuers=1), 0)
+    name = D.name(D.rdn(3, b"Synth Issuer 000"))
+    uniq = []
+    for ln in list(range(1, 41)) * 6:                                # six keys of every length 1..40
+        s = bytes([rng.randrange(1, 0x7f)] + [rng.randrange(256) for _ in range(ln - 1)])
+        uniq.append(D.cert(serial=s, issuer=name, not_after=D.utctime("270101000000Z")))
+    certs = list(uniq)
+    certs += [uniq[rng.randrange(len(uniq))] for _ in range(len(uniq))]          # every key about once more, anywhere
+    rng.shuffle(certs)
+    whole = Batch.from_certs(certs, [0] * len(certs))
+    whole.payload = np.concatenate([whole.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    o, st, unk, eh = run_oracle(whole, [issuer], b"", True, 0)
+    assert (st == 0).all() and int(unk.sum()) == len(uniq)
+    engines = []
+    for _ in range(world):
+        e = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10)
+        e.add_issuers([issuer])
+        e.set_filter(b"", True, 0)
+        engines.append(e)
+    g = Group.local(engines)
+    if mode == "bloom":
+        g.bloom_config(1 << 14)
+    keep, shards, ranges = [], [], []
+    for r in range(world):
+        lo, hi = shard_range(len(certs), r, world)
+        b = Batch.from_certs(certs[lo:hi], [0] * (hi - lo))
+        t = to_dev(b)
+        keep.append(t)
+        shards.append(dev_shard(t, hi - lo, order_base=lo))
+        ranges.append((lo, hi))
+    stats = g.map_batch(mode, shards)
+    check_shards_against_oracle(keep, stats, ranges, st, unk)
+    assert g.total_count() == o.total_count() == len(uniq)
+    if mode == "owner":
+        assert g.info().wire_bytes_sent > 0
+    stats2 = g.map_batch(mode, shards)                              # replay: everything is known, wherever it lives
+    assert all(s.n_new == 0 for s in stats2)
+    g.close()
+    for e in engines:
+        e.close()
+
+
+def test_local_group_runs_its_ranks_concurrently():
+    """A LOCAL group's ranks run their phases on host threads of their own (round 2: one after the other, each ending in
+    a stream synchronisation — a single-process group over 8 devices mapped one GPU at a time).  Three engines on the one
+    device: the map kernels of the three ranks are in flight together, so the round takes clearly less than three times
+    one rank's round (each rank's kernel alone cannot fill the device at this size)."""
+    import time
+    cfg = synth.config(seed=61, n_issuers=16, dup_permille=100)
+    issuers = synth.issuers(cfg)
+    n = 4096                                                       # 64 workgroups per rank: a quarter of the CUs
+    def one_round(world, reps=30):
+        engines = [make_engine(issuers, table_slots=1 << 20) for _ in range(world)]
+        g = Group.local(engines)
+        keep = [to_dev(synth.host_batch(cfg, r * n, n)) for r in range(world)]
+        shards = [dev_shard(keep[r], n, order_base=r * n) for r in range(world)]
+        g.map_batch("local", shards)
+        best = 1e9
+        for _ in range(reps):
+            for e in engines:
+                e.reset_known()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g.map_batch("local", shards)
+            best = min(best, time.perf_counter() - t0)
+        g.close()
+        for e in engines:
+            e.close()
+        return best
+    t1, t3 = one_round(1), one_round(3)
+    assert t3 < 2.2 * t1, (t1, t3)

@@ -88,10 +88,8 @@ os._exit(0 if not hung else 3)
 
 
 def build_fake():
-    if not os.path.exists(FAKE_LIB) or os.path.getmtime(FAKE_LIB) < os.path.getmtime(FAKE_SRC):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                               FAKE_SRC, "-o", FAKE_LIB, "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
-    return FAKE_LIB
+    from tests.harness import build_fake_rccl
+    return build_fake_rccl()
 
 
 @pytest.mark.parametrize("mode", ["owner", "bloom", "local"])
