@@ -7,12 +7,20 @@ batch that is already resident in HBM.  The known-certificate table is cleared i
 timed step, so every step does the same "first sighting" work.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N                       # spawns its own N rank processes (one per GPU), rank 0 prints the line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # … or runs under a launcher's RANK/WORLD_SIZE
 
-N > 1: the entry stream is sharded by log-index range (rank r owns [r·E, (r+1)·E), weak scaling);
-the only data-path collective of the default mode is the RCCL all-reduce of the per-issuer count vector, issued by
-the library itself (ctmr_group_issuer_counts); torch.distributed only carries the 128-byte group id at start-up.
+N > 1 (BASELINE configs[3]): ONE batch of --total-entries (default 100 M) is split by log-index range — rank r owns
+[r·T/N, (r+1)·T/N), strong scaling — and the dedup is GLOBAL and exact by default (--dedup bloom: the all-gather of
+per-GPU Bloom filters as an exact pre-filter; --dedup owner: the owner-computes key exchange), what one Redis SADD gives
+the reference's processes (storage/rediscache.go:57-65; cmd/ct-fetch/ct-fetch.go:288-305).  --dedup local keeps per-shard
+sets and says so.  --entries E instead gives every GPU E entries (weak scaling).  Everything on the data path — shard
+maps, exchanges, the all-reduce of the per-issuer counts, barriers, the max of the step time — goes through the library's
+own RCCL group; the host only hands the 128-byte group id to its ranks (environment of the spawned processes, or one
+broadcast over the launcher's rendezvous).  At every N the run checks itself: Σ NEW and every entry's WasUnknown against
+the generator's duplicate structure, the all-reduced per-issuer counts against the generator, and a strided sample of
+every rank's shard (+ the out-of-shard sources of its duplicates) against the oracle.
 """
 import argparse
 import json
@@ -152,12 +160,13 @@ def parse_pmc_csv(outdir, counter, kernel_substr):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-def measure_traffic(args, entries, kernel_substr):
-    """HBM traffic of the map kernel, measured NOW on this build: re-executes this script on a smaller batch of the same
-    corpus under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace flags:
-    MI355X_MICROARCH.md §HBM / §rocprofv3 PMC slots) and returns bytes per certificate.  gfx950 correction: FETCH_SIZE
+def measure_traffic(args, entries, kernels, mode_args=()):
+    """HBM traffic of the named kernels, measured NOW on this build: re-executes this script on a smaller batch of the
+    same corpus under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace flags:
+    MI355X_MICROARCH.md §HBM / §rocprofv3 PMC slots) and returns bytes per ENTRY per kernel.  gfx950 correction: FETCH_SIZE
     tallies 128-byte requests at 64 bytes — x2 (calibrated on this access pattern too: scripts/calib_fetch.hip,
-    profiles/r01/s2); WRITE_SIZE as is.  Both are reported in KiB by rocprofv3."""
+    profiles/r01/s2); WRITE_SIZE as is.  Both are reported in KiB by rocprofv3.  `kernels`: name substrings; the first
+    one is the line's dominant kernel.  `mode_args`: what selects this line's mode in the child (--raw, --meta, …)."""
     import shutil
     import subprocess
     import tempfile
@@ -167,9 +176,9 @@ def measure_traffic(args, entries, kernel_substr):
     tmp = tempfile.mkdtemp(prefix="ctmr_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     env = dict(os.environ, CTMR_BENCH_CHILD="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
     child = [sys.executable, os.path.abspath(__file__), "--entries", str(entries), "--steps", "2", "--warmup", "1",
-             "--no-cpu", "--traffic", "off", "--issuers", str(args.issuers), "--variant", str(args.variant),
-             "--dup-permille", str(args.dup_permille)] + (["--mixed"] if args.mixed else [])
-    out = {"entries": entries}
+             "--no-cpu", "--traffic", "off", "--no-secondary", "--issuers", str(args.issuers), "--variant", str(args.variant),
+             "--dup-permille", str(args.dup_permille)] + list(mode_args)
+    out = {"entries": entries, "kernels": {}}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(tmp, c)
         try:
@@ -177,15 +186,21 @@ def measure_traffic(args, entries, kernel_substr):
                                cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
         except subprocess.TimeoutExpired:
             return None, f"rocprofv3 --pmc {c} pass timed out"
-        v, n = parse_pmc_csv(d, c, kernel_substr)
-        if v is None:
-            return None, f"rocprofv3 --pmc {c}: no rows for {kernel_substr} (rc {r.returncode}): " + r.stdout.decode(errors="replace")[-300:]
-        out[c + "_KB_per_launch"] = v
-        out["launches"] = n
+        for k in kernels:
+            v, n = parse_pmc_csv(d, c, k)
+            if v is None:
+                return None, f"rocprofv3 --pmc {c}: no rows for {k} (rc {r.returncode}): " + r.stdout.decode(errors="replace")[-300:]
+            out["kernels"].setdefault(k, {})[c + "_KB_per_launch"] = v
+            out["kernels"][k]["launches"] = n
     shutil.rmtree(tmp, ignore_errors=True)
-    out["fetch_bytes_per_cert"] = 2.0 * out["FETCH_SIZE_KB_per_launch"] * 1024.0 / entries
-    out["write_bytes_per_cert"] = out["WRITE_SIZE_KB_per_launch"] * 1024.0 / entries
-    out["traffic_bytes_per_cert"] = out["fetch_bytes_per_cert"] + out["write_bytes_per_cert"]
+    for k, t in out["kernels"].items():
+        t["fetch_bytes_per_cert"] = 2.0 * t["FETCH_SIZE_KB_per_launch"] * 1024.0 / entries
+        t["write_bytes_per_cert"] = t["WRITE_SIZE_KB_per_launch"] * 1024.0 / entries
+        t["traffic_bytes_per_cert"] = t["fetch_bytes_per_cert"] + t["write_bytes_per_cert"]
+    first = out["kernels"][kernels[0]]
+    for f in ("FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "launches", "fetch_bytes_per_cert", "write_bytes_per_cert",
+              "traffic_bytes_per_cert"):
+        out[f] = first[f]                     # the dominant kernel's figures at the top level (the r02 file format)
     out["lib_sha256_16"] = lib_hash()
     return out, None
 
@@ -209,15 +224,16 @@ def strided_sample(E, slices, per_slice):
     return [(k * (E // slices), k * (E // slices) + per_slice) for k in range(slices)]
 
 
-def gather_sample(d_off, d_pay, d_iss, d_et, ranges, extra_idx, extra_certs, pad, np):
+def gather_sample(d_off, d_pay, d_iss, d_et, ranges, extra_idx, extra_certs, pad, np, base=0):
     """One host batch = the sampled slices copied back from HBM + `extra` single entries (index → (der, issuer_idx,
-    entry_type)), all in ascending log-index order.  Returns (payload, offsets, issuer_idx, entry_type, global_index)."""
+    entry_type)), all in ascending log-index order.  `ranges` index the device arrays (a rank's shard); `base` = log
+    index of the shard's entry 0; `extra_idx` are log indices.  Returns (payload, offsets, issuer_idx, entry_type, log_index)."""
     pieces = []          # (first_index, payload u8, lens u64, iss u32, et u8)
     for lo, hi in ranges:
         offs = d_off[lo:hi + 1].cpu().numpy().astype(np.uint64)
         pay = d_pay[int(offs[0]):int(offs[-1])].cpu().numpy()
-        pieces.append((lo, pay, np.diff(offs), d_iss[lo:hi].cpu().numpy().astype(np.uint32),
-                       d_et[lo:hi].cpu().numpy().astype(np.uint8), np.arange(lo, hi, dtype=np.uint64)))
+        pieces.append((base + lo, pay, np.diff(offs), d_iss[lo:hi].cpu().numpy().astype(np.uint32),
+                       d_et[lo:hi].cpu().numpy().astype(np.uint8), np.arange(base + lo, base + hi, dtype=np.uint64)))
     for i, (der, iss, et) in zip(extra_idx, extra_certs):
         pieces.append((int(i), np.frombuffer(der, np.uint8), np.array([len(der)], np.uint64),
                        np.array([iss], np.uint32), np.array([et], np.uint8), np.array([i], np.uint64)))
@@ -255,19 +271,64 @@ def synth_is_dup_at(seed, idx, dup_permille, np):
         return (idx > 0) & ((h % np.uint64(1000)) < np.uint64(dup_permille))
 
 
-def share_group_id(dist, rank, make_id):
-    """Control path of `--gpus N`: rank 0 makes the 128-byte group id (ncclGetUniqueId through the library), every rank
-    receives it — the one thing the host carries between its processes; the data path never touches torch.distributed."""
+def _mix64_t(z, torch):
+    """_mix64 on int64 tensors (two's-complement wrap-around is the uint64 arithmetic; shifts made logical by masking)."""
+    def c(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+    z = z + c(0x9e3779b97f4a7c15)
+    z = (z ^ lsr(z, 30)) * c(0xbf58476d1ce4e5b9)
+    z = (z ^ lsr(z, 27)) * c(0x94d049bb133111eb)
+    return z ^ lsr(z, 31)
+
+
+def synth_is_dup_torch(seed, first, n, dup_permille, torch, dev):
+    """synth_is_dup for entries [first, first+n) as a bool tensor on `dev` (the numpy form takes seconds at 100 M entries)."""
+    import numpy as np
+    i = torch.arange(first, first + n, dtype=torch.int64, device=dev)
+    with np.errstate(over="ignore"):
+        base = int(_mix64(np.uint64(seed) ^ np.uint64((1 * 0xd6e8feb86659fd93) & 0xffffffffffffffff), np))
+    base = base - (1 << 64) if base >= (1 << 63) else base
+    h = _mix64_t(i + base, torch)
+    hi, lo = (h >> 32) & 0xffffffff, h & 0xffffffff            # h mod 1000 without an unsigned type
+    r = ((hi % 1000) * ((1 << 32) % 1000) + lo % 1000) % 1000
+    return (i > 0) & (r < dup_permille)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher environment: this process becomes the launcher.  It makes the group id
+    (ncclGetUniqueId through the library — the bootstrap listener lives in this process, which therefore stays until the
+    ranks are done), starts one copy of itself per rank with RANK / LOCAL_RANK / WORLD_SIZE and the id in the
+    environment, lets rank 0's line through and returns the worst exit code."""
+    import subprocess
+    from ct_mapreduce_amd.distributed import Group
+    gid = Group.unique_id()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), CTMR_GROUP_ID=gid.hex(),
+                   CTMR_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write(f"bench: rank exit codes {codes}\n")
+    return max(abs(c) for c in codes)
+
+
+def group_id_from_launcher(rank, make_id):
+    """Under a launcher (torchrun: RANK / WORLD_SIZE / MASTER_* in the environment): rank 0 makes the 128-byte group id
+    and one broadcast over the launcher's rendezvous (gloo, 127.0.0.1) hands it to the others — the only thing
+    torch.distributed carries; the process group is torn down right after."""
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("CTMR_DIST_BACKEND", "gloo"))
     box = [make_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
+    dist.destroy_process_group()
     return box[0]
-
-
-def max_over_ranks(dist, seconds, dev):
-    import torch
-    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
 
 
 def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers):
@@ -337,14 +398,55 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
     eng.close()
 
 
+def oracle_sample_check(np, torch, ctmr, synth, N, cfg, dup_permille, issuers, filt, now, dev, base, E, d_off, d_pay, d_iss,
+                        d_et, d_rec, slices, per):
+    """The oracle-checked sample of ONE rank's shard = the one-core cpu_baseline leg: `slices` equally spaced slices of
+    the shard, copied back from HBM, plus — generated on the host, byte-identical to the device generator
+    (tests/test_gpu_parity.py) — every entry outside them whose key a sampled duplicate repeats, WHEREVER in the log it
+    lies (mostly in other ranks' shards when the batch is split), all in log order.  The generator repeats keys of
+    NON-duplicate entries only (csrc/synth.h synth_src), so the oracle's WasUnknown over this closed set is the whole
+    batch's answer for every entry in it (tests/test_bench_helpers_cpu.py) — provided the dedup is global."""
+    ranges = strided_sample(E, slices, per)
+    per = ranges[0][1] - ranges[0][0]
+    in_sample = np.concatenate([np.arange(base + lo, base + hi, dtype=np.uint64) for lo, hi in ranges])
+    src, isdup = synth_src(cfg.seed, in_sample, dup_permille, np)
+    extra = np.setdiff1d(src[isdup], in_sample)
+    extra_certs = [synth.leaf(cfg, int(i)) for i in extra]
+    arrays = gather_sample(d_off, d_pay, d_iss, d_et, ranges, extra, extra_certs, N.PAYLOAD_PAD, np, base=base)
+    sample = len(arrays[4])
+    cpu, (ost, ounk) = cpu_baseline(arrays[:3], issuers, filt, now, sample, arrays[3])
+    cpu["sample"] = (f"{slices} equally spaced slices of {per} entries of the same synthetic batch, copied back from HBM, + the "
+                     f"{len(extra)} entries outside them whose keys sampled duplicates repeat; " + cpu["sample"])
+    mine = (arrays[4] >= base) & (arrays[4] < base + E)            # the rest are sources that live in other shards
+    gidx = torch.from_numpy((arrays[4][mine] - np.uint64(base)).astype(np.int64)).to(dev)
+    rec = d_rec.view(-1, 32)[gidx].cpu().numpy().reshape(-1).view(ctmr.engine.RECORD_DTYPE)
+    gnew = (rec["flags"] & 2) != 0
+    ost_m, ounk_m = ost[mine], ounk[mine]
+    info = {"entries": int(sample), "entries_of_this_shard": int(mine.sum()), "slices": slices, "entries_per_slice": per,
+            "sources_outside_the_slices": int(len(extra)),
+            "pass": int((ost_m == 0).sum()), "was_unknown": int((ounk_m != 0).sum()),
+            "known_duplicates": int(((ost_m == 0) & (ounk_m == 0)).sum()),
+            "status_mismatches": int((rec["status"] != ost_m).sum()),
+            "was_unknown_mismatches": int((gnew != (ounk_m != 0)).sum())}
+    return cpu, info, arrays, ranges
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--entries", type=int, default=int(os.environ.get("CTMR_BENCH_ENTRIES", 100_000_000)),
-                    help="entries per GPU (weak scaling); default = BASELINE's 100M-entry batch "
-                         "(≈152 GB of DER resident in HBM); halved automatically if it does not fit")
+    ap.add_argument("--total-entries", type=int, default=0,
+                    help="ONE batch of this many entries split over the GPUs by log-index range (strong scaling; BASELINE "
+                         "configs[3]).  Default: BASELINE's 100M-entry batch (≈152 GB of DER; halved automatically if a "
+                         "shard does not fit its GPU)")
+    ap.add_argument("--entries", type=int, default=0,
+                    help="entries PER GPU instead (weak scaling); at --gpus 1 the same thing as --total-entries")
+    ap.add_argument("--dedup", default="auto", choices=["auto", "bloom", "owner", "local"],
+                    help="N > 1: how the known-certificate sets of the ranks relate.  bloom (auto): global, exact — all-gather "
+                         "of per-GPU Bloom filters as a pre-filter + exact lookups; owner: global, exact — owner-computes key "
+                         "exchange; local: per-shard sets (NOT the reference's one set: duplicates across shards are counted "
+                         "twice — the line says so)")
     ap.add_argument("--issuers", type=int, default=256)
     ap.add_argument("--table-slots-log2", type=int, default=0,
                     help="known-certificate table size (default: the power of two >= 2 x entries: load 0.35-0.47 when full)")
@@ -371,18 +473,17 @@ def main():
     ap.add_argument("--mixed", action="store_true",
                     help="the mixed synthetic corpus (half EC P-256 keys, 40%% OV-like subjects of 120-260 bytes, longer "
                          "issuer names, one GeneralizedTime in four) instead of the SURVEY §8(d) corpus: how the map "
-                         "behaves when the lanes of a wave do not walk identical layouts; not the default workload")
+                         "behaves when the lanes of a wave do not walk identical layouts.  The default run reports it as "
+                         "secondary.mixed; this flag makes it the line's workload")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary.mixed leg of the default run")
     ap.add_argument("--pem", action="store_true",
                     help="also time the PEM write-back kernels (k_pem_len + scan + k_pem_encode, SURVEY §8(f) N1) over "
                          "the first 16M entries of the NEW list")
     ap.add_argument("--global-dedup", nargs="?", const="owner", default=None, choices=["owner", "bloom"],
-                    help="BASELINE config 5's cross-GPU form instead of the shard-local reduce.  owner (default): the "
-                         "owner-computes key exchange (distributed.run_global_dedup: export → all-to-all over RCCL → "
-                         "owner insert → flags back → apply); at N=1 the exchange is local and this measures the three "
-                         "exchange-mode kernels.  bloom: the north_star's all-gather of per-GPU Bloom filters as an exact "
-                         "pre-filter (distributed.run_bloom_dedup: local insert → filter all-gather → probe → exact "
-                         "lookup at the peers whose filter matched → apply); at N=1 this measures the add/probe/apply "
-                         "kernels on top of the ordinary reduce")
+                    help="BASELINE config 5's corpus (10%% duplicates, anywhere earlier in the stream) through the group "
+                         "layer's exact modes even at N = 1, where there is no peer and the line prices what each mode "
+                         "costs a rank on top of the plain reduce (phase times and bytes handed to the transport in "
+                         "`exchange`).  At N > 1 the same as --dedup owner|bloom with that corpus")
     ap.add_argument("--raw", action="store_true",
                     help="feed raw get-entries blobs (leaf_input ‖ extra_data, ≈3.06 KB per entry): adds the "
                          "LogEntryFromLeaf decode and the Chain[0] → issuer match in front of the map (SURVEY §8(f) N2); "
@@ -393,8 +494,8 @@ def main():
                          "(include/ctmr.h); the default compares every byte of every entry's Chain[0]")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off"],
                     help="auto (default, N=1 only): after the timed steps re-execute this script on --traffic-entries "
-                         "entries of the same corpus under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate "
-                         "passes) and report the map kernel's measured HBM traffic; off: roofline.traffic = null")
+                         "entries of the same corpus and mode under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
+                         "(separate passes) and report the measured HBM traffic of the line's kernels; off: roofline.traffic = null")
     ap.add_argument("--traffic-entries", type=int, default=10_000_000)
     ap.add_argument("--traffic-file", default=None,
                     help="use this earlier measurement (the JSON this script writes to gpurun_out/traffic_map.json) instead "
@@ -404,46 +505,62 @@ def main():
                          "batch — so that the DEFER / duplicate paths of the insert run at headline scale (default 2 %%)")
     ap.add_argument("--sample-slices", type=int, default=60,
                     help="the oracle-checked sample (= the one-core cpu_baseline leg) is this many equally spaced slices "
-                         "of the batch …")
+                         "of every rank's shard …")
     ap.add_argument("--sample-per-slice", type=int, default=0,
-                    help="… of this many entries each (default: --cpu-sample / --sample-slices), plus every entry "
+                    help="… of this many entries each (default: --cpu-sample / ranks / --sample-slices), plus every entry "
                          "outside the slices whose key a sampled duplicate repeats")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: become the launcher
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
     import ct_mapreduce_amd as ctmr
     from ct_mapreduce_amd import synth, _native as N
+    from ct_mapreduce_amd.distributed import Group, shard as make_shard, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local %= max(torch.cuda.device_count(), 1)      # (CTMR_DIST_BACKEND=gloo lets two test ranks share one GPU)
+    local %= max(torch.cuda.device_count(), 1)      # (the tests let several ranks share the one reachable GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if args.gpus > 1 or world > 1:
-        # CONTROL path only: torch.distributed (gloo over 127.0.0.1, the launcher's rendezvous) carries the 128-byte
-        # group id from rank 0 to the others.  Everything on the data path — shard maps, key exchange, Bloom
+    gid = None
+    if world > 1:
+        # CONTROL path: the 128-byte group id reaches the ranks through the environment (spawned by this script) or by
+        # one broadcast over the launcher's rendezvous.  Everything on the data path — shard maps, key exchange, Bloom
         # all-gather, the all-reduce of the per-issuer counts, the barriers and the max-over-ranks of the step time —
         # goes through the library's own RCCL group (ctmr_group_*, csrc/engine/group.inc).
-        import torch.distributed as dist
-        dist.init_process_group(os.environ.get("CTMR_DIST_BACKEND", "gloo"))
-        world, rank = dist.get_world_size(), dist.get_rank()
-    else:
-        dist = None
+        gid = bytes.fromhex(os.environ["CTMR_GROUP_ID"]) if os.environ.get("CTMR_GROUP_ID") else \
+            group_id_from_launcher(rank, Group.unique_id)
 
     filt = b"Synth Issuer 0,Synth Issuer 1"      # BASELINE config 3: passes issuers 000-199
-    # the global-dedup modes run BASELINE config 5's corpus: 10 % of the entries repeat an earlier entry's key —
+    # the --global-dedup lines run BASELINE config 5's corpus: 10 % of the entries repeat an earlier entry's key —
     # anywhere earlier in the stream, i.e. usually in another rank's shard
     dup_permille = 100 if args.global_dedup else args.dup_permille
+    mode = args.global_dedup or (args.dedup if args.dedup != "auto" else ("bloom" if world > 1 else "plain"))
+    if world == 1 and not args.global_dedup and args.dedup in ("auto", "local"):
+        mode = "plain"                            # one rank: its own set IS the global set — no group layer in the way
     cfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
                        ca_permille=10, expired_permille=10, profile=1 if args.mixed else 0)
     now = synth.BASE_TIME
     issuers = synth.issuers(cfg)
 
+    if args.stream:
+        return run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers)
+
+    # ---- the workload: one batch split by log index (strong), or E entries per GPU (weak)
+    env_total = int(os.environ.get("CTMR_BENCH_ENTRIES", 0))
+    weak = args.entries > 0 and world > 1
+    total = (args.entries * world) if args.entries else (args.total_entries or env_total or 100_000_000)
+    if args.raw and not (args.entries or args.total_entries or env_total):
+        total = 40_000_000          # ≈122 GB of raw entries + the table
+
     raw_view = {}
 
-    def setup_raw(E):
+    def setup_raw(first, E, this_cfg):
         eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
                           map_variant=args.variant, profile=True, collect_meta=args.meta)
         eng.set_filter(filt, False, now)              # no add_issuers: Chain[0] certificates register themselves
@@ -451,11 +568,10 @@ def main():
             # … in shard order, so issuer index k would name different issuers on different ranks and the count
             # all-reduce would add apples to oranges: with several ranks, register the same list up front
             eng.add_issuers(issuers)
-        first = rank * E
         d_bounds = torch.empty(2 * E + 1, dtype=torch.int64, device=dev)
-        total = eng.synth_entries_device(cfg, first, E, d_bounds.data_ptr(), 0, 0)
-        d_blob = torch.empty(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
-        eng.synth_entries_device(cfg, first, E, d_bounds.data_ptr(), d_blob.data_ptr(), d_blob.numel())
+        nbytes = eng.synth_entries_device(this_cfg, first, E, d_bounds.data_ptr(), 0, 0)
+        d_blob = torch.empty(nbytes + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+        eng.synth_entries_device(this_cfg, first, E, d_bounds.data_ptr(), d_blob.data_ptr(), d_blob.numel())
         d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         d_new = torch.empty(E, dtype=torch.int64, device=dev)
         d_ts = torch.empty(E, dtype=torch.int64, device=dev)
@@ -464,77 +580,79 @@ def main():
         raw_view["end"] = torch.empty(E, dtype=torch.int64, device=dev)
         raw_view["iss"] = torch.empty(E, dtype=torch.int32, device=dev)
         raw_view["et"] = torch.empty(E, dtype=torch.uint8, device=dev)
+        raw_view["c0len"] = torch.empty(E, dtype=torch.int32, device=dev)
+        raw_view["c0start"] = torch.empty(E, dtype=torch.int64, device=dev)
         raw_view["view"] = N.EntryView(cert_start=raw_view["start"].data_ptr(), cert_end=raw_view["end"].data_ptr(),
                                        issuer_idx=raw_view["iss"].data_ptr(), entry_type=raw_view["et"].data_ptr(),
-                                       timestamp=d_ts.data_ptr(), chain0_start=None, chain0_len=None)
-        raw_view["blob_bytes"] = total
+                                       timestamp=d_ts.data_ptr(), chain0_start=raw_view["c0start"].data_ptr(),
+                                       chain0_len=raw_view["c0len"].data_ptr())
+        raw_view["blob_bytes"] = nbytes
         torch.cuda.synchronize()
         return eng, d_bounds, d_blob, d_ts, None, d_rec, d_new
 
-    def setup(E):
+    def setup(first, E, this_cfg):
         if args.raw:
-            return setup_raw(E)
+            return setup_raw(first, E, this_cfg)
         eng = ctmr.Engine(device=local, table_slots=(1 << args.table_slots_log2) if args.table_slots_log2 else pow2_at_least(int(E * 2)),
                           pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
                           lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
-        eng.add_issuers(issuers)
+        eng.add_issuers(synth.issuers(this_cfg))
         eng.set_filter(filt, False, now)
-        # ---- synthetic shard [rank·E, (rank+1)·E), generated directly in HBM
-        first = rank * E
+        # ---- synthetic shard [first, first + E), generated directly in HBM
         d_off = torch.empty(E + 1, dtype=torch.int64, device=dev)
-        total = eng.synth_device(cfg, first, E, d_off.data_ptr(), 0, 0, 0, 0)
-        d_pay = torch.empty(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+        nbytes = eng.synth_device(this_cfg, first, E, d_off.data_ptr(), 0, 0, 0, 0)
+        d_pay = torch.empty(nbytes + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
         d_iss = torch.empty(E, dtype=torch.int32, device=dev)
         d_et = torch.empty(E, dtype=torch.uint8, device=dev)
-        eng.synth_device(cfg, first, E, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(),
+        eng.synth_device(this_cfg, first, E, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(),
                          d_iss.data_ptr(), d_et.data_ptr())
         d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         d_new = torch.empty(E, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         return eng, d_off, d_pay, d_iss, d_et, d_rec, d_new
 
-    if args.stream:
-        return run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers)
-
-    E = args.entries
-    if args.raw and "CTMR_BENCH_ENTRIES" not in os.environ and E == 100_000_000:
-        E = 40_000_000          # ≈122 GB of raw entries + the table
     t_gen = time.perf_counter()
     while True:
+        first, hi = (rank * args.entries, (rank + 1) * args.entries) if weak else shard_range(total, rank, world)
+        E = hi - first
+        fits = 1
         try:
-            eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(E)
-            break
-        except (ctmr.CtmrError, RuntimeError) as ex:   # does not fit in this GPU's HBM: halve
-            if E <= 1_000_000:
-                raise
-            sys.stderr.write(f"bench: {E} entries do not fit ({ex}); trying {E // 2}\n")
+            eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(first, E, cfg)
+        except (ctmr.CtmrError, RuntimeError) as ex:   # does not fit in this GPU's HBM
+            fits = 0
+            sys.stderr.write(f"bench: rank {rank}: {E} entries do not fit ({ex})\n")
             eng = d_off = d_pay = d_iss = d_et = d_rec = d_new = None
             torch.cuda.empty_cache()
-            E //= 2
+        if world == 1:
+            if fits:
+                break
+        else:
+            break       # several ranks agree below (the group does not exist yet: a failed rank reports and leaves)
+        if total <= 1_000_000:
+            raise SystemExit("bench: even 1 M entries do not fit")
+        total //= 2
+        if weak:
+            args.entries //= 2
+        sys.stderr.write(f"bench: trying {total} entries\n")
+    if eng is None:
+        raise SystemExit(f"bench: rank {rank}: the shard does not fit this GPU — use --total-entries / --entries")
     t_gen = time.perf_counter() - t_gen
     if args.raw and args.trusted_chain:
         eng.set_chain0_match(N.CHAIN0_TRUSTED_LOG)
-    from ct_mapreduce_amd.distributed import Group, shard as make_shard
     group = None
-    torch_fallback = None
-    if dist is not None:
-        try:
-            group = Group.rccl(eng, share_group_id(dist, rank, Group.unique_id), rank, world)
-        except Exception as ex:          # noqa: BLE001 — librccl missing / communicator refused: say so, keep measuring
-            # the count all-reduce, barriers and the max of the step time then go over torch.distributed (the control
-            # path's process group); the line says so in config.parallelism.  The global-dedup modes need the group.
-            if args.global_dedup:
-                raise
-            torch_fallback = f"{type(ex).__name__}: {ex}"
-            sys.stderr.write(f"bench: RCCL group not available ({torch_fallback}); collectives over torch.distributed\n")
-    elif args.global_dedup:
-        group = Group.local([eng])          # N = 1: the exchange is local, this measures each mode's kernels
-    if args.global_dedup == "bloom":
-        group.bloom_config(pow2_at_least(16 * E))       # ≈16 filter bits per key held
+    if world > 1:
+        group = Group.rccl(eng, gid, rank, world)
+    elif mode != "plain":
+        group = Group.local([eng])          # N = 1: no peer — this prices each mode's kernels on one rank
+    if mode == "bloom":
+        per_rank = max(E, (total + world - 1) // world)
+        group.bloom_config(pow2_at_least(16 * per_rank))       # ≈16 filter bits per key held; same size on every rank
     global_counts = [None]
     dstats = []
     meta_ms, meta_items = [], []
     d_items = torch.empty(32 * (1 << 22), dtype=torch.uint8, device=dev) if args.meta else None
+    phase_ms = np.zeros(8)
+    wire = [0, 0, 0]
 
     def step():
         eng.reset_known()
@@ -544,10 +662,13 @@ def main():
                                      d_new.data_ptr())
             dstats.append(ds)
         elif group is not None:
-            # one native call: this rank's shard map + (owner | Bloom) exchange over RCCL (copies when N = 1)
-            st = group.map_batch(args.global_dedup or "local",
+            # one native call: this rank's shard map + (owner | Bloom) exchange over RCCL (nothing to exchange when N = 1)
+            st = group.map_batch("local" if mode == "local" else mode,
                                  [make_shard(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
-                                             d_rec.data_ptr(), d_new.data_ptr(), order_base=rank * E)])[0]
+                                             d_rec.data_ptr(), d_new.data_ptr(), order_base=first)])[0]
+            gi = group.info()
+            phase_ms[:] += np.array(list(gi.ms_phase))
+            wire[0] += int(gi.wire_bytes_sent); wire[1] += int(gi.keys_sent); wire[2] += int(gi.filter_bytes_received)
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
                                       E, d_rec.data_ptr(), d_new.data_ptr())
@@ -561,21 +682,17 @@ def main():
         if group is not None and world > 1:
             # per-issuer unique counts merged over xGMI: ncclAllReduce inside ctmr_group_issuer_counts (2 KiB)
             global_counts[0] = group.issuer_counts(len(issuers))
-        elif torch_fallback and world > 1:
-            c = torch.from_numpy(eng.issuer_counts()[:len(issuers)].astype(np.int64))
-            dist.all_reduce(c)
-            global_counts[0] = c.numpy().astype(np.uint64)
         return st
 
     def barrier():
         if group is not None and world > 1:
             group.barrier()
-        elif torch_fallback and world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
+    phase_ms[:] = 0
+    wire[:] = [0, 0, 0]
     ms_map = []
     stats = None
     barrier()
@@ -587,17 +704,42 @@ def main():
     dt = time.perf_counter() - t0
     if group is not None and world > 1:
         dt = float(group.all_reduce_u64([int(dt * 1e9)], op_max=True)[0]) * 1e-9      # the slowest rank's time
-    elif torch_fallback and world > 1:
-        dt = max_over_ranks(dist, dt, torch.device("cpu"))
+    if world == 1:
+        global_counts[0] = eng.issuer_counts()[:len(issuers)]
 
-    # HBM traffic of the map kernel per launch: PMC counters can only be collected under rocprofv3, in their own
-    # passes — this script re-executes itself under the profiler on a smaller batch of the same corpus (bytes per
-    # certificate do not depend on the batch size: every launch streams ≫ the 256 MB of on-die cache) and scales.
+    # ---- the run checks itself, at every N ------------------------------------------------------------------------
+    # (a) every entry's WasUnknown and Σ NEW against the generator's duplicate structure: entry i repeats an EARLIER
+    #     entry's key iff synth_is_dup(i), wherever in the log that earlier entry lies — so, with a global set, a rank's
+    #     NEW entries are exactly its PASS ∧ ¬dup ones; (b) the all-reduced per-issuer vector against the same structure.
+    checks = None
+    if not args.raw:
+        recs = d_rec.view(-1, 32)[:E]
+        passed = recs[:, 0] == 0
+        is_new = (recs[:, 1] & 2) != 0
+        dupm = synth_is_dup_torch(cfg.seed, first, E, dup_permille, torch, dev)
+        want_new = passed & ~dupm
+        bad = int((is_new != want_new).sum().item()) + int(int(stats.n_new) != int(is_new.sum().item()))
+        want_counts = torch.bincount(d_iss[:E][want_new].to(torch.int64), minlength=len(issuers))[:len(issuers)].cpu().numpy().astype(np.uint64)
+        tot = np.concatenate([[bad, int(stats.n_new), int(want_new.sum().item())], want_counts]).astype(np.uint64)
+        if world > 1:
+            tot = group.all_reduce_u64(tot)
+        checks = {"entries_disagreeing_with_generator": int(tot[0]), "n_new_all_ranks": int(tot[1]),
+                  "n_new_expected_from_generator": int(tot[2]),
+                  "per_issuer_counts_match_generator": bool((np.asarray(global_counts[0], np.uint64) == tot[3:]).all()),
+                  "issuer_counts_all_ranks_sum": int(np.asarray(global_counts[0], np.uint64).sum())}
+
+    # HBM traffic of the line's kernels per launch: PMC counters can only be collected under rocprofv3, in their own
+    # passes — this script re-executes itself under the profiler on a smaller batch of the same corpus and mode (bytes
+    # per entry do not depend on the batch size: every launch streams ≫ the 256 MB of on-die cache) and scales.
     traffic = traffic_info = traffic_err = None
-    kname = MAP_KERNELS[args.variant or DEFAULT_VARIANT].split("<")[0]
+    vname = MAP_KERNELS[args.variant or DEFAULT_VARIANT]
+    kname = vname.split("<")[0]
+    kernels = [kname] + (["k_decode_match"] if args.raw else []) + (["k_meta_new"] if args.meta else [])
+    mode_args = (["--mixed"] if args.mixed else []) + (["--raw"] if args.raw else []) + (["--meta"] if args.meta else []) + \
+                (["--trusted-chain"] if args.trusted_chain else []) + (["--global-dedup", args.global_dedup] if args.global_dedup else [])
     plain = not (args.raw or args.global_dedup or args.meta)
-    if rank == 0 and world == 1 and plain and not os.environ.get("CTMR_BENCH_CHILD"):
-        if args.traffic_file:
+    if rank == 0 and world == 1 and not os.environ.get("CTMR_BENCH_CHILD"):
+        if args.traffic_file and plain:
             try:
                 t = json.load(open(args.traffic_file))
                 if t.get("lib_sha256_16") == lib_hash() and "traffic_bytes_per_cert" in t:
@@ -608,47 +750,57 @@ def main():
                 traffic_err = f"traffic file unreadable: {ex}"
         elif args.traffic == "auto":
             t_tr = time.perf_counter()
-            traffic_info, traffic_err = measure_traffic(args, min(E, args.traffic_entries), kname)
+            traffic_info, traffic_err = measure_traffic(args, min(E, args.traffic_entries), kernels, mode_args)
             if traffic_info:
                 traffic_info["source"] = "measured by this run (rocprofv3 --pmc, two passes)"
                 traffic_info["seconds"] = round(time.perf_counter() - t_tr, 1)
-                try:
-                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                    json.dump(traffic_info, open(os.path.join(ROOT, "gpurun_out", "traffic_map.json"), "w"))
-                except OSError:
-                    pass
+                if plain and not args.mixed:
+                    try:
+                        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                        json.dump(traffic_info, open(os.path.join(ROOT, "gpurun_out", "traffic_map.json"), "w"))
+                    except OSError:
+                        pass
         if traffic_info:
             traffic = traffic_info["traffic_bytes_per_cert"] * E
 
-    n_total = E * world
-    if args.global_dedup:   # no per-kernel events here: the map time is not separable
-        ms_map = [dt / args.steps * 1e3]
+    n_total = total if not weak else args.entries * world
     value = n_total * args.steps / dt
-    alg_bytes = stats.payload_bytes + ALG_BYTES_FIXED * E     # raw mode: payload_bytes is the whole blob — see "raw"
-    if (args.variant or DEFAULT_VARIANT) in FUSED:
+    # ALGORITHMIC bytes of the map kernel: Σ L_i + 45·E (+ 64 per PASS entry for the fused probe).  Raw
+    # mode: L_i is the certificate the map parses (cert_end − cert_start), not the blob — decode + match are priced below.
+    cert_bytes = int((raw_view["end"] - raw_view["start"]).sum().item()) if args.raw else int(stats.payload_bytes)
+    alg_bytes = cert_bytes + ALG_BYTES_FIXED * E
+    fused_variant = (args.variant or DEFAULT_VARIANT) in FUSED
+    if fused_variant:
         alg_bytes += ALG_BYTES_PROBE * int(stats.by_status[0])
     avg_ms = sum(ms_map) / len(ms_map)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    shard_note = (f"{n_total} entries in ONE batch split by log-index range over {world} GPUs" if not weak
+                  else f"{args.entries} entries per GPU x {world}")
+    parallelism = {"plain": "1 GPU, one known-certificate set",
+                   "local": f"log-index shards x{world}, PER-SHARD sets (NOT the reference's single set: a key that spans two shards "
+                            "is counted on both) + per-issuer count all-reduce over RCCL",
+                   "bloom": f"log-index shards x{world}, GLOBAL exact dedup: Bloom-filter all-gather pre-filter + exact lookups "
+                            "+ per-issuer count all-reduce, over RCCL inside the library",
+                   "owner": f"log-index shards x{world}, GLOBAL exact dedup: owner-computes key exchange (32-byte records) "
+                            "+ per-issuer count all-reduce, over RCCL inside the library"}[mode]
     out = {
         "metric": "certificates/sec whole-node + achieved HBM GB/s, 100M-entry synthetic CT batch",
         "value": value, "unit": "certificates/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{E} synthetic ~1.5 KB DER CT entries per GPU, {args.issuers} issuers (Zipf), "
-                               f"{dup_permille / 10:g} % duplicates of earlier entries, "
+        "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{shard_note}: synthetic ~1.5 KB DER CT entries, {args.issuers} issuers (Zipf), "
+                               f"{dup_permille / 10:g} % duplicates of earlier entries (anywhere in the log), "
                                "issuerCN prefix filter + known-certificate dedup + per-issuer unique counts "
                                "(BASELINE configs[2]/[3] shape)",
-                   "entries_per_gpu": E, "mean_der_bytes": stats.payload_bytes / E,
-                   "parallelism": f"log-index shards x{world}" + ("" if world == 1 else
-                                  " + per-issuer count all-reduce over RCCL inside the library (ctmr_group_issuer_counts)" if group is not None
-                                  else f" + count all-reduce over torch.distributed (RCCL group unavailable: {torch_fallback})"),
+                   "total_entries": n_total, "entries_on_rank0": E, "mean_der_bytes": cert_bytes / E,
+                   "dedup": mode, "parallelism": parallelism,
                    "map_variant": args.variant or DEFAULT_VARIANT,
                    "gen_seconds": round(t_gen, 2)},
         # roofline of the dominant kernel.  `frac` is PHYSICAL when the traffic was measured: HBM bytes the kernel moved
         # (PMC counters) ÷ its average launch time ÷ peak.  The walk skips key, SAN body and signature by length, so the
         # SURVEY §8(d) algorithmic figure (every certificate byte "read once") counts bytes that never move:
         # `frac_algorithmic` is kept beside it, never instead of it.
-        "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or DEFAULT_VARIANT],
+        "roofline": {"bound": "hbm", "kernel": vname if (mode == "plain" and not args.meta) else kname,
                      "achieved": (traffic if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9,
                      "achieved_basis": "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE) / avg launch time" if traffic
                                        else "ALGORITHMIC bytes / avg launch time (no PMC measurement in this run"
@@ -659,12 +811,16 @@ def main():
                      "frac_of_streaming_ceiling": (traffic / (avg_ms * 1e-3) / 1e9 / 6290.0) if traffic else None,
                      "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-                     "alg_bytes_formula": "sum(L_i) + 45*E" + (" + 64*PASS (table probe)" if (args.variant or DEFAULT_VARIANT) in FUSED else "")},
+                     "alg_bytes_formula": "sum(L_i) + 45*E" + (" + 64*PASS (table probe)" if fused_variant else "")
+                                          + (" with L_i = the certificate the map parses (not the blob)" if args.raw else "")},
         "kernel_ms": {"map": stats.ms_map, "insert": stats.ms_insert, "resolve": stats.ms_resolve,
                       "compact": stats.ms_compact, "total": stats.ms_total},
-        "result": {"n_new": int(stats.n_new), "n_dup": int(stats.n_dup), "by_status": [int(x) for x in stats.by_status],
-                   "issuer_counts_all_ranks_sum": int(global_counts[0].sum()) if global_counts[0] is not None else None},
+        "result": {"n_new": int(stats.n_new), "n_dup": int(stats.n_dup), "by_status": [int(x) for x in stats.by_status]},
     }
+    if checks is not None:
+        out["checks"] = checks
+    if out["roofline"]["frac"] > 1.0 or out["roofline"]["frac_algorithmic"] > 1.0:
+        out["roofline"]["invalid"] = "a fraction above 1 is a pricing error, not a result"
     if args.pem:
         m = min(int(stats.n_new), 16_000_000)
         d_po = torch.empty(m + 1, dtype=torch.int64, device=dev)
@@ -675,52 +831,42 @@ def main():
                                                   d_po.data_ptr())
             return eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_new.data_ptr(), m, d_pem_ptr, cap,
                                          d_po.data_ptr())
-        total = pem_call(0, 0)
-        d_pem = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+        pem_total = pem_call(0, 0)
+        d_pem = torch.empty(pem_total + 64, dtype=torch.uint8, device=dev)
         t_p = []
         for _ in range(3):
             t0p = time.perf_counter()
-            pem_call(d_pem.data_ptr(), total + 64)
+            pem_call(d_pem.data_ptr(), pem_total + 64)
             t_p.append(time.perf_counter() - t0p)
         import base64
         po = d_po[:3].cpu().numpy()
-        first = int(d_new[0].item())
+        first_new = int(d_new[0].item())
         starts_t = raw_view["start"] if args.raw else d_off[:-1]
         ends_t = raw_view["end"] if args.raw else d_off[1:]
-        der = d_pay[int(starts_t[first].item()):int(ends_t[first].item())].cpu().numpy().tobytes()
+        der = d_pay[int(starts_t[first_new].item()):int(ends_t[first_new].item())].cpu().numpy().tobytes()
         b64 = base64.b64encode(der)                  # pem.EncodeToMemory: 64-column base64 between the two marker lines
         want = (b"-----BEGIN CERTIFICATE-----\n" + b"".join(b64[k:k + 64] + b"\n" for k in range(0, len(b64), 64)) +
                 b"-----END CERTIFICATE-----\n")
         ok_pem = d_pem[int(po[0]):int(po[1])].cpu().numpy().tobytes() == want
         in_bytes = int((ends_t[d_new[:m]] - starts_t[d_new[:m]]).sum().item())
-        out["pem"] = {"certificates": m, "pem_bytes": int(total), "der_bytes": in_bytes, "ms_wall": min(t_p) * 1e3,
-                      "certs_per_s": m / min(t_p), "GBps_read_plus_written": (in_bytes + total) / min(t_p) / 1e9,
+        out["pem"] = {"certificates": m, "pem_bytes": int(pem_total), "der_bytes": in_bytes, "ms_wall": min(t_p) * 1e3,
+                      "certs_per_s": m / min(t_p), "GBps_read_plus_written": (in_bytes + pem_total) / min(t_p) / 1e9,
                       "first_block_matches_stdlib_base64": bool(ok_pem)}
-    if args.global_dedup:
-        out["config"]["workload"] = out["config"]["workload"].replace(
-            "(BASELINE configs[2]/[3] shape)", "— mostly in other ranks' shards "
-            "(BASELINE configs[4] corpus, one round)")
-        # exactness of the GLOBAL dedup against the generator's structure: entry i repeats an earlier entry's key iff
-        # synth_is_dup(i), wherever that earlier entry lives — so this rank's NEW entries are its PASS ∧ ¬dup ones
-        status = d_rec.view(-1, 32)[:E, 0].cpu().numpy()
-        is_new = (d_rec.view(-1, 32)[:E, 1].cpu().numpy() & 2) != 0
-        dup = synth_is_dup(cfg.seed, rank * E, E, dup_permille, np)
-        bad = int((is_new != ((status == 0) & ~dup)).sum()) + int(int(stats.n_new) != int(is_new.sum()))
-        bad, n_new_all = (int(v) for v in group.all_reduce_u64([bad, int(stats.n_new)]))
+    if group is not None:
+        # what the exact mode costs on top of the map: wall time of the round's phases on rank 0 (each ends with the
+        # stream drained) and what was handed to the transport for OTHER ranks, per step
+        names = ["map_and_local_insert", "key_export_or_filter_gather_and_probe", "key_records_all_to_all",
+                 "owner_insert_or_exact_lookup_and_resolve", "flags_all_to_all", "apply_and_compaction", "control_collectives"]
         gi = group.info()
-        out["result"]["global_dedup"] = {"mode": args.global_dedup, "n_new_all_ranks": n_new_all,
-                                         "entries_disagreeing_with_generator": bad,
-                                         "transport": "rccl" if gi.transport else "local (one rank: copies)",
-                                         "key_records_sent_by_rank0": int(gi.keys_sent),
-                                         "filter_bytes_received_by_rank0": int(gi.filter_bytes_received)}
-        out["roofline"]["note"] = "avg_launch_ms is the wall time of the whole step, not one kernel"
-        out["roofline"]["achieved"] = out["roofline"]["frac"] = None      # no single kernel to price: see kernel_ms of the default mode
-        if args.global_dedup == "bloom":
-            out["config"]["parallelism"] = f"log-index shards x{world} + Bloom-filter all-gather pre-filter + exact lookup (global dedup)"
-            out["roofline"]["kernel"] = "whole Bloom-mode step (map + insert + filter add + all-gather + probe + lookup + apply)"
-        else:
-            out["config"]["parallelism"] = f"log-index shards x{world} + owner-computes key exchange (global dedup)"
-            out["roofline"]["kernel"] = "whole exchange-mode step (export + all-to-all + owner insert + apply)"
+        out["exchange"] = {"mode": mode, "transport": "rccl" if gi.transport else "local (one rank: nothing to exchange)",
+                           "ms_phase_rank0": {nm: float(phase_ms[k]) / args.steps for k, nm in enumerate(names)},
+                           "wire_bytes_sent_by_rank0_per_step": wire[0] / args.steps,
+                           "key_records_sent_by_rank0_per_step": wire[1] / args.steps,
+                           "filter_bytes_received_by_rank0_per_step": wire[2] / args.steps,
+                           "key_record_bytes": {"owner": 32, "bloom": 64}.get(mode)}
+        if args.global_dedup:
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "(BASELINE configs[2]/[3] shape)", "(BASELINE configs[4] corpus, one round)")
     if args.fingerprint and not args.raw:
         d_dg = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         fp_ms = [eng.fingerprint_device(d_pay.data_ptr(), d_off.data_ptr(), 0, E, d_dg.data_ptr()) for _ in range(3)]
@@ -747,49 +893,58 @@ def main():
                        "note": "cold = first call (empty memo: every (issuer, expDate), DN and CRL DP is a first "
                                "sighting); warm = later steps (the known-certificate table is cleared every step, the "
                                "memo is not: every certificate is new again, nothing is a first sighting)"}
+        if traffic_info and "k_meta_new" in traffic_info["kernels"]:
+            tm = traffic_info["kernels"]["k_meta_new"]
+            out["meta"]["k_meta_new_traffic_bytes_per_new_certificate"] = tm["traffic_bytes_per_cert"] * min(E, args.traffic_entries) / max(int(stats.n_new) * min(E, args.traffic_entries) / E, 1)
     if args.raw:
         ds = dstats[-1]
-        out["config"]["workload"] = (f"{E} RAW get-entries (leaf_input+extra_data, {stats.payload_bytes / E:.0f} B/entry) per GPU: "
+        c0_bytes = int(raw_view["c0len"].to(torch.int64).sum().item())
+        # decode + match: bounds (16 B) and the leaf header (≈ 15 B) in, the view (37 B) out, and — exact mode — every
+        # byte of every Chain[0]; trusted-log mode reads 32 of them
+        dm_alg = (c0_bytes if not args.trusted_chain else 32 * E) + 68 * E
+        dm_ms = ds.ms_match + ds.ms_decode
+        out["config"]["workload"] = (f"{E} RAW get-entries (leaf_input+extra_data, {stats.payload_bytes / E:.0f} B/entry): "
                                      "LogEntryFromLeaf decode + Chain[0] issuer match + " + out["config"]["workload"])
         out["raw"] = {"blob_bytes": int(ds.blob_bytes), "ms_decode": ds.ms_decode, "ms_match": ds.ms_match,
                       "n_x509": int(ds.n_x509), "n_precert": int(ds.n_precert),
                       "issuers_registered_by_the_engine": eng.issuer_count(),
                       "chain0_match": "trusted-log (bytewise on first sighting per call, then length + first/last 16 B)"
                                       if args.trusted_chain else "exact (every byte of every Chain[0])",
-                      "note": "roofline.achieved counts the WHOLE blob as the map kernel's algorithmic bytes although it "
-                              "skips extra_data and the precert TBS; decode and the first match round are one kernel (ms_decode = 0, ms_match = both)"}
+                      "chain0_bytes": c0_bytes, "certificate_bytes_the_map_parses": cert_bytes,
+                      "note": "decode and the first match round are one kernel (ms_decode = 0, ms_match = both)"}
+        rdm = {"bound": "hbm", "kernel": "k_decode_match", "alg_bytes_per_launch": dm_alg, "avg_launch_ms": dm_ms,
+               "alg_bytes_formula": ("sum(chain0_len)" if not args.trusted_chain else "32*E") + " + 68*E (bounds 16 + leaf header 15 + view 37)",
+               "achieved_algorithmic": dm_alg / (dm_ms * 1e-3) / 1e9, "frac_algorithmic": dm_alg / (dm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None}
+        if traffic_info and "k_decode_match" in traffic_info["kernels"]:
+            td = traffic_info["kernels"]["k_decode_match"]
+            rdm["traffic"] = td["traffic_bytes_per_cert"] * E
+            rdm["traffic_bytes_per_entry"] = td["traffic_bytes_per_cert"]
+            rdm["achieved"] = rdm["traffic"] / (dm_ms * 1e-3) / 1e9
+            rdm["frac"] = rdm["achieved"] / HBM_PEAK_GBPS
+        out["roofline_decode_match"] = rdm
         out["kernel_ms"]["decode"] = ds.ms_decode
         out["kernel_ms"]["match"] = ds.ms_match
-    if rank == 0:
-        if world == 1 and not args.no_cpu and not args.raw:
-            # ---- the oracle-checked sample = the one-core cpu_baseline leg: equally spaced slices over the WHOLE batch,
-            # copied back from HBM, plus — generated on the host, byte-identical to the device generator
-            # (tests/test_gpu_parity.py) — every entry outside the slices whose key a sampled duplicate repeats, all in
-            # log order.  The generator repeats keys of NON-duplicate entries only (csrc/synth.h synth_src), so the
-            # oracle's WasUnknown over this closed set is the whole batch's answer for every entry in it.
-            per = args.sample_per_slice or max(1, min(args.cpu_sample, E) // args.sample_slices)
-            ranges = strided_sample(E, args.sample_slices, per)
-            in_sample = np.concatenate([np.arange(lo, hi, dtype=np.uint64) for lo, hi in ranges])
-            src, isdup = synth_src(cfg.seed, in_sample, dup_permille, np)
-            extra = np.setdiff1d(src[isdup], in_sample)
-            extra_certs = [synth.leaf(cfg, int(i)) for i in extra]
-            arrays = gather_sample(d_off, d_pay, d_iss, d_et, ranges, extra, extra_certs, N.PAYLOAD_PAD, np)
-            sample = len(arrays[4])
-            base, (ost, ounk) = cpu_baseline(arrays[:3], issuers, filt, now, sample, arrays[3])
-            base["sample"] = (f"{args.sample_slices} equally spaced slices of {per} entries of the same synthetic batch, copied "
-                              f"back from HBM, + the {len(extra)} entries outside them whose keys sampled duplicates repeat; "
-                              + base["sample"])
-            out["cpu_baseline"] = base
-            gidx = torch.from_numpy(arrays[4].astype(np.int64)).to(dev)
-            rec = d_rec.view(-1, 32)[gidx].cpu().numpy().reshape(-1).view(ctmr.engine.RECORD_DTYPE)
-            gnew = (rec["flags"] & 2) != 0
-            out["parity_vs_oracle_on_sample"] = bool((rec["status"] == ost).all() and (gnew == (ounk != 0)).all())
-            out["parity_sample"] = {"entries": int(sample), "slices": args.sample_slices, "entries_per_slice": per,
-                                    "sources_outside_the_slices": int(len(extra)),
-                                    "pass": int((ost == 0).sum()), "was_unknown": int((ounk != 0).sum()),
-                                    "known_duplicates": int(((ost == 0) & (ounk == 0)).sum()),
-                                    "status_mismatches": int((rec["status"] != ost).sum()),
-                                    "was_unknown_mismatches": int((gnew != (ounk != 0)).sum())}
+
+    # ---- oracle-checked sample of every rank's shard; the CPU baseline legs on rank 0 at N = 1
+    if not args.no_cpu and not args.raw:
+        per_rank_sample = max(min(args.cpu_sample, total) // world, 1)
+        per = args.sample_per_slice or max(1, min(per_rank_sample, E) // args.sample_slices)
+        base_cpu, pinfo, arrays, ranges = oracle_sample_check(np, torch, ctmr, synth, N, cfg, dup_permille, issuers, filt, now, dev,
+                                                              first, E, d_off, d_pay, d_iss, d_et, d_rec, args.sample_slices, per)
+        mism = np.array([pinfo["status_mismatches"], pinfo["was_unknown_mismatches"], pinfo["entries_of_this_shard"],
+                         pinfo["known_duplicates"]], np.uint64)
+        if world > 1:
+            mism = group.all_reduce_u64(mism)
+        out["parity_vs_oracle_on_sample"] = bool(mism[0] == 0 and mism[1] == 0)
+        out["parity_sample"] = dict(pinfo, ranks=world, status_mismatches_all_ranks=int(mism[0]),
+                                    was_unknown_mismatches_all_ranks=int(mism[1]), entries_checked_all_ranks=int(mism[2]),
+                                    known_duplicates_all_ranks=int(mism[3]),
+                                    note="rank 0's figures, then the sums over all ranks" if world > 1 else "")
+        if mode == "local" and world > 1:
+            out["parity_sample"]["note"] += "; per-shard sets: mismatches against the single-set oracle are expected"
+        if rank == 0 and world == 1:
+            out["cpu_baseline"] = base_cpu
             # what the walk must read of these certificates, against the measured traffic
             k = min(20000, per)
             offs_k = arrays[1][:k + 1]
@@ -830,13 +985,55 @@ def main():
                               f"shared Redis; not the Go binary), best of 3, {best[1]:.2f} s",
                     "host_cores_available": os.cpu_count(), "cgroup_cpu_quota": quota,
                     "pass_count_matches_gpu": bool(ok_mt),
-                    "one_core": {"value": base["value"], "sample": base["sample"]}}
+                    "one_core": {"value": base_cpu["value"], "sample": base_cpu["sample"]}}
+                del arrays_mt, pay_mt
+
+    # ---- secondary.mixed: the same line on the corpus that looks like a real log (the driver's record carries both)
+    if (rank == 0 and world == 1 and plain and not args.mixed and not args.no_secondary and not os.environ.get("CTMR_BENCH_CHILD")
+            and not args.variant and not args.pem and not args.fingerprint):
+        try:
+            eng.close()
+            eng = d_off = d_pay = d_iss = d_et = d_rec = d_new = None
+            torch.cuda.empty_cache()
+            mcfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
+                                ca_permille=10, expired_permille=10, profile=1)
+            eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(0, E, mcfg)
+            mms, mst = [], None
+            for k in range(1 + 3):
+                eng.reset_known()
+                torch.cuda.synchronize()
+                t0m = time.perf_counter()
+                mst = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
+                                           d_rec.data_ptr(), d_new.data_ptr())
+                if k:
+                    mms.append((time.perf_counter() - t0m, mst.ms_map))
+            m_step = sum(t for t, _ in mms) / len(mms)
+            m_map = sum(m for _, m in mms) / len(mms)
+            m_alg = int(mst.payload_bytes) + ALG_BYTES_FIXED * E + ALG_BYTES_PROBE * int(mst.by_status[0])
+            sec = {"workload": "the same batch on the MIXED corpus (half EC P-256 keys, 40 % OV-like subjects of 120-260 B, longer "
+                               "issuer names, one GeneralizedTime in four): the lanes of a wave do not walk identical layouts",
+                   "value": E / m_step, "unit": "certificates/sec", "ms_per_step": m_step * 1e3, "steps": len(mms),
+                   "note": "step = table clear + map_batch, host-timed like the headline (reset_known is asynchronous: the clear overlaps nothing else)",
+                   "map_ms": m_map, "mean_der_bytes": int(mst.payload_bytes) / E,
+                   "frac_algorithmic": m_alg / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "frac": None}
+            if args.traffic == "auto":
+                margs = argparse.Namespace(**vars(args))
+                mt, merr = measure_traffic(margs, min(E, args.traffic_entries), [kname], ["--mixed"])
+                if mt:
+                    sec["traffic_bytes_per_cert"] = mt["traffic_bytes_per_cert"]
+                    sec["traffic"] = mt["traffic_bytes_per_cert"] * E
+                    sec["frac"] = sec["traffic"] / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                else:
+                    sec["traffic_error"] = merr
+            out["secondary"] = {"mixed": sec}
+        except (ctmr.CtmrError, RuntimeError) as ex:
+            out["secondary"] = {"mixed": {"error": str(ex)}}
+    if rank == 0:
         print(json.dumps(out))
     if group is not None:
         group.close()
-    if dist is not None:
-        dist.destroy_process_group()
-    eng.close()
+    if eng is not None:
+        eng.close()
 
 
 if __name__ == "__main__":

@@ -86,3 +86,14 @@ def test_strided_sample_closure_gives_the_whole_batch_answer():
     assert (st_s == st_w[gidx]).all()
     assert (unk_s == unk_w[gidx]).all()
     assert ((st_s == 0) & (unk_s == 0)).sum() > 300              # known duplicates are in the sample
+
+
+def test_the_torch_form_of_the_duplicate_predicate_is_the_numpy_one():
+    """bench.py checks every entry's WasUnknown against the generator at every N; at 100 M entries the predicate is
+    evaluated on the device with int64 tensors (no unsigned 64-bit type in torch): it must be the numpy restatement."""
+    import torch
+    for seed, first, permille in ((20260925, 0, 20), (20260925, 123_456_789, 100), (7, 99_999_000, 150)):
+        n = 200_000
+        want = bench.synth_is_dup(seed, first, n, permille, np)
+        got = bench.synth_is_dup_torch(seed, first, n, permille, torch, torch.device("cpu")).numpy()
+        assert (got == want).all() and 0 < want.sum() < n
