@@ -203,7 +203,7 @@ struct ctmr_engine {
   int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
   uint64_t meta_precheck_n = 0;            // entries of the last map call whose ent[] carries the memo pre-check (0 = none)
   const uint32_t* meta_precheck_ent = nullptr;
-  std::unordered_map<unsigned long long, uint32_t> qh_first;  // candidate hash → first registered certificate with it
+  std::unordered_map<unsigned long long, uint32_t> qh_first;  // (upper half of the candidate hash, length) → table slot of the first registered certificate with it
   std::vector<std::string> pending_issuers;  // auto_register off: what the last decode found unregistered
   unsigned long long* d_pend = nullptr;    // PEND_SLOTS claim words
   uint32_t* d_unreg = nullptr;             // UNREG_CAP entry indices
@@ -354,17 +354,27 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
 // rebuilt on the GPU (k_rehash) into the smallest power of two that holds (live + incoming) at load <= 1/2 — larger
 // when members were added, the SAME size when the slots were eaten by tombstones (expiry sweeps, SetRemove), which a
 // rebuild leaves behind.  When even max_slots cannot hold the batch the call fails with CTMR_E_FULL BEFORE anything
-// was inserted: a batch is applied completely or not at all.
+// was inserted: a batch is applied completely or not at all.  CONSERVATIVE on purpose: `incoming` counts every entry of
+// the batch as a new key (which ones are duplicates is what the call is about to find out), so a capped table
+// (max_table_slots) may refuse a batch of mostly-known entries that would have fitted.
 int ensure_capacity(ctmr_engine* e, uint64_t incoming) {
   if ((e->occupied + incoming) * 4 <= e->nslots * 3) return CTMR_OK;
   // how many members are alive decides the new size: count them with the rebuild itself when tombstones may exist
   uint64_t want = pow2_at_least((e->occupied + incoming) * 2);
   if (want > e->max_slots) want = e->max_slots;
   if (want < e->nslots) want = e->nslots;
-  for (int attempt = 0; attempt < 2; attempt++) {
+  // the smallest table that still keeps the 3/4 bound: what to fall back to when the comfortable size (load 1/2, old and
+  // new table resident at once) does not fit the device
+  uint64_t least = pow2_at_least(((e->occupied + incoming) * 4 + 2) / 3);
+  if (least < e->nslots) least = e->nslots;
+  for (int attempt = 0; attempt < 3; attempt++) {
     Slot* nt = nullptr;
     if (hipMalloc(&nt, want * sizeof(Slot)) != hipSuccess) {
       (void)hipGetLastError();
+      if (want > least && least <= e->max_slots) {  // retry at the smallest size that holds the call
+        want = least;
+        continue;
+      }
       return fail(e, CTMR_E_NOMEM, "known-certificate table: cannot allocate %llu slots for the rebuild",
                   (unsigned long long)want);
     }

@@ -319,3 +319,60 @@ def test_trusted_log_never_trusts_registered_certificates_that_share_a_candidate
         eng.close()
     for f in ("status", "flags", "issuer_idx", "serial"):
         assert (recs[N.CHAIN0_EXACT][f] == recs[N.CHAIN0_TRUSTED_LOG][f]).all(), f
+
+
+def test_trusted_log_compares_bytes_when_two_registered_certificates_share_tag_and_length():
+    """Round-2 advisor finding: the trusted-log match accepts a candidate on the UPPER HALF of the candidate hash (what a
+    table word carries) + the length, but only certificates with equal FULL hashes were marked as twins.  Two registered
+    certificates of one length whose hashes agree in the upper 32 bits and in the table's home slot — found here by
+    search, with a numpy port of cert_quick_hash over the signature's last 16 bytes — must still be told apart: every
+    entry's Chain[0] is the SECOND one, the first one sits in front of it in the probe run."""
+    U = np.uint64
+
+    def qh_mix(z):
+        z = (z ^ (z >> U(30))) * U(0xbf58476d1ce4e5b9)
+        z = (z ^ (z >> U(27))) * U(0x94d049bb133111eb)
+        return z ^ (z >> U(31))
+
+    cfg = synth.config(seed=79, n_issuers=1)
+    iss = synth.issuer(cfg, 0)
+    L = len(iss)
+    rng = np.random.default_rng(20260923)
+    n = 1 << 22
+    tails = rng.integers(0, 1 << 32, (n, 4), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = qh_mix(U(0x9e3779b97f4a7c15) + U(L))
+        hd = np.frombuffer(iss[:16], "<u4").astype(np.uint64)
+        for k in range(4):
+            h = qh_mix(h ^ (hd[k] << U(1) | U(1)))
+        h = np.full(n, h, np.uint64)
+        for k in range(4):
+            h = qh_mix(h ^ (tails[:, k] << U(1)))
+    slots = 1024                                                   # idb_ht_size of an engine with max_issuers <= 256
+    sig = ((h >> U(32)) << U(10)) | (h & U(slots - 1))
+    order = np.argsort(sig, kind="stable")
+    same = np.nonzero(sig[order][1:] == sig[order][:-1])[0]
+    assert len(same) >= 1, "search space too small"
+    a, b = int(order[same[0]]), int(order[same[0] + 1])
+    assert h[a] != h[b]                                             # different hashes: round 2 saw no twins here
+    certs = [iss[:-16] + tails[k].astype("<u4").tobytes() for k in (a, b)]
+    assert certs[0] != certs[1] and len(certs[0]) == L
+    from tests import harness                                       # the numpy port IS the product's hash (host build)
+    harness.product_decode_entry(b"\0" * 16, b"\0" * 4)              # (builds and binds the harness library)
+    for k, c in zip((a, b), certs):
+        assert harness._entry.harness_quick_hash(c, len(c)) == int(h[k])
+    good = synth.host_entries(cfg, 0, 3000)
+    raw = RawEntries.from_pairs([(good.leaf_input(i), chain([certs[1]])) for i in range(good.n)])
+    raw.blob = np.concatenate([raw.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    recs = {}
+    for mode in (N.CHAIN0_EXACT, N.CHAIN0_TRUSTED_LOG):
+        eng = ctmr.Engine(device=0, table_slots=1 << 15, pair_slots=1 << 14, max_issuers=256)
+        eng.set_filter(b"", False, NOW)
+        eng.set_chain0_match(mode)
+        eng.add_issuers(certs)
+        res = eng.map_entries(raw)
+        recs[mode] = res.records
+        assert (res.records["issuer_idx"][res.records["status"] == 0] == 1).all(), mode   # the second certificate, bytewise
+        eng.close()
+    for f in ("status", "flags", "issuer_idx", "serial"):
+        assert (recs[N.CHAIN0_EXACT][f] == recs[N.CHAIN0_TRUSTED_LOG][f]).all(), f
