@@ -5,7 +5,6 @@
 // Redis for keys that are not known-certificate sets (crl::, issuer::, log:: …) plus the
 // issuer registry.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -201,6 +200,7 @@ struct ctmr_engine {
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
   bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
   int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
+  bool strict_leaf = false;                // ctmr_set_strict_leaf: parse the leaf TBSCertificate of precertificate entries
   uint64_t meta_precheck_n = 0;            // entries of the last map call whose ent[] carries the memo pre-check (0 = none)
   const uint32_t* meta_precheck_ent = nullptr;
   std::unordered_map<unsigned long long, uint32_t> qh_first;  // (upper half of the candidate hash, length) → table slot of the first registered certificate with it
@@ -325,6 +325,21 @@ int upload_filter(ctmr_engine* e) {
 }
 
 int ensure_capacity(ctmr_engine* e, uint64_t incoming);
+
+// in-place prefix sum of n u64 on the engine's stream (reduce.h: k_scan64_*); tile sums live in scratch buffer `which`
+int scan_u64(ctmr_engine* e, uint64_t* d_data, uint64_t n, bool inclusive, int which) {
+  if (n == 0) return CTMR_OK;
+  const uint64_t nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+  int r;
+  if ((r = ensure(e, which, nt * 8))) return r;
+  unsigned long long* d_sums = (unsigned long long*)e->d_scratch[which];
+  unsigned long long* d = (unsigned long long*)d_data;
+  hipLaunchKernelGGL(k_scan64_tiles, dim3((unsigned)nt), dim3(256), 0, e->stream, (const unsigned long long*)d, n, d_sums);
+  hipLaunchKernelGGL(k_scan64_sums, dim3(1), dim3(1024), 0, e->stream, d_sums, nt);
+  if (inclusive) hipLaunchKernelGGL((k_scan64_apply<true>), dim3((unsigned)nt), dim3(256), 0, e->stream, d, n, (const unsigned long long*)d_sums);
+  else hipLaunchKernelGGL((k_scan64_apply<false>), dim3((unsigned)nt), dim3(256), 0, e->stream, d, n, (const unsigned long long*)d_sums);
+  return CTMR_OK;
+}
 
 int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uint8_t* m, size_t n,
              int* out) {

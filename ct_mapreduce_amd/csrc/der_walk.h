@@ -396,7 +396,10 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
   if constexpr (has_note_issuer<R>::value) r.note_issuer(pos, len);
 }
 
-template <class R>
+// TBS_ONLY: the buffer is a bare TBSCertificate (what a precertificate entry's MerkleTreeLeaf carries) — what CT-go's
+// x509.ParseTBSCertificate accepts: the TBSCertificate SEQUENCE must fill the buffer ("trailing data" otherwise) and there
+// is no signatureAlgorithm / signatureValue behind it; everything inside is parsed as for a certificate.
+template <class R, bool TBS_ONLY = false>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv) {
   o.serial_off = o.serial_len = 0;
 #pragma unroll
@@ -412,12 +415,17 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
   uint32_t tag, cs, ce;
   r.touch(0, 256);
-  // Certificate ::= SEQUENCE filling the buffer exactly
-  rd_hdr(r, L, 0, L, ok, tag, cs, ce);
-  ok = ok & (tag == 0x30u) & (ce == L);
-  // tbsCertificate
-  rd_hdr(r, L, cs, L, ok, tag, cs, ce);
-  ok = ok & (tag == 0x30u);
+  if constexpr (!TBS_ONLY) {
+    // Certificate ::= SEQUENCE filling the buffer exactly
+    rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+    ok = ok & (tag == 0x30u) & (ce == L);
+    // tbsCertificate
+    rd_hdr(r, L, cs, L, ok, tag, cs, ce);
+    ok = ok & (tag == 0x30u);
+  } else {
+    rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+    ok = ok & (tag == 0x30u) & (ce == L);
+  }
   const uint32_t tbs_end = ce;
   uint32_t q = cs;
   // Version int `asn1:"optional,explicit,default:0,tag:0"`: an empty wrapper is an error ("zero length explicit tag
@@ -612,19 +620,25 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
       e = x_end;
     }
   }
-  // signatureAlgorithm, signatureValue BIT STRING (Go asn1 parseBitString); bytes behind them are ignored
-  const TailView<R> tv{r};
-  uint32_t sq;
-  alg_id(tv, L, tbs_end, L, ok, sq);
-  rd_hdr(tv, L, sq, L, ok, tag, cs, ce);
-  ok = ok & (tag == 0x03u);
-  bit_string_check(tv, L, cs, ce - cs, ok);
+  if constexpr (!TBS_ONLY) {
+    // signatureAlgorithm, signatureValue BIT STRING (Go asn1 parseBitString); bytes behind them are ignored
+    const TailView<R> tv{r};
+    uint32_t sq;
+    alg_id(tv, L, tbs_end, L, ok, sq);
+    rd_hdr(tv, L, sq, L, ok, tag, cs, ce);
+    ok = ok & (tag == 0x03u);
+    bit_string_check(tv, L, cs, ce - cs, ok);
+  }
   return ok;
 }
 
 template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr) {
   return filter ? walk_cert(r, L, o, true, *filter) : walk_cert(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
+}
+template <class R>
+CTMR_HD bool walk_tbs(R& r, uint32_t L, Walk& o) {
+  return walk_cert<R, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
 }
 
 }  // namespace ctmr

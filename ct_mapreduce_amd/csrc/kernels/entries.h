@@ -31,7 +31,45 @@ struct DecodeArgs {
   uint64_t* chain0_start;
   uint32_t* chain0_len;
   unsigned long long* counters;  // [0] x509 [1] precert [2] decode error [3] len(Chain) < 1
+  const uint8_t* leaf_bad;       // null, or per entry: the precertificate entry's leaf TBSCertificate does not parse
+                                 // (k_leaf_tbs_check, CTMR strict_leaf) — LogEntryFromLeaf fails, the entry is dropped
 };
+
+// strict_leaf (round 3): ct.LogEntryFromLeaf parses a precertificate entry's leaf TBSCertificate
+// (x509.ParseTBSCertificate) and fails — the downloader drops the entry (cmd/ct-fetch/ct-fetch.go:452-459) — when that
+// parse fails fatally; the default decode only length-checks it.  One precertificate entry per lane, the TBS pulled through
+// the same per-lane LDS windows as the map (coop_fill), walk_tbs = the certificate walk without the outer wrapper and the
+// signature.  Runs BEFORE the decode + match kernel, which treats a flagged entry as undecodable: its Chain[0] is never
+// looked at, let alone registered.  Costs one more pass over ≈ 3 windows of every precertificate entry: opt-in.
+__global__ void __launch_bounds__(64) k_leaf_tbs_check(const uint8_t* blob, const uint64_t* bounds, uint64_t n, uint64_t limit,
+                                                       uint8_t* leaf_bad) {
+  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t i = first + lane;
+  DevBytes b{blob};
+  uint64_t lo = 0;
+  uint32_t len = 0;
+  bool pre = false;
+  if (i < n) {
+    const uint64_t l0 = bounds[2 * i], l1 = bounds[2 * i + 1];
+    // MerkleTreeLeaf: version(1) leaf_type(1) timestamp(8) entry_type(2) | issuer_key_hash(32) | TBSCertificate<1..2^24-1>
+    if (l1 >= l0 + 47u && b.u8(l0 + 1) == 0u && b.be(l0 + 10, 2) == 1u) {
+      len = b.be(l0 + 44, 3);
+      lo = l0 + 47u;
+      pre = len != 0u && lo + len <= l1;  // anything else is the decoder's business
+    }
+  }
+  const uint64_t g_me = pre ? (lo & ~15ull) : ~0ull;
+  coop_fill<false>(blob, limit, g_me, lane);
+  bool ok = true;
+  if (pre) {
+    WinReaderC<16> r{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)), (int32_t)(int64_t)(g_me - lo)}};
+    Walk w;
+    ok = walk_tbs(r, len, w);
+  }
+  if (i < n) leaf_bad[i] = (uint8_t)(pre && !ok);
+}
+
 
 // ct.LogEntryFromLeaf, one raw entry per lane (entry_decode.h).  Reads ≈ 5 scattered header words per entry
 // (leaf header, extensions length behind the certificate, the chain headers); the certificates themselves
@@ -50,6 +88,7 @@ __global__ void __launch_bounds__(256) k_entry_decode(DecodeArgs a) {
     if (i >= a.n) break;
     EntryDec d;
     decode_entry(b, a.bounds[2 * i], a.bounds[2 * i + 1], a.bounds[2 * i + 2], d);
+    if (a.leaf_bad && a.leaf_bad[i]) d.ok = false;
     a.cert_start[i] = d.ok ? d.cert_lo : 0ull;
     a.cert_end[i] = d.ok ? d.cert_hi : 0ull;
     a.entry_type[i] = d.ok ? (uint8_t)d.entry_type : (uint8_t)CTMR_ENTRY_INVALID;
@@ -316,6 +355,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k
     d.ok = false; d.entry_type = 0; d.chain0_lo = 0; d.chain0_len = 0; d.n_chain = 0;
     if (live) {
       decode_entry(b, a.bounds[2 * i], a.bounds[2 * i + 1], a.bounds[2 * i + 2], d);
+      if (a.leaf_bad && a.leaf_bad[i]) d.ok = false;  // strict_leaf: LogEntryFromLeaf failed on the leaf's TBSCertificate
       a.cert_start[i] = d.ok ? d.cert_lo : 0ull;
       a.cert_end[i] = d.ok ? d.cert_hi : 0ull;
       a.entry_type[i] = d.ok ? (uint8_t)d.entry_type : (uint8_t)CTMR_ENTRY_INVALID;

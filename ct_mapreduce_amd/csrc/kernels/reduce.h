@@ -672,4 +672,94 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(const uint32_t* blk_new, u
   }
 }
 
+// ------------------------------------------------------------------ device-wide prefix sum of u64, in place
+// (PEM offsets of the NEW list, offsets of the synthetic generators: up to 2·10^8 elements.)  Three launches, the data
+// read twice and written once: per-tile sums (4 096 elements per 256-thread block, 16 consecutive elements per thread,
+// loaded as eight 16-byte vectors) → k_scan64_sums, one workgroup, exclusive scan of the tile sums → every tile scans
+// itself on top of its base.  Hand-written instead of hipcub::DeviceScan (round 2 review): the same three passes,
+// no temporary-storage query, no library in the product's link line.
+constexpr uint32_t SCAN_TILE = 4096;
+
+__device__ __forceinline__ unsigned long long block_exclusive_256(unsigned long long v, unsigned long long* total) {
+  __shared__ unsigned long long wsum[4];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long y = __shfl_up(x, d);
+    if ((int)lane >= d) x += y;
+  }
+  __syncthreads();  // (wsum may still be read by the previous call)
+  if (lane == 63) wsum[wv] = x;
+  __syncthreads();
+  unsigned long long before = 0, all = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    if (k < wv) before += wsum[k];
+    all += wsum[k];
+  }
+  if (total) *total = all;
+  return before + x - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan64_tiles(const unsigned long long* data, uint64_t n, unsigned long long* tile_sum) {
+  const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 16u;
+  unsigned long long s = 0;
+  if (i0 + 16 <= n) {
+    const ulonglong2* p = (const ulonglong2*)(data + i0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const ulonglong2 v = p[k];
+      s += v.x + v.y;
+    }
+  } else {
+    for (uint64_t i = i0; i < n && i < i0 + 16; i++) s += data[i];
+  }
+  unsigned long long all;
+  (void)block_exclusive_256(s, &all);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = all;
+}
+
+__global__ void __launch_bounds__(1024) k_scan64_sums(unsigned long long* sums, uint64_t nt) {  // exclusive, in place
+  __shared__ unsigned long long part[1024];
+  const uint64_t per = (nt + 1023) / 1024;
+  const uint64_t lo = (uint64_t)threadIdx.x * per < nt ? (uint64_t)threadIdx.x * per : nt;
+  const uint64_t hi = lo + per < nt ? lo + per : nt;
+  unsigned long long sum = 0;
+  for (uint64_t i = lo; i < hi; i++) sum += sums[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const unsigned long long t = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned long long run = part[threadIdx.x] - sum;
+  for (uint64_t i = lo; i < hi; i++) {
+    const unsigned long long v = sums[i];
+    sums[i] = run;
+    run += v;
+  }
+}
+
+template <bool INCLUSIVE>
+__global__ void __launch_bounds__(256) k_scan64_apply(unsigned long long* data, uint64_t n, const unsigned long long* tile_base) {
+  const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 16u;
+  unsigned long long v[16];
+  unsigned long long s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    v[k] = i0 + k < n ? data[i0 + k] : 0ull;
+    s += v[k];
+  }
+  unsigned long long run = tile_base[blockIdx.x] + block_exclusive_256(s, nullptr);
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const unsigned long long x = v[k];
+    if (i0 + k < n) data[i0 + k] = INCLUSIVE ? run + x : run;
+    run += x;
+  }
+}
+
 }  // namespace ctmr

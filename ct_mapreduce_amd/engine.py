@@ -408,6 +408,10 @@ class Engine:
         first sighting per call, then identified by length + first/last 16 bytes) — include/ctmr.h."""
         self._ck(self._lib.ctmr_set_chain0_match(self._h, int(mode)))
 
+    def set_strict_leaf(self, on: bool):
+        """Walk the leaf TBSCertificate of precertificate entries as ct.LogEntryFromLeaf does (include/ctmr.h); default off."""
+        self._ck(self._lib.ctmr_set_strict_leaf(self._h, int(bool(on))))
+
     def pending_issuers(self):
         """Distinct Chain[0] certificates the last raw-entry call found unregistered (auto-registration off)."""
         need, cnt = C.c_size_t(), C.c_uint64()

@@ -476,6 +476,14 @@ int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need,
 #define CTMR_CHAIN0_EXACT 0
 #define CTMR_CHAIN0_TRUSTED_LOG 1
 int ctmr_set_chain0_match(ctmr_engine* e, int mode);
+/* Precertificate entries: ct.LogEntryFromLeaf (cmd/ct-fetch/ct-fetch.go:452) also parses the TBSCertificate the
+ * MerkleTreeLeaf carries (CT-go x509.ParseTBSCertificate) and the downloader drops the entry when that fails fatally
+ * (:453-459).  Default (0): the leaf TBSCertificate is length-checked only — identical results on every entry a log
+ * that validated its submissions can serve, and one pass less over ≈ 400 bytes of every precertificate entry.
+ * on = 1: the raw-entry calls walk it (the certificate walk without the outer wrapper and the signature) before anything
+ * else looks at the entry; an entry whose leaf TBSCertificate does not parse gets CTMR_ENTRY_INVALID /
+ * CTMR_ST_ENTRY_DECODE_ERROR and its Chain[0] is never registered, as in the reference. */
+int ctmr_set_strict_leaf(ctmr_engine* e, int on);
 /* ctmr_pem_encode_device for an entry view: PEM of the certificates d_idx[0..n_idx) names, straight out of the blob. */
 int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* d_view,
                                 const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,

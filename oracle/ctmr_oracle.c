@@ -273,18 +273,27 @@ static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint
   return 1;
 }
 
-void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
+/* tbs_only: the buffer is a bare TBSCertificate — CT-go x509.ParseTBSCertificate, which ct.LogEntryFromLeaf applies to the
+ * TBSCertificate of a precertificate entry's MerkleTreeLeaf (cmd/ct-fetch/ct-fetch.go:452): asn1.Unmarshal into
+ * tbsCertificate, "trailing data" when anything follows it, then the same parseCertificate as for a whole certificate
+ * (there is no signatureAlgorithm / signatureValue to look at).  CT-go v1.1.0 is not on this machine: recalled, unverified,
+ * like the rest of the CT-go boundary. */
+static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) {
   memset(out, 0, sizeof(*out));
   tlv t;
   int site = 0;
   if (L > 0x7fffffffu) FAIL(1);
-  /* Certificate ::= SEQUENCE, no trailing data (x509.ParseCertificate) */
-  if (!rd_tlv(d, 0, L, &t) || t.tag != 0x30) FAIL(2);
-  if ((uint64_t)t.hl + t.len != L) FAIL(3);
   uint64_t cert_end = L;
-  uint64_t p = t.hl;
+  uint64_t p = 0;
+  if (!tbs_only) {
+    /* Certificate ::= SEQUENCE, no trailing data (x509.ParseCertificate) */
+    if (!rd_tlv(d, 0, L, &t) || t.tag != 0x30) FAIL(2);
+    if ((uint64_t)t.hl + t.len != L) FAIL(3);
+    p = t.hl;
+  }
   /* tbsCertificate */
   if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x30) FAIL(4);
+  if (tbs_only && (uint64_t)t.hl + t.len != L) FAIL(3);
   out->tbs_off = (uint32_t)p;
   out->tbs_len = t.hl + t.len;
   uint64_t tbs_end = p + t.hl + t.len;
@@ -435,14 +444,19 @@ void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) {
       }
     }
   }
-  /* signatureAlgorithm, signatureValue BIT STRING; whatever follows inside the Certificate is ignored */
-  p = tbs_end;
-  if (!alg_id(d, p, cert_end, &t, &site, 42)) FAIL(site);
-  p += t.hl + t.len;
-  if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x03) FAIL(45);
-  if (!bit_string_ok(d, p + t.hl, t.len)) FAIL(46);
+  if (!tbs_only) {
+    /* signatureAlgorithm, signatureValue BIT STRING; whatever follows inside the Certificate is ignored */
+    p = tbs_end;
+    if (!alg_id(d, p, cert_end, &t, &site, 42)) FAIL(site);
+    p += t.hl + t.len;
+    if (!rd_tlv(d, p, cert_end, &t) || t.tag != 0x03) FAIL(45);
+    if (!bit_string_ok(d, p + t.hl, t.len)) FAIL(46);
+  }
   out->ok = 1;
 }
+
+void orc_parse_cert(const uint8_t* d, size_t L, orc_cert* out) { parse_impl(d, L, out, 0); }
+void orc_parse_tbs(const uint8_t* d, size_t L, orc_cert* out) { parse_impl(d, L, out, 1); }
 
 /* ------------------------------------------------------------------ SHA-256 */
 
@@ -741,6 +755,7 @@ struct orc_engine {
   char* filter;
   size_t filter_len;
   int log_expired;
+  int strict_leaf; /* LogEntryFromLeaf's parse of a precertificate entry's leaf TBSCertificate (orc_engine_set_strict_leaf) */
   int64_t now;
   int64_t inserted;
   int64_t* sorted; /* lazily built sorted key index */
@@ -1109,6 +1124,8 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
   out->ok = 1;
 }
 
+void orc_engine_set_strict_leaf(orc_engine* e, int on) { e->strict_leaf = on != 0; }
+
 void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
                           uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,
                           uint64_t* out_timestamp) {
@@ -1120,6 +1137,13 @@ void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bo
                      (size_t)(bounds[2 * i + 2] - bounds[2 * i + 1]), &d);
     int st = ORC_ST_ENTRY_DECODE_ERROR, unk = 0;
     int32_t eh = 0;
+    if (d.ok && d.entry_type == 1 && e->strict_leaf) {
+      /* ct.LogEntryFromLeaf: x509.ParseTBSCertificate(leaf TBSCertificate); a fatal error fails the whole entry, which the
+       * downloader then drops (ct-fetch.go:452-459) — non-fatal findings are kept there */
+      orc_cert tc;
+      orc_parse_tbs(leaf + d.tbs_off, d.tbs_len, &tc);
+      if (!tc.ok) d.ok = 0;
+    }
     if (d.ok) {
       /* ct-fetch.go:198-204 the certificate; :215 len(Chain) < 1; :221 Chain[0] */
       const uint8_t* c = (d.cert_in_extra ? extra : leaf) + d.cert_off;

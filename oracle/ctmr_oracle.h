@@ -70,6 +70,8 @@ typedef struct {
 #define ORC_NF_LAX_INTEGER 2     /* an INTEGER only CT-go's lax asn1 re-parse accepts: not minimally encoded */
 
 void orc_parse_cert(const uint8_t* der, size_t len, orc_cert* out);
+/* a bare TBSCertificate (CT-go x509.ParseTBSCertificate: what LogEntryFromLeaf applies to a precertificate entry's leaf) */
+void orc_parse_tbs(const uint8_t* tbs, size_t len, orc_cert* out);
 
 /* FIPS 180-4 SHA-256 (Go stdlib crypto/sha256 in types.go:155-159). */
 void orc_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
@@ -175,6 +177,8 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
 /* The downloader + insertCTWorker over raw entries: blob/bounds layout of include/ctmr.h (leaf_input_i =
  * [bounds[2i], bounds[2i+1]), extra_data_i = [bounds[2i+1], bounds[2i+2])).  Entries LogEntryFromLeaf rejects get
  * ORC_ST_ENTRY_DECODE_ERROR.  out_timestamp may be NULL. */
+/* 1: a precertificate entry whose leaf TBSCertificate does not parse is undecodable (ct.LogEntryFromLeaf, ct-fetch.go:452) */
+void orc_engine_set_strict_leaf(orc_engine*, int on);
 void orc_engine_raw_batch(orc_engine*, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
                           uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,
                           uint64_t* out_timestamp);

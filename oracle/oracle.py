@@ -59,6 +59,8 @@ def lib():
             build()
         L = C.CDLL(path)
         L.orc_parse_cert.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Cert)]
+        L.orc_parse_tbs.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Cert)]
+        L.orc_engine_set_strict_leaf.argtypes = [C.c_void_p, C.c_int]
         L.orc_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.restype = C.c_size_t
@@ -126,6 +128,13 @@ def parse_cert(der: bytes) -> Cert:
     return c
 
 
+def parse_tbs(tbs: bytes) -> Cert:
+    """A bare TBSCertificate (what ct.LogEntryFromLeaf parses of a precertificate entry's leaf)."""
+    c = Cert()
+    lib().orc_parse_tbs(tbs, len(tbs), C.byref(c))
+    return c
+
+
 def sha256(b: bytes) -> bytes:
     out = C.create_string_buffer(32)
     lib().orc_sha256(b, len(b), out)
@@ -169,6 +178,10 @@ class Engine:
 
     def __init__(self, issuer_cn_filter: bytes = b"", log_expired: bool = False, now: int = 0):
         self._h = lib().orc_engine_new(issuer_cn_filter, len(issuer_cn_filter), int(log_expired), now)
+
+    def set_strict_leaf(self, on: bool):
+        """Precertificate entries: fail the entry when its leaf TBSCertificate does not parse (LogEntryFromLeaf)."""
+        lib().orc_engine_set_strict_leaf(self._h, int(bool(on)))
 
     def close(self):
         if self._h:

@@ -1,6 +1,7 @@
 """One-off fuzz campaign on the GPU box for the raw get-entries path (k_decode_match → map/reduce):
 damaged TLS framing and damaged certificate bodies against the oracle's LogEntryFromLeaf + insertCTWorker restatement.
     gpurun -- 'python scripts/fuzz_gpu_entries.py 1000000'
+    gpurun -- 'STRICT_LEAF=1 python scripts/fuzz_gpu_entries.py 1000000'     # half the engines in strict_leaf mode (round 3)
 """
 import os
 import random
@@ -48,10 +49,13 @@ def main():
         raw = RawEntries.from_pairs(pairs)
         raw.blob = np.concatenate([raw.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
         filt, log_exp = rng.choice(((b"", True), (b"Synth Issuer 00", False), (b"", False)))
+        strict = bool(os.environ.get("STRICT_LEAF")) and rng.random() < 0.5
         eng = ctmr.Engine(device=0, table_slots=1 << 18, pair_slots=1 << 18, collect_meta=True)
         eng.set_filter(filt, log_exp, now)
+        eng.set_strict_leaf(strict)
         res = eng.map_entries(raw)
         o = orc.Engine(filt, log_exp, now)
+        o.set_strict_leaf(strict)
         st, unk, eh, ts = o.raw_batch(raw.blob, raw.bounds)
         r = res.records
         parsed = (st != orc.ST_PARSE_ERROR) & (st != orc.ST_ENTRY_DECODE_ERROR)
@@ -67,7 +71,7 @@ def main():
         eng.close()
         done += chunk
         hist = [int((st == k).sum()) for k in range(8)]
-        print(f"{done} entries, status histogram {hist}, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+        print(f"{done} entries{' (strict_leaf)' if strict else ''}, status histogram {hist}, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     print("FUZZ", "OK" if bad == 0 else "FAILED", done, bad)
     sys.exit(1 if bad else 0)
 

@@ -75,6 +75,15 @@ def product_walk(der: bytes, fill=0xA5, cn_filter=None) -> HarnessOut:
     return o
 
 
+def product_walk_tbs(tbs: bytes, fill=0xA5) -> HarnessOut:
+    """The product's walk over a bare TBSCertificate (strict_leaf)."""
+    product_walk(b"\x30\x00")          # builds and binds the library
+    _walk.harness_walk_tbs.argtypes = [C.c_char_p, C.c_uint32, C.c_uint8, C.POINTER(HarnessOut)]
+    o = HarnessOut()
+    _walk.harness_walk_tbs(tbs, len(tbs), fill, C.byref(o))
+    return o
+
+
 def walk_touched(der: bytes, phase: int = 0, cn_filter: bytes = b""):
     """(accepted, bytes the walk's reads cover, distinct 128-byte lines they lie in when the certificate starts at
     byte `phase` of a line) — bench.py's needed_bytes accounting."""

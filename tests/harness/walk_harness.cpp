@@ -72,6 +72,26 @@ extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, c
   out->nonfatal = (int32_t)w.nonfatal;
 }
 
+// The walk over a BARE TBSCertificate (strict_leaf: what LogEntryFromLeaf parses of a precertificate entry's leaf)
+extern "C" void harness_walk_tbs(const uint8_t* tbs, uint32_t len, uint8_t fill, HarnessOut* out) {
+  std::vector<uint8_t> buf((size_t)len + 64, fill);
+  memcpy(buf.data(), tbs, len);
+  PaddedReader r{buf.data()};
+  ctmr::Walk w;
+  const bool ok = ctmr::walk_tbs(r, len, w);
+  memset(out, 0, sizeof *out);
+  out->ok = ok;
+  if (!ok) return;
+  out->serial_off = w.serial_off; out->serial_len = w.serial_len;
+  out->not_before = w.not_before; out->not_after = w.not_after;
+  out->cn_off = w.cn_off; out->cn_len = w.cn_len;
+  out->bc_valid = w.bc_valid; out->is_ca = w.is_ca;
+  out->spki_off = w.spki_off; out->spki_len = w.spki_len;
+  memcpy(out->serial_w, w.serial_w, 20);
+  out->cn_match = w.cn_match;
+  out->nonfatal = (int32_t)w.nonfatal;
+}
+
 // What the walk READS: every ld4/ldg marks its four bytes.  Used by bench.py's "needed_bytes" accounting (the bytes and
 // the distinct 128-byte HBM lines a certificate's walk covers when the certificate starts at byte `phase` of a line),
 // against which the measured traffic of the map kernel is an over-fetch ratio.

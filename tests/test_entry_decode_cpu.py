@@ -190,3 +190,37 @@ def test_raw_batch_equals_packed_batch_through_the_oracle():
     assert (st1 == st2).all() and (unk1 == unk2).all() and (eh1 == eh2).all()
     assert o1.keys() == o2.keys() and o1.total_count() == o2.total_count()
     assert (ts == synth.BASE_TIME * 1000 + np.arange(2000, dtype=np.uint64)).all()
+
+
+def test_strict_leaf_drops_precert_entries_whose_leaf_tbs_does_not_parse():
+    """ct.LogEntryFromLeaf parses a precertificate entry's leaf TBSCertificate too (ct-fetch.go:452); with strict_leaf the
+    oracle fails the entry when that parse fails fatally, X509 entries and the default mode are untouched."""
+    from ct_mapreduce_amd import synth
+    from ct_mapreduce_amd.engine import RawEntries
+    from tests.test_walk_cpu import tbs_of
+    cfg = synth.config(seed=12, n_issuers=2, dup_permille=0, ca_permille=0, expired_permille=0)
+    iss = synth.issuer(cfg, 0)
+    certs = [synth.leaf(cfg, i)[0] for i in range(6)]
+    good_tbs = tbs_of(certs[0])
+    bad_tbs = bytearray(good_tbs)
+    bad_tbs[1] = 0x84                                           # the TBSCertificate's own length field lies
+    pairs = [
+        (precert_leaf(good_tbs, ts=1), asn1cert(certs[0]) + chain([iss])),            # fine
+        (precert_leaf(bytes(bad_tbs), ts=2), asn1cert(certs[1]) + chain([iss])),      # leaf TBS broken, submitted precert fine
+        (precert_leaf(good_tbs + b"\x00", ts=3), asn1cert(certs[2]) + chain([iss])),  # trailing data behind the TBS
+        (precert_leaf(certs[3], ts=4), asn1cert(certs[3]) + chain([iss])),            # a whole certificate where a TBS belongs
+        (x509_leaf(certs[4], ts=5), chain([iss])),                                    # X509 entries have no leaf TBS
+        (precert_leaf(tbs_of(certs[5]), ts=6), asn1cert(certs[5]) + chain([iss])),
+    ]
+    raw = RawEntries.from_pairs(pairs)
+    blob = np.concatenate([raw.blob, np.zeros(64, np.uint8)])
+    lax = orc.Engine(b"", False, synth.BASE_TIME)
+    st0, unk0, _, _ = lax.raw_batch(blob, raw.bounds)
+    assert (st0 == orc.ST_PASS).all() and unk0.all()
+    strict = orc.Engine(b"", False, synth.BASE_TIME)
+    strict.set_strict_leaf(True)
+    st1, unk1, _, ts1 = strict.raw_batch(blob, raw.bounds)
+    E = orc.ST_ENTRY_DECODE_ERROR
+    assert list(st1) == [orc.ST_PASS, E, E, E, orc.ST_PASS, orc.ST_PASS]
+    assert list(unk1) == [1, 0, 0, 0, 1, 1] and list(ts1) == [1, 0, 0, 0, 5, 6]
+    assert strict.total_count() == 3

@@ -376,3 +376,70 @@ def test_trusted_log_compares_bytes_when_two_registered_certificates_share_tag_a
         eng.close()
     for f in ("status", "flags", "issuer_idx", "serial"):
         assert (recs[N.CHAIN0_EXACT][f] == recs[N.CHAIN0_TRUSTED_LOG][f]).all(), f
+
+
+def test_raw_entries_wrapped_around_the_reference_certificates_on_the_gpu():
+    """The committed N2 fixtures (tests/golden/entries_from_reference_pems.json: the reference's own test certificates
+    as RFC 6962 leaves / extra_data, encoded independently, expectations derived from the reference's goldens) through
+    the product: decode + Chain[0] match + map + reduce on the GPU, in both Chain[0] modes."""
+    from tests.test_oracle_golden import load_entry_fixture, STATUS_NAMES
+    fx, pairs, raw = load_entry_fixture()
+    for mode in (N.CHAIN0_EXACT, N.CHAIN0_TRUSTED_LOG):
+        eng = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10)
+        eng.set_filter(fx["filter"].encode(), fx["log_expired"], fx["now"])
+        eng.set_chain0_match(mode)
+        res = eng.map_entries(raw)
+        for i, e in enumerate(fx["entries"]):
+            r = res.records[i]
+            assert int(r["status"]) == STATUS_NAMES[e["status"]] and bool(r["flags"] & 2) == e["was_unknown"], e["name"]
+            assert int(res.timestamp[i]) == e["timestamp"] and bool(r["flags"] & N.FL_PRECERT) == (e["entry_type"] == 1)
+            if e.get("serial_hex"):
+                assert bytes(r["serial"][:int(r["serial_len"])]).hex() == e["serial_hex"]
+                assert orc.exp_date_id(int(r["exp_hour"])) == e["exp_date"]
+                assert eng.issuer_id(int(r["issuer_idx"])) == e["issuer_id"]
+        assert sorted(k.decode() for k in eng.keys(b"serials::*")) == fx["final_keys"]
+        assert eng.total_count() == fx["final_total_count"] and eng.issuer_count() == 2     # kEmptySPKI, kRealSPKI registered on the way
+        for k in fx["final_keys"]:
+            assert eng.set_list(k.encode()) == [bytes.fromhex("00aa")]
+        check_against_oracle(eng, raw, orc.Engine(fx["filter"].encode(), fx["log_expired"], fx["now"]), res)
+        eng.close()
+
+
+def test_strict_leaf_walks_the_leaf_tbs_of_precertificate_entries():
+    """ctmr_set_strict_leaf(1): the leaf TBSCertificate of every precertificate entry is parsed as ct.LogEntryFromLeaf
+    does (ct-fetch.go:452); entries whose TBS fails are undecodable and their Chain[0] is never registered.  Synthetic
+    entries with the leaf damaged at random (the precert entries' TBS lies in leaf_input) + hand-built cases, against the
+    oracle in strict mode; the default mode on the same input keeps its round-2 answers."""
+    from tests.test_walk_cpu import tbs_of, mutate
+    rng = random.Random(20260925)
+    cfg = synth.config(seed=15, n_issuers=8, dup_permille=50)
+    raw = synth.host_entries(cfg, 0, 4000)
+    only = synth.issuer(synth.config(seed=99, n_issuers=1), 0)          # an issuer that ONLY broken-leaf entries name
+    cert = synth.leaf(cfg, 7)[0]
+    pairs = []
+    for i in range(raw.n):
+        leaf, extra = raw.leaf_input(i), raw.extra_data(i)
+        if leaf[10:12] == b"\x00\x01" and rng.random() < 0.5:           # damage inside the leaf's TBSCertificate only
+            tbs = mutate(rng, leaf[47:-2])
+            leaf = leaf[:44] + len(tbs).to_bytes(3, "big") + tbs + leaf[-2:]
+        pairs.append((leaf, extra))
+    bad = bytearray(tbs_of(cert)); bad[1] = 0x84
+    pairs += [(precert_leaf(bytes(bad), ts=7), asn1cert(cert) + chain([only])),
+              (precert_leaf(tbs_of(cert) + b"\x00", ts=8), asn1cert(cert) + chain([only])),
+              (precert_leaf(b"\x30\x00", ts=9), asn1cert(cert) + chain([only]))]
+    rng.shuffle(pairs)
+    mixed = RawEntries.from_pairs(pairs)
+    mixed.blob = np.concatenate([mixed.blob, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    seen = {}
+    for strict in (True, False):
+        eng = ctmr.Engine(device=0, table_slots=1 << 15, pair_slots=1 << 14)
+        eng.set_filter(b"", True, NOW)
+        eng.set_strict_leaf(strict)
+        res = eng.map_entries(mixed)
+        o = orc.Engine(b"", True, NOW)
+        o.set_strict_leaf(strict)
+        st, _ = check_against_oracle(eng, mixed, o, res)
+        seen[strict] = (int((st == orc.ST_ENTRY_DECODE_ERROR).sum()), eng.issuer_count())
+        eng.close()
+    assert seen[True][0] > seen[False][0] + 200                          # the damaged leaves are what the strict mode drops
+    assert seen[False][1] == seen[True][1] + 1                           # … and their Chain[0] was never registered

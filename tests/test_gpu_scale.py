@@ -3,9 +3,10 @@
 configs[1]  1 M synthetic ~1.5 KB certificates, single issuer, known-certificate dedup — bit-exact against the oracle on
             every entry (the batch is generated in HBM and copied back for the CPU run).
 configs[2]  10 M certificates, 256 issuers, issuerCN prefix filter + per-issuer unique counts — too large for the
-            oracle inside a test, so checked through size-independent properties of the generator and of set insertion:
-            new ⇔ PASS ∧ first carrier of its key, per-issuer counts = histogram of the new entries, idempotent replay,
-            checksum of the NEW list.
+            oracle to run whole inside a test, so checked (i) through size-independent properties of the generator and
+            of set insertion: new ⇔ PASS ∧ first carrier of its key, per-issuer counts = histogram of the new entries,
+            idempotent replay, the NEW list; and (ii) bit-exact against the oracle on a strided, duplicate-closed
+            sample of 1.1 M entries (bench.py's parity leg).
 (configs[3]/[4] — 100 M-entry batch, 1 B-entry stream — run in bench.py / bench.py --stream with the same checks.)"""
 import os
 import sys
@@ -23,7 +24,7 @@ from oracle import oracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import synth_is_dup  # noqa: E402  (numpy restatement of the generator's duplicate structure)
+from bench import synth_is_dup, oracle_sample_check  # noqa: E402  (the generator's duplicate structure; bench.py's oracle sample)
 
 NOW = synth.BASE_TIME
 
@@ -101,6 +102,14 @@ def test_config2_ten_million_256_issuers_properties():
     # Σ SCARD over the keys of one issuer = its count (the statistics tool's own arithmetic)
     k0 = [k for k in eng.keys(b"serials::*::" + eng.issuer_id(7).encode())]
     assert sum(eng.set_cardinality(k) for k in k0) == int(counts[7])
+    # … and against the ORACLE (round 3): 40 equally spaced slices of 25 000 entries over the whole batch + every entry
+    # outside them whose key a sampled duplicate repeats, in log order — the closed set on which the oracle's answer is
+    # the whole batch's answer (tests/test_bench_helpers_cpu.py); ≈ 1.1 M entries, status and WasUnknown bit-exact
+    filt = b"Synth Issuer 0,Synth Issuer 1"
+    _, pinfo, _, _ = oracle_sample_check(np, torch, ctmr, synth, N, cfg, 100, synth.issuers(cfg), filt, NOW, dev, 0, n,
+                                         d_off, d_pay, d_iss, d_et, d_rec, 40, 25_000)
+    assert pinfo["status_mismatches"] == 0 and pinfo["was_unknown_mismatches"] == 0
+    assert pinfo["entries"] > 1_000_000 and pinfo["known_duplicates"] > 50_000 and pinfo["sources_outside_the_slices"] > 50_000
     # idempotence: replaying the batch finds every stored entry known
     st2 = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
                                d_rec.data_ptr(), d_new.data_ptr())

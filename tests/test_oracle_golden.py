@@ -3,6 +3,9 @@ import base64
 import calendar
 import hashlib
 import json
+import os
+
+import numpy as np
 
 from oracle import oracle as orc
 
@@ -205,3 +208,48 @@ def test_golden_files_are_current():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "golden", "make_golden.py")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+STATUS_NAMES = {"PASS": orc.ST_PASS, "PARSE_ERROR": orc.ST_PARSE_ERROR, "FILTERED_CA": orc.ST_FILTERED_CA,
+                "FILTERED_EXPIRED": orc.ST_FILTERED_EXPIRED, "FILTERED_CN": orc.ST_FILTERED_CN, "NO_ISSUER": orc.ST_NO_ISSUER}
+
+
+def load_entry_fixture():
+    import base64
+    import json
+    from ct_mapreduce_amd.engine import RawEntries
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "entries_from_reference_pems.json")))
+    pairs = [(base64.b64decode(e["leaf_input"]), base64.b64decode(e["extra_data"])) for e in fx["entries"]]
+    raw = RawEntries.from_pairs(pairs)
+    raw.blob = np.concatenate([raw.blob, np.zeros(64, np.uint8)])
+    return fx, pairs, raw
+
+
+def test_raw_entries_wrapped_around_the_reference_certificates():
+    """N2's decode oracle pinned on more than hand-built vectors (round 3): the reference's own certificates wrapped
+    into RFC 6962 leaves / extra_data by an encoder that shares no code with the oracle (tests/golden/make_entries.py),
+    with what the reference's loop must make of every entry derived from the reference's goldens."""
+    import hashlib
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    assert subprocess.run([sys.executable, os.path.join(here, "golden", "make_entries.py")]).returncode == 0   # fixture is current
+    fx, pairs, raw = load_entry_fixture()
+    o = orc.Engine(fx["filter"].encode(), fx["log_expired"], fx["now"])
+    st, unk, eh, ts = o.raw_batch(raw.blob, raw.bounds)
+    for i, e in enumerate(fx["entries"]):
+        d = orc.decode_entry(*pairs[i])
+        assert d.ok and d.entry_type == e["entry_type"] and d.timestamp == e["timestamp"] == int(ts[i]), e["name"]
+        src = pairs[i][1] if d.cert_in_extra else pairs[i][0]
+        assert hashlib.sha256(src[d.cert_off:d.cert_off + d.cert_len]).hexdigest() == e["cert_sha256"], e["name"]
+        if e["chain0_sha256"] is None:
+            assert d.chain0_len == 0
+        else:
+            assert hashlib.sha256(pairs[i][1][d.chain0_off:d.chain0_off + d.chain0_len]).hexdigest() == e["chain0_sha256"]
+        assert int(st[i]) == STATUS_NAMES[e["status"]] and bool(unk[i]) == e["was_unknown"], e["name"]
+        if e.get("exp_date"):
+            assert orc.exp_date_id(int(eh[i])) == e["exp_date"]
+    assert sorted(k.decode() for k in o.keys() if k.startswith(b"serials::")) == fx["final_keys"]
+    assert o.total_count() == fx["final_total_count"]
+    for k in fx["final_keys"]:
+        assert o.members(k.encode()) == [bytes.fromhex("00aa")]      # raw serial octets, leading zero kept (types_test.go:81-101)

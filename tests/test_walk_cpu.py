@@ -232,3 +232,55 @@ def test_product_walk_equals_oracle_on_mutated_edge_certificates():
             der = mutate(rng, der)
         accepted += same(der)
     assert 1000 < accepted < 11000
+
+
+# ---- strict_leaf: the bare TBSCertificate of a precertificate entry's MerkleTreeLeaf (round 3) -----------------------
+def tbs_of(der):
+    """The TBSCertificate TLV of a well-formed certificate (tests only: two definite-length headers)."""
+    def hdr(p):
+        ln = der[p + 1]
+        if ln < 0x80:
+            return p + 2, p + 2 + ln
+        k = ln & 0x7f
+        return p + 2 + k, p + 2 + k + int.from_bytes(der[p + 2:p + 2 + k], "big")
+    c0, _ = hdr(0)
+    _, t1 = hdr(c0)
+    return der[c0:t1]
+
+
+def same_tbs(tbs):
+    o = orc.parse_tbs(tbs)
+    p = harness.product_walk_tbs(tbs, 0xA5)
+    p2 = harness.product_walk_tbs(tbs, 0x30)
+    assert bool(o.ok) == bool(p.ok) == bool(p2.ok), (o.ok, o.err_site, p.ok, p2.ok)
+    if o.ok:
+        for f in FIELDS:
+            assert getattr(o, f) == getattr(p, f) == getattr(p2, f), f
+    return bool(o.ok)
+
+
+def test_tbs_walk_is_the_certificate_walk_without_wrapper_and_signature(golden_certs):
+    cfg = synth.config(seed=5, n_issuers=8, profile=1)
+    for der in list(golden_certs.values()) + [synth.leaf(cfg, i)[0] for i in range(60)] + edge_seeds():
+        whole = orc.parse_cert(der)
+        if not whole.ok:
+            continue
+        tbs = tbs_of(der)
+        assert same_tbs(tbs)
+        t = orc.parse_tbs(tbs)
+        off = der.index(tbs)                      # every position moves by the outer header
+        assert (t.serial_off + off, t.serial_len, t.not_after, t.bc_valid, t.is_ca) == \
+               (whole.serial_off, whole.serial_len, whole.not_after, whole.bc_valid, whole.is_ca)
+        assert not same_tbs(tbs + b"\x00")        # x509.ParseTBSCertificate: trailing data
+        assert not same_tbs(tbs[:-1]) and not same_tbs(der)     # a whole certificate is not a TBSCertificate
+
+
+def test_product_tbs_walk_equals_oracle_on_mutations(golden_certs):
+    rng = random.Random(20260924)
+    cfg = synth.config(seed=6, n_issuers=16, ca_permille=200, expired_permille=50)
+    seeds = [tbs_of(d) for d in list(golden_certs.values()) + [synth.leaf(cfg, i)[0] for i in range(40)] + edge_seeds()
+             if orc.parse_cert(d).ok]
+    accepted = 0
+    for r in range(8000):
+        accepted += same_tbs(mutate(rng, seeds[r % len(seeds)]))
+    assert 400 < accepted < 7600
