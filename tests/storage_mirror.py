@@ -1,5 +1,8 @@
-"""Host mirror of the reference's `storage` package over the C ABI — same names, argument meaning
-and error behaviour, so the tests read like the reference's own (storage/*_test.go).
+"""TEST SCAFFOLDING (moved out of the product package in round 3): a Python twin of the reference's `storage` package
+over the C ABI — same names, argument meaning and error behaviour, so that the end-to-end tests read like the reference's
+own (storage/*_test.go).  The host mirror a cgo binding would look like is the C++ one, include/ctmr_storage.hpp (with the
+reference's test suites in tests/host/); what the PRODUCT keeps in Python is ct_mapreduce_amd/remote_cache.py
+(GpuRemoteCache + the Redis-protocol export/import of N4).
 
   types        Issuer, SPKI, Serial, ExpDate, UniqueCertIdentifier, CertificateLog   storage/types.go
   RemoteCache  GpuRemoteCache (libctmr: serials sets in HBM) / MockRemoteCache       storage/types.go:83-102, mockcache.go
@@ -22,8 +25,10 @@ import time as _time
 
 import numpy as np
 
-from . import _native as N
-from .engine import Batch, Engine
+from ct_mapreduce_amd import _native as N
+from ct_mapreduce_amd.engine import Batch, Engine
+from ct_mapreduce_amd import remote_cache as _rc
+from ct_mapreduce_amd.remote_cache import redis_dump, redis_load  # noqa: F401  (re-exported for the tests)
 
 kExpirationFormat = "%Y-%m-%d"
 kExpirationFormatWithHour = "%Y-%m-%d-%H"
@@ -321,34 +326,14 @@ class MockRemoteCache(RemoteCache):
         return CertificateLog.from_json(d[0].decode())
 
 
-class GpuRemoteCache(RemoteCache):
-    """The drop-in for RedisCache on this path: `serials::…` sets live in the HBM table behind
-    libctmr; every other key (crl::, issuer::, log state) in the library's host-side store."""
-
-    def __init__(self, engine: Engine):
-        self.engine = engine
-
-    def SetInsert(self, key, entry): return self.engine.set_insert(_b(key), _b(entry))
-    def SetRemove(self, key, entry): return self.engine.set_remove(_b(key), _b(entry))
-    def SetContains(self, key, entry): return self.engine.set_contains(_b(key), _b(entry))
-    def SetList(self, key): return self.engine.set_list(_b(key))
-    def SetToChan(self, key): return iter(self.engine.set_list(_b(key)))
-    def SetCardinality(self, key): return self.engine.set_cardinality(_b(key))
-    def Exists(self, key): return self.engine.exists(_b(key))
-    def ExpireAt(self, key, unix_seconds): self.engine.expire_at(_b(key), unix_seconds)
-    def KeysToChan(self, pattern): return iter(self.engine.keys(_b(pattern)))
+class GpuRemoteCache(_rc.GpuRemoteCache, RemoteCache):
+    """The product's cache (ct_mapreduce_amd/remote_cache.py) with the typed log-state methods of the mirror."""
 
     def StoreLogState(self, log):                 # rediscache.go:180-190: key "log::<shortURL>"
-        key = b"log::" + _b(log.ShortURL)
-        for old in self.engine.set_list(key):
-            self.engine.set_remove(key, old)
-        self.engine.set_insert(key, log.to_json().encode())
+        self.StoreLogStateJSON(log.ShortURL, log.to_json().encode())
 
     def LoadLogState(self, shortUrl):
-        d = self.engine.set_list(b"log::" + _b(shortUrl))
-        if not d:
-            raise KeyError("Log state not found")
-        return CertificateLog.from_json(d[0].decode())
+        return CertificateLog.from_json(self.LoadLogStateJSON(shortUrl).decode())
 
 
 # -------------------------------------------------------------------------- KnownCertificates
@@ -906,76 +891,4 @@ def storage_statistics(db: FilesystemDatabase):
         out[issuerObj.Issuer.ID()] = (len(issuerObj.ExpDates), count, sorted(crls), sorted(dns))
     return out, totalSerials, totalCRLs
 
-
-# ------------------------------------------------------------------------------------------------
-# N4, second half: the sets as a Redis protocol stream.  `redis-cli --pipe < dump` loads them into the Redis of a
-# reference deployment (or a scratch one), so that a real ct-fetch run elsewhere and this engine can be diffed with
-# the reference's own tools (storage-statistics, SCARD/SMEMBERS); redis_load() is the way back.
-_SET_PATTERNS = ("%s::*" % kSerials, "%s::*" % kCrls, "%s::*" % kIssuers)
-
-
-def _resp(*args) -> bytes:
-    out = [b"*%d\r\n" % len(args)]
-    for a in args:
-        a = _b(a)
-        out.append(b"$%d\r\n" % len(a) + a + b"\r\n")
-    return b"".join(out)
-
-
-def redis_dump(cache: RemoteCache, out, patterns=_SET_PATTERNS, members_per_command=512) -> dict:
-    """Writes SADD commands for every set matching `patterns` (members are raw bytes — serials contain NULs, which
-    RESP bulk strings carry unchanged) and, for the known-certificate sets, the EXPIREAT the reference puts on them:
-    the expDate of the key (KnownCertificates.setExpiryFlag, storage/knowncertificates.go:98-104).  → counts."""
-    n_keys = n_members = 0
-    prefix = (kSerials + "::").encode()
-    for pat in patterns:
-        for key in sorted(cache.KeysToChan(pat)):
-            key = _b(key)
-            members = sorted(set(cache.SetToChan(key)))       # SetToChan may repeat members (knowncertificates.go:80-93)
-            for i in range(0, len(members), members_per_command):
-                out.write(_resp(b"SADD", key, *members[i:i + members_per_command]))
-            if key.startswith(prefix):
-                exp = ExpDate.Parse(key[len(prefix):].split(b"::", 1)[0].decode())
-                out.write(_resp(b"EXPIREAT", key, str(exp.ExpireTime())))
-            n_keys += 1
-            n_members += len(members)
-    return {"keys": n_keys, "members": n_members}
-
-
-def redis_load(cache: RemoteCache, stream) -> dict:
-    """Applies a redis_dump() stream (RESP arrays of bulk strings; SADD and EXPIREAT) to `cache`."""
-    data = stream.read()
-    pos, n_cmd, n_new = 0, 0, 0
-
-    def line():
-        nonlocal pos
-        e = data.index(b"\r\n", pos)
-        v = data[pos:e]
-        pos = e + 2
-        return v
-
-    while pos < len(data):
-        head = line()
-        if head[:1] != b"*":
-            raise ValueError("not a RESP array at byte %d" % (pos - len(head) - 2))
-        args = []
-        for _ in range(int(head[1:])):
-            ln = line()
-            if ln[:1] != b"$":
-                raise ValueError("not a bulk string at byte %d" % (pos - len(ln) - 2))
-            n = int(ln[1:])
-            args.append(data[pos:pos + n])
-            if data[pos + n:pos + n + 2] != b"\r\n":
-                raise ValueError("bulk string not terminated at byte %d" % (pos + n))
-            pos += n + 2
-        cmd = args[0].upper()
-        if cmd == b"SADD":
-            for m in args[2:]:
-                n_new += bool(cache.SetInsert(args[1], m))
-        elif cmd == b"EXPIREAT":
-            cache.ExpireAt(args[1], int(args[2]))
-        else:
-            raise ValueError("unsupported command %r" % cmd)
-        n_cmd += 1
-    return {"commands": n_cmd, "inserted": n_new}
 

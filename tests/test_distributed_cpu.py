@@ -34,16 +34,16 @@ def _worker(rank, world, port, n_total, out):
     import bench
     from ct_mapreduce_amd import synth
     from oracle import oracle as orc
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    # bench.py's control path: rank 0 makes the group id, every rank ends up with the same 128 bytes
-    gid = bench.share_group_id(dist, rank, lambda: bytes([7]) * 100 + os.urandom(28))
-    assert len(gid) == 128 and gid[:100] == bytes([7]) * 100
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    # bench.py's control path under a launcher: rank 0 makes the group id, one broadcast over the launcher's
+    # rendezvous, every rank ends up with the same 128 bytes — and the process group is gone again afterwards
+    gid = bench.group_id_from_launcher(rank, lambda: bytes([7]) * 100 + os.urandom(28))
+    assert len(gid) == 128 and gid[:100] == bytes([7]) * 100 and not dist.is_initialized()
+    os.environ["MASTER_PORT"] = str(port + 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # (the rest of this test's own plumbing)
     box = [None] * world
     dist.all_gather_object(box, gid)
     assert all(b == box[0] for b in box)
-    assert bench.max_over_ranks(dist, 1.0 + rank, torch.device("cpu")) == float(world)
     # the shard-local mode: rank r maps [lo, hi) with its own known-certificate sets; counts are summed
     cfg = synth.config(seed=77, n_issuers=8, dup_permille=0, ca_permille=20, expired_permille=20)
     issuers = synth.issuers(cfg)

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 import torch  # noqa: E402,F401
 
 import ct_mapreduce_amd as ctmr
-from ct_mapreduce_amd import synth, _native as N, storage as S
+from ct_mapreduce_amd import synth, _native as N
+from tests import storage_mirror as S
 from ct_mapreduce_amd.engine import Batch
 from oracle import oracle as orc
 from tests import der as D

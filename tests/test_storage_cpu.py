@@ -8,7 +8,7 @@ import os
 
 import pytest
 
-from ct_mapreduce_amd import storage as S
+from tests import storage_mirror as S
 from tests import der as D
 
 

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 import torch  # noqa: E402,F401
 
 import ct_mapreduce_amd as ctmr
-from ct_mapreduce_amd import storage as S, synth
+from ct_mapreduce_amd import synth
+from tests import storage_mirror as S
 from oracle import oracle as orc
 from tests.test_storage_cpu import (known_certificates_suite, duplicate_crls_suite, accumulate_suite,
                                     issuer_and_dates_suite, log_state_suite, utc)
