@@ -335,7 +335,7 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
     """BASELINE config 5 on ONE GPU (the cross-GPU form is distributed.run_global_dedup): a long stream with 10 %
     duplicates, the known-certificate table persisting across waves."""
     T = args.stream
-    W = args.entries if args.entries != 100_000_000 else 50_000_000
+    W = args.entries or 50_000_000
     W = min(W, T)
     cfg = synth.config(seed=20260921 + 5, n_issuers=args.issuers, zipf=1, dup_permille=100, ca_permille=10,
                        expired_permille=10)
@@ -382,6 +382,12 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
         waves += 1
     ok = ok and eng.total_count() == tot_new
     achieved = tot_bytes / (t_map * 1e-3) / 1e9
+    # measured HBM traffic of the map kernel in this mode: a 40 M-entry stream in 4 waves of 10 M under rocprofv3 --pmc
+    # (the table persists across the waves, as here; bytes per entry averaged over the launches)
+    traffic_info = traffic_err = None
+    if args.traffic == "auto" and not os.environ.get("CTMR_BENCH_CHILD"):
+        kname = MAP_KERNELS[args.variant or DEFAULT_VARIANT].split("<")[0]
+        traffic_info, traffic_err = measure_traffic(args, 10_000_000, [kname], ["--stream", "40000000"])
     out = {"metric": "certificates/sec whole-node + achieved HBM GB/s, 100M-entry synthetic CT batch",
            "value": T / t_gpu, "unit": "certificates/sec", "n_gpus": 1, "steps": waves, "warmup": 0,
            "ms_per_step": t_gpu / waves * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -391,9 +397,20 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
                       "table_slots": int(min(slots, 1 << 31)), "map_variant": args.variant or DEFAULT_VARIANT},
            "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or DEFAULT_VARIANT], "achieved": achieved,
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                        "achieved_basis": "ALGORITHMIC bytes / map kernel time",
+                        "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
                         "alg_bytes_formula": "sum(L_i) + 45*E + 64*PASS (table probe), summed over the waves"},
            "result": {"n_new": tot_new, "n_dup": tot_dup, "n_pass": tot_pass, "total_count": eng.total_count(),
                       "duplicate_structure_matches_generator_in_every_wave": bool(ok)}}
+    if traffic_info:
+        r = out["roofline"]
+        r["traffic"] = traffic_info["traffic_bytes_per_cert"] * T          # over the whole stream
+        r["traffic_measurement"] = traffic_info
+        r["achieved"] = r["traffic"] / (t_map * 1e-3) / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBPS
+        r["achieved_basis"] = "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, 40 M-entry stream of the same corpus) / map kernel time"
+    elif traffic_err:
+        out["roofline"]["traffic_error"] = traffic_err
     print(json.dumps(out))
     eng.close()
 
@@ -560,14 +577,21 @@ def main():
 
     raw_view = {}
 
-    def setup_raw(first, E, this_cfg):
-        eng = ctmr.Engine(device=local, table_slots=pow2_at_least(int(E * 2)), pair_slots=1 << 22,
-                          map_variant=args.variant, profile=True, collect_meta=args.meta)
-        eng.set_filter(filt, False, now)              # no add_issuers: Chain[0] certificates register themselves
-        if world > 1:
-            # … in shard order, so issuer index k would name different issuers on different ranks and the count
-            # all-reduce would add apples to oranges: with several ranks, register the same list up front
-            eng.add_issuers(issuers)
+    def make_engine(E, this_cfg):
+        """The engine and its known-certificate table — the one allocation every rank can always make; the group is
+        created on it BEFORE the batch is generated, so that a rank whose shard does not fit can still tell the others."""
+        eng = ctmr.Engine(device=local, table_slots=(1 << args.table_slots_log2) if args.table_slots_log2 else pow2_at_least(int(E * 2)),
+                          pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
+                          lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
+        eng.set_filter(filt, False, now)
+        if not args.raw or world > 1:
+            # raw entries register their Chain[0] certificates themselves — in shard order, so issuer index k would name
+            # different issuers on different ranks and the count all-reduce would add apples to oranges: with several
+            # ranks, register the same list up front
+            eng.add_issuers(synth.issuers(this_cfg))
+        return eng
+
+    def fill_raw(eng, first, E, this_cfg):
         d_bounds = torch.empty(2 * E + 1, dtype=torch.int64, device=dev)
         nbytes = eng.synth_entries_device(this_cfg, first, E, d_bounds.data_ptr(), 0, 0)
         d_blob = torch.empty(nbytes + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
@@ -588,16 +612,11 @@ def main():
                                        chain0_len=raw_view["c0len"].data_ptr())
         raw_view["blob_bytes"] = nbytes
         torch.cuda.synchronize()
-        return eng, d_bounds, d_blob, d_ts, None, d_rec, d_new
+        return d_bounds, d_blob, d_ts, None, d_rec, d_new
 
-    def setup(first, E, this_cfg):
+    def fill(eng, first, E, this_cfg):
         if args.raw:
-            return setup_raw(first, E, this_cfg)
-        eng = ctmr.Engine(device=local, table_slots=(1 << args.table_slots_log2) if args.table_slots_log2 else pow2_at_least(int(E * 2)),
-                          pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
-                          lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
-        eng.add_issuers(synth.issuers(this_cfg))
-        eng.set_filter(filt, False, now)
+            return fill_raw(eng, first, E, this_cfg)
         # ---- synthetic shard [first, first + E), generated directly in HBM
         d_off = torch.empty(E + 1, dtype=torch.int64, device=dev)
         nbytes = eng.synth_device(this_cfg, first, E, d_off.data_ptr(), 0, 0, 0, 0)
@@ -609,40 +628,59 @@ def main():
         d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         d_new = torch.empty(E, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
-        return eng, d_off, d_pay, d_iss, d_et, d_rec, d_new
+        return d_off, d_pay, d_iss, d_et, d_rec, d_new
+
+    def setup(first, E, this_cfg):
+        eng = make_engine(E, this_cfg)
+        try:
+            return (eng,) + fill(eng, first, E, this_cfg)
+        except (ctmr.CtmrError, RuntimeError):
+            eng.close()
+            raise
 
     t_gen = time.perf_counter()
+    group = None
+
+    def my_shard():
+        return (rank * args.entries, (rank + 1) * args.entries) if weak else shard_range(total, rank, world)
+
+    first, hi = my_shard()
+    E = hi - first
+    if world > 1:
+        eng = make_engine(E, cfg)
+        group = Group.rccl(eng, gid, rank, world)       # every rank joins before any of them can run out of memory
     while True:
-        first, hi = (rank * args.entries, (rank + 1) * args.entries) if weak else shard_range(total, rank, world)
+        first, hi = my_shard()
         E = hi - first
         fits = 1
         try:
-            eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(first, E, cfg)
+            if world > 1:
+                d_off, d_pay, d_iss, d_et, d_rec, d_new = fill(eng, first, E, cfg)
+            else:
+                eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(first, E, cfg)
         except (ctmr.CtmrError, RuntimeError) as ex:   # does not fit in this GPU's HBM
             fits = 0
             sys.stderr.write(f"bench: rank {rank}: {E} entries do not fit ({ex})\n")
-            eng = d_off = d_pay = d_iss = d_et = d_rec = d_new = None
+            d_off = d_pay = d_iss = d_et = d_rec = d_new = None
+            raw_view.clear()
             torch.cuda.empty_cache()
-        if world == 1:
-            if fits:
-                break
-        else:
-            break       # several ranks agree below (the group does not exist yet: a failed rank reports and leaves)
+        if world > 1:
+            fits = int(int(group.all_reduce_u64([0 if fits else 1])[0]) == 0)      # the ranks halve together or not at all
+        if fits:
+            break
         if total <= 1_000_000:
             raise SystemExit("bench: even 1 M entries do not fit")
+        d_off = d_pay = d_iss = d_et = d_rec = d_new = None
+        raw_view.clear()
+        torch.cuda.empty_cache()
         total //= 2
         if weak:
             args.entries //= 2
         sys.stderr.write(f"bench: trying {total} entries\n")
-    if eng is None:
-        raise SystemExit(f"bench: rank {rank}: the shard does not fit this GPU — use --total-entries / --entries")
     t_gen = time.perf_counter() - t_gen
     if args.raw and args.trusted_chain:
         eng.set_chain0_match(N.CHAIN0_TRUSTED_LOG)
-    group = None
-    if world > 1:
-        group = Group.rccl(eng, gid, rank, world)
-    elif mode != "plain":
+    if world == 1 and mode != "plain":
         group = Group.local([eng])          # N = 1: no peer — this prices each mode's kernels on one rank
     if mode == "bloom":
         per_rank = max(E, (total + world - 1) // world)
