@@ -492,7 +492,11 @@ def main():
                          "issuer names, one GeneralizedTime in four) instead of the SURVEY §8(d) corpus: how the map "
                          "behaves when the lanes of a wave do not walk identical layouts.  The default run reports it as "
                          "secondary.mixed; this flag makes it the line's workload")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary.mixed leg of the default run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (mixed corpus, 128-byte aligned layout) of the default run")
+    ap.add_argument("--aligned", type=int, default=0, metavar="BYTES",
+                    help="lay every certificate at a multiple of BYTES (an entry view instead of the packed layout; payload grows "
+                         "by the padding): what the map moves per certificate depends on where certificates start inside "
+                         "128-byte lines.  The default run reports --aligned 128 as secondary.aligned128")
     ap.add_argument("--pem", action="store_true",
                     help="also time the PEM write-back kernels (k_pem_len + scan + k_pem_encode, SURVEY §8(f) N1) over "
                          "the first 16M entries of the NEW list")
@@ -527,6 +531,11 @@ def main():
                     help="… of this many entries each (default: --cpu-sample / ranks / --sample-slices), plus every entry "
                          "outside the slices whose key a sampled duplicate repeats")
     args = ap.parse_args()
+
+    if args.aligned and (args.raw or args.global_dedup or args.gpus > 1 or args.stream or args.pem or args.fingerprint or args.meta):
+        ap.error("--aligned is a layout variant of the plain one-GPU line")
+    if args.aligned & (args.aligned - 1):
+        ap.error("--aligned takes a power of two")
 
     # ---- N > 1 without a launcher: become the launcher
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -617,6 +626,8 @@ def main():
     def fill(eng, first, E, this_cfg):
         if args.raw:
             return fill_raw(eng, first, E, this_cfg)
+        if args.aligned:
+            return fill_aligned(eng, first, E, this_cfg, args.aligned)
         # ---- synthetic shard [first, first + E), generated directly in HBM
         d_off = torch.empty(E + 1, dtype=torch.int64, device=dev)
         nbytes = eng.synth_device(this_cfg, first, E, d_off.data_ptr(), 0, 0, 0, 0)
@@ -627,6 +638,24 @@ def main():
                          d_iss.data_ptr(), d_et.data_ptr())
         d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
         d_new = torch.empty(E, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        return d_off, d_pay, d_iss, d_et, d_rec, d_new
+
+    def fill_aligned(eng, first, E, this_cfg, align):
+        """The same certificates as an entry view, each starting at a multiple of `align` bytes."""
+        d_off = torch.empty(E + 1, dtype=torch.int64, device=dev)
+        d_end = torch.empty(E, dtype=torch.int64, device=dev)
+        nbytes = eng.synth_view_device(this_cfg, first, E, align, d_off.data_ptr(), d_end.data_ptr(), 0, 0, 0, 0)
+        d_pay = torch.empty(nbytes + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+        d_iss = torch.empty(E, dtype=torch.int32, device=dev)
+        d_et = torch.empty(E, dtype=torch.uint8, device=dev)
+        eng.synth_view_device(this_cfg, first, E, align, d_off.data_ptr(), d_end.data_ptr(), d_pay.data_ptr(), d_pay.numel(),
+                              d_iss.data_ptr(), d_et.data_ptr())
+        d_rec = torch.empty(E * 32, dtype=torch.uint8, device=dev)
+        d_new = torch.empty(E, dtype=torch.int64, device=dev)
+        raw_view["aligned"] = (d_end, nbytes, N.EntryView(cert_start=d_off.data_ptr(), cert_end=d_end.data_ptr(),
+                                                          issuer_idx=d_iss.data_ptr(), entry_type=d_et.data_ptr(),
+                                                          timestamp=None, chain0_start=None, chain0_len=None))
         torch.cuda.synchronize()
         return d_off, d_pay, d_iss, d_et, d_rec, d_new
 
@@ -707,6 +736,9 @@ def main():
             gi = group.info()
             phase_ms[:] += np.array(list(gi.ms_phase))
             wire[0] += int(gi.wire_bytes_sent); wire[1] += int(gi.keys_sent); wire[2] += int(gi.filter_bytes_received)
+        elif args.aligned:
+            st = eng.map_view_device(d_pay.data_ptr(), raw_view["aligned"][1], raw_view["aligned"][2], E, d_rec.data_ptr(),
+                                     d_new.data_ptr())
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(),
                                       E, d_rec.data_ptr(), d_new.data_ptr())
@@ -773,7 +805,7 @@ def main():
     vname = MAP_KERNELS[args.variant or DEFAULT_VARIANT]
     kname = vname.split("<")[0]
     kernels = [kname] + (["k_decode_match"] if args.raw else []) + (["k_meta_new"] if args.meta else [])
-    mode_args = (["--mixed"] if args.mixed else []) + (["--raw"] if args.raw else []) + (["--meta"] if args.meta else []) + \
+    mode_args = (["--mixed"] if args.mixed else []) + (["--aligned", str(args.aligned)] if args.aligned else []) + (["--raw"] if args.raw else []) + (["--meta"] if args.meta else []) + \
                 (["--trusted-chain"] if args.trusted_chain else []) + (["--global-dedup", args.global_dedup] if args.global_dedup else [])
     plain = not (args.raw or args.global_dedup or args.meta)
     if rank == 0 and world == 1 and not os.environ.get("CTMR_BENCH_CHILD"):
@@ -805,7 +837,12 @@ def main():
     value = n_total * args.steps / dt
     # ALGORITHMIC bytes of the map kernel: Σ L_i + 45·E (+ 64 per PASS entry for the fused probe).  Raw
     # mode: L_i is the certificate the map parses (cert_end − cert_start), not the blob — decode + match are priced below.
-    cert_bytes = int((raw_view["end"] - raw_view["start"]).sum().item()) if args.raw else int(stats.payload_bytes)
+    if args.raw:
+        cert_bytes = int((raw_view["end"] - raw_view["start"]).sum().item())
+    elif args.aligned:
+        cert_bytes = int((raw_view["aligned"][0] - d_off[:E]).sum().item())
+    else:
+        cert_bytes = int(stats.payload_bytes)
     alg_bytes = cert_bytes + ALG_BYTES_FIXED * E
     fused_variant = (args.variant or DEFAULT_VARIANT) in FUSED
     if fused_variant:
@@ -921,6 +958,9 @@ def main():
                               "bound": "valu", "blocks_per_s": (stats.payload_bytes / 64 + 1.5 * E) / (ms_fp * 1e-3),
                               "matches_hashlib_on_first_1000": bool(okfp),
                               "note": "auxiliary op, not on the reference's path (SURVEY D2); VALU roofline in DESIGN.md §5"}
+    if args.aligned:
+        out["config"]["workload"] = (f"ALIGNED layout (every certificate at a multiple of {args.aligned} bytes, an entry view; "
+                                     f"{raw_view['aligned'][1] / E:.0f} B of payload per entry with the padding): " + out["config"]["workload"])
     if args.mixed:
         out["config"]["workload"] = "MIXED corpus (EC/RSA keys, OV-like subjects, GeneralizedTime): " + out["config"]["workload"]
     if args.meta and meta_ms:
@@ -965,7 +1005,7 @@ def main():
         out["kernel_ms"]["match"] = ds.ms_match
 
     # ---- oracle-checked sample of every rank's shard; the CPU baseline legs on rank 0 at N = 1
-    if not args.no_cpu and not args.raw:
+    if not args.no_cpu and not args.raw and not args.aligned:
         per_rank_sample = max(min(args.cpu_sample, total) // world, 1)
         per = args.sample_per_slice or max(1, min(per_rank_sample, E) // args.sample_slices)
         base_cpu, pinfo, arrays, ranges = oracle_sample_check(np, torch, ctmr, synth, N, cfg, dup_permille, issuers, filt, now, dev,
@@ -1026,46 +1066,65 @@ def main():
                     "one_core": {"value": base_cpu["value"], "sample": base_cpu["sample"]}}
                 del arrays_mt, pay_mt
 
-    # ---- secondary.mixed: the same line on the corpus that looks like a real log (the driver's record carries both)
-    if (rank == 0 and world == 1 and plain and not args.mixed and not args.no_secondary and not os.environ.get("CTMR_BENCH_CHILD")
-            and not args.variant and not args.pem and not args.fingerprint):
-        try:
-            eng.close()
-            eng = d_off = d_pay = d_iss = d_et = d_rec = d_new = None
-            torch.cuda.empty_cache()
-            mcfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
-                                ca_permille=10, expired_permille=10, profile=1)
-            eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(0, E, mcfg)
-            mms, mst = [], None
-            for k in range(1 + 3):
-                eng.reset_known()
-                torch.cuda.synchronize()
-                t0m = time.perf_counter()
-                mst = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
-                                           d_rec.data_ptr(), d_new.data_ptr())
-                if k:
-                    mms.append((time.perf_counter() - t0m, mst.ms_map))
-            m_step = sum(t for t, _ in mms) / len(mms)
-            m_map = sum(m for _, m in mms) / len(mms)
-            m_alg = int(mst.payload_bytes) + ALG_BYTES_FIXED * E + ALG_BYTES_PROBE * int(mst.by_status[0])
-            sec = {"workload": "the same batch on the MIXED corpus (half EC P-256 keys, 40 % OV-like subjects of 120-260 B, longer "
-                               "issuer names, one GeneralizedTime in four): the lanes of a wave do not walk identical layouts",
-                   "value": E / m_step, "unit": "certificates/sec", "ms_per_step": m_step * 1e3, "steps": len(mms),
-                   "note": "step = table clear + map_batch, host-timed like the headline (reset_known is asynchronous: the clear overlaps nothing else)",
-                   "map_ms": m_map, "mean_der_bytes": int(mst.payload_bytes) / E,
-                   "frac_algorithmic": m_alg / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "frac": None}
-            if args.traffic == "auto":
-                margs = argparse.Namespace(**vars(args))
-                mt, merr = measure_traffic(margs, min(E, args.traffic_entries), [kname], ["--mixed"])
-                if mt:
-                    sec["traffic_bytes_per_cert"] = mt["traffic_bytes_per_cert"]
-                    sec["traffic"] = mt["traffic_bytes_per_cert"] * E
-                    sec["frac"] = sec["traffic"] / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS
-                else:
-                    sec["traffic_error"] = merr
-            out["secondary"] = {"mixed": sec}
-        except (ctmr.CtmrError, RuntimeError) as ex:
-            out["secondary"] = {"mixed": {"error": str(ex)}}
+    # ---- secondary lines inside the default run (the driver's record carries them next to the headline):
+    #      mixed      the same batch on the corpus that looks like a real log
+    #      aligned128 the headline corpus with every certificate laid at a multiple of 128 bytes (what the layout is worth)
+    if (rank == 0 and world == 1 and plain and not args.mixed and not args.aligned and not args.no_secondary
+            and not os.environ.get("CTMR_BENCH_CHILD") and not args.variant and not args.pem and not args.fingerprint):
+        out["secondary"] = {}
+        legs = (("mixed", 1, 0, "the same batch on the MIXED corpus (half EC P-256 keys, 40 % OV-like subjects of 120-260 B, longer "
+                 "issuer names, one GeneralizedTime in four): the lanes of a wave do not walk identical layouts", ["--mixed"]),
+                ("aligned128", 0, 128, "the headline corpus with every certificate laid at a multiple of 128 bytes (an entry view; "
+                 "the payload grows by the padding): the front window of a certificate then starts on a line boundary", ["--aligned", "128"]))
+        for name, profile, align, what, leg_args in legs:
+            try:
+                if eng is not None:
+                    eng.close()
+                eng = d_off = d_pay = d_iss = d_et = d_rec = d_new = None
+                raw_view.clear()
+                torch.cuda.empty_cache()
+                lcfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
+                                    ca_permille=10, expired_permille=10, profile=profile)
+                args.aligned = align
+                eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(0, E, lcfg)
+                mms, mst = [], None
+                for k in range(1 + 3):
+                    torch.cuda.synchronize()
+                    t0m = time.perf_counter()
+                    eng.reset_known()
+                    if align:
+                        mst = eng.map_view_device(d_pay.data_ptr(), raw_view["aligned"][1], raw_view["aligned"][2], E,
+                                                  d_rec.data_ptr(), d_new.data_ptr())
+                    else:
+                        mst = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), E,
+                                                   d_rec.data_ptr(), d_new.data_ptr())
+                    if k:
+                        mms.append((time.perf_counter() - t0m, mst.ms_map))
+                m_step = sum(t for t, _ in mms) / len(mms)
+                m_map = sum(m for _, m in mms) / len(mms)
+                l_bytes = int((raw_view["aligned"][0] - d_off[:E]).sum().item()) if align else int(mst.payload_bytes)
+                m_alg = l_bytes + ALG_BYTES_FIXED * E + ALG_BYTES_PROBE * int(mst.by_status[0])
+                sec = {"workload": what, "value": E / m_step, "unit": "certificates/sec", "ms_per_step": m_step * 1e3, "steps": len(mms),
+                       "note": "step = table clear + one map/reduce call, host-timed like the headline",
+                       "map_ms": m_map, "mean_der_bytes": l_bytes / E, "n_new": int(mst.n_new),
+                       "frac_algorithmic": m_alg / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "frac": None}
+                if align:
+                    sec["payload_bytes_per_entry_with_padding"] = raw_view["aligned"][1] / E
+                    sec["same_results_as_the_packed_layout"] = bool(int(mst.n_new) == int(stats.n_new) and
+                                                                    [int(x) for x in mst.by_status] == [int(x) for x in stats.by_status])
+                if args.traffic == "auto":
+                    targs = argparse.Namespace(**dict(vars(args), aligned=0))
+                    mt, merr = measure_traffic(targs, min(E, args.traffic_entries), [kname], leg_args)
+                    if mt:
+                        sec["traffic_bytes_per_cert"] = mt["traffic_bytes_per_cert"]
+                        sec["traffic"] = mt["traffic_bytes_per_cert"] * E
+                        sec["frac"] = sec["traffic"] / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                    else:
+                        sec["traffic_error"] = merr
+                out["secondary"][name] = sec
+            except (ctmr.CtmrError, RuntimeError) as ex:
+                out["secondary"][name] = {"error": str(ex)}
+        args.aligned = 0
     if rank == 0:
         print(json.dumps(out))
     if group is not None:

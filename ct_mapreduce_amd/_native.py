@@ -177,6 +177,8 @@ SIGNATURES = {
                                      _P, _P]),
     "ctmr_synth_device": (C.c_int, [_P, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P,
                                     C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
+    "ctmr_synth_view_device": (C.c_int, [_P, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.c_uint32, _P, _P, _P,
+                                         C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
 }
 
 _LIB = None

@@ -208,6 +208,38 @@ __global__ void __launch_bounds__(256) k_synth_len(SynthCfg c, uint64_t first, u
   if (i == 0) offsets[0] = 0;
 }
 
+// Entry-view form of the same certificates: certificate i at starts[i] (a multiple of `align` once scanned), ends[i] =
+// starts[i] + its length.  k_synth_len_view leaves the PADDED lengths in starts[1..n] (scanned by the host) and the true
+// lengths in ends[]; k_synth_emit_view writes the bytes and turns ends[] into end positions.
+__global__ void __launch_bounds__(256) k_synth_len_view(SynthCfg c, uint64_t first, uint64_t n, uint32_t align,
+                                                        uint64_t* starts, uint64_t* ends) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  BackWriter w{nullptr, SYNTH_MAX_LEN};
+  uint32_t iss;
+  uint8_t et;
+  synth_leaf_emit(c, first + i, w, iss, et);
+  const uint64_t len = SYNTH_MAX_LEN - w.pos;
+  starts[i + 1] = (len + align - 1u) & ~(uint64_t)(align - 1u);  // align is a power of two
+  ends[i] = len;
+  if (i == 0) starts[0] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_synth_emit_view(SynthCfg c, uint64_t first, uint64_t n, const uint64_t* starts,
+                                                         uint64_t* ends, uint8_t* payload, uint32_t* issuer_idx,
+                                                         uint8_t* entry_type) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t len = (uint32_t)ends[i];
+  BackWriter w{payload + starts[i], len};
+  uint32_t iss;
+  uint8_t et;
+  synth_leaf_emit(c, first + i, w, iss, et);
+  issuer_idx[i] = iss;
+  entry_type[i] = et;
+  ends[i] = starts[i] + len;
+}
+
 __global__ void __launch_bounds__(256) k_synth_emit(SynthCfg c, uint64_t first, uint64_t n,
                                                     const uint64_t* offsets, uint8_t* payload,
                                                     uint32_t* issuer_idx, uint8_t* entry_type) {

@@ -561,6 +561,17 @@ class Engine:
         self._ck(self._lib.ctmr_reset_known(self._h))
 
     # ---- synthetic input (bench / tests)
+    def synth_view_device(self, cfg: N.SynthConfig, first, n, align, d_starts, d_ends, d_payload, payload_cap,
+                          d_issuer_idx, d_entry_type) -> int:
+        """The synthetic certificates as an entry view, every certificate at a multiple of `align` bytes."""
+        out = C.c_uint64()
+        self._ck(self._lib.ctmr_synth_view_device(
+            self._h, C.byref(cfg), first, n, align, C.c_void_p(d_starts), C.c_void_p(d_ends),
+            C.c_void_p(d_payload) if d_payload else None, payload_cap,
+            C.c_void_p(d_issuer_idx) if d_issuer_idx else None,
+            C.c_void_p(d_entry_type) if d_entry_type else None, C.byref(out)))
+        return out.value
+
     def synth_device(self, cfg: N.SynthConfig, first, n, d_offsets, d_payload, payload_cap,
                      d_issuer_idx, d_entry_type) -> int:
         out = C.c_uint64()

@@ -565,6 +565,14 @@ int ctmr_synth_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first
                       uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
                       uint32_t* d_issuer_idx, uint8_t* d_entry_type, uint64_t* payload_bytes);
 
+/* The same certificates as an ENTRY VIEW with every certificate starting at a multiple of `align` bytes (a power of two
+ * up to 4096): d_starts u64[n+1] (d_starts[n] = bytes used), d_ends u64[n]; feed it to ctmr_map_view_device.  What the map
+ * moves per certificate depends on where certificates start inside 128-byte lines: a host that writes
+ * its decoded entries at aligned offsets gets the difference for nothing.  With d_payload == NULL only the positions. */
+int ctmr_synth_view_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n, uint32_t align,
+                           uint64_t* d_starts, uint64_t* d_ends, uint8_t* d_payload, uint64_t payload_cap,
+                           uint32_t* d_issuer_idx, uint8_t* d_entry_type, uint64_t* payload_bytes);
+
 /* Raw get-entries form of the same synthetic entries (input of ctmr_decode_entries_*): entry i is
  * leaf_input ‖ extra_data with the certificate of ctmr_synth_leaf(i) as X509Entry (entry_type 0; extra_data = chain
  * [issuer]) or as PrecertChainEntry.pre_certificate (entry_type 1; the leaf carries issuer_key_hash + the TBS; chain

@@ -116,3 +116,45 @@ def test_config2_ten_million_256_issuers_properties():
     assert st2.n_new == 0 and st2.n_dup == int((status == N.ST_PASS).sum())
     assert (eng.issuer_counts().astype(np.int64) == counts).all()
     eng.close()
+
+
+def test_aligned_entry_view_is_the_same_certificates_at_aligned_offsets():
+    """ctmr_synth_view_device (bench.py --aligned, secondary.aligned128): the synthetic certificates laid at multiples of
+    128 bytes as an entry view — byte-identical certificates, identical records / NEW list / counts through
+    ctmr_map_view_device."""
+    n, dev = 200_000, torch.device("cuda:0")
+    cfg = synth.config(seed=20260921 + 4, n_issuers=64, zipf=1, dup_permille=50, ca_permille=10, expired_permille=10)
+    results = []
+    for align in (0, 128):
+        eng = ctmr.Engine(device=0, table_slots=1 << 19, pair_slots=1 << 16)
+        eng.add_issuers(synth.issuers(cfg))
+        eng.set_filter(b"Synth Issuer 0", False, NOW)
+        d_rec = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+        d_new = torch.empty(n, dtype=torch.int64, device=dev)
+        if align:
+            d_st = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            d_en = torch.empty(n, dtype=torch.int64, device=dev)
+            total = eng.synth_view_device(cfg, 0, n, align, d_st.data_ptr(), d_en.data_ptr(), 0, 0, 0, 0)
+            d_pay = torch.zeros(total + N.PAYLOAD_PAD + 16, dtype=torch.uint8, device=dev)
+            d_iss = torch.empty(n, dtype=torch.int32, device=dev)
+            d_et = torch.empty(n, dtype=torch.uint8, device=dev)
+            eng.synth_view_device(cfg, 0, n, align, d_st.data_ptr(), d_en.data_ptr(), d_pay.data_ptr(), d_pay.numel(),
+                                  d_iss.data_ptr(), d_et.data_ptr())
+            assert int((d_st[:n] % align).abs().sum().item()) == 0 and int(d_st[n].item()) == total
+            view = N.EntryView(cert_start=d_st.data_ptr(), cert_end=d_en.data_ptr(), issuer_idx=d_iss.data_ptr(),
+                               entry_type=d_et.data_ptr(), timestamp=None, chain0_start=None, chain0_len=None)
+            st = eng.map_view_device(d_pay.data_ptr(), total, view, n, d_rec.data_ptr(), d_new.data_ptr())
+            lens = (d_en - d_st[:n]).cpu().numpy()
+            first = d_pay[int(d_st[5].item()):int(d_en[5].item())].cpu().numpy().tobytes()
+        else:
+            d_off, d_pay, d_iss, d_et, total = device_batch(eng, cfg, 0, n, dev)
+            st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
+                                      d_rec.data_ptr(), d_new.data_ptr())
+            lens = np.diff(d_off.cpu().numpy())
+            first = d_pay[int(d_off[5].item()):int(d_off[6].item())].cpu().numpy().tobytes()
+        results.append((d_rec.cpu().numpy().copy(), d_new[:st.n_new].cpu().numpy().copy(), int(st.n_new),
+                        [int(x) for x in st.by_status], eng.issuer_counts().copy(), lens, first, d_iss.cpu().numpy().copy()))
+        eng.close()
+    a, b = results
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2] == b[2] > 0 and a[3] == b[3]
+    assert (a[4] == b[4]).all() and (a[5] == b[5]).all() and a[6] == b[6] == synth.leaf(cfg, 5)[0] and (a[7] == b[7]).all()
