@@ -112,3 +112,72 @@ def test_rccl_transport_with_several_ranks_on_one_gpu(world, mode):
     assert all(o_["max"] == world for o_ in outs)
     if mode == "owner":
         assert sum(o_["keys_sent"] for o_ in outs) == sum(o_["keys_received"] for o_ in outs) > 0
+
+
+FAIL_CHILD = r'''
+import json, sys, threading, time
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import synth
+from ct_mapreduce_amd.distributed import Group, shard, shard_range
+
+world, mode = int(sys.argv[2]), sys.argv[3]
+DEV = torch.device("cuda:0")
+cfg = synth.config(seed=58, n_issuers=8, dup_permille=200)
+issuers = synth.issuers(cfg)
+gid = Group.unique_id()
+out = [None] * world
+
+def rank_main(r):
+    lo, hi = shard_range(4000, r, world)
+    b = synth.host_batch(cfg, lo, hi - lo)
+    pay = torch.from_numpy(np.concatenate([b.payload, np.zeros(64, np.uint8)])).to(DEV)
+    off = torch.from_numpy(b.offsets.astype(np.int64)).to(DEV)
+    iss = torch.from_numpy(b.issuer_idx.astype(np.int32)).to(DEV)
+    et = torch.from_numpy(b.entry_type).to(DEV)
+    rec = torch.zeros(b.n * 32, dtype=torch.uint8, device=DEV)
+    e = ctmr.Engine(device=0, table_slots=1 << 14, pair_slots=1 << 10)
+    e.add_issuers(issuers)
+    e.set_filter(b"", False, synth.BASE_TIME)
+    g = Group.rccl(e, gid, r, world)
+    if mode == "bloom":
+        g.bloom_config(1 << 14)
+    t0 = time.time()
+    try:
+        # rank 1 forgets its records buffer: ITS call fails — and so must everybody's, instead of waiting for it for ever
+        g.map_batch(mode, [shard(pay.data_ptr(), off.data_ptr(), iss.data_ptr(), et.data_ptr(), b.n,
+                                 0 if r == 1 else rec.data_ptr(), 0, order_base=lo)])
+        out[r] = {"error": None}
+    except ctmr.CtmrError as ex:
+        out[r] = {"error": ex.code, "msg": str(ex), "seconds": time.time() - t0}
+    g.close()
+    e.close()
+
+ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+for t in ts: t.start()
+for t in ts: t.join(40)
+print(json.dumps({"out": out, "hung": [r for r, t in enumerate(ts) if t.is_alive()]}))
+sys.stdout.flush()
+import os
+os._exit(0)
+'''
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom"])
+def test_a_rank_that_fails_does_not_leave_its_peers_in_a_collective(mode):
+    """Round-2 advisor finding: a rank-local failure before or between collectives returned early on that rank only and
+    every peer blocked for ever in the next all-gather / send-recv.  The control rows carry a status word now: all three
+    ranks come back with an error, promptly."""
+    env = dict(os.environ, CTMR_RCCL_LIB=build_fake())
+    p = subprocess.run([sys.executable, "-c", FAIL_CHILD, ROOT, "3", mode], env=env, capture_output=True, text=True, timeout=120)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert line, p.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert not res["hung"], res
+    outs = res["out"]
+    assert all(o_ is not None and o_["error"] is not None for o_ in outs), outs
+    assert outs[1]["error"] == -1 and "d_records" in outs[1]["msg"]              # the culprit: CTMR_E_INVAL, its own message
+    assert all("rank 1 failed" in outs[r]["msg"] for r in (0, 2)), outs          # the others: told who it was
+    assert all(o_["seconds"] < 20 for o_ in outs)
