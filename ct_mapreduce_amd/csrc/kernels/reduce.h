@@ -428,7 +428,11 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
           mine = rem_owner == xa.rank;
         }
         if (mine) {
+#ifdef CTMR_EXP_NO_PROBE  // sweep builds, MEASUREMENT ONLY (wrong results): the kernel without any table access
+          state = ES_CLAIMED;
+#else
           state = insert_probe_h(ia, i, meta, s, h, claimed, q0, q1, q2, q3);
+#endif
         } else {  // (XM_OWNER) the record that leaves; serials of 21..40 octets take the 64-byte path (k_xl_export)
           state = ES_REMOTE;
           rem_long = slen > 20u;
@@ -455,7 +459,11 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   }
   store_records_wave(a, first, live, o0, o1);
   __builtin_amdgcn_wave_barrier();
+#ifdef CTMR_EXP_NO_SLOT_IMAGE  // sweep builds, MEASUREMENT ONLY (wrong results): what the slot image store adds to WRITE_SIZE
+  (void)q0; (void)q1; (void)q2; (void)q3;
+#else
   store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
+#endif
   if constexpr (MODE == XM_OWNER) {
     // the wave's key records, grouped by owner: one ballot per rank gives every record its place and the per-owner counts
     const bool rem = rem_owner != KEY_NO_OWNER && rem_owner != xa.rank && !rem_long;
