@@ -713,7 +713,8 @@ def main():
         group = Group.local([eng])          # N = 1: no peer — this prices each mode's kernels on one rank
     if mode == "bloom":
         per_rank = max(E, (total + world - 1) // world)
-        group.bloom_config(pow2_at_least(16 * per_rank))       # ≈16 filter bits per key held; same size on every rank
+        bits_per_key = int(os.environ.get("CTMR_BLOOM_BITS_PER_KEY", 16))
+        group.bloom_config(pow2_at_least(bits_per_key * per_rank))   # ≈16 filter bits per key held; same size on every rank
     global_counts = [None]
     dstats = []
     meta_ms, meta_items = [], []

@@ -367,7 +367,8 @@ int ctmr_group_create_rccl(ctmr_engine* engine, const uint8_t id[CTMR_GROUP_ID_B
 void ctmr_group_destroy(ctmr_group* g);
 const char* ctmr_group_last_error(const ctmr_group* g);
 int ctmr_group_info(ctmr_group* g, ctmr_group_stats* out);
-/* bits per rank: power of two, ≈16 per key a rank will ever hold; same on every rank. */
+/* bits per rank: power of two, ≈16 per key a rank will ever hold; same on every rank.  (A group of ONE rank has no peer
+ * to ask: it keeps no filter and its Bloom rounds are the plain reduce.) */
 int ctmr_group_bloom_config(ctmr_group* g, uint64_t bits);
 int ctmr_group_map_batch(ctmr_group* g, int mode, const ctmr_shard* shards, ctmr_batch_stats* stats);
 /* Σ over ALL ranks of ctmr_issuer_counts / ctmr_total_count (storage-statistics.go:44-53 over the whole deployment):
