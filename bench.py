@@ -302,6 +302,8 @@ def spawn_ranks(n):
     ranks are done), starts one copy of itself per rank with RANK / LOCAL_RANK / WORLD_SIZE and the id in the
     environment, lets rank 0's line through and returns the worst exit code."""
     import subprocess
+    import torch  # noqa: F401  (the ranks import torch before the library loads librccl: the id must come from the SAME
+    #                             librccl — PyTorch-ROCm bundles one under the same SONAME — not from another version's bootstrap)
     from ct_mapreduce_amd.distributed import Group
     gid = Group.unique_id()
     procs = []
