@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32
 
 
-MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16>", 15: "k_map_fused<16, false>"}   # 1, 2: sweep build only
+MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16>", 15: "k_map_fused<16, false, 0>"}   # 1, 2: sweep build only
 DEFAULT_VARIANT = 15
 FUSED = (15,)          # map kernels that also do pass 1 of the known-certificate insert
 ALG_BYTES_PROBE = 64   # per PASS entry: 32 B slot read + 32 B slot write — fused kernels only
@@ -852,7 +852,8 @@ def main():
         alg_bytes += ALG_BYTES_PROBE * int(stats.by_status[0])
     avg_ms = sum(ms_map) / len(ms_map)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    shard_note = (f"{n_total} entries in ONE batch split by log-index range over {world} GPUs" if not weak
+    shard_note = (f"{n_total} entries in one batch on one GPU" if world == 1 else
+                  f"{n_total} entries in ONE batch split by log-index range over {world} GPUs" if not weak
                   else f"{args.entries} entries per GPU x {world}")
     parallelism = {"plain": "1 GPU, one known-certificate set",
                    "local": f"log-index shards x{world}, PER-SHARD sets (NOT the reference's single set: a key that spans two shards "

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <system_error>
 #include <thread>
 #include <cmath>
 #include <cstdarg>
