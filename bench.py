@@ -333,77 +333,114 @@ def group_id_from_launcher(rank, make_id):
     return box[0]
 
 
-def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers):
-    """BASELINE config 5 on ONE GPU (the cross-GPU form is distributed.run_global_dedup): a long stream with 10 %
-    duplicates, the known-certificate table persisting across waves."""
+def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers, gid=None):
+    """BASELINE configs[4]: a long stream with 10 % duplicates, the known-certificate sets persisting across waves.  One GPU:
+    one engine, one table.  N > 1: every wave is split by log-index range over the ranks and deduplicated GLOBALLY through
+    the group (owner-computes by default — in a long stream it moves fewer bytes than ever-growing filters; --dedup bloom for
+    the north_star's variant); the sets persist on the ranks across the waves."""
+    from ct_mapreduce_amd.distributed import Group, shard as make_shard, shard_range
     T = args.stream
-    W = args.entries or 50_000_000
-    W = min(W, T)
+    W = min(args.entries or 50_000_000, T)              # entries per wave, over all ranks
     cfg = synth.config(seed=20260921 + 5, n_issuers=args.issuers, zipf=1, dup_permille=100, ca_permille=10,
                        expired_permille=10)
-    slots = pow2_at_least(int(T * 1.6))
-    eng = ctmr.Engine(device=local, table_slots=min(slots, 1 << 31), pair_slots=1 << 22, map_variant=args.variant,
-                      profile=True)
+    mode = "plain" if world == 1 else (args.dedup if args.dedup != "auto" else "owner")
+    per_rank_keys = (T + world - 1) // world
+    slots = min(pow2_at_least(int(per_rank_keys * 1.6)), 1 << 31)
+    eng = ctmr.Engine(device=local, table_slots=slots, pair_slots=1 << 22, map_variant=args.variant, profile=True)
     eng.add_issuers(synth.issuers(cfg))
     eng.set_filter(filt, False, now)
-    d_off = torch.empty(W + 1, dtype=torch.int64, device=dev)
-    d_iss = torch.empty(W, dtype=torch.int32, device=dev)
-    d_et = torch.empty(W, dtype=torch.uint8, device=dev)
-    d_rec = torch.empty(W * 32, dtype=torch.uint8, device=dev)
-    d_new = torch.empty(W, dtype=torch.int64, device=dev)
-    d_pay = torch.empty(int(W * 1600) + 4096, dtype=torch.uint8, device=dev)
+    group = None
+    if world > 1:
+        group = Group.rccl(eng, gid, rank, world)
+        if mode == "bloom":
+            group.bloom_config(pow2_at_least(16 * per_rank_keys))
+    Wr = (W + world - 1) // world + 1                    # the largest shard of a wave
+    d_off = torch.empty(Wr + 1, dtype=torch.int64, device=dev)
+    d_iss = torch.empty(Wr, dtype=torch.int32, device=dev)
+    d_et = torch.empty(Wr, dtype=torch.uint8, device=dev)
+    d_rec = torch.empty(Wr * 32, dtype=torch.uint8, device=dev)
+    d_new = torch.empty(Wr, dtype=torch.int64, device=dev)
+    d_pay = torch.empty(int(Wr * 1600) + 4096, dtype=torch.uint8, device=dev)
     t_gpu = t_map = 0.0
     tot_new = tot_dup = tot_pass = tot_bytes = 0
+    bad_entries = 0
+    wire = 0
     ok = True
     waves = 0
     first = 0
     while first < T:
-        n = min(W, T - first)
-        eng.synth_device(cfg, first, n, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_iss.data_ptr(),
-                         d_et.data_ptr())
+        n_wave = min(W, T - first)
+        lo, hi = shard_range(n_wave, rank, world)
+        n = hi - lo
+        if n:
+            eng.synth_device(cfg, first + lo, n, d_off.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_iss.data_ptr(),
+                             d_et.data_ptr())
         torch.cuda.synchronize()
+        if group is not None:
+            group.barrier()
         t0 = time.perf_counter()
-        st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
-                                  d_rec.data_ptr(), d_new.data_ptr())
+        if group is not None:
+            st = group.map_batch(mode, [make_shard(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
+                                                   d_rec.data_ptr(), d_new.data_ptr(), order_base=first + lo)])[0]
+            wire += int(group.info().wire_bytes_sent)
+        else:
+            st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
+                                      d_rec.data_ptr(), d_new.data_ptr())
         t_gpu += time.perf_counter() - t0
         t_map += st.ms_map
         # the generator's structure: entry i duplicates an EARLIER entry's key iff synth_is_dup(i) — in this wave or
-        # any earlier one — so PASS ∧ dup must be known and PASS ∧ ¬dup must be new, wave by wave
-        status = d_rec.view(-1, 32)[:n, 0].cpu().numpy()
-        dup = synth_is_dup(cfg.seed, first, n, 100, np)
-        exp_new = int(((status == 0) & ~dup).sum())
-        exp_dup = int(((status == 0) & dup).sum())
+        # any earlier one, on this rank or any other — so PASS ∧ dup must be known and PASS ∧ ¬dup must be new, wave by wave
+        recs = d_rec.view(-1, 32)[:n]
+        passed = recs[:, 0] == 0
+        is_new = (recs[:, 1] & 2) != 0
+        dupm = synth_is_dup_torch(cfg.seed, first + lo, n, 100, torch, dev)
+        exp_new = int((passed & ~dupm).sum().item())
+        exp_dup = int((passed & dupm).sum().item())
+        bad_entries += int((is_new != (passed & ~dupm)).sum().item())
         good = exp_new == int(st.n_new) and exp_dup == int(st.n_dup)
         ok = ok and good
-        sys.stderr.write(f"stream: wave {waves} [{first}, {first + n}) new {st.n_new} dup {st.n_dup} "
+        sys.stderr.write(f"stream: rank {rank} wave {waves} [{first + lo}, {first + hi}) new {st.n_new} dup {st.n_dup} "
                          f"({'ok' if good else 'MISMATCH: expected %d/%d' % (exp_new, exp_dup)}) "
                          f"map {st.ms_map:.2f} ms total {st.ms_total:.2f} ms\n")
         tot_new += int(st.n_new); tot_dup += int(st.n_dup); tot_pass += int(st.by_status[0])
         tot_bytes += int(st.payload_bytes) + ALG_BYTES_FIXED * n + ALG_BYTES_PROBE * int(st.by_status[0])
-        first += n
+        first += n_wave
         waves += 1
-    ok = ok and eng.total_count() == tot_new
+    total_count = eng.total_count()
+    if group is not None:
+        # the slowest rank's time; the sums over the ranks; every rank must have matched the generator in every wave
+        t_gpu = float(group.all_reduce_u64([int(t_gpu * 1e9)], op_max=True)[0]) * 1e-9
+        tot_new, tot_dup, tot_pass, bad_entries, not_ok, total_count = (int(v) for v in group.all_reduce_u64(
+            [tot_new, tot_dup, tot_pass, bad_entries, 0 if ok else 1, total_count]))
+        ok = not_ok == 0
+    ok = ok and total_count == tot_new and bad_entries == 0
     achieved = tot_bytes / (t_map * 1e-3) / 1e9
     # measured HBM traffic of the map kernel in this mode: a 40 M-entry stream in 4 waves of 10 M under rocprofv3 --pmc
     # (the table persists across the waves, as here; bytes per entry averaged over the launches)
     traffic_info = traffic_err = None
-    if args.traffic == "auto" and not os.environ.get("CTMR_BENCH_CHILD"):
+    if world == 1 and args.traffic == "auto" and not os.environ.get("CTMR_BENCH_CHILD"):
         kname = MAP_KERNELS[args.variant or DEFAULT_VARIANT].split("<")[0]
         traffic_info, traffic_err = measure_traffic(args, 10_000_000, [kname], ["--stream", "40000000"])
     out = {"metric": "certificates/sec whole-node + achieved HBM GB/s, 100M-entry synthetic CT batch",
-           "value": T / t_gpu, "unit": "certificates/sec", "n_gpus": 1, "steps": waves, "warmup": 0,
-           "ms_per_step": t_gpu / waves * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "value": T / t_gpu, "unit": "certificates/sec", "n_gpus": world, "steps": waves, "warmup": 0,
+           "ms_per_step": t_gpu / waves * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
-           "config": {"workload": f"STREAM of {T} entries with 10% duplicates in {waves} waves of {W} through one "
-                                  "known-certificate table (BASELINE configs[4] on one GPU); generation untimed",
-                      "table_slots": int(min(slots, 1 << 31)), "map_variant": args.variant or DEFAULT_VARIANT},
-           "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or DEFAULT_VARIANT], "achieved": achieved,
+           "config": {"workload": f"STREAM of {T} entries with 10% duplicates in {waves} waves of {W}"
+                                  + (" through one known-certificate table (BASELINE configs[4] on one GPU)" if world == 1 else
+                                     f", every wave split by log-index range over {world} GPUs, sets persisting on the ranks "
+                                     "(BASELINE configs[4])") + "; generation untimed",
+                      "dedup": mode, "table_slots_per_rank": int(slots), "map_variant": args.variant or DEFAULT_VARIANT},
+           "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or DEFAULT_VARIANT].split("<")[0] if world > 1 else
+                        MAP_KERNELS[args.variant or DEFAULT_VARIANT], "achieved": achieved,
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                        "achieved_basis": "ALGORITHMIC bytes / map kernel time",
+                        "achieved_basis": "ALGORITHMIC bytes of rank 0 / its map kernel time",
                         "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
                         "alg_bytes_formula": "sum(L_i) + 45*E + 64*PASS (table probe), summed over the waves"},
-           "result": {"n_new": tot_new, "n_dup": tot_dup, "n_pass": tot_pass, "total_count": eng.total_count(),
+           "result": {"n_new": tot_new, "n_dup": tot_dup, "n_pass": tot_pass, "total_count": total_count,
+                      "entries_disagreeing_with_generator": bad_entries,
                       "duplicate_structure_matches_generator_in_every_wave": bool(ok)}}
+    if group is not None:
+        out["exchange"] = {"mode": mode, "transport": "rccl", "wire_bytes_sent_by_rank0_over_the_stream": wire}
     if traffic_info:
         r = out["roofline"]
         r["traffic"] = traffic_info["traffic_bytes_per_cert"] * T          # over the whole stream
@@ -413,7 +450,10 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
         r["achieved_basis"] = "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, 40 M-entry stream of the same corpus) / map kernel time"
     elif traffic_err:
         out["roofline"]["traffic_error"] = traffic_err
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if group is not None:
+        group.close()
     eng.close()
 
 
@@ -534,6 +574,8 @@ def main():
                          "outside the slices whose key a sampled duplicate repeats")
     args = ap.parse_args()
 
+    if args.stream and (args.raw or args.global_dedup or args.meta or args.pem or args.fingerprint):
+        ap.error("--stream runs the plain map/reduce (with --gpus N: through the group)")
     if args.aligned and (args.raw or args.global_dedup or args.gpus > 1 or args.stream or args.pem or args.fingerprint or args.meta):
         ap.error("--aligned is a layout variant of the plain one-GPU line")
     if args.aligned & (args.aligned - 1):
@@ -577,7 +619,7 @@ def main():
     issuers = synth.issuers(cfg)
 
     if args.stream:
-        return run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers)
+        return run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers, gid)
 
     # ---- the workload: one batch split by log index (strong), or E entries per GPU (weak)
     env_total = int(os.environ.get("CTMR_BENCH_ENTRIES", 0))

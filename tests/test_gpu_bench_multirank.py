@@ -76,3 +76,16 @@ def test_one_gpu_line_still_carries_its_checks():
     assert d["n_gpus"] == 1 and d["config"]["dedup"] == "plain" and "exchange" not in d
     assert d["checks"]["entries_disagreeing_with_generator"] == 0 and d["checks"]["per_issuer_counts_match_generator"]
     assert d["parity_vs_oracle_on_sample"] is True and d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("dedup", ["auto", "bloom"])
+def test_stream_over_several_ranks_keeps_its_sets_across_waves(dedup):
+    """BASELINE configs[4] in its multi-GPU form: a stream with 10 % duplicates in waves, every wave split by log index
+    over the ranks, the known-certificate sets persisting on the ranks; every wave's NEW / known counts and every entry's
+    WasUnknown equal the generator's structure, the ranks' sets add up to Σ NEW."""
+    d = run_bench(["--gpus", "3", "--stream", "400000", "--entries", "100000", "--dedup", dedup, "--traffic", "off"])
+    assert d["n_gpus"] == 3 and d["steps"] == 4 and d["config"]["dedup"] == ("owner" if dedup == "auto" else "bloom")
+    r = d["result"]
+    assert r["duplicate_structure_matches_generator_in_every_wave"] is True and r["entries_disagreeing_with_generator"] == 0
+    assert r["total_count"] == r["n_new"] > 300000 and r["n_dup"] > 20000
+    assert d["exchange"]["wire_bytes_sent_by_rank0_over_the_stream"] > 0
