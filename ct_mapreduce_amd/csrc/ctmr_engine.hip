@@ -159,6 +159,10 @@ struct RoundCtx {
   std::vector<uint64_t> counts32;
   std::vector<KeyRec> xl;   // … those records, sorted by (owner, order)
   bool resolved = false;    // owner-computes round: ctmr_xchg_insert_device has run
+  // members with serials longer than CTMR_MAX_SERIAL that this batch added to the host-side set, in log order: a group
+  // round settles them between the ranks afterwards (engine/group.inc: round_finish)
+  struct HostNew { uint64_t i; int32_t exp_hour; uint32_t canon; std::string member; };
+  std::vector<HostNew> host_list;
 };
 
 struct ctmr_engine {

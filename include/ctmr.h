@@ -266,7 +266,8 @@ typedef struct {
  *   apply:  the sender's records left the map with CTMR_FL_WAS_UNKNOWN set; the returned bytes (same order as the
  *           records were sent) take it away from the entries whose key was known; compacts d_new_idx, fills stats.
  *   Every rank must have registered the same issuers in the same order.  Serials longer than CTMR_MAX_SERIAL are not
- *   exchanged (they stay shard-local on the host side).  shard.d_records is required. ---- */
+ *   exchanged by these per-rank steps (each rank's host-side set decides them for its shard); ctmr_group_map_batch
+ *   settles them between the ranks at the end of the round.  shard.d_records is required. ---- */
 int ctmr_xchg_map_device(ctmr_engine* e, const ctmr_shard* shard, uint32_t world, uint32_t rank, uint32_t ord_base,
                          uint64_t* counts32, uint64_t* n_long);
 int ctmr_xchg_keys_device(ctmr_engine* e, void* d_keys32_out, void* d_keys64_out, uint64_t* counts64);
@@ -299,7 +300,7 @@ int ctmr_xchg_apply_device(ctmr_engine* e, const void* d_sent32, const uint8_t* 
  *           round continues it: only the entries that lose the flag are touched).
  *   d_ends NULL = packed batch (d_offsets has n+1 entries); otherwise entry-view ranges (ctmr_entry_view).
  *   d_records NULL = the engine's own records of the last map call.  Same issuers in the same order on every rank.
- *   Serials longer than CTMR_MAX_SERIAL stay shard-local on the host side, as above. ---- */
+ *   Serials longer than CTMR_MAX_SERIAL: as above (settled between the ranks by ctmr_group_map_batch). ---- */
 /* bits: power of two, 2^12..2^40, ≈16 per key this rank will ever hold.  d_words NULL: the library allocates the
  * filter; otherwise a caller-owned device buffer of bits/8 bytes (e.g. this rank's row of the all-gather buffer),
  * zeroed by the call, which must outlive the engine's use of it.  Same size on every rank. */
@@ -337,6 +338,10 @@ int ctmr_bloom_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, 
  *           CTMR_DEDUP_BLOOM  all-gather of per-GPU Bloom filters as an exact pre-filter (ctmr_bloom_* above; needs
  *                             ctmr_group_bloom_config): local insert → filter all-gather → probe → key records only to
  *                             the peers whose filter matched → exact lookup → flags back → apply
+ *           Both exact modes also settle the members with serials longer than CTMR_MAX_SERIAL (host-side sets) between
+ *           the ranks at the end of a round: the lists of such members added in the round are all-gathered with the
+ *           closing status row, a member some rank held before is known to every rank, otherwise the lowest log index
+ *           keeps it — stored once, like every other key.  A round without such members pays nothing for it.
  *   shards  one ctmr_shard (above) per LOCAL rank, rank order.  Ranks hold CONTIGUOUS log-index ranges in rank order
  *           (rank r's entries all precede rank r+1's: ct-fetch's -offset/-limit split).  d_records is required in the
  *           OWNER and BLOOM modes.  stats: one per local rank (may be NULL).

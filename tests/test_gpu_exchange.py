@@ -263,8 +263,9 @@ def test_raw_shards_with_synchronised_issuer_registration():
 def test_serials_of_every_length_across_ranks(world, mode):
     """Serial numbers of 1..45 octets, duplicated across shards.  The owner-computes exchange sends keys with serials of
     up to 20 octets as 32-byte records and the rare 21..40-octet ones as 64-byte records on a path of their own; serials
-    beyond CTMR_MAX_SERIAL stay in the shard-local host-side set (documented).  Everything up to 40 octets must dedup
-    globally exactly like the single-stream oracle, whichever rank owns the key and whichever rank saw it first."""
+    beyond CTMR_MAX_SERIAL live in host-side sets, which the group settles between the ranks at the end of the round.
+    Everything must dedup globally exactly like the single-stream oracle, whichever rank holds the key and whichever
+    rank saw it first."""
     import random
     from ct_mapreduce_amd.engine import Batch
     from tests import der as D
@@ -272,7 +273,7 @@ def test_serials_of_every_length_across_ranks(world, mode):
     issuer = synth.issuer(synth.config(n_issuers=1), 0)
     name = D.name(D.rdn(3, b"Synth Issuer 000"))
     uniq = []
-    for ln in list(range(1, 41)) * 6:                                # six keys of every length 1..40
+    for ln in list(range(1, 46)) * 6:                                # six keys of every length 1..45
         s = bytes([rng.randrange(1, 0x7f)] + [rng.randrange(256) for _ in range(ln - 1)])
         uniq.append(D.cert(serial=s, issuer=name, not_after=D.utctime("270101000000Z")))
     certs = list(uniq)
@@ -306,6 +307,61 @@ def test_serials_of_every_length_across_ranks(world, mode):
         assert g.info().wire_bytes_sent > 0
     stats2 = g.map_batch(mode, shards)                              # replay: everything is known, wherever it lives
     assert all(s.n_new == 0 for s in stats2)
+    g.close()
+    for e in engines:
+        e.close()
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom"])
+def test_long_serials_across_ranks_and_rounds(mode):
+    """Serials beyond CTMR_MAX_SERIAL (41..60 octets; Go's parser takes any length): round 1 puts each key on some rank,
+    round 2 presents the same keys to OTHER ranks together with fresh ones, twice within the round on different ranks —
+    a member some rank held before is known everywhere, a fresh one goes to the lowest log index, every member is stored
+    once (Σ total_count = the oracle's), and the NEW lists follow."""
+    import random
+    from ct_mapreduce_amd.engine import Batch
+    from tests import der as D
+    rng = random.Random(99)
+    world = 3
+    issuer = synth.issuer(synth.config(n_issuers=1), 0)
+    name = D.name(D.rdn(3, b"Synth Issuer 000"))
+    def cert(ln):
+        s = bytes([rng.randrange(1, 0x7f)] + [rng.randrange(256) for _ in range(ln - 1)])
+        return D.cert(serial=s, issuer=name, not_after=D.utctime("270101000000Z"))
+    first = [cert(rng.choice((41, 44, 48, 60, 12, 30))) for _ in range(60)]
+    fresh = [cert(rng.choice((41, 45, 50, 8))) for _ in range(40)]
+    round1 = list(first)
+    round2 = first[::-1] + fresh + fresh[::-1] + first[:10]          # old keys on other ranks, fresh ones twice
+    rng.shuffle(round2)
+    o = None
+    engines = []
+    for _ in range(world):
+        e = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10)
+        e.add_issuers([issuer])
+        e.set_filter(b"", True, 0)
+        engines.append(e)
+    g = Group.local(engines)
+    if mode == "bloom":
+        g.bloom_config(1 << 14)
+    base = 0
+    for rnd, certs in enumerate((round1, round2, round2)):
+        whole = Batch.from_certs(certs, [0] * len(certs))
+        whole.payload = np.concatenate([whole.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+        o, st, unk, eh = run_oracle(whole, [issuer], b"", True, 0, engine=o)
+        assert (st == 0).all() and int(unk.sum()) == (len(first), len(fresh), 0)[rnd]
+        keep, shards, ranges = [], [], []
+        for r in range(world):
+            lo, hi = shard_range(len(certs), r, world)
+            t = to_dev(Batch.from_certs(certs[lo:hi], [0] * (hi - lo)))
+            keep.append(t)
+            shards.append(dev_shard(t, hi - lo, order_base=base + lo))
+            ranges.append((lo, hi))
+        stats = g.map_batch(mode, shards)
+        check_shards_against_oracle(keep, stats, ranges, st, unk)
+        assert sum(int(s.n_host_set) for s in stats) > 0
+        assert g.total_count() == o.total_count()
+        base += len(certs)
+    assert g.total_count() == len(first) + len(fresh)
     g.close()
     for e in engines:
         e.close()

@@ -181,3 +181,95 @@ def test_a_rank_that_fails_does_not_leave_its_peers_in_a_collective(mode):
     assert outs[1]["error"] == -1 and "d_records" in outs[1]["msg"]              # the culprit: CTMR_E_INVAL, its own message
     assert all("rank 1 failed" in outs[r]["msg"] for r in (0, 2)), outs          # the others: told who it was
     assert all(o_["seconds"] < 20 for o_ in outs)
+
+
+LONG_CHILD = r'''
+import json, random, sys, threading
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+import ct_mapreduce_amd as ctmr
+from ct_mapreduce_amd import synth, _native as N
+from ct_mapreduce_amd.distributed import Group, shard, shard_range
+from ct_mapreduce_amd.engine import Batch, RECORD_DTYPE
+from tests import der as D
+from tests.gpu_common import run_oracle
+
+world, mode = int(sys.argv[2]), sys.argv[3]
+DEV = torch.device("cuda:0")
+rng = random.Random(7)
+issuer = synth.issuer(synth.config(n_issuers=1), 0)
+name = D.name(D.rdn(3, b"Synth Issuer 000"))
+def cert(ln):
+    s = bytes([rng.randrange(1, 0x7f)] + [rng.randrange(256) for _ in range(ln - 1)])
+    return D.cert(serial=s, issuer=name, not_after=D.utctime("270101000000Z"))
+first = [cert(rng.choice((41, 44, 48, 60, 12, 30))) for _ in range(45)]
+fresh = [cert(rng.choice((41, 45, 50, 8))) for _ in range(30)]
+round2 = first[::-1] + fresh + fresh[::-1] + first[:10]
+rng.shuffle(round2)
+rounds, o, base = [], None, 0
+for certs in (first, round2, round2):
+    whole = Batch.from_certs(certs, [0] * len(certs))
+    whole.payload = np.concatenate([whole.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    o, st, unk, eh = run_oracle(whole, [issuer], b"", True, 0, engine=o)
+    rounds.append((certs, st, unk, base, int(o.total_count())))
+    base += len(certs)
+gid = Group.unique_id()
+out, errs = [None] * world, []
+
+def rank_main(r):
+    try:
+        e = ctmr.Engine(device=0, table_slots=1 << 12, pair_slots=1 << 10)
+        e.add_issuers([issuer])
+        e.set_filter(b"", True, 0)
+        g = Group.rccl(e, gid, r, world)
+        if mode == "bloom":
+            g.bloom_config(1 << 14)
+        ok, totals = True, []
+        for certs, st, unk, base, total in rounds:
+            lo, hi = shard_range(len(certs), r, world)
+            b = Batch.from_certs(certs[lo:hi], [0] * (hi - lo))
+            pay = torch.from_numpy(np.concatenate([b.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])).to(DEV)
+            off = torch.from_numpy(b.offsets.astype(np.int64)).to(DEV)
+            iss = torch.from_numpy(b.issuer_idx.astype(np.int32)).to(DEV)
+            et = torch.from_numpy(b.entry_type).to(DEV)
+            rec = torch.zeros(b.n * 32, dtype=torch.uint8, device=DEV)
+            new = torch.zeros(max(b.n, 1), dtype=torch.int64, device=DEV)
+            stats = g.map_batch(mode, [shard(pay.data_ptr(), off.data_ptr(), iss.data_ptr(), et.data_ptr(), b.n,
+                                             rec.data_ptr(), new.data_ptr(), order_base=base + lo)])[0]
+            recs = rec.cpu().numpy().view(RECORD_DTYPE)
+            ok = ok and bool((recs["status"] == st[lo:hi]).all() and (((recs["flags"] & 2) != 0) == (unk[lo:hi] != 0)).all())
+            newl = new[:stats.n_new].cpu().numpy()
+            ok = ok and stats.n_new == int(unk[lo:hi].sum()) and bool((newl == np.nonzero(unk[lo:hi])[0]).all())
+            totals.append(int(g.total_count()) == total)
+        out[r] = {"ok": ok, "totals": totals}
+        g.close()
+        e.close()
+    except Exception as ex:   # noqa: BLE001
+        errs.append(f"rank {r}: {type(ex).__name__}: {ex}")
+
+ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+for t in ts: t.start()
+for t in ts: t.join(40)
+hung = [r for r, t in enumerate(ts) if t.is_alive()]
+print(json.dumps({"out": out, "errs": errs, "hung": hung}))
+sys.stdout.flush()
+import os
+os._exit(0 if not hung else 3)
+'''
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom"])
+def test_long_serials_are_settled_over_the_rccl_transport(mode):
+    """Members with serials beyond CTMR_MAX_SERIAL live in host-side sets; a group round settles them between the ranks
+    through the closing control rows (all-gather of the round's additions, all-reduce of "held before").  Three ranks over
+    the stand-in librccl, three rounds: keys new in round 1, the same keys on other ranks plus fresh ones twice in
+    round 2, a replay — records, NEW lists and the summed cardinality equal the single-stream oracle's."""
+    env = dict(os.environ, CTMR_RCCL_LIB=build_fake())
+    p = subprocess.run([sys.executable, "-c", LONG_CHILD, ROOT, "3", mode], env=env, capture_output=True, text=True,
+                       timeout=100)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert line, p.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert not res["errs"] and not res["hung"], res
+    assert all(o_ is not None and o_["ok"] and all(o_["totals"]) for o_ in res["out"]), res
