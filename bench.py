@@ -535,6 +535,9 @@ def main():
                          "behaves when the lanes of a wave do not walk identical layouts.  The default run reports it as "
                          "secondary.mixed; this flag makes it the line's workload")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (mixed corpus, 128-byte aligned layout) of the default run")
+    ap.add_argument("--strict-strings", action="store_true",
+                    help="ctmr_set_strict_strings(1): the opt-in pre-pass over the Names' string values (what it costs: ms_per_step "
+                         "and kernel_ms.map of this line against the default line)")
     ap.add_argument("--aligned", type=int, default=0, metavar="BYTES",
                     help="lay every certificate at a multiple of BYTES (an entry view instead of the packed layout; payload grows "
                          "by the padding): what the map moves per certificate depends on where certificates start inside "
@@ -637,6 +640,8 @@ def main():
                           pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
                           lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
         eng.set_filter(filt, False, now)
+        if args.strict_strings:
+            eng.set_strict_strings(True)
         if not args.raw or world > 1:
             # raw entries register their Chain[0] certificates themselves — in shard order, so issuer index k would name
             # different issuers on different ranks and the count all-reduce would add apples to oranges: with several
@@ -916,6 +921,7 @@ def main():
                    "total_entries": n_total, "entries_on_rank0": E, "mean_der_bytes": cert_bytes / E,
                    "dedup": mode, "parallelism": parallelism,
                    "map_variant": args.variant or DEFAULT_VARIANT,
+                   **({"strict_strings": True} if args.strict_strings else {}),
                    "gen_seconds": round(t_gen, 2)},
         # roofline of the dominant kernel.  `frac` is PHYSICAL when the traffic was measured: HBM bytes the kernel moved
         # (PMC counters) ÷ its average launch time ÷ peak.  The walk skips key, SAN body and signature by length, so the

@@ -151,6 +151,7 @@ SIGNATURES = {
     "ctmr_set_issuer_autoregister": (C.c_int, [_P, C.c_int]),
     "ctmr_set_chain0_match": (C.c_int, [_P, C.c_int]),
     "ctmr_set_strict_leaf": (C.c_int, [_P, C.c_int]),
+    "ctmr_set_strict_strings": (C.c_int, [_P, C.c_int]),
     "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "ctmr_pem_encode_view_device": (C.c_int, [_P, _P, C.POINTER(EntryView), _P, C.c_uint64, _P, C.c_uint64, _P,
                                               C.POINTER(C.c_uint64)]),

@@ -205,6 +205,7 @@ struct ctmr_engine {
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
   bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
   int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
+  bool strict_strings = false;             // ctmr_set_strict_strings: character sets of the Names' string values (non-fatal finding)
   bool strict_leaf = false;                // ctmr_set_strict_leaf: parse the leaf TBSCertificate of precertificate entries
   uint64_t meta_precheck_n = 0;            // entries of the last map call whose ent[] carries the memo pre-check (0 = none)
   const uint32_t* meta_precheck_ent = nullptr;
@@ -258,7 +259,8 @@ struct ctmr_engine {
 namespace {
 
 enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP, SC_VIEW, SC_ISS_A, SC_ISS_B, SC_ISS_C, SC_META, SC_ITEMS,
-       SC_XSTAGE, SC_XWCNT, SC_XCNT, SC_XBASE, SC_XSLOT, SC_XL };  // owner-computes exchange (engine/exchange.inc)
+       SC_XSTAGE, SC_XWCNT, SC_XCNT, SC_XBASE, SC_XSLOT, SC_XL,
+       SC_NFX };  // strict_strings: the pre-pass's finding per entry  // owner-computes exchange (engine/exchange.inc)
 constexpr uint32_t UNREG_CAP = 16384;
 
 int fail(const ctmr_engine* e, int code, const char* fmt, ...) {

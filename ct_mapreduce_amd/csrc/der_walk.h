@@ -43,10 +43,12 @@ struct Walk {
   // where IssuerMetadata.Accumulate's inputs lie (storage/issuermetadata.go:92-138), packed off | len << 16
   // (meta_pack): the issuer Name TLV, and the OCTET STRING content of extension 2.5.29.31
   uint32_t meta_issuer, meta_crl;
+  uint32_t issuer_name, subject_name;  // where the two Name TLVs start (name_strings_ok)
 };
 
 constexpr uint32_t WALK_NF_NEGATIVE_SERIAL = 1u;  // "x509: negative serial number"
 constexpr uint32_t WALK_NF_LAX_INTEGER = 2u;      // an INTEGER only CT-go's lax asn1 re-parse accepts (not minimal)
+constexpr uint32_t WALK_NF_STRING = 4u;           // strict_strings only: a Name value breaks its string type's character set
 
 constexpr uint32_t META_NONE = 0u;           // no such element
 constexpr uint32_t META_HOST = 0xffffffffu;  // does not fit 16+16 bits, or the extension occurs twice: host parse
@@ -374,6 +376,84 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
   return ce;
 }
 
+// strict_strings (opt-in): the character-set rules Go's encoding/asn1 applies when it unmarshals an
+// AttributeTypeAndValue's `Value interface{}` of a universal, primitive string type — a violation is a parse error of the
+// stdlib; what certificate-transparency-go's lax fork makes of it is NOT verifiable here, so the finding is filed as
+// non-fatal (WALK_NF_STRING) behind a switch that is off by default:
+//   PrintableString (0x13)  isPrintable with '*' and '&' allowed: A-Z a-z 0-9 space ' ( ) + , - . / : = ? * &
+//   NumericString   (0x12)  0-9 and space
+//   IA5String       (0x16)  every octet < 0x80
+//   UTF8String      (0x0c)  utf8.Valid: no overlong forms, no surrogates, nothing above U+10FFFF, no truncated sequence
+// T61String is taken as it is.  The Name at q has been accepted by walk_name (the structure is not checked again).
+CTMR_HD bool string_byte_ok(uint32_t tag, uint32_t b) {
+  // bit c of the mask = octet c is allowed
+  const unsigned long long pr_lo = 0xa7ffffc100000000ull, pr_hi = 0x07fffffe07fffffeull;
+  const unsigned long long nu_lo = 0x03ff000100000000ull;
+  if (b >= 0x80u) return false;
+  if (tag == 0x16u) return true;
+  const unsigned long long lo = tag == 0x13u ? pr_lo : nu_lo, hi = tag == 0x13u ? pr_hi : 0ull;
+  return (((b < 64u ? lo : hi) >> (b & 63u)) & 1ull) != 0ull;
+}
+
+template <class R>
+CTMR_HD bool name_strings_ok(const R& r, uint32_t L, uint32_t q, uint32_t tbs_end) {
+  bool hdr_ok = true, good = true;
+  uint32_t tag, cs, ce;
+  rd_hdr(r, L, q, tbs_end, hdr_ok, tag, cs, ce);
+  const uint32_t s_end = ce;
+  uint32_t a = cs;
+  while (hdr_ok & good & (a < s_end)) {  // RDNs
+    uint32_t t1, c1, e1;
+    rd_hdr(r, L, a, s_end, hdr_ok, t1, c1, e1);
+    uint32_t x = c1;
+    while (hdr_ok & good & (x < e1)) {  // AttributeTypeAndValues
+      uint32_t t2, c2, e2, to, co, eo, tv, cv, ev;
+      rd_hdr(r, L, x, e1, hdr_ok, t2, c2, e2);
+      rd_hdr(r, L, c2, e2, hdr_ok, to, co, eo);
+      rd_hdr(r, L, eo, e2, hdr_ok, tv, cv, ev);
+      if (hdr_ok & ((tv == 0x13u) | (tv == 0x12u) | (tv == 0x16u))) {
+        for (uint32_t p = cv; good & (p < ev); p += 4u) {
+          const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
+          for (uint32_t k = 0; k < nb; k++) good = good & string_byte_ok(tv, (w >> (8u * k)) & 0xffu);
+        }
+      } else if (hdr_ok & (tv == 0x0cu)) {
+        uint32_t need = 0u, lo = 0x80u, hi = 0xbfu;  // continuation octets still owed, and the range of the next one
+        for (uint32_t p = cv; good & (p < ev); p += 4u) {
+          const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
+          for (uint32_t k = 0; k < nb; k++) {
+            const uint32_t b = (w >> (8u * k)) & 0xffu;
+            if (need == 0u) {
+              if (b < 0x80u) {
+              } else if ((b >= 0xc2u) & (b <= 0xdfu)) {
+                need = 1u;
+              } else if ((b >= 0xe0u) & (b <= 0xefu)) {
+                need = 2u;
+                lo = b == 0xe0u ? 0xa0u : 0x80u;
+                hi = b == 0xedu ? 0x9fu : 0xbfu;
+              } else if ((b >= 0xf0u) & (b <= 0xf4u)) {
+                need = 3u;
+                lo = b == 0xf0u ? 0x90u : 0x80u;
+                hi = b == 0xf4u ? 0x8fu : 0xbfu;
+              } else {
+                good = false;
+              }
+            } else {
+              good = good & (b >= lo) & (b <= hi);
+              lo = 0x80u;
+              hi = 0xbfu;
+              need--;
+            }
+          }
+        }
+        good = good & (need == 0u);
+      }
+      x = e2;
+    }
+    a = e1;
+  }
+  return good;
+}
+
 // `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
 // windowed reader that about `need` bytes from pos are read next; r.touch_tail(pos, tail) that the
 // bytes from pos AND the bytes at `tail` are read next; other readers ignore both.
@@ -399,7 +479,9 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // TBS_ONLY: the buffer is a bare TBSCertificate (what a precertificate entry's MerkleTreeLeaf carries) — what CT-go's
 // x509.ParseTBSCertificate accepts: the TBSCertificate SEQUENCE must fill the buffer ("trailing data" otherwise) and there
 // is no signatureAlgorithm / signatureValue behind it; everything inside is parsed as for a certificate.
-template <class R, bool TBS_ONLY = false>
+// NAMES_ONLY: stop behind the subject Name (k_name_strings: only where the two Names lie is wanted; whether the rest of
+// the certificate parses is the map's business).
+template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv) {
   o.serial_off = o.serial_len = 0;
 #pragma unroll
@@ -411,6 +493,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   o.bc_valid = o.is_ca = false;
   o.nonfatal = 0u;
   o.meta_issuer = o.meta_crl = META_NONE;
+  o.issuer_name = o.subject_name = 0u;
   bool ok = L <= 0x7fffffffu;
   L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
   uint32_t tag, cs, ce;
@@ -467,6 +550,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // issuer Name → last string-typed CommonName
   {
     const uint32_t n0 = q;
+    o.issuer_name = q;
     q = walk_name<true>(r, L, q, tbs_end, ok, o.cn_off, o.cn_len);
     o.meta_issuer = meta_pack(n0, q - n0);
     note_issuer_if(r, n0, q - n0);  // readers that look the Name up while it is at hand (the map kernel's memo pre-check)
@@ -492,9 +576,11 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     q = ce;
 #else
     uint32_t d0 = 0, d1 = 0;
+    o.subject_name = q;
     q = walk_name<false>(r, L, q, tbs_end, ok, d0, d1);
 #endif
   }
+  if constexpr (NAMES_ONLY) return ok;
   // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo): publicKeyInfo ::= SEQUENCE { AlgorithmIdentifier,
   // BIT STRING }; the key bits themselves are skipped by length.  A long subject (OV/EV certificates) puts this header
   // past the front window: say so, instead of leaving a window-only reader to its slow exact path.
@@ -635,6 +721,10 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
 template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr) {
   return filter ? walk_cert(r, L, o, true, *filter) : walk_cert(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
+}
+template <class R>
+CTMR_HD bool walk_names(R& r, uint32_t L, Walk& o) {
+  return walk_cert<R, false, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
 }
 template <class R>
 CTMR_HD bool walk_tbs(R& r, uint32_t L, Walk& o) {

@@ -412,6 +412,11 @@ class Engine:
         """Walk the leaf TBSCertificate of precertificate entries as ct.LogEntryFromLeaf does (include/ctmr.h); default off."""
         self._ck(self._lib.ctmr_set_strict_leaf(self._h, int(bool(on))))
 
+    def set_strict_strings(self, on: bool):
+        """Go-stdlib character-set rules for the string values of both Names, filed as a non-fatal finding (include/ctmr.h);
+        default off.  Set it before registering issuers."""
+        self._ck(self._lib.ctmr_set_strict_strings(self._h, int(bool(on))))
+
     def pending_issuers(self):
         """Distinct Chain[0] certificates the last raw-entry call found unregistered (auto-registration off)."""
         need, cnt = C.c_size_t(), C.c_uint64()

@@ -490,6 +490,15 @@ int ctmr_set_chain0_match(ctmr_engine* e, int mode);
  * else looks at the entry; an entry whose leaf TBSCertificate does not parse gets CTMR_ENTRY_INVALID /
  * CTMR_ST_ENTRY_DECODE_ERROR and its Chain[0] is never registered, as in the reference. */
 int ctmr_set_strict_leaf(ctmr_engine* e, int on);
+/* Character sets of the string values in the issuer and subject Names.  Go's encoding/asn1 rejects a PrintableString
+ * with an octet outside A-Z a-z 0-9 space ' ( ) + , - . / : = ? (and '*', '&', which it tolerates), a NumericString
+ * with anything but digits and space, an IA5String with an octet >= 0x80 and a UTF8String that is not valid UTF-8.
+ * certificate-transparency-go's fork of that package is more lenient towards some of these — which, cannot be verified
+ * without its source — so the rules are an OPT-IN (default 0: not checked, as in earlier versions) and a violation is
+ * filed as a NON-FATAL finding: an X509 entry keeps its certificate, a precertificate and a Chain[0] issuer are
+ * dropped (cmd/ct-fetch/ct-fetch.go:202-209, 221-225, 452-459).  on = 1: every map call runs a pre-pass over the front
+ * of each certificate; issuers are judged when they are registered (set the switch before registering them). */
+int ctmr_set_strict_strings(ctmr_engine* e, int on);
 /* ctmr_pem_encode_device for an entry view: PEM of the certificates d_idx[0..n_idx) names, straight out of the blob. */
 int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* d_view,
                                 const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,

@@ -246,8 +246,60 @@ static int alg_id(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, int* site_
 
 /* pkix.RDNSequence at p: SEQUENCE OF SET OF SEQUENCE { type OID, value ANY }.  cn: the last AttributeTypeAndValue
  * with OID 2.5.4.3 whose value is a string type (pkix.Name.FillFromRDNSequence), or NULL. */
+/* Go encoding/asn1 (go1.13), parseField for an `interface{}` target: a universal, primitive value is decoded by its tag,
+ * and a string that breaks its type's character set is a parse error of the STDLIB:
+ *   parsePrintableString  isPrintable(b, allowAsterisk, allowAmpersand)  "PrintableString contains invalid character"
+ *   parseNumericString    '0'..'9' or ' '                                 "NumericString contains invalid character"
+ *   parseIA5String        b < utf8.RuneSelf (0x80)                         "IA5String contains invalid character"
+ *   parseUTF8String       utf8.Valid                                       "asn1: invalid UTF-8 string"
+ * (T61String: taken as it is.)  What CT-go's lax fork does with them is unverified; the findings are collected apart from
+ * `nonfatal` and only an engine with strict_strings set treats them as one more non-fatal finding. */
+static int utf8_valid(const uint8_t* s, uint32_t n) {
+  uint32_t i = 0;
+  while (i < n) {
+    uint32_t c = s[i], len, cp, min;
+    if (c < 0x80) { i++; continue; }
+    if ((c & 0xe0) == 0xc0) { len = 2; cp = c & 0x1f; min = 0x80; }
+    else if ((c & 0xf0) == 0xe0) { len = 3; cp = c & 0x0f; min = 0x800; }
+    else if ((c & 0xf8) == 0xf0) { len = 4; cp = c & 0x07; min = 0x10000; }
+    else return 0;                       /* a continuation octet or 0xF8.. where a sequence must start */
+    if (i + len > n) return 0;           /* truncated */
+    for (uint32_t k = 1; k < len; k++) {
+      if ((s[i + k] & 0xc0) != 0x80) return 0;
+      cp = (cp << 6) | (s[i + k] & 0x3f);
+    }
+    if (cp < min) return 0;              /* overlong */
+    if (cp >= 0xd800 && cp <= 0xdfff) return 0; /* surrogate */
+    if (cp > 0x10ffff) return 0;
+    i += len;
+  }
+  return 1;
+}
+
+static int string_findings(const uint8_t* s, uint32_t n, uint32_t tag) {
+  static const char printable[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789 '()+,-./:=?*&";
+  switch (tag) {
+    case 0x13:
+      for (uint32_t i = 0; i < n; i++)
+        if (s[i] == 0 || !memchr(printable, s[i], sizeof printable - 1)) return ORC_SF_PRINTABLE;
+      return 0;
+    case 0x12:
+      for (uint32_t i = 0; i < n; i++)
+        if (!((s[i] >= '0' && s[i] <= '9') || s[i] == ' ')) return ORC_SF_NUMERIC;
+      return 0;
+    case 0x16:
+      for (uint32_t i = 0; i < n; i++)
+        if (s[i] >= 0x80) return ORC_SF_IA5;
+      return 0;
+    case 0x0c:
+      return utf8_valid(s, n) ? 0 : ORC_SF_UTF8;
+    default:
+      return 0;
+  }
+}
+
 static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint32_t* cn_off, uint32_t* cn_len,
-                        int* site_out, int site) {
+                        int* site_out, int site, int32_t* sfind) {
   if (!rd_tlv(d, p, end, t) || t->tag != 0x30) FAIL0(site);
   uint64_t r = p + t->hl, r_end = r + t->len;
   while (r < r_end) {
@@ -261,6 +313,7 @@ static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint
       if (!rd_tlv(d, b, b_end, &oid) || oid.tag != 0x06 || !oid_ok(d, b + oid.hl, oid.len)) FAIL0(site + 3);
       uint64_t vpos = b + oid.hl + oid.len;
       if (!rd_tlv(d, vpos, b_end, &val)) FAIL0(site + 4);  /* ANY: must be there and fit; anything behind it is ignored */
+      *sfind |= string_findings(d + vpos + val.hl, val.len, val.tag);
       if (cn_off && oid.len == 3 && d[b + oid.hl] == 0x55 && d[b + oid.hl + 1] == 0x04 &&
           d[b + oid.hl + 2] == 0x03 && is_string_tag(val.tag)) {
         *cn_off = (uint32_t)(vpos + val.hl);
@@ -326,7 +379,7 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
   if (!alg_id(d, q, tbs_end, &t, &site, 11)) FAIL(site);
   q += t.hl + t.len;
   /* issuer Name (asn1.RawValue, then asn1.Unmarshal into pkix.RDNSequence) */
-  if (!rdn_sequence(d, q, tbs_end, &t, &out->cn_off, &out->cn_len, &site, 50)) FAIL(site);
+  if (!rdn_sequence(d, q, tbs_end, &t, &out->cn_off, &out->cn_len, &site, 50, &out->string_findings)) FAIL(site);
   out->issuer_off = (uint32_t)q;
   out->issuer_len = t.hl + t.len;
   q += t.hl + t.len;
@@ -343,7 +396,7 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
   }
   q += t.hl + t.len;
   /* subject Name: same structure; no field of it is consumed */
-  if (!rdn_sequence(d, q, tbs_end, &t, NULL, NULL, &site, 60)) FAIL(site);
+  if (!rdn_sequence(d, q, tbs_end, &t, NULL, NULL, &site, 60, &out->string_findings)) FAIL(site);
   q += t.hl + t.len;
   /* subjectPublicKeyInfo: full TLV = RawSubjectPublicKeyInfo (types.go:109-115);
    * publicKeyInfo ::= SEQUENCE { algorithm AlgorithmIdentifier, publicKey BIT STRING } */
@@ -755,6 +808,7 @@ struct orc_engine {
   char* filter;
   size_t filter_len;
   int log_expired;
+  int strict_strings; /* the stdlib's character-set rules for the Names' string values, as non-fatal findings (orc_engine_set_strict_strings) */
   int strict_leaf; /* LogEntryFromLeaf's parse of a precertificate entry's leaf TBSCertificate (orc_engine_set_strict_leaf) */
   int64_t now;
   int64_t inserted;
@@ -972,7 +1026,7 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   orc_parse_cert(leaf, leaf_len, &c); /* :198-204 */
   /* X509 entry: the certificate LogEntryFromLeaf parsed, kept unless the error was fatal (:452-459);
    * precertificate: parsed here, dropped on ANY error, x509.NonFatalErrors included (:202-209) */
-  if (!c.ok || (entry_type == 1 && c.nonfatal)) return ORC_ST_PARSE_ERROR; /* :206-209 */
+  if (!c.ok || (entry_type == 1 && (c.nonfatal || (e->strict_strings && c.string_findings)))) return ORC_ST_PARSE_ERROR; /* :206-209 */
   if (exp_hour) *exp_hour = orc_exp_hour(c.not_after);
   if (serial) *serial = leaf + c.serial_off;
   if (serial_len) *serial_len = c.serial_len;
@@ -981,7 +1035,7 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   if (!issuer_der) return ORC_ST_NO_ISSUER; /* :215-219 */
   orc_cert ic;
   orc_parse_cert(issuer_der, issuer_len, &ic); /* :221 */
-  if (!ic.ok || ic.nonfatal) return ORC_ST_ISSUER_PARSE_ERROR; /* any err :222-225 */
+  if (!ic.ok || ic.nonfatal || (e->strict_strings && ic.string_findings)) return ORC_ST_ISSUER_PARSE_ERROR; /* any err :222-225 */
   /* Store: filesystemdatabase.go:158-211 */
   int32_t eh = orc_exp_hour(c.not_after);           /* :160 */
   char issuer_id[45];
@@ -1125,6 +1179,7 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
 }
 
 void orc_engine_set_strict_leaf(orc_engine* e, int on) { e->strict_leaf = on != 0; }
+void orc_engine_set_strict_strings(orc_engine* e, int on) { e->strict_strings = on != 0; }
 
 void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
                           uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,

@@ -64,8 +64,14 @@ typedef struct {
   uint32_t exts_off, exts_end;       /* contents of the SEQUENCE OF Extension, 0/0 when the certificate has none */
   int32_t nonfatal;      /* ORC_NF_*: findings CT-go reports as x509.NonFatalErrors — the certificate is handed out
                             all the same; kept for X509 entries, dropped for precertificates and Chain[0] issuers */
+  int32_t string_findings; /* ORC_SF_*: Name values that break their string type's character set (Go stdlib rules; kept apart
+                              from `nonfatal`: only an engine with strict_strings set acts on them) */
 } orc_cert;
 
+#define ORC_SF_PRINTABLE 1
+#define ORC_SF_NUMERIC 2
+#define ORC_SF_IA5 4
+#define ORC_SF_UTF8 8
 #define ORC_NF_NEGATIVE_SERIAL 1 /* "x509: negative serial number" */
 #define ORC_NF_LAX_INTEGER 2     /* an INTEGER only CT-go's lax asn1 re-parse accepts: not minimally encoded */
 
@@ -179,6 +185,8 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
  * ORC_ST_ENTRY_DECODE_ERROR.  out_timestamp may be NULL. */
 /* 1: a precertificate entry whose leaf TBSCertificate does not parse is undecodable (ct.LogEntryFromLeaf, ct-fetch.go:452) */
 void orc_engine_set_strict_leaf(orc_engine*, int on);
+/* Go stdlib character-set rules for the string values of both Names, filed as non-fatal findings (default off) */
+void orc_engine_set_strict_strings(orc_engine*, int on);
 void orc_engine_raw_batch(orc_engine*, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
                           uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,
                           uint64_t* out_timestamp);

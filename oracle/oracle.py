@@ -35,10 +35,12 @@ class Cert(C.Structure):
                 ("bc_valid", C.c_int32), ("is_ca", C.c_int32),
                 ("spki_off", C.c_uint32), ("spki_len", C.c_uint32),
                 ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32), ("issuer_off", C.c_uint32), ("issuer_len", C.c_uint32),
-                ("exts_off", C.c_uint32), ("exts_end", C.c_uint32), ("nonfatal", C.c_int32)]
+                ("exts_off", C.c_uint32), ("exts_end", C.c_uint32), ("nonfatal", C.c_int32),
+                ("string_findings", C.c_int32)]
 
 
 NF_NEGATIVE_SERIAL, NF_LAX_INTEGER = 1, 2
+SF_PRINTABLE, SF_NUMERIC, SF_IA5, SF_UTF8 = 1, 2, 4, 8
 
 
 def pem_encode(der: bytes) -> bytes:
@@ -61,6 +63,7 @@ def lib():
         L.orc_parse_cert.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Cert)]
         L.orc_parse_tbs.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Cert)]
         L.orc_engine_set_strict_leaf.argtypes = [C.c_void_p, C.c_int]
+        L.orc_engine_set_strict_strings.argtypes = [C.c_void_p, C.c_int]
         L.orc_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.restype = C.c_size_t
@@ -182,6 +185,10 @@ class Engine:
     def set_strict_leaf(self, on: bool):
         """Precertificate entries: fail the entry when its leaf TBSCertificate does not parse (LogEntryFromLeaf)."""
         lib().orc_engine_set_strict_leaf(self._h, int(bool(on)))
+
+    def set_strict_strings(self, on: bool):
+        """Character sets of the Names' string values (Go stdlib rules) as one more non-fatal finding; default off."""
+        lib().orc_engine_set_strict_strings(self._h, int(bool(on)))
 
     def close(self):
         if self._h:

@@ -17,6 +17,7 @@ import ct_mapreduce_amd as ctmr  # noqa: E402
 from ct_mapreduce_amd import synth, _native as N  # noqa: E402
 from ct_mapreduce_amd.engine import Batch  # noqa: E402
 from tests import der as D  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
 from tests.gpu_common import run_oracle, expected_records  # noqa: E402
 from tests.test_walk_cpu import mutate, edge_seeds  # noqa: E402
 from tests.test_gpu_meta import expected_first_sightings, got_first_sightings  # noqa: E402
@@ -55,6 +56,11 @@ def main():
     seeds += [D.cert(serial=bytes([k + 1]) * (k + 1), issuer=n1,
                      exts=[D.BC_NOT_CA, D.ext(0x1f, D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa0, D.tlv(0x86, b"http://c.example/%d" % k))))))])
               for k in range(24)]
+    if os.environ.get("STRICT_STRINGS"):   # Names whose string values sit at the edges of their character sets
+        for tag, val in ((0x13, b"Org (EU) *&+,-./:=?'"), (0x12, b"0123 456"), (0x16, b"a@b.example"), (0x0c, "Zürich 東京".encode()),
+                         (0x0c, b"\xf0\x9f\x98\x80\xed\x9f\xbf\xe0\xa0\x80"), (0x14, b"t61 \xe4")):
+            seeds += [D.cert(serial=bytes([9, tag, k]), issuer=D.name(D.rdn(10, val, tag), D.rdn(3, b"Synth Issuer 000")),
+                             subject=D.name(D.rdn(3, val, tag))) for k in range(4)]
     seeds += edge_seeds() * 6      # the Go-specific rules (numeric zones, lax INTEGERs, unique ids, high tags, lying wrappers): weighted up
     print("seeds", len(seeds), flush=True)
     bad = 0
@@ -74,9 +80,13 @@ def main():
         eng = ctmr.Engine(device=0, table_slots=1 << 18, pair_slots=1 << 18, collect_meta=True)
         eng.add_issuers(issuers)
         eng.set_filter(filt, log_exp, now)
+        strict = bool(os.environ.get("STRICT_STRINGS")) and rng.random() < 0.5
+        eng.set_strict_strings(strict)
         res = eng.map_batch(batch)
-        o, st, unk, eh = run_oracle(batch, issuers, filt, log_exp, now)
-        flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh)
+        o = orc.Engine(filt, log_exp, now)
+        o.set_strict_strings(strict)
+        o, st, unk, eh = run_oracle(batch, issuers, filt, log_exp, now, engine=o)
+        flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh, strict)
         r = res.records
         diff = ((r["status"] != st) | (r["flags"] != flags) | (r["serial_len"] != serial_len) | (r["exp_hour"] != exp_hour) |
                 (r["serial"] != serial).any(axis=1))

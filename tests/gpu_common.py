@@ -16,7 +16,7 @@ def run_oracle(batch, issuers, filt=b"", log_expired=False, now=0, engine=None):
     return o, st, unk, eh
 
 
-def expected_records(batch, st, unk, eh):
+def expected_records(batch, st, unk, eh, strict_strings=False):
     """What the 32-byte records must contain, derived from the oracle."""
     n = batch.n
     serial_len = np.zeros(n, np.uint16)
@@ -28,7 +28,8 @@ def expected_records(batch, st, unk, eh):
         c = orc.parse_cert(der)
         if batch.entry_type[i] == 1:
             flags[i] |= 1
-        if not c.ok or (batch.entry_type[i] == 1 and c.nonfatal):   # a dropped certificate reports no fields
+        nonfatal = c.nonfatal or (strict_strings and c.string_findings)
+        if not c.ok or (batch.entry_type[i] == 1 and nonfatal):     # a dropped certificate reports no fields
             continue
         exp_hour[i] = eh[i]
         serial_len[i] = min(c.serial_len, 0xffff)
@@ -41,8 +42,8 @@ def expected_records(batch, st, unk, eh):
     return flags, serial_len, exp_hour, serial
 
 
-def assert_records_equal(res, batch, st, unk, eh):
-    flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh)
+def assert_records_equal(res, batch, st, unk, eh, strict_strings=False):
+    flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh, strict_strings)
     r = res.records
     assert (r["status"] == st).all(), np.nonzero(r["status"] != st)[0][:10]
     assert (r["flags"] == flags).all(), np.nonzero(r["flags"] != flags)[0][:10]

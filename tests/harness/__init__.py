@@ -84,6 +84,13 @@ def product_walk_tbs(tbs: bytes, fill=0xA5) -> HarnessOut:
     return o
 
 
+def product_name_strings(der: bytes, fill=0xA5) -> int:
+    """strict_strings: 1 = the Names' string values keep to their types' character sets, 0 = a finding, -1 = no parse."""
+    product_walk(b"\x30\x00")
+    _walk.harness_name_strings.argtypes = [C.c_char_p, C.c_uint32, C.c_uint8]
+    return _walk.harness_name_strings(der, len(der), fill)
+
+
 def walk_touched(der: bytes, phase: int = 0, cn_filter: bytes = b""):
     """(accepted, bytes the walk's reads cover, distinct 128-byte lines they lie in when the certificate starts at
     byte `phase` of a line) — bench.py's needed_bytes accounting."""
