@@ -526,9 +526,10 @@ def main():
                     help="also time the auxiliary whole-certificate SHA-256 kernel (k_fingerprint; VALU-bound, not on "
                          "the reference's path) over the batch")
     ap.add_argument("--stream", type=int, default=0, metavar="TOTAL",
-                    help="BASELINE config 5 on one GPU: stream TOTAL entries with 10%% duplicates through one engine in "
-                         "waves of --entries (default 50M), the known-certificate table persisting across waves; "
-                         "checks n_new / n_dup of every wave against the generator's duplicate structure")
+                    help="BASELINE configs[4]: stream TOTAL entries with 10%% duplicates in waves of --entries (default 50M, over "
+                         "all ranks), the known-certificate sets persisting across waves; with --gpus N every wave is split by "
+                         "log index over the ranks and deduplicated through the group (--dedup, default owner); checks every "
+                         "wave and every entry's WasUnknown against the generator's duplicate structure")
     ap.add_argument("--mixed", action="store_true",
                     help="the mixed synthetic corpus (half EC P-256 keys, 40%% OV-like subjects of 120-260 bytes, longer "
                          "issuer names, one GeneralizedTime in four) instead of the SURVEY §8(d) corpus: how the map "

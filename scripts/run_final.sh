@@ -26,6 +26,10 @@ for spec in "2 bloom" "4 bloom" "4 owner" "2 local"; do
   CTMR_RCCL_LIB=$(cat $OUT/fake.path) timeout 900 python bench.py --gpus $1 --dedup $2 --total-entries 16000000 --steps 3 --traffic off > $OUT/bench_fake_rccl_n$1_$2.json 2> $OUT/bench_fake_rccl_n$1_$2.err; python -c "$J
 print('gpus $1 $2 (one GPU, stand-in librccl)', d['value'], d['ms_per_step'], d['scaling'], d['checks'], d['parity_vs_oracle_on_sample'], d['exchange']['ms_phase_rank0'], d['exchange']['wire_bytes_sent_by_rank0_per_step'])" $OUT/bench_fake_rccl_n$1_$2.json || tail -5 $OUT/bench_fake_rccl_n$1_$2.err
 done
+CTMR_RCCL_LIB=$(cat $OUT/fake.path) timeout 600 python bench.py --gpus 3 --stream 48000000 --entries 12000000 --traffic off > $OUT/bench_fake_rccl_n3_stream.json 2> $OUT/bench_fake_rccl_n3_stream.err; python -c "$J
+print('gpus 3 stream (one GPU, stand-in librccl)', d['value'], d['ms_per_step'], d['config']['dedup'], d['result'], d['exchange'])" $OUT/bench_fake_rccl_n3_stream.json || tail -5 $OUT/bench_fake_rccl_n3_stream.err
+timeout 600 python bench.py --strict-strings --no-cpu --no-secondary --traffic off > $OUT/bench_strictstrings.json 2> $OUT/bench_strictstrings.err; python -c "$J
+print('--strict-strings', d['value'], d['ms_per_step'], d['kernel_ms'])" $OUT/bench_strictstrings.json
 for m in "--raw" "--raw --meta --pem" "--meta" "--stream 1000000000" "--global-dedup owner" "--global-dedup bloom" "--raw --trusted-chain"; do
   tag=$(echo $m | tr -d ' -'); timeout 900 python bench.py $m --no-cpu --steps 3 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err; python -c "$J
 r=d['roofline']
