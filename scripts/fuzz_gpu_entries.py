@@ -2,6 +2,7 @@
 damaged TLS framing and damaged certificate bodies against the oracle's LogEntryFromLeaf + insertCTWorker restatement.
     gpurun -- 'python scripts/fuzz_gpu_entries.py 1000000'
     gpurun -- 'STRICT_LEAF=1 python scripts/fuzz_gpu_entries.py 1000000'     # half the engines in strict_leaf mode (round 3)
+    gpurun -- 'STRICT_STRINGS=1 python scripts/fuzz_gpu_entries.py 1000000'  # half the engines in strict_strings mode (round 3)
 """
 import os
 import random
@@ -53,9 +54,12 @@ def main():
         eng = ctmr.Engine(device=0, table_slots=1 << 18, pair_slots=1 << 18, collect_meta=True)
         eng.set_filter(filt, log_exp, now)
         eng.set_strict_leaf(strict)
+        strings = bool(os.environ.get("STRICT_STRINGS")) and rng.random() < 0.5
+        eng.set_strict_strings(strings)
         res = eng.map_entries(raw)
         o = orc.Engine(filt, log_exp, now)
         o.set_strict_leaf(strict)
+        o.set_strict_strings(strings)
         st, unk, eh, ts = o.raw_batch(raw.blob, raw.bounds)
         r = res.records
         parsed = (st != orc.ST_PARSE_ERROR) & (st != orc.ST_ENTRY_DECODE_ERROR)

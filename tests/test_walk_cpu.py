@@ -25,6 +25,8 @@ def same(der):
         s20 = der[o.serial_off:o.serial_off + min(o.serial_len, 20)].ljust(20, b"\0")
         assert b"".join(int(w).to_bytes(4, "little") for w in p.serial_w) == s20
         assert p.cn_match == 1
+        # strict_strings: the character sets of the Names' string values (stdlib rules), product vs oracle
+        assert harness.product_name_strings(der, 0xA5) == harness.product_name_strings(der, 0x30) == (1 if o.string_findings == 0 else 0)
         meta = orc.cert_meta(der)               # IssuerMetadata's inputs come from the same walk: RawIssuer is the Name it validated
         assert meta is not None and meta[0] == der[o.issuer_off:o.issuer_off + o.issuer_len] and meta[0][:1] == b"\x30"
         cn = der[o.cn_off:o.cn_off + o.cn_len]
