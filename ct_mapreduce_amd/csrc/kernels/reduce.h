@@ -174,34 +174,10 @@ __device__ __forceinline__ uint32_t insert_probe_h(const InsertArgs& a, uint64_t
                                                    uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
   const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
   const unsigned long long w0 = tagw | (a.ord_base + (uint32_t)i);
-#ifdef CTMR_EXP_ARENA  // sweep builds, MEASUREMENT ONLY (wrong results): what an index table of 8-byte words (claimed by the
-  // CAS alone) + a key arena written in entry order would cost — the first 2 GiB of the table's memory stand in for the
-  // index, the bytes behind 4 GiB for the arena (needs table_slots >= 2^27)
-  {
-    unsigned long long* idx = (unsigned long long*)a.table;
-    uint64_t j8 = h & a.mask;
-    uint32_t st = ES_FULL;
-    for (uint32_t probes = 0; probes < 64; probes++) {
-      const unsigned long long old = atomicCAS(&idx[j8], 0ull, w0);
-      if (old == 0ull) { st = ES_CLAIMED; break; }
-      if ((old & 0xffffffff00000000ull) == tagw) { a.slot_id[i] = (uint32_t)j8; st = ES_DEFER; break; }
-      j8 = (j8 + 1) & a.mask;
-    }
-    uint4* cell = (uint4*)((uint8_t*)a.table + (4ull << 30) + (uint64_t)i * 32u);
-    cell[0] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)s[0], (uint32_t)(s[0] >> 32));
-    cell[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)w0);
-    (void)claimed; (void)q0; (void)q1; (void)q2; (void)q3;
-    return st == ES_DEFER ? ES_CLAIMED : st;  // (pass 2 must not look at these slots)
-  }
-#endif
   uint64_t j = h & a.mask;
   for (uint64_t probes = 0; probes <= a.mask; probes++) {
     Slot* sl = a.table + j;
-#ifdef CTMR_EXP_PLAIN_CLAIM  // sweep builds, MEASUREMENT ONLY (wrong results): the home slot is taken without asking
-    const unsigned long long old = 0ull;
-#else
     const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
-#endif
     if (old == 0ull) {  // claimed
       q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)meta, (uint32_t)(meta >> 32));
       q1 = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
