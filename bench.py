@@ -1042,7 +1042,9 @@ def main():
                       "chain0_match": "trusted-log (bytewise on first sighting per call, then length + first/last 16 B)"
                                       if args.trusted_chain else "exact (every byte of every Chain[0])",
                       "chain0_bytes": c0_bytes, "certificate_bytes_the_map_parses": cert_bytes,
-                      "note": "decode and the first match round are one kernel (ms_decode = 0, ms_match = both)"}
+                      "note": "decode and the first match round are one kernel (ms_decode = 0, ms_match = both)",
+                      "parity_note": "the decode's oracle follows RFC 6962 3.4/4.6 and CT-go's struct tags; the reference holds "
+                                     "no raw-entry fixture, so parity with CT-go's LogEntryFromLeaf is UNPINNED (DESIGN.md 3.2)"}
         rdm = {"bound": "hbm", "kernel": "k_decode_match", "alg_bytes_per_launch": dm_alg, "avg_launch_ms": dm_ms,
                "alg_bytes_formula": ("sum(chain0_len)" if not args.trusted_chain else "32*E") + " + 68*E (bounds 16 + leaf header 15 + view 37)",
                "achieved_algorithmic": dm_alg / (dm_ms * 1e-3) / 1e9, "frac_algorithmic": dm_alg / (dm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
