@@ -61,7 +61,7 @@ def main():
             pool.append((D.cert(serial=s, issuer=names[k], not_after=D.utctime("270101000000Z")), k))
         for _ in range(20):
             c, k = rng.choice(pool)
-            pool.append((mutate(rng, c), k))
+            pool.append((mutate(rng, c) if len(c) > 8 else c, k))
         engines = []
         for _ in range(world):
             e = ctmr.Engine(device=0, table_slots=1 << rng.choice((10, 12, 14)), pair_slots=1 << 10)
