@@ -26,6 +26,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "host_keys.h"
 #include "kernels.h"
 
 using namespace ctmr;

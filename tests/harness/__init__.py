@@ -118,6 +118,27 @@ def ossl_extract(der: bytes):
     return o
 
 
+_hk = None
+
+
+def host_keys_lib():
+    """Host build of csrc/host_keys.h: the wire form and the verdict of a group round's long-serial settlement."""
+    global _hk
+    if _hk is None:
+        src = os.path.join(HERE, "host_keys_harness.cpp")
+        dep = os.path.join(HERE, "..", "..", "ct_mapreduce_amd", "csrc", "host_keys.h")
+        out = os.path.join(HERE, "libhost_keys_harness.so")
+        if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(dep)):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", src, "-o", out])
+        _hk = C.CDLL(out)
+        _hk.harness_host_keys_verdict.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64),
+                                                  C.POINTER(C.c_uint8), C.c_uint32]
+        _hk.harness_host_keys_append.argtypes = [C.c_uint64, C.c_int32, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64),
+                                                 C.c_uint32]
+        _hk.harness_host_keys_append.restype = C.c_uint32
+    return _hk
+
+
 def build_fake_rccl() -> str:
     """The stand-in for librccl (fake_rccl.cpp: ranks as threads or processes on ONE GPU, bytes through POSIX shared
     memory), built on demand; hand the path to the library through CTMR_RCCL_LIB."""
