@@ -4,6 +4,10 @@
 // insert whose keys were first routed to the XCD that owns their table region could gain, nothing more.
 //   modes  0 agent CAS (the product's claim)      1 workgroup CAS        2 agent fetch_or, result unused
 //          3 workgroup fetch_or, result unused    4 plain 8-byte load    5 plain 8-byte store
+//          6..9 the insert's pair: agent CAS on word 0 of the slot, then the 64-byte slot image (4 x 16 B from the claiming
+//               lane) — 6 plain stores, 7 non-temporal (nt), 8 sc1, 9 sc0 sc1: does a store that leaves the L2 at once
+//               meet the line the atomic has just dirtied while the Infinity Cache still holds it?
+//          10   the same pair with the image stored by four adjacent lanes per slot (the product's store_slots_wave)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -35,8 +39,36 @@ __global__ void __launch_bounds__(256) k_rand(unsigned long long* table, uint64_
       (void)__hip_atomic_fetch_or(p, z | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (MODE == 4) {
       old = *(volatile unsigned long long*)p;
-    } else {
+    } else if (MODE == 5) {
       *p = z | 1ull;
+    } else {
+      unsigned long long e = 0;
+      __hip_atomic_compare_exchange_strong(p, &e, z | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = e;
+      if (MODE != 10 && e == 0ull) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v;
+        v.x = (uint32_t)z | 1u; v.y = (uint32_t)(z >> 32); v.z = 7u; v.w = (uint32_t)i;
+        u32x4* q = (u32x4*)p;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (MODE == 6) q[k] = v;
+          else if (MODE == 7) __builtin_nontemporal_store(v, q + k);
+          else if (MODE == 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q + k), "v"(v) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q + k), "v"(v) : "memory");
+        }
+      }
+    }
+  }
+  if (MODE == 10) {  // the product's form (store_slots_wave): four adjacent lanes emit one whole slot, 16 slots per instruction
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t j = z & mask;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t src = 16u * r + (lane >> 2);
+      const uint64_t sj = __shfl(j, src);
+      const unsigned long long so = __shfl(old, src);
+      if (so == 0ull) ((uint4*)(table + sj * 8))[lane & 3u] = make_uint4((uint32_t)z | 1u, 7u, (uint32_t)sj, lane);
     }
   }
   if (old == 0x1234567ull) out[0] = 1;
@@ -76,5 +108,11 @@ int main(int argc, char** argv) {
   run<3>(table, slots, n, out, "fetch_or, workgroup scope, result unused");
   run<4>(table, slots, n, out, "plain 8-byte load");
   run<5>(table, slots, n, out, "plain 8-byte store");
+  run<6>(table, slots, n, out, "agent CAS + 64-byte slot image, plain stores");
+  run<7>(table, slots, n, out, "agent CAS + 64-byte slot image, nt stores");
+  run<8>(table, slots, n, out, "agent CAS + 64-byte slot image, sc1 stores");
+  run<9>(table, slots, n, out, "agent CAS + 64-byte slot image, sc0 sc1 stores");
+  run<10>(table, slots, n, out, "agent CAS + 64-byte slot image, four lanes per slot (the product's store_slots_wave)");
+  run<6>(table, slots, n, out, "agent CAS + 64-byte slot image, plain stores (again)");
   return 0;
 }
