@@ -413,13 +413,19 @@ CTMR_HD bool name_strings_ok(const R& r, uint32_t L, uint32_t q, uint32_t tbs_en
       rd_hdr(r, L, eo, e2, hdr_ok, tv, cv, ev);
       if (hdr_ok & ((tv == 0x13u) | (tv == 0x12u) | (tv == 0x16u))) {
         for (uint32_t p = cv; good & (p < ev); p += 4u) {
-          const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
-          for (uint32_t k = 0; k < nb; k++) good = good & string_byte_ok(tv, (w >> (8u * k)) & 0xffu);
+          const uint32_t nb = ev - p < 4u ? ev - p : 4u, keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+          const uint32_t w = (ldc(r, p, L) & keep) | (0x30303030u & ~keep);  // octets behind the value count as '0': in every set
+          good = good & ((w & 0x80808080u) == 0u);                           // all three sets are 7-bit
+          if (tv != 0x16u)
+            good = good & string_byte_ok(tv, w & 0x7fu) & string_byte_ok(tv, (w >> 8) & 0x7fu) &
+                   string_byte_ok(tv, (w >> 16) & 0x7fu) & string_byte_ok(tv, (w >> 24) & 0x7fu);
         }
       } else if (hdr_ok & (tv == 0x0cu)) {
         uint32_t need = 0u, lo = 0x80u, hi = 0xbfu;  // continuation octets still owed, and the range of the next one
         for (uint32_t p = cv; good & (p < ev); p += 4u) {
           const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
+          const uint32_t keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+          if ((need == 0u) & ((w & keep & 0x80808080u) == 0u)) continue;  // four ASCII octets between sequences
           for (uint32_t k = 0; k < nb; k++) {
             const uint32_t b = (w >> (8u * k)) & 0xffu;
             if (need == 0u) {
