@@ -6,6 +6,11 @@
 #include "../../include/ctmr.h"
 #include "der_walk.h"
 
+// Launch bounds of every kernel that runs the certificate walk: one wave per workgroup, and a register file of at most
+// 168 VGPRs (three waves per SIMD) — LDS lets 9 such waves onto a CU.  The bound is also what the compiler gives the
+// walk's out-of-line helpers (spki_key.h: the curve checks), whose attributes it derives from their callers.
+#define CTMR_WALK_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
+
 namespace ctmr {
 
 // ---------------------------------------------------------------- known-certificate table
@@ -88,7 +93,7 @@ struct FilterDev {
   uint32_t active;       // len(*ctconfig.IssuerCNFilter) != 0
   uint32_t n_pieces;     // strings.Split(filter, ",")
   uint32_t log_expired;
-  uint32_t pad;
+  uint32_t strict_spki;  // ctmr_set_strict_spki: the walk also parses the public key (spki_key.h); on by default
   long long now;
   uint32_t piece_len[64];
   uint32_t piece_word[64];  // index of the piece's first word in words[]

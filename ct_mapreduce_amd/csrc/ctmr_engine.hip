@@ -207,6 +207,7 @@ struct ctmr_engine {
   bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
   int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
   bool strict_strings = false;             // ctmr_set_strict_strings: character sets of the Names' string values (non-fatal finding)
+  bool strict_spki = true;                 // ctmr_set_strict_spki: parsePublicKey's verdict on the key inside subjectPublicKeyInfo (spki_key.h)
   bool strict_leaf = false;                // ctmr_set_strict_leaf: parse the leaf TBSCertificate of precertificate entries
   uint64_t meta_precheck_n = 0;            // entries of the last map call whose ent[] carries the memo pre-check (0 = none)
   const uint32_t* meta_precheck_ent = nullptr;

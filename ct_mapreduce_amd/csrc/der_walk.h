@@ -285,18 +285,23 @@ CTMR_HD void bit_string_check(const R& r, uint32_t L, uint32_t c, uint32_t len, 
 // pkix.AlgorithmIdentifier ::= SEQUENCE { algorithm OBJECT IDENTIFIER, parameters ANY OPTIONAL } at p, inside [p, end):
 // the OID must be there, non-empty and end on an octet without the continuation bit (parseObjectIdentifier, as far as
 // it is modelled); parameters, when present, must be one well-formed TLV that fits; anything behind is ignored.
+// What alg_id found: the algorithm OID's content octets and the parameters element (absent: par_e == par_p).
+struct AlgView {
+  uint32_t oid_c, oid_e;
+  uint32_t par_p, par_tag, par_c, par_e;
+};
+
 template <class R>
-CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& after) {
+CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& after, AlgView* av = nullptr) {
   uint32_t tag, cs, ce, to, co, eo;
   rd_hdr(r, L, p, end, ok, tag, cs, ce);
   rd_hdr(r, L, cs, ce, ok, to, co, eo);
   const uint32_t lastp = eo - 1u;
   const uint32_t last = ldc(r, lastp, L);
   ok = ok & (tag == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
-  if (ok & (eo < ce)) {
-    uint32_t tp, cp, ep;
-    rd_hdr(r, L, eo, ce, ok, tp, cp, ep);
-  }
+  uint32_t tp = 0u, cp = eo, ep = eo;
+  if (ok & (eo < ce)) rd_hdr(r, L, eo, ce, ok, tp, cp, ep);
+  if (av) *av = AlgView{co, eo, eo, tp, cp, ok ? ep : eo};
   after = ce;
 }
 
@@ -313,6 +318,10 @@ struct TailView {
   const R& r;
   CTMR_HD uint32_t ld4(uint32_t pos) const { return r.ldg(pos); }
 };
+
+}  // namespace ctmr
+#include "spki_key.h"  // the key inside subjectPublicKeyInfo (parsePublicKey)
+namespace ctmr {
 
 // pkix.RDNSequence at q (asn1.RawValue in the tbsCertificate, then asn1.Unmarshal into pkix.RDNSequence): SEQUENCE OF
 // SET OF SEQUENCE { type OID, value ANY }; bytes behind the value inside an AttributeTypeAndValue are ignored.
@@ -487,8 +496,9 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // is no signatureAlgorithm / signatureValue behind it; everything inside is parsed as for a certificate.
 // NAMES_ONLY: stop behind the subject Name (k_name_strings: only where the two Names lie is wanted; whether the rest of
 // the certificate parses is the map's business).
+// spki: also parse the public key as CT-go's parsePublicKey does (spki_key.h; ctmr_set_strict_spki, on by default).
 template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false>
-CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv) {
+CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv, bool spki = true) {
   o.serial_off = o.serial_len = 0;
 #pragma unroll
   for (int k = 0; k < 5; k++) o.serial_w[k] = 0;
@@ -592,22 +602,28 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // past the front window: say so, instead of leaving a window-only reader to its slow exact path.
   // (A wave-cooperative form of this refill — the lanes in need served 16 lanes per certificate, as touch_tail does —
   //  measured no gain on the mixed corpus: 25.45 ms against 25.3 ms per 100 M, session 5.)
-  r.touch(q, 40);
+  r.touch(q, 48);
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
   o.spki_off = q;
   o.spki_len = ce - q;
+  AlgView key_alg{0u, 0u, 0u, 0u, 0u, 0u};
+  KeyPending key_pending;
+  key_pending.alg = PK_OTHER;
   {
     uint32_t k, tk, ck, ek;
-    alg_id(r, L, cs, ce, ok, k);
+    alg_id(r, L, cs, ce, ok, k, &key_alg);
     rd_hdr(r, L, k, ce, ok, tk, ck, ek);
     ok = ok & (tk == 0x03u);
     bit_string_check(r, L, ck, ek - ck, ok);
+    // the key itself: what the window holds now, and the far reads of the common case issued (spki_key.h)
+    if (spki) spki_key_begin(r, L, key_alg, ck, ek, ok, o.nonfatal, key_pending);
   }
   q = ce;
   // what follows the key (unique ids, extensions) and the tail behind the TBS are both known now:
   // a two-region reader fetches them in one burst
   r.touch_tail(q, tbs_end);
+  if (spki) spki_key_finish(r, L, key_alg, key_pending, ok, o.nonfatal);
   // UniqueId, SubjectUniqueId asn1.BitString `optional,tag:1|2`, Extensions `optional,explicit,tag:3`: each parses the
   // header at the current position (which must be a valid header) and skips itself when the tag is not its own;
   // whatever is left in the TBSCertificate after the three is ignored.
@@ -725,16 +741,17 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
 }
 
 template <class R>
-CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr) {
-  return filter ? walk_cert(r, L, o, true, *filter) : walk_cert(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
+CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr, bool spki = true) {
+  return filter ? walk_cert(r, L, o, true, *filter, spki)
+                : walk_cert(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki);
 }
 template <class R>
 CTMR_HD bool walk_names(R& r, uint32_t L, Walk& o) {
   return walk_cert<R, false, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
 }
 template <class R>
-CTMR_HD bool walk_tbs(R& r, uint32_t L, Walk& o) {
-  return walk_cert<R, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
+CTMR_HD bool walk_tbs(R& r, uint32_t L, Walk& o, bool spki = true) {
+  return walk_cert<R, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki);
 }
 
 }  // namespace ctmr

@@ -41,8 +41,8 @@ struct DecodeArgs {
 // the same per-lane LDS windows as the map (coop_fill), walk_tbs = the certificate walk without the outer wrapper and the
 // signature.  Runs BEFORE the decode + match kernel, which treats a flagged entry as undecodable: its Chain[0] is never
 // looked at, let alone registered.  Costs one more pass over ≈ 3 windows of every precertificate entry: opt-in.
-__global__ void __launch_bounds__(64) k_leaf_tbs_check(const uint8_t* blob, const uint64_t* bounds, uint64_t n, uint64_t limit,
-                                                       uint8_t* leaf_bad) {
+__global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uint64_t* bounds, uint64_t n, uint64_t limit,
+                                                       uint8_t* leaf_bad, uint32_t strict_spki) {
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64) k_leaf_tbs_check(const uint8_t* blob, cons
   if (pre) {
     WinReaderC<16> r{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)), (int32_t)(int64_t)(g_me - lo)}};
     Walk w;
-    ok = walk_tbs(r, len, w);
+    ok = walk_tbs(r, len, w, strict_spki != 0u);
   }
   if (i < n) leaf_bad[i] = (uint8_t)(pre && !ok);
 }

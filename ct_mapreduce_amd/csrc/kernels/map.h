@@ -68,7 +68,7 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
   const FilterDev* f = a.filt;
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
-  bool ok = walk_cert(r, L, w, f->active != 0u, fv);  // L > 2^31-1 is rejected inside, without divergence
+  bool ok = walk_cert(r, L, w, f->active != 0u, fv, f->strict_spki != 0u);  // L > 2^31-1 is rejected inside, without divergence
   const uint32_t iss = in.iss, et = in.et;
   // An X509 entry's certificate was parsed by ct.LogEntryFromLeaf, which keeps it unless the error is fatal
   // (ct-fetch.go:452-459); a precertificate is parsed in insertCTWorker and dropped on ANY error, CT-go's
@@ -179,7 +179,7 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
 // window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: WIN_LDS_BYTES per wave.
 // The first fill is wave-cooperative (coop_fill, readers.h).
 template <int WCH>
-__global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
+__global__ void CTMR_WALK_BOUNDS k_map_winc(MapArgs a) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;

@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 //   XM_BLOOM  Bloom variant: the key of every entry that claimed or may claim a slot (CLAIMED / DEFER) is added to the
 //             rank's cumulative filter with one fire-and-forget 8-byte atomicOr — no separate pass over the records.
 template <int WCH, bool META, int MODE>
-__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
+__global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;

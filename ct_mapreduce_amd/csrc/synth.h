@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "der_walk.h"  // CTMR_HD
+#include "synth_p256.h"
 
 namespace ctmr {
 
@@ -211,9 +212,13 @@ CTMR_HD void put_rsa_spki(BackWriter& w, Rng& r) {
   w.hdr(0x30, end);
 }
 
-CTMR_HD void put_ec_spki(BackWriter& w, Rng& r) {  // id-ecPublicKey, prime256v1, uncompressed point: 91 bytes
+// id-ecPublicKey, prime256v1, uncompressed point: 91 bytes.  The point is a REAL curve point (one of the 64 of
+// synth_p256.h, picked by the stream): CT-go's parsePublicKey (elliptic.Unmarshal) — like OpenSSL — rejects a
+// certificate whose point is off the curve, so 64 random bytes (rounds 1–3) made a corpus the reference drops.
+CTMR_HD void put_ec_spki(BackWriter& w, Rng& r) {
+  static constexpr uint8_t kPoints[64][64] = CTMR_P256_POINTS;
   const uint32_t end = w.pos;
-  w.random(r, 64);
+  w.bytes(kPoints[r.next() & 63u], 64);
   w.put(0x04);
   w.put(0x00);
   w.hdr(0x03, end);

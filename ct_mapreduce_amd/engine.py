@@ -412,6 +412,10 @@ class Engine:
         """Walk the leaf TBSCertificate of precertificate entries as ct.LogEntryFromLeaf does (include/ctmr.h); default off."""
         self._ck(self._lib.ctmr_set_strict_leaf(self._h, int(bool(on))))
 
+    def set_strict_spki(self, on: bool):
+        """parsePublicKey's verdict on the key inside subjectPublicKeyInfo (ctmr_set_strict_spki): ON by default."""
+        self._ck(self._lib.ctmr_set_strict_spki(self._h, int(bool(on))))
+
     def set_strict_strings(self, on: bool):
         """Go-stdlib character-set rules for the string values of both Names, filed as a non-fatal finding (include/ctmr.h);
         default off.  Set it before registering issuers."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTMR_ABI_VERSION 4
+#define CTMR_ABI_VERSION 5
 
 enum {
   CTMR_OK = 0,
@@ -490,6 +490,18 @@ int ctmr_set_chain0_match(ctmr_engine* e, int mode);
  * else looks at the entry; an entry whose leaf TBSCertificate does not parse gets CTMR_ENTRY_INVALID /
  * CTMR_ST_ENTRY_DECODE_ERROR and its Chain[0] is never registered, as in the reference. */
 int ctmr_set_strict_leaf(ctmr_engine* e, int on);
+/* The public key inside subjectPublicKeyInfo.  x509.ParseCertificate (cmd/ct-fetch/ct-fetch.go:202, :221, :452) ends in
+ * CT-go's parsePublicKey: an RSA key that is not SEQUENCE { INTEGER n, INTEGER e > 0 } with nothing behind it, a DSA key or
+ * parameter set that is not positive INTEGERs, an EC key whose parameters do not name P-224/256/384/521 (or secp192r1)
+ * or whose point is not an uncompressed point ON that curve is a FATAL parse error — the entry never reaches Store, in
+ * any role; RSA parameters other than NULL, an INTEGER of the key that is not minimally encoded, a modulus <= 0 and
+ * secp192r1 are non-fatal findings (an X509 entry keeps its certificate, a precertificate and a Chain[0] issuer are
+ * dropped, like every other finding).  Other algorithms' keys are not looked at.  ON by default since ABI v5 (rounds
+ * 1-3 skipped the key bits by length and accepted such certificates); on = 0 restores that, for a host that has
+ * already parsed the keys.  Applies to the map, to issuers registered AFTER the call and, with strict_leaf, to the leaf
+ * TBSCertificate.  Rules and their provenance (recalled from CT-go v1.1.0, cross-checked against OpenSSL): spki_key.h,
+ * DESIGN.md §3.1. */
+int ctmr_set_strict_spki(ctmr_engine* e, int on);
 /* Character sets of the string values in the issuer and subject Names.  Go's encoding/asn1 rejects a PrintableString
  * with an octet outside A-Z a-z 0-9 space ' ( ) + , - . / : = ? (and '*', '&', which it tolerates), a NumericString
  * with anything but digits and space, an IA5String with an octet >= 0x80 and a UTF8String that is not valid UTF-8.

@@ -326,6 +326,235 @@ static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint
   return 1;
 }
 
+/* ------------------------------------------------------------------ the public key
+ * certificate-transparency-go x509.parsePublicKey (called by parseCertificate for every certificate the path parses:
+ * cmd/ct-fetch/ct-fetch.go:202, :221, and :452 inside LogEntryFromLeaf).  CT-go v1.1.0 is not on this machine: the rules
+ * are RECALLED (parity unpinned like the rest of the CT-go boundary); OpenSSL's X509_get_pubkey is the
+ * independent opinion the tests hold against them.
+ *   asn1Data := keyData.PublicKey.RightAlign()
+ *   RSA (1.2.840.113549.1.1.1; RSAES-OAEP 1.2.840.113549.1.1.7 for the key part):
+ *     parameters != asn1.NullBytes → nfe "RSA key missing NULL parameters" (RSA only);
+ *     asn1.Unmarshal(asn1Data, &pkcs1PublicKey{N *big.Int; E int}) — on error the lax re-parse, its success is an nfe;
+ *     rest != empty → fatal "trailing data after RSA public key"; N <= 0 → nfe; E <= 0 → fatal
+ *   DSA (1.2.840.10040.4.1): asn1Data = INTEGER y (lax re-parse → nfe), no rest; parameters = dsaAlgorithmParameters
+ *     {P, Q, G *big.Int} by the strict parser only; any of the four <= 0 → fatal
+ *   ECDSA (1.2.840.10045.2.1): parameters = exactly one OBJECT IDENTIFIER; namedCurveFromOID: P-224, P-256, P-384, P-521,
+ *     and CT-go's secp192r1 with an nfe; otherwise fatal "unsupported elliptic curve"; elliptic.Unmarshal (Go 1.13):
+ *     len = 1 + 2*ceil(bits/8), data[0] = 4, x < p, y < p, IsOnCurve: y^2 = x^3 - 3x + b mod p; nil → fatal
+ *   anything else: parsePublicKey returns (nil, nil) — the key is not looked at.
+ * Big numbers here: 32-bit limbs, multiplication mod p by double-and-add over the bits of one factor — nothing in common
+ * with the product's Montgomery form (ct_mapreduce_amd/csrc/spki_key.h). */
+#define BN_W 18
+typedef struct { uint32_t w[BN_W]; } bn;
+
+static void bn_from_be(bn* r, const uint8_t* s, size_t n) {
+  memset(r, 0, sizeof *r);
+  for (size_t i = 0; i < n; i++) {
+    size_t bit = 8 * (n - 1 - i);
+    r->w[bit / 32] |= (uint32_t)s[i] << (bit % 32);
+  }
+}
+static void bn_from_hex(bn* r, const char* h) {
+  uint8_t b[72];
+  size_t n = strlen(h) / 2;
+  for (size_t i = 0; i < n; i++) {
+    unsigned v;
+    sscanf(h + 2 * i, "%2x", &v);
+    b[i] = (uint8_t)v;
+  }
+  bn_from_be(r, b, n);
+}
+static int bn_cmp(const bn* a, const bn* b) {
+  for (int i = BN_W - 1; i >= 0; i--)
+    if (a->w[i] != b->w[i]) return a->w[i] < b->w[i] ? -1 : 1;
+  return 0;
+}
+static void bn_add(bn* r, const bn* a, const bn* b) { /* no overflow: values stay below 2^545 */
+  uint64_t c = 0;
+  for (int i = 0; i < BN_W; i++) {
+    c += (uint64_t)a->w[i] + b->w[i];
+    r->w[i] = (uint32_t)c;
+    c >>= 32;
+  }
+}
+static void bn_sub(bn* r, const bn* a, const bn* b) { /* a >= b */
+  int64_t c = 0;
+  for (int i = 0; i < BN_W; i++) {
+    c += (int64_t)a->w[i] - b->w[i];
+    r->w[i] = (uint32_t)c;
+    c >>= 32;
+  }
+}
+static void bn_addmod(bn* r, const bn* a, const bn* b, const bn* p) {
+  bn t;
+  bn_add(&t, a, b);
+  if (bn_cmp(&t, p) >= 0) bn_sub(&t, &t, p);
+  *r = t;
+}
+static void bn_submod(bn* r, const bn* a, const bn* b, const bn* p) {
+  bn t;
+  if (bn_cmp(a, b) >= 0) {
+    bn_sub(&t, a, b);
+  } else {
+    bn_add(&t, a, p);
+    bn_sub(&t, &t, b);
+  }
+  *r = t;
+}
+static void bn_mulmod(bn* r, const bn* a, const bn* b, const bn* p) {
+  bn acc;
+  memset(&acc, 0, sizeof acc);
+  for (int bit = BN_W * 32 - 1; bit >= 0; bit--) {
+    bn_addmod(&acc, &acc, &acc, p);
+    if ((b->w[bit / 32] >> (bit % 32)) & 1) bn_addmod(&acc, &acc, a, p);
+  }
+  *r = acc;
+}
+
+typedef struct { const char* oid_hex; uint32_t bits; const char* p; const char* b; int insecure; } ec_curve;
+static const ec_curve EC_CURVES[5] = {
+    {"2a8648ce3d030107", 256, "ffffffff00000001000000000000000000000000ffffffffffffffffffffffff",
+     "5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b", 0},
+    {"2b81040022", 384,
+     "fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffeffffffff0000000000000000ffffffff",
+     "b3312fa7e23ee7e4988e056be3f82d19181d9c6efe8141120314088f5013875ac656398d8a2ed19d2a85c8edd3ec2aef", 0},
+    {"2b81040023", 521,
+     "01ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff",
+     "0051953eb9618e1c9a1f929a21a0b68540eea2da725b99b315f3b8b489918ef109e156193951ec7e937b1652c0bd3bb1bf073573df883d2c34f1ef451fd46b503f00",
+     0},
+    {"2b81040021", 224, "ffffffffffffffffffffffffffffffff000000000000000000000001",
+     "b4050a850c04b3abf54132565044b0b7d7bfd8ba270b39432355ffb4", 0},
+    {"2a8648ce3d030101", 192, "fffffffffffffffffffffffffffffffeffffffffffffffff",
+     "64210519e59c80e70fa7e9ab72243049feb8deecc146b9b1", 1}, /* CT-go's secp192r1: "insecure curve" nfe */
+};
+
+/* elliptic.Unmarshal(curve, data) != nil */
+static int ec_unmarshal_ok(const ec_curve* c, const uint8_t* data, size_t n) {
+  size_t bl = (c->bits + 7) / 8;
+  if (n != 1 + 2 * bl || data[0] != 4) return 0;
+  bn p, b, x, y, three, l, r, t;
+  bn_from_hex(&p, c->p);
+  bn_from_hex(&b, c->b);
+  bn_from_be(&x, data + 1, bl);
+  bn_from_be(&y, data + 1 + bl, bl);
+  if (bn_cmp(&x, &p) >= 0 || bn_cmp(&y, &p) >= 0) return 0;
+  memset(&three, 0, sizeof three);
+  three.w[0] = 3;
+  bn_mulmod(&l, &y, &y, &p);      /* y^2 */
+  bn_mulmod(&r, &x, &x, &p);
+  bn_mulmod(&r, &r, &x, &p);      /* x^3 */
+  bn_mulmod(&t, &x, &three, &p);
+  bn_submod(&r, &r, &t, &p);      /* - 3x */
+  bn_addmod(&r, &r, &b, &p);      /* + b */
+  return bn_cmp(&l, &r) == 0;
+}
+
+/* *big.Int / int at p inside [p, end) of buffer k: 1 = minimal, -1 = only the lax parse accepts it, 0 = error.
+ * *sign = sign of the value, *len = content length, *after = end of the element. */
+static int key_integer(const uint8_t* k, uint64_t p, uint64_t end, int* sign, uint32_t* len, uint64_t* after) {
+  tlv t;
+  if (!rd_tlv(k, p, end, &t) || t.tag != 0x02) return 0;
+  uint64_t c = p + t.hl;
+  int ci = check_integer(k, c, t.len);
+  if (ci == 0) return 0;
+  if (k[c] & 0x80) {
+    *sign = -1;
+  } else {
+    *sign = 0;
+    for (uint32_t i = 0; i < t.len; i++)
+      if (k[c + i]) *sign = 1;
+  }
+  *len = t.len;
+  *after = c + t.len;
+  return ci;
+}
+
+static int bytes_are(const uint8_t* d, uint32_t n, const char* hex) {
+  if (strlen(hex) != 2 * (size_t)n) return 0;
+  for (uint32_t i = 0; i < n; i++) {
+    unsigned v;
+    sscanf(hex + 2 * i, "%2x", &v);
+    if (d[i] != v) return 0;
+  }
+  return 1;
+}
+
+/* spki = contents of the SubjectPublicKeyInfo SEQUENCE, already accepted by the structural walk.  Sets
+ * out->spki_fatal (an error site, 0 = none) and ORs ORC_PK_* findings into out->spki_findings. */
+static void check_public_key(const uint8_t* d, uint64_t k, uint64_t k_end, orc_cert* out) {
+  tlv a, oid, par, bits;
+  rd_tlv(d, k, k_end, &a);
+  uint64_t x = k + a.hl, x_end = x + a.len;
+  rd_tlv(d, x, x_end, &oid);
+  const uint8_t* oc = d + x + oid.hl;
+  x += oid.hl + oid.len;
+  int has_par = x < x_end;
+  uint64_t par_p = x;
+  if (has_par) rd_tlv(d, x, x_end, &par);
+  uint32_t par_total = has_par ? par.hl + par.len : 0;
+  uint64_t bp = k + a.hl + a.len;
+  rd_tlv(d, bp, k_end, &bits);
+  uint64_t bc = bp + bits.hl;
+  /* BitString.RightAlign */
+  uint32_t n = bits.len - 1, shift = d[bc];
+  uint8_t* key = (uint8_t*)malloc((size_t)n + 8);
+  memset(key, 0, (size_t)n + 8);
+  for (uint32_t i = 0; i < n; i++) {
+    uint8_t cur = d[bc + 1 + i], prev = i ? d[bc + i] : 0;
+    key[i] = shift ? (uint8_t)((prev << (8 - shift)) | (cur >> shift)) : cur;
+  }
+  int is_rsa = bytes_are(oc, oid.len, "2a864886f70d010101"), is_oaep = bytes_are(oc, oid.len, "2a864886f70d010107");
+#define PKFAIL(site)            \
+  do {                          \
+    out->spki_fatal = (site);   \
+    free(key);                  \
+    return;                     \
+  } while (0)
+  if (is_rsa || is_oaep) {
+    if (is_rsa && !(par_total == 2 && d[par_p] == 0x05 && d[par_p + 1] == 0x00)) out->spki_findings |= ORC_PK_RSA_PARAMS;
+    tlv seq;
+    if (!rd_tlv(key, 0, n, &seq) || seq.tag != 0x30) PKFAIL(80);
+    if ((uint64_t)seq.hl + seq.len != n) PKFAIL(81); /* trailing data after RSA public key */
+    uint64_t q = seq.hl, q_end = n, after;
+    int sign;
+    uint32_t len;
+    int ci = key_integer(key, q, q_end, &sign, &len, &after);
+    if (ci == 0) PKFAIL(82);
+    if (ci < 0) out->spki_findings |= ORC_PK_LAX_INTEGER;
+    if (sign <= 0) out->spki_findings |= ORC_PK_RSA_MODULUS;
+    ci = key_integer(key, after, q_end, &sign, &len, &after);
+    if (ci == 0) PKFAIL(83);
+    if (len > 8) PKFAIL(84); /* parseInt64: integer too large */
+    if (ci < 0) out->spki_findings |= ORC_PK_LAX_INTEGER;
+    if (sign <= 0) PKFAIL(85); /* RSA public exponent is not a positive number */
+  } else if (bytes_are(oc, oid.len, "2a8648ce380401")) {
+    int sign;
+    uint32_t len;
+    uint64_t after;
+    int ci = key_integer(key, 0, n, &sign, &len, &after);
+    if (ci == 0) PKFAIL(86);
+    if (after != n) PKFAIL(87); /* trailing data after DSA public key */
+    if (ci < 0) out->spki_findings |= ORC_PK_LAX_INTEGER;
+    if (sign <= 0) PKFAIL(88);
+    if (!has_par || par.tag != 0x30) PKFAIL(89);
+    uint64_t q = par_p + par.hl, q_end = par_p + par_total;
+    for (int i = 0; i < 3; i++) {
+      if (key_integer(d, q, q_end, &sign, &len, &q) != 1) PKFAIL(90); /* strict parse only */
+      if (sign <= 0) PKFAIL(91);
+    }
+  } else if (bytes_are(oc, oid.len, "2a8648ce3d0201")) {
+    if (!has_par || par.tag != 0x06) PKFAIL(92);
+    const ec_curve* c = NULL;
+    for (int i = 0; i < 5; i++)
+      if (bytes_are(d + par_p + par.hl, par.len, EC_CURVES[i].oid_hex)) c = &EC_CURVES[i];
+    if (!c) PKFAIL(93); /* unsupported elliptic curve (or not a well-formed OID at all) */
+    if (c->insecure) out->spki_findings |= ORC_PK_INSECURE_CURVE;
+    if (!ec_unmarshal_ok(c, key, n)) PKFAIL(94); /* failed to unmarshal elliptic curve point */
+  }
+#undef PKFAIL
+  free(key);
+}
+
 /* tbs_only: the buffer is a bare TBSCertificate — CT-go x509.ParseTBSCertificate, which ct.LogEntryFromLeaf applies to the
  * TBSCertificate of a precertificate entry's MerkleTreeLeaf (cmd/ct-fetch/ct-fetch.go:452): asn1.Unmarshal into
  * tbsCertificate, "trailing data" when anything follows it, then the same parseCertificate as for a whole certificate
@@ -409,6 +638,7 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
     if (!alg_id(d, k, k_end, &a, &site, 70)) FAIL(site);
     k += a.hl + a.len;
     if (!rd_tlv(d, k, k_end, &a) || a.tag != 0x03 || !bit_string_ok(d, k + a.hl, a.len)) FAIL(73);
+    check_public_key(d, q + t.hl, k_end, out); /* parsePublicKey: spki_fatal / spki_findings, applied by the engine (strict_spki) */
   }
   q += t.hl + t.len;
   /* UniqueId, SubjectUniqueId asn1.BitString `optional,tag:1|2`; Extensions `optional,explicit,tag:3`.  Each
@@ -809,6 +1039,7 @@ struct orc_engine {
   size_t filter_len;
   int log_expired;
   int strict_strings; /* the stdlib's character-set rules for the Names' string values, as non-fatal findings (orc_engine_set_strict_strings) */
+  int strict_spki; /* parsePublicKey's verdict on the key inside subjectPublicKeyInfo (orc_engine_set_strict_spki; ON by default) */
   int strict_leaf; /* LogEntryFromLeaf's parse of a precertificate entry's leaf TBSCertificate (orc_engine_set_strict_leaf) */
   int64_t now;
   int64_t inserted;
@@ -824,6 +1055,7 @@ orc_engine* orc_engine_new(const char* filter, size_t filter_len, int log_expire
   e->filter[filter_len] = 0;
   e->filter_len = filter_len;
   e->log_expired = log_expired;
+  e->strict_spki = 1;
   e->now = now;
   e->k2s_n = 64;
   e->key_to_set = (uint64_t*)calloc(e->k2s_n * 2, sizeof(uint64_t));
@@ -1026,7 +1258,9 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   orc_parse_cert(leaf, leaf_len, &c); /* :198-204 */
   /* X509 entry: the certificate LogEntryFromLeaf parsed, kept unless the error was fatal (:452-459);
    * precertificate: parsed here, dropped on ANY error, x509.NonFatalErrors included (:202-209) */
-  if (!c.ok || (entry_type == 1 && (c.nonfatal || (e->strict_strings && c.string_findings)))) return ORC_ST_PARSE_ERROR; /* :206-209 */
+  if (!c.ok || (e->strict_spki && c.spki_fatal)) return ORC_ST_PARSE_ERROR;
+  if (entry_type == 1 && (c.nonfatal || (e->strict_strings && c.string_findings) || (e->strict_spki && c.spki_findings)))
+    return ORC_ST_PARSE_ERROR; /* :206-209 */
   if (exp_hour) *exp_hour = orc_exp_hour(c.not_after);
   if (serial) *serial = leaf + c.serial_off;
   if (serial_len) *serial_len = c.serial_len;
@@ -1035,7 +1269,8 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   if (!issuer_der) return ORC_ST_NO_ISSUER; /* :215-219 */
   orc_cert ic;
   orc_parse_cert(issuer_der, issuer_len, &ic); /* :221 */
-  if (!ic.ok || ic.nonfatal || (e->strict_strings && ic.string_findings)) return ORC_ST_ISSUER_PARSE_ERROR; /* any err :222-225 */
+  if (!ic.ok || ic.nonfatal || (e->strict_strings && ic.string_findings) || (e->strict_spki && (ic.spki_fatal || ic.spki_findings)))
+    return ORC_ST_ISSUER_PARSE_ERROR; /* any err :222-225 */
   /* Store: filesystemdatabase.go:158-211 */
   int32_t eh = orc_exp_hour(c.not_after);           /* :160 */
   char issuer_id[45];
@@ -1179,6 +1414,7 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
 }
 
 void orc_engine_set_strict_leaf(orc_engine* e, int on) { e->strict_leaf = on != 0; }
+void orc_engine_set_strict_spki(orc_engine* e, int on) { e->strict_spki = on != 0; }
 void orc_engine_set_strict_strings(orc_engine* e, int on) { e->strict_strings = on != 0; }
 
 void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
@@ -1197,7 +1433,7 @@ void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bo
        * downloader then drops (ct-fetch.go:452-459) — non-fatal findings are kept there */
       orc_cert tc;
       orc_parse_tbs(leaf + d.tbs_off, d.tbs_len, &tc);
-      if (!tc.ok) d.ok = 0;
+      if (!tc.ok || (e->strict_spki && tc.spki_fatal)) d.ok = 0;
     }
     if (d.ok) {
       /* ct-fetch.go:198-204 the certificate; :215 len(Chain) < 1; :221 Chain[0] */

@@ -66,12 +66,19 @@ typedef struct {
                             all the same; kept for X509 entries, dropped for precertificates and Chain[0] issuers */
   int32_t string_findings; /* ORC_SF_*: Name values that break their string type's character set (Go stdlib rules; kept apart
                               from `nonfatal`: only an engine with strict_strings set acts on them) */
+  int32_t spki_fatal;    /* parsePublicKey (CT-go, recalled): 0 = the key parses, else the check that failed — a FATAL error
+                            of x509.ParseCertificate; kept apart from `ok`: an engine acts on it unless strict_spki is off */
+  int32_t spki_findings; /* ORC_PK_*: what parsePublicKey files as non-fatal (same switch) */
 } orc_cert;
 
 #define ORC_SF_PRINTABLE 1
 #define ORC_SF_NUMERIC 2
 #define ORC_SF_IA5 4
 #define ORC_SF_UTF8 8
+#define ORC_PK_RSA_PARAMS 1     /* "x509: RSA key missing NULL parameters" */
+#define ORC_PK_LAX_INTEGER 2    /* an INTEGER of the key only the lax re-parse accepts */
+#define ORC_PK_RSA_MODULUS 4    /* "x509: RSA modulus is not a positive number" */
+#define ORC_PK_INSECURE_CURVE 8 /* secp192r1 */
 #define ORC_NF_NEGATIVE_SERIAL 1 /* "x509: negative serial number" */
 #define ORC_NF_LAX_INTEGER 2     /* an INTEGER only CT-go's lax asn1 re-parse accepts: not minimally encoded */
 
@@ -187,6 +194,8 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
 void orc_engine_set_strict_leaf(orc_engine*, int on);
 /* Go stdlib character-set rules for the string values of both Names, filed as non-fatal findings (default off) */
 void orc_engine_set_strict_strings(orc_engine*, int on);
+/* parsePublicKey's verdict on the key (ON by default: the reference always parses the key); 0 = rounds 1-3 behaviour */
+void orc_engine_set_strict_spki(orc_engine*, int on);
 void orc_engine_raw_batch(orc_engine*, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
                           uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,
                           uint64_t* out_timestamp);

@@ -36,11 +36,12 @@ class Cert(C.Structure):
                 ("spki_off", C.c_uint32), ("spki_len", C.c_uint32),
                 ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32), ("issuer_off", C.c_uint32), ("issuer_len", C.c_uint32),
                 ("exts_off", C.c_uint32), ("exts_end", C.c_uint32), ("nonfatal", C.c_int32),
-                ("string_findings", C.c_int32)]
+                ("string_findings", C.c_int32), ("spki_fatal", C.c_int32), ("spki_findings", C.c_int32)]
 
 
 NF_NEGATIVE_SERIAL, NF_LAX_INTEGER = 1, 2
 SF_PRINTABLE, SF_NUMERIC, SF_IA5, SF_UTF8 = 1, 2, 4, 8
+PK_RSA_PARAMS, PK_LAX_INTEGER, PK_RSA_MODULUS, PK_INSECURE_CURVE = 1, 2, 4, 8
 
 
 def pem_encode(der: bytes) -> bytes:
@@ -64,6 +65,7 @@ def lib():
         L.orc_parse_tbs.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Cert)]
         L.orc_engine_set_strict_leaf.argtypes = [C.c_void_p, C.c_int]
         L.orc_engine_set_strict_strings.argtypes = [C.c_void_p, C.c_int]
+        L.orc_engine_set_strict_spki.argtypes = [C.c_void_p, C.c_int]
         L.orc_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.restype = C.c_size_t
@@ -125,17 +127,31 @@ def decode_entry(leaf_input: bytes, extra_data: bytes) -> Entry:
     return e
 
 
-def parse_cert(der: bytes) -> Cert:
-    c = Cert()
-    lib().orc_parse_cert(der, len(der), C.byref(c))
+NF_SPKI = 8   # parsePublicKey filed a non-fatal finding (mirrors the product's WALK_NF_SPKI)
+
+
+def _fold_spki(c: Cert, strict_spki: bool) -> Cert:
+    """What an engine with strict_spki (the default) makes of parsePublicKey's verdict: a fatal error is a parse error,
+    a finding one more non-fatal finding.  The C struct keeps the two apart (spki_fatal / spki_findings)."""
+    if strict_spki:
+        if c.ok and c.spki_fatal:
+            c.ok, c.err_site = 0, c.spki_fatal
+        if c.spki_findings:
+            c.nonfatal |= NF_SPKI
     return c
 
 
-def parse_tbs(tbs: bytes) -> Cert:
+def parse_cert(der: bytes, strict_spki: bool = True) -> Cert:
+    c = Cert()
+    lib().orc_parse_cert(der, len(der), C.byref(c))
+    return _fold_spki(c, strict_spki)
+
+
+def parse_tbs(tbs: bytes, strict_spki: bool = True) -> Cert:
     """A bare TBSCertificate (what ct.LogEntryFromLeaf parses of a precertificate entry's leaf)."""
     c = Cert()
     lib().orc_parse_tbs(tbs, len(tbs), C.byref(c))
-    return c
+    return _fold_spki(c, strict_spki)
 
 
 def sha256(b: bytes) -> bytes:
@@ -189,6 +205,10 @@ class Engine:
     def set_strict_strings(self, on: bool):
         """Character sets of the Names' string values (Go stdlib rules) as one more non-fatal finding; default off."""
         lib().orc_engine_set_strict_strings(self._h, int(bool(on)))
+
+    def set_strict_spki(self, on: bool):
+        """parsePublicKey's verdict on the key inside subjectPublicKeyInfo (default ON, as in the reference)."""
+        lib().orc_engine_set_strict_spki(self._h, int(bool(on)))
 
     def close(self):
         if self._h:

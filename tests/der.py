@@ -36,7 +36,27 @@ def gentime(s):
 
 
 SIGALG = bytes.fromhex("300d06092a864886f70d01010b0500")
-EC_SPKI = bytes.fromhex("3059301306072a8648ce3d020106082a8648ce3d030107034200") + bytes(range(1, 66))
+# id-ecPublicKey / prime256v1 with the curve's base point G as the key: a point ON the curve (CT-go's parsePublicKey —
+# elliptic.Unmarshal — and OpenSSL both reject a certificate whose point is not)
+P256_G = bytes.fromhex("6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296"
+                       "4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5")
+EC_SPKI = bytes.fromhex("3059301306072a8648ce3d020106082a8648ce3d030107034200") + b"\x04" + P256_G
+
+
+def spki(alg_oid, params, key_bits, pad=0):
+    """SubjectPublicKeyInfo from the algorithm OID's content octets, the parameters TLV (b"" = absent) and the BIT
+    STRING's octets behind the pad count."""
+    return seq(seq(tlv(0x06, alg_oid), params), tlv(0x03, bytes([pad]) + key_bits))
+
+
+OID_RSA = bytes.fromhex("2a864886f70d010101")
+OID_DSA = bytes.fromhex("2a8648ce380401")
+OID_EC = bytes.fromhex("2a8648ce3d0201")
+NULL = b"\x05\x00"
+
+
+def rsa_spki(n=b"\x00" + b"\xc3" * 256, e=b"\x01\x00\x01", params=NULL, inner_extra=b"", outer_extra=b"", pad=0, alg=OID_RSA):
+    return spki(alg, params, seq(tlv(0x02, n), tlv(0x02, e), inner_extra) + outer_extra, pad)
 
 
 def ext(oid_last, value, critical=None):

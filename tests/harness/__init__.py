@@ -10,7 +10,7 @@ def _build(src, out, cmd):
     outp = os.path.join(HERE, out)
     srcp = os.path.join(HERE, src)
     csrc = os.path.join(HERE, "..", "..", "ct_mapreduce_amd", "csrc")
-    deps = [os.path.join(csrc, h) for h in ("der_walk.h", "entry_decode.h")]
+    deps = [os.path.join(csrc, h) for h in ("der_walk.h", "spki_key.h", "ec_curves.h", "entry_decode.h")]
     if (not os.path.exists(outp) or os.path.getmtime(outp) < os.path.getmtime(srcp)
             or any(os.path.getmtime(outp) < os.path.getmtime(d) for d in deps)):
         subprocess.check_call(cmd + [srcp, "-o", outp])
@@ -75,6 +75,12 @@ def product_walk(der: bytes, fill=0xA5, cn_filter=None) -> HarnessOut:
     return o
 
 
+def product_set_spki(on: bool):
+    """The host build's strict_spki switch (default on): parse the public key as CT-go's parsePublicKey does."""
+    product_walk(b"\x30\x00")
+    _walk.harness_set_spki(int(bool(on)))
+
+
 def product_walk_tbs(tbs: bytes, fill=0xA5) -> HarnessOut:
     """The product's walk over a bare TBSCertificate (strict_leaf)."""
     product_walk(b"\x30\x00")          # builds and binds the library
@@ -112,10 +118,18 @@ def ossl_extract(der: bytes):
             subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", srcp, "-o", outp, "-lcrypto"])
         _ossl = C.CDLL(outp)
         _ossl.ossl_extract.argtypes = [C.c_char_p, C.c_long, C.POINTER(OsslOut)]
+        _ossl.ossl_pubkey_ok.argtypes = [C.c_char_p, C.c_long]
     o = OsslOut()
     if not _ossl.ossl_extract(der, len(der), C.byref(o)):
         return None
     return o
+
+
+def ossl_pubkey_ok(der: bytes) -> int:
+    """OpenSSL's opinion on the public key: 1 = certificate and key decode (X509_get_pubkey), 0 = the key does not,
+    -1 = the certificate does not."""
+    ossl_extract(b"\x30\x00")
+    return _ossl.ossl_pubkey_ok(der, len(der))
 
 
 _hk = None

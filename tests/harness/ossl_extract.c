@@ -49,3 +49,17 @@ int ossl_extract(const unsigned char* der, long len, ossl_out* o) {
   X509_free(x);
   return 1;
 }
+
+/* Third opinion on the PUBLIC KEY (round 4): 1 = OpenSSL decodes the certificate AND its key (X509_get_pubkey: the
+ * RSAPublicKey structure, an EC point on its named curve, …), 0 = the certificate decodes but the key does not,
+ * -1 = the certificate does not decode.  ossl_extract above only re-encodes the raw SPKI and never looks inside. */
+int ossl_pubkey_ok(const unsigned char* der, long len) {
+  const unsigned char* p = der;
+  X509* x = d2i_X509(NULL, &p, len);
+  if (!x || p != der + len) { if (x) X509_free(x); return -1; }
+  EVP_PKEY* k = X509_get_pubkey(x);
+  int ok = k != NULL;
+  if (k) EVP_PKEY_free(k);
+  X509_free(x);
+  return ok;
+}

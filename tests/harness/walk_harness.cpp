@@ -14,6 +14,7 @@ struct PaddedReader {
     return v;
   }
   uint32_t ldg(uint32_t pos) const { return ld4(pos); }
+  ctmr::RawCert raw() const { return ctmr::RawCert{(const uint32_t*)p, 0}; }  // the out-of-line key checks, as on the device
   void touch(uint32_t, uint32_t) const {}
   void touch_tail(uint32_t, uint32_t) const {}
 };
@@ -29,6 +30,10 @@ struct HarnessOut {
   int32_t cn_match;
   int32_t nonfatal;
 };
+
+// spki: 1 = the walk also parses the public key (ctmr_set_strict_spki, the default), 0 = rounds 1-3 behaviour
+static int g_spki = 1;
+extern "C" void harness_set_spki(int on) { g_spki = on; }
 
 extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, const char* filter,
                                uint32_t flen, int use_filter, HarnessOut* out);
@@ -58,7 +63,7 @@ extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, c
   memcpy(buf.data(), der, len);
   PaddedReader r{buf.data()};
   ctmr::Walk w;
-  const bool ok = ctmr::walk_cert(r, len, w, use_filter ? &fv : nullptr);
+  const bool ok = ctmr::walk_cert(r, len, w, use_filter ? &fv : nullptr, g_spki != 0);
   memset(out, 0, sizeof *out);
   out->ok = ok;
   if (!ok) return;
@@ -78,7 +83,7 @@ extern "C" void harness_walk_tbs(const uint8_t* tbs, uint32_t len, uint8_t fill,
   memcpy(buf.data(), tbs, len);
   PaddedReader r{buf.data()};
   ctmr::Walk w;
-  const bool ok = ctmr::walk_tbs(r, len, w);
+  const bool ok = ctmr::walk_tbs(r, len, w, g_spki != 0);
   memset(out, 0, sizeof *out);
   out->ok = ok;
   if (!ok) return;

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), n
         assert n in N.SIGNATURES, f"{n} missing from the ctypes binding"
     assert sorted(N.SIGNATURES) == names
-    assert lib.ctmr_abi_version() == N.ABI_VERSION == 4
+    assert lib.ctmr_abi_version() == N.ABI_VERSION == 5
 
 
 def test_struct_sizes_match_the_header():

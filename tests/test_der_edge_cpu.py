@@ -152,7 +152,9 @@ def test_version_wrapper_and_int_rules():
 def test_algorithm_identifiers_and_spki_structure():
     def spki(alg, key=D.tlv(0x03, b"\x00" + bytes(65))):
         return D.seq(alg, key)
-    ec = D.seq(D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 2, 1), D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 3, 1, 7))
+    # the STRUCTURE of publicKeyInfo, under an algorithm parsePublicKey does not know (1.2.840.10045.2.2: the key bits
+    # are not looked at; tests/test_spki_cpu.py has the keys of the algorithms it does know)
+    ec = D.seq(D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 2, 2), D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 3, 1, 7))
     assert both(D.cert(spki=spki(ec))).ok
     assert both(D.cert(spki=spki(D.seq(D.oid(0x2a, 3))))).ok                          # parameters are optional
     assert both(D.cert(spki=spki(D.seq(D.oid(0x2a, 3), D.tlv(0x05, b""), D.tlv(0x05, b""))))).ok   # extra elements ignored

@@ -1,0 +1,330 @@
+"""The public key inside subjectPublicKeyInfo (round 4, ctmr_set_strict_spki — ON by default): CT-go's parsePublicKey as
+restated by the oracle (oracle/ctmr_oracle.c check_public_key) and by the product's walk (csrc/spki_key.h, host build),
+one hand-built certificate per rule, both in every case; OpenSSL's X509_get_pubkey as the independent opinion where
+the two libraries' rules coincide (well-formed keys, points off the curve).  CPU only.
+
+Reference call sites: cmd/ct-fetch/ct-fetch.go:202 (precertificate), :221 (Chain[0]), :452 (X509 entry, inside
+ct.LogEntryFromLeaf) — a fatal error drops the entry in every role, a non-fatal finding only in the first two."""
+import random
+import subprocess
+
+import pytest
+
+from ct_mapreduce_amd import synth
+from oracle import oracle as orc
+from tests import der as D
+from tests import harness
+
+NF_SPKI = orc.NF_SPKI
+
+# (OpenSSL curve name, named-curve OID octets, p, b, base point) — base points from `openssl ecparam -param_enc explicit`
+CURVES = {
+    "P256": ("2a8648ce3d030107", 32,
+             "6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296"
+             "4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5"),
+    "P384": ("2b81040022", 48,
+             "aa87ca22be8b05378eb1c71ef320ad746e1d3b628ba79b9859f741e082542a385502f25dbf55296c3a545e3872760ab7"
+             "3617de4a96262c6f5d9e98bf9292dc29f8f41dbd289a147ce9da3113b5f0b8c00a60b1ce1d7e819d7a431d7c90ea0e5f"),
+    "P521": ("2b81040023", 66,
+             "00c6858e06b70404e9cd9e3ecb662395b4429c648139053fb521f828af606b4d3dbaa14b5e77efe75928fe1dc127a2ffa8de3348b3c1856a429bf97e7e31c2e5bd66"
+             "011839296a789a3bc0045c8a5fb42c7d1bd998f54449579b446817afbd17273e662c97ee72995ef42640c550b9013fad0761353c7086a272c24088be94769fd16650"),
+    "P224": ("2b81040021", 28,
+             "b70e0cbd6bb4bf7f321390b94a03c1d356c21122343280d6115c1d21"
+             "bd376388b5f723fb4c22dfe6cd4375a05a07476444d5819985007e34"),
+    "P192": ("2a8648ce3d030101", 24,
+             "188da80eb03090f67cbf20eb43a18800f4ff0afd82ff1012"
+             "07192b95ffc8da78631011ed6b24cdd573f977a11e794811"),
+}
+PRIMES = {"P256": 2**256 - 2**224 + 2**192 + 2**96 - 1, "P384": 2**384 - 2**128 - 2**96 + 2**32 - 1, "P521": 2**521 - 1,
+          "P224": 2**224 - 2**96 + 1, "P192": 2**192 - 2**64 - 1}
+BS = {"P256": 0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B,
+      "P384": 0xB3312FA7E23EE7E4988E056BE3F82D19181D9C6EFE8141120314088F5013875AC656398D8A2ED19D2A85C8EDD3EC2AEF,
+      "P521": 0x0051953EB9618E1C9A1F929A21A0B68540EEA2DA725B99B315F3B8B489918EF109E156193951EC7E937B1652C0BD3BB1BF073573DF883D2C34F1EF451FD46B503F00,
+      "P224": 0xB4050A850C04B3ABF54132565044B0B7D7BFD8BA270B39432355FFB4,
+      "P192": 0x64210519E59C80E70FA7E9AB72243049FEB8DEECC146B9B1}
+
+
+def ec_add(p, q, prime):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2 and (y1 + y2) % prime == 0:
+        return None
+    lam = ((3 * x1 * x1 - 3) * pow(2 * y1, -1, prime) if p == q else (y2 - y1) * pow(x2 - x1, -1, prime)) % prime
+    x3 = (lam * lam - x1 - x2) % prime
+    return x3, (lam * (x1 - x3) - y1) % prime
+
+
+def ec_mul(k, p, prime):
+    r = None
+    while k:
+        if k & 1:
+            r = ec_add(r, p, prime)
+        p = ec_add(p, p, prime)
+        k >>= 1
+    return r
+
+
+def point(curve, k=1):
+    """k·G of the curve as X ‖ Y octets (pure-Python arithmetic, checked against the curve equation)."""
+    _, bl, g = CURVES[curve]
+    g = bytes.fromhex(g)
+    prime = PRIMES[curve]
+    x, y = ec_mul(k, (int.from_bytes(g[:bl], "big"), int.from_bytes(g[bl:], "big")), prime)
+    assert (y * y - (x ** 3 - 3 * x + BS[curve])) % prime == 0
+    return x.to_bytes(bl, "big") + y.to_bytes(bl, "big")
+
+
+def ec_spki(curve="P256", pt=None, params=None, prefix=b"\x04", pad=0):
+    pt = point(curve) if pt is None else pt
+    params = D.tlv(0x06, bytes.fromhex(CURVES[curve][0])) if params is None else params
+    return D.spki(D.OID_EC, params, prefix + pt, pad)
+
+
+def verdict(c, role_nf=None):
+    """(accepted, findings) of the certificate, asserted equal between oracle and product, with the key parse on and off."""
+    o = orc.parse_cert(c)
+    p = harness.product_walk(c)
+    p2 = harness.product_walk(c, 0x00)
+    assert bool(o.ok) == bool(p.ok) == bool(p2.ok), (o.ok, o.err_site, p.ok)
+    if o.ok:
+        assert o.nonfatal == p.nonfatal == p2.nonfatal, (o.nonfatal, p.nonfatal)
+    # the switch: off = the key bits are skipped by length, as in rounds 1-3
+    off = orc.parse_cert(c, strict_spki=False)
+    harness.product_set_spki(False)
+    try:
+        q = harness.product_walk(c)
+    finally:
+        harness.product_set_spki(True)
+    assert bool(off.ok) == bool(q.ok) and (not off.ok or off.nonfatal == q.nonfatal)
+    assert off.ok or not o.ok                     # the key parse only ever removes certificates
+    return bool(o.ok), (o.nonfatal if o.ok else None)
+
+
+def cert(spki, **kw):
+    return D.cert(spki=spki, exts=[D.BC_NOT_CA], **kw)
+
+
+def test_rsa_keys():
+    assert verdict(cert(D.rsa_spki())) == (True, 0)
+    assert harness.ossl_pubkey_ok(cert(D.rsa_spki())) == 1
+    # parameters: anything but NULL is a finding ("RSA key missing NULL parameters"), never fatal
+    assert verdict(cert(D.rsa_spki(params=b""))) == (True, NF_SPKI)
+    assert verdict(cert(D.rsa_spki(params=D.tlv(0x05, b"\x00")))) == (True, NF_SPKI)
+    assert verdict(cert(D.rsa_spki(params=D.tlv(0x30, b"")))) == (True, NF_SPKI)
+    assert verdict(cert(D.rsa_spki(params=D.NULL + D.NULL))) == (True, 0)      # elements behind the parameters are ignored
+    # the SEQUENCE must fill the BIT STRING; elements behind the exponent INSIDE it are ignored
+    assert verdict(cert(D.rsa_spki(outer_extra=b"\x00")))[0] is False
+    assert verdict(cert(D.rsa_spki(outer_extra=D.NULL)))[0] is False
+    assert verdict(cert(D.rsa_spki(inner_extra=D.NULL))) == (True, 0)
+    assert verdict(cert(D.rsa_spki(inner_extra=b"\xff")))[0] is True           # not even a header: never looked at
+    # modulus: sign and minimality
+    assert verdict(cert(D.rsa_spki(n=b"\xc3" * 256))) == (True, NF_SPKI)       # negative
+    assert verdict(cert(D.rsa_spki(n=b"\x00"))) == (True, NF_SPKI)             # zero
+    assert verdict(cert(D.rsa_spki(n=b"\x00\x00\x00"))) == (True, NF_SPKI)     # zero, not minimal
+    assert verdict(cert(D.rsa_spki(n=b"\x00\x00\x00\x01"))) == (True, NF_SPKI) # positive, not minimal (lax re-parse)
+    assert verdict(cert(D.rsa_spki(n=b"\x00" * 300 + b"\x01"))) == (True, NF_SPKI)
+    assert verdict(cert(D.rsa_spki(n=b"")))[0] is False                        # empty INTEGER
+    assert verdict(cert(D.rsa_spki(n=b"\x01"))) == (True, 0)
+    # exponent: an `int` — at most 8 octets, positive
+    for e, want in ((b"\x03", (True, 0)), (b"\x01\x00\x01", (True, 0)), (b"\x7f" + b"\xff" * 7, (True, 0)),
+                    (b"\x00", (False, None)), (b"\xff", (False, None)), (b"\x80\x00\x01", (False, None)), (b"", (False, None)),
+                    (b"\x00\x01", (True, NF_SPKI)), (b"\x00" * 7 + b"\x01", (True, NF_SPKI)), (b"\x00" * 8, (False, None)),
+                    (b"\x00" * 8 + b"\x01", (False, None)), (b"\x01" * 9, (False, None)), (b"\xff\xff", (False, None))):
+        assert verdict(cert(D.rsa_spki(e=e))) == want, e.hex()
+    # wrong shapes
+    key = lambda body: cert(D.spki(D.OID_RSA, D.NULL, body))
+    for body in (b"", b"\x30", D.tlv(0x31, D.tlv(0x02, b"\x01") + D.tlv(0x02, b"\x03")), D.seq(D.tlv(0x02, b"\x05")),
+                 D.seq(), D.seq(D.tlv(0x04, b"\x05"), D.tlv(0x02, b"\x03")), D.seq(D.tlv(0x02, b"\x05"), D.tlv(0x03, b"\x03")),
+                 D.seq(D.tlv(0x02, b"\x05"), D.tlv(0x02, b"\x03"))[:-1], b"\x30\x81\x06" + D.tlv(0x02, b"\x05") + D.tlv(0x02, b"\x03")):
+        assert verdict(key(body))[0] is False, body.hex()
+    assert verdict(key(D.seq(D.tlv(0x02, b"\x05"), D.tlv(0x02, b"\x03")))) == (True, 0)
+    # RSAES-OAEP: the key part is parsed the same way, the NULL-parameters finding does not apply
+    assert verdict(cert(D.rsa_spki(alg=bytes.fromhex("2a864886f70d010107"), params=D.seq()))) == (True, 0)
+    assert verdict(cert(D.rsa_spki(alg=bytes.fromhex("2a864886f70d010107"), e=b"\x00")))[0] is False
+    # an algorithm parsePublicKey does not know: the key is not looked at
+    assert verdict(cert(D.spki(bytes.fromhex("2a864886f70d010102"), D.NULL, b"garbage"))) == (True, 0)
+    assert verdict(cert(D.spki(bytes.fromhex("2b6570"), b"", b"\x01" * 31))) == (True, 0)      # Ed25519, short
+
+
+def test_rsa_key_far_from_the_window():
+    """A subject long enough to push the key out of the first 256 bytes, and a 4096-bit modulus that puts the exponent
+    ~0.5 KB behind it: the product reads both through ldk (no window), the verdicts do not move."""
+    long_subject = D.name(*[D.rdn(10, b"organisation %02d of a very long subject" % i) for i in range(8)])
+    for e, want in ((b"\x01\x00\x01", (True, 0)), (b"\x00", (False, None)), (b"\x00\x03", (True, NF_SPKI))):
+        c = D.cert(spki=D.rsa_spki(n=b"\x00" + b"\xa7" * 512, e=e), subject=long_subject, exts=[D.BC_NOT_CA])
+        assert verdict(c) == want
+
+
+def test_pad_bits_shift_the_key():
+    """asn1Data = PublicKey.RightAlign(): a BIT STRING with n pad bits is shifted right by n before it is parsed."""
+    good = D.seq(D.tlv(0x02, b"\x00\xc1\x23\x45\x67"), D.tlv(0x02, b"\x01\x00\x01"))
+    for pad in range(1, 8):
+        # the octets whose right-aligned form is `good`: shift left by pad (the last pad bits are zero)
+        v = int.from_bytes(good, "big") << pad
+        shifted = v.to_bytes(len(good) + 1, "big")
+        body = shifted[1:] if shifted[0] == 0 else None
+        if body is None:
+            continue                                      # the first octet would need more than 8 bits
+        assert verdict(cert(D.spki(D.OID_RSA, D.NULL, body, pad=pad))) == (True, 0), pad
+        assert verdict(cert(D.spki(D.OID_RSA, D.NULL, good[:-1] + bytes([good[-1] & (0xff << pad) & 0xff]), pad=pad)))[0] is False
+    # EC: the shifted string has the right length, its first octet is not 04 any more unless the octets were made for it
+    pt = point("P256")
+    v = int.from_bytes(b"\x04" + pt, "big") << 1
+    body = v.to_bytes(66, "big")
+    assert body[0] == 0
+    assert verdict(cert(D.spki(D.OID_EC, D.tlv(0x06, bytes.fromhex(CURVES["P256"][0])), body[1:], pad=1))) == (True, 0)
+    assert verdict(cert(ec_spki(pad=1, pt=pt[:-1] + bytes([pt[-1] & 0xfe]))))[0] is False
+
+
+def test_ec_keys_on_every_curve():
+    for curve in CURVES:
+        for k in (1, 2, 3, 0xdeadbeef, 2**100 + 7):
+            c = cert(ec_spki(curve, point(curve, k)))
+            assert verdict(c) == (True, NF_SPKI if curve == "P192" else 0), (curve, k)
+            assert harness.ossl_pubkey_ok(c) == 1
+        pt = bytearray(point(curve, 5))
+        bl = CURVES[curve][1]
+        for pos in (0, bl - 1, bl, 2 * bl - 1):           # one bit of x or y: off the curve
+            bad = bytearray(pt)
+            bad[pos] ^= 0x01
+            c = cert(ec_spki(curve, bytes(bad)))
+            assert verdict(c)[0] is False, (curve, pos)
+            assert harness.ossl_pubkey_ok(c) == 0
+        # x >= p, y >= p (x + p satisfies the equation mod p; Unmarshal rejects it before it gets there)
+        prime = PRIMES[curve]
+        x, y = int.from_bytes(pt[:bl], "big"), int.from_bytes(pt[bl:], "big")
+        for xx, yy in ((x + prime, y), (x, y + prime)):
+            if xx < 1 << (8 * bl) and yy < 1 << (8 * bl):
+                assert verdict(cert(ec_spki(curve, xx.to_bytes(bl, "big") + yy.to_bytes(bl, "big"))))[0] is False, curve
+        # length and form
+        assert verdict(cert(ec_spki(curve, bytes(pt)[:-1])))[0] is False
+        assert verdict(cert(ec_spki(curve, bytes(pt) + b"\x00")))[0] is False
+        assert verdict(cert(ec_spki(curve, bytes(pt), prefix=b"\x02")))[0] is False
+        assert verdict(cert(ec_spki(curve, bytes(pt[:bl]), prefix=b"\x02")))[0] is False     # compressed: not before Go 1.15
+        assert verdict(cert(ec_spki(curve, bytes(pt), prefix=b"")))[0] is False
+    # the point of one curve under the name of another
+    assert verdict(cert(ec_spki("P256", point("P256"), params=D.tlv(0x06, bytes.fromhex(CURVES["P384"][0])))))[0] is False
+    # (0, 0), (0, sqrt(b)) …: the all-zero point is on none of the curves
+    assert verdict(cert(ec_spki("P256", bytes(64))))[0] is False
+
+
+def test_ec_parameters():
+    good = bytes.fromhex(CURVES["P256"][0])
+    for params, ok in ((D.tlv(0x06, good), True), (b"", False), (D.NULL, False), (D.tlv(0x06, good[:-1]), False),
+                       (D.tlv(0x06, good + b"\x00"), False), (D.tlv(0x06, good[:-1] + b"\x08"), False),
+                       (D.tlv(0x06, bytes.fromhex("2b8104000a")), False),                    # secp256k1: unsupported curve
+                       (D.tlv(0x0c, good), False), (D.seq(D.tlv(0x06, good)), False),          # explicit parameters
+                       (D.tlv(0x06, good) + D.NULL, True)):                                     # behind the parameters: ignored
+        assert verdict(cert(ec_spki(params=params)))[0] is ok, params.hex()
+
+
+def test_dsa_keys():
+    P, Q, G, Y = b"\x00\xe3" + b"\x11" * 126, b"\x00\xc9" + b"\x22" * 19, b"\x5a" * 128, b"\x3c" * 128
+    par = lambda p=P, q=Q, g=G, extra=b"": D.seq(D.tlv(0x02, p), D.tlv(0x02, q), D.tlv(0x02, g), extra)
+    dsa = lambda params, key: cert(D.spki(D.OID_DSA, params, key))
+    assert verdict(dsa(par(), D.tlv(0x02, Y))) == (True, 0)
+    assert verdict(dsa(par(extra=D.NULL), D.tlv(0x02, Y))) == (True, 0)
+    assert verdict(dsa(par(), D.tlv(0x02, b"\x00" + Y))) == (True, NF_SPKI)                   # y by the lax re-parse
+    for params, key in ((b"", D.tlv(0x02, Y)), (D.NULL, D.tlv(0x02, Y)), (par(), D.tlv(0x02, Y) + b"\x00"),
+                        (par(), D.tlv(0x02, b"\x00")), (par(), D.tlv(0x02, b"\x80" + Y)), (par(), D.tlv(0x04, Y)),
+                        (par(p=b"\x00"), D.tlv(0x02, Y)), (par(q=b"\xff"), D.tlv(0x02, Y)), (par(g=b""), D.tlv(0x02, Y)),
+                        (par(p=b"\x00\x00\x01"), D.tlv(0x02, Y)),                               # parameters: strict parse only
+                        (D.seq(D.tlv(0x02, P), D.tlv(0x02, Q)), D.tlv(0x02, Y)), (D.tlv(0x31, par()[2:]), D.tlv(0x02, Y))):
+        assert verdict(dsa(params, key))[0] is False, (params.hex()[:40], key.hex()[:20])
+
+
+def test_the_three_roles():
+    """A fatal key error drops the entry in every role; a finding only the precertificate and the Chain[0] issuer
+    (cmd/ct-fetch/ct-fetch.go:452-459 vs :202-209 vs :221-225)."""
+    issuer = D.cert(exts=[D.BC_CA])
+    fatal = cert(ec_spki(pt=bytes(range(64))))
+    finding = cert(D.rsa_spki(params=b""))
+    fine = cert(D.rsa_spki())
+    e = orc.Engine(b"", True, 0)
+    assert e.entry(fatal, issuer, 0)[0] == e.entry(fatal, issuer, 1)[0] == orc.ST_PARSE_ERROR
+    assert e.entry(finding, issuer, 0)[0] == orc.ST_PASS and e.entry(finding, issuer, 1)[0] == orc.ST_PARSE_ERROR
+    assert e.entry(fine, D.cert(spki=ec_spki(pt=bytes(range(64))), exts=[D.BC_CA]), 0)[0] == orc.ST_ISSUER_PARSE_ERROR
+    assert e.entry(fine, D.cert(spki=D.rsa_spki(params=b""), exts=[D.BC_CA]), 0)[0] == orc.ST_ISSUER_PARSE_ERROR
+    assert e.entry(fine, issuer, 1)[0] == orc.ST_PASS
+    off = orc.Engine(b"", True, 0)
+    off.set_strict_spki(False)
+    assert off.entry(fatal, issuer, 1)[0] == orc.ST_PASS and off.entry(finding, issuer, 1)[0] == orc.ST_PASS
+
+
+def spki_mutate(rng, der, lo, hi):
+    """One mutation aimed at the SubjectPublicKeyInfo [lo, hi) of a certificate (lengths are NOT fixed up: most mutants
+    that change a length die in the structural walk, as they should)."""
+    b = bytearray(der)
+    k = rng.randrange(6)
+    p = rng.randrange(lo, hi)
+    if k == 0:
+        b[p] ^= 1 << rng.randrange(8)
+    elif k == 1:
+        b[p] = rng.choice((0, 1, 2, 3, 4, 5, 6, 0x30, 0x7f, 0x80, 0x81, 0xff))
+    elif k == 2:                                          # the pad octet / first key octets
+        q = der.find(b"\x03", lo, hi)
+        if q >= 0:
+            b[min(q + rng.randrange(2, 6), hi - 1)] = rng.randrange(256)
+    elif k == 3:                                          # the tail of the key: exponent, last point octets
+        b[hi - 1 - rng.randrange(min(8, hi - lo))] = rng.choice((0, 1, 0x80, 0xff, rng.randrange(256)))
+    elif k == 4:                                          # algorithm / curve OID octets
+        b[lo + rng.randrange(min(24, hi - lo))] ^= 1 << rng.randrange(8)
+    else:
+        b[p] = (b[p] + rng.choice((1, 255))) & 0xff
+    return bytes(b)
+
+
+def key_seeds():
+    seeds = [cert(D.rsa_spki()), cert(D.rsa_spki(params=b"")), cert(D.rsa_spki(n=b"\x00\x00\x00\x01", e=b"\x00\x03")),
+             cert(D.rsa_spki(n=b"\x7f", e=b"\x03")), cert(D.spki(D.OID_RSA, D.NULL, D.seq(D.tlv(0x02, b"\x05"), D.tlv(0x02, b"\x03"))))]
+    seeds += [cert(ec_spki(c, point(c, 7))) for c in CURVES]
+    P, Q, G, Y = b"\x00\xe3" + b"\x11" * 30, b"\x00\xc9" + b"\x22" * 19, b"\x5a" * 31, b"\x3c" * 31
+    seeds.append(cert(D.spki(D.OID_DSA, D.seq(D.tlv(0x02, P), D.tlv(0x02, Q), D.tlv(0x02, G)), D.tlv(0x02, Y))))
+    return seeds
+
+
+def test_product_equals_oracle_on_key_mutations():
+    rng = random.Random(20261001)
+    cfg = synth.config(seed=77, n_issuers=4, profile=1)
+    seeds = key_seeds() + [synth.leaf(cfg, i)[0] for i in range(12)]
+    spans = []
+    for s in seeds:
+        c = orc.parse_cert(s)
+        assert c.ok, s.hex()
+        spans.append((c.spki_off, c.spki_off + c.spki_len))
+    accepted = rejected_by_key = 0
+    for r in range(30000):
+        i = r % len(seeds)
+        der = spki_mutate(rng, seeds[i], *spans[i])
+        if rng.randrange(4) == 0:
+            der = spki_mutate(rng, der, *spans[i])
+        ok, _ = verdict(der)
+        accepted += ok
+        rejected_by_key += (not ok) and bool(orc.parse_cert(der, strict_spki=False).ok)
+    assert accepted > 3000 and rejected_by_key > 3000, (accepted, rejected_by_key)
+
+
+def test_every_synthetic_key_decodes_in_openssl():
+    """The generator's corpora must lie inside what the reference accepts: every leaf of BOTH profiles and every issuer
+    goes through OpenSSL's X509_get_pubkey (the round-3 mixed corpus carried 64 random octets as P-256 points: about
+    half of it was certificates Go and OpenSSL reject)."""
+    n_ec = 0
+    for profile in (0, 1):
+        cfg = synth.config(seed=20260921 + profile, n_issuers=64, profile=profile, dup_permille=100, ca_permille=20,
+                           expired_permille=20)
+        for i in range(10000):
+            der = synth.leaf(cfg, i)[0]
+            assert harness.ossl_pubkey_ok(der) == 1, (profile, i)
+            n_ec += der.find(bytes.fromhex("2a8648ce3d0201")) >= 0
+            if i % 10 == 0:
+                c = orc.parse_cert(der)
+                assert c.ok and c.nonfatal == 0 and harness.product_walk(der).ok
+        for k in range(64):
+            der = synth.issuer(cfg, k)
+            assert harness.ossl_pubkey_ok(der) == 1
+            c = orc.parse_cert(der)
+            assert c.ok and c.nonfatal == 0 and harness.product_walk(der).ok
+    assert 4000 < n_ec < 6000

@@ -204,7 +204,9 @@ def edge_seeds():
     high tag numbers, odd basicConstraints, explicit wrappers that lie about their length): mutations of these land on
     headers far more often than mutations of a 1.5 KB certificate do."""
     from tests import der as D
-    ec = D.seq(D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 2, 1), D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 3, 1, 7))
+    # (an algorithm parsePublicKey does not know: this seed is about the STRUCTURE around the key; tests/test_spki_cpu.py
+    #  holds the seeds whose keys are parsed)
+    ec = D.seq(D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 2, 2), D.oid(0x2a, 0x86, 0x48, 0xce, 0x3d, 3, 1, 7))
     hi = D.seq(D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), b"\x5f\x28\x01x")), D.rdn(3, b"cn"), D.rdn(10, b"o", tag=0x13))
     return [
         D.cert(exts=[D.BC_NOT_CA]),
