@@ -539,6 +539,9 @@ def main():
     ap.add_argument("--strict-strings", action="store_true",
                     help="ctmr_set_strict_strings(1): the opt-in pre-pass over the Names' string values (what it costs: ms_per_step "
                          "and kernel_ms.map of this line against the default line)")
+    ap.add_argument("--no-strict-spki", action="store_true",
+                    help="ctmr_set_strict_spki(0): skip the public key by length as rounds 1-3 did (the A/B of what parsing the "
+                         "key — parsePublicKey, on by default like in the reference — costs the map kernel)")
     ap.add_argument("--aligned", type=int, default=0, metavar="BYTES",
                     help="lay every certificate at a multiple of BYTES (an entry view instead of the packed layout; payload grows "
                          "by the padding): what the map moves per certificate depends on where certificates start inside "
@@ -643,6 +646,8 @@ def main():
         eng.set_filter(filt, False, now)
         if args.strict_strings:
             eng.set_strict_strings(True)
+        if args.no_strict_spki:
+            eng.set_strict_spki(False)
         if not args.raw or world > 1:
             # raw entries register their Chain[0] certificates themselves — in shard order, so issuer index k would name
             # different issuers on different ranks and the count all-reduce would add apples to oranges: with several
@@ -923,6 +928,7 @@ def main():
                    "dedup": mode, "parallelism": parallelism,
                    "map_variant": args.variant or DEFAULT_VARIANT,
                    **({"strict_strings": True} if args.strict_strings else {}),
+                   **({"strict_spki": False} if args.no_strict_spki else {}),
                    "gen_seconds": round(t_gen, 2)},
         # roofline of the dominant kernel.  `frac` is PHYSICAL when the traffic was measured: HBM bytes the kernel moved
         # (PMC counters) ÷ its average launch time ÷ peak.  The walk skips key, SAN body and signature by length, so the

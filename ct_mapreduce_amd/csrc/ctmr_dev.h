@@ -6,9 +6,9 @@
 #include "../../include/ctmr.h"
 #include "der_walk.h"
 
-// Launch bounds of every kernel that runs the certificate walk: one wave per workgroup, and a register file of at most
-// 168 VGPRs (three waves per SIMD) — LDS lets 9 such waves onto a CU.  The bound is also what the compiler gives the
-// walk's out-of-line helpers (spki_key.h: the curve checks), whose attributes it derives from their callers.
+// Launch bounds of the kernels whose walk evaluates the curve equation on the spot (issuer registration, the strict_leaf
+// TBS check — not the map kernels, which defer it: spki_key.h): one wave per workgroup, at most 168 VGPRs.  The bound is
+// also what the compiler gives the out-of-line curve checks, whose attributes it derives from their callers.
 #define CTMR_WALK_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 
 namespace ctmr {
@@ -86,6 +86,7 @@ struct DevStats {
   unsigned long long n_new, n_dup, n_host, n_full, pair_full;
   unsigned long long n_remote;  // owner-computes rounds: PASS entries whose key left for its owner (counted in n_new, optimistically)
   unsigned long long n_xl;      // … of them with a 21..40-octet serial (they travel as 64-byte records)
+  unsigned long long n_pending; // strict_spki: entries whose EC key owes the curve equation (k_ec_resolve exits at once on 0)
 };
 
 // map-kernel filter constants (device memory; uniform reads)

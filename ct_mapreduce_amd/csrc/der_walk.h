@@ -44,6 +44,9 @@ struct Walk {
   // (meta_pack): the issuer Name TLV, and the OCTET STRING content of extension 2.5.29.31
   uint32_t meta_issuer, meta_crl;
   uint32_t issuer_name, subject_name;  // where the two Name TLVs start (name_strings_ok)
+  // walk_cert<…, EC_DEFER>: an EC key accepted except for the curve equation (spki_key.h) — ec_curve 1..5 (0: nothing
+  // pending), the certificate offset of the point's X coordinate, the BIT STRING's pad count.  The caller owes the check.
+  uint32_t ec_curve, ec_pos, ec_shift;
 };
 
 constexpr uint32_t WALK_NF_NEGATIVE_SERIAL = 1u;  // "x509: negative serial number"
@@ -292,7 +295,7 @@ struct AlgView {
 };
 
 template <class R>
-CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& after, AlgView* av = nullptr) {
+CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& after, AlgView& av) {
   uint32_t tag, cs, ce, to, co, eo;
   rd_hdr(r, L, p, end, ok, tag, cs, ce);
   rd_hdr(r, L, cs, ce, ok, to, co, eo);
@@ -301,8 +304,13 @@ CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, 
   ok = ok & (tag == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
   uint32_t tp = 0u, cp = eo, ep = eo;
   if (ok & (eo < ce)) rd_hdr(r, L, eo, ce, ok, tp, cp, ep);
-  if (av) *av = AlgView{co, eo, eo, tp, cp, ok ? ep : eo};
+  av = AlgView{co, eo, eo, tp, cp, ok ? ep : eo};  // (by reference: a pointer that may be null puts the view in scratch memory)
   after = ce;
+}
+template <class R>
+CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, uint32_t& after) {
+  AlgView unused;
+  alg_id(r, L, p, end, ok, after, unused);
 }
 
 CTMR_HD bool string_tag(uint32_t t) {
@@ -497,7 +505,8 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // NAMES_ONLY: stop behind the subject Name (k_name_strings: only where the two Names lie is wanted; whether the rest of
 // the certificate parses is the map's business).
 // spki: also parse the public key as CT-go's parsePublicKey does (spki_key.h; ctmr_set_strict_spki, on by default).
-template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false>
+// EC_DEFER (the map kernels): an EC key's curve equation is not evaluated here — Walk.ec_* says what is owed (spki_key.h).
+template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false, bool EC_DEFER = false>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv, bool spki = true) {
   o.serial_off = o.serial_len = 0;
 #pragma unroll
@@ -510,6 +519,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   o.nonfatal = 0u;
   o.meta_issuer = o.meta_crl = META_NONE;
   o.issuer_name = o.subject_name = 0u;
+  o.ec_curve = o.ec_pos = o.ec_shift = 0u;
   bool ok = L <= 0x7fffffffu;
   L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
   uint32_t tag, cs, ce;
@@ -612,7 +622,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   key_pending.alg = PK_OTHER;
   {
     uint32_t k, tk, ck, ek;
-    alg_id(r, L, cs, ce, ok, k, &key_alg);
+    alg_id(r, L, cs, ce, ok, k, key_alg);
     rd_hdr(r, L, k, ce, ok, tk, ck, ek);
     ok = ok & (tk == 0x03u);
     bit_string_check(r, L, ck, ek - ck, ok);
@@ -623,7 +633,11 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // what follows the key (unique ids, extensions) and the tail behind the TBS are both known now:
   // a two-region reader fetches them in one burst
   r.touch_tail(q, tbs_end);
-  if (spki) spki_key_finish(r, L, key_alg, key_pending, ok, o.nonfatal);
+  if (spki) {
+    EcPending ecp;
+    spki_key_finish<EC_DEFER>(r, L, key_alg, key_pending, ok, o.nonfatal, ecp);
+    o.ec_curve = ecp.curve; o.ec_pos = ecp.pos; o.ec_shift = ecp.shift;
+  }
   // UniqueId, SubjectUniqueId asn1.BitString `optional,tag:1|2`, Extensions `optional,explicit,tag:3`: each parses the
   // header at the current position (which must be a valid header) and skips itself when the tag is not its own;
   // whatever is left in the TBSCertificate after the three is ignored.
@@ -737,13 +751,14 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     ok = ok & (tag == 0x03u);
     bit_string_check(tv, L, cs, ce - cs, ok);
   }
+  o.ec_curve = ok ? o.ec_curve : 0u;
   return ok;
 }
 
 template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr, bool spki = true) {
-  return filter ? walk_cert(r, L, o, true, *filter, spki)
-                : walk_cert(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki);
+  return filter ? walk_cert<R>(r, L, o, true, *filter, spki)
+                : walk_cert<R>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki);
 }
 template <class R>
 CTMR_HD bool walk_names(R& r, uint32_t L, Walk& o) {

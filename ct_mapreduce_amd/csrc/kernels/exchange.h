@@ -145,7 +145,12 @@ __global__ void __launch_bounds__(256) k_keys_insert(const Rec* keys, uint64_t n
     const unsigned long long w0 = tagw | k.ord;
     uint64_t j = h & mask;
     uint32_t sid = SID_FULL;
-    for (uint64_t probes = 0; probes <= mask; probes++) {
+    // meta == 0 (no VALID bit): a record its sender withdrew — the EC point of the certificate turned out to be off its
+    // curve after the key had been staged (k_ec_resolve).  Never inserted, answered "not new"; the sender's entry is a
+    // parse error by then and ignores the answer.
+    const uint64_t limit = k.meta == 0ull ? 0ull : mask + 1ull;
+    if (k.meta == 0ull) sid = SID_NONE;
+    for (uint64_t probes = 0; probes < limit; probes++) {
       Slot* sl = table + j;
       const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
       if (old == 0ull) {  // claimed: the 64-byte image leaves four lanes per slot, whole slots per store instruction

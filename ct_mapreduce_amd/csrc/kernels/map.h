@@ -23,6 +23,8 @@ struct MapArgs {
   uint2* meta_loc;          // null, or per entry (Walk.meta_issuer, Walk.meta_crl) for k_meta_new (config.collect_meta)
   const uint8_t* nf_extra;  // null, or per entry: further non-fatal findings (WALK_NF_*) of a pre-pass — k_name_strings
                             // (ctmr_set_strict_strings)
+  unsigned long long* keypos;  // strict_spki: per entry, written ONLY for an entry whose EC key still owes the curve equation
+                               // (keypos_pack; spki_key.h "where the curve equation runs") — k_ec_resolve reads it
   uint32_t optimistic_new;  // 1: PASS records leave the map with CTMR_FL_WAS_UNKNOWN already set — the
                             // reduce only CLEARS it for the (rare) duplicates, so the common case costs
                             // no second scattered write into the record array
@@ -37,6 +39,15 @@ __device__ __forceinline__ void cert_range(const uint64_t* offsets, const uint64
 }
 __device__ __forceinline__ uint64_t map_limit(const MapArgs& a) {
   return a.ends ? a.limit : a.offsets[a.n] + CTMR_PAYLOAD_PAD;
+}
+
+// An entry whose EC key owes the curve equation ("key pending"): where the point lies, for k_ec_resolve.
+//   bits 0..31 certificate offset of X, 32..34 curve (1..5), 35..37 the BIT STRING's pad count,
+//   38 the entry's key left for its owner (XM_OWNER) as record 39..44 of its wave's staging group
+// Inside a kernel the record's flag byte carries bit 7 for such an entry; it never leaves the library.
+constexpr uint32_t FL_KEY_PENDING = 0x80u;
+__device__ __forceinline__ unsigned long long keypos_pack(uint32_t pos, uint32_t curve, uint32_t shift) {
+  return (unsigned long long)pos | ((unsigned long long)(curve & 7u) << 32) | ((unsigned long long)(shift & 7u) << 35);
 }
 
 // Everything after the bytes are addressable: walk, filters, record.
@@ -63,12 +74,13 @@ __device__ __forceinline__ EntryIn load_entry_in(const MapArgs& a, uint64_t idx)
 
 template <class R>
 __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, const EntryIn& in, uint4& o0,
-                                        uint4& o1, uint2* meta_words = nullptr) {
+                                        uint4& o1, uint2* meta_words = nullptr, unsigned long long* keypos_out = nullptr) {
   Walk w;
   const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
   const FilterDev* f = a.filt;
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
-  bool ok = walk_cert(r, L, w, f->active != 0u, fv, f->strict_spki != 0u);  // L > 2^31-1 is rejected inside, without divergence
+  // L > 2^31-1 is rejected inside, without divergence.  EC_DEFER: an EC key's curve equation is k_ec_resolve's business
+  bool ok = walk_cert<R, false, false, true>(r, L, w, f->active != 0u, fv, (f->strict_spki != 0u) & (a.keypos != nullptr));
   const uint32_t iss = in.iss, et = in.et;
   // An X509 entry's certificate was parsed by ct.LogEntryFromLeaf, which keeps it unless the error is fatal
   // (ct-fetch.go:452-459); a precertificate is parsed in insertCTWorker and dropped on ANY error, CT-go's
@@ -94,6 +106,13 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   }
   uint32_t flags = et == 1u ? CTMR_FL_PRECERT : 0u;
   if (a.optimistic_new && status == CTMR_ST_PASS) flags |= CTMR_FL_WAS_UNKNOWN;
+  // key pending — whatever the status: a certificate whose point is off its curve is a PARSE error in the reference,
+  // before any filter looks at it; k_ec_resolve rewrites the record when the equation fails
+  const bool pending = ok & (w.ec_curve != 0u);
+  const unsigned long long kp = pending ? keypos_pack(w.ec_pos, w.ec_curve, w.ec_shift) : 0ull;
+  if (pending) flags |= FL_KEY_PENDING;
+  if (keypos_out) *keypos_out = kp;
+  else if (pending) a.keypos[idx] = kp;
   uint32_t slen = 0, s[5] = {0, 0, 0, 0, 0};
   int32_t exp_hour = 0;
   if (ok) {
@@ -179,7 +198,7 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
 // window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: WIN_LDS_BYTES per wave.
 // The first fill is wave-cooperative (coop_fill, readers.h).
 template <int WCH>
-__global__ void CTMR_WALK_BOUNDS k_map_winc(MapArgs a) {
+__global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;

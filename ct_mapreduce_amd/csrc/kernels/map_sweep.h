@@ -26,7 +26,7 @@ struct LdsReader {
 // contiguous in the packed payload, so it is copied with perfectly coalesced 16-B/lane loads
 // (1 KiB per wave instruction) into LDS; then lane l walks certificate first+l out of LDS.
 
-__global__ void CTMR_WALK_BOUNDS k_map_tile(MapArgs a) {
+__global__ void __launch_bounds__(64) k_map_tile(MapArgs a) {
   const uint32_t lane = threadIdx.x;
   const uint32_t C = a.certs_per_tile;
   const uint64_t first = (uint64_t)blockIdx.x * C;

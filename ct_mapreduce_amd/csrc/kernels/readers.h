@@ -126,6 +126,9 @@ struct WinReader {
     return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
   }
   __device__ __forceinline__ RawCert raw() const { return RawCert{g32, base}; }  // spki_key.h: the out-of-line key checks
+  // spki_key.h key_reader_of: a snapshot of this base reader, by value (window hit, else a plain global load; none of the
+  // derived readers' miss bookkeeping)
+  __device__ __forceinline__ WinReader<WCH> key_bytes() const { return WinReader<WCH>{g32, base, limit, win, grel}; }
   __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {  // straight from global memory
     const uint64_t a = base + pos;
     const uint64_t i = a >> 2;
@@ -216,9 +219,6 @@ struct WinReaderS : WinReaderC<WCH> {
   __device__ __forceinline__ void note_issuer(uint32_t pos, uint32_t len) {
     hook.note_issuer(this->win, pos - (uint32_t)this->grel, len, WinReader<WCH>::WBYTES - 8u);
   }
-  // anywhere in the certificate, no miss bookkeeping: the window when it holds the bytes, else a plain global load
-  // (spki_key.h: an RSA exponent, a curve point — bytes the walk's windows are not placed for)
-  __device__ __forceinline__ uint32_t ldk(uint32_t pos) const { return WinReader<WCH>::ld4(pos); }
   __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {
     const uint32_t off = pos - tl_pos;
     const uint32_t wi = off >> 2;

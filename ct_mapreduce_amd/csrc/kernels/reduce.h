@@ -78,8 +78,14 @@ struct InsertArgs {
   uint32_t* ent;           // per entry: status(0..2) | state(3..5) | canonical issuer << 8
   uint64_t n;
   uint32_t epoch;
-  DevStats* stats;         // n_xl (owner-computes rounds)
+  DevStats* stats;         // n_xl (owner-computes rounds), n_pending
   uint32_t ord_base;       // order of entry 0 in the round (keyrec.h; 0 outside a group round): w[0] carries ord_base + i
+  // k_ec_resolve (strict_spki): where the pending EC points lie, the owner-computes staging array (a key that left for its
+  // owner before its point was checked is withdrawn there) and the rank's Bloom filter (null: none)
+  const unsigned long long* keypos;
+  KeyRec32* stage;
+  unsigned long long* bloom;
+  uint64_t bloom_wmask;
 };
 
 // Per-entry state of the reduce (bits 3..5 of ent[i]); the low 3 bits carry record.status.
@@ -90,9 +96,13 @@ enum : uint32_t {
   ES_DUP = 3,      // known: since an earlier batch, or a lower log index of this batch holds the key
   ES_HOST = 4,     // serial longer than CTMR_MAX_SERIAL: exact host-side set
   ES_FULL = 5,     // table full
-  ES_REMOTE = 6    // owner-computes round: the key belongs to another rank and left as a key record; WasUnknown unless
+  ES_REMOTE = 6,   // owner-computes round: the key belongs to another rank and left as a key record; WasUnknown unless
                    // the owner says otherwise (apply clears it) — in the NEW list, NOT in this rank's per-issuer counts
+  ES_PENDING = 7   // strict_spki: reached the set, the key is this rank's, but its EC point owes the curve equation: NOT
+                   // inserted yet — k_ec_resolve checks the point and inserts (no entry leaves round_begin in this state)
 };
+// ent[] bit 7: the entry's EC key owes the curve equation (any status, any state); k_ec_resolve clears it
+constexpr uint32_t ENT_KEY_PENDING = 0x80u;
 __device__ __forceinline__ uint32_t ent_pack(uint32_t status, uint32_t state, uint32_t canon) {
   return (status & 7u) | (state << 3) | (canon << 8);
 }
@@ -245,16 +255,21 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
     const uint4* rp = (const uint4*)(a.records + i);
     const uint4 r0 = rp[0];
     status = r0.x & 0xffu;
+    // key pending (the map's internal record flag): the flag moves into ent[], and an entry that would be inserted waits
+    const bool pending = ((r0.x >> 8) & FL_KEY_PENDING) != 0u;
+    uint32_t fl_out = (r0.x >> 8) & 0xffu & ~FL_KEY_PENDING;
     if (status == CTMR_ST_PASS) {
       canon = a.canon[r0.z];
       const uint4 r1 = rp[1];
-      state = insert_probe(a, i, r0, r1, canon, claimed, q0, q1, q2, q3);
-      if (state != ES_CLAIMED && state != ES_DEFER) {  // not (yet) unknown: drop the optimistic flag
-        uint8_t* fl = (uint8_t*)(a.records + i) + 1;
-        *fl = (uint8_t)((r0.x >> 8) & ~CTMR_FL_WAS_UNKNOWN);
-      }
+      const uint32_t slen = r0.x >> 16;
+      state = (pending && slen <= CTMR_MAX_SERIAL) ? (uint32_t)ES_PENDING
+                                                   : insert_probe(a, i, r0, r1, canon, claimed, q0, q1, q2, q3);
+      if (state != ES_CLAIMED && state != ES_DEFER && state != ES_PENDING) fl_out &= ~(uint32_t)CTMR_FL_WAS_UNKNOWN;  // not (yet) unknown
     }
-    a.ent[i] = ent_pack(status, state, canon);
+    if (fl_out != ((r0.x >> 8) & 0xffu)) ((uint8_t*)(a.records + i))[1] = (uint8_t)fl_out;
+    a.ent[i] = ent_pack(status, state, canon) | (pending ? ENT_KEY_PENDING : 0u);
+    const unsigned long long mp = __ballot(pending);
+    if (mp && lane == (uint32_t)(__ffsll((long long)mp) - 1)) atomicAdd(&a.stats->n_pending, (unsigned long long)__popcll(mp));
   }
   store_slots_wave(a.table, img[wv], lane, claimed, q0, q1, q2, q3);
 }
@@ -346,7 +361,7 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 //   XM_BLOOM  Bloom variant: the key of every entry that claimed or may claim a slot (CLAIMED / DEFER) is added to the
 //             rank's cumulative filter with one fire-and-forget 8-byte atomicOr — no separate pass over the records.
 template <int WCH, bool META, int MODE>
-__global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
+__global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
@@ -385,6 +400,8 @@ __global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck
   uint32_t rem_owner = KEY_NO_OWNER;  // XM_OWNER: the rank this entry's key record goes to
   bool rem_long = false;
   uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+  unsigned long long keypos = 0ull;
+  bool pending = false;
   if (live) {
     using Hook = typename std::conditional<META, MetaHook, NoRefillHook>::type;
     WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
@@ -396,11 +413,13 @@ __global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck
       r.hook.dn_seen = false;
     }
     uint2 ml = make_uint2(META_NONE, META_NONE);
-    map_one(r, hi - lo, i, a, in, o0, o1, &ml);
+    map_one(r, hi - lo, i, a, in, o0, o1, &ml, &keypos);
     if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
       GlobalReader g{(const uint32_t*)a.payload, lo};
-      map_one(g, hi - lo, i, a, in, o0, o1);
+      map_one(g, hi - lo, i, a, in, o0, o1, nullptr, &keypos);
     }
+    pending = keypos != 0ull;  // strict_spki: an EC key that owes the curve equation — ent[] carries that, not the record
+    o0.x &= ~(FL_KEY_PENDING << 8);
     const uint32_t status = o0.x & 0xffu;
     uint32_t state = ES_NONE;
     // META: only a certificate that WAS unknown reaches IssuerMetadata.Accumulate; of those, only one that brings
@@ -431,7 +450,8 @@ __global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck
 #ifdef CTMR_EXP_NO_PROBE  // sweep builds, MEASUREMENT ONLY (wrong results): the kernel without any table access
           state = ES_CLAIMED;
 #else
-          state = insert_probe_h(ia, i, meta, s, h, claimed, q0, q1, q2, q3);
+          // (a key whose EC point is not checked yet is not inserted: k_ec_resolve does both)
+          state = pending ? (uint32_t)ES_PENDING : insert_probe_h(ia, i, meta, s, h, claimed, q0, q1, q2, q3);
 #endif
         } else {  // (XM_OWNER) the record that leaves; serials of 21..40 octets take the 64-byte path (k_xl_export)
           state = ES_REMOTE;
@@ -448,9 +468,10 @@ __global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck
           }
         }
       }
-      if (state != ES_CLAIMED && state != ES_DEFER && state != ES_REMOTE) o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
+      if (state != ES_CLAIMED && state != ES_DEFER && state != ES_REMOTE && state != ES_PENDING)
+        o0.x &= ~((uint32_t)CTMR_FL_WAS_UNKNOWN << 8);
     }
-    uint32_t e = ent_pack(status, state, canon);
+    uint32_t e = ent_pack(status, state, canon) | (pending ? ENT_KEY_PENDING : 0u);
     if constexpr (META) {
       const bool seen = meta_try && meta_tail_finish(mc, canon, mt, (int32_t)o0.y, r.win);
       e |= seen ? 0u : ENT_META_UNSEEN;
@@ -464,6 +485,13 @@ __global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck
 #else
   store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
 #endif
+  {  // strict_spki: how many entries owe k_ec_resolve a curve equation (0 in a batch of RSA keys: it exits at once)
+    const unsigned long long mp = __ballot(pending);
+    if (mp && lane == 0) atomicAdd(&ia.stats->n_pending, (unsigned long long)__popcll(mp));
+    if constexpr (MODE != XM_OWNER) {
+      if (pending) a.keypos[i] = keypos;
+    }
+  }
   if constexpr (MODE == XM_OWNER) {
     // the wave's key records, grouped by owner: one ballot per rank gives every record its place and the per-owner counts
     const bool rem = rem_owner != KEY_NO_OWNER && rem_owner != xa.rank && !rem_long;
@@ -481,6 +509,8 @@ __global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck
       out[0] = k0;
       out[1] = k1;
     }
+    // a pending key that left for its owner: k_ec_resolve withdraws record `pos` of this wave's group when the point is bad
+    if (pending) a.keypos[i] = keypos | (rem ? (1ull << 38) | ((unsigned long long)pos << 39) : 0ull);
     if (lane < MAX_WORLD) xa.wave_cnt[(uint64_t)blockIdx.x * MAX_WORLD + lane] = (uint8_t)mine_cnt;
     const unsigned long long ml = __ballot(rem_owner != KEY_NO_OWNER && rem_owner != xa.rank && rem_long);
     if (ml && lane == 0) atomicAdd(&ia.stats->n_xl, (unsigned long long)__popcll(ml));
@@ -502,6 +532,127 @@ __global__ void CTMR_WALK_BOUNDS k_map_fused(MapArgs a, InsertArgs ia, MetaCheck
 // fetches the next batch's front windows into registers while walking the current one.  256 VGPRs → 8 waves per CU,
 // and the first vector load inside the walk (the issuerCN filter words) waits on vmcnt for the prefetch issued just
 // before it, so the overlap never materialises: 26.0 ms against 23.1 ms, profiles/r01/s4/sweep_pipe.txt.)
+// ------------------------------------------------------------------ strict_spki: the curve equation, then the insert
+// spki_key.h "where the curve equation runs": the map leaves an entry whose EC key passed everything but
+// y² = x³ − 3x + b "key pending" (ent[] bit 7, the point's place in keypos[]); this kernel — its own register file: the
+// four modular products need 84..170 VGPRs — evaluates the equation and
+//   point bad   the entry becomes what the map makes of a certificate that does not parse (status PARSE_ERROR, nothing
+//               else reported); a key record that already left for its owner (XM_OWNER) is withdrawn (meta = 0);
+//   point good  the pending bit goes; an entry in state ES_PENDING (would reach the set, key is this rank's) is inserted
+//               with the fully synchronised protocol of table_upsert — claims of this kernel publish w[1] last, slots of
+//               pass 1 and of earlier batches are complete — and the ORDER rule: whoever of (holder, me) has the higher
+//               order in the round loses.  The entry's ent[] word is written BEFORE its key becomes findable, as
+//               "claimed"; afterwards it is only ever downgraded by byte writes (mine or a winner's mark_dup), so no
+//               update is lost whoever comes last.
+// Runs between the map (+ k_insert) and k_insert2; a batch without pending entries costs one launch of blocks that read
+// one word and leave.
+__device__ __forceinline__ uint32_t upsert_ordered(const InsertArgs& a, ctmr_record* records, unsigned long long meta,
+                                                   const unsigned long long s[5], uint32_t ord, unsigned long long* h_out) {
+  const unsigned long long h = key_hash(meta, s);
+  *h_out = h;
+  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
+  uint64_t j = h & a.mask;
+  for (uint64_t probes = 0; probes <= a.mask;) {
+    Slot* sl = a.table + j;
+    unsigned long long w0 = ld_agent(&sl->w[0]);
+    if (w0 == 0ull) {
+      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | ord);
+      if (old == 0ull) {
+        st_agent(&sl->w[2], (unsigned long long)a.epoch);
+#pragma unroll
+        for (int k = 0; k < 5; k++) st_agent(&sl->w[3 + k], s[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(&sl->w[1], meta);
+        return ES_CLAIMED;
+      }
+      w0 = old;
+    }
+    if ((w0 & 0xffffffff00000000ull) == tagw && w0 != SLOT_TOMB) {
+      const unsigned long long m = ld_agent(&sl->w[1]);
+      if (!(m & SLOT_VALID)) continue;  // claimed by another lane of this kernel, not published yet: poll
+      bool eq = m == meta;
+#pragma unroll
+      for (int k = 0; k < 5; k++) eq = eq && ld_agent(&sl->w[3 + k]) == s[k];
+      if (eq) {
+        if ((uint32_t)ld_agent(&sl->w[2]) != a.epoch) return ES_DUP;  // known since an earlier batch
+        const uint32_t other = (uint32_t)atomicMin(&sl->w[0], tagw | ord);
+        if (other < ord) return ES_DUP;       // a lower order of this round holds the key
+        if (other != ord) mark_dup_ord(a, records, other);
+        return ES_CLAIMED;                    // (unless a still lower order joins and marks it)
+      }
+    }
+    j = probe_next(j, probes, a.mask);
+    probes++;
+  }
+  return ES_FULL;
+}
+
+__device__ __forceinline__ void ec_resolve_one(const InsertArgs& a, ctmr_record* records, uint64_t i, uint32_t e) {
+  const unsigned long long kp = a.keypos[i];
+  uint64_t lo, hi;
+  cert_range(a.offsets, a.ends, i, lo, hi);
+  const RawReader rr{RawCert{(const uint32_t*)a.payload, lo}};
+  const uint32_t L = (uint32_t)(hi - lo), pos = (uint32_t)kp, curve = (uint32_t)(kp >> 32) & 7u, shift = (uint32_t)(kp >> 35) & 7u;
+  const SpkiView<RawReader> v{rr, pos - 1u, shift};
+  bool good;
+  switch (curve) {
+    case 1u: good = ec_on_curve<CurveP256>(v, L, pos); break;
+    case 2u: good = ec_on_curve<CurveP384>(v, L, pos); break;
+    case 3u: good = ec_on_curve<CurveP521>(v, L, pos); break;
+    case 4u: good = ec_on_curve<CurveP224>(v, L, pos); break;
+    default: good = ec_on_curve<CurveP192>(v, L, pos); break;
+  }
+  uint4* rp = (uint4*)(records + i);
+  if (!good) {  // x509.ParseCertificate fails: map_one's record of such a certificate
+    const uint4 r0 = rp[0];
+    rp[0] = make_uint4(CTMR_ST_PARSE_ERROR | (((r0.x >> 8) & CTMR_FL_PRECERT) << 8), 0u, r0.z, 0u);
+    rp[1] = make_uint4(0u, 0u, 0u, 0u);
+    if ((kp >> 38) & 1ull) a.stage[(i & ~63ull) + ((kp >> 39) & 63ull)].meta = 0ull;  // the owner ignores it
+    a.ent[i] = ent_pack(CTMR_ST_PARSE_ERROR, ES_NONE, e >> 8) | (e & 0x40u);
+    return;
+  }
+  uint32_t ne = e & ~ENT_KEY_PENDING;
+  if (ent_state(e) != ES_PENDING) {  // filtered, without issuer, left for its owner, host-side serial: what the map said
+    a.ent[i] = ne;
+    return;
+  }
+  ne = (ne & ~(7u << 3)) | ((uint32_t)ES_CLAIMED << 3);
+  a.ent[i] = ne;
+  __threadfence();  // the word is in place before the key can be found (and the entry marked) by anybody
+  const uint4 r0 = rp[0], r1 = rp[1];
+  unsigned long long s[5], h;
+  record_key(a, i, r0, r1, s);
+  const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
+  const uint32_t state = upsert_ordered(a, records, meta, s, a.ord_base + (uint32_t)i, &h);
+  if (state != ES_CLAIMED) {
+    ((uint8_t*)(a.ent + i))[0] = (uint8_t)((ne & 0xc7u) | (state << 3));
+    uint8_t* fl = (uint8_t*)(records + i) + 1;
+    *fl = (uint8_t)(*fl & ~CTMR_FL_WAS_UNKNOWN);
+  } else if (a.bloom) {
+    uint64_t word;
+    unsigned long long bits;
+    bloom_pos(h, a.bloom_wmask, word, bits);
+    atomicOr(&a.bloom[word], bits);
+  }
+}
+
+constexpr uint32_t EC_PER_BLOCK = 1024;
+__global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* records) {
+  if (a.stats->n_pending == 0ull) return;
+  const uint64_t i0 = (uint64_t)blockIdx.x * EC_PER_BLOCK + threadIdx.x * 4u;
+  if (i0 >= a.n) return;
+  uint32_t e[4] = {0u, 0u, 0u, 0u};
+  if (i0 + 4 <= a.n) {
+    const uint4 v = *(const uint4*)(a.ent + i0);
+    e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+  } else {
+    for (uint32_t k = 0; i0 + k < a.n; k++) e[k] = a.ent[i0 + k];
+  }
+#pragma unroll 1
+  for (uint32_t k = 0; k < 4; k++)
+    if (e[k] & ENT_KEY_PENDING) ec_resolve_one(a, records, i0 + k, e[k]);
+}
+
 // Wave-aggregated add: one atomic per distinct key per wave (the "match-any" loop).
 __device__ __forceinline__ void wave_agg_add(bool active, uint32_t key, unsigned long long* arr) {
   unsigned long long todo = __ballot(active);

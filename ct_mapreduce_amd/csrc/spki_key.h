@@ -26,8 +26,7 @@
 // as a precertificate or a Chain[0] issuer (der_walk.h Walk.nonfatal).
 //
 // Byte access: the algorithm, the BIT STRING header and the first key octets sit in the window the walk holds at that
-// point; the exponent, a curve point, DSA parameters do not — they are read through Reader::ldk(pos) ("anywhere in the
-// certificate": window hit or a plain global load; no miss bookkeeping).  Readers without ldk use ld4.
+// point; the exponent, a curve point, DSA parameters do not — they are read through key_reader_of(reader) (below).
 #pragma once
 #include "ec_curves.h"
 
@@ -35,20 +34,37 @@ namespace ctmr {
 
 constexpr uint32_t WALK_NF_SPKI = 8u;  // parsePublicKey filed a non-fatal finding (see above)
 
+// Byte access for the key: Reader::key_bytes() — a SMALL reader by value ("anywhere in the certificate": the window when it
+// holds the bytes, else a plain global load; no miss bookkeeping) — for readers that have one; the others (global-memory and
+// host readers, whose ld4 works anywhere) are used through a reference.  By value matters on the GPU: a view that held a
+// reference to the map kernel's window reader (which every ld4 updates) kept that reader in scratch memory — 144 bytes of
+// private segment and stores all over the walk (measured, round 4).
+template <class R>
+struct RefReader {
+  const R& r;
+  CTMR_HD uint32_t ld4(uint32_t pos) const { return r.ld4(pos); }
+};
 template <class R, class = void>
-struct has_ldk : std::false_type {};
+struct has_key_bytes : std::false_type {};
 template <class R>
-struct has_ldk<R, std::void_t<decltype(std::declval<const R&>().ldk(0u))>> : std::true_type {};
+struct has_key_bytes<R, std::void_t<decltype(std::declval<const R&>().key_bytes())>> : std::true_type {};
 template <class R>
-CTMR_HD uint32_t ldk_of(const R& r, uint32_t pos) {
-  if constexpr (has_ldk<R>::value) return r.ldk(pos);
-  else return r.ld4(pos);
+CTMR_HD auto key_reader_of(const R& r) {
+  if constexpr (has_key_bytes<R>::value) return r.key_bytes();
+  else return RefReader<R>{r};
 }
+template <class R>
+using KeyReaderOf = decltype(key_reader_of(std::declval<const R&>()));
 
-// The rare, register-hungry checks (a curve point: four modular products over up to 17 limbs; DSA) are NOT inlined into
-// the walk: inlined, the five curves took the map kernel from 121 to 245 VGPRs plus scratch.  They are out-of-line
-// functions over the certificate's bytes in memory (Reader::raw(): the dword view and the certificate's start), so the
-// kernel pays a call on the lanes that have such a key and its register file is sized by the walk, not by P-521.
+// Where the curve equation runs.  Four modular products over 6..17 limbs per lane need 84 (P-256) to 170 VGPRs; inlined
+// into the map kernel they took it from 121 to 245 VGPRs plus scratch, and as out-of-line calls they made it a non-leaf
+// kernel whose hot path spilled (37.7 instead of 22.6 ms per 100 M certificates, measured, round 4).  So the walk of a MAP
+// kernel does everything about an EC key except the equation (algorithm, named curve, length, the 04) and hands the point's
+// place out (walk_cert<…, EC_DEFER = true> → Walk.ec_*): the entry leaves the map "key pending" and k_ec_resolve
+// (kernels/reduce.h) — a kernel of its own, with its own register file, that exits at once when no entry is pending —
+// checks the point before the entry is inserted.  Every other caller of the walk (issuer registration, the strict_leaf
+// TBS check, the host builds) evaluates the equation on the spot through one out-of-line function per curve
+// (Reader::raw(): the bytes in memory), so a kernel's register file is sized by the largest ONE of them.
 // Readers without raw() (the test harness's byte-counting reader) take the same code inline.
 #if defined(__HIPCC__)
 #define CTMR_HD_NOINLINE __host__ __device__ __attribute__((noinline))
@@ -75,13 +91,25 @@ struct has_raw<R, std::void_t<decltype(std::declval<const R&>().raw())>> : std::
 
 // The right-aligned key octets as a reader in CERTIFICATE coordinates: octet at `pos` of the aligned string =
 // B[pos-1] << (8-shift) | B[pos] >> shift with B[c0-1] = 0 (encoding/asn1 BitString.RightAlign; shift = pad count).
-template <class R>
+template <class K>
 struct SpkiView {
-  const R& r;
+  K r;  // key_reader_of(reader): by value
   uint32_t c0, shift;
+  // twelve octets fetched ahead (an RSA key's publicExponent, spki_key_begin): served from registers.  (Part of this
+  // view, not a view over it: a reader reached through two levels of references stays in scratch memory.)
+  uint32_t at = 0u, e0 = 0u, e1 = 0u, e2 = 0u;
+  bool pre = false;
   CTMR_HD uint32_t ld4(uint32_t pos) const {
-    if (shift == 0u) return ldk_of(r, pos);
-    const uint32_t lo = ldk_of(r, pos - 1u), hi = ldk_of(r, pos + 3u);
+    const uint32_t off = pos - at;
+    if (pre & (off <= 8u)) {  // (64-bit shifts, not selects by `off`: the compiler turns those into a table in scratch memory)
+      const unsigned long long a = (unsigned long long)e0 | ((unsigned long long)e1 << 32);
+      const unsigned long long b = (unsigned long long)e1 | ((unsigned long long)e2 << 32);
+      const unsigned long long x = (off & 4u) ? b : a;
+      const uint32_t w = (uint32_t)(x >> (8u * (off & 3u)));
+      return (off & 8u) ? e2 : w;
+    }
+    if (shift == 0u) return r.ld4(pos);
+    const uint32_t lo = r.ld4(pos - 1u), hi = r.ld4(pos + 3u);
     unsigned long long be = ((unsigned long long)__builtin_bswap32(lo) << 8) | (hi & 0xffu);  // B[pos-1] … B[pos+3]
     if (pos == c0) be &= 0xffffffffull;
     return __builtin_bswap32((uint32_t)(be >> shift));
@@ -304,7 +332,7 @@ CTMR_HD void spki_key_begin(const R& r, uint32_t L, const AlgView& a, uint32_t c
       const bool null_par = (a.par_e - a.par_p == 2u) & ((ldc(r, a.par_p, L) & 0xffffu) == 0x0005u);
       nf = null_par ? nf : (nf | WALK_NF_SPKI);
     }
-    const SpkiView<R> v{r, kp.c0, kp.shift};
+    const SpkiView<KeyReaderOf<R>> v{key_reader_of(r), kp.c0, kp.shift};
     uint32_t ts, ss, se, n_end, n_len;
     int n_sign;
     rd_hdr(v, L, kp.c0, ek, ok, ts, ss, se);
@@ -315,32 +343,13 @@ CTMR_HD void spki_key_begin(const R& r, uint32_t L, const AlgView& a, uint32_t c
     kp.e_end = se;
     if (ok & (kp.shift == 0u)) {
       const uint32_t p = n_end < L ? n_end : L;
-      kp.e0 = ldk_of(r, p);
-      kp.e1 = ldk_of(r, p + 4u);
-      kp.e2 = ldk_of(r, p + 8u);
+      kp.e0 = v.r.ld4(p);
+      kp.e1 = v.r.ld4(p + 4u);
+      kp.e2 = v.r.ld4(p + 8u);
       kp.pre = true;
     }
   }
 }
-
-// a reader over the twelve prefetched octets (positions outside them fall through to the certificate)
-template <class R>
-struct ExpView {
-  const SpkiView<R>& v;
-  uint32_t at, e0, e1, e2;
-  bool pre;
-  CTMR_HD uint32_t ld4(uint32_t pos) const {
-    const uint32_t off = pos - at;
-    if (pre & (off <= 8u)) {
-      const uint32_t lo = off < 4u ? e0 : (off < 8u ? e1 : e2);
-      const uint32_t hi = off < 4u ? e1 : (off < 8u ? e2 : 0u);
-      const uint32_t sh = 8u * (off & 3u);
-      if ((off & 3u) == 0u) return lo;
-      if (off < 8u) return (lo >> sh) | (hi << (32u - sh));
-    }
-    return v.ld4(pos);
-  }
-};
 
 template <class C, class V>
 CTMR_HD bool ec_point_ok(const V& v, uint32_t L, uint32_t c0, uint32_t ek) {
@@ -382,7 +391,7 @@ CTMR_HD_NOINLINE bool ec_key_far(RawCert rc, uint32_t L, uint32_t c0, uint32_t e
 }
 // elliptic.Unmarshal for the curve the parameters name (curve = 1..5: P-256, P-384, P-521, P-224, secp192r1)
 template <class R>
-CTMR_HD bool ec_key_check(const R& r, const SpkiView<R>& v, uint32_t L, uint32_t curve, uint32_t c0, uint32_t ek) {
+CTMR_HD bool ec_key_check(const R& r, const SpkiView<KeyReaderOf<R>>& v, uint32_t L, uint32_t curve, uint32_t c0, uint32_t ek) {
   if constexpr (has_raw<R>::value) {
     const RawCert rc = r.raw();
     switch (curve) {
@@ -409,13 +418,21 @@ CTMR_HD_NOINLINE bool dsa_key_far(RawCert rc, uint32_t L, uint32_t c0, uint32_t 
   return dsa_key_body(v, pv, L, c0, ek, par_p, par_e, nf_out);
 }
 
-// Phase 2 — anywhere behind phase 1 (the walk calls it behind its next window fill).
-template <class R>
-CTMR_HD void spki_key_finish(const R& r, uint32_t L, const AlgView& a, const KeyPending& kp, bool& ok, uint32_t& nf) {
+// What a deferring walk reports about an EC key it accepted so far: curve (1..5 as in ec_key_check; 0 = nothing pending),
+// certificate offset of the point's X coordinate and the BIT STRING's pad count.
+struct EcPending {
+  uint32_t curve, pos, shift;
+};
+
+// Phase 2 — anywhere behind phase 1 (the walk calls it behind its next window fill).  EC_DEFER: see the top of the file.
+template <bool EC_DEFER, class R>
+CTMR_HD void spki_key_finish(const R& r, uint32_t L, const AlgView& a, const KeyPending& kp, bool& ok, uint32_t& nf,
+                             EcPending& ecp) {
+  ecp.curve = ecp.pos = ecp.shift = 0u;
   if (!ok | (kp.alg == PK_OTHER)) return;
-  const SpkiView<R> v{r, kp.c0, kp.shift};
+  const SpkiView<KeyReaderOf<R>> v{key_reader_of(r), kp.c0, kp.shift};
   if ((kp.alg == PK_RSA) | (kp.alg == PK_RSA_OAEP)) {
-    const ExpView<R> ev{v, kp.e_pos < L ? kp.e_pos : L, kp.e0, kp.e1, kp.e2, kp.pre};
+    const SpkiView<KeyReaderOf<R>> ev{key_reader_of(r), kp.c0, kp.shift, kp.e_pos < L ? kp.e_pos : L, kp.e0, kp.e1, kp.e2, kp.pre};
     uint32_t e_after, e_len;
     int e_sign;
     key_integer(ev, L, kp.e_pos, kp.e_end, ok, nf, e_after, e_sign, e_len);
@@ -423,17 +440,17 @@ CTMR_HD void spki_key_finish(const R& r, uint32_t L, const AlgView& a, const Key
   } else if (kp.alg == PK_DSA) {
     uint32_t nfd = 0u;
     bool good;
-    if constexpr (has_raw<R>::value) {
+    if constexpr (has_raw<R>::value && !EC_DEFER) {
       good = dsa_key_far(r.raw(), L, kp.c0, kp.ek, kp.shift, a.par_p, a.par_e, &nfd);
-    } else {
-      const SpkiView<R> pv{r, 0u, 0u};
+    } else {  // (a map kernel: no calls — the DSA walk is a few header reads, cheap in registers)
+      const SpkiView<KeyReaderOf<R>> pv{key_reader_of(r), 0u, 0u};
       good = dsa_key_body(v, pv, L, kp.c0, kp.ek, a.par_p, a.par_e, &nfd);
     }
     ok = ok & good;
     nf |= nfd;
   } else {  // PK_EC
     // asn1.Unmarshal(Parameters.FullBytes, &namedCurveOID): one OBJECT IDENTIFIER; namedCurveFromOID
-    const SpkiView<R> pv{r, 0u, 0u};
+    const SpkiView<KeyReaderOf<R>> pv{key_reader_of(r), 0u, 0u};
     const uint32_t n = a.par_e - a.par_c;
     const uint32_t w0 = ldc(pv, a.par_c, L), w1 = ldc(pv, a.par_c + 4u, L);
     const bool is_oid = (a.par_e != a.par_p) & (a.par_tag == 0x06u);
@@ -447,7 +464,19 @@ CTMR_HD void spki_key_finish(const R& r, uint32_t L, const AlgView& a, const Key
     curve = (secg & (s5 == 0x21u)) ? 4u : curve;
     curve = (ansi & (a8 == 0x01u)) ? 5u : curve;
     nf = curve == 5u ? (nf | WALK_NF_SPKI) : nf;  // "insecure curve (secp192r1) specified"
-    ok = ok & (curve != 0u) && ec_key_check(r, v, L, curve, kp.c0, kp.ek);
+    // elliptic.Unmarshal: the length, the 04 …
+    const uint32_t bytes = curve == 1u ? 32u : curve == 2u ? 48u : curve == 3u ? 66u : curve == 4u ? 28u : 24u;
+    ok = ok & (curve != 0u) & (kp.ek - kp.c0 == 1u + 2u * bytes) & ((ldc(v, kp.c0, L) & 0xffu) == 0x04u);
+    // … and the point: x < p, y < p, on the curve
+    if constexpr (EC_DEFER) {
+      if (ok) {
+        ecp.curve = curve;
+        ecp.pos = kp.c0 + 1u;
+        ecp.shift = kp.shift;
+      }
+    } else {
+      ok = ok && ec_key_check(r, v, L, curve, kp.c0, kp.ek);
+    }
   }
 }
 

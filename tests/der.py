@@ -41,6 +41,10 @@ SIGALG = bytes.fromhex("300d06092a864886f70d01010b0500")
 P256_G = bytes.fromhex("6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296"
                        "4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5")
 EC_SPKI = bytes.fromhex("3059301306072a8648ce3d020106082a8648ce3d030107034200") + b"\x04" + P256_G
+# a second key on the curve (2·G), for tests that need two distinct SubjectPublicKeyInfos
+P256_2G = bytes.fromhex("7cf27b188d034f7e8a52380304b51ac3c08969e277f21b35a60b48fc47669978"
+                        "07775510db8ed040293d9ac69f7430dbba7dade63ce982299e04b79d227873d1")
+EC_SPKI_2 = EC_SPKI[:27] + P256_2G
 
 
 def spki(alg_oid, params, key_bits, pad=0):

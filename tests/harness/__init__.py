@@ -125,6 +125,20 @@ def ossl_extract(der: bytes):
     return o
 
 
+class OsslVerdict(C.Structure):
+    _fields_ = [("stage", C.c_int), ("ext_nid", C.c_int), ("n_ext", C.c_int), ("reason", C.c_char * 96)]
+
+
+def ossl_verdict(der: bytes) -> OsslVerdict:
+    """OpenSSL's accept/reject opinion by stage: 0 everything decodes, 1 d2i_X509, 2 trailing bytes, 3 the public key,
+    4 a validity time, 5 the body of an extension it has a decoder for (ext_nid)."""
+    ossl_extract(b"\x30\x00")
+    _ossl.ossl_verdict.argtypes = [C.c_char_p, C.c_long, C.POINTER(OsslVerdict)]
+    v = OsslVerdict()
+    _ossl.ossl_verdict(der, len(der), C.byref(v))
+    return v
+
+
 def ossl_pubkey_ok(der: bytes) -> int:
     """OpenSSL's opinion on the public key: 1 = certificate and key decode (X509_get_pubkey), 0 = the key does not,
     -1 = the certificate does not."""

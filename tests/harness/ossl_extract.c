@@ -1,6 +1,8 @@
 /* Test-only: OpenSSL 3 as an INDEPENDENT X.509 field extractor.
  * Not the Go parser — a cross-check that the oracle's walk reads the right bytes. */
 #include <openssl/asn1.h>
+#include <openssl/err.h>
+#include <openssl/objects.h>
 #include <openssl/x509.h>
 #include <openssl/x509v3.h>
 #include <string.h>
@@ -62,4 +64,64 @@ int ossl_pubkey_ok(const unsigned char* der, long len) {
   if (k) EVP_PKEY_free(k);
   X509_free(x);
   return ok;
+}
+
+/* The whole third opinion on ACCEPT / REJECT (scripts/diff_openssl.py, round 4): which stage of OpenSSL's handling of the
+ * certificate fails first, and why.  stage: 0 = everything decodes; 1 = d2i_X509; 2 = bytes left behind the certificate;
+ * 3 = the public key (X509_get_pubkey); 4 = a validity time (ASN1_TIME_check); 5 = the body of an extension OpenSSL has a
+ * decoder for (ext_nid says which).  reason = OpenSSL's reason string of the error it raised. */
+typedef struct {
+  int stage;
+  int ext_nid;
+  int n_ext;
+  char reason[96];
+} ossl_verdict_t;
+
+static void take_reason(ossl_verdict_t* v) {
+  /* the EARLIEST error of the queue is the root cause ("wrong tag", "invalid object encoding", …); the errors raised on
+   * the way up carry "Field=…, Type=…" data: the innermost of those says where */
+  unsigned long e;
+  const char* data;
+  int flags;
+  char where[64] = "";
+  const char* r = NULL;
+  while ((e = ERR_get_error_all(NULL, NULL, NULL, &data, &flags)) != 0) {
+    if (!r) r = ERR_reason_error_string(e);
+    if (!where[0] && data && (flags & ERR_TXT_STRING) && data[0]) snprintf(where, sizeof where, "%s", data);
+  }
+  snprintf(v->reason, sizeof v->reason, "%s @ %s", r ? r : "(no reason)", where);
+}
+
+int ossl_verdict(const unsigned char* der, long len, ossl_verdict_t* v) {
+  memset(v, 0, sizeof *v);
+  ERR_clear_error();
+  const unsigned char* p = der;
+  X509* x = d2i_X509(NULL, &p, len);
+  if (!x) { v->stage = 1; take_reason(v); return 1; }
+  if (p != der + len) { v->stage = 2; snprintf(v->reason, sizeof v->reason, "trailing bytes"); X509_free(x); return 2; }
+  EVP_PKEY* k = X509_get_pubkey(x);
+  if (!k) { v->stage = 3; take_reason(v); X509_free(x); return 3; }
+  EVP_PKEY_free(k);
+  if (ASN1_TIME_check(X509_get0_notBefore(x)) != 1 || ASN1_TIME_check(X509_get0_notAfter(x)) != 1) {
+    v->stage = 4; snprintf(v->reason, sizeof v->reason, "time check"); ERR_clear_error(); X509_free(x); return 4;
+  }
+  int n = X509_get_ext_count(x);
+  v->n_ext = n;
+  for (int i = 0; i < n; i++) {
+    X509_EXTENSION* e = X509_get_ext(x, i);
+    if (!X509V3_EXT_get(e)) continue;            /* no decoder for this extension: nothing to say */
+    void* d = X509V3_EXT_d2i(e);
+    if (!d) {
+      v->stage = 5;
+      v->ext_nid = OBJ_obj2nid(X509_EXTENSION_get_object(e));
+      take_reason(v);
+      X509_free(x);
+      return 5;
+    }
+    const X509V3_EXT_METHOD* m = X509V3_EXT_get(e);
+    if (m->it) ASN1_item_free(d, ASN1_ITEM_ptr(m->it)); else if (m->ext_free) m->ext_free(d);
+  }
+  ERR_clear_error();
+  X509_free(x);
+  return 0;
 }

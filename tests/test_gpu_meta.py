@@ -106,7 +106,7 @@ def test_first_sightings_on_synthetic_batches():
 
 def test_crl_and_dn_edge_cases():
     iss_cert = D.cert(serial=b"\x11", exts=[D.BC_CA], subject=D.name(D.rdn(3, b"Edge CA")))
-    other = D.cert(serial=b"\x12", exts=[D.BC_CA], subject=D.name(D.rdn(3, b"Edge CA 2")), spki=D.EC_SPKI[:-1] + b"\x77")
+    other = D.cert(serial=b"\x12", exts=[D.BC_CA], subject=D.name(D.rdn(3, b"Edge CA 2")), spki=D.EC_SPKI_2)
     n1 = D.name(D.rdn(6, b"US", 0x13), D.rdn(10, b"Edge Org"), D.rdn(3, b"Edge CA"))
     n2 = D.name(D.rdn(3, b"Edge CA"), D.rdn(10, b"Edge Org"))          # same attributes, other order: other DN
     big = D.name(D.rdn(10, b"x" * 5000), D.rdn(3, b"Edge CA"))
