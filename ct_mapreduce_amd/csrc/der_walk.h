@@ -288,6 +288,63 @@ CTMR_HD void bit_string_check(const R& r, uint32_t L, uint32_t c, uint32_t len, 
 // pkix.AlgorithmIdentifier ::= SEQUENCE { algorithm OBJECT IDENTIFIER, parameters ANY OPTIONAL } at p, inside [p, end):
 // the OID must be there, non-empty and end on an octet without the continuation bit (parseObjectIdentifier, as far as
 // it is modelled); parameters, when present, must be one well-formed TLV that fits; anything behind is ignored.
+// Go asn1 parseObjectIdentifier on content [c, e): a run of base-128 integers (parseBase128Int) — each at most 5 octets,
+// its first octet not 0x80 ("integer is not minimally encoded"), its value at most 2^31 − 1 ("base 128 integer too
+// large": a five-octet integer whose first octet carries more than three payload bits), the last one complete.  OpenSSL
+// rejects the first and the last of these as well ("invalid object encoding"); rounds 1–3 only looked at the last octet.
+template <class R>
+CTMR_HD bool oid_arcs_exact(const R& r, uint32_t L, uint32_t c, uint32_t e) {  // octet by octet (rare: see oid_arcs_ok)
+  bool good = e != c;
+  uint32_t run = 0u, first = 0u;  // octets of the integer under way, and its first octet
+  for (uint32_t p = c; good & (p < e); p += 4u) {
+    const uint32_t w = ldc(r, p, L);
+    const uint32_t nb = e - p < 4u ? e - p : 4u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      if (k < nb) {
+        const uint32_t b = (w >> (8u * k)) & 0xffu;
+        first = run == 0u ? b : first;
+        good = good & !((run == 0u) & (b == 0x80u));
+        run++;
+        good = good & (run <= 5u);
+        if (!(b & 0x80u)) {
+          good = good & !((run == 5u) & ((first & 0x78u) != 0u));
+          run = 0u;
+        }
+      }
+    }
+  }
+  return good & (run == 0u);
+}
+// Four octets per step: no integer starts with 0x80 (an octet equal to 0x80 whose predecessor does not continue), the
+// last octet ends one, and — as long as the whole OID holds at most three continuation octets, which every OID of the
+// X.509 world does — no integer can reach five octets, so the size rules hold by counting.  Otherwise: the exact loop.
+template <class R>
+CTMR_HD bool oid_arcs_ok(const R& r, uint32_t L, uint32_t c, uint32_t e) {
+#ifdef CTMR_EXP_NO_OIDARCS  // measurement build: rounds 1-3 looked at the last octet only
+  const uint32_t lastp = e - 1u;
+  return (e != c) & ((ldc(r, lastp, L) & 0x80u) == 0u);
+#else
+  bool good = e != c;
+  uint32_t conts = 0u, prev = 0u;  // continuation octets so far; 0x80 when the octet before this word continues
+  for (uint32_t p = c; p < e; p += 4u) {
+    const uint32_t nb = e - p < 4u ? e - p : 4u;
+    const uint32_t keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+    const uint32_t w = ldc(r, p, L);
+    const uint32_t cb = w & 0x80808080u & keep;
+    const uint32_t t = (w ^ 0x80808080u) | ~keep;  // zero octet ⇔ the octet is 0x80
+    const uint32_t is80 = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+    const uint32_t starts = ~((cb << 8) | prev);   // bit 7 of octet k: the octet before it does not continue
+    good = good & ((is80 & starts) == 0u);
+    conts += (uint32_t)__builtin_popcount(cb);
+    prev = (cb >> (8u * (nb - 1u))) & 0x80u;
+  }
+  good = good & (prev == 0u);
+  if (good & (conts > 3u)) good = oid_arcs_exact(r, L, c, e);
+  return good;
+#endif
+}
+
 // What alg_id found: the algorithm OID's content octets and the parameters element (absent: par_e == par_p).
 struct AlgView {
   uint32_t oid_c, oid_e;
@@ -299,9 +356,16 @@ CTMR_HD void alg_id(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok, 
   uint32_t tag, cs, ce, to, co, eo;
   rd_hdr(r, L, p, end, ok, tag, cs, ce);
   rd_hdr(r, L, cs, ce, ok, to, co, eo);
-  const uint32_t lastp = eo - 1u;
-  const uint32_t last = ldc(r, lastp, L);
-  ok = ok & (tag == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
+  ok = ok & (tag == 0x30u) & (to == 0x06u);
+  {  // the algorithm OID's arcs: the families every certificate of the Web PKI uses are recognised by two compares (their
+     // octets are a valid encoding), anything else takes the general test — which costs the map 1.5 ms per 100 M
+     // certificates when all three AlgorithmIdentifiers of every certificate go through it (measured, round 4)
+    const uint32_t n = eo - co, w0 = ldc(r, co, L), w1 = ldc(r, co + 4u, L), w2 = ldc(r, co + 8u, L);
+    const bool pkcs1 = (n == 9u) & (w0 == 0x8648862au) & (w1 == 0x01010df7u) & ((w2 & 0x80u) == 0u);     // 1.2.840.113549.1.1.x
+    const bool x962 = (w0 == 0xce48862au) & (((n == 8u) & ((w1 & 0x80ffffffu) == 0x0003043du)) |             // ecdsa-with-SHA2 …10045.4.3.x
+                                             ((n == 7u) & ((w1 & 0x00ffffffu) == 0x0001023du)));              // id-ecPublicKey …10045.2.1
+    ok = ok && (pkcs1 | x962 || oid_arcs_ok(r, L, co, eo));
+  }
   uint32_t tp = 0u, cp = eo, ep = eo;
   if (ok & (eo < ce)) rd_hdr(r, L, eo, ce, ok, tp, cp, ep);
   av = AlgView{co, eo, eo, tp, cp, ok ? ep : eo};  // (by reference: a pointer that may be null puts the view in scratch memory)
@@ -336,8 +400,37 @@ namespace ctmr {
 // CN = true: also finds the last attribute with OID 2.5.4.3 whose value is a string type (the types Go decodes to a
 // `string`; pkix.Name.FillFromRDNSequence).  One flattened loop: each iteration decodes either a SET (RDN) header or
 // one AttributeTypeAndValue.  Returns the end of the Name.
+// An AttributeTypeAndValue's `Value interface{}`: Go's encoding/asn1 decodes a universal, primitive value by its tag, and
+// besides the string types (strict_strings) it knows INTEGER (parseInt64: non-empty, at most 8 octets; not minimal →
+// only the lax re-parse accepts it), BIT STRING (parseBitString), OBJECT IDENTIFIER (parseObjectIdentifier), UTCTime and
+// GeneralizedTime (the validity's own rules) — a value of one of these types that does not parse fails the Name, and with
+// it x509.ParseCertificate.  Everything else (OCTET STRING, BOOLEAN, constructed and non-universal values) is taken as it
+// is.  value_plain(tag): not one of the five.  Round 4 (DESIGN.md §3.1 listed it as not checked before).
+CTMR_HD bool value_plain(uint32_t tag) {
+#ifdef CTMR_EXP_NO_NAMEVAL  // measurement build
+  return true;
+#endif
+  return ((tag < 32u) & (((0x0180004cu >> (tag & 31u)) & 1u) != 0u)) == 0;
+}
+template <class R>
+CTMR_HD void name_value_check(const R& r, uint32_t L, uint32_t tag, uint32_t c, uint32_t e, bool& ok, uint32_t& nf) {
+  if (tag == 0x02u) {
+    bool neg;
+    int_check(r, L, c, e - c, ok, nf, neg);
+    ok = ok & (e - c <= 8u);
+  } else if (tag == 0x03u) {
+    bit_string_check(r, L, c, e - c, ok);
+  } else if (tag == 0x06u) {
+    ok = ok && oid_arcs_ok(r, L, c, e);
+  } else {
+    int64_t t;
+    rd_time(r, L, c, tag, e - c, ok, t);
+  }
+}
+
 template <bool CN, class R>
-CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool& ok, uint32_t& cn_off, uint32_t& cn_len) {
+CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool& ok, uint32_t& cn_off, uint32_t& cn_len,
+                           uint32_t& nf) {
   uint32_t tag, cs, ce;
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
@@ -354,11 +447,13 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
       // value hdr — when every length is short form (the usual 2.5.4.x attribute).  One independent 12-byte
       // read replaces five dependent header reads; each header read is an LDS round trip on the critical path.
       const uint32_t w0 = ldc(r, a, L), w1 = ldc(r, a + 4u, L), w2 = ldc(r, a + 8u, L);
-      const bool fast = ((w0 & 0x80ff80ffu) == 0x00300031u) & ((w1 & 0xffffu) == 0x0306u) &
-                        ((w2 & 0x800080u) == 0u) & ((w2 & 0x1f00u) != 0x1f00u);  // short value length, OID ends, low value tag
+      // three one-octet arcs (2.5.4.x), short value length, low value tag — and a value Go does not look into (value_plain)
+      const uint32_t tvf = (w2 >> 8) & 0xffu;
+      const bool fast = ((w0 & 0x80ff80ffu) == 0x00300031u) & ((w1 & 0x8080ffffu) == 0x00000306u) &
+                        ((w2 & 0x800080u) == 0u) & ((w2 & 0x1f00u) != 0x1f00u) & value_plain(tvf);
       if (fast) {
         const uint32_t set_end = a + 2u + ((w0 >> 8) & 0xffu), atv_end = a + 4u + (w0 >> 24);
-        const uint32_t tv = (w2 >> 8) & 0xffu, cv = a + 11u, ev = cv + ((w2 >> 16) & 0xffu);
+        const uint32_t tv = tvf, cv = a + 11u, ev = cv + ((w2 >> 16) & 0xffu);
         ok = ok & (set_end <= s_end) & (atv_end <= set_end) & (ev <= atv_end);
         if constexpr (CN) {
           const bool is_cn = (((w1 >> 16) | ((w2 & 0xffu) << 16)) == 0x030455u) & string_tag(tv);
@@ -378,10 +473,10 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
       rd_hdr(r, L, a, a_end, ok, t1, c1, e1);      // AttributeTypeAndValue
       rd_hdr(r, L, c1, e1, ok, to, co, eo);        // type OID
       const uint32_t oidw = ldc(r, co, L);
-      const uint32_t lastp = eo - 1u;
-      const uint32_t last = ldc(r, lastp, L);
       rd_hdr(r, L, eo, e1, ok, tv, cv, ev);        // value
-      ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
+      ok = ok & (t1 == 0x30u) & (to == 0x06u);
+      ok = ok && oid_arcs_ok(r, L, co, eo);
+      if (ok & !value_plain(tv)) name_value_check(r, L, tv, cv, ev, ok, nf);
       if constexpr (CN) {
         const bool is_cn = (eo - co == 3u) & ((oidw & 0xffffffu) == 0x030455u) & string_tag(tv);
         cn_off = is_cn ? cv : cn_off;
@@ -577,7 +672,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   {
     const uint32_t n0 = q;
     o.issuer_name = q;
-    q = walk_name<true>(r, L, q, tbs_end, ok, o.cn_off, o.cn_len);
+    q = walk_name<true>(r, L, q, tbs_end, ok, o.cn_off, o.cn_len, o.nonfatal);
     o.meta_issuer = meta_pack(n0, q - n0);
     note_issuer_if(r, n0, q - n0);  // readers that look the Name up while it is at hand (the map kernel's memo pre-check)
     if (use_filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, fv) : false;
@@ -603,7 +698,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
 #else
     uint32_t d0 = 0, d1 = 0;
     o.subject_name = q;
-    q = walk_name<false>(r, L, q, tbs_end, ok, d0, d1);
+    q = walk_name<false>(r, L, q, tbs_end, ok, d0, d1, o.nonfatal);
 #endif
   }
   if constexpr (NAMES_ONLY) return ok;
@@ -634,6 +729,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // a two-region reader fetches them in one burst
   r.touch_tail(q, tbs_end);
   if (spki) {
+    key_tail_of(r, q, key_pending);  // the 16 octets around the key's end, when the reader fetched them with the tail
     EcPending ecp;
     spki_key_finish<EC_DEFER>(r, L, key_alg, key_pending, ok, o.nonfatal, ecp);
     o.ec_curve = ecp.curve; o.ec_pos = ecp.pos; o.ec_shift = ecp.shift;
@@ -681,7 +777,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
       // Fast form: Extension hdr, a 3-byte extnID with its hdr, optional critical BOOLEAN and the extnValue hdr
       // lie in the 12 bytes at e when every length is short form (every 2.5.29.x extension under 128 bytes).
       const uint32_t w0 = ldc(r, e, L), w1 = ldc(r, e + 4u, L), w2 = ldc(r, e + 8u, L);
-      const bool p0 = ((w0 & 0xffff80ffu) == 0x03060030u) & ((w1 & 0x800000u) == 0u);
+      const bool p0 = ((w0 & 0xffff80ffu) == 0x03060030u) & ((w1 & 0x808080u) == 0u);  // three one-octet arcs (2.5.29.x)
       const uint32_t b7 = w1 >> 24, b9 = (w2 >> 8) & 0xffu;
       const bool nc = p0 & (b7 == 0x04u) & ((w2 & 0x80u) == 0u);
       const bool cr = p0 & (b7 == 0x01u) & ((w2 & 0x80ff00ffu) == 0x00040001u) & ((b9 == 0x00u) | (b9 == 0xffu));
@@ -697,10 +793,9 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         rd_hdr(r, L, e, e_end, ok, t1, x, x_end);   // Extension
         rd_hdr(r, L, x, x_end, ok, to, co, eo);     // extnID
         oidw = ldc(r, co, L);
-        const uint32_t lastp = eo - 1u;
-        const uint32_t last = ldc(r, lastp, L);
         rd_hdr(r, L, eo, x_end, ok, tv, cv, ev);    // critical or extnValue
-        ok = ok & (t1 == 0x30u) & (to == 0x06u) & (eo != co) & ((last & 0x80u) == 0u);
+        ok = ok & (t1 == 0x30u) & (to == 0x06u);
+        ok = ok && oid_arcs_ok(r, L, co, eo);
         if (tv == 0x01u) {  // critical BOOLEAN
           const uint32_t bv = ldc(r, cv, L) & 0xffu;
           ok = ok & (ev - cv == 1u) & ((bv == 0x00u) | (bv == 0xffu));

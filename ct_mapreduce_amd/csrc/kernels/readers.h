@@ -194,6 +194,10 @@ struct WinReaderS : WinReaderC<WCH> {
   // three dependent, uncoalesced global round trips per wave; now they are register selects.
   uint32_t tl[8];
   uint32_t tl_pos;  // certificate offset of tl[0]'s first byte; 0x80000000 = not fetched (positions are < 2^31)
+  // … and the 16 octets [pos − 12, pos + 4) around the end of the SubjectPublicKeyInfo (an RSA key's publicExponent sits
+  // there, spki_key.h): one more unaligned 16-byte load in the same burst instead of dependent reads ~0.3 KB off the window
+  uint32_t kt[4];
+  bool kt_ok;
   Hook hook{};  // by value: a pointer to state that lives across loop iterations keeps that state out of registers
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     uint32_t rel = pos - (uint32_t)this->grel;
@@ -208,12 +212,20 @@ struct WinReaderS : WinReaderC<WCH> {
     const bool have = ta + 32u <= this->limit;
     const uint8_t* tp = (const uint8_t*)this->g32 + (have ? ta : 0ull);
     const U16t a = *(const U16t*)tp, b = *(const U16t*)(tp + 16);  // in flight with the refill below
+    const bool kh = (pos >= 12u) & (this->base + pos + 4u <= this->limit);
+    const U16t kk = *(const U16t*)((const uint8_t*)this->g32 + (kh ? this->base + pos - 12u : 0ull));
+    kt[0] = kk.a; kt[1] = kk.b; kt[2] = kk.c; kt[3] = kk.d;
+    kt_ok = kh;
     hook.issue();
     WinReaderC<WCH>::touch_tail(pos, tail);
     hook.resolve();
     tl[0] = a.a; tl[1] = a.b; tl[2] = a.c; tl[3] = a.d;
     tl[4] = b.a; tl[5] = b.b; tl[6] = b.c; tl[7] = b.d;
     tl_pos = have ? tail : 0x80000000u;
+  }
+  struct KeyTail { bool valid; uint32_t at; uint32_t w[4]; };
+  __device__ __forceinline__ KeyTail key_tail(uint32_t pos) const {  // spki_key.h key_tail_of: pos = what touch_tail got
+    return KeyTail{kt_ok, pos - 12u, {kt[0], kt[1], kt[2], kt[3]}};
   }
   // der_walk.h: the issuer Name [pos, pos+len) has just been walked — the front window still holds it
   __device__ __forceinline__ void note_issuer(uint32_t pos, uint32_t len) {

@@ -538,119 +538,97 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
 // four modular products need 84..170 VGPRs — evaluates the equation and
 //   point bad   the entry becomes what the map makes of a certificate that does not parse (status PARSE_ERROR, nothing
 //               else reported); a key record that already left for its owner (XM_OWNER) is withdrawn (meta = 0);
-//   point good  the pending bit goes; an entry in state ES_PENDING (would reach the set, key is this rank's) is inserted
-//               with the fully synchronised protocol of table_upsert — claims of this kernel publish w[1] last, slots of
-//               pass 1 and of earlier batches are complete — and the ORDER rule: whoever of (holder, me) has the higher
-//               order in the round loses.  The entry's ent[] word is written BEFORE its key becomes findable, as
-//               "claimed"; afterwards it is only ever downgraded by byte writes (mine or a winner's mark_dup), so no
-//               update is lost whoever comes last.
-// Runs between the map (+ k_insert) and k_insert2; a batch without pending entries costs one launch of blocks that read
-// one word and leave.
-__device__ __forceinline__ uint32_t upsert_ordered(const InsertArgs& a, ctmr_record* records, unsigned long long meta,
-                                                   const unsigned long long s[5], uint32_t ord, unsigned long long* h_out) {
-  const unsigned long long h = key_hash(meta, s);
-  *h_out = h;
-  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
-  uint64_t j = h & a.mask;
-  for (uint64_t probes = 0; probes <= a.mask;) {
-    Slot* sl = a.table + j;
-    unsigned long long w0 = ld_agent(&sl->w[0]);
-    if (w0 == 0ull) {
-      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | ord);
-      if (old == 0ull) {
-        st_agent(&sl->w[2], (unsigned long long)a.epoch);
-#pragma unroll
-        for (int k = 0; k < 5; k++) st_agent(&sl->w[3 + k], s[k]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_agent(&sl->w[1], meta);
-        return ES_CLAIMED;
-      }
-      w0 = old;
-    }
-    if ((w0 & 0xffffffff00000000ull) == tagw && w0 != SLOT_TOMB) {
-      const unsigned long long m = ld_agent(&sl->w[1]);
-      if (!(m & SLOT_VALID)) continue;  // claimed by another lane of this kernel, not published yet: poll
-      bool eq = m == meta;
-#pragma unroll
-      for (int k = 0; k < 5; k++) eq = eq && ld_agent(&sl->w[3 + k]) == s[k];
-      if (eq) {
-        if ((uint32_t)ld_agent(&sl->w[2]) != a.epoch) return ES_DUP;  // known since an earlier batch
-        const uint32_t other = (uint32_t)atomicMin(&sl->w[0], tagw | ord);
-        if (other < ord) return ES_DUP;       // a lower order of this round holds the key
-        if (other != ord) mark_dup_ord(a, records, other);
-        return ES_CLAIMED;                    // (unless a still lower order joins and marks it)
-      }
-    }
-    j = probe_next(j, probes, a.mask);
-    probes++;
-  }
-  return ES_FULL;
-}
-
-__device__ __forceinline__ void ec_resolve_one(const InsertArgs& a, ctmr_record* records, uint64_t i, uint32_t e) {
-  const unsigned long long kp = a.keypos[i];
-  uint64_t lo, hi;
-  cert_range(a.offsets, a.ends, i, lo, hi);
-  const RawReader rr{RawCert{(const uint32_t*)a.payload, lo}};
-  const uint32_t L = (uint32_t)(hi - lo), pos = (uint32_t)kp, curve = (uint32_t)(kp >> 32) & 7u, shift = (uint32_t)(kp >> 35) & 7u;
-  const SpkiView<RawReader> v{rr, pos - 1u, shift};
-  bool good;
-  switch (curve) {
-    case 1u: good = ec_on_curve<CurveP256>(v, L, pos); break;
-    case 2u: good = ec_on_curve<CurveP384>(v, L, pos); break;
-    case 3u: good = ec_on_curve<CurveP521>(v, L, pos); break;
-    case 4u: good = ec_on_curve<CurveP224>(v, L, pos); break;
-    default: good = ec_on_curve<CurveP192>(v, L, pos); break;
-  }
-  uint4* rp = (uint4*)(records + i);
-  if (!good) {  // x509.ParseCertificate fails: map_one's record of such a certificate
-    const uint4 r0 = rp[0];
-    rp[0] = make_uint4(CTMR_ST_PARSE_ERROR | (((r0.x >> 8) & CTMR_FL_PRECERT) << 8), 0u, r0.z, 0u);
-    rp[1] = make_uint4(0u, 0u, 0u, 0u);
-    if ((kp >> 38) & 1ull) a.stage[(i & ~63ull) + ((kp >> 39) & 63ull)].meta = 0ull;  // the owner ignores it
-    a.ent[i] = ent_pack(CTMR_ST_PARSE_ERROR, ES_NONE, e >> 8) | (e & 0x40u);
-    return;
-  }
-  uint32_t ne = e & ~ENT_KEY_PENDING;
-  if (ent_state(e) != ES_PENDING) {  // filtered, without issuer, left for its owner, host-side serial: what the map said
-    a.ent[i] = ne;
-    return;
-  }
-  ne = (ne & ~(7u << 3)) | ((uint32_t)ES_CLAIMED << 3);
-  a.ent[i] = ne;
-  __threadfence();  // the word is in place before the key can be found (and the entry marked) by anybody
-  const uint4 r0 = rp[0], r1 = rp[1];
-  unsigned long long s[5], h;
-  record_key(a, i, r0, r1, s);
-  const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
-  const uint32_t state = upsert_ordered(a, records, meta, s, a.ord_base + (uint32_t)i, &h);
-  if (state != ES_CLAIMED) {
-    ((uint8_t*)(a.ent + i))[0] = (uint8_t)((ne & 0xc7u) | (state << 3));
-    uint8_t* fl = (uint8_t*)(records + i) + 1;
-    *fl = (uint8_t)(*fl & ~CTMR_FL_WAS_UNKNOWN);
-  } else if (a.bloom) {
-    uint64_t word;
-    unsigned long long bits;
-    bloom_pos(h, a.bloom_wmask, word, bits);
-    atomicOr(&a.bloom[word], bits);
-  }
+//   point good  the pending bit goes; an entry in state ES_PENDING (would reach the set, key is this rank's) gets PASS 1
+//               of the insert exactly as the map's other entries got it inside the fused kernel (insert_probe_h + the
+//               cooperative slot store): claim, or DEFER on a same-tag slot of this batch — k_insert2, which runs next,
+//               settles those.  (First version, measured: the fully synchronised upsert — agent-scope loads, CAS, six
+//               written-through stores and a drained publish per key — 80 ms per 47 M keys; every one of them a DRAM
+//               read + write at the memory side, profiles/r03/calib_atomics_by_scope.jsonl.)
+// A block takes 1 024 consecutive entries, compacts the pending ones into LDS and walks that list 256 at a time: the
+// lanes of a wave are busy whatever share of the batch has EC keys.  A batch without any costs one launch of blocks that
+// read one word and leave.
+template <class C>
+__device__ __forceinline__ bool ec_point_bits(const uint32_t* words, unsigned long long xbit) {
+  uint32_t x[C::NL], y[C::NL];
+  fe_load_bits<C>(words, xbit, x);
+  fe_load_bits<C>(words, xbit + 8ull * C::BYTES, y);
+  return ec_equation<C>(x, y);
 }
 
 constexpr uint32_t EC_PER_BLOCK = 1024;
 __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* records) {
+  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 slot images (store_slots_wave)
+  __shared__ uint16_t list[EC_PER_BLOCK];
+  __shared__ uint32_t n_list;
   if (a.stats->n_pending == 0ull) return;
-  const uint64_t i0 = (uint64_t)blockIdx.x * EC_PER_BLOCK + threadIdx.x * 4u;
-  if (i0 >= a.n) return;
-  uint32_t e[4] = {0u, 0u, 0u, 0u};
-  if (i0 + 4 <= a.n) {
-    const uint4 v = *(const uint4*)(a.ent + i0);
-    e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
-  } else {
-    for (uint32_t k = 0; i0 + k < a.n; k++) e[k] = a.ent[i0 + k];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t blk0 = (uint64_t)blockIdx.x * EC_PER_BLOCK;
+  if (threadIdx.x == 0) n_list = 0u;
+  __syncthreads();
+  {  // the pending entries of this block's 1 024, four ent[] words per thread
+    const uint64_t i0 = blk0 + threadIdx.x * 4u;
+    uint32_t e[4] = {0u, 0u, 0u, 0u};
+    if (i0 + 4 <= a.n) {
+      const uint4 v = *(const uint4*)(a.ent + i0);
+      e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+    } else {
+      for (uint32_t k = 0; i0 + k < a.n; k++) e[k] = a.ent[i0 + k];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (e[k] & ENT_KEY_PENDING) list[atomicAdd(&n_list, 1u)] = (uint16_t)(threadIdx.x * 4u + k);
   }
-#pragma unroll 1
-  for (uint32_t k = 0; k < 4; k++)
-    if (e[k] & ENT_KEY_PENDING) ec_resolve_one(a, records, i0 + k, e[k]);
+  __syncthreads();
+  const uint32_t cnt = n_list;
+  for (uint32_t base = 0; base < cnt; base += 256u) {  // (block-uniform trip count: store_slots_wave is cooperative)
+    const uint32_t t = base + threadIdx.x;
+    uint64_t claimed = ~0ull;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+    if (t < cnt) {
+      const uint64_t i = blk0 + list[t];
+      const uint32_t e = a.ent[i];
+      const unsigned long long kp = a.keypos[i];
+      uint64_t lo, hi;
+      cert_range(a.offsets, a.ends, i, lo, hi);
+      const uint32_t pos = (uint32_t)kp, curve = (uint32_t)(kp >> 32) & 7u, shift = (uint32_t)(kp >> 35) & 7u;
+      const unsigned long long xbit = 8ull * (lo + pos) - shift;  // where X starts, as a bit position in the payload
+      bool good;
+      switch (curve) {
+        case 1u: good = ec_point_bits<CurveP256>((const uint32_t*)a.payload, xbit); break;
+        case 2u: good = ec_point_bits<CurveP384>((const uint32_t*)a.payload, xbit); break;
+        case 3u: good = ec_point_bits<CurveP521>((const uint32_t*)a.payload, xbit); break;
+        case 4u: good = ec_point_bits<CurveP224>((const uint32_t*)a.payload, xbit); break;
+        default: good = ec_point_bits<CurveP192>((const uint32_t*)a.payload, xbit); break;
+      }
+      uint4* rp = (uint4*)(records + i);
+      if (!good) {  // x509.ParseCertificate fails: map_one's record of such a certificate
+        const uint4 r0 = rp[0];
+        rp[0] = make_uint4(CTMR_ST_PARSE_ERROR | (((r0.x >> 8) & CTMR_FL_PRECERT) << 8), 0u, r0.z, 0u);
+        rp[1] = make_uint4(0u, 0u, 0u, 0u);
+        if ((kp >> 38) & 1ull) a.stage[(i & ~63ull) + ((kp >> 39) & 63ull)].meta = 0ull;  // the owner ignores it
+        a.ent[i] = ent_pack(CTMR_ST_PARSE_ERROR, ES_NONE, e >> 8);
+      } else if (ent_state(e) != ES_PENDING) {  // filtered, without issuer, left for its owner, host-side serial: as the map said
+        a.ent[i] = e & ~ENT_KEY_PENDING;
+      } else {
+        const uint4 r0 = rp[0], r1 = rp[1];
+        unsigned long long s[5];
+        record_key(a, i, r0, r1, s);
+        const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
+        const unsigned long long h = key_hash(meta, s);
+        const uint32_t state = insert_probe_h(a, i, meta, s, h, claimed, q0, q1, q2, q3);
+        if (state != ES_CLAIMED && state != ES_DEFER) {
+          ((uint8_t*)(records + i))[1] = (uint8_t)((r0.x >> 8) & ~CTMR_FL_WAS_UNKNOWN);
+        } else if (a.bloom) {
+          uint64_t word;
+          unsigned long long bits;
+          bloom_pos(h, a.bloom_wmask, word, bits);
+          atomicOr(&a.bloom[word], bits);
+        }
+        a.ent[i] = (e & ~(ENT_KEY_PENDING | (7u << 3))) | (state << 3);
+      }
+    }
+    store_slots_wave(a.table, img[wv], lane, claimed, q0, q1, q2, q3);
+  }
 }
 
 // Wave-aggregated add: one atomic per distinct key per wave (the "match-any" loop).

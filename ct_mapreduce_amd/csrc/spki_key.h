@@ -95,18 +95,19 @@ template <class K>
 struct SpkiView {
   K r;  // key_reader_of(reader): by value
   uint32_t c0, shift;
-  // twelve octets fetched ahead (an RSA key's publicExponent, spki_key_begin): served from registers.  (Part of this
-  // view, not a view over it: a reader reached through two levels of references stays in scratch memory.)
-  uint32_t at = 0u, e0 = 0u, e1 = 0u, e2 = 0u;
+  // sixteen octets fetched ahead (around the end of the key: an RSA key's publicExponent — Reader::key_tail), served from
+  // registers.  (Part of this view, not a view over it: a reader reached through two levels of references stays in
+  // scratch memory.)
+  uint32_t at = 0u, e0 = 0u, e1 = 0u, e2 = 0u, e3 = 0u;
   bool pre = false;
   CTMR_HD uint32_t ld4(uint32_t pos) const {
     const uint32_t off = pos - at;
-    if (pre & (off <= 8u)) {  // (64-bit shifts, not selects by `off`: the compiler turns those into a table in scratch memory)
+    if (pre & (off <= 12u)) {  // (64-bit shifts, not selects by `off`: the compiler turns those into a table in scratch memory)
       const unsigned long long a = (unsigned long long)e0 | ((unsigned long long)e1 << 32);
-      const unsigned long long b = (unsigned long long)e1 | ((unsigned long long)e2 << 32);
-      const unsigned long long x = (off & 4u) ? b : a;
-      const uint32_t w = (uint32_t)(x >> (8u * (off & 3u)));
-      return (off & 8u) ? e2 : w;
+      const unsigned long long b = (unsigned long long)e2 | ((unsigned long long)e3 << 32);
+      const uint32_t sh = 8u * (off & 7u);
+      const unsigned long long lo64 = (off & 8u) ? b : a, hi64 = (off & 8u) ? 0ull : b;
+      return (uint32_t)(sh ? ((lo64 >> sh) | (hi64 << (64u - sh))) : lo64);
     }
     if (shift == 0u) return r.ld4(pos);
     const uint32_t lo = r.ld4(pos - 1u), hi = r.ld4(pos + 3u);
@@ -218,14 +219,13 @@ CTMR_HD void fe_load(const V& v, uint32_t L, uint32_t pos, uint32_t (&out)[C::NL
 }
 
 // elliptic.Unmarshal's tests behind the length and the 04: x < p, y < p, y² = x³ − 3x + b.  Evaluated as
-//   mont(mont(y,y), 1) == mont(mont(x,x) − 3R⁻¹, x) + bR⁻²   (both sides carry R⁻²; four products, one of them by 1),
-// x first and y only when x's side is done: two field elements and one product's state are live at a time.
-template <class C, class V>
-CTMR_HD bool ec_on_curve(const V& v, uint32_t L, uint32_t pos) {
+//   mont(mont(y,y), 1) == mont(mont(x,x) − 3R⁻¹, x) + bR⁻²   (both sides carry R⁻²; four products, one of them by 1).
+// x and y are consumed.
+template <class C>
+CTMR_HD bool ec_equation(uint32_t (&x)[C::NL], uint32_t (&y)[C::NL]) {
   constexpr int NL = C::NL;
-  uint32_t x[NL], u[NL];
-  fe_load<C>(v, L, pos, x);
-  bool in_range = fe_lt_p<C>(x);
+  const bool in_range = fe_lt_p<C>(x) & fe_lt_p<C>(y);
+  uint32_t u[NL];
 #pragma unroll
   for (int j = 0; j < NL; j++) u[j] = x[j];
   mont_mul<C>(x, u);  // u = x²R⁻¹
@@ -266,9 +266,6 @@ CTMR_HD bool ec_on_curve(const V& v, uint32_t L, uint32_t pos) {
       br = (s >> 32) & 1ull;
     }
   }
-  uint32_t y[NL];
-  fe_load<C>(v, L, pos + C::BYTES, y);
-  in_range = in_range & fe_lt_p<C>(y);
 #pragma unroll
   for (int j = 0; j < NL; j++) u[j] = y[j];
   mont_mul<C>(y, u);  // u = y²R⁻¹
@@ -279,6 +276,36 @@ CTMR_HD bool ec_on_curve(const V& v, uint32_t L, uint32_t pos) {
 #pragma unroll
   for (int j = 0; j < NL; j++) diff |= x[j] ^ u[j];
   return in_range & (diff == 0u);
+}
+
+template <class C, class V>
+CTMR_HD bool ec_on_curve(const V& v, uint32_t L, uint32_t pos) {
+  uint32_t x[C::NL], y[C::NL];
+  fe_load<C>(v, L, pos, x);
+  fe_load<C>(v, L, pos + C::BYTES, y);
+  return ec_equation<C>(x, y);
+}
+
+// One coordinate straight out of memory, for k_ec_resolve: the C::BYTES octets that START at bit `bit` of the buffer
+// `words` (bit = 8·octet position − the BIT STRING's pad count: BitString.RightAlign as a bit offset; bits count from the
+// most significant bit of octet 0), as little-endian limbs.  NL + 1 aligned dwords, loaded unconditionally and together —
+// one memory latency — and funnel-shifted into place.  (Through a byte reader every 4-octet read is a branch and a wait
+// of its own: ≈ 70 dependent round trips per point, 80 ms per 47 M points, measured.)
+template <class C>
+CTMR_HD void fe_load_bits(const uint32_t* words, unsigned long long bit, uint32_t (&out)[C::NL]) {
+  constexpr int NL = C::NL;
+  constexpr uint32_t lead = 32u * (uint32_t)NL - 8u * C::BYTES;  // unused high bits of the top limb (P-521: 16)
+  const unsigned long long start = bit - lead;                  // the limbs as NL whole big-endian words from here
+  const unsigned long long d0 = start >> 5;
+  const uint32_t r = (uint32_t)start & 31u;
+  uint32_t w[NL + 1];
+#pragma unroll
+  for (int k = 0; k <= NL; k++) w[k] = __builtin_bswap32(words[d0 + (unsigned long long)k]);
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    const uint32_t v = r ? ((w[k] << r) | (w[k + 1] >> (32u - r))) : w[k];
+    out[NL - 1 - k] = (k == 0 && lead) ? (v & (0xffffffffu >> lead)) : v;
+  }
 }
 
 enum : uint32_t { PK_OTHER = 0, PK_RSA = 1, PK_RSA_OAEP = 2, PK_DSA = 3, PK_EC = 4 };
@@ -299,16 +326,27 @@ CTMR_HD uint32_t spki_algorithm(const R& r, uint32_t L, const AlgView& a) {
   return alg;
 }
 
-// The far reads of the common case, issued before the walk's next window fill and looked at behind it (their round
-// trip hides behind the fill's): an RSA key's publicExponent — its TLV starts where the modulus ends.
+// What phase 1 leaves for phase 2 (the walk fills its next window in between).  An RSA key's publicExponent — its TLV
+// starts where the modulus ends, ~0.3 KB behind everything the window holds — is read in phase 2, out of the sixteen
+// octets around the key's end that a windowed reader fetches together with that next window (no round trip of its own).
 struct KeyPending {
   uint32_t alg;        // PK_*; PK_OTHER also stands for "nothing left to check"
   uint32_t c0, ek, shift;
   uint32_t e_pos;      // RSA: where the publicExponent's TLV starts; seq_end in e_end
   uint32_t e_end;
-  uint32_t e0, e1, e2; // RSA, shift == 0: the 12 octets at e_pos
-  bool pre;            // e0..e2 are valid
+  uint32_t k_at, k0, k1, k2, k3;  // sixteen octets of the certificate from k_at on, fetched with the walk's tail (key_tail_of)
+  bool pre;            // … are valid
 };
+
+// Readers that fetch the octets around the key's end together with their next window (kernels/readers.h WinReaderS::
+// touch_tail) hand them over here; for the others the exponent is read where it lies.
+template <class R, class = void>
+struct has_key_tail : std::false_type {};
+template <class R>
+struct has_key_tail<R, std::void_t<decltype(std::declval<const R&>().key_tail(0u))>> : std::true_type {};
+
+template <class R>
+CTMR_HD void key_tail_of(const R& r, uint32_t q, KeyPending& kp);  // (defined behind KeyPending's users)
 
 // Phase 1 — behind the SubjectPublicKeyInfo's own checks, with the window on its first octets.  [ck, ek) = the BIT
 // STRING's content (ck = the pad octet, already validated by bit_string_check).
@@ -321,7 +359,7 @@ CTMR_HD void spki_key_begin(const R& r, uint32_t L, const AlgView& a, uint32_t c
   kp.ek = ek;
   kp.shift = 0u;
   kp.e_pos = kp.e_end = 0u;
-  kp.e0 = kp.e1 = kp.e2 = 0u;
+  kp.k_at = kp.k0 = kp.k1 = kp.k2 = kp.k3 = 0u;
   if (!ok) return;
   const uint32_t alg = spki_algorithm(r, L, a);
   if (alg == PK_OTHER) return;
@@ -341,13 +379,15 @@ CTMR_HD void spki_key_begin(const R& r, uint32_t L, const AlgView& a, uint32_t c
     nf = (n_sign <= 0) ? (nf | WALK_NF_SPKI) : nf;  // "x509: RSA modulus is not a positive number"
     kp.e_pos = n_end;
     kp.e_end = se;
-    if (ok & (kp.shift == 0u)) {
-      const uint32_t p = n_end < L ? n_end : L;
-      kp.e0 = v.r.ld4(p);
-      kp.e1 = v.r.ld4(p + 4u);
-      kp.e2 = v.r.ld4(p + 8u);
-      kp.pre = true;
-    }
+  }
+}
+
+template <class R>
+CTMR_HD void key_tail_of(const R& r, uint32_t q, KeyPending& kp) {
+  if constexpr (has_key_tail<R>::value) {
+    const auto t = r.key_tail(q);
+    kp.pre = t.valid & (kp.shift == 0u);
+    kp.k_at = t.at; kp.k0 = t.w[0]; kp.k1 = t.w[1]; kp.k2 = t.w[2]; kp.k3 = t.w[3];
   }
 }
 
@@ -432,7 +472,7 @@ CTMR_HD void spki_key_finish(const R& r, uint32_t L, const AlgView& a, const Key
   if (!ok | (kp.alg == PK_OTHER)) return;
   const SpkiView<KeyReaderOf<R>> v{key_reader_of(r), kp.c0, kp.shift};
   if ((kp.alg == PK_RSA) | (kp.alg == PK_RSA_OAEP)) {
-    const SpkiView<KeyReaderOf<R>> ev{key_reader_of(r), kp.c0, kp.shift, kp.e_pos < L ? kp.e_pos : L, kp.e0, kp.e1, kp.e2, kp.pre};
+    const SpkiView<KeyReaderOf<R>> ev{key_reader_of(r), kp.c0, kp.shift, kp.k_at, kp.k0, kp.k1, kp.k2, kp.k3, kp.pre};
     uint32_t e_after, e_len;
     int e_sign;
     key_integer(ev, L, kp.e_pos, kp.e_end, ok, nf, e_after, e_sign, e_len);

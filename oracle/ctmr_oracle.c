@@ -201,9 +201,28 @@ static int check_int32(const uint8_t* d, uint64_t content, uint32_t len) {
   return c;
 }
 
-/* parseObjectIdentifier, as far as it is modelled: non-empty and the last octet ends an arc. */
+/* Go asn1 parseObjectIdentifier: non-empty, and every base-128 integer of it (parseBase128Int) at most 5 octets long, not
+ * led by 0x80 ("integer is not minimally encoded"), at most 2^31 - 1 ("base 128 integer too large") and complete
+ * ("truncated base 128 integer").  Round 4 (scripts/diff_openssl.py: OpenSSL rejects a 0x80-led arc as well — "invalid
+ * object encoding"); before, only the last octet was looked at. */
 static int oid_ok(const uint8_t* d, uint64_t content, uint32_t len) {
-  return len != 0 && (d[content + len - 1] & 0x80) == 0;
+  if (len == 0) return 0;
+  uint32_t i = 0;
+  while (i < len) {
+    uint64_t v = 0;
+    uint32_t k = 0;
+    for (;;) {
+      if (i >= len) return 0;               /* truncated */
+      if (k == 5) return 0;                 /* too large */
+      uint8_t b = d[content + i++];
+      if (k == 0 && b == 0x80) return 0;    /* not minimally encoded */
+      v = (v << 7) | (b & 0x7f);
+      k++;
+      if (!(b & 0x80)) break;
+    }
+    if (v > 0x7fffffffu) return 0;
+  }
+  return 1;
 }
 
 /* parseBitString on contents [c, c+len) */
@@ -299,7 +318,7 @@ static int string_findings(const uint8_t* s, uint32_t n, uint32_t tag) {
 }
 
 static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint32_t* cn_off, uint32_t* cn_len,
-                        int* site_out, int site, int32_t* sfind) {
+                        int* site_out, int site, int32_t* sfind, int32_t* nfind) {
   if (!rd_tlv(d, p, end, t) || t->tag != 0x30) FAIL0(site);
   uint64_t r = p + t->hl, r_end = r + t->len;
   while (r < r_end) {
@@ -314,6 +333,23 @@ static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint
       uint64_t vpos = b + oid.hl + oid.len;
       if (!rd_tlv(d, vpos, b_end, &val)) FAIL0(site + 4);  /* ANY: must be there and fit; anything behind it is ignored */
       *sfind |= string_findings(d + vpos + val.hl, val.len, val.tag);
+      { /* Value interface{}: a universal primitive INTEGER / BIT STRING / OBJECT IDENTIFIER / UTCTime / GeneralizedTime is
+         * decoded (parseInt64, parseBitString, parseObjectIdentifier, parseUTCTime, parseGeneralizedTime) and fails the Name
+         * when it does not parse; a not minimally encoded INTEGER is what the lax re-parse accepts (round 4) */
+        uint64_t vc = vpos + val.hl;
+        if (val.tag == 0x02) {
+          int ci = check_integer(d, vc, val.len);
+          if (ci == 0 || val.len > 8) FAIL0(site + 5);
+          if (ci < 0) *nfind |= ORC_NF_LAX_INTEGER;
+        } else if (val.tag == 0x03) {
+          if (!bit_string_ok(d, vc, val.len)) FAIL0(site + 5);
+        } else if (val.tag == 0x06) {
+          if (!oid_ok(d, vc, val.len)) FAIL0(site + 5);
+        } else if (val.tag == 0x17 || val.tag == 0x18) {
+          int64_t unused;
+          if (!parse_time(d, &val, vc, &unused)) FAIL0(site + 5);
+        }
+      }
       if (cn_off && oid.len == 3 && d[b + oid.hl] == 0x55 && d[b + oid.hl + 1] == 0x04 &&
           d[b + oid.hl + 2] == 0x03 && is_string_tag(val.tag)) {
         *cn_off = (uint32_t)(vpos + val.hl);
@@ -608,7 +644,7 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
   if (!alg_id(d, q, tbs_end, &t, &site, 11)) FAIL(site);
   q += t.hl + t.len;
   /* issuer Name (asn1.RawValue, then asn1.Unmarshal into pkix.RDNSequence) */
-  if (!rdn_sequence(d, q, tbs_end, &t, &out->cn_off, &out->cn_len, &site, 50, &out->string_findings)) FAIL(site);
+  if (!rdn_sequence(d, q, tbs_end, &t, &out->cn_off, &out->cn_len, &site, 50, &out->string_findings, &out->nonfatal)) FAIL(site);
   out->issuer_off = (uint32_t)q;
   out->issuer_len = t.hl + t.len;
   q += t.hl + t.len;
@@ -625,7 +661,7 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
   }
   q += t.hl + t.len;
   /* subject Name: same structure; no field of it is consumed */
-  if (!rdn_sequence(d, q, tbs_end, &t, NULL, NULL, &site, 60, &out->string_findings)) FAIL(site);
+  if (!rdn_sequence(d, q, tbs_end, &t, NULL, NULL, &site, 60, &out->string_findings, &out->nonfatal)) FAIL(site);
   q += t.hl + t.len;
   /* subjectPublicKeyInfo: full TLV = RawSubjectPublicKeyInfo (types.go:109-115);
    * publicKeyInfo ::= SEQUENCE { algorithm AlgorithmIdentifier, publicKey BIT STRING } */

@@ -43,17 +43,22 @@ SITES = {
     91: "DSA param <= 0", 92: "EC params not an OID", 93: "EC unknown curve", 94: "EC point",
 }
 
-EXPLAINED = {}   # filled in below, bucket key → (who is closer to Go, and why)
+from scripts.diff_openssl_explained import a_rule, B_RULES  # noqa: E402
+
+PK_OIDS = {bytes.fromhex("2a864886f70d010101"): "rsa", bytes.fromhex("2a864886f70d010107"): "rsa",
+           bytes.fromhex("2a8648ce380401"): "dsa", bytes.fromhex("2a8648ce3d0201"): "ec"}
 
 
-def X(key, text):
-    EXPLAINED[key] = text
-
-
-def load_explanations():
-    # imported late so that the table can sit at the end of the file, behind the code that uses it
-    from scripts.diff_openssl_explained import fill
-    fill(X)
+def key_class(der, o):
+    """How the oracle's parsePublicKey saw the key of a certificate it accepted: unknown-alg / finding / plain."""
+    sp = der[o.spki_off:o.spki_off + o.spki_len]
+    i = sp.find(b"\x06")
+    alg = PK_OIDS.get(sp[i + 2:i + 2 + sp[i + 1]]) if 0 <= i < 12 else None
+    if alg is None:
+        return "unknown-alg"
+    if o.nonfatal & orc.NF_SPKI:
+        return "finding"
+    return alg
 
 
 def seeds():
@@ -76,16 +81,72 @@ def seeds():
     return out
 
 
-def bucket_of(o, v):
-    """None when the two agree; else the bucket key."""
+def bucket_of(der, o, v):
+    """None when the two agree; else (direction, rule, status, text-or-None, raw) — raw = what to print when no rule matches."""
     o_ok = bool(o.ok)
     s_ok = v.stage == 0
     if o_ok == s_ok:
         return None
     if o_ok:
+        stage = {1: "d2i", 2: "trailing", 3: "pubkey", 4: "time", 5: "ext"}[v.stage]
         r = v.reason.decode()
-        return ("A", {1: "d2i", 2: "trailing", 3: "pubkey", 4: "time", 5: "ext"}[v.stage] + (":nid%d" % v.ext_nid if v.stage == 5 else ""), r)
-    return ("B", SITES.get(o.err_site, "site %d" % o.err_site), "")
+        sub = ""
+        if stage == "pubkey":
+            sub = key_class(der, o)
+            if sub in ("rsa", "dsa", "ec"):
+                sub = "trailing-in-struct" if pubkey_has_trailing(der, o) else "other"
+        if stage == "ext":
+            stage = "ext:%s" % ext_name(v.ext_nid)
+        hit = a_rule(stage, r, sub)
+        raw = "%s | %s %s" % (stage, r, sub)
+        return ("A",) + (hit if hit else (raw, None, None))
+    site = SITES.get(o.err_site, "site %d" % o.err_site)
+    hit = B_RULES.get(site)
+    return ("B", site) + (hit if hit else (None, None))
+
+
+def pubkey_has_trailing(der, o):
+    """An RSA key with octets behind the exponent inside RSAPublicKey / a DSA parameter set with a fourth element."""
+    try:
+        sp = der[o.spki_off:o.spki_off + o.spki_len]
+        c = orc.parse_cert(der, strict_spki=False)
+        # walk RSAPublicKey by hand: BIT STRING content behind the AlgorithmIdentifier
+        def hdr(b, p):
+            ln = b[p + 1]
+            if ln < 0x80:
+                return p + 2, p + 2 + ln
+            k = ln & 0x7f
+            return p + 2 + k, p + 2 + k + int.from_bytes(b[p + 2:p + 2 + k], "big")
+        s0, _ = hdr(sp, 0)
+        a0, a1 = hdr(sp, s0)
+        b0, b1 = hdr(sp, a1)
+        key = sp[b0 + 1:b1]
+        if sp.find(bytes.fromhex("2a864886f70d0101")) >= 0:
+            q0, q1 = hdr(key, 0)
+            n0, n1 = hdr(key, q0)
+            e0, e1 = hdr(key, n1)
+            return e1 < q1
+        if sp.find(bytes.fromhex("2a8648ce380401")) >= 0:
+            p0, p1 = hdr(sp, a0 + 2 + sp[a0 + 1])
+            x = p0
+            for _ in range(3):
+                _, x = hdr(sp, x)
+            return x < p1
+    except Exception:
+        pass
+    return False
+
+
+_EXT = {}
+
+
+def ext_name(nid):
+    names = {82: "subjectKeyIdentifier", 83: "keyUsage", 85: "subjectAltName", 86: "issuerAltName", 87: "basicConstraints",
+             88: "crlNumber", 89: "certificatePolicies", 90: "authorityKeyIdentifier", 103: "crlDistributionPoints",
+             126: "extKeyUsage", 177: "authorityInfoAccess", 666: "nameConstraints", 747: "policyMappings",
+             401: "policyConstraints", 430: "holdInstructionCode", 140: "deltaCRL", 857: "freshestCRL", 748: "inhibitAnyPolicy",
+             71: "netscapeCertType", 72: "nsBaseUrl", 78: "nsComment", 951: "ctPrecertSCTs", 952: "ctPrecertPoison"}
+    return names.get(nid, "nid%d" % nid)
 
 
 def main():
@@ -112,7 +173,7 @@ def main():
             der = mutate(rng, der)
         o = orc.parse_cert(der)
         v = harness.ossl_verdict(der)
-        b = bucket_of(o, v)
+        b = bucket_of(der, o, v)
         if b is None:
             if o.ok:
                 agree_acc += 1
@@ -122,20 +183,21 @@ def main():
         buckets[b] += 1
         if b not in example or len(der) < len(example[b]):
             example[b] = der
-    try:
-        load_explanations()
-    except ImportError:
-        pass
     print("# differential accept/reject campaign: oracle (= product, bit for bit) vs OpenSSL %s" % "3")
     print("# %d mutants (seed %d) of %d seed certificates, %.0f s; both accept %d, both reject %d, disagree %d in %d buckets"
           % (total, seed, len(sd), time.time() - t0, agree_acc, agree_rej, sum(buckets.values()), len(buckets)))
     print("# A = the oracle accepts what OpenSSL rejects; B = the oracle rejects what OpenSSL accepts")
     unexplained = 0
+    by_status = collections.Counter()
     for b, n in sorted(buckets.items(), key=lambda kv: (kv[0][0], -kv[1])):
-        why = EXPLAINED.get(b) or EXPLAINED.get(b[:2])
-        if not why:
+        direction, rule, status, text = b[0], b[1], b[2], b[3]
+        if status is None:
             unexplained += 1
-        print("%s | %-28s | %-40s | %7d | %s" % (b[0], b[1], b[2], n, why or "UNEXPLAINED  example: " + example[b].hex()[:600]))
+            print("%s | %-52s | %7d | UNEXPLAINED  example: %s" % (direction, rule, n, example[b].hex()[:1200]))
+        else:
+            by_status[direction, status] += n
+            print("%s | %-52s | %7d | %-8s | %s" % (direction, rule, n, status, text))
+    print("# by status: " + ", ".join("%s/%s %d" % (k[0], k[1], v) for k, v in sorted(by_status.items())))
     print("# unexplained buckets: %d" % unexplained)
     sys.exit(1 if unexplained else 0)
 

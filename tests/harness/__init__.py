@@ -81,6 +81,14 @@ def product_set_spki(on: bool):
     _walk.harness_set_spki(int(bool(on)))
 
 
+def product_ec_point_bits(buf: bytes, xbit: int, curve: int) -> bool:
+    """k_ec_resolve's loader + curve equation (host build): X starts at BIT xbit of buf; curve 1..5 = P-256, P-384, P-521,
+    P-224, secp192r1."""
+    product_walk(b"\x30\x00")
+    _walk.harness_ec_point_bits.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_int]
+    return bool(_walk.harness_ec_point_bits(buf, len(buf), xbit, curve))
+
+
 def product_walk_tbs(tbs: bytes, fill=0xA5) -> HarnessOut:
     """The product's walk over a bare TBSCertificate (strict_leaf)."""
     product_walk(b"\x30\x00")          # builds and binds the library

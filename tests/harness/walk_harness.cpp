@@ -159,3 +159,23 @@ extern "C" int harness_walk_touched(const uint8_t* der, uint32_t len, uint32_t p
   *lines128 = nl;
   return ok;
 }
+
+// k_ec_resolve's loader + equation on the host: the point whose X starts at BIT `xbit` of buf (RightAlign as a bit offset)
+extern "C" int harness_ec_point_bits(const uint8_t* buf, uint32_t len, uint64_t xbit, int curve) {
+  std::vector<uint32_t> w((len + 3) / 4 + 40, 0xa5a5a5a5u);
+  memcpy(w.data(), buf, len);
+  auto run = [&](auto tag) {
+    using C = decltype(tag);
+    uint32_t x[C::NL], y[C::NL];
+    ctmr::fe_load_bits<C>(w.data(), xbit, x);
+    ctmr::fe_load_bits<C>(w.data(), xbit + 8ull * C::BYTES, y);
+    return (int)ctmr::ec_equation<C>(x, y);
+  };
+  switch (curve) {
+    case 1: return run(ctmr::CurveP256{});
+    case 2: return run(ctmr::CurveP384{});
+    case 3: return run(ctmr::CurveP521{});
+    case 4: return run(ctmr::CurveP224{});
+    default: return run(ctmr::CurveP192{});
+  }
+}

@@ -211,6 +211,28 @@ def test_ec_keys_on_every_curve():
     assert verdict(cert(ec_spki("P256", bytes(64))))[0] is False
 
 
+def test_the_resolve_kernels_bit_offset_loader():
+    """k_ec_resolve reads a pending point straight out of the payload as aligned dwords + funnel shifts, X starting at bit
+    8·position − pad count: every curve, every byte phase, every pad count; one flipped bit anywhere in the point fails."""
+    rng = random.Random(11)
+    for cid, curve in enumerate(("P256", "P384", "P521", "P224", "P192"), start=1):
+        bl = CURVES[curve][1]
+        pt = point(curve, 0x1234567 + cid)
+        for phase in range(4):
+            for shift in range(8):
+                pre = bytes(rng.randrange(256) for _ in range(9 + phase))
+                v = int.from_bytes(pt, "big") << shift                      # RightAlign undoes this
+                body = v.to_bytes(2 * bl + 1, "big")
+                lead = bytes([pre[-1] & (0xff << shift) & 0xff | body[0]])    # the pad bits' neighbours: other key octets
+                buf = pre[:-1] + lead + body[1:] + bytes(rng.randrange(256) for _ in range(7))
+                xbit = 8 * len(pre) - shift
+                assert harness.product_ec_point_bits(buf, xbit, cid), (curve, phase, shift)
+                bad = bytearray(buf)
+                at = len(pre) + rng.randrange(2 * bl - 1)
+                bad[at] ^= 1 << rng.randrange(1, 7)
+                assert not harness.product_ec_point_bits(bytes(bad), xbit, cid), (curve, phase, shift, at)
+
+
 def test_ec_parameters():
     good = bytes.fromhex(CURVES["P256"][0])
     for params, ok in ((D.tlv(0x06, good), True), (b"", False), (D.NULL, False), (D.tlv(0x06, good[:-1]), False),
