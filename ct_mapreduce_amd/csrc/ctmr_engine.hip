@@ -160,6 +160,8 @@ struct RoundCtx {
   std::vector<uint64_t> counts32;
   std::vector<KeyRec> xl;   // … those records, sorted by (owner, order)
   bool resolved = false;    // owner-computes round: ctmr_xchg_insert_device has run
+  bool own_counted = false; // the table was rebuilt between round_begin and round_collect: `occupied` (= the rebuild's live
+                            // count) already holds this shard's own claims — round_collect must not add them again
   // members with serials longer than CTMR_MAX_SERIAL that this batch added to the host-side set, in log order: a group
   // round settles them between the ranks afterwards (engine/group.inc: round_finish)
   struct HostNew { uint64_t i; int32_t exp_hour; uint32_t canon; std::string member; };

@@ -842,13 +842,9 @@ __device__ __forceinline__ unsigned long long block_exclusive_256(unsigned long 
 __global__ void __launch_bounds__(256) k_scan64_tiles(const unsigned long long* data, uint64_t n, unsigned long long* tile_sum) {
   const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 16u;
   unsigned long long s = 0;
-  if (i0 + 16 <= n) {
-    const ulonglong2* p = (const ulonglong2*)(data + i0);
+  if (i0 + 16 <= n) {  // (8-byte loads: every caller passes an array + 1 — 8-byte, not 16-byte aligned)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const ulonglong2 v = p[k];
-      s += v.x + v.y;
-    }
+    for (int k = 0; k < 16; k++) s += data[i0 + k];
   } else {
     for (uint64_t i = i0; i < n && i < i0 + 16; i++) s += data[i];
   }

@@ -235,7 +235,10 @@ int ctmr_reset_known(ctmr_engine* e);
 
 /* One rank's input of a multi-GPU round (ctmr_group_map_batch, ctmr_xchg_map_device): device pointers on that rank's
  * GPU, as ctmr_map_batch_device takes them; d_ends != NULL: an entry view (d_offsets = cert_start, d_ends = cert_end,
- * blob_bytes set).  order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown). */
+ * blob_bytes set).  order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown).  The
+ * shards of one round must cover DISJOINT order ranges [order_base, order_base + n): two ranks that present the same new
+ * key under the same order both keep WasUnknown (nothing tells them apart) — a host that leaves every order_base at 0 has
+ * asked for that. */
 typedef struct {
   const uint8_t* d_payload;
   const uint64_t* d_offsets;
@@ -373,7 +376,9 @@ void ctmr_group_destroy(ctmr_group* g);
 const char* ctmr_group_last_error(const ctmr_group* g);
 int ctmr_group_info(ctmr_group* g, ctmr_group_stats* out);
 /* bits per rank: power of two, ≈16 per key a rank will ever hold; same on every rank.  (A group of ONE rank has no peer
- * to ask: it keeps no filter and its Bloom rounds are the plain reduce.) */
+ * to ask: it keeps no filter and its Bloom rounds are the plain reduce.)  * One mode per group: the first round's mode is the only one the group accepts afterwards (CTMR_E_INVAL otherwise) — the
+ * modes keep a key in different places and cannot see each other's.
+ */
 int ctmr_group_bloom_config(ctmr_group* g, uint64_t bits);
 int ctmr_group_map_batch(ctmr_group* g, int mode, const ctmr_shard* shards, ctmr_batch_stats* stats);
 /* Σ over ALL ranks of ctmr_issuer_counts / ctmr_total_count (storage-statistics.go:44-53 over the whole deployment):

@@ -28,6 +28,8 @@ A_RULES = [
      "INTEGER not minimally encoded: only CT-go's lax re-parse accepts it — non-fatal finding WALK_NF_LAX_INTEGER"),
     ("d2i", r"(wrong tag|header too long|too long|explicit tag not constructed|unexpected eoc|type not constructed) @ Field=extensions", "go-rule",
      "[3] whose inner element is not a SEQUENCE (the optional field stays unset: no extensions) or whose length overruns: Go only requires the inner header to parse and the inner element to fit the TBSCertificate"),
+    ("d2i", r"(wrong tag|too long|header too long|type not constructed|unexpected eoc|sequence not constructed|illegal padding|boolean is wrong length|invalid object encoding) @ (Field=\w+, )?Type=X509_EXTENSION", "go-rule",
+     "[3] whose inner element carries tag 0x10 (SEQUENCE without the constructed bit): not a SEQUENCE to Go — the optional field stays unset and the octets are never looked at; OpenSSL matches the tag number alone and parses them as Extensions"),
     ("d2i", r"mstring (not universal|wrong tag)", "go-rule",
      "AttributeTypeAndValue.Value is `interface{}`: any well-formed TLV that fits is accepted (a non-universal or constructed value is left nil); OpenSSL wants a DirectoryString-like type"),
     ("d2i", r"@ Field=parameter, Type=X509_ALGOR", "go-rule",
