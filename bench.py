@@ -333,6 +333,178 @@ def group_id_from_launcher(rank, make_id):
     return box[0]
 
 
+class WriteBack:
+    """BASELINE configs[4]'s other half: what FilesystemDatabase.Store does behind WasUnknown (storage/filesystemdatabase.go:
+    183-208) for every wave of the stream — IssuerMetadata.Accumulate's first sightings (k_meta_new over the NEW list), the
+    PEM block of every new certificate (k_pem_encode, in chunks of the NEW list) and backend.StoreCertificatePEM +
+    markDirty through the C++ restatement of the reference's backends (ct_mapreduce_amd/host_writeback.py).
+    noop: the reference with certPath unset — the PEM bytes are produced (pem.EncodeToMemory runs before the backend is asked)
+    and dropped on the device.  disk: device → pinned host → LocalDiskBackend files, two chunks in flight: the GPU goes on
+    with the next chunk / wave while the host writes; when it must wait for the host, that time is the STALL."""
+    CHUNK = 8_000_000
+
+    def __init__(self, args, eng, synth, cfg, torch, np, dev, Wr, rank, filt, now, N):
+        import tempfile
+        from ct_mapreduce_amd.host_writeback import HostWriter
+        self.torch, self.np, self.eng, self.dev, self.synth, self.cfg, self.N = torch, np, eng, dev, synth, cfg, N
+        self.filt, self.now, self.rank = filt, now, rank
+        self.disk = args.write_back == "disk"
+        self.ch = min(Wr, self.CHUNK)
+        self.pem_cap = self.ch * 2900 + 4096
+        nbuf = 2 if self.disk else 1
+        self.d_pem = [torch.empty(self.pem_cap, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        self.d_pemoff = [torch.empty(self.ch + 1, dtype=torch.int64, device=dev) for _ in range(nbuf)]
+        self.d_items = torch.empty(32 * (1 << 20), dtype=torch.uint8, device=dev)
+        self.root = self.cwd0 = None
+        if self.disk:
+            base = args.write_back_dir or tempfile.mkdtemp(prefix="ctmr_wb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            self.root = os.path.join(base, "certs%d" % rank)
+            os.makedirs(self.root, exist_ok=True)
+            # LocalDiskBackend.MarkDirty writes <day>/dirty relative to the CURRENT directory (localdiskbackend.go:89-91)
+            self.cwd0 = os.getcwd()
+            self.dirty_dir = os.path.join(base, "cwd%d" % rank)
+            os.makedirs(self.dirty_dir, exist_ok=True)
+            os.chdir(self.dirty_dir)
+            self.h_pem = [torch.empty(self.pem_cap, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self.h_off = [torch.empty(self.ch + 1, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+            self.h_rec = [torch.empty(self.ch * 32, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        n_iss = len(synth.issuers(cfg))
+        self.writer = HostWriter(self.root, [eng.issuer_id(k) for k in range(n_iss)], args.write_back_threads)
+        self.jobs = [None, None]
+        self.turn = 0
+        self.files = self.pem_bytes = self.skipped = self.meta_items = self.new_total = 0
+        self.t_stall = self.t_meta = self.t_pem = self.t_host_busy = 0.0
+        self.check = None
+        self.days = set()
+
+    def _retire(self, b):
+        if self.jobs[b] is not None:
+            t0 = time.perf_counter()
+            f, by, sk, sec = self.writer.wait(self.jobs[b])
+            self.t_stall += time.perf_counter() - t0
+            self.files += f; self.pem_bytes += by; self.skipped += sk; self.t_host_busy += sec
+            self.jobs[b] = None
+
+    def wave(self, k, first, n, n_new, d_pay, d_off, d_iss, d_et, d_rec, d_new):
+        torch = self.torch
+        self.new_total += n_new
+        if n_new:
+            t0 = time.perf_counter()
+            self.meta_items += self.eng.meta_new_device(d_pay.data_ptr(), d_off.data_ptr(), 0, d_rec.data_ptr(), d_new.data_ptr(),
+                                                        n_new, self.d_items.data_ptr(), 1 << 20)
+            torch.cuda.synchronize()
+            self.t_meta += time.perf_counter() - t0
+        recs = d_rec.view(-1, 32)[:n]
+        if self.disk and n:     # markDirty: every entry that reached Store marks its day (filesystemdatabase.go:204-208)
+            hours = recs[recs[:, 0] == 0][:, 4:8].contiguous().view(torch.int32).view(-1)
+            days = torch.unique(torch.div(hours, 24, rounding_mode="floor")).tolist()
+            fresh = [d for d in days if d not in self.days]
+            self.days.update(fresh)
+            if fresh:
+                self.writer.mark_dirty(fresh)
+        for c in range(0, n_new, self.ch):
+            m = min(self.ch, n_new - c)
+            b = self.turn
+            self._retire(b)                       # the buffers of two chunks ago are free again (disk) / nothing (noop)
+            t0 = time.perf_counter()
+            nbytes = self.eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_new.data_ptr() + 8 * c, m,
+                                                self.d_pem[b % len(self.d_pem)].data_ptr(), self.pem_cap,
+                                                self.d_pemoff[b % len(self.d_pemoff)].data_ptr())
+            torch.cuda.synchronize()
+            self.t_pem += time.perf_counter() - t0
+            if not self.disk:
+                self.files += m; self.pem_bytes += nbytes     # NoopBackend.StoreCertificatePEM: nothing to do with them
+                continue
+            idx = d_new[c:c + m]
+            self.h_rec[b][:m * 32].copy_(d_rec.view(-1, 32)[idx].reshape(-1), non_blocking=True)
+            self.h_off[b][:m + 1].copy_(self.d_pemoff[b][:m + 1], non_blocking=True)
+            self.h_pem[b][:nbytes].copy_(self.d_pem[b][:nbytes], non_blocking=True)
+            torch.cuda.synchronize()
+            self.jobs[b] = self.writer.submit(self.h_pem[b].data_ptr(), self.h_off[b].data_ptr(), self.h_rec[b].data_ptr(), m)
+            self.turn ^= 1
+        if self.disk and k == 0 and self.check is None:
+            self._retire(0); self._retire(1)
+            t0 = time.perf_counter()
+            self.check = self._check_wave0(first, n, n_new, d_pay, d_off, d_iss, d_et)
+            return time.perf_counter() - t0       # the checker's time is not the product's
+        return 0.0
+
+    def _check_wave0(self, first, n, n_new, d_pay, d_off, d_iss, d_et):
+        """The files on disk after wave 0 = the oracle's NEW set of wave 0: same paths, same bytes (every file when there
+        are at most 300 000, else 20 000 of them)."""
+        from oracle import oracle as orc
+        np = self.np
+        t0 = time.perf_counter()
+        off = d_off[:n + 1].cpu().numpy().astype(np.uint64)
+        pay = d_pay[:int(off[n]) + self.N.PAYLOAD_PAD].cpu().numpy()
+        iss = d_iss[:n].cpu().numpy().astype(np.uint32)
+        et = d_et[:n].cpu().numpy()
+        issuers = self.synth.issuers(self.cfg)
+        io = np.zeros(len(issuers) + 1, np.uint64)
+        io[1:] = np.cumsum([len(x) for x in issuers])
+        o = orc.Engine(self.filt, False, self.now)
+        st, unk, eh = o.batch(pay, off, iss, np.frombuffer(b"".join(issuers), np.uint8), io, entry_type=et)
+        want = {}
+        ids = [self.eng.issuer_id(k) for k in range(len(issuers))]
+        import base64
+        for i in np.nonzero(unk)[0]:
+            der = pay[int(off[i]):int(off[i + 1])].tobytes()
+            c = orc.parse_cert(der)
+            serial = der[c.serial_off:c.serial_off + c.serial_len]
+            want[os.path.join(orc.exp_date_id(int(eh[i])), ids[int(iss[i])], base64.urlsafe_b64encode(serial).decode())] = int(i)
+        have = set()
+        for dp, _, fs in os.walk(self.root):
+            rel = os.path.relpath(dp, self.root)
+            have.update(os.path.join(rel, f) for f in fs)
+        same_paths = have == set(want)
+        paths = sorted(want)
+        if len(paths) > 300_000:
+            paths = paths[::max(1, len(paths) // 20_000)]
+        bad = 0
+        for pth in paths:
+            i = want[pth]
+            try:
+                bad += open(os.path.join(self.root, pth), "rb").read() != orc.pem_encode(pay[int(off[i]):int(off[i + 1])].tobytes())
+            except OSError:
+                bad += 1
+        dirty = sorted(os.listdir(self.dirty_dir))
+        want_days = sorted({orc.day_id(int(orc.parse_cert(pay[int(off[i]):int(off[i + 1])].tobytes()).not_after))
+                            for i in np.nonzero(st == 0)[0][::max(1, int((st == 0).sum()) // 5000)]})
+        return {"wave": 0, "entries": int(n), "oracle_new": int(unk.sum()), "gpu_new": int(n_new), "files_on_disk": len(have),
+                "paths_equal_the_oracles_new_set": bool(same_paths), "files_compared_bytewise": len(paths),
+                "files_differing": int(bad), "dirty_markers_cover_the_sampled_days": bool(set(want_days) <= set(dirty)),
+                "seconds": round(time.perf_counter() - t0, 1)}
+
+    def finish(self):
+        self._retire(0); self._retire(1)
+
+    def report(self, wall, t_timed):
+        if self.cwd0:
+            os.chdir(self.cwd0)
+        self.writer.close()
+        ok = self.files + self.skipped == self.new_total and (self.check is None or (
+            self.check["paths_equal_the_oracles_new_set"] and self.check["files_differing"] == 0 and
+            self.check["oracle_new"] == self.check["gpu_new"] and self.check["dirty_markers_cover_the_sampled_days"]))
+        out = {"backend": "LocalDiskBackend" if self.disk else "NoopBackend", "new_certificates": self.new_total,
+               "files_handed_to_the_backend": self.files, "long_serials_left_to_the_host_parse": self.skipped,
+               "pem_bytes": self.pem_bytes, "pem_GB_per_s_of_the_encode_kernels": self.pem_bytes / max(self.t_pem, 1e-9) / 1e9,
+               "ms_meta_total": self.t_meta * 1e3, "ms_pem_total": self.t_pem * 1e3,
+               "meta_first_sightings": self.meta_items, "ok": bool(ok)}
+        if self.disk:
+            out.update({"root": self.root, "host_threads": self.writer.threads,
+                        "host_files_per_s": self.files / max(self.t_host_busy, 1e-9),
+                        "host_busy_s": self.t_host_busy, "stall_s_waiting_for_the_host": self.t_stall,
+                        "stall_fraction_of_the_timed_region": self.t_stall / max(t_timed, 1e-9),
+                        "check_wave0_vs_oracle": self.check,
+                        "note": "device → pinned host copies of PEM bytes are inside the timed region (PCIe-inclusive by nature); "
+                                "the host writer runs while the GPU maps the next chunk / wave, the GPU waits only when both "
+                                "host buffers are still being written"})
+        else:
+            out["note"] = ("storage.NoopBackend ignores the PEM bytes: they are encoded on the GPU (the reference runs "
+                           "pem.EncodeToMemory before it asks the backend) and never copied to the host")
+        return out
+
+
 def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, filt, now, issuers, gid=None):
     """BASELINE configs[4]: a long stream with 10 % duplicates, the known-certificate sets persisting across waves.  One GPU:
     one engine, one table.  N > 1: every wave is split by log-index range over the ranks and deduplicated GLOBALLY through
@@ -340,13 +512,15 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
     the north_star's variant); the sets persist on the ranks across the waves."""
     from ct_mapreduce_amd.distributed import Group, shard as make_shard, shard_range
     T = args.stream
-    W = min(args.entries or 50_000_000, T)              # entries per wave, over all ranks
+    wb = args.write_back
+    W = min(args.entries or (50_000_000 if not wb else 25_000_000 if wb == "noop" else 1_000_000), T)   # entries per wave, over all ranks
     cfg = synth.config(seed=20260921 + 5, n_issuers=args.issuers, zipf=1, dup_permille=100, ca_permille=10,
                        expired_permille=10)
     mode = "plain" if world == 1 else (args.dedup if args.dedup != "auto" else "owner")
     per_rank_keys = (T + world - 1) // world
     slots = min(pow2_at_least(int(per_rank_keys * 1.6)), 1 << 31)
-    eng = ctmr.Engine(device=local, table_slots=slots, pair_slots=1 << 22, map_variant=args.variant, profile=True)
+    eng = ctmr.Engine(device=local, table_slots=slots, pair_slots=1 << 22, map_variant=args.variant, profile=True,
+                      collect_meta=bool(wb))
     eng.add_issuers(synth.issuers(cfg))
     eng.set_filter(filt, False, now)
     group = None
@@ -368,6 +542,8 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
     ok = True
     waves = 0
     first = 0
+    wbs = WriteBack(args, eng, synth, cfg, torch, np, dev, Wr, rank, filt, now, N) if wb else None
+    t_wall0 = time.perf_counter()
     while first < T:
         n_wave = min(W, T - first)
         lo, hi = shard_range(n_wave, rank, world)
@@ -386,6 +562,8 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
         else:
             st = eng.map_batch_device(d_pay.data_ptr(), d_off.data_ptr(), d_iss.data_ptr(), d_et.data_ptr(), n,
                                       d_rec.data_ptr(), d_new.data_ptr())
+        if wbs is not None:   # FilesystemDatabase.Store behind WasUnknown, for the wave (filesystemdatabase.go:183-208)
+            t0 += wbs.wave(waves, first + lo, n, int(st.n_new), d_pay, d_off, d_iss, d_et, d_rec, d_new)
         t_gpu += time.perf_counter() - t0
         t_map += st.ms_map
         # the generator's structure: entry i duplicates an EARLIER entry's key iff synth_is_dup(i) — in this wave or
@@ -406,6 +584,13 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
         tot_bytes += int(st.payload_bytes) + ALG_BYTES_FIXED * n + ALG_BYTES_PROBE * int(st.by_status[0])
         first += n_wave
         waves += 1
+    wb_out = None
+    if wbs is not None:
+        t0 = time.perf_counter()
+        wbs.finish()
+        t_gpu += time.perf_counter() - t0
+        wb_out = wbs.report(time.perf_counter() - t_wall0, t_gpu)
+        ok = ok and wb_out["ok"]
     total_count = eng.total_count()
     if group is not None:
         # the slowest rank's time; the sums over the ranks; every rank must have matched the generator in every wave
@@ -418,7 +603,7 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
     # measured HBM traffic of the map kernel in this mode: a 40 M-entry stream in 4 waves of 10 M under rocprofv3 --pmc
     # (the table persists across the waves, as here; bytes per entry averaged over the launches)
     traffic_info = traffic_err = None
-    if world == 1 and args.traffic == "auto" and not os.environ.get("CTMR_BENCH_CHILD"):
+    if world == 1 and args.traffic == "auto" and not wb and not os.environ.get("CTMR_BENCH_CHILD"):
         kname = MAP_KERNELS[args.variant or DEFAULT_VARIANT].split("<")[0]
         traffic_info, traffic_err = measure_traffic(args, 10_000_000, [kname], ["--stream", "40000000"])
     out = {"metric": "certificates/sec whole-node + achieved HBM GB/s, 100M-entry synthetic CT batch",
@@ -441,6 +626,12 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
                       "duplicate_structure_matches_generator_in_every_wave": bool(ok)}}
     if group is not None:
         out["exchange"] = {"mode": mode, "transport": "rccl", "wire_bytes_sent_by_rank0_over_the_stream": wire}
+    if wb_out is not None:
+        out["write_back"] = wb_out
+        out["config"]["workload"] += (f"; WITH storage.Backend write-back ({wb}): IssuerMetadata first sightings, PEM of every new "
+                                      "certificate on the GPU, " + ("storage.NoopBackend" if wb == "noop" else
+                                      "storage.LocalDiskBackend through pinned host buffers and the native host writer") +
+                                      " — `value` counts the whole of it")
     if traffic_info:
         r = out["roofline"]
         r["traffic"] = traffic_info["traffic_bytes_per_cert"] * T          # over the whole stream
@@ -530,6 +721,15 @@ def main():
                          "all ranks), the known-certificate sets persisting across waves; with --gpus N every wave is split by "
                          "log index over the ranks and deduplicated through the group (--dedup, default owner); checks every "
                          "wave and every entry's WasUnknown against the generator's duplicate structure")
+    ap.add_argument("--write-back", choices=["noop", "disk"], default=None,
+                    help="with --stream: BASELINE configs[4] WHOLE — per wave, behind the map/reduce: IssuerMetadata first "
+                         "sightings (k_meta_new), PEM of the NEW list on the GPU (k_pem_encode) and the storage backend: "
+                         "noop = storage.NoopBackend (certPath unset: the PEM bytes are produced and dropped, nothing leaves "
+                         "the GPU), disk = storage.LocalDiskBackend on --write-back-dir (default: a fresh directory under "
+                         "/dev/shm or $TMPDIR) fed through pinned host buffers by the native host writer, double-buffered so "
+                         "that wave k's files are written while wave k+1 is mapped; wave 0's files are compared with the oracle")
+    ap.add_argument("--write-back-dir", default=None)
+    ap.add_argument("--write-back-threads", type=int, default=0, help="host writer threads (default: the cores, at most 32)")
     ap.add_argument("--mixed", action="store_true",
                     help="the mixed synthetic corpus (half EC P-256 keys, 40%% OV-like subjects of 120-260 bytes, longer "
                          "issuer names, one GeneralizedTime in four) instead of the SURVEY §8(d) corpus: how the map "
@@ -582,7 +782,9 @@ def main():
     args = ap.parse_args()
 
     if args.stream and (args.raw or args.global_dedup or args.meta or args.pem or args.fingerprint):
-        ap.error("--stream runs the plain map/reduce (with --gpus N: through the group)")
+        ap.error("--stream runs the plain map/reduce (with --gpus N: through the group); --write-back adds metadata + PEM + backend")
+    if args.write_back and not args.stream:
+        ap.error("--write-back belongs to --stream")
     if args.aligned and (args.raw or args.global_dedup or args.gpus > 1 or args.stream or args.pem or args.fingerprint or args.meta):
         ap.error("--aligned is a layout variant of the plain one-GPU line")
     if args.aligned & (args.aligned - 1):
