@@ -9,7 +9,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "host", "test_storage.cpp")
-HDRS = [os.path.join(ROOT, "include", "ctmr_storage.hpp"), os.path.join(ROOT, "include", "ctmr.h")]
+HDRS = [os.path.join(ROOT, "include", "ctmr_storage.hpp"), os.path.join(ROOT, "include", "ctmr.h"),
+        os.path.join(ROOT, "tests", "host", "ctmr_storage_mocks.hpp")]
 EXE = os.path.join(ROOT, "tests", "host", "test_storage.run")
 LIBDIR = os.path.join(ROOT, "ct_mapreduce_amd")
 
