@@ -21,8 +21,6 @@ struct MapArgs {
   uint32_t certs_per_tile;  // CTMR_SWEEP builds only (k_map_tile)
   uint32_t lds_bytes;       // dynamic LDS size of the launch (k_map_tile)
   uint2* meta_loc;          // null, or per entry (Walk.meta_issuer, Walk.meta_crl) for k_meta_new (config.collect_meta)
-  const uint8_t* nf_extra;  // null, or per entry: further non-fatal findings (WALK_NF_*) of a pre-pass — k_name_strings
-                            // (ctmr_set_strict_strings)
   unsigned long long* keypos;  // strict_spki: per entry, written ONLY for an entry whose EC key still owes the curve equation
                                // (keypos_pack; spki_key.h "where the curve equation runs") — k_ec_resolve reads it
   uint32_t optimistic_new;  // 1: PASS records leave the map with CTMR_FL_WAS_UNKNOWN already set — the
@@ -55,18 +53,13 @@ __device__ __forceinline__ unsigned long long keypos_pack(uint32_t pos, uint32_t
 // The fused kernel loads them BEFORE it waits for the certificate's bytes (k_map_fused), so that the two dependent
 // loads (issuer_idx → issuer_valid) are not two exposed round trips behind the walk.
 struct EntryIn {
-  uint32_t iss, et, nf_extra;
+  uint32_t iss, et;
   bool iss_in_range, iss_valid;
 };
 __device__ __forceinline__ EntryIn load_entry_in(const MapArgs& a, uint64_t idx) {
   EntryIn e;
   e.iss = a.issuer_idx[idx];
   e.et = a.entry_type ? a.entry_type[idx] : 0u;
-#ifdef CTMR_EXP_NO_NFX  // measurement build: what the (normally null) strict_strings pointer costs the default kernel
-  e.nf_extra = 0u;
-#else
-  e.nf_extra = a.nf_extra ? a.nf_extra[idx] : 0u;
-#endif
   e.iss_in_range = e.iss != CTMR_NO_ISSUER && e.iss < a.n_issuers;
   e.iss_valid = e.iss_in_range && a.issuer_valid[e.iss] != 0;
   return e;
@@ -80,12 +73,14 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   const FilterDev* f = a.filt;
   const FilterView fv{f->n_pieces, f->piece_len, f->piece_word, f->words};
   // L > 2^31-1 is rejected inside, without divergence.  EC_DEFER: an EC key's curve equation is k_ec_resolve's business
-  bool ok = walk_cert<R, false, false, true>(r, L, w, f->active != 0u, fv, (f->strict_spki != 0u) & (a.keypos != nullptr));
+  // strict_strings: only a precertificate can lose its place over a string finding (an X509 entry is kept, below)
   const uint32_t iss = in.iss, et = in.et;
+  bool ok = walk_cert<R, false, false, true>(r, L, w, f->active != 0u, fv, (f->strict_spki != 0u) & (a.keypos != nullptr),
+                                             (f->strict_strings != 0u) & (et == 1u));
   // An X509 entry's certificate was parsed by ct.LogEntryFromLeaf, which keeps it unless the error is fatal
   // (ct-fetch.go:452-459); a precertificate is parsed in insertCTWorker and dropped on ANY error, CT-go's
   // x509.NonFatalErrors included (:202-209).  Fields of a dropped certificate are not reported.
-  ok = ok & !((et == 1u) & ((w.nonfatal | in.nf_extra) != 0u));
+  ok = ok & !((et == 1u) & (w.nonfatal != 0u));
   uint32_t status;
   if (et == CTMR_ENTRY_INVALID) {
     status = CTMR_ST_ENTRY_DECODE_ERROR;  // never reached entryChan (ct-fetch.go:452-459)
@@ -145,31 +140,6 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   uint4* out = (uint4*)(a.records + idx);
   out[0] = o0;
   out[1] = o1;
-}
-
-// strict_strings (ctmr_set_strict_strings, opt-in): one certificate per lane through the same per-lane LDS windows as the
-// map (one wave-cooperative fill of the front 256 bytes: both Names lie there unless the subject is very long, and then the
-// reader fetches what is missing) — the walk up to the end of the subject Name, then the character sets of the string values
-// in both Names (der_walk.h name_strings_ok).  Runs before the map, which takes the finding as one more non-fatal one (a
-// precertificate is dropped, an X509 entry kept).  Costs a second pass over the front of every certificate: opt-in.
-__global__ void __launch_bounds__(64) k_name_strings(const uint8_t* payload, const uint64_t* offsets, const uint64_t* ends,
-                                                     uint64_t n, uint64_t limit, uint8_t* nf_extra) {
-  const uint32_t lane = threadIdx.x;
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
-  const bool live = i < n;
-  uint64_t lo = 0, hi = 0;
-  if (live) cert_range(offsets, ends, i, lo, hi);
-  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
-  if (!ends) limit = offsets[n] + CTMR_PAYLOAD_PAD;  // packed batch: what map_limit() gives the map
-  coop_fill<false>(payload, limit, g_me, lane);
-  if (!live) return;
-  WinReaderC<16> r{{(const uint32_t*)payload, lo, limit, (uint32_t*)(smem + win_off(lane)), (int32_t)(int64_t)(g_me - lo)}};
-  const uint64_t len64 = hi - lo;
-  const uint32_t L = len64 <= 0x7fffffffull ? (uint32_t)len64 : 0x80000000u;
-  Walk w;
-  const bool ok = walk_names(r, L, w);
-  const bool good = !ok || (name_strings_ok(r, L, w.issuer_name, L) && name_strings_ok(r, L, w.subject_name, L));
-  nf_extra[i] = good ? 0 : (uint8_t)WALK_NF_STRING;
 }
 
 // Record store for the one-wave-per-workgroup window kernels: the 64 records of the wave (2 KiB,

@@ -513,8 +513,9 @@ int ctmr_set_strict_spki(ctmr_engine* e, int on);
  * certificate-transparency-go's fork of that package is more lenient towards some of these — which, cannot be verified
  * without its source — so the rules are an OPT-IN (default 0: not checked, as in earlier versions) and a violation is
  * filed as a NON-FATAL finding: an X509 entry keeps its certificate, a precertificate and a Chain[0] issuer are
- * dropped (cmd/ct-fetch/ct-fetch.go:202-209, 221-225, 452-459).  on = 1: every map call runs a pre-pass over the front
- * of each certificate; issuers are judged when they are registered (set the switch before registering them). */
+ * dropped (cmd/ct-fetch/ct-fetch.go:202-209, 221-225, 452-459).  on = 1: the map checks the two Names of every
+ * precertificate while its walk holds them (since round 4; a pre-pass over every certificate before); issuers are
+ * judged when they are registered (set the switch before registering them). */
 int ctmr_set_strict_strings(ctmr_engine* e, int on);
 /* ctmr_pem_encode_device for an entry view: PEM of the certificates d_idx[0..n_idx) names, straight out of the blob. */
 int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* d_view,

@@ -20,6 +20,7 @@ from tests import der as D  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests.gpu_common import run_oracle, expected_records  # noqa: E402
 from tests.test_walk_cpu import mutate, edge_seeds  # noqa: E402
+from tests.test_spki_cpu import key_seeds, spki_mutate  # noqa: E402
 from tests.test_gpu_meta import expected_first_sightings, got_first_sightings  # noqa: E402
 
 
@@ -62,6 +63,11 @@ def main():
             seeds += [D.cert(serial=bytes([9, tag, k]), issuer=D.name(D.rdn(10, val, tag), D.rdn(3, b"Synth Issuer 000")),
                              subject=D.name(D.rdn(3, val, tag))) for k in range(4)]
     seeds += edge_seeds() * 6      # the Go-specific rules (numeric zones, lax INTEGERs, unique ids, high tags, lying wrappers): weighted up
+    seeds += key_seeds() * 6       # round 4: keys of every algorithm parsePublicKey knows (RSA forms, the five curves, DSA)
+    spans = []                     # where each seed's SubjectPublicKeyInfo lies: a third of the mutations aim there
+    for sd in seeds:
+        c = orc.parse_cert(sd, strict_spki=False)
+        spans.append((c.spki_off, c.spki_off + c.spki_len) if c.ok and c.spki_len else None)
     print("seeds", len(seeds), flush=True)
     bad = 0
     done = 0
@@ -69,8 +75,12 @@ def main():
     while done < total:
         certs, iss, ets = [], [], []
         for r in range(chunk):
-            s = seeds[rng.randrange(len(seeds))]
-            m = mutate(rng, s) if rng.randrange(8) else s
+            k = rng.randrange(len(seeds))
+            s = seeds[k]
+            if spans[k] and rng.randrange(3) == 0:
+                m = spki_mutate(rng, s, *spans[k])
+            else:
+                m = mutate(rng, s) if rng.randrange(8) else s
             if rng.randrange(4) == 0 and len(m) > 1:
                 m = mutate(rng, m)
             certs.append(m); iss.append(rng.randrange(len(issuers))); ets.append(rng.randrange(2))
@@ -82,11 +92,14 @@ def main():
         eng.set_filter(filt, log_exp, now)
         strict = bool(os.environ.get("STRICT_STRINGS")) and rng.random() < 0.5
         eng.set_strict_strings(strict)
+        spki = rng.random() < 0.85                   # the key parse (on by default) — and now and then off
+        eng.set_strict_spki(spki)
         res = eng.map_batch(batch)
         o = orc.Engine(filt, log_exp, now)
         o.set_strict_strings(strict)
+        o.set_strict_spki(spki)
         o, st, unk, eh = run_oracle(batch, issuers, filt, log_exp, now, engine=o)
-        flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh, strict)
+        flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh, strict, spki)
         r = res.records
         diff = ((r["status"] != st) | (r["flags"] != flags) | (r["serial_len"] != serial_len) | (r["exp_hour"] != exp_hour) |
                 (r["serial"] != serial).any(axis=1))
