@@ -605,7 +605,15 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
         const uint4 r0 = rp[0];
         rp[0] = make_uint4(CTMR_ST_PARSE_ERROR | (((r0.x >> 8) & CTMR_FL_PRECERT) << 8), 0u, r0.z, 0u);
         rp[1] = make_uint4(0u, 0u, 0u, 0u);
-        if ((kp >> 38) & 1ull) a.stage[(i & ~63ull) + ((kp >> 39) & 63ull)].meta = 0ull;  // the owner ignores it
+        if ((kp >> 38) & 1ull) {
+          a.stage[(i & ~63ull) + ((kp >> 39) & 63ull)].meta = 0ull;  // the owner ignores it
+        } else if (ent_state(e) == ES_REMOTE) {
+          // left for its owner but not staged: a 21..40-octet serial, which k_xl_export collects from ent[] afterwards —
+          // it will not find this entry any more, so the count the map took (DevStats.n_xl) must not include it.  (Found
+          // by scripts/fuzz_gpu_groups.py: the host sized the 64-byte record list by the stale count and sent its
+          // uninitialised tail — owner 0, order 0 — which cost entry 0 of rank 0 its WasUnknown.)
+          atomicAdd(&a.stats->n_xl, ~0ull);
+        }
         a.ent[i] = ent_pack(CTMR_ST_PARSE_ERROR, ES_NONE, e >> 8);
       } else if (ent_state(e) != ES_PENDING) {  // filtered, without issuer, left for its owner, host-side serial: as the map said
         a.ent[i] = e & ~ENT_KEY_PENDING;

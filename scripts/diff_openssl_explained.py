@@ -44,6 +44,8 @@ A_RULES = [
      "a 00 00 element (tag 0, length 0) where Go reads an ANY / ignores trailing octets: a well-formed TLV to encoding/asn1, an end-of-contents marker out of place to OpenSSL"),
     ("time", r"", "go-rule",
      "validity time with a numeric zone whose hours are above 23 (…+8100): time.Parse of the Go 1.13 toolchain does not range-check the zone's hours and Format prints them back, so the serialise-back test passes (DESIGN §3.1); OpenSSL's ASN1_TIME_check refuses it"),
+    ("extbc", r"", "go-rule",
+     "basicConstraints IS modelled, by Go's struct rules: `struct { IsCA bool optional; MaxPathLen int optional }` — an element of another type leaves the optional field at its default and whatever follows inside the SEQUENCE is ignored (DESIGN §3.1); OpenSSL's BASIC_CONSTRAINTS template wants BOOLEAN then INTEGER and nothing else"),
     ("ext", r"", "looser",
      "the BODY of an extension other than basicConstraints is malformed.  crypto/x509 parses keyUsage, subjectAltName, nameConstraints, cRLDistributionPoints, authorityKeyIdentifier, extKeyUsage, subjectKeyIdentifier, certificatePolicies and authorityInfoAccess and fails on a malformed one (which of these CT-go downgrades to non-fatal is not recoverable here); the walk skips those bodies by length — 0.5–1 KB per certificate it never fetches.  Listed in DESIGN §3.1 as not checked; extensions Go has no parser for are in this bucket only because OpenSSL has one"),
 ]
@@ -125,10 +127,12 @@ def a_rule(stage, reason_where, sub):
             if name == "pubkey-" + sub:
                 return name, status, text
         return None
+    if stage == "ext:basicConstraints":
+        stage = "extbc:basicConstraints"
     for st, rx, status, text in A_RULES:
         if st == stage.split(":")[0] and rx is not None and re.search(rx, reason_where):
             name = st + ": " + (rx[:48] if rx else "(any)")
-            if st == "ext":
-                name = stage
+            if st in ("ext", "extbc"):
+                name = "ext:" + stage.split(":")[1]
             return name, status, text
     return None

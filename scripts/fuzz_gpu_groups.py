@@ -59,12 +59,14 @@ def main():
             k = rng.randrange(len(issuers))
             s = bytes([rng.randrange(1, 0x7f)] + [rng.randrange(256) for _ in range(ln - 1)])
             pool.append((D.cert(serial=s, issuer=names[k], not_after=D.utctime("270101000000Z")), k))
-        for _ in range(20):
+        for _ in range(0 if os.environ.get("NO_MUTANTS") else 20):
             c, k = rng.choice(pool)
             pool.append((mutate(rng, c) if len(c) > 8 else c, k))
         engines = []
         for _ in range(world):
             e = ctmr.Engine(device=0, table_slots=1 << rng.choice((10, 12, 14)), pair_slots=1 << 10)
+            if os.environ.get("NO_SPKI"):
+                e.set_strict_spki(False)
             e.add_issuers(issuers)
             e.set_filter(filt, log_exp, NOW)
             engines.append(e)
@@ -72,6 +74,8 @@ def main():
         if mode == "bloom":
             g.bloom_config(1 << rng.choice((12, 14, 16)))
         o = orc.Engine(filt, log_exp, NOW)
+        if os.environ.get("NO_SPKI"):
+            o.set_strict_spki(False)
         base = 0
         ok = True
         for rnd in range(rng.choice((1, 2, 3))):
@@ -100,6 +104,24 @@ def main():
                     stats[r].n_new == int(unk.sum()) and (keep[r][5][:stats[r].n_new].cpu().numpy() == np.nonzero(unk)[0]).all()
                 if not good:
                     ok = False
+                    if os.environ.get("VERBOSE"):
+                        lo_, hi_ = bounds[r], bounds[r + 1]
+                        for q in np.nonzero(((rec["flags"] & 2) != 0) != (unk != 0))[0][:6]:
+                            c = items[lo_ + int(q)][0]
+                            pc = orc.parse_cert(c)
+                            print("   entry", int(q), "of", m, "gpu flags", int(rec["flags"][q]), "oracle unk", int(unk[q]), "status", int(st[q]),
+                                  "serial_len", pc.serial_len, "ec" if c.find(bytes.fromhex("2a8648ce3d0201")) >= 0 else "rsa",
+                                  "copies in round", sum(1 for cc, _ in items if cc == c), flush=True)
+                            for rr in range(world):
+                                st2, unk2 = want[rr]
+                                rec2 = keep[rr][4].cpu().numpy().view(RECORD_DTYPE)[:len(st2)]
+                                for q2 in range(len(st2)):
+                                    if items[bounds[rr] + q2][0] == c:
+                                        print("      copy: rank", rr, "idx", q2, "gpu flags", int(rec2["flags"][q2]), "status", int(rec2["status"][q2]),
+                                              "oracle unk", int(unk2[q2]), "et", int(rec2["flags"][q2]) & 1, flush=True)
+                            nbad = sum(1 for rr in range(world) for q2 in range(len(want[rr][0]))
+                                       if want[rr][0][q2] == 1 and items[bounds[rr] + q2][0].find(bytes.fromhex("2a8648ce3d0201")) >= 0)
+                            print("      EC certificates with PARSE_ERROR in the round:", nbad, flush=True)
                     print(f"MISMATCH trial {trial} round {rnd} rank {r} world {world} mode {mode}: "
                           f"status {int((rec['status'] != st).sum())} flags {int((((rec['flags'] & 2) != 0) != (unk != 0)).sum())} "
                           f"n_new {stats[r].n_new} vs {int(unk.sum())}", flush=True)

@@ -184,3 +184,66 @@ def test_mixed_corpus_is_accepted_whole_and_the_switch_changes_nothing_on_it():
             assert_records_equal(res, batch, st, unk, eh)
         eng.close()
     assert (recs[0] == recs[1]).all()
+
+
+@pytest.mark.parametrize("mode", ["owner", "bloom"])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_groups_withdraw_the_keys_of_certificates_whose_point_is_off_the_curve(world, mode):
+    """Global dedup with EC keys: an entry whose key belongs to another rank leaves the map as a key record BEFORE its curve
+    point has been checked (k_ec_resolve runs behind the map); when the point is bad the record is withdrawn — a staged
+    32-byte record, or, for a 21..40-octet serial, the entry's place in the 64-byte record list (whose COUNT must follow:
+    scripts/fuzz_gpu_groups.py found a stale count sending an uninitialised record that cost entry 0 its WasUnknown)."""
+    from ct_mapreduce_amd.distributed import Group
+    from tests.test_gpu_exchange import to_dev, dev_shard
+    rng = random.Random(100 * world + len(mode))
+    iname = D.name(D.rdn(3, b"Synth Issuer 000"))
+    issuers = [D.cert(serial=b"\x01", subject=iname, issuer=iname, exts=[D.BC_CA]),
+               D.cert(serial=b"\x02", subject=iname, issuer=iname, spki=D.EC_SPKI_2, exts=[D.BC_CA])]
+    pool = []
+    for k in range(160):
+        ln = rng.choice((8, 16, 20, 21, 30, 40))
+        serial = bytes([1 + rng.randrange(0x7e)] + [rng.randrange(256) for _ in range(ln - 1)])
+        kind = k % 4
+        pt = point("P256", 3 + k)
+        if kind == 1:
+            pt = pt[:-1] + bytes([pt[-1] ^ 1])                         # off the curve: parse error in every role
+        sp = D.rsa_spki() if kind == 3 else ec_spki("P384" if kind == 2 else "P256", point("P384", 3 + k) if kind == 2 else pt)
+        pool.append((D.cert(serial=serial, issuer=iname, spki=sp, exts=[D.BC_NOT_CA]), k % 2))
+    items = [rng.choice(pool) for _ in range(1500)]
+    items[0] = pool[3]                                                 # entry 0 of rank 0: an RSA key that must stay NEW
+    bounds = [0] + sorted(rng.randrange(1, len(items)) for _ in range(world - 1)) + [len(items)]
+    engines = []
+    for _ in range(world):
+        e = ctmr.Engine(device=0, table_slots=1 << 13, pair_slots=1 << 10)
+        e.add_issuers(issuers)
+        e.set_filter(b"", True, NOW)
+        engines.append(e)
+    g = Group.local(engines)
+    if mode == "bloom":
+        g.bloom_config(1 << 14)
+    o = orc.Engine(b"", True, NOW)
+    io = np.zeros(len(issuers) + 1, np.uint64)
+    io[1:] = np.cumsum([len(x) for x in issuers])
+    blob = np.frombuffer(b"".join(issuers), np.uint8)
+    keep, shards, want = [], [], []
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        b = Batch.from_certs([c for c, _ in items[lo:hi]], [k for _, k in items[lo:hi]], [rng.randrange(2) for _ in range(hi - lo)])
+        pay = np.concatenate([b.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+        want.append(o.batch(pay, b.offsets, b.issuer_idx, blob, io, entry_type=b.entry_type))
+        keep.append(to_dev(b))
+        shards.append(dev_shard(keep[-1], b.n, order_base=lo))
+    stats = g.map_batch(mode, shards)
+    n_err = 0
+    for r in range(world):
+        st, unk, _ = want[r]
+        rec = keep[r][4].cpu().numpy().view(ctmr.engine.RECORD_DTYPE)[:len(st)]
+        assert (rec["status"] == st).all(), r
+        assert (((rec["flags"] & 2) != 0) == (unk != 0)).all(), (r, np.nonzero(((rec["flags"] & 2) != 0) != (unk != 0))[0][:5])
+        assert stats[r].n_new == int(unk.sum())
+        n_err += int((st == orc.ST_PARSE_ERROR).sum())
+    assert n_err > 200
+    assert g.total_count() == o.total_count()
+    g.close()
+    for e in engines:
+        e.close()
