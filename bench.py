@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32
 
 
-MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16>", 15: "k_map_fused<16, false, 0>"}   # 1, 2: sweep build only
+MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16, false>", 15: "k_map_fused<16, false, 0, false>"}   # 1, 2: sweep build only
 DEFAULT_VARIANT = 15
 FUSED = (15,)          # map kernels that also do pass 1 of the known-certificate insert
 ALG_BYTES_PROBE = 64   # per PASS entry: 32 B slot read + 32 B slot write — fused kernels only
@@ -1064,7 +1064,8 @@ def main():
     kname = vname.split("<")[0]
     kernels = [kname] + (["k_decode_match"] if args.raw else []) + (["k_meta_new"] if args.meta else [])
     mode_args = (["--mixed"] if args.mixed else []) + (["--aligned", str(args.aligned)] if args.aligned else []) + (["--raw"] if args.raw else []) + (["--meta"] if args.meta else []) + \
-                (["--trusted-chain"] if args.trusted_chain else []) + (["--global-dedup", args.global_dedup] if args.global_dedup else [])
+                (["--trusted-chain"] if args.trusted_chain else []) + (["--global-dedup", args.global_dedup] if args.global_dedup else []) + \
+                (["--strict-strings"] if args.strict_strings else []) + (["--no-strict-spki"] if args.no_strict_spki else [])
     plain = not (args.raw or args.global_dedup or args.meta)
     if rank == 0 and world == 1 and not os.environ.get("CTMR_BENCH_CHILD"):
         if args.traffic_file and plain:

@@ -605,7 +605,9 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // +11.5 ms per 100 M certificates) — right behind each Name, while the window holds it, the character sets of its string
 // values are checked (name_strings_ok) and a violation is filed as WALK_NF_STRING.  The caller passes it only where the
 // finding can matter (a precertificate, a Chain[0] issuer — an X509 entry keeps its certificate either way).
-template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false, bool EC_DEFER = false>
+// STRINGS = false compiles the check out: the map kernels carry it in instantiations of their own (the code's mere presence
+// cost the default kernel 0.5 ms per 100 M certificates, A/B on one box, round 4).
+template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false, bool EC_DEFER = false, bool STRINGS = true>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv, bool spki = true, bool strings = false) {
   o.serial_off = o.serial_len = 0;
 #pragma unroll
@@ -619,6 +621,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   o.meta_issuer = o.meta_crl = META_NONE;
   o.issuer_name = o.subject_name = 0u;
   o.ec_curve = o.ec_pos = o.ec_shift = 0u;
+  if constexpr (!STRINGS) strings = false;
   bool ok = L <= 0x7fffffffu;
   L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
   uint32_t tag, cs, ce;

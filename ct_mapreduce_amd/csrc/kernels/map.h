@@ -65,7 +65,8 @@ __device__ __forceinline__ EntryIn load_entry_in(const MapArgs& a, uint64_t idx)
   return e;
 }
 
-template <class R>
+// STRICT: the instantiation for engines with ctmr_set_strict_strings (the Names' character sets, inside the walk).
+template <bool STRICT = false, class R>
 __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, const EntryIn& in, uint4& o0,
                                         uint4& o1, uint2* meta_words = nullptr, unsigned long long* keypos_out = nullptr) {
   Walk w;
@@ -75,8 +76,8 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   // L > 2^31-1 is rejected inside, without divergence.  EC_DEFER: an EC key's curve equation is k_ec_resolve's business
   // strict_strings: only a precertificate can lose its place over a string finding (an X509 entry is kept, below)
   const uint32_t iss = in.iss, et = in.et;
-  bool ok = walk_cert<R, false, false, true>(r, L, w, f->active != 0u, fv, (f->strict_spki != 0u) & (a.keypos != nullptr),
-                                             (f->strict_strings != 0u) & (et == 1u));
+  bool ok = walk_cert<R, false, false, true, STRICT>(r, L, w, f->active != 0u, fv, (f->strict_spki != 0u) & (a.keypos != nullptr),
+                                                     STRICT & (et == 1u));
   // An X509 entry's certificate was parsed by ct.LogEntryFromLeaf, which keeps it unless the error is fatal
   // (ct-fetch.go:452-459); a precertificate is parsed in insertCTWorker and dropped on ANY error, CT-go's
   // x509.NonFatalErrors included (:202-209).  Fields of a dropped certificate are not reported.
@@ -127,16 +128,16 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   if (meta_words) *meta_words = ml;
 }
 
-template <class R>
+template <bool STRICT = false, class R>
 __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a, uint4& o0, uint4& o1) {
   const EntryIn in = load_entry_in(a, idx);
-  map_one(r, len64, idx, a, in, o0, o1);
+  map_one<STRICT>(r, len64, idx, a, in, o0, o1);
 }
 
-template <class R>
+template <bool STRICT = false, class R>
 __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, const MapArgs& a) {
   uint4 o0, o1;
-  map_one(r, len64, idx, a, o0, o1);
+  map_one<STRICT>(r, len64, idx, a, o0, o1);
   uint4* out = (uint4*)(a.records + idx);
   out[0] = o0;
   out[1] = o1;
@@ -167,7 +168,7 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
 // one certificate per lane, all 64 lanes busy, DER stays in global memory and is pulled through a per-lane LDS
 // window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: WIN_LDS_BYTES per wave.
 // The first fill is wave-cooperative (coop_fill, readers.h).
-template <int WCH>
+template <int WCH, bool STRICT = false>
 __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   if (live) {
     WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
                        (int32_t)(int64_t)(g_me - lo)}};
-    map_one(r, hi - lo, i, a, o0, o1);
+    map_one<STRICT>(r, hi - lo, i, a, o0, o1);
   }
   store_records_wave(a, first, live, o0, o1);
 }

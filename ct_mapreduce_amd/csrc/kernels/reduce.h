@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 //             staging array into per-owner partitions in log order.
 //   XM_BLOOM  Bloom variant: the key of every entry that claimed or may claim a slot (CLAIMED / DEFER) is added to the
 //             rank's cumulative filter with one fire-and-forget 8-byte atomicOr — no separate pass over the records.
-template <int WCH, bool META, int MODE>
+template <int WCH, bool META, int MODE, bool STRICT = false>
 __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
   static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
@@ -413,10 +413,10 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
       r.hook.dn_seen = false;
     }
     uint2 ml = make_uint2(META_NONE, META_NONE);
-    map_one(r, hi - lo, i, a, in, o0, o1, &ml, &keypos);
+    map_one<STRICT>(r, hi - lo, i, a, in, o0, o1, &ml, &keypos);
     if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
       GlobalReader g{(const uint32_t*)a.payload, lo};
-      map_one(g, hi - lo, i, a, in, o0, o1, nullptr, &keypos);
+      map_one<STRICT>(g, hi - lo, i, a, in, o0, o1, nullptr, &keypos);
     }
     pending = keypos != 0ull;  // strict_spki: an EC key that owes the curve equation — ent[] carries that, not the record
     o0.x &= ~(FL_KEY_PENDING << 8);
