@@ -13,23 +13,40 @@
 
 namespace ctmr {
 
-// ---------------------------------------------------------------- known-certificate table
-// Open addressing, linear probing, one 64-byte slot per known certificate
-// (= one member of a Redis set "serials::<expDate>::<issuerID>", knowncertificates.go:28-55):
-//   w[0]  tag32 << 32 | min_idx32   claimed with atomicCAS(0 → …); same-key entries of one
-//                                   batch atomicMin their batch index into the low half so the
-//                                   lowest log index is the one that "was unknown"
-//   w[1]  VALID(63) | serial_len(62..56) | canonical issuer (55..32) | exp_hour (31..0)
-//                                   published last (write-through) — readers poll it
-//   w[2]  epoch of the batch that created the slot
-//   w[3..7] serial octets, zero padded (CTMR_MAX_SERIAL = 40)
-struct __attribute__((aligned(64))) Slot {
-  unsigned long long w[8];
+// ---------------------------------------------------------------- known-certificate table (round 4: index + arena)
+// One member of a Redis set "serials::<expDate>::<issuerID>" (knowncertificates.go:28-55) = one claimed word of the
+// INDEX — open addressing, linear probing, 8 bytes per slot:
+//     tag24 << 40 | ref40        0 = empty, all ones = removed member (tombstone)
+// — and one 64-byte CELL of the ARENA, arena[ref], that holds the key.  A round's entries get consecutive cells
+// (ref = the round's base + the entry's index; keys received from other ranks are appended behind), so the cells of a
+// wave are written as ONE contiguous 4 KiB store instead of 64 random 64-byte slot images, a claim is ONE random 8-byte
+// atomic, "known since an earlier round" is ref < the round's base, and a reset clears 8 bytes per slot instead of 64.
+// (Rounds 1–3: 64-byte slots holding claim word, key and epoch together — the image store behind the CAS was a second
+// random DRAM transaction per new key, ≈ 1.2 ms of the map kernel per 94 M keys, and the bench cleared 17 GB per step.)
+//   meta  VALID(63) | SHADOW(62) | serial_len(61..56) | canonical issuer (55..32) | exp_hour (31..0)
+//   s     serial octets, zero padded (CTMR_MAX_SERIAL = 40)
+//   ord   order of the entry in its round (kernels/keyrec.h): among the presenters of one new key the lowest keeps
+//         WasUnknown — pass 2 moves the index word to the lowest presenter's cell
+// A cell is written BEFORE a word that points to it can be read for comparison: pass 1 never reads cells of its own
+// round (a same-tag word of this round = DEFER), and whoever publishes a word later wrote its cell in pass 1.
+struct __attribute__((aligned(64))) KeyCell {
+  unsigned long long meta;
+  unsigned long long s[5];
+  uint32_t ord;
+  uint32_t pad0;
+  unsigned long long pad1;
 };
-static_assert(sizeof(Slot) == 64, "slot");
+static_assert(sizeof(KeyCell) == 64, "cell");
+struct Table {
+  unsigned long long* index;
+  uint64_t mask;   // slots − 1
+  KeyCell* arena;
+};
 
 constexpr unsigned long long SLOT_VALID = 1ull << 63;
-constexpr unsigned long long SLOT_TOMB = 0xffffffff00000000ull;  // removed member
+constexpr unsigned long long CELL_SHADOW = 1ull << 62;  // Bloom-variant global dedup: known for dedup, counted by another rank
+constexpr unsigned long long REF_MASK = (1ull << 40) - 1ull;
+constexpr unsigned long long IDX_TOMB = ~0ull;           // removed member
 constexpr uint32_t SID_NONE = 0xffffffffu;       // entry did not reach the set
 constexpr uint32_t SID_HOST = 0xfffffffeu;       // serial longer than CTMR_MAX_SERIAL
 constexpr uint32_t SID_FULL = 0xfffffffdu;       // table full
@@ -67,11 +84,17 @@ __host__ __device__ inline uint64_t probe_next(uint64_t j, uint64_t k, uint64_t 
   return (j + 1ull) & mask;
 }
 
-__host__ __device__ inline uint32_t key_tag(unsigned long long h) {
-  uint32_t t = (uint32_t)(h >> 32);
+__host__ __device__ inline uint32_t key_tag(unsigned long long h) {  // 24 bits, never 0 (empty) nor all ones (tombstone)
+  uint32_t t = (uint32_t)(h >> 40);
   if (t == 0u) t = 1u;
-  if (t == 0xffffffffu) t = 0xfffffffeu;
+  if (t == 0xffffffu) t = 0xfffffeu;
   return t;
+}
+__host__ __device__ inline unsigned long long idx_word(unsigned long long h, unsigned long long ref) {
+  return ((unsigned long long)key_tag(h) << 40) | ref;
+}
+__host__ __device__ inline bool idx_same_tag(unsigned long long w, unsigned long long h) {
+  return (w >> 40) == (unsigned long long)key_tag(h);
 }
 
 // ---------------------------------------------------------------- (expDate, issuer) → cardinality

@@ -154,6 +154,8 @@ struct RoundCtx {
   bool compacted = false;   // the NEW list has been written
   DevStats hs{};            // after round_collect
   uint64_t payload_bytes = 0, host_new = 0;
+  uint64_t ref0 = 0;        // arena cell of this shard's entry 0
+  uint64_t recv_ref0 = 0;   // owner-computes round: arena cell of the first received key
   uint64_t lost = 0;        // entries that lost WasUnknown to another rank after the resolve (exchange / Bloom apply)
   uint64_t remote_new = 0;  // owner-computes round: received keys that were new here
   uint64_t n_xl = 0;        // owner-computes round: keys with 21..40-octet serials that left as 64-byte records
@@ -179,9 +181,13 @@ struct ctmr_engine {
   bool own_stream = false;
   ctmr_config cfg{};
   bool tile_attr_set = false;  // CTMR_SWEEP builds: k_map_tile's dynamic-LDS attribute is set on this engine's device
-  // known-certificate table
-  Slot* table = nullptr;
+  // known-certificate table: index words + key cells (ctmr_dev.h)
+  unsigned long long* index = nullptr;
   uint64_t nslots = 0;
+  KeyCell* arena = nullptr;
+  uint64_t arena_cap = 0;   // cells
+  uint64_t arena_used = 0;  // cells handed out (a round takes one per entry + one per received key; point inserts one each)
+  Table tbl() const { return Table{index, nslots - 1, arena}; }
   uint64_t max_slots = 0;   // growth limit (config.max_table_slots; at most 2^31: slot ids are 32-bit)
   uint64_t occupied = 0;    // slots claimed since the table was last (re)built: live members + tombstones
   uint32_t rebuilds = 0;
@@ -233,7 +239,7 @@ struct ctmr_engine {
   unsigned long long* d_bloom = nullptr;
   uint64_t bloom_words = 0;
   bool bloom_owned = false;                // false: the filter lives in a caller-owned buffer
-  uint32_t bloom_round_epoch = 0;          // epoch of the batch of the current round (0 = empty batch)
+  uint64_t bloom_round_ref0 = ~0ull;       // arena cell of entry 0 of the current Bloom round's batch (~0 = empty batch: nothing of this round)
   bool last_meta_valid = false;            // SC_ITEMS holds the items of the last host batch
   uint64_t last_meta_items = 0;
   // the last ctmr_map_entries (host variant): ctmr_pem_new encodes from its view
@@ -359,14 +365,16 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
   unsigned long long s[5];
   pack_serial(m, n, s);
   const unsigned long long meta = key_meta(exp_hour, canon, (uint32_t)n);
+  unsigned long long my_ref = 0;
   if (op == 0) {
     int rc = ensure_capacity(e, 1);
     if (rc) return rc;
     e->epoch++;
+    my_ref = e->arena_used++;  // the member's cell (left unused when the member turns out to be known)
   }
   if (op != 1) e->pairs_dirty = true;
-  hipLaunchKernelGGL(k_set_op, dim3(1), dim3(64), 0, e->stream, e->table, e->nslots - 1, meta, s[0],
-                     s[1], s[2], s[3], s[4], op, e->epoch, e->issuer_counts, e->pairs,
+  hipLaunchKernelGGL(k_set_op, dim3(1), dim3(64), 0, e->stream, e->tbl(), meta, s[0],
+                     s[1], s[2], s[3], s[4], op, my_ref, e->issuer_counts, e->pairs,
                      e->npairs - 1, e->d_bloom, e->bloom_words ? e->bloom_words - 1 : 0, e->d_result);
   uint32_t res[2];
   HIPCHK(e, hipMemcpyAsync(res, e->d_result, 8, hipMemcpyDeviceToHost, e->stream));
@@ -385,19 +393,45 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
 // was inserted: a batch is applied completely or not at all.  CONSERVATIVE on purpose: `incoming` counts every entry of
 // the batch as a new key (which ones are duplicates is what the call is about to find out), so a capped table
 // (max_table_slots) may refuse a batch of mostly-known entries that would have fitted.
+// The arena: `incoming` more cells behind arena_used.  Grows by doubling; the cells keep their places (every index word
+// stays valid), the old block is copied device to device and freed.
+static int ensure_arena(ctmr_engine* e, uint64_t incoming) {
+  if (e->arena_used + incoming <= e->arena_cap) return CTMR_OK;
+  uint64_t want = e->arena_cap ? e->arena_cap : 1024;
+  while (want < e->arena_used + incoming) want *= 2;
+  if (want > (1ull << 40)) return fail(e, CTMR_E_FULL, "known-certificate arena: more than 2^40 key cells");
+  KeyCell* na = nullptr;
+  if (hipMalloc(&na, want * sizeof(KeyCell)) != hipSuccess) {
+    (void)hipGetLastError();
+    want = e->arena_used + incoming;  // the exact size, when doubling does not fit the device
+    if (hipMalloc(&na, want * sizeof(KeyCell)) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(e, CTMR_E_NOMEM, "known-certificate arena: cannot allocate %llu key cells", (unsigned long long)want);
+    }
+  }
+  if (e->arena_used) HIPCHK(e, hipMemcpyAsync(na, e->arena, e->arena_used * sizeof(KeyCell), hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  (void)hipFree(e->arena);
+  e->arena = na;
+  e->arena_cap = want;
+  return CTMR_OK;
+}
+
 int ensure_capacity(ctmr_engine* e, uint64_t incoming) {
+  int ar;
+  if ((ar = ensure_arena(e, incoming))) return ar;  // one cell per entry / received key / point insert
   if ((e->occupied + incoming) * 4 <= e->nslots * 3) return CTMR_OK;
   // how many members are alive decides the new size: count them with the rebuild itself when tombstones may exist
   uint64_t want = pow2_at_least((e->occupied + incoming) * 2);
   if (want > e->max_slots) want = e->max_slots;
   if (want < e->nslots) want = e->nslots;
-  // the smallest table that still keeps the 3/4 bound: what to fall back to when the comfortable size (load 1/2, old and
-  // new table resident at once) does not fit the device
+  // the smallest index that still keeps the 3/4 bound: what to fall back to when the comfortable size (load 1/2, old and
+  // new index resident at once) does not fit the device
   uint64_t least = pow2_at_least(((e->occupied + incoming) * 4 + 2) / 3);
   if (least < e->nslots) least = e->nslots;
   for (int attempt = 0; attempt < 3; attempt++) {
-    Slot* nt = nullptr;
-    if (hipMalloc(&nt, want * sizeof(Slot)) != hipSuccess) {
+    unsigned long long* nt = nullptr;
+    if (hipMalloc(&nt, want * 8) != hipSuccess) {
       (void)hipGetLastError();
       if (want > least && least <= e->max_slots) {  // retry at the smallest size that holds the call
         want = least;
@@ -406,16 +440,16 @@ int ensure_capacity(ctmr_engine* e, uint64_t incoming) {
       return fail(e, CTMR_E_NOMEM, "known-certificate table: cannot allocate %llu slots for the rebuild",
                   (unsigned long long)want);
     }
-    HIPCHK(e, hipMemsetAsync(nt, 0, want * sizeof(Slot), e->stream));
+    HIPCHK(e, hipMemsetAsync(nt, 0, want * 8, e->stream));
     HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
     hipLaunchKernelGGL(k_rehash, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream,
-                       (const Slot*)e->table, e->nslots, nt, want - 1, e->d_count);
+                       (const unsigned long long*)e->index, e->nslots, Table{nt, want - 1, e->arena}, e->d_count);
     unsigned long long live = 0;
     HIPCHK(e, hipMemcpyAsync(&live, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipGetLastError());
-    (void)hipFree(e->table);
-    e->table = nt;
+    (void)hipFree(e->index);
+    e->index = nt;
     e->nslots = want;
     e->occupied = live;
     e->rebuilds++;
@@ -436,7 +470,7 @@ int ensure_pairs(ctmr_engine* e) {
     HIPCHK(e, hipMemsetAsync(e->pairs, 0, e->npairs * sizeof(PairSlot), e->stream));
     HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
     hipLaunchKernelGGL(k_build_pairs, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream,
-                       e->table, e->nslots, e->pairs, e->npairs - 1, e->d_count);
+                       e->tbl(), e->pairs, e->npairs - 1, e->d_count);
     unsigned long long full;
     HIPCHK(e, hipMemcpyAsync(&full, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));

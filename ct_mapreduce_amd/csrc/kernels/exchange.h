@@ -128,46 +128,43 @@ __global__ void __launch_bounds__(256) k_xl_export(InsertArgs a, uint32_t world,
 }
 
 // Owner side, pass 1 / pass 2 / resolve on received key records (same protocol as the fused map's pass 1 and k_insert2).
-// `loc` describes the owner's OWN shard of the round (ent, ord_base, n; records_local): received records that beat one of
-// its entries mark it.
+// Received record k of the round gets the arena cell recv_ref0 + k (the cells of a wave as one contiguous store, like
+// the map's); `loc` describes the owner's OWN shard of the round (ent, ord_base, n, ref0; records_local): received
+// records that beat one of its entries mark it.  A word of THIS round = ref >= loc.ref0 (the received cells lie behind
+// the shard's own).
 template <class Rec>
-__global__ void __launch_bounds__(256) k_keys_insert(const Rec* keys, uint64_t n, Slot* table, uint64_t mask,
-                                                     uint32_t epoch, uint32_t* slot_id) {
-  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 slot images (store_slots_wave, as k_insert)
+__global__ void __launch_bounds__(256) k_keys_insert(const Rec* keys, uint64_t n, Table t, unsigned long long round_ref0,
+                                                     unsigned long long recv_ref0, uint32_t* slot_id) {
+  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 key cells (store_cells_wave)
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint64_t claimed = ~0ull;
-  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  KeyView k{};
+  bool keyed = false;
   if (i < n) {
-    const KeyView k = load_key(keys, i);
+    k = load_key(keys, i);
     const unsigned long long h = key_hash(k.meta, k.s);
-    const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
-    const unsigned long long w0 = tagw | k.ord;
-    uint64_t j = h & mask;
+    const unsigned long long mine = idx_word(h, recv_ref0 + i);
+    uint64_t j = h & t.mask;
     uint32_t sid = SID_FULL;
     // meta == 0 (no VALID bit): a record its sender withdrew — the EC point of the certificate turned out to be off its
     // curve after the key had been staged (k_ec_resolve).  Never inserted, answered "not new"; the sender's entry is a
     // parse error by then and ignores the answer.
-    const uint64_t limit = k.meta == 0ull ? 0ull : mask + 1ull;
+    const uint64_t limit = k.meta == 0ull ? 0ull : t.mask + 1ull;
     if (k.meta == 0ull) sid = SID_NONE;
+    keyed = k.meta != 0ull;
     for (uint64_t probes = 0; probes < limit; probes++) {
-      Slot* sl = table + j;
-      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
-      if (old == 0ull) {  // claimed: the 64-byte image leaves four lanes per slot, whole slots per store instruction
-        q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)k.meta, (uint32_t)(k.meta >> 32));
-        q1 = make_uint4(epoch, 0u, (uint32_t)k.s[0], (uint32_t)(k.s[0] >> 32));
-        q2 = make_uint4((uint32_t)k.s[1], (uint32_t)(k.s[1] >> 32), (uint32_t)k.s[2], (uint32_t)(k.s[2] >> 32));
-        q3 = make_uint4((uint32_t)k.s[3], (uint32_t)(k.s[3] >> 32), (uint32_t)k.s[4], (uint32_t)(k.s[4] >> 32));
-        claimed = j;
+      const unsigned long long old = atomicCAS(&t.index[j], 0ull, mine);
+      if (old == 0ull) {
         sid = (uint32_t)j;
         break;
       }
-      if ((old & 0xffffffff00000000ull) == tagw) {
-        const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
-        if (ep != 0u && ep != epoch) {
-          bool eq = sl->w[1] == k.meta;
+      if (old != IDX_TOMB && idx_same_tag(old, h)) {
+        const unsigned long long oref = old & REF_MASK;
+        if (oref < round_ref0) {  // an earlier round's key
+          const KeyCell* c = t.arena + oref;
+          bool eq = (c->meta & ~CELL_SHADOW) == k.meta;
 #pragma unroll
-          for (int q = 0; q < 5; q++) eq = eq && sl->w[3 + q] == k.s[q];
+          for (int q = 0; q < 5; q++) eq = eq && c->s[q] == k.s[q];
           if (eq) {
             sid = SID_DUP_OLD;
             break;
@@ -177,15 +174,16 @@ __global__ void __launch_bounds__(256) k_keys_insert(const Rec* keys, uint64_t n
           break;
         }
       }
-      j = probe_next(j, probes, mask);
+      j = probe_next(j, probes, t.mask);
     }
     slot_id[i] = sid;
   }
-  store_slots_wave(table, img[wv], lane, claimed, q0, q1, q2, q3);
+  const uint64_t first = (uint64_t)blockIdx.x * 256 + 64u * wv;
+  if (first < n) store_cells_wave(t.arena + recv_ref0 + first, n - first, img[wv], lane, keyed, k.meta, k.s, k.ord);
 }
 
 template <class Rec>
-__global__ void __launch_bounds__(256) k_keys_insert2(const Rec* keys, uint64_t n, InsertArgs loc,
+__global__ void __launch_bounds__(256) k_keys_insert2(const Rec* keys, uint64_t n, InsertArgs loc, unsigned long long recv_ref0,
                                                       ctmr_record* records_local, uint32_t* slot_id) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -193,28 +191,27 @@ __global__ void __launch_bounds__(256) k_keys_insert2(const Rec* keys, uint64_t 
   if (sid >= SID_DUP_OLD || !(sid & SID_DEFER)) return;
   sid &= ~SID_DEFER;
   const KeyView k = load_key(keys, i);
-  Slot* sl = loc.table + sid;
-  bool eq = sl->w[1] == k.meta;
-#pragma unroll
-  for (int q = 0; q < 5; q++) eq = eq && sl->w[3 + q] == k.s[q];
-  unsigned long long prev = ~0ull;
-  if (eq) {
-    prev = atomicMin(&sl->w[0], ((unsigned long long)key_tag(key_hash(k.meta, k.s)) << 32) | k.ord);
-  } else {
+  const unsigned long long h = key_hash(k.meta, k.s);
+  const unsigned long long my_ref = recv_ref0 + i;
+  const unsigned long long w = ld_agent(&loc.t.index[sid]);
+  if (!cell_equals(loc.t.arena + (w & REF_MASK), k.meta, k.s)) {  // another key under the same tag
     bool created;
-    sid = table_upsert(loc.table, loc.mask, k.meta, k.s, k.ord, loc.epoch, true, &created, &prev);
-    if (sid >= SID_DUP_OLD || created) prev = ~0ull;
+    unsigned long long holder = 0ull;
+    sid = index_upsert(loc.t, k.meta, k.s, my_ref, true, &created, &holder);
+    slot_id[i] = sid;
+    if (sid >= SID_DUP_OLD || created) return;  // full (SID_FULL), or holds its slot now
+    if ((holder & REF_MASK) < loc.ref0) {       // found in an earlier round after all
+      slot_id[i] = SID_DUP_OLD;
+      return;
+    }
   }
   slot_id[i] = sid;
-  if (prev != ~0ull) {  // whoever of (previous holder, this record) has the higher order loses; told here when it is local
-    const uint32_t other = (uint32_t)prev;
-    mark_dup_ord(loc, records_local, other < k.ord ? k.ord : other);
-  }
+  (void)settle_order(loc, records_local, sid, h, my_ref, k.ord);  // whether it kept the word is read back in k_keys_resolve
 }
 
 template <class Rec>
-__global__ void __launch_bounds__(1024) k_keys_resolve(const Rec* keys, uint64_t n, uint64_t nb, const Slot* table,
-                                                       uint32_t epoch, const uint32_t* slot_id, uint8_t* flags,
+__global__ void __launch_bounds__(1024) k_keys_resolve(const Rec* keys, uint64_t n, uint64_t nb, Table t,
+                                                       unsigned long long recv_ref0, const uint32_t* slot_id, uint8_t* flags,
                                                        unsigned long long* issuer_counts, DevStats* stats) {
   __shared__ uint32_t ih[RES_LDS_ISSUERS];
   __shared__ uint32_t cnt[2];
@@ -230,11 +227,9 @@ __global__ void __launch_bounds__(1024) k_keys_resolve(const Rec* keys, uint64_t
       if (sid == SID_FULL) {
         is_full = true;
       } else if (sid < SID_DUP_OLD) {
-        const Slot* sl = table + sid;
-        const unsigned long long w0 = sl->w[0], w1 = sl->w[1], w2 = sl->w[2];
-        const uint32_t ord = ((const uint32_t*)(keys + i))[sizeof(Rec) == 32 ? 7 : 14];  // KeyRec32.ord / low half of KeyRec.pad
-        is_new = (uint32_t)w2 == epoch && (uint32_t)w0 == ord;
-        canon = (uint32_t)(w1 >> 32) & 0xffffffu;
+        // new here = the slot's word points to THIS record's cell (nobody with a lower order of the round took it)
+        is_new = (t.index[sid] & REF_MASK) == recv_ref0 + i;
+        canon = (uint32_t)(t.arena[recv_ref0 + i].meta >> 32) & 0xffffffu;
       }
       flags[i] = is_new ? 1 : 0;
     }
@@ -289,7 +284,6 @@ __global__ void __launch_bounds__(256) k_apply_lost(const Rec* sent, const uint8
 // Filter: blocked Bloom, one 64-bit word per key, 4 bits inside it — one 8-byte atomicOr to add, one 8-byte load per
 // peer to probe.  At 16 filter bits per key the false-positive rate is ≈ 0.5 % (only extra key traffic, never a wrong
 // answer).
-constexpr unsigned long long SLOT_SHADOW = 1ull << 63;  // Slot.w[2]: key is counted by another rank
 
 __device__ __forceinline__ bool entry_key(const InsertArgs& a, uint64_t i, unsigned long long& meta,
                                           unsigned long long s[5]) {
@@ -398,50 +392,46 @@ __global__ void __launch_bounds__(1024) k_bloom_scatter(InsertArgs a, uint32_t w
 }
 
 // read-only find (the batch that filled the table has completed: plain loads)
-__device__ __forceinline__ uint32_t table_find(const Slot* table, uint64_t mask, unsigned long long meta,
-                                               const unsigned long long s[5]) {
+__device__ __forceinline__ uint32_t table_find(const Table& t, unsigned long long meta, const unsigned long long s[5]) {
   const unsigned long long h = key_hash(meta, s);
-  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
-  uint64_t j = h & mask;
-  for (uint64_t probes = 0; probes <= mask; probes++) {
-    const Slot* sl = table + j;
-    const unsigned long long w0 = sl->w[0];
-    if (w0 == 0ull) return SID_NONE;
-    if ((w0 & 0xffffffff00000000ull) == tagw && w0 != SLOT_TOMB) {
-      bool eq = sl->w[1] == meta;
+  uint64_t j = h & t.mask;
+  for (uint64_t probes = 0; probes <= t.mask; probes++) {
+    const unsigned long long w = t.index[j];
+    if (w == 0ull) return SID_NONE;
+    if (w != IDX_TOMB && idx_same_tag(w, h)) {
+      const KeyCell* c = t.arena + (w & REF_MASK);
+      bool eq = (c->meta & ~CELL_SHADOW) == meta;
 #pragma unroll
-      for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+      for (int k = 0; k < 5; k++) eq = eq && c->s[k] == s[k];
       if (eq) return (uint32_t)j;
     }
-    j = probe_next(j, probes, mask);
+    j = probe_next(j, probes, t.mask);
   }
   return SID_NONE;
 }
 
-// Peer side: flags[k] = 1 when the key is known here before the asker's entry — since an earlier round, or since
-// this round under a lower global order.
-__global__ void __launch_bounds__(256) k_keys_lookup(const KeyRec* keys, uint64_t n, const Slot* table, uint64_t mask,
-                                                     uint32_t round_epoch, unsigned long long order_base,
-                                                     uint8_t* flags) {
+// Peer side: flags[k] = 1 when the key is known here before the asker's entry — since an earlier round (its cell lies
+// below the round's first one), or since this round under a lower global order.
+__global__ void __launch_bounds__(256) k_keys_lookup(const KeyRec* keys, uint64_t n, Table t, unsigned long long round_ref0,
+                                                     unsigned long long order_base, uint8_t* flags) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const KeyRec k = keys[i];
-  const uint32_t sid = table_find(table, mask, k.meta, k.s);
+  const uint32_t sid = table_find(t, k.meta, k.s);
   uint8_t f = 0;
   if (sid != SID_NONE) {
-    const unsigned long long w0 = table[sid].w[0], w2 = table[sid].w[2];
-    f = (uint32_t)w2 != round_epoch || order_base + (uint32_t)w0 < k.pad;
+    const unsigned long long ref = t.index[sid] & REF_MASK;
+    f = ref < round_ref0 || order_base + t.arena[ref].ord < k.pad;
   }
   flags[i] = f;
 }
 
 // Asker side: a flagged key loses WasUnknown (once, however many peers flagged it), leaves the per-issuer count and
-// its slot becomes SHADOW; its ent[] word, the NEW count of its 1024-entry block and the `lost` counter follow, so that
+// its cell becomes SHADOW; its ent[] word, the NEW count of its 1024-entry block and the `lost` counter follow, so that
 // the NEW list is compacted from ent[] as after a plain batch.
 __global__ void __launch_bounds__(256) k_bloom_apply(const KeyRec* sent, const uint8_t* flags, uint64_t n_keys,
-                                                     ctmr_record* records, uint32_t* ent, uint32_t* blk_new, Slot* table,
-                                                     uint64_t mask, unsigned long long* issuer_counts,
-                                                     unsigned long long* n_lost) {
+                                                     ctmr_record* records, uint32_t* ent, uint32_t* blk_new, Table t,
+                                                     unsigned long long* issuer_counts, unsigned long long* n_lost) {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool lost = false;
   uint32_t canon = 0;
@@ -451,8 +441,8 @@ __global__ void __launch_bounds__(256) k_bloom_apply(const KeyRec* sent, const u
     if ((old >> 8) & CTMR_FL_WAS_UNKNOWN) {
       lost = true;
       canon = (uint32_t)(kr.meta >> 32) & 0xffffffu;
-      const uint32_t sid = table_find(table, mask, kr.meta, kr.s);
-      if (sid != SID_NONE) atomicOr(&table[sid].w[2], SLOT_SHADOW);
+      const uint32_t sid = table_find(t, kr.meta, kr.s);
+      if (sid != SID_NONE) atomicOr(&t.arena[t.index[sid] & REF_MASK].meta, CELL_SHADOW);
       ((uint8_t*)(ent + kr.src))[0] = (uint8_t)(CTMR_ST_PASS | (ES_DUP << 3));
       atomicSub(&blk_new[kr.src >> 10], 1u);
     }

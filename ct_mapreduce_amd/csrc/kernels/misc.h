@@ -67,16 +67,26 @@ __global__ void __launch_bounds__(256) k_fingerprint(const uint8_t* payload, con
 
 // ------------------------------------------------------------------ RemoteCache point ops
 // op: 0 = SetInsert, 1 = SetContains, 2 = SetRemove.  result[0] = 1 when inserted / present /
-// removed; result[1] = SID_FULL marker on a full table.
-__global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, unsigned long long s0,
+// removed; result[1] = SID_FULL marker on a full table.  SetInsert: `my_ref` is a fresh arena cell the host reserved
+// for this call (it stays unused when the member was known).
+__global__ void k_set_op(Table t, unsigned long long meta, unsigned long long s0,
                          unsigned long long s1, unsigned long long s2, unsigned long long s3,
-                         unsigned long long s4, int op, uint32_t epoch,
+                         unsigned long long s4, int op, unsigned long long my_ref,
                          unsigned long long* issuer_counts, PairSlot* pairs, uint64_t pmask,
                          unsigned long long* bloom, uint64_t bloom_wmask, uint32_t* result) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const unsigned long long s[5] = {s0, s1, s2, s3, s4};
   bool created = false;
-  const uint32_t sid = table_upsert(table, mask, meta, s, 0xffffffffu, epoch, op == 0, &created);
+  unsigned long long holder = 0ull;
+  if (op == 0) {  // the cell first, visible, then the word that points to it
+    KeyCell* c = t.arena + my_ref;
+    st_agent(&c->meta, meta);
+#pragma unroll
+    for (int k = 0; k < 5; k++) st_agent(&c->s[k], s[k]);
+    __hip_atomic_store(&c->ord, 0xffffffffu, __ATOMIC_RELAXED, AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const uint32_t sid = index_upsert(t, meta, s, my_ref, op == 0, &created, &holder);
   result[0] = 0;
   result[1] = sid == SID_FULL;
   if (sid == SID_FULL) return;
@@ -93,92 +103,89 @@ __global__ void k_set_op(Slot* table, uint64_t mask, unsigned long long meta, un
   } else if (op == 1) {
     result[0] = sid != SID_NONE;
   } else if (sid != SID_NONE) {
-    const bool shadow = (table[sid].w[2] & SLOT_SHADOW) != 0;  // counted by another rank: nothing to take off here
-    table[sid].w[0] = SLOT_TOMB;
-    table[sid].w[1] = 0;
+    const bool shadow = (t.arena[holder & REF_MASK].meta & CELL_SHADOW) != 0;  // counted by another rank: nothing to take off here
+    t.index[sid] = IDX_TOMB;
     if (!shadow) atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
     result[0] = 1;
   }
 }
 
 // Drop every member whose (exp_hour, canonical issuer) matches, or — with any_key — every
-// member with exp_hour*3600 <= now (Redis EXPIREAT set by knowncertificates.go:98-104).
-__global__ void __launch_bounds__(256) k_sweep(Slot* table, uint64_t nslots, int any_key,
+// member with exp_hour*3600 <= now (Redis EXPIREAT set by knowncertificates.go:98-104).  One index word per thread; the
+// key of a live word is read from its cell.
+__global__ void __launch_bounds__(256) k_sweep(Table t, int any_key,
                                                long long now, uint32_t exp_hour_key, uint32_t canon_key,
                                                unsigned long long* issuer_counts, PairSlot* pairs,
                                                uint64_t pmask, unsigned long long* removed) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= nslots) return;
-  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
-  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  if (j > t.mask) return;
+  const unsigned long long w = t.index[j];
+  if (w == 0ull || w == IDX_TOMB) return;
+  const unsigned long long w1 = t.arena[w & REF_MASK].meta;
   const int32_t eh = (int32_t)(uint32_t)w1;
   const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
   const bool hit = any_key ? ((long long)eh * 3600 <= now) : ((uint32_t)eh == exp_hour_key && canon == canon_key);
   if (!hit) return;
-  const bool shadow = (table[j].w[2] & SLOT_SHADOW) != 0;  // counted by another rank (Bloom-variant global dedup)
-  table[j].w[0] = SLOT_TOMB;
-  table[j].w[1] = 0;
-  if (shadow) return;
+  t.index[j] = IDX_TOMB;
+  if (w1 & CELL_SHADOW) return;  // counted by another rank (Bloom-variant global dedup)
   atomicAdd(&issuer_counts[canon], (unsigned long long)-1ll);
   atomicAdd(removed, 1ull);
 }
 
-// Table growth / compaction: every live member of the old table is re-inserted into the new (zeroed) one — the
-// keys are distinct, so one CAS claims the slot and plain stores fill it (the kernel boundary publishes them).  The
-// slot image moves verbatim: the tag half of w[0] is a function of the key hash, not of the table size; w[2] keeps
-// the creating batch's epoch and the SHADOW bit.  Tombstones stay behind, which is how their slots are recovered.
-__global__ void __launch_bounds__(256) k_rehash(const Slot* old_table, uint64_t old_slots, Slot* table, uint64_t mask,
+// Table growth: every live word of the old index is re-inserted into the new (zeroed) one — the keys are distinct, so
+// one CAS claims the slot.  The word moves verbatim (tag and ref do not depend on the table size; the arena — copied
+// as it is when it grows too — keeps every cell where it was).  Tombstones stay behind, which is how their slots are
+// recovered.  The slot in the new index comes from the key's hash: read from the cell.
+__global__ void __launch_bounds__(256) k_rehash(const unsigned long long* old_index, uint64_t old_slots, Table t,
                                                 unsigned long long* moved) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= old_slots) return;
-  const Slot* o = old_table + j;
-  const unsigned long long w0 = o->w[0], w1 = o->w[1];
-  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID)) return;
+  const unsigned long long w = old_index[j];
+  if (w == 0ull || w == IDX_TOMB) return;
+  const KeyCell* c = t.arena + (w & REF_MASK);
   unsigned long long s[5];
 #pragma unroll
-  for (int k = 0; k < 5; k++) s[k] = o->w[3 + k];
-  const unsigned long long w2 = o->w[2];
-  uint64_t q = key_hash(w1, s) & mask;
-  for (uint64_t probes = 0;; probes++) {  // the new table holds at most half as many members as it has slots: this terminates
-    if (atomicCAS(&table[q].w[0], 0ull, w0) == 0ull) break;
-    q = probe_next(q, probes, mask);
+  for (int k = 0; k < 5; k++) s[k] = c->s[k];
+  uint64_t q = key_hash(c->meta & ~CELL_SHADOW, s) & t.mask;
+  for (uint64_t probes = 0;; probes++) {  // the new index holds at most half as many members as it has slots: this terminates
+    if (atomicCAS(&t.index[q], 0ull, w) == 0ull) break;
+    q = probe_next(q, probes, t.mask);
   }
-  Slot* d = table + q;
-  d->w[1] = w1;
-  d->w[2] = w2;
-#pragma unroll
-  for (int k = 0; k < 5; k++) d->w[3 + k] = s[k];
   atomicAdd(moved, 1ull);
 }
 
 // Rebuild the (expDate, issuer) → SCARD table from the known-certificate table (lazy: only the
 // statistics-style queries SetCardinality / Exists / KeysToChan need it).
-__global__ void __launch_bounds__(256) k_build_pairs(const Slot* table, uint64_t nslots, PairSlot* pairs,
-                                                     uint64_t pmask, unsigned long long* full) {
+__global__ void __launch_bounds__(256) k_build_pairs(Table t, PairSlot* pairs, uint64_t pmask, unsigned long long* full) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= nslots) return;
-  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
-  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID) || (table[j].w[2] & SLOT_SHADOW)) return;
+  if (j > t.mask) return;
+  const unsigned long long w = t.index[j];
+  if (w == 0ull || w == IDX_TOMB) return;
+  const unsigned long long w1 = t.arena[w & REF_MASK].meta;
+  if (w1 & CELL_SHADOW) return;
   const uint32_t canon = (uint32_t)(w1 >> 32) & 0xffffffu;
   if (!pair_add(pairs, pmask, ((unsigned long long)(canon + 1) << 32) | (uint32_t)w1, 1)) atomicAdd(full, 1ull);
 }
 
 // SetList / SetToChan: gather the serials of one set.  out entries are 48 bytes:
 // [u32 len][40 bytes serial][u32 pad].
-__global__ void __launch_bounds__(256) k_list(const Slot* table, uint64_t nslots, uint32_t exp_hour_key,
+__global__ void __launch_bounds__(256) k_list(Table t, uint32_t exp_hour_key,
                                               uint32_t canon_key, uint8_t* out, uint64_t cap,
                                               unsigned long long* count) {
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= nslots) return;
-  const unsigned long long w0 = table[j].w[0], w1 = table[j].w[1];
-  if (w0 == 0ull || w0 == SLOT_TOMB || !(w1 & SLOT_VALID) || (table[j].w[2] & SLOT_SHADOW)) return;
+  if (j > t.mask) return;
+  const unsigned long long w = t.index[j];
+  if (w == 0ull || w == IDX_TOMB) return;
+  const KeyCell* c = t.arena + (w & REF_MASK);
+  const unsigned long long w1 = c->meta;
+  if (w1 & CELL_SHADOW) return;
   if ((uint32_t)w1 != exp_hour_key || ((uint32_t)(w1 >> 32) & 0xffffffu) != canon_key) return;
   const unsigned long long k = atomicAdd(count, 1ull);
   if (k >= cap) return;
   unsigned long long* o = (unsigned long long*)(out + k * 48);
-  o[0] = (w1 >> 56) & 0x7full;
+  o[0] = (w1 >> 56) & 0x3full;
 #pragma unroll
-  for (int q = 0; q < 5; q++) o[1 + q] = table[j].w[3 + q];
+  for (int q = 0; q < 5; q++) o[1 + q] = c->s[q];
 }
 
 // KeysToChan: dump the non-empty (expDate, issuer) pairs.

@@ -16,54 +16,52 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, AGENT);
 }
 
-// Find-or-insert one key.  Returns the slot index (or SID_FULL); *created tells whether this
-// call claimed the slot.  idx32 = batch index merged with atomicMin (pass 0xffffffff for
-// point operations).  Visibility: payload words are written through (agent-scope atomic
-// stores), drained with s_waitcnt vmcnt(0), then w[1] is published; readers poll w[1] with
-// agent-scope loads (MI355X_MICROARCH.md "handoff-flag": write-through payload + drained flag).
-__device__ __forceinline__ uint32_t table_upsert(Slot* table, uint64_t mask, unsigned long long meta,
-                                                 const unsigned long long s[5], uint32_t idx32,
-                                                 uint32_t epoch, bool insert, bool* created,
-                                                 unsigned long long* prev_w0 = nullptr) {
+// The key of a cell against (meta, s): the SHADOW bit is not part of the key.
+__device__ __forceinline__ bool cell_equals(const KeyCell* c, unsigned long long meta, const unsigned long long s[5]) {
+  bool eq = (ld_agent(&c->meta) & ~CELL_SHADOW) == meta;
+#pragma unroll
+  for (int k = 0; k < 5; k++) eq = eq && ld_agent(&c->s[k]) == s[k];
+  return eq;
+}
+__device__ __forceinline__ void cell_write(KeyCell* c, unsigned long long meta, const unsigned long long s[5], uint32_t ord) {
+  uint4* q = (uint4*)c;
+  q[0] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+  q[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+  q[2] = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+  q[3] = make_uint4(ord, 0u, 0u, 0u);
+}
+
+// Find-or-insert one key with the fully synchronised protocol (point operations, pass 2's rare fallback): returns the
+// index slot (or SID_NONE / SID_FULL) and, through *holder, the word found there.  insert: the caller has WRITTEN
+// arena[my_ref] already and made it visible (the word is what publishes the cell) — *created tells whether this call
+// claimed the slot.  Every word met on the way points to a complete cell: pass-1 cells are complete behind the kernel
+// boundary, and a word published here was preceded by its cell.
+__device__ __forceinline__ uint32_t index_upsert(const Table& t, unsigned long long meta, const unsigned long long s[5],
+                                                 unsigned long long my_ref, bool insert, bool* created,
+                                                 unsigned long long* holder = nullptr) {
   const unsigned long long h = key_hash(meta, s);
-  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
-  uint64_t j = h & mask;
+  const unsigned long long mine = idx_word(h, my_ref);
+  uint64_t j = h & t.mask;
   *created = false;
-  uint64_t probes = 0;
-  for (;;) {
-    Slot* sl = table + j;
-    unsigned long long w0 = ld_agent(&sl->w[0]);
-    if (w0 == 0ull) {
+  for (uint64_t probes = 0; probes <= t.mask; probes++) {
+    unsigned long long w = ld_agent(&t.index[j]);
+    if (w == 0ull) {
       if (!insert) return SID_NONE;
-      const unsigned long long old = atomicCAS(&sl->w[0], 0ull, tagw | idx32);
+      const unsigned long long old = atomicCAS(&t.index[j], 0ull, mine);
       if (old == 0ull) {
-        st_agent(&sl->w[2], (unsigned long long)epoch);
-#pragma unroll
-        for (int k = 0; k < 5; k++) st_agent(&sl->w[3 + k], s[k]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_agent(&sl->w[1], meta);
         *created = true;
+        if (holder) *holder = mine;
         return (uint32_t)j;
       }
-      w0 = old;
+      w = old;
     }
-    if ((w0 & 0xffffffff00000000ull) == tagw && w0 != SLOT_TOMB) {
-      const unsigned long long m = ld_agent(&sl->w[1]);
-      if (!(m & SLOT_VALID)) continue;  // creator has not published yet: poll again
-      bool eq = m == meta;
-#pragma unroll
-      for (int k = 0; k < 5; k++) eq = eq && ld_agent(&sl->w[3 + k]) == s[k];
-      if (eq) {
-        if (insert && idx32 != 0xffffffffu) {
-          const unsigned long long old = atomicMin(&sl->w[0], tagw | idx32);
-          if (prev_w0) *prev_w0 = old;
-        }
-        return (uint32_t)j;
-      }
+    if (w != IDX_TOMB && idx_same_tag(w, h) && cell_equals(t.arena + (w & REF_MASK), meta, s)) {
+      if (holder) *holder = w;
+      return (uint32_t)j;
     }
-    j = probe_next(j, probes, mask);
-    if (++probes > mask) return SID_FULL;
+    j = probe_next(j, probes, t.mask);
   }
+  return SID_FULL;
 }
 
 struct InsertArgs {
@@ -72,12 +70,12 @@ struct InsertArgs {
   const uint64_t* offsets;
   const uint64_t* ends;    // null = packed batch (MapArgs)
   const uint32_t* canon;   // issuer_idx → canonical issuer
-  Slot* table;
-  uint64_t mask;
+  Table t;                 // the known-certificate table: index words + key cells (ctmr_dev.h)
+  unsigned long long ref0; // arena cell of entry 0 of this batch: entry i's key lives in arena[ref0 + i]; a word whose ref
+                           // is below ref0 belongs to an earlier round (complete, comparable at once)
   uint32_t* slot_id;       // candidate slot of DEFER entries (written for those only)
   uint32_t* ent;           // per entry: status(0..2) | state(3..5) | canonical issuer << 8
   uint64_t n;
-  uint32_t epoch;
   DevStats* stats;         // n_xl (owner-computes rounds), n_pending
   uint32_t ord_base;       // order of entry 0 in the round (keyrec.h; 0 outside a group round): w[0] carries ord_base + i
   // k_ec_resolve (strict_spki): where the pending EC points lie, the owner-computes staging array (a key that left for its
@@ -165,92 +163,76 @@ __device__ __forceinline__ void record_key(const InsertArgs& a, uint64_t i, cons
   }
 }
 
-// KnownCertificates.WasUnknown → RemoteCache.SetInsert (knowncertificates.go:38-55) for every
-// PASS entry, against the in-HBM table.  PASS 1 (this kernel) never reads anything another lane
-// of the same launch wrote except the CAS word itself:
-//   empty slot      → one atomicCAS claims it (state CLAIMED); the 64-byte slot image is written
-//                     after the probe loop, four lanes per slot, so that one store instruction emits
-//                     whole 64-byte slots (one memory transaction each) instead of four partial ones
-//   same tag, slot of an OLDER batch (epoch in [1, cur)) → fully visible: compare now (state DUP)
-//   same tag, slot of THIS batch (epoch 0 = not written yet, or cur) → remember the slot (state
-//                     DEFER), decide in pass 2 after the kernel boundary made every pass-1 store visible
-// Records arrive with WAS_UNKNOWN set optimistically by the map; it is cleared here / in pass 2
-// for duplicates only.  The reduce's later passes read the 4-byte ent[] word, never the table.
-// Pass-1 set insert of one PASS record held in registers (r0, r1 = the two 16-byte halves of the record).
-// On a claim the 64-byte slot image is returned in q0..q3 and `claimed` is the slot index; the caller
-// stores it cooperatively (store_slots_wave).  Returns the ES_* state.
+// KnownCertificates.WasUnknown → RemoteCache.SetInsert (knowncertificates.go:38-55) for every PASS entry, against the
+// in-HBM table.  PASS 1 never reads anything another lane of the same launch wrote except the index word itself:
+//   empty slot      → one atomicCAS claims it for arena[ref0 + i] (state CLAIMED)
+//   same tag, word of an EARLIER round (ref < ref0) → its cell is complete: compare now (state DUP, or probe on)
+//   same tag, word of THIS round → remember the slot (state DEFER), decide in pass 2 behind the kernel boundary
+// and every entry's key goes into its own cell, arena[ref0 + i] — whether it claimed or not (a DEFER entry may have to
+// insert itself in pass 2, and a word may be moved to any presenter's cell) — the 64 cells of a wave as one contiguous
+// 4 KiB store (store_cells_wave).  Records arrive with WAS_UNKNOWN set optimistically by the map; it is cleared here /
+// in pass 2 for duplicates only.  The reduce's later passes read the 4-byte ent[] word, never the table.
 __device__ __forceinline__ uint32_t insert_probe_h(const InsertArgs& a, uint64_t i, unsigned long long meta,
-                                                   const unsigned long long s[5], unsigned long long h, uint64_t& claimed,
-                                                   uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
-  const unsigned long long tagw = (unsigned long long)key_tag(h) << 32;
-  const unsigned long long w0 = tagw | (a.ord_base + (uint32_t)i);
-  uint64_t j = h & a.mask;
-  for (uint64_t probes = 0; probes <= a.mask; probes++) {
-    Slot* sl = a.table + j;
-    const unsigned long long old = atomicCAS(&sl->w[0], 0ull, w0);
-    if (old == 0ull) {  // claimed
-      q0 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)meta, (uint32_t)(meta >> 32));
-      q1 = make_uint4(a.epoch, 0u, (uint32_t)s[0], (uint32_t)(s[0] >> 32));
-      q2 = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
-      q3 = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
-      claimed = j;
-      return ES_CLAIMED;
-    }
-    if ((old & 0xffffffff00000000ull) == tagw) {
-      const uint32_t ep = (uint32_t)ld_agent(&sl->w[2]);
-      if (ep != 0u && ep != a.epoch) {  // older batch: complete and visible
-        bool eq = sl->w[1] == meta;
+                                                   const unsigned long long s[5], unsigned long long h) {
+  const unsigned long long mine = idx_word(h, a.ref0 + i);
+  uint64_t j = h & a.t.mask;
+  for (uint64_t probes = 0; probes <= a.t.mask; probes++) {
+    const unsigned long long old = atomicCAS(&a.t.index[j], 0ull, mine);
+    if (old == 0ull) return ES_CLAIMED;
+    if (old != IDX_TOMB && idx_same_tag(old, h)) {
+      const unsigned long long oref = old & REF_MASK;
+      if (oref < a.ref0) {  // an earlier round's key: complete and visible
+        const KeyCell* c = a.t.arena + oref;
+        bool eq = (c->meta & ~CELL_SHADOW) == meta;
 #pragma unroll
-        for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
+        for (int k = 0; k < 5; k++) eq = eq && c->s[k] == s[k];
         if (eq) return ES_DUP;
       } else {
         a.slot_id[i] = (uint32_t)j;
         return ES_DEFER;
       }
     }
-    j = probe_next(j, probes, a.mask);
+    j = probe_next(j, probes, a.t.mask);
   }
   return ES_FULL;
 }
 
 __device__ __forceinline__ uint32_t insert_probe(const InsertArgs& a, uint64_t i, const uint4& r0, const uint4& r1,
-                                                 uint32_t canon, uint64_t& claimed, uint4& q0, uint4& q1, uint4& q2,
-                                                 uint4& q3) {
+                                                 uint32_t canon, unsigned long long& meta, unsigned long long s[5]) {
   const uint32_t slen = r0.x >> 16;
+  meta = 0ull;
   if (slen > CTMR_MAX_SERIAL) return ES_HOST;
-  unsigned long long s[5];
   record_key(a, i, r0, r1, s);
-  const unsigned long long meta = key_meta((int32_t)r0.y, canon, slen);
-  return insert_probe_h(a, i, meta, s, key_hash(meta, s), claimed, q0, q1, q2, q3);
+  meta = key_meta((int32_t)r0.y, canon, slen);
+  return insert_probe_h(a, i, meta, s, key_hash(meta, s));
 }
 
-// Cooperative slot write of one wave: lane L parks its 64-byte image at img[L*4 .. L*4+3]; store
-// instruction r then has lane L write quarter L%4 of the slot of lane 16r + L/4, so four adjacent
-// lanes emit one whole slot.  (w[0] is rewritten with the value the CAS stored: concurrent CAS
-// attempts of this pass see a non-zero word either way; atomicMin only runs in pass 2.)
-__device__ __forceinline__ void store_slots_wave(Slot* table, uint4* img, uint32_t lane, uint64_t claimed,
-                                                 const uint4& q0, const uint4& q1, const uint4& q2, const uint4& q3) {
+// The key cells of one wave's 64 consecutive entries, arena[ref0 + first … + 64): every lane parks its 64-byte cell in
+// LDS, then each of four store instructions writes 1 KiB of consecutive bytes.  `keyed` = the lane has a key (a PASS
+// entry with a serial of at most 40 octets); the others write a cell without VALID.
+__device__ __forceinline__ void store_cells_wave(KeyCell* cells, uint64_t n_left, uint4* img, uint32_t lane, bool keyed,
+                                                 unsigned long long meta, const unsigned long long s[5], uint32_t ord) {
   uint4* my = img + lane * 4;
-  my[0] = q0; my[1] = q1; my[2] = q2; my[3] = q3;
+  const unsigned long long m = keyed ? meta : 0ull;
+  my[0] = make_uint4((uint32_t)m, (uint32_t)(m >> 32), (uint32_t)s[0], (uint32_t)(s[0] >> 32));
+  my[1] = make_uint4((uint32_t)s[1], (uint32_t)(s[1] >> 32), (uint32_t)s[2], (uint32_t)(s[2] >> 32));
+  my[2] = make_uint4((uint32_t)s[3], (uint32_t)(s[3] >> 32), (uint32_t)s[4], (uint32_t)(s[4] >> 32));
+  my[3] = make_uint4(ord, 0u, 0u, 0u);
   __builtin_amdgcn_wave_barrier();
+  const uint32_t nvec = n_left >= 64 ? 256u : (uint32_t)n_left * 4u;
+  uint4* out = (uint4*)cells;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t src = 16u * r + (lane >> 2);
-    const uint64_t sj = __shfl(claimed, src);
-    if (sj != ~0ull) {
-      const uint4 v = img[r * 64 + lane];
-      ((uint4*)(table + sj))[lane & 3u] = v;
-    }
-  }
+  for (int r = 0; r < 4; r++)
+    if (64u * r + lane < nvec) out[64 * r + lane] = img[64 * r + lane];
 }
 
 __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
-  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 slot images
+  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 key cells
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t state = ES_NONE, status = CTMR_ST__COUNT, canon = 0;
-  uint64_t claimed = ~0ull;  // slot index when this lane claimed one
-  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  unsigned long long meta = 0ull, s[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+  bool keyed = false;
   if (i < a.n) {
     const uint4* rp = (const uint4*)(a.records + i);
     const uint4 r0 = rp[0];
@@ -262,8 +244,14 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
       canon = a.canon[r0.z];
       const uint4 r1 = rp[1];
       const uint32_t slen = r0.x >> 16;
-      state = (pending && slen <= CTMR_MAX_SERIAL) ? (uint32_t)ES_PENDING
-                                                   : insert_probe(a, i, r0, r1, canon, claimed, q0, q1, q2, q3);
+      if (pending && slen <= CTMR_MAX_SERIAL) {
+        state = ES_PENDING;
+        record_key(a, i, r0, r1, s);
+        meta = key_meta((int32_t)r0.y, canon, slen);
+      } else {
+        state = insert_probe(a, i, r0, r1, canon, meta, s);
+      }
+      keyed = slen <= CTMR_MAX_SERIAL;
       if (state != ES_CLAIMED && state != ES_DEFER && state != ES_PENDING) fl_out &= ~(uint32_t)CTMR_FL_WAS_UNKNOWN;  // not (yet) unknown
     }
     if (fl_out != ((r0.x >> 8) & 0xffu)) ((uint8_t*)(a.records + i))[1] = (uint8_t)fl_out;
@@ -271,50 +259,69 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
     const unsigned long long mp = __ballot(pending);
     if (mp && lane == (uint32_t)(__ffsll((long long)mp) - 1)) atomicAdd(&a.stats->n_pending, (unsigned long long)__popcll(mp));
   }
-  store_slots_wave(a.table, img[wv], lane, claimed, q0, q1, q2, q3);
+  const uint64_t first = (uint64_t)blockIdx.x * 256 + 64u * wv;
+  if (first < a.n)
+    store_cells_wave(a.t.arena + a.ref0 + first, a.n - first, img[wv], lane, keyed, meta, s, a.ord_base + (uint32_t)i);
 }
 
-// PASS 2: DEFER entries — their candidate slot was created by this batch and is complete now.
-// Equal key → atomicMin the batch index into w[0]; the RETURNED previous minimum tells who loses:
-// whichever of (previous holder, me) has the higher log index is marked DUP, so after this pass
-// exactly the lowest log index of every new key is still CLAIMED/DEFER — nobody has to re-read the
-// table to find out.  A 32-bit tag collision between different keys (≈2^-32 per probe) falls back
-// to the fully synchronised upsert, which is also safe against other pass-2 lanes inserting the
-// same key concurrently.
-// Whoever loses a key of this round to a lower order: when it is an entry of THIS shard its ent[] word and its record
-// say so; an entry of another rank (owner-computes round) is told by its owner's flag byte (k_keys_resolve).
+// PASS 2: DEFER entries — their candidate word was published by this round, and every cell of the round is complete now.
+// The word's cell holds the slot's key (whichever presenter's cell it points to: the word only ever moves between
+// presenters of ONE key).  Same key → the lowest ORDER must end up holding the word: if the holder's order is lower I
+// lose (DUP); else I move the word to my cell with a compare-and-swap and the former holder loses — when it is an entry
+// of THIS shard its ent[] word and its record say so (mark_dup_ord); an entry of another rank (owner-computes round) is
+// told by its owner's answer, which asks "does the word still point to MY cell?" (k_keys_resolve).  Another key under
+// the same 24-bit tag (2^-24 per probe): the entry inserts itself with the synchronised probe — its cell is there already.
 __device__ __forceinline__ void mark_dup_ord(const InsertArgs& a, ctmr_record* records, uint32_t loser_ord) {
   const uint32_t li = loser_ord - a.ord_base;  // wraps for lower ranks' orders: then >= n as well
   if ((uint64_t)li < a.n) mark_dup(a.ent, records, li);
 }
 
+// Settles one presenter (key, order `ord`, cell `my_ref`) against the word at slot sid.  Returns true when the presenter
+// keeps (so far) WasUnknown; losers of this shard are marked on the way.
+__device__ __forceinline__ bool settle_order(const InsertArgs& a, ctmr_record* records, uint32_t sid, unsigned long long h,
+                                             unsigned long long my_ref, uint32_t ord) {
+  unsigned long long w = ld_agent(&a.t.index[sid]);
+  for (;;) {
+    const unsigned long long href = w & REF_MASK;
+    if (href == my_ref) return true;
+    if (href < a.ref0) return false;  // (cannot happen for a DEFER slot; a point insert of an earlier round: known)
+    const uint32_t hord = __hip_atomic_load(&a.t.arena[href].ord, __ATOMIC_RELAXED, AGENT);
+    if (hord < ord) return false;     // a lower order of this round holds the key
+    const unsigned long long old = atomicCAS(&a.t.index[sid], w, idx_word(h, my_ref));
+    if (old == w) {
+      mark_dup_ord(a, records, hord);
+      return true;
+    }
+    w = old;                          // somebody else moved it meanwhile: look again
+  }
+}
+
 __device__ __forceinline__ void insert2_one(const InsertArgs& a, ctmr_record* records, uint64_t i, uint32_t e) {
-  const uint32_t sid = a.slot_id[i];
+  uint32_t sid = a.slot_id[i];
   const uint4* rp = (const uint4*)(a.records + i);
   const uint4 r0 = rp[0], r1 = rp[1];
   unsigned long long s[5];
   record_key(a, i, r0, r1, s);
   const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
+  const unsigned long long h = key_hash(meta, s);
   const uint32_t ord = a.ord_base + (uint32_t)i;
-  Slot* sl = a.table + sid;
-  bool eq = sl->w[1] == meta;
-#pragma unroll
-  for (int k = 0; k < 5; k++) eq = eq && sl->w[3 + k] == s[k];
-  unsigned long long prev = ~0ull;
-  if (eq) {
-    const unsigned long long tagw = (unsigned long long)key_tag(key_hash(meta, s)) << 32;
-    prev = atomicMin(&sl->w[0], tagw | ord);
-  } else {
+  const unsigned long long my_ref = a.ref0 + i;
+  const unsigned long long w = ld_agent(&a.t.index[sid]);
+  if (!cell_equals(a.t.arena + (w & REF_MASK), meta, s)) {  // another key under the same tag
     bool created;
-    const uint32_t r = table_upsert(a.table, a.mask, meta, s, ord, a.epoch, true, &created, &prev);
-    if (r == SID_FULL) {
+    unsigned long long holder = 0ull;
+    sid = index_upsert(a.t, meta, s, my_ref, true, &created, &holder);
+    if (sid == SID_FULL) {
       ((uint8_t*)(a.ent + i))[0] = (uint8_t)(CTMR_ST_PASS | (ES_FULL << 3));
       return;
     }
     if (created) return;  // stays DEFER = unknown unless a lower order joins and marks it
+    if ((holder & REF_MASK) < a.ref0) {  // found in an earlier round after all
+      mark_dup(a.ent, records, (uint32_t)i);
+      return;
+    }
   }
-  const uint32_t other = (uint32_t)prev;
-  mark_dup_ord(a, records, other < ord ? ord : other);
+  if (!settle_order(a, records, sid, h, my_ref, ord)) mark_dup(a.ent, records, (uint32_t)i);
 }
 
 // Four entries per thread, one 16-byte load of ent[]: nearly every entry is not DEFER, so the kernel is a scan of
@@ -395,8 +402,8 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
   coop_fill<false>(a.payload, limit, g_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-  uint64_t claimed = ~0ull;
-  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+  unsigned long long kmeta = 0ull, ks[5] = {0ull, 0ull, 0ull, 0ull, 0ull};  // the entry's key, for its arena cell
+  bool keyed = false;
   uint32_t rem_owner = KEY_NO_OWNER;  // XM_OWNER: the rank this entry's key record goes to
   bool rem_long = false;
   uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
@@ -437,9 +444,10 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
       if (slen > CTMR_MAX_SERIAL) {
         state = ES_HOST;
       } else {
-        unsigned long long s[5];
+        unsigned long long* const s = ks;
         record_key(ia, i, o0, o1, s);
-        const unsigned long long meta = key_meta((int32_t)o0.y, canon, slen);
+        const unsigned long long meta = kmeta = key_meta((int32_t)o0.y, canon, slen);
+        keyed = true;
         const unsigned long long h = key_hash(meta, s);
         bool mine = true;
         if constexpr (MODE == XM_OWNER) {
@@ -451,7 +459,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
           state = ES_CLAIMED;
 #else
           // (a key whose EC point is not checked yet is not inserted: k_ec_resolve does both)
-          state = pending ? (uint32_t)ES_PENDING : insert_probe_h(ia, i, meta, s, h, claimed, q0, q1, q2, q3);
+          state = pending ? (uint32_t)ES_PENDING : insert_probe_h(ia, i, meta, s, h);
 #endif
         } else {  // (XM_OWNER) the record that leaves; serials of 21..40 octets take the 64-byte path (k_xl_export)
           state = ES_REMOTE;
@@ -480,11 +488,9 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   }
   store_records_wave(a, first, live, o0, o1);
   __builtin_amdgcn_wave_barrier();
-#ifdef CTMR_EXP_NO_SLOT_IMAGE  // sweep builds, MEASUREMENT ONLY (wrong results): what the slot image store adds to WRITE_SIZE
-  (void)q0; (void)q1; (void)q2; (void)q3;
-#else
-  store_slots_wave(ia.table, (uint4*)smem, lane, claimed, q0, q1, q2, q3);
-#endif
+  // the wave's 64 key cells, arena[ref0 + first …): one contiguous 4 KiB store (the window area is free by now)
+  if (first < a.n)
+    store_cells_wave(ia.t.arena + ia.ref0 + first, a.n - first, (uint4*)smem, lane, keyed, kmeta, ks, ia.ord_base + (uint32_t)i);
   {  // strict_spki: how many entries owe k_ec_resolve a curve equation (0 in a batch of RSA keys: it exits at once)
     const unsigned long long mp = __ballot(pending);
     if (mp && lane == 0) atomicAdd(&ia.stats->n_pending, (unsigned long long)__popcll(mp));
@@ -539,9 +545,9 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
 //   point bad   the entry becomes what the map makes of a certificate that does not parse (status PARSE_ERROR, nothing
 //               else reported); a key record that already left for its owner (XM_OWNER) is withdrawn (meta = 0);
 //   point good  the pending bit goes; an entry in state ES_PENDING (would reach the set, key is this rank's) gets PASS 1
-//               of the insert exactly as the map's other entries got it inside the fused kernel (insert_probe_h + the
-//               cooperative slot store): claim, or DEFER on a same-tag slot of this batch — k_insert2, which runs next,
-//               settles those.  (First version, measured: the fully synchronised upsert — agent-scope loads, CAS, six
+//               of the insert exactly as the map's other entries got it inside the fused kernel (insert_probe_h; its key
+//               cell was written by the map): claim, or DEFER on a same-tag word of this round — k_insert2, which runs
+//               next, settles those.  (First version, measured: the fully synchronised upsert — agent-scope loads, CAS, six
 //               written-through stores and a drained publish per key — 80 ms per 47 M keys; every one of them a DRAM
 //               read + write at the memory side, profiles/r03/calib_atomics_by_scope.jsonl.)
 // A block takes 1 024 consecutive entries, compacts the pending ones into LDS and walks that list 256 at a time: the
@@ -557,11 +563,9 @@ __device__ __forceinline__ bool ec_point_bits(const uint32_t* words, unsigned lo
 
 constexpr uint32_t EC_PER_BLOCK = 1024;
 __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* records) {
-  __shared__ __attribute__((aligned(16))) uint4 img[4][64 * 4];  // per wave: 64 slot images (store_slots_wave)
   __shared__ uint16_t list[EC_PER_BLOCK];
   __shared__ uint32_t n_list;
   if (a.stats->n_pending == 0ull) return;
-  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t blk0 = (uint64_t)blockIdx.x * EC_PER_BLOCK;
   if (threadIdx.x == 0) n_list = 0u;
   __syncthreads();
@@ -580,10 +584,8 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
   }
   __syncthreads();
   const uint32_t cnt = n_list;
-  for (uint32_t base = 0; base < cnt; base += 256u) {  // (block-uniform trip count: store_slots_wave is cooperative)
+  for (uint32_t base = 0; base < cnt; base += 256u) {
     const uint32_t t = base + threadIdx.x;
-    uint64_t claimed = ~0ull;
-    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
     if (t < cnt) {
       const uint64_t i = blk0 + list[t];
       const uint32_t e = a.ent[i];
@@ -623,7 +625,7 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
         record_key(a, i, r0, r1, s);
         const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);
         const unsigned long long h = key_hash(meta, s);
-        const uint32_t state = insert_probe_h(a, i, meta, s, h, claimed, q0, q1, q2, q3);
+        const uint32_t state = insert_probe_h(a, i, meta, s, h);  // (its cell was written by the map, like every entry's)
         if (state != ES_CLAIMED && state != ES_DEFER) {
           ((uint8_t*)(records + i))[1] = (uint8_t)((r0.x >> 8) & ~CTMR_FL_WAS_UNKNOWN);
         } else if (a.bloom) {
@@ -635,7 +637,6 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
         a.ent[i] = (e & ~(ENT_KEY_PENDING | (7u << 3))) | (state << 3);
       }
     }
-    store_slots_wave(a.table, img[wv], lane, claimed, q0, q1, q2, q3);
   }
 }
 
