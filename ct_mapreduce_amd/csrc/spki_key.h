@@ -336,6 +336,7 @@ struct KeyPending {
   uint32_t e_end;
   uint32_t k_at, k0, k1, k2, k3;  // sixteen octets of the certificate from k_at on, fetched with the walk's tail (key_tail_of)
   bool pre;            // … are valid
+  bool fast;           // RSA: the key had the common shape up to the modulus (spki_key_begin): the exponent may take the short way too
 };
 
 // Readers that fetch the octets around the key's end together with their next window (kernels/readers.h WinReaderS::
@@ -355,6 +356,7 @@ CTMR_HD void spki_key_begin(const R& r, uint32_t L, const AlgView& a, uint32_t c
                             KeyPending& kp) {
   kp.alg = PK_OTHER;
   kp.pre = false;
+  kp.fast = false;
   kp.c0 = ck + 1u;
   kp.ek = ek;
   kp.shift = 0u;
@@ -370,15 +372,30 @@ CTMR_HD void spki_key_begin(const R& r, uint32_t L, const AlgView& a, uint32_t c
       const bool null_par = (a.par_e - a.par_p == 2u) & ((ldc(r, a.par_p, L) & 0xffffu) == 0x0005u);
       nf = null_par ? nf : (nf | WALK_NF_SPKI);
     }
-    const SpkiView<KeyReaderOf<R>> v{key_reader_of(r), kp.c0, kp.shift};
-    uint32_t ts, ss, se, n_end, n_len;
-    int n_sign;
-    rd_hdr(v, L, kp.c0, ek, ok, ts, ss, se);
-    ok = ok & (ts == 0x30u) & (se == ek);  // "x509: trailing data after RSA public key"
-    key_integer(v, L, ss, se, ok, nf, n_end, n_sign, n_len);
-    nf = (n_sign <= 0) ? (nf | WALK_NF_SPKI) : nf;  // "x509: RSA modulus is not a positive number"
-    kp.e_pos = n_end;
-    kp.e_end = se;
+    // The shape every RSA key of 2048 bits and more has — 30 82 ll ll | 02 82 nn nn | modulus, minimal and positive — is
+    // recognised from three reads of the window (the general parse below costs ≈ 100 vector instructions more per
+    // certificate, and on a power-limited part instructions are clock: DESIGN.md §7).  Anything else takes the general parse.
+    const uint32_t h0 = ldc(r, kp.c0, L), h1 = ldc(r, kp.c0 + 4u, L), h2 = ldc(r, kp.c0 + 8u, L);
+    const uint32_t seqlen = __builtin_bswap32(h0) & 0xffffu, nlen = __builtin_bswap32(h1) & 0xffffu;
+    const uint32_t b0 = h2 & 0xffu, b1 = (h2 >> 8) & 0xffu;
+    const bool shape = (kp.shift == 0u) & ((h0 & 0xffffu) == 0x8230u) & (seqlen >= 256u) & (kp.c0 + 4u + seqlen == ek) &
+                       ((h1 & 0xffffu) == 0x8202u) & (nlen >= 256u) & (nlen + 4u < seqlen) &
+                       (((b0 - 1u) < 0x7fu) | ((b0 == 0u) & (b1 >= 0x80u)));
+    kp.fast = shape;
+    if (shape) {
+      kp.e_pos = kp.c0 + 8u + nlen;
+      kp.e_end = ek;
+    } else {
+      const SpkiView<KeyReaderOf<R>> v{key_reader_of(r), kp.c0, kp.shift};
+      uint32_t ts, ss, se, n_end, n_len;
+      int n_sign;
+      rd_hdr(v, L, kp.c0, ek, ok, ts, ss, se);
+      ok = ok & (ts == 0x30u) & (se == ek);  // "x509: trailing data after RSA public key"
+      key_integer(v, L, ss, se, ok, nf, n_end, n_sign, n_len);
+      nf = (n_sign <= 0) ? (nf | WALK_NF_SPKI) : nf;  // "x509: RSA modulus is not a positive number"
+      kp.e_pos = n_end;
+      kp.e_end = se;
+    }
   }
 }
 
@@ -473,6 +490,13 @@ CTMR_HD void spki_key_finish(const R& r, uint32_t L, const AlgView& a, const Key
   const SpkiView<KeyReaderOf<R>> v{key_reader_of(r), kp.c0, kp.shift};
   if ((kp.alg == PK_RSA) | (kp.alg == PK_RSA_OAEP)) {
     const SpkiView<KeyReaderOf<R>> ev{key_reader_of(r), kp.c0, kp.shift, kp.k_at, kp.k0, kp.k1, kp.k2, kp.k3, kp.pre};
+    if (kp.fast) {  // the exponent as the last element: 02 len e…, 1..8 octets, minimal and positive — else the general parse
+      const uint32_t t = ldc(ev, kp.e_pos, L);
+      const uint32_t len = (t >> 8) & 0xffu, e0 = (t >> 16) & 0xffu, e1 = t >> 24;
+      if (((t & 0xffu) == 0x02u) & ((len - 1u) < 8u) & (kp.e_pos + 2u + len == kp.e_end) &
+          (((e0 - 1u) < 0x7fu) | ((e0 == 0u) & (len > 1u) & (e1 >= 0x80u))))
+        return;
+    }
     uint32_t e_after, e_len;
     int e_sign;
     key_integer(ev, L, kp.e_pos, kp.e_end, ok, nf, e_after, e_sign, e_len);
