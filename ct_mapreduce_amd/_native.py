@@ -168,6 +168,7 @@ SIGNATURES = {
     "ctmr_meta_new": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]),
     "ctmr_meta_reset": (C.c_int, [_P]),
     "ctmr_fingerprint_device": (C.c_int, [_P, _P, _P, _P, C.c_uint64, _P, C.POINTER(C.c_float)]),
+    # include/ctmr_bench.h — the synthetic corpus generator: exported by the same library, NOT part of the drop-in ABI
     "ctmr_synth_entries_host": (C.c_uint64, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P, C.c_uint64]),
     "ctmr_synth_entries_device": (C.c_int, [_P, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, _P, _P, C.c_uint64,
                                             C.POINTER(C.c_uint64)]),

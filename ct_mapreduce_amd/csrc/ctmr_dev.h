@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/ctmr.h"
+#include "../../include/ctmr_bench.h"
 #include "der_walk.h"
 
 // Launch bounds of the kernels whose walk evaluates the curve equation on the spot (issuer registration, the strict_leaf

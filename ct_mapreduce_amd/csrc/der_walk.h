@@ -43,7 +43,7 @@ struct Walk {
   // where IssuerMetadata.Accumulate's inputs lie (storage/issuermetadata.go:92-138), packed off | len << 16
   // (meta_pack): the issuer Name TLV, and the OCTET STRING content of extension 2.5.29.31
   uint32_t meta_issuer, meta_crl;
-  uint32_t issuer_name, subject_name;  // where the two Name TLVs start (name_strings_ok)
+  uint32_t issuer_name, subject_name;  // where the two Name TLVs start
   // walk_cert<…, EC_DEFER>: an EC key accepted except for the curve equation (spki_key.h) — ec_curve 1..5 (0: nothing
   // pending), the certificate offset of the point's X coordinate, the BIT STRING's pad count.  The caller owes the check.
   uint32_t ec_curve, ec_pos, ec_shift;
@@ -395,6 +395,77 @@ struct TailView {
 #include "spki_key.h"  // the key inside subjectPublicKeyInfo (parsePublicKey)
 namespace ctmr {
 
+// strict_strings (opt-in, DESIGN.md §3.1): the character-set rules Go's encoding/asn1 applies when it unmarshals an
+// AttributeTypeAndValue's `Value interface{}` of a universal, primitive string type — a violation is a parse error of the
+// stdlib; what certificate-transparency-go's lax fork makes of it is NOT verifiable here, so the finding is filed as
+// non-fatal (WALK_NF_STRING) behind a switch that is off by default:
+//   PrintableString (0x13)  isPrintable with '*' and '&' allowed: A-Z a-z 0-9 space ' ( ) + , - . / : = ? * &
+//   NumericString   (0x12)  0-9 and space
+//   IA5String       (0x16)  every octet < 0x80
+//   UTF8String      (0x0c)  utf8.Valid: no overlong forms, no surrogates, nothing above U+10FFFF, no truncated sequence
+// T61String is taken as it is.  walk_name<…, STRINGS = true> checks each value where it meets it, while the window holds it
+// (round 4; a second pass over the Name re-read its headers and, on a long subject, found the window moved on).
+CTMR_HD bool string_byte_ok(uint32_t tag, uint32_t b) {
+  // bit c of the mask = octet c is allowed
+  const unsigned long long pr_lo = 0xa7ffffc100000000ull, pr_hi = 0x07fffffe07fffffeull;
+  const unsigned long long nu_lo = 0x03ff000100000000ull;
+  if (b >= 0x80u) return false;
+  if (tag == 0x16u) return true;
+  const unsigned long long lo = tag == 0x13u ? pr_lo : nu_lo, hi = tag == 0x13u ? pr_hi : 0ull;
+  return (((b < 64u ? lo : hi) >> (b & 63u)) & 1ull) != 0ull;
+}
+
+// the value [cv, ev) of universal type tv against its character set
+template <class R>
+CTMR_HD bool value_strings_ok(R& r, uint32_t L, uint32_t tv, uint32_t cv, uint32_t ev) {
+  bool good = true;
+  if ((tv == 0x13u) | (tv == 0x12u) | (tv == 0x16u)) {
+    for (uint32_t p = cv; good & (p < ev); p += 4u) {
+      if (((p - cv) & 63u) == 0u) r.touch(p, ev - p < 64u ? ev - p : 64u);
+      const uint32_t nb = ev - p < 4u ? ev - p : 4u, keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+      const uint32_t w = (ldc(r, p, L) & keep) | (0x30303030u & ~keep);  // octets behind the value count as '0': in every set
+      good = good & ((w & 0x80808080u) == 0u);                           // all three sets are 7-bit
+      if (tv != 0x16u)
+        good = good & string_byte_ok(tv, w & 0x7fu) & string_byte_ok(tv, (w >> 8) & 0x7fu) &
+               string_byte_ok(tv, (w >> 16) & 0x7fu) & string_byte_ok(tv, (w >> 24) & 0x7fu);
+    }
+  } else if (tv == 0x0cu) {
+    uint32_t need = 0u, lo = 0x80u, hi = 0xbfu;  // continuation octets still owed, and the range of the next one
+    for (uint32_t p = cv; good & (p < ev); p += 4u) {
+      if (((p - cv) & 63u) == 0u) r.touch(p, ev - p < 64u ? ev - p : 64u);
+      const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
+      const uint32_t keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+      if ((need == 0u) & ((w & keep & 0x80808080u) == 0u)) continue;  // four ASCII octets between sequences
+      for (uint32_t k = 0; k < nb; k++) {
+        const uint32_t b = (w >> (8u * k)) & 0xffu;
+        if (need == 0u) {
+          if (b < 0x80u) {
+          } else if ((b >= 0xc2u) & (b <= 0xdfu)) {
+            need = 1u;
+          } else if ((b >= 0xe0u) & (b <= 0xefu)) {
+            need = 2u;
+            lo = b == 0xe0u ? 0xa0u : 0x80u;
+            hi = b == 0xedu ? 0x9fu : 0xbfu;
+          } else if ((b >= 0xf0u) & (b <= 0xf4u)) {
+            need = 3u;
+            lo = b == 0xf0u ? 0x90u : 0x80u;
+            hi = b == 0xf4u ? 0x8fu : 0xbfu;
+          } else {
+            good = false;
+          }
+        } else {
+          good = good & (b >= lo) & (b <= hi);
+          lo = 0x80u;
+          hi = 0xbfu;
+          need--;
+        }
+      }
+    }
+    good = good & (need == 0u);
+  }
+  return good;
+}
+
 // pkix.RDNSequence at q (asn1.RawValue in the tbsCertificate, then asn1.Unmarshal into pkix.RDNSequence): SEQUENCE OF
 // SET OF SEQUENCE { type OID, value ANY }; bytes behind the value inside an AttributeTypeAndValue are ignored.
 // CN = true: also finds the last attribute with OID 2.5.4.3 whose value is a string type (the types Go decodes to a
@@ -428,9 +499,9 @@ CTMR_HD void name_value_check(const R& r, uint32_t L, uint32_t tag, uint32_t c, 
   }
 }
 
-template <bool CN, class R>
+template <bool CN, bool STRINGS, class R>
 CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool& ok, uint32_t& cn_off, uint32_t& cn_len,
-                           uint32_t& nf) {
+                           uint32_t& nf, bool strings) {
   uint32_t tag, cs, ce;
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
@@ -455,6 +526,8 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
         const uint32_t set_end = a + 2u + ((w0 >> 8) & 0xffu), atv_end = a + 4u + (w0 >> 24);
         const uint32_t tv = tvf, cv = a + 11u, ev = cv + ((w2 >> 16) & 0xffu);
         ok = ok & (set_end <= s_end) & (atv_end <= set_end) & (ev <= atv_end);
+        if constexpr (STRINGS)
+          if (strings & ok) nf = value_strings_ok(r, L, tv, cv, ev) ? nf : (nf | WALK_NF_STRING);
         if constexpr (CN) {
           const bool is_cn = (((w1 >> 16) | ((w2 & 0xffu) << 16)) == 0x030455u) & string_tag(tv);
           cn_off = is_cn ? cv : cn_off;
@@ -477,6 +550,8 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
       ok = ok & (t1 == 0x30u) & (to == 0x06u);
       ok = ok && oid_arcs_ok(r, L, co, eo);
       if (ok & !value_plain(tv)) name_value_check(r, L, tv, cv, ev, ok, nf);
+      if constexpr (STRINGS)
+        if (strings & ok) nf = value_strings_ok(r, L, tv, cv, ev) ? nf : (nf | WALK_NF_STRING);
       if constexpr (CN) {
         const bool is_cn = (eo - co == 3u) & ((oidw & 0xffffffu) == 0x030455u) & string_tag(tv);
         cn_off = is_cn ? cv : cn_off;
@@ -486,90 +561,6 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
     }
   }
   return ce;
-}
-
-// strict_strings (opt-in, DESIGN.md §3.1): the character-set rules Go's encoding/asn1 applies when it unmarshals an
-// AttributeTypeAndValue's `Value interface{}` of a universal, primitive string type — a violation is a parse error of the
-// stdlib; what certificate-transparency-go's lax fork makes of it is NOT verifiable here, so the finding is filed as
-// non-fatal (WALK_NF_STRING) behind a switch that is off by default:
-//   PrintableString (0x13)  isPrintable with '*' and '&' allowed: A-Z a-z 0-9 space ' ( ) + , - . / : = ? * &
-//   NumericString   (0x12)  0-9 and space
-//   IA5String       (0x16)  every octet < 0x80
-//   UTF8String      (0x0c)  utf8.Valid: no overlong forms, no surrogates, nothing above U+10FFFF, no truncated sequence
-// T61String is taken as it is.  The Name at q has been accepted by walk_name (the structure is not checked again).
-CTMR_HD bool string_byte_ok(uint32_t tag, uint32_t b) {
-  // bit c of the mask = octet c is allowed
-  const unsigned long long pr_lo = 0xa7ffffc100000000ull, pr_hi = 0x07fffffe07fffffeull;
-  const unsigned long long nu_lo = 0x03ff000100000000ull;
-  if (b >= 0x80u) return false;
-  if (tag == 0x16u) return true;
-  const unsigned long long lo = tag == 0x13u ? pr_lo : nu_lo, hi = tag == 0x13u ? pr_hi : 0ull;
-  return (((b < 64u ? lo : hi) >> (b & 63u)) & 1ull) != 0ull;
-}
-
-template <class R>
-CTMR_HD bool name_strings_ok(const R& r, uint32_t L, uint32_t q, uint32_t tbs_end) {
-  bool hdr_ok = true, good = true;
-  uint32_t tag, cs, ce;
-  rd_hdr(r, L, q, tbs_end, hdr_ok, tag, cs, ce);
-  const uint32_t s_end = ce;
-  uint32_t a = cs;
-  while (hdr_ok & good & (a < s_end)) {  // RDNs
-    uint32_t t1, c1, e1;
-    rd_hdr(r, L, a, s_end, hdr_ok, t1, c1, e1);
-    uint32_t x = c1;
-    while (hdr_ok & good & (x < e1)) {  // AttributeTypeAndValues
-      uint32_t t2, c2, e2, to, co, eo, tv, cv, ev;
-      rd_hdr(r, L, x, e1, hdr_ok, t2, c2, e2);
-      rd_hdr(r, L, c2, e2, hdr_ok, to, co, eo);
-      rd_hdr(r, L, eo, e2, hdr_ok, tv, cv, ev);
-      if (hdr_ok & ((tv == 0x13u) | (tv == 0x12u) | (tv == 0x16u))) {
-        for (uint32_t p = cv; good & (p < ev); p += 4u) {
-          const uint32_t nb = ev - p < 4u ? ev - p : 4u, keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
-          const uint32_t w = (ldc(r, p, L) & keep) | (0x30303030u & ~keep);  // octets behind the value count as '0': in every set
-          good = good & ((w & 0x80808080u) == 0u);                           // all three sets are 7-bit
-          if (tv != 0x16u)
-            good = good & string_byte_ok(tv, w & 0x7fu) & string_byte_ok(tv, (w >> 8) & 0x7fu) &
-                   string_byte_ok(tv, (w >> 16) & 0x7fu) & string_byte_ok(tv, (w >> 24) & 0x7fu);
-        }
-      } else if (hdr_ok & (tv == 0x0cu)) {
-        uint32_t need = 0u, lo = 0x80u, hi = 0xbfu;  // continuation octets still owed, and the range of the next one
-        for (uint32_t p = cv; good & (p < ev); p += 4u) {
-          const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
-          const uint32_t keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
-          if ((need == 0u) & ((w & keep & 0x80808080u) == 0u)) continue;  // four ASCII octets between sequences
-          for (uint32_t k = 0; k < nb; k++) {
-            const uint32_t b = (w >> (8u * k)) & 0xffu;
-            if (need == 0u) {
-              if (b < 0x80u) {
-              } else if ((b >= 0xc2u) & (b <= 0xdfu)) {
-                need = 1u;
-              } else if ((b >= 0xe0u) & (b <= 0xefu)) {
-                need = 2u;
-                lo = b == 0xe0u ? 0xa0u : 0x80u;
-                hi = b == 0xedu ? 0x9fu : 0xbfu;
-              } else if ((b >= 0xf0u) & (b <= 0xf4u)) {
-                need = 3u;
-                lo = b == 0xf0u ? 0x90u : 0x80u;
-                hi = b == 0xf4u ? 0x8fu : 0xbfu;
-              } else {
-                good = false;
-              }
-            } else {
-              good = good & (b >= lo) & (b <= hi);
-              lo = 0x80u;
-              hi = 0xbfu;
-              need--;
-            }
-          }
-        }
-        good = good & (need == 0u);
-      }
-      x = e2;
-    }
-    a = e1;
-  }
-  return good;
 }
 
 // `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
@@ -603,7 +594,7 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // EC_DEFER (the map kernels): an EC key's curve equation is not evaluated here — Walk.ec_* says what is owed (spki_key.h).
 // strings: strict_strings inside the walk (round 4: the pre-pass of round 3 filled the same front window a second time,
 // +11.5 ms per 100 M certificates) — right behind each Name, while the window holds it, the character sets of its string
-// values are checked (name_strings_ok) and a violation is filed as WALK_NF_STRING.  The caller passes it only where the
+// values are checked (walk_name → value_strings_ok) and a violation is filed as WALK_NF_STRING.  The caller passes it only where the
 // finding can matter (a precertificate, a Chain[0] issuer — an X509 entry keeps its certificate either way).
 // STRINGS = false compiles the check out: the map kernels carry it in instantiations of their own (the code's mere presence
 // cost the default kernel 0.5 ms per 100 M certificates, A/B on one box, round 4).
@@ -679,8 +670,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   {
     const uint32_t n0 = q;
     o.issuer_name = q;
-    q = walk_name<true>(r, L, q, tbs_end, ok, o.cn_off, o.cn_len, o.nonfatal);
-    if (strings & ok) o.nonfatal |= name_strings_ok(r, L, n0, tbs_end) ? 0u : WALK_NF_STRING;
+    q = walk_name<true, STRINGS>(r, L, q, tbs_end, ok, o.cn_off, o.cn_len, o.nonfatal, strings);
     o.meta_issuer = meta_pack(n0, q - n0);
     note_issuer_if(r, n0, q - n0);  // readers that look the Name up while it is at hand (the map kernel's memo pre-check)
     if (use_filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, fv) : false;
@@ -706,8 +696,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
 #else
     uint32_t d0 = 0, d1 = 0;
     o.subject_name = q;
-    q = walk_name<false>(r, L, q, tbs_end, ok, d0, d1, o.nonfatal);
-    if (strings & ok) o.nonfatal |= name_strings_ok(r, L, o.subject_name, tbs_end) ? 0u : WALK_NF_STRING;
+    q = walk_name<false, STRINGS>(r, L, q, tbs_end, ok, d0, d1, o.nonfatal, strings);
 #endif
   }
   if constexpr (NAMES_ONLY) return ok;
@@ -860,9 +849,9 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
 }
 
 template <class R>
-CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr, bool spki = true) {
-  return filter ? walk_cert<R>(r, L, o, true, *filter, spki)
-                : walk_cert<R>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki);
+CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr, bool spki = true, bool strings = false) {
+  return filter ? walk_cert<R>(r, L, o, true, *filter, spki, strings)
+                : walk_cert<R>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki, strings);
 }
 template <class R>
 CTMR_HD bool walk_names(R& r, uint32_t L, Walk& o) {

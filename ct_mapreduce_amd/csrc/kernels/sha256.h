@@ -91,8 +91,8 @@ __global__ void CTMR_WALK_BOUNDS k_issuer_ids(const uint8_t* der, const uint64_t
   const uint32_t L = (uint32_t)(offsets[i + 1] - offsets[i]);
   Walk w;
   // any err of x509.ParseCertificate(Chain[0]) skips the entry, non-fatal findings included (ct-fetch.go:221-225)
-  bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w, nullptr, strict_spki != 0u) && w.nonfatal == 0u;
-  if (ok && strict_strings) ok = name_strings_ok(r, L, w.issuer_name, L) && name_strings_ok(r, L, w.subject_name, L);
+  bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w, nullptr, strict_spki != 0u, strict_strings != 0u) &&
+            w.nonfatal == 0u;  // strict_strings: a character-set finding in either Name is one more of them (WALK_NF_STRING)
   valid[i] = ok ? 1 : 0;
   uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (ok) sha256_lane(r, w.spki_off, w.spki_len, kc, dg);

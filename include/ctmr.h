@@ -235,10 +235,12 @@ int ctmr_reset_known(ctmr_engine* e);
 
 /* One rank's input of a multi-GPU round (ctmr_group_map_batch, ctmr_xchg_map_device): device pointers on that rank's
  * GPU, as ctmr_map_batch_device takes them; d_ends != NULL: an entry view (d_offsets = cert_start, d_ends = cert_end,
- * blob_bytes set).  order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown).  The
- * shards of one round must cover DISJOINT order ranges [order_base, order_base + n): two ranks that present the same new
- * key under the same order both keep WasUnknown (nothing tells them apart) — a host that leaves every order_base at 0 has
- * asked for that. */
+ * blob_bytes set).  order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown; owner
+ * mode derives the orders itself from the shards' sizes).  The shards of one Bloom round must cover order ranges
+ * [order_base, order_base + n) that ASCEND WITH THE RANK AND DO NOT OVERLAP — log-index shards do —: two ranks presenting
+ * the same new key under the same order would both keep WasUnknown.  ctmr_group_map_batch checks this over the whole
+ * group in the round's opening control row and fails on every rank with CTMR_E_INVAL otherwise (a host that leaves every
+ * order_base at 0 is told so, before anything is inserted). */
 typedef struct {
   const uint8_t* d_payload;
   const uint64_t* d_offsets;
@@ -348,9 +350,12 @@ int ctmr_bloom_apply_device(ctmr_engine* e, ctmr_record* d_records, uint64_t n, 
  *   shards  one ctmr_shard (above) per LOCAL rank, rank order.  Ranks hold CONTIGUOUS log-index ranges in rank order
  *           (rank r's entries all precede rank r+1's: ct-fetch's -offset/-limit split).  d_records is required in the
  *           OWNER and BLOOM modes.  stats: one per local rank (may be NULL).
- *   errors  a rank that fails inside a round keeps taking part in the round's collectives (its peers would block for
- *           ever otherwise) and every rank's call returns the error at the end; the sets of a failed round are
- *           unspecified — destroy the group. ---- */
+ *   errors  an exact round opens with a control row (status, mode, filter size, order range of every rank): a call a rank
+ *           must refuse — unknown mode, another mode than the group's, no filter configured, a bad shard, ranks that
+ *           disagree about any of these — fails THERE, on every rank together and before anything is inserted.  A rank
+ *           that fails later keeps taking part in the round's collectives (its peers would block for ever otherwise)
+ *           and every rank's call returns the error at the end; the sets of a round that failed after its opening row
+ *           are unspecified — destroy the group. ---- */
 typedef struct ctmr_group ctmr_group;
 #define CTMR_GROUP_ID_BYTES 128
 enum { CTMR_DEDUP_LOCAL = 0, CTMR_DEDUP_OWNER = 1, CTMR_DEDUP_BLOOM = 2 };
@@ -565,55 +570,8 @@ int ctmr_meta_reset(ctmr_engine* e);
 int ctmr_fingerprint_device(ctmr_engine* e, const uint8_t* d_payload, const uint64_t* d_offsets,
                             const uint64_t* d_ends, uint64_t n, uint8_t* d_digests, float* ms);
 
-/* ---- benchmark / test input generator (SURVEY.md §8(d) synthetic CT batch); not part of the
- *      reference's surface.  Deterministic in (seed, index); host and device emit identical bytes. */
-typedef struct {
-  uint64_t seed;
-  uint32_t n_issuers;      /* 1 or 256 … */
-  uint32_t zipf;           /* 1 = Zipf(s=1) issuer popularity, 0 = uniform */
-  uint32_t dup_permille;   /* entries re-emitting an earlier (issuer, serial, notAfter) */
-  uint32_t ca_permille;    /* basicConstraints CA:TRUE leaves (filter 1) */
-  uint32_t expired_permille; /* notAfter < base time (filter 2 when now == base) */
-  uint32_t mean_len;       /* 0 = 1536 */
-  int64_t base_time;       /* 0 = 2026-01-01T00:00:00Z */
-  uint32_t profile;        /* 0 = the SURVEY §8(d) corpus (RSA-2048 keys, 38-byte subjects, UTCTime);
-                              1 = mixed: half the keys EC P-256, 40 % OV-like subjects of 120…260 bytes, longer issuer
-                                  names for two issuers in three, one GeneralizedTime notAfter in four */
-  uint32_t reserved;
-} ctmr_synth_config;
-
-/* Length of synthetic leaf i / issuer certificate k, and their bytes (host side). */
-uint32_t ctmr_synth_leaf_len(const ctmr_synth_config* c, uint64_t i);
-uint32_t ctmr_synth_leaf(const ctmr_synth_config* c, uint64_t i, uint8_t* out, uint32_t cap,
-                         uint32_t* issuer_idx, uint8_t* entry_type);
-uint32_t ctmr_synth_issuer(const ctmr_synth_config* c, uint32_t k, uint8_t* out, uint32_t cap);
-/* Host batch [first, first+n): offsets u64[n+1] (relative), payload (capacity cap), issuer_idx,
- * entry_type.  Returns the payload bytes needed (nothing is written past cap). */
-uint64_t ctmr_synth_host(const ctmr_synth_config* c, uint64_t first, uint64_t n, uint64_t* offsets,
-                         uint8_t* payload, uint64_t cap, uint32_t* issuer_idx, uint8_t* entry_type);
-/* Generate entries [first, first+n) directly in HBM: d_offsets u64[n+1] (relative to the
- * batch start), d_payload (capacity payload_cap), d_issuer_idx u32[n], d_entry_type u8[n].
- * *payload_bytes = bytes written.  With d_payload == NULL only offsets are produced. */
-int ctmr_synth_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n,
-                      uint64_t* d_offsets, uint8_t* d_payload, uint64_t payload_cap,
-                      uint32_t* d_issuer_idx, uint8_t* d_entry_type, uint64_t* payload_bytes);
-
-/* The same certificates as an ENTRY VIEW with every certificate starting at a multiple of `align` bytes (a power of two
- * up to 4096): d_starts u64[n+1] (d_starts[n] = bytes used), d_ends u64[n]; feed it to ctmr_map_view_device.  What the map
- * moves per certificate depends on where certificates start inside 128-byte lines: a host that writes
- * its decoded entries at aligned offsets gets the difference for nothing.  With d_payload == NULL only the positions. */
-int ctmr_synth_view_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n, uint32_t align,
-                           uint64_t* d_starts, uint64_t* d_ends, uint8_t* d_payload, uint64_t payload_cap,
-                           uint32_t* d_issuer_idx, uint8_t* d_entry_type, uint64_t* payload_bytes);
-
-/* Raw get-entries form of the same synthetic entries (input of ctmr_decode_entries_*): entry i is
- * leaf_input ‖ extra_data with the certificate of ctmr_synth_leaf(i) as X509Entry (entry_type 0; extra_data = chain
- * [issuer]) or as PrecertChainEntry.pre_certificate (entry_type 1; the leaf carries issuer_key_hash + the TBS; chain
- * [issuer]).  bounds u64[2n+1] relative to the batch start.  Same conventions as ctmr_synth_host / _device. */
-uint64_t ctmr_synth_entries_host(const ctmr_synth_config* c, uint64_t first, uint64_t n, uint64_t* bounds,
-                                 uint8_t* blob, uint64_t cap);
-int ctmr_synth_entries_device(ctmr_engine* e, const ctmr_synth_config* c, uint64_t first, uint64_t n,
-                              uint64_t* d_bounds, uint8_t* d_blob, uint64_t blob_cap, uint64_t* blob_bytes);
+/* The synthetic CT corpus generator bench.py and the tests use (ctmr_synth_*) is declared in ctmr_bench.h: the same
+ * library exports it, but it is NOT part of the drop-in ABI — a host of the reference never binds it. */
 
 #ifdef __cplusplus
 }

@@ -98,14 +98,14 @@ extern "C" void harness_walk_tbs(const uint8_t* tbs, uint32_t len, uint8_t fill,
 }
 
 // strict_strings: the product's verdict on the character sets of the string values in both Names (der_walk.h
-// name_strings_ok) — 1 = fine, 0 = a finding, -1 = the certificate does not parse
+// walk_name → value_strings_ok) — 1 = fine, 0 = a finding, -1 = the certificate does not parse
 extern "C" int harness_name_strings(const uint8_t* der, uint32_t len, uint8_t fill) {
   std::vector<uint8_t> buf((size_t)len + 64, fill);
   memcpy(buf.data(), der, len);
   PaddedReader r{buf.data()};
   ctmr::Walk w;
-  if (!ctmr::walk_cert(r, len, w)) return -1;
-  return ctmr::name_strings_ok(r, len, w.issuer_name, len) && ctmr::name_strings_ok(r, len, w.subject_name, len) ? 1 : 0;
+  if (!ctmr::walk_cert(r, len, w, nullptr, g_spki, true)) return -1;
+  return (w.nonfatal & ctmr::WALK_NF_STRING) ? 0 : 1;
 }
 
 // What the walk READS: every ld4/ldg marks its four bytes.  Used by bench.py's "needed_bytes" accounting (the bytes and

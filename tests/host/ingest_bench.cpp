@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "ctmr.h"
+#include "ctmr_bench.h"
 
 static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "ctmr_storage.hpp"
+#include "ctmr_bench.h"          // the synthetic corpus (not part of the drop-in ABI)
 #include "ctmr_storage_mocks.hpp"  // the reference's test doubles (MockRemoteCache, MockBackend)
 
 #include <hip/hip_runtime_api.h>  // device buffers of the multi-GPU group test (host API only; g++ -D__HIP_PLATFORM_AMD__)

@@ -280,3 +280,67 @@ def test_signature_bit_string_rules():
     assert both(D.cert(sig=b"\x08\xff")).ok == 0
     assert both(D.cert(sig=b"\x03\xf8")).ok == 1
     assert both(D.cert(sig=b"\x03\xfc")).ok == 0
+
+
+def _attr(oid_tlv, value_tlv):
+    return D.seq(D.tlv(0x31, D.seq(oid_tlv, value_tlv)))
+
+
+def test_object_identifier_arcs_follow_parse_base128_int():
+    """parseObjectIdentifier / parseBase128Int: an arc is at most 5 octets, at most 2^31 - 1 (the first arc pair
+    included), complete, and not led by 0x80 ("integer is not minimally encoded")."""
+    val = D.tlv(0x0c, b"x")
+    good = [D.oid(0x55, 4, 3),
+            D.oid(0x2a, 0x87, 0xff, 0xff, 0xff, 0x7f),         # arc 2^31 - 1
+            D.oid(0x87, 0xff, 0xff, 0xff, 0x7f),               # the first octets may be a long arc too (2.x)
+            D.oid(0x2a, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x09, 0x0a, 0x0b, 0x0c, 0x0d, 0x0e, 0x0f, 0x10)]
+    bad = [D.oid(0x2a, 0x88, 0x80, 0x80, 0x80, 0x00),          # 2^31: "base 128 integer too large"
+           D.oid(0x2a, 0x8f, 0xff, 0xff, 0xff, 0x7f),          # 5 octets, above int32
+           D.oid(0x2a, 0x81, 0x80, 0x80, 0x80, 0x80, 0x00),    # 6 octets
+           D.oid(0x88, 0x80, 0x80, 0x80, 0x00),                # the same in first position
+           D.oid(0x2a, 0x03, 0x81),                            # truncated
+           D.oid(0x2a, 0x80, 0x01),                            # padded arc: not minimally encoded
+           D.oid(0x80, 0x2a),                                  # … in first position
+           D.oid()]                                            # empty
+    for o in good:
+        for where in ("subject", "issuer"):
+            assert both(D.cert(**{where: _attr(o, val)})).ok, (o.hex(), where)
+        assert both(D.cert(exts=[D.seq(o, D.tlv(0x04, b""))])).ok, o.hex()        # extnID
+    for o in bad:
+        for where in ("subject", "issuer"):
+            assert not both(D.cert(**{where: _attr(o, val)})).ok, (o.hex(), where)
+        assert not both(D.cert(exts=[D.seq(o, D.tlv(0x04, b""))])).ok, o.hex()
+    # AlgorithmIdentifier OIDs obey the same rule (tbs signature and the SPKI algorithm)
+    assert both(D.cert(spki=D.spki(bytes.fromhex("2a87ffffff7f"), D.NULL, b"\x01\x02"))).ok
+    assert not both(D.cert(spki=D.spki(bytes.fromhex("2a8880808000"), D.NULL, b"\x01\x02"))).ok
+
+
+def test_name_values_of_the_types_go_decodes():
+    """An AttributeTypeAndValue's Value is an interface{}: INTEGER, BIT STRING, OBJECT IDENTIFIER and the two time types
+    are decoded by their tag and a malformed one fails the Name; every other type is taken as it is."""
+    t = D.oid(0x55, 4, 5)
+    good = [D.tlv(0x02, b"\x01"), D.tlv(0x02, b"\x7f" + b"\xff" * 7), D.tlv(0x02, b"\xff"),          # int64
+            D.tlv(0x03, b"\x00"), D.tlv(0x03, b"\x07\x80"), D.tlv(0x03, b"\x00\xa5\x5a"),
+            D.tlv(0x06, b"\x2a\x03"), D.tlv(0x06, b"\x2a\x87\xff\xff\xff\x7f"),
+            D.utctime("250101000000Z"), D.gentime("20250101000000Z"), D.utctime("2501010000Z"),
+            D.tlv(0x04, b"\xff\xff"), D.tlv(0x01, b"\x42"), D.tlv(0x05, b"x"), D.tlv(0x30, b"\xff"),    # not looked into
+            D.tlv(0x1e, b"\x00"), D.tlv(0x14, b"\xff"), D.tlv(0x82, b"\xff"), D.tlv(0x0a, b"")]
+    bad = [D.tlv(0x02, b""), D.tlv(0x02, b"\x01" + b"\x00" * 8),                                      # empty; 9 octets
+           D.tlv(0x03, b""), D.tlv(0x03, b"\x08\x00"), D.tlv(0x03, b"\x01\x01"), D.tlv(0x03, b"\x01"),
+           D.tlv(0x06, b""), D.tlv(0x06, b"\x2a\x81"), D.tlv(0x06, b"\x2a\x88\x80\x80\x80\x00"),
+           D.utctime("250101000000"), D.utctime("251301000000Z"), D.gentime("20250101000000+0000"),
+           D.tlv(0x17, b""), D.tlv(0x18, b"2025")]
+    for v in good:
+        for where in ("subject", "issuer"):
+            assert both(D.cert(**{where: _attr(t, v)})).ok, (v.hex(), where)
+    for v in bad:
+        for where in ("subject", "issuer"):
+            assert not both(D.cert(**{where: _attr(t, v)})).ok, (v.hex(), where)
+    # a not minimally encoded INTEGER is what only the lax re-parse takes: a non-fatal finding, as for the serial number
+    lax = both(D.cert(subject=_attr(t, D.tlv(0x02, b"\x00\x01"))))
+    assert lax.ok and lax.nonfatal & 2
+    # the same value types behind a long-form attribute (the walk's general path) and inside a multi-valued RDN
+    multi = D.seq(D.tlv(0x31, D.seq(t, D.tlv(0x0c, b"x")) + D.seq(t, D.tlv(0x03, b"\x08\x00"))))
+    assert not both(D.cert(subject=multi)).ok
+    long_form = D.seq(D.tlv(0x31, D.seq(t, b"\x02\x81\x01\x05")))
+    assert not both(D.cert(subject=long_form)).ok          # the value's length is not minimally encoded

@@ -209,3 +209,45 @@ def test_point_inserted_keys_are_in_the_filter():
     g.close()
     for e in engines:
         e.close()
+
+
+def test_a_round_the_group_must_refuse_fails_before_anything_is_inserted():
+    """The opening control row of an exact round (group.inc round_header): overlapping or descending order ranges in a
+    Bloom round, a Bloom round without a filter, an unknown mode and a second mode on one group are refused on every rank
+    with nothing inserted — and the group is still usable afterwards."""
+    world = 2
+    cfg = synth.config(seed=68, n_issuers=2)
+    issuers = synth.issuers(cfg)
+    engines, g = build_world(world, issuers, 1 << 14)
+    shards, keep, ranges = load_shards(cfg, 0, 400, world)
+    same = [dev_shard(keep[0], 200, order_base=0), dev_shard(keep[1], 200, order_base=0)]          # the forgotten order_base
+    down = [dev_shard(keep[0], 200, order_base=200), dev_shard(keep[1], 200, order_base=0)]
+    lap = [dev_shard(keep[0], 200, order_base=0), dev_shard(keep[1], 200, order_base=199)]
+    for bad in (same, down, lap):
+        with pytest.raises(ctmr.CtmrError, match="order ranges"):
+            g.map_batch("bloom", bad)
+        assert g.total_count() == 0
+    with pytest.raises(ctmr.CtmrError):
+        g.map_batch(7, shards)
+    assert g.total_count() == 0
+    b = synth.host_batch(cfg, 0, 400)
+    o, st, unk, eh = run_oracle(b, issuers, FILT, False, NOW)
+    stats = g.map_batch("bloom", shards)                                                          # the proper round still runs
+    check_round(keep, ranges, stats, st, unk)
+    with pytest.raises(ctmr.CtmrError, match="group of its own"):
+        g.map_batch("owner", shards)
+    assert g.total_count() == int(unk.sum())
+    g.close()
+    for e in engines:
+        e.close()
+    # no filter configured: refused through the same row
+    engines = [make_engine(issuers) for _ in range(world)]
+    g = Group.local(engines)
+    with pytest.raises(ctmr.CtmrError, match="bloom_config"):
+        g.map_batch("bloom", shards)
+    assert g.total_count() == 0
+    stats = g.map_batch("owner", shards)                                                          # the refused call did not fix the mode
+    assert sum(s.n_new for s in stats) == int(unk.sum())
+    g.close()
+    for e in engines:
+        e.close()
