@@ -1148,6 +1148,7 @@ def main():
                      "frac_of_streaming_ceiling": (traffic / (avg_ms * 1e-3) / 1e9 / 6290.0) if traffic else None,
                      "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                     "launch_ms": [round(m, 3) for m in ms_map],
                      "alg_bytes_formula": "sum(L_i) + 45*E" + (" + 64*PASS (table probe)" if fused_variant else "")
                                           + (" with L_i = the certificate the map parses (not the blob)" if args.raw else "")},
         "kernel_ms": {"map": stats.ms_map, "insert": stats.ms_insert, "resolve": stats.ms_resolve,

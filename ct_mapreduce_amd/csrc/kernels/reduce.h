@@ -699,51 +699,65 @@ constexpr uint32_t RES_LDS_ISSUERS = 4096;
 __global__ void __launch_bounds__(1024) k_resolve(ResolveArgs a, uint64_t nb) {
   __shared__ uint32_t hist[CTMR_ST__COUNT + 5];
   __shared__ uint32_t ih[RES_LDS_ISSUERS];
-  __shared__ uint32_t blk_cnt;
+  __shared__ uint32_t blk_cnt[4];
   if (threadIdx.x < CTMR_ST__COUNT + 5) hist[threadIdx.x] = 0;
   for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024) ih[k] = 0;
   __syncthreads();
-  for (uint64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
-    if (threadIdx.x == 0) blk_cnt = 0;
+  // Four entries per thread, one 16-byte load: a workgroup takes FOUR 1024-entry blocks per step (threads 256q..256q+255
+  // hold block q's entries), so that it has four times the bytes in flight between its barriers — with one entry per
+  // thread the kernel ran at the ≈ 1 TB/s that 2 048 four-byte loads per CU and round trip give (0.40 ms per 100 M).
+  const uint64_t nsb = (nb + 3) / 4;
+  for (uint64_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+    if (threadIdx.x < 4) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t i = blk * 1024 + threadIdx.x;
-    bool is_new = false, is_dup = false, is_host = false, is_full = false, is_remote = false;
-    uint32_t status = CTMR_ST__COUNT, canon = 0;
-    if (i < a.n) {
-      const uint32_t e = a.ent[i];
-      status = e & 7u;
-      const uint32_t st = ent_state(e);
-      canon = e >> 8;
-      is_new = (st == ES_CLAIMED) | (st == ES_DEFER);
-      is_dup = st == ES_DUP;
-      is_host = st == ES_HOST;
-      is_full = st == ES_FULL;
-      is_remote = st == ES_REMOTE;  // counted where it is stored: by the key's owner (k_keys_resolve)
-    }
-    if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
-    wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, a.issuer_counts);
-    is_new = is_new | is_remote;  // from here on: "in the NEW list" (optimistically, for a key that left)
-    // (the per-(expDate, issuer) cardinalities are rebuilt lazily by k_build_pairs on the first
-    //  SetCardinality/KeysToChan after a mutation — they are statistics, not hot-path state)
-    const unsigned long long m_new = __ballot(is_new), m_dup = __ballot(is_dup),
-                             m_host = __ballot(is_host), m_full = __ballot(is_full), m_rem = __ballot(is_remote);
-    if ((threadIdx.x & 63) == 0) {
-      if (m_rem) atomicAdd(&hist[CTMR_ST__COUNT + 4], (uint32_t)__popcll(m_rem));
-      if (m_new) {
-        atomicAdd(&blk_cnt, (uint32_t)__popcll(m_new));
-        atomicAdd(&hist[CTMR_ST__COUNT], (uint32_t)__popcll(m_new));
+    const uint64_t i0 = sb * 4096 + (uint64_t)threadIdx.x * 4u;
+    uint32_t e[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // status 7 with state 7: counted nowhere
+    bool live[4] = {false, false, false, false};
+    if (i0 + 4 <= a.n) {
+      const uint4 v = *(const uint4*)(a.ent + i0);
+      e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+      live[0] = live[1] = live[2] = live[3] = true;
+    } else {
+      for (uint32_t k = 0; i0 + k < a.n; k++) {
+        e[k] = a.ent[i0 + k];
+        live[k] = true;
       }
-      if (m_dup) atomicAdd(&hist[CTMR_ST__COUNT + 1], (uint32_t)__popcll(m_dup));
-      if (m_host) atomicAdd(&hist[CTMR_ST__COUNT + 2], (uint32_t)__popcll(m_host));
-      if (m_full) atomicAdd(&hist[CTMR_ST__COUNT + 3], (uint32_t)__popcll(m_full));
     }
+    uint32_t w_new = 0, w_dup = 0, w_host = 0, w_full = 0, w_rem = 0;
 #pragma unroll
-    for (uint32_t st = 0; st < CTMR_ST__COUNT; st++) {
-      const unsigned long long m = __ballot(status == st);
-      if ((threadIdx.x & 63) == 0 && m) atomicAdd(&hist[st], (uint32_t)__popcll(m));
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t status = live[k] ? (e[k] & 7u) : (uint32_t)CTMR_ST__COUNT;
+      const uint32_t st = ent_state(e[k]), canon = e[k] >> 8;
+      bool is_new = live[k] & ((st == ES_CLAIMED) | (st == ES_DEFER));
+      const bool is_remote = live[k] & (st == ES_REMOTE);  // counted where it is stored: by the key's owner (k_keys_resolve)
+      if (is_new && canon < RES_LDS_ISSUERS) atomicAdd(&ih[canon], 1u);
+      wave_agg_add(is_new && canon >= RES_LDS_ISSUERS, canon, a.issuer_counts);
+      is_new = is_new | is_remote;  // from here on: "in the NEW list" (optimistically, for a key that left)
+      // (the per-(expDate, issuer) cardinalities are rebuilt lazily by k_build_pairs on the first
+      //  SetCardinality/KeysToChan after a mutation — they are statistics, not hot-path state)
+      w_new += (uint32_t)__popcll(__ballot(is_new));
+      w_dup += (uint32_t)__popcll(__ballot(live[k] & (st == ES_DUP)));
+      w_host += (uint32_t)__popcll(__ballot(live[k] & (st == ES_HOST)));
+      w_full += (uint32_t)__popcll(__ballot(live[k] & (st == ES_FULL)));
+      w_rem += (uint32_t)__popcll(__ballot(is_remote));
+#pragma unroll
+      for (uint32_t s = 0; s < CTMR_ST__COUNT; s++) {
+        const unsigned long long m = __ballot(status == s);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&hist[s], (uint32_t)__popcll(m));
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (w_rem) atomicAdd(&hist[CTMR_ST__COUNT + 4], w_rem);
+      if (w_new) {
+        atomicAdd(&blk_cnt[threadIdx.x >> 8], w_new);
+        atomicAdd(&hist[CTMR_ST__COUNT], w_new);
+      }
+      if (w_dup) atomicAdd(&hist[CTMR_ST__COUNT + 1], w_dup);
+      if (w_host) atomicAdd(&hist[CTMR_ST__COUNT + 2], w_host);
+      if (w_full) atomicAdd(&hist[CTMR_ST__COUNT + 3], w_full);
     }
     __syncthreads();
-    if (threadIdx.x == 0) a.blk_new[blk] = blk_cnt;
+    if (threadIdx.x < 4 && sb * 4 + threadIdx.x < nb) a.blk_new[sb * 4 + threadIdx.x] = blk_cnt[threadIdx.x];
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < RES_LDS_ISSUERS; k += 1024)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # what the driver does at round end (build check, smoke, GPU tests, default bench) + the profiled run of the same command
-# and the secondary bench lines DESIGN.md quotes.  Round 3 set.
+# and the secondary bench lines DESIGN.md quotes.  Round 4 set.
 set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; mkdir -p $OUT; rm -rf $OUT/*
 cd $R
@@ -35,4 +35,7 @@ for m in "--raw" "--raw --meta --pem" "--meta" "--stream 1000000000" "--global-d
 r=d['roofline']
 print('$m', d['value'], d['ms_per_step'], 'frac', r['frac'], 'alg', r.get('frac_algorithmic'), r.get('invalid'), d.get('kernel_ms'), d.get('exchange',{}).get('ms_phase_rank0'), (d.get('roofline_decode_match') or {}).get('frac'), d.get('result',{}).get('duplicate_structure_matches_generator_in_every_wave'))" $OUT/bench_$tag.json || tail -3 $OUT/bench_$tag.err
 done
-timeout 600 python scripts/rank_cost_at_world.py 12500000 8 > $OUT/rank_cost_12m5_w8.json 2>&1; tail -1 $OUT/rank_cost_12m5_w8.json | cut -c1-400
+for spec in "50000000 2" "25000000 4" "12500000 8"; do
+  set -- $spec
+  timeout 600 python scripts/rank_cost_at_world.py $1 $2 > $OUT/rank_cost_$1_w$2.json 2>&1; tail -1 $OUT/rank_cost_$1_w$2.json | cut -c1-600
+done
