@@ -78,6 +78,12 @@ class IssuerInfo(C.Structure):
                 ("issuer_id", C.c_char * 48)]
 
 
+class TableInfo(C.Structure):
+    _fields_ = [("slots", C.c_uint64), ("occupied", C.c_uint64), ("arena_cells", C.c_uint64), ("arena_used", C.c_uint64),
+                ("rebuilds", C.c_uint64), ("arena_compactions", C.c_uint64), ("arena_growths", C.c_uint64),
+                ("reserved", C.c_uint64)]
+
+
 class SynthConfig(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_issuers", C.c_uint32), ("zipf", C.c_uint32),
                 ("dup_permille", C.c_uint32), ("ca_permille", C.c_uint32),
@@ -123,6 +129,7 @@ SIGNATURES = {
     "ctmr_total_count": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ctmr_issuer_counts_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
     "ctmr_reset_known": (C.c_int, [_P]),
+    "ctmr_table_info_get": (C.c_int, [_P, C.POINTER(TableInfo)]),
     "ctmr_xchg_map_device": (C.c_int, [_P, C.POINTER(Shard), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)]),
     "ctmr_xchg_keys_device": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint64)]),

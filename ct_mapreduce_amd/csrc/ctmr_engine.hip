@@ -191,6 +191,7 @@ struct ctmr_engine {
   uint64_t max_slots = 0;   // growth limit (config.max_table_slots; at most 2^31: slot ids are 32-bit)
   uint64_t occupied = 0;    // slots claimed since the table was last (re)built: live members + tombstones
   uint32_t rebuilds = 0;
+  uint32_t arena_compactions = 0, arena_growths = 0;
   PairSlot* pairs = nullptr;
   uint64_t npairs = 0;
   unsigned long long* issuer_counts = nullptr;
@@ -343,7 +344,7 @@ int upload_filter(ctmr_engine* e) {
   return CTMR_OK;
 }
 
-int ensure_capacity(ctmr_engine* e, uint64_t incoming);
+int ensure_capacity(ctmr_engine* e, uint64_t incoming, bool round_start = false);
 
 // in-place prefix sum of n u64 on the engine's stream (reduce.h: k_scan64_*); tile sums live in scratch buffer `which`
 int scan_u64(ctmr_engine* e, uint64_t* d_data, uint64_t n, bool inclusive, int which) {
@@ -394,9 +395,31 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
 // the batch as a new key (which ones are duplicates is what the call is about to find out), so a capped table
 // (max_table_slots) may refuse a batch of mostly-known entries that would have fitted.
 // The arena: `incoming` more cells behind arena_used.  Grows by doubling; the cells keep their places (every index word
-// stays valid), the old block is copied device to device and freed.
-static int ensure_arena(ctmr_engine* e, uint64_t incoming) {
+// stays valid), the old block is copied device to device and freed.  At the START of a round (never inside one: a round's
+// own cells are told from older ones by their position) unreferenced cells are squeezed out instead, when that alone makes
+// room and at least a quarter of the used cells is garbage (k_arena_compact; `occupied` — the index slots claimed since
+// the last rebuild, tombstones included — bounds the live cells from above).
+static int ensure_arena(ctmr_engine* e, uint64_t incoming, bool round_start) {
   if (e->arena_used + incoming <= e->arena_cap) return CTMR_OK;
+  if (round_start && e->occupied + incoming <= e->arena_cap && e->occupied * 4 <= e->arena_used * 3) {
+    KeyCell* na = nullptr;
+    if (hipMalloc(&na, e->arena_cap * sizeof(KeyCell)) == hipSuccess) {
+      HIPCHK(e, hipMemsetAsync(e->d_count, 0, 8, e->stream));
+      hipLaunchKernelGGL(k_arena_compact, dim3((unsigned)((e->nslots + 255) / 256)), dim3(256), 0, e->stream, e->index,
+                         e->nslots, (const KeyCell*)e->arena, na, e->d_count);
+      unsigned long long live = 0;
+      HIPCHK(e, hipMemcpyAsync(&live, e->d_count, 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      HIPCHK(e, hipGetLastError());
+      (void)hipFree(e->arena);
+      e->arena = na;
+      e->arena_used = live;
+      e->arena_compactions++;
+      if (e->arena_used + incoming <= e->arena_cap) return CTMR_OK;
+    } else {
+      (void)hipGetLastError();  // no room for a second arena of this size: fall through to the exact-size growth below
+    }
+  }
   uint64_t want = e->arena_cap ? e->arena_cap : 1024;
   while (want < e->arena_used + incoming) want *= 2;
   if (want > (1ull << 40)) return fail(e, CTMR_E_FULL, "known-certificate arena: more than 2^40 key cells");
@@ -414,12 +437,13 @@ static int ensure_arena(ctmr_engine* e, uint64_t incoming) {
   (void)hipFree(e->arena);
   e->arena = na;
   e->arena_cap = want;
+  e->arena_growths++;
   return CTMR_OK;
 }
 
-int ensure_capacity(ctmr_engine* e, uint64_t incoming) {
+int ensure_capacity(ctmr_engine* e, uint64_t incoming, bool round_start) {
   int ar;
-  if ((ar = ensure_arena(e, incoming))) return ar;  // one cell per entry / received key / point insert
+  if ((ar = ensure_arena(e, incoming, round_start))) return ar;  // one cell per entry / received key / point insert
   if ((e->occupied + incoming) * 4 <= e->nslots * 3) return CTMR_OK;
   // how many members are alive decides the new size: count them with the rebuild itself when tombstones may exist
   uint64_t want = pow2_at_least((e->occupied + incoming) * 2);

@@ -412,7 +412,7 @@ namespace ctmr {
 CTMR_HD bool string_word_ok(uint32_t tag, uint32_t w) {
   const uint32_t H = 0x80808080u;
   const auto ge = [](uint32_t x, uint32_t c) { return x + (0x80u - c) * 0x01010101u; };
-  const auto eq = [H](uint32_t x, uint32_t c) { return H - (x ^ (c * 0x01010101u)); };
+  const auto eq = [](uint32_t x, uint32_t c) { return 0x80808080u - (x ^ (c * 0x01010101u)); };
   uint32_t okb;
   if (tag == 0x13u) {
     const uint32_t lw = w | 0x20202020u;  // A-Z onto a-z; nothing else lands in a-z

@@ -254,19 +254,33 @@ __global__ void __launch_bounds__(1024) k_keys_resolve(const Rec* keys, uint64_t
 template <class Rec>
 __global__ void __launch_bounds__(256) k_apply_lost(const Rec* sent, const uint8_t* flags, uint64_t n_keys, InsertArgs loc,
                                                     ctmr_record* records, uint32_t* blk_new, unsigned long long* lost) {
-  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  bool lose = false;
-  if (k < n_keys && flags[k] == 0) {
-    const uint32_t ord = ((const uint32_t*)(sent + k))[sizeof(Rec) == 32 ? 7 : 14];
-    const uint32_t li = ord - loc.ord_base;
-    if ((uint64_t)li < loc.n && ent_state(loc.ent[li]) == ES_REMOTE) {
-      mark_dup(loc.ent, records, li);
-      atomicSub(&blk_new[li >> 10], 1u);
-      lose = true;
+  // Four records per thread and ONE atomic on the global counter per workgroup: with one per wave (160 000 of them on one
+  // address for 10 M records, nearly every wave holding a loser) the counter's serialisation was the kernel — 1.85 ms per
+  // 10.3 M records, more than the owner-side insert of the same records (round 4, rocprofv3 of rank_cost_at_world.py).
+  __shared__ uint32_t blk_lost;
+  if (threadIdx.x == 0) blk_lost = 0;
+  __syncthreads();
+  const uint64_t k0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4u;
+  uint32_t mine = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < 4; q++) {
+    const uint64_t k = k0 + q;
+    if (k < n_keys && flags[k] == 0) {
+      const uint32_t ord = ((const uint32_t*)(sent + k))[sizeof(Rec) == 32 ? 7 : 14];
+      const uint32_t li = ord - loc.ord_base;
+      if ((uint64_t)li < loc.n && ent_state(loc.ent[li]) == ES_REMOTE) {
+        mark_dup(loc.ent, records, li);
+        atomicSub(&blk_new[li >> 10], 1u);
+        mine++;
+      }
     }
   }
-  const unsigned long long m = __ballot(lose);
-  if (m && (threadIdx.x & 63) == 0) atomicAdd(lost, (unsigned long long)__popcll(m));
+  // (count per wave: three ballots over the bits of 0..4)
+  const unsigned long long b0 = __ballot(mine & 1u), b1 = __ballot(mine & 2u), b2 = __ballot(mine & 4u);
+  const uint32_t wsum = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+  if (wsum && (threadIdx.x & 63) == 0) atomicAdd(&blk_lost, wsum);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_lost) atomicAdd(lost, (unsigned long long)blk_lost);
 }
 
 // ------------------------------------------------------------------ cross-GPU dedup, Bloom pre-filter variant

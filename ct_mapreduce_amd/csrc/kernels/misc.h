@@ -154,6 +154,40 @@ __global__ void __launch_bounds__(256) k_rehash(const unsigned long long* old_in
   atomicAdd(moved, 1ull);
 }
 
+// Arena compaction: a batch reserves one cell per ENTRY, and the cell of an entry that was not new (a duplicate, a filtered
+// certificate) is never referenced — in a deployment that keeps meeting known certificates (a restart that re-reads a log,
+// overlapping fetch ranges) those cells would fill the arena with nothing.  Before a round that does not fit any more, and
+// when at least a quarter of the used cells is garbage, the live cells are moved into a fresh arena: every live index
+// word (the words stay where they are: a word's slot depends on the key's hash only) gets the next free cell of the new
+// arena, wave-aggregated, and its ref is rewritten in place.  Cells lose their entry order, which nothing relies on
+// between rounds ("earlier round" = ref < ref0 still holds: every moved cell lies below the next round's ref0).
+__global__ void __launch_bounds__(256) k_arena_compact(unsigned long long* index, uint64_t nslots, const KeyCell* old_arena,
+                                                       KeyCell* new_arena, unsigned long long* used) {
+  __shared__ uint32_t wcnt[4];
+  __shared__ unsigned long long blk_base;
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long w = j < nslots ? index[j] : 0ull;
+  const bool live = (w != 0ull) & (w != IDX_TOMB);
+  const unsigned long long m = __ballot(live);
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic on the shared counter per workgroup
+    const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    blk_base = tot ? atomicAdd(used, (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  if (!live) return;
+  unsigned long long base = blk_base;
+  for (uint32_t k = 0; k < wv; k++) base += wcnt[k];
+  const unsigned long long nref = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+  const uint4* src = (const uint4*)(old_arena + (w & REF_MASK));
+  uint4* dst = (uint4*)(new_arena + nref);
+  const uint4 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+  dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
+  index[j] = (w & ~REF_MASK) | nref;
+}
+
 // Rebuild the (expDate, issuer) → SCARD table from the known-certificate table (lazy: only the
 // statistics-style queries SetCardinality / Exists / KeysToChan need it).
 __global__ void __launch_bounds__(256) k_build_pairs(Table t, PairSlot* pairs, uint64_t pmask, unsigned long long* full) {

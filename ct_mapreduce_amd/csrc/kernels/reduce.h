@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
     if (fl_out != ((r0.x >> 8) & 0xffu)) ((uint8_t*)(a.records + i))[1] = (uint8_t)fl_out;
     a.ent[i] = ent_pack(status, state, canon) | (pending ? ENT_KEY_PENDING : 0u);
     const unsigned long long mp = __ballot(pending);
-    if (mp && lane == (uint32_t)(__ffsll((long long)mp) - 1)) atomicAdd(&a.stats->n_pending, (unsigned long long)__popcll(mp));
+    if (mp && lane == (uint32_t)(__ffsll((long long)mp) - 1) && ld_agent(&a.stats->n_pending) == 0ull)
+      st_agent(&a.stats->n_pending, 1ull);  // a flag, not a count (see k_map_fused)
   }
   const uint64_t first = (uint64_t)blockIdx.x * 256 + 64u * wv;
   if (first < a.n)
@@ -500,9 +501,11 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   // the wave's 64 key cells, arena[ref0 + first …): one contiguous 4 KiB store (the window area is free by now)
   if (first < a.n)
     store_cells_wave(ia.t.arena + ia.ref0 + first, a.n - first, (uint4*)smem, lane, keyed, kmeta, ks, ia.ord_base + (uint32_t)i);
-  {  // strict_spki: how many entries owe k_ec_resolve a curve equation (0 in a batch of RSA keys: it exits at once)
+  {  // strict_spki: does any entry owe k_ec_resolve a curve equation?  (No, in a batch of RSA keys: it exits at once.)  A flag
+     // that the first waves set, not a count: on the mixed corpus nearly every wave has such entries, and 1.5 M atomics on
+     // one address serialise at the memory side behind the kernel's back.
     const unsigned long long mp = __ballot(pending);
-    if (mp && lane == 0) atomicAdd(&ia.stats->n_pending, (unsigned long long)__popcll(mp));
+    if (mp && lane == 0 && ld_agent(&ia.stats->n_pending) == 0ull) st_agent(&ia.stats->n_pending, 1ull);
     if constexpr (MODE != XM_OWNER) {
       if (pending) a.keypos[i] = keypos;
     }

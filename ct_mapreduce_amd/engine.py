@@ -569,6 +569,12 @@ class Engine:
     def reset_known(self):
         self._ck(self._lib.ctmr_reset_known(self._h))
 
+    def table_info(self) -> N.TableInfo:
+        """How full the known-certificate table is: index slots / occupied, arena cells / used, rebuilds, compactions."""
+        out = N.TableInfo()
+        self._ck(self._lib.ctmr_table_info_get(self._h, C.byref(out)))
+        return out
+
     # ---- synthetic input (bench / tests)
     def synth_view_device(self, cfg: N.SynthConfig, first, n, align, d_starts, d_ends, d_payload, payload_cap,
                           d_issuer_idx, d_entry_type) -> int:

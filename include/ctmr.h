@@ -233,6 +233,20 @@ int ctmr_issuer_counts_device(ctmr_engine* e, void** d_counts, uint32_t* n);
 /* Drop every known certificate (table, pair counts, counters, host-side sets keep keys). */
 int ctmr_reset_known(ctmr_engine* e);
 
+/* How full the known-certificate table is (what `INFO memory` / `DBSIZE` tell the operator of the reference's Redis,
+ * storage/rediscache.go:21-45).  The table is an index of 8-byte words (slots) over an arena of 64-byte key cells; a batch
+ * takes one cell per entry and cells of entries that were not new are squeezed out again when the arena runs short
+ * (arena_compactions), before it is grown (arena_growths); the index is rebuilt at load 3/4 (rebuilds). */
+typedef struct {
+  uint64_t slots;              /* index words */
+  uint64_t occupied;           /* index words claimed since the last rebuild: live members + tombstones */
+  uint64_t arena_cells;        /* capacity of the key-cell arena */
+  uint64_t arena_used;         /* cells handed out (live + not yet squeezed out) */
+  uint64_t rebuilds, arena_compactions, arena_growths;
+  uint64_t reserved;
+} ctmr_table_info;
+int ctmr_table_info_get(ctmr_engine* e, ctmr_table_info* out);
+
 /* One rank's input of a multi-GPU round (ctmr_group_map_batch, ctmr_xchg_map_device): device pointers on that rank's
  * GPU, as ctmr_map_batch_device takes them; d_ends != NULL: an entry view (d_offsets = cert_start, d_ends = cert_end,
  * blob_bytes set).  order_base = log index of the shard's entry 0 (Bloom mode: the lowest order keeps WasUnknown; owner

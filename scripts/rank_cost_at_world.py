@@ -81,7 +81,8 @@ def main():
     best = min(ph[1:], key=lambda p: sum(p[:4]))
     out["owner"] = {"map_and_local_insert_and_counts_ms": best[0], "partition_gather_ms": best[1],
                     "owner_insert_of_as_many_records_and_resolve_ms": best[2], "apply_and_compaction_ms": best[3],
-                    "sum_ms": sum(best[:4]), "records_exported": best[4], "record_bytes_to_the_wire": best[4] * 32 + best[4]}
+                    "sum_ms": sum(best[:4]), "records_exported": best[4], "record_bytes_to_the_wire": best[4] * 32 + best[4],
+                    "n_new_after_apply": best[5]}
     # ---- Bloom variant, this rank's side
     bits = pow2(16 * E)
     d_filters = torch.zeros(W * bits // 8, dtype=torch.uint8, device=dev)

@@ -92,6 +92,51 @@ def test_table_grows_and_recovers_tombstones():
     eng.close()
 
 
+def test_the_arena_squeezes_out_the_cells_of_known_certificates():
+    """A batch takes one key cell per ENTRY; the cells of entries that were not new are garbage.  A deployment that keeps
+    meeting known certificates (a restart that re-reads a log) must not grow for it: before a round that does not fit the
+    arena any more the live cells are compacted (k_arena_compact) — same answers, same sets, no growth."""
+    cfg = synth.config(seed=31, n_issuers=6, dup_permille=100)
+    issuers = synth.issuers(cfg)
+    eng = ctmr.Engine(device=0, table_slots=1 << 13, pair_slots=1 << 14)      # arena: 4 096 cells to begin with
+    eng.add_issuers(issuers)
+    eng.set_filter(b"", True, NOW)
+    o = orc.Engine(b"", True, NOW)
+    io = np.zeros(len(issuers) + 1, np.uint64)
+    io[1:] = np.cumsum([len(x) for x in issuers])
+    blob = np.frombuffer(b"".join(issuers), np.uint8)
+    assert eng.table_info().arena_cells == 4096
+    b = synth.host_batch(cfg, 0, 1500)
+    for rnd in range(14):                             # the same 1 500 entries again and again: 21 000 cells without squeezing
+        res = eng.map_batch(b)
+        st, unk, _ = o.batch(b.payload, b.offsets, b.issuer_idx, blob, io, entry_type=b.entry_type)
+        assert (((res.records["flags"] & 2) != 0) == (unk != 0)).all(), rnd
+        assert (res.records["status"] == st).all()
+    ti = eng.table_info()
+    assert ti.arena_cells == 4096 and ti.arena_compactions >= 3 and ti.arena_growths == 0 and ti.rebuilds == 0
+    assert ti.arena_used <= ti.occupied + 1500 and ti.occupied == eng.total_count() == o.total_count()
+    # new members after compactions: cells are handed out behind the squeezed ones; removal and re-insert still work
+    b2 = synth.host_batch(cfg, 5000, 1200)
+    res = eng.map_batch(b2)
+    st, unk, _ = o.batch(b2.payload, b2.offsets, b2.issuer_idx, blob, io, entry_type=b2.entry_type)
+    assert (((res.records["flags"] & 2) != 0) == (unk != 0)).all()
+    assert eng.total_count() == o.total_count()
+    assert sorted(eng.keys(b"serials::*")) == [k for k in o.keys() if k.startswith(b"serials::")]
+    key = sorted(eng.keys(b"serials::*"))[3]
+    assert eng.set_list(key) == o.members(key)
+    counts = eng.issuer_counts()
+    for k in range(len(issuers)):
+        assert int(counts[k]) == o.issuer_count(eng.issuer_id(k))
+    # a batch larger than what squeezing frees: the arena grows as before
+    b3 = synth.host_batch(cfg, 20000, 9000)
+    res = eng.map_batch(b3)
+    st, unk, _ = o.batch(b3.payload, b3.offsets, b3.issuer_idx, blob, io, entry_type=b3.entry_type)
+    assert (((res.records["flags"] & 2) != 0) == (unk != 0)).all()
+    ti = eng.table_info()
+    assert ti.arena_growths >= 1 and ti.rebuilds >= 1 and eng.total_count() == o.total_count()
+    eng.close()
+
+
 def test_members_inserted_before_their_issuer_is_registered_are_migrated():
     """a Redis restore (storage.redis_load) or a RemoteCache.SetInsert ahead of add_issuers put
     `serials::` members of a not-yet-registered issuer ID into the host-side store, where the map's dedup never
