@@ -505,13 +505,11 @@ static int key_integer(const uint8_t* k, uint64_t p, uint64_t end, int* sign, ui
   return ci;
 }
 
+static int hex_nibble(char c) { return c <= '9' ? c - '0' : (c | 0x20) - 'a' + 10; }
 static int bytes_are(const uint8_t* d, uint32_t n, const char* hex) {
   if (strlen(hex) != 2 * (size_t)n) return 0;
-  for (uint32_t i = 0; i < n; i++) {
-    unsigned v;
-    sscanf(hex + 2 * i, "%2x", &v);
-    if (d[i] != v) return 0;
-  }
+  for (uint32_t i = 0; i < n; i++)
+    if (d[i] != (uint8_t)(hex_nibble(hex[2 * i]) << 4 | hex_nibble(hex[2 * i + 1]))) return 0;
   return 1;
 }
 
@@ -533,8 +531,9 @@ static void check_public_key(const uint8_t* d, uint64_t k, uint64_t k_end, orc_c
   uint64_t bc = bp + bits.hl;
   /* BitString.RightAlign */
   uint32_t n = bits.len - 1, shift = d[bc];
-  uint8_t* key = (uint8_t*)malloc((size_t)n + 8);
-  memset(key, 0, (size_t)n + 8);
+  uint8_t key_small[1032];
+  uint8_t* key = (size_t)n + 8 <= sizeof key_small ? key_small : (uint8_t*)malloc((size_t)n + 8);
+  memset(key + n, 0, 8);
   for (uint32_t i = 0; i < n; i++) {
     uint8_t cur = d[bc + 1 + i], prev = i ? d[bc + i] : 0;
     key[i] = shift ? (uint8_t)((prev << (8 - shift)) | (cur >> shift)) : cur;
@@ -543,7 +542,7 @@ static void check_public_key(const uint8_t* d, uint64_t k, uint64_t k_end, orc_c
 #define PKFAIL(site)            \
   do {                          \
     out->spki_fatal = (site);   \
-    free(key);                  \
+    if (key != key_small) free(key); \
     return;                     \
   } while (0)
   if (is_rsa || is_oaep) {
@@ -588,7 +587,7 @@ static void check_public_key(const uint8_t* d, uint64_t k, uint64_t k_end, orc_c
     if (!ec_unmarshal_ok(c, key, n)) PKFAIL(94); /* failed to unmarshal elliptic curve point */
   }
 #undef PKFAIL
-  free(key);
+  if (key != key_small) free(key);
 }
 
 /* tbs_only: the buffer is a bare TBSCertificate — CT-go x509.ParseTBSCertificate, which ct.LogEntryFromLeaf applies to the
