@@ -152,6 +152,17 @@ struct MatchArgs {
   unsigned long long* counters; // [0] entries left unregistered, [1] list entries, [2] pend overflow
 };
 
+// Chain[0] is read once, by the comparison and by nothing else: non-temporal, like the map's window fills (unaligned
+// form).  A/B on one box, 40 M raw entries: decode + match 11.74 / 12.21 → 10.96 / 11.00 ms; the map kernel behind it
+// 9.90 / 10.31 → 10.44 / 10.49 ms; the step 22.5 / 23.3 → 22.5 / 22.4 ms (profiles/r04/ab_raw_chain0_nontemporal.txt).
+typedef uint32_t ctmr_u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ U16 ld_chain16(const uint8_t* p) {
+  const ctmr_u32x4_u t = __builtin_nontemporal_load((const ctmr_u32x4_u*)p);
+  U16 r;
+  r.a = t.x; r.b = t.y; r.c = t.z; r.d = t.w;
+  return r;
+}
+
 __device__ __forceinline__ bool eq16_prefix(const U16& x, const uint4& y, uint32_t rem) {  // first min(rem,16) bytes equal
   const uint32_t d[4] = {x.a ^ y.x, x.b ^ y.y, x.c ^ y.z, x.d ^ y.w};
   bool eq = true;
@@ -228,17 +239,17 @@ __device__ __forceinline__ void match_wave(const MatchArgs& a, bool need, uint64
         const uint8_t* db = a.idb_der + __shfl(db_off, src[u]);
         const uint32_t off0 = lane * 16u, off1 = off0 + 1024u;
         if (off0 < s_len) {
-          const U16 x = *(const U16*)(a.blob + s_lo + off0);  // ≤ 15 bytes past Chain[0]: CTMR_PAYLOAD_PAD
+          const U16 x = ld_chain16(a.blob + s_lo + off0);  // ≤ 15 bytes past Chain[0]: CTMR_PAYLOAD_PAD
           const uint4 y = *(const uint4*)(db + off0);
           eq[u] = eq16_prefix(x, y, s_len - off0);
         }
         if (off1 < s_len) {
-          const U16 x = *(const U16*)(a.blob + s_lo + off1);
+          const U16 x = ld_chain16(a.blob + s_lo + off1);
           const uint4 y = *(const uint4*)(db + off1);
           eq[u] = eq[u] && eq16_prefix(x, y, s_len - off1);
         }
         for (uint32_t off = off0 + 2048u; off < s_len; off += 1024u) {  // > 2 KiB: rare
-          const U16 x = *(const U16*)(a.blob + s_lo + off);
+          const U16 x = ld_chain16(a.blob + s_lo + off);
           const uint4 y = *(const uint4*)(db + off);
           eq[u] = eq[u] && eq16_prefix(x, y, s_len - off);
         }

@@ -12,7 +12,7 @@ namespace ctmr {
 //            k_key_gather turn that into per-owner partitions, ascending log order inside a partition (what the
 //            all-to-all sends).  Serials of 21..40 octets (rare) leave as 64-byte records (k_xl_export).
 //   owner    k_keys_insert / k_keys_insert2 / k_keys_resolve: the two-pass insert of reduce.h over received records, in
-//            the SAME epoch as the owner's own shard — every w[0] carries the entry's ORDER in the round (keyrec.h), so
+//            the SAME round as the owner's own shard — every key cell carries the entry's ORDER in the round (keyrec.h), so
 //            the lowest log index wins whoever held the entry; a received record that beats an entry of the owner's own
 //            shard marks it (mark_dup_ord); one "was unknown" byte per record goes back.
 //   sender   k_apply_lost: records leave the map optimistically NEW (ES_REMOTE); only the losers are touched.
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) k_apply_lost(const Rec* sent, const uint8
 // against the other ranks' filters — a Bloom filter has no false negatives, so a key that hits no peer filter exists
 // on no other rank and needs no exchange at all; a key that hits peer p's filter (a real cross-rank duplicate or a
 // false positive) is sent to p, which looks it up EXACTLY in its table and answers "known here before you": found
-// with an older epoch, or found in this round under a lower global order (= lower log index).  Exactly one rank — the
+// in a cell of an earlier round, or found in this round under a lower global order (= lower log index).  Exactly one rank — the
 // lowest log index — keeps WasUnknown for each key.  The asker then clears the flag, takes the key out of its
 // per-issuer count and marks its slot SHADOW (known for dedup, not counted or listed: the sets of the ranks stay
 // disjoint, so Σ over ranks of SCARD / per-issuer counts is the global value, as in the owner-computes variant).

@@ -80,7 +80,8 @@ typedef struct {
 typedef struct {
   uint32_t struct_size;       /* sizeof(ctmr_config) */
   int32_t device;             /* HIP device ordinal */
-  uint64_t table_slots;       /* known-certificate table capacity (64-B slots; rounded up to 2^k); 0 = 2^24 */
+  uint64_t table_slots;       /* known-certificate table: index slots (8-byte words; rounded up to 2^k); 0 = 2^24.
+                                 The 64-byte key cells live in an arena of slots/2 cells that grows on demand */
   uint64_t pair_slots;        /* (expDate,issuer) cardinality table capacity; 0 = 2^22 */
   uint32_t max_issuers;       /* 0 = 65536 */
   uint32_t certs_per_tile;    /* sweep build only (variant 1); 0 = default */
@@ -279,7 +280,7 @@ typedef struct {
  *           loop over one log.  counts32[w] (host) = 32-byte records for owner w; *n_long = 64-byte records (all owners).
  *   keys:   writes the records, partitioned by owner, ascending order inside a partition, into the caller's send
  *           buffers (Σ counts32 × 32 bytes; n_long × 64 bytes, counts64[w] of them for owner w).
- *   insert: the owner inserts what it received (any order of senders) in the epoch of its own shard and writes one byte
+ *   insert: the owner inserts what it received (any order of senders) into the round of its own shard and writes one byte
  *           per record: 1 = was unknown.  Bumps the owner's per-issuer counters (a key is counted where it is stored).
  *           Must be called once per round on every rank, received records or not: it also settles the rank's own shard.
  *   apply:  the sender's records left the map with CTMR_FL_WAS_UNKNOWN set; the returned bytes (same order as the
