@@ -111,6 +111,7 @@ struct DevStats {
   unsigned long long n_remote;  // owner-computes rounds: PASS entries whose key left for its owner (counted in n_new, optimistically)
   unsigned long long n_xl;      // … of them with a 21..40-octet serial (they travel as 64-byte records)
   unsigned long long n_pending; // strict_spki: non-zero = some entry's EC key owes the curve equation (k_ec_resolve exits at once on 0)
+  unsigned long long n_pending_other;  // … on a curve other than P-256 (k_ec_resolve<false>: the kernel with the big register file)
 };
 
 // map-kernel filter constants (device memory; uniform reads)

@@ -257,8 +257,10 @@ __global__ void __launch_bounds__(256) k_insert(InsertArgs a) {
     if (fl_out != ((r0.x >> 8) & 0xffu)) ((uint8_t*)(a.records + i))[1] = (uint8_t)fl_out;
     a.ent[i] = ent_pack(status, state, canon) | (pending ? ENT_KEY_PENDING : 0u);
     const unsigned long long mp = __ballot(pending);
-    if (mp && lane == (uint32_t)(__ffsll((long long)mp) - 1) && ld_agent(&a.stats->n_pending) == 0ull)
+    if (mp && lane == (uint32_t)(__ffsll((long long)mp) - 1) && ld_agent(&a.stats->n_pending) == 0ull) {
       st_agent(&a.stats->n_pending, 1ull);  // a flag, not a count (see k_map_fused)
+      st_agent(&a.stats->n_pending_other, 1ull);  // (this path does not look at the curve: both resolve kernels take a look)
+    }
   }
   const uint64_t first = (uint64_t)blockIdx.x * 256 + 64u * wv;
   if (first < a.n)
@@ -506,6 +508,8 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
      // one address serialise at the memory side behind the kernel's back.
     const unsigned long long mp = __ballot(pending);
     if (mp && lane == 0 && ld_agent(&ia.stats->n_pending) == 0ull) st_agent(&ia.stats->n_pending, 1ull);
+    const unsigned long long mo = __ballot(pending && ((keypos >> 32) & 7ull) != 1ull);  // a curve other than P-256
+    if (mo && lane == 0 && ld_agent(&ia.stats->n_pending_other) == 0ull) st_agent(&ia.stats->n_pending_other, 1ull);
     if constexpr (MODE != XM_OWNER) {
       if (pending) a.keypos[i] = keypos;
     }
@@ -573,11 +577,17 @@ __device__ __forceinline__ bool ec_point_bits(const uint32_t* words, unsigned lo
   return ec_equation<C>(x, y);
 }
 
+// Two instantiations, launched one after the other: P256 = true takes the P-256 keys — every EC key of the public CT logs
+// but a few — with 8-limb field elements (≈ 110 VGPRs: four waves per SIMD); P256 = false takes the other curves, whose
+// 17-limb worst case (P-521) costs 206 VGPRs and two waves per SIMD — as ONE kernel the rare curves set the register file,
+// and the occupancy, of the common one (7.1 ms per 50 M P-256 keys, round 4).  Each exits at once when the map saw no key
+// of its kind.
 constexpr uint32_t EC_PER_BLOCK = 1024;
+template <bool P256>
 __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* records) {
   __shared__ uint16_t list[EC_PER_BLOCK];
   __shared__ uint32_t n_list;
-  if (a.stats->n_pending == 0ull) return;
+  if ((P256 ? a.stats->n_pending : a.stats->n_pending_other) == 0ull) return;
   const uint64_t blk0 = (uint64_t)blockIdx.x * EC_PER_BLOCK;
   if (threadIdx.x == 0) n_list = 0u;
   __syncthreads();
@@ -592,7 +602,8 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
     }
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++)
-      if (e[k] & ENT_KEY_PENDING) list[atomicAdd(&n_list, 1u)] = (uint16_t)(threadIdx.x * 4u + k);
+      if ((e[k] & ENT_KEY_PENDING) && ((((uint32_t)(a.keypos[i0 + k] >> 32) & 7u) == 1u) == P256))
+        list[atomicAdd(&n_list, 1u)] = (uint16_t)(threadIdx.x * 4u + k);
   }
   __syncthreads();
   const uint32_t cnt = n_list;
@@ -607,12 +618,15 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
       const uint32_t pos = (uint32_t)kp, curve = (uint32_t)(kp >> 32) & 7u, shift = (uint32_t)(kp >> 35) & 7u;
       const unsigned long long xbit = 8ull * (lo + pos) - shift;  // where X starts, as a bit position in the payload
       bool good;
-      switch (curve) {
-        case 1u: good = ec_point_bits<CurveP256>((const uint32_t*)a.payload, xbit); break;
-        case 2u: good = ec_point_bits<CurveP384>((const uint32_t*)a.payload, xbit); break;
-        case 3u: good = ec_point_bits<CurveP521>((const uint32_t*)a.payload, xbit); break;
-        case 4u: good = ec_point_bits<CurveP224>((const uint32_t*)a.payload, xbit); break;
-        default: good = ec_point_bits<CurveP192>((const uint32_t*)a.payload, xbit); break;
+      if constexpr (P256) {
+        good = ec_point_bits<CurveP256>((const uint32_t*)a.payload, xbit);
+      } else {
+        switch (curve) {
+          case 2u: good = ec_point_bits<CurveP384>((const uint32_t*)a.payload, xbit); break;
+          case 3u: good = ec_point_bits<CurveP521>((const uint32_t*)a.payload, xbit); break;
+          case 4u: good = ec_point_bits<CurveP224>((const uint32_t*)a.payload, xbit); break;
+          default: good = ec_point_bits<CurveP192>((const uint32_t*)a.payload, xbit); break;
+        }
       }
       uint4* rp = (uint4*)(records + i);
       if (!good) {  // x509.ParseCertificate fails: map_one's record of such a certificate
