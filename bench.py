@@ -842,7 +842,9 @@ def main():
     def make_engine(E, this_cfg):
         """The engine and its known-certificate table — the one allocation every rank can always make; the group is
         created on it BEFORE the batch is generated, so that a rank whose shard does not fit can still tell the others."""
-        eng = ctmr.Engine(device=local, table_slots=(1 << args.table_slots_log2) if args.table_slots_log2 else pow2_at_least(int(E * 2)),
+        # index slots: 4 per entry (load ≤ 0.25 at 8 bytes a slot — 4 GB for the 100 M batch; rounds 1–3 sized their 64-byte
+        # slots 2 per entry).  Same-box sweep, round 4: 2^27 / 2^28 / 2^29 slots → map 24.9 / 22.3 / 21.6 ms per 100 M.
+        eng = ctmr.Engine(device=local, table_slots=(1 << args.table_slots_log2) if args.table_slots_log2 else pow2_at_least(int(E * 4)),
                           pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
                           lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
         eng.set_filter(filt, False, now)
