@@ -526,6 +526,8 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
     group = None
     if world > 1:
         group = Group.rccl(eng, gid, rank, world)
+        if args.chunks > 1:
+            group.set_chunks(args.chunks)
         if mode == "bloom":
             group.bloom_config(pow2_at_least(16 * per_rank_keys))
     Wr = (W + world - 1) // world + 1                    # the largest shard of a wave
@@ -697,6 +699,9 @@ def main():
                          "of per-GPU Bloom filters as a pre-filter + exact lookups; owner: global, exact — owner-computes key "
                          "exchange; local: per-shard sets (NOT the reference's one set: duplicates across shards are counted "
                          "twice — the line says so)")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="N > 1, --dedup owner: every shard is mapped in this many chunks, chunk c's key records travelling on a "
+                         "second stream while chunk c + 1 is walked (ctmr_group_set_chunks); same results")
     ap.add_argument("--issuers", type=int, default=256)
     ap.add_argument("--table-slots-log2", type=int, default=0,
                     help="known-certificate table size (default: the power of two >= 2 x entries: load 0.35-0.47 when full)")
@@ -937,6 +942,8 @@ def main():
     if world > 1:
         eng = make_engine(E, cfg)
         group = Group.rccl(eng, gid, rank, world)       # every rank joins before any of them can run out of memory
+        if args.chunks > 1:
+            group.set_chunks(args.chunks)
     while True:
         first, hi = my_shard()
         E = hi - first

@@ -132,6 +132,8 @@ SIGNATURES = {
     "ctmr_table_info_get": (C.c_int, [_P, C.POINTER(TableInfo)]),
     "ctmr_xchg_map_device": (C.c_int, [_P, C.POINTER(Shard), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)]),
+    "ctmr_xchg_map_chunk_device": (C.c_int, [_P, C.POINTER(Shard), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, _P,
+                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ctmr_xchg_keys_device": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint64)]),
     "ctmr_xchg_insert_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P]),
     "ctmr_xchg_apply_device": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64, C.POINTER(BatchStats)]),
@@ -148,6 +150,7 @@ SIGNATURES = {
     "ctmr_group_destroy": (None, [_P]),
     "ctmr_group_last_error": (C.c_char_p, [_P]),
     "ctmr_group_info": (C.c_int, [_P, C.POINTER(GroupStats)]),
+    "ctmr_group_set_chunks": (C.c_int, [_P, C.c_uint32]),
     "ctmr_group_bloom_config": (C.c_int, [_P, C.c_uint64]),
     "ctmr_group_map_batch": (C.c_int, [_P, C.c_int, C.POINTER(Shard), C.POINTER(BatchStats)]),
     "ctmr_group_issuer_counts": (C.c_int, [_P, _P, C.c_uint32]),

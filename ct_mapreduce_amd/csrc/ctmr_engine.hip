@@ -162,6 +162,8 @@ struct RoundCtx {
   std::vector<uint64_t> counts32;
   std::vector<KeyRec> xl;   // … those records, sorted by (owner, order)
   bool resolved = false;    // owner-computes round: ctmr_xchg_insert_device has run
+  bool chunked = false;     // … mapped in chunks (ctmr_xchg_map_chunk_device): the 32-byte records were gathered chunk by chunk
+  uint64_t chunk_next = 0;  // … first entry not mapped yet (the round is open for the next chunk while < n)
   bool own_counted = false; // the table was rebuilt between round_begin and round_collect: `occupied` (= the rebuild's live
                             // count) already holds this shard's own claims — round_collect must not add them again
   // members with serials longer than CTMR_MAX_SERIAL that this batch added to the host-side set, in log order: a group

@@ -91,6 +91,11 @@ class Group:
     def bloom_config(self, bits: int):
         self._check(self._lib.ctmr_group_bloom_config(self._h, bits))
 
+    def set_chunks(self, chunks: int):
+        """Owner-computes rounds map every shard in `chunks` pieces, chunk c's key records travelling while chunk c + 1
+        is walked (include/ctmr.h: ctmr_group_set_chunks); results are those of the unchunked round."""
+        self._check(self._lib.ctmr_group_set_chunks(self._h, int(chunks)))
+
     def map_batch(self, mode, shards):
         """One round.  shards: one N.Shard per local rank (rank order).  Returns the per-rank BatchStats."""
         mode = MODES.get(mode, mode)

@@ -290,6 +290,12 @@ typedef struct {
  *   settles them between the ranks at the end of the round.  shard.d_records is required. ---- */
 int ctmr_xchg_map_device(ctmr_engine* e, const ctmr_shard* shard, uint32_t world, uint32_t rank, uint32_t ord_base,
                          uint64_t* counts32, uint64_t* n_long);
+/* ctmr_xchg_map_device for entries [lo, hi) of the shard (lo a multiple of 1024; chunks in ascending order from 0, the
+ * last ends at sh->n): map + this chunk's exported records gathered into d_keys32_out at once (per-owner partitions of the
+ * chunk; counts32[w] of them for owner w).  After the last chunk the round stands as after ctmr_xchg_map_device;
+ * ctmr_xchg_keys_device then delivers only the 64-byte records (*n_long, set by the last chunk). */
+int ctmr_xchg_map_chunk_device(ctmr_engine* e, const ctmr_shard* sh, uint32_t world, uint32_t rank, uint32_t ord_base,
+                               uint64_t lo, uint64_t hi, void* d_keys32_out, uint64_t* counts32, uint64_t* n_long);
 int ctmr_xchg_keys_device(ctmr_engine* e, void* d_keys32_out, void* d_keys64_out, uint64_t* counts64);
 int ctmr_xchg_insert_device(ctmr_engine* e, const void* d_keys32, uint64_t n32, const void* d_keys64, uint64_t n64,
                             uint8_t* d_flags32, uint8_t* d_flags64);
@@ -395,6 +401,13 @@ int ctmr_group_create_rccl(ctmr_engine* engine, const uint8_t id[CTMR_GROUP_ID_B
 void ctmr_group_destroy(ctmr_group* g);
 const char* ctmr_group_last_error(const ctmr_group* g);
 int ctmr_group_info(ctmr_group* g, ctmr_group_stats* out);
+/* Owner-computes rounds map every shard in `chunks` pieces (1..64; default 1 = as one): the key records of chunk c travel on
+ * a second stream per rank while chunk c + 1 is being walked, and the owner-side insert, the bytes back and the apply run
+ * once at the end over everything.  Results are those of the unchunked round, entry for entry (inside one round the order
+ * in which keys reach their owner does not matter: storage/rediscache.go:57-65 answers per key, not per batch).  Costs one
+ * small control collective per chunk and exchange buffers sized for the worst case.  Every rank of the group sets the same
+ * value (checked in the round's opening control row); Bloom and LOCAL rounds ignore it. */
+int ctmr_group_set_chunks(ctmr_group* g, uint32_t chunks);
 /* bits per rank: power of two, ≈16 per key a rank will ever hold; same on every rank.  (A group of ONE rank has no peer
  * to ask: it keeps no filter and its Bloom rounds are the plain reduce.)  * One mode per group: the first round's mode is the only one the group accepts afterwards (CTMR_E_INVAL otherwise) — the
  * modes keep a key in different places and cannot see each other's.

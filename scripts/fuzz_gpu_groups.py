@@ -73,13 +73,17 @@ def main():
         g = Group.local(engines)
         if mode == "bloom":
             g.bloom_config(1 << rng.choice((12, 14, 16)))
+        big = False
+        if mode == "owner" and rng.random() < 0.5:      # shards mapped in chunks (ctmr_group_set_chunks): the same answers
+            g.set_chunks(rng.choice((2, 3, 5)))
+            big = rng.random() < 0.4                     # … and rounds large enough for several non-empty chunks per shard
         o = orc.Engine(filt, log_exp, NOW)
         if os.environ.get("NO_SPKI"):
             o.set_strict_spki(False)
         base = 0
         ok = True
         for rnd in range(rng.choice((1, 2, 3))):
-            n = rng.randrange(0, 700)
+            n = rng.randrange(0, 700) if not big else rng.randrange(2500, 6000)
             items = [rng.choice(pool) for _ in range(n)]                  # with replacement: duplicates anywhere
             cuts = sorted(rng.randrange(0, n + 1) for _ in range(world - 1))
             bounds = [0] + cuts + [n]

@@ -52,6 +52,16 @@ def test_self_launched_ranks_split_one_batch_and_dedup_globally(world, dedup):
     assert d["value"] > 0 and abs(d["value"] - 300000 * 1000 / d["ms_per_step"]) < 1e-3 * d["value"]
 
 
+def test_owner_rounds_in_chunks_over_rank_processes():
+    """bench.py --gpus 3 --dedup owner --chunks 4: the shards are mapped in four pieces, each piece's key records handed to
+    the transport before the next is walked — the line's checks are those of the unchunked run."""
+    d = run_bench(["--gpus", "3", "--total-entries", "300000", "--dedup", "owner", "--chunks", "4"] + COMMON)
+    c = d["checks"]
+    assert c["entries_disagreeing_with_generator"] == 0 and c["n_new_all_ranks"] == c["n_new_expected_from_generator"] > 0
+    assert c["per_issuer_counts_match_generator"] and d["parity_vs_oracle_on_sample"] is True
+    assert d["exchange"]["wire_bytes_sent_by_rank0_per_step"] > 0
+
+
 def test_per_shard_sets_are_an_explicit_option_and_say_what_they_are():
     d = run_bench(["--gpus", "2", "--total-entries", "200000", "--dedup", "local"] + COMMON)
     assert d["config"]["dedup"] == "local" and "PER-SHARD" in d["config"]["parallelism"]

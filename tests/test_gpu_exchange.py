@@ -15,6 +15,7 @@ from ct_mapreduce_amd import synth, _native as N
 from ct_mapreduce_amd.distributed import Group, shard, shard_range, decode_synchronised
 from ct_mapreduce_amd.engine import RECORD_DTYPE
 from tests.gpu_common import run_oracle
+from oracle import oracle as orc
 
 DEV = torch.device("cuda:0")
 NOW = synth.BASE_TIME
@@ -396,3 +397,62 @@ def test_local_group_runs_its_ranks_concurrently():
         return best
     t1, t3 = one_round(1), one_round(3)
     assert t3 < 2.2 * t1, (t1, t3)
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 2), (3, 4), (4, 7), (2, 64)])
+def test_owner_rounds_mapped_in_chunks_give_the_unchunked_answers(world, chunks):
+    """ctmr_group_set_chunks: every shard is mapped in K pieces, chunk c's key records travel on the transfer streams while
+    chunk c + 1 is walked, the owner-side insert runs once over everything.  Inside one round the order in which keys
+    reach their owner does not matter: records, NEW lists, statistics, counts and sets equal the oracle's over three
+    rounds — shards of uneven size (one smaller than a chunk, one empty), duplicates within chunks, across chunks, across
+    ranks and across rounds, EC keys whose records are withdrawn after the map had staged them."""
+    cfg = synth.config(seed=71, n_issuers=12, dup_permille=300, ca_permille=20, expired_permille=20, profile=1)
+    issuers = synth.issuers(cfg)
+    engines = [make_engine(issuers) for _ in range(world)]
+    g = Group.local(engines)
+    g.set_chunks(chunks)
+    o = None
+    rng = np.random.default_rng(chunks * 10 + world)
+    sizes_by_round = [[5000, 300, 0, 2600], [1024, 2048, 3000, 1], [4100, 4100, 10, 700]]
+    base = 0
+    for rnd, sizes in enumerate(sizes_by_round):
+        keep, shards, want = [], [], []
+        lo = base
+        for r in range(world):
+            n = sizes[r]
+            b = synth.host_batch(cfg, lo, n)
+            if n > 40:                                            # keys damaged at their end: EC points off their curve
+                certs = [b.cert(i) for i in range(n)]
+                for j in rng.choice(n, size=8, replace=False):
+                    c = orc.parse_cert(certs[j], strict_spki=False)
+                    if c.ok:
+                        end = c.spki_off + c.spki_len
+                        certs[j] = certs[j][:end - 3] + b"\x00\x01\x02" + certs[j][end:]
+                b = ctmr.Batch.from_certs(certs, b.issuer_idx, b.entry_type)
+            o, st, unk, _ = run_oracle(b, issuers, FILT, False, NOW, engine=o)
+            want.append((st, unk))
+            t = to_dev(b)
+            keep.append(t)
+            shards.append(dev_shard(t, n, order_base=lo))
+            lo += n
+        base = lo
+        stats = g.map_batch("owner", shards)
+        for r in range(world):
+            st, unk = want[r]
+            rec = keep[r][4].cpu().numpy().view(RECORD_DTYPE)[:len(st)]
+            assert (rec["status"] == st).all(), (rnd, r)
+            assert (((rec["flags"] & 2) != 0) == (unk != 0)).all(), (rnd, r, np.nonzero(((rec["flags"] & 2) != 0) != (unk != 0))[0][:8])
+            assert stats[r].n_new == int(unk.sum())
+            assert (keep[r][5][:stats[r].n_new].cpu().numpy() == np.nonzero(unk)[0]).all()
+    assert g.total_count() == o.total_count() == sum(e.total_count() for e in engines)
+    total = g.issuer_counts(len(issuers))
+    for k in range(len(issuers)):
+        assert int(total[k]) == o.issuer_count(engines[0].issuer_id(k))
+    allkeys = sorted(sum((e.keys(b"serials::*") for e in engines), []))
+    assert sorted(set(allkeys)) == [k for k in o.keys() if k.startswith(b"serials::")]
+    key = sorted(set(allkeys))[len(set(allkeys)) // 2]            # the ranks hold disjoint parts of a set
+    members = sum((e.set_list(key) for e in engines), [])
+    assert len(members) == len(set(members)) and sorted(members) == sorted(o.members(key))
+    g.close()
+    for e in engines:
+        e.close()

@@ -225,6 +225,8 @@ def rank_main(r):
         g = Group.rccl(e, gid, r, world)
         if mode == "bloom":
             g.bloom_config(1 << 14)
+        if len(sys.argv) > 4:
+            g.set_chunks(int(sys.argv[4]))
         ok, totals = True, []
         for certs, st, unk, base, total in rounds:
             lo, hi = shard_range(len(certs), r, world)
@@ -257,6 +259,19 @@ sys.stdout.flush()
 import os
 os._exit(0 if not hung else 3)
 '''
+
+
+def test_chunked_owner_rounds_over_the_rccl_transport():
+    """The same three rounds with every shard mapped in three chunks (ctmr_group_set_chunks): one control row and one
+    grouped send/recv per chunk on the transfer stream, the 64-byte records and the long serials behind the last chunk."""
+    env = dict(os.environ, CTMR_RCCL_LIB=build_fake())
+    p = subprocess.run([sys.executable, "-c", LONG_CHILD, ROOT, "3", "owner", "3"], env=env, capture_output=True, text=True,
+                       timeout=100)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert line, p.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert not res["errs"] and not res["hung"], res
+    assert all(o_ is not None and o_["ok"] and all(o_["totals"]) for o_ in res["out"]), res
 
 
 @pytest.mark.parametrize("mode", ["owner", "bloom"])
