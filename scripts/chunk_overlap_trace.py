@@ -1,8 +1,8 @@
 """Do the key records of chunk c travel while chunk c + 1 is being mapped?  (VERDICT r03 #5a.)  A LOCAL group of two
 engines on the one reachable GPU, owner-computes rounds, shards mapped whole (chunks = 1) and in four chunks; the
-rocprofv3 kernel + memory-copy traces say which device-to-device copies of key records ran while a map kernel was in flight.
+rocprofv3 kernel trace says which device-to-device copies of key records ran while a map kernel was in flight.
 
-    rocprofv3 --kernel-trace --memory-copy-trace -d OUT -o trace --output-format csv -- python scripts/chunk_overlap_trace.py run
+    rocprofv3 --kernel-trace -d OUT -o trace --output-format csv -- python scripts/chunk_overlap_trace.py run
     python scripts/chunk_overlap_trace.py report OUT
 """
 import csv
@@ -57,19 +57,20 @@ def run():
 
 
 def report(outdir):
+    # on one device a device-to-device hipMemcpyAsync runs as a blit KERNEL (__amd_rocclr_copyBuffer), not as an SDMA copy:
+    # both the maps and the key-record copies are in the kernel trace
     maps, copies = [], []
     for f in glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
+            iv = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
             if "k_map_fused" in r["Kernel_Name"]:
-                maps.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-    for f in glob.glob(os.path.join(outdir, "**", "*memory_copy_trace.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "DEVICE_TO_DEVICE" in r.get("Direction", "").upper().replace("MEMORY_COPY_", ""):
-                copies.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+                maps.append(iv)
+            elif "copyBuffer" in r["Kernel_Name"] and iv[1] - iv[0] > 20_000:   # tens of MB of key records, not control words
+                copies.append(iv)
     maps.sort()
-    copies = sorted(c for c in copies if c[1] - c[0] > 20_000)      # the key-record copies (tens of MB), not the control words
+    copies.sort()
     print(f"{len(maps)} k_map_fused launches, {len(copies)} device-to-device copies longer than 20 us")
-    # split the trace at the largest gap between map launches: first half = chunks 1, second = chunks 4
+    # split the trace at the largest gap between map launches: first part = chunks 1, second = chunks 4
     gaps = sorted(((maps[i + 1][0] - maps[i][1], i) for i in range(len(maps) - 1)), reverse=True)
     cut = maps[gaps[0][1]][1] if gaps else 0
     for name, lo, hi in (("shards mapped whole (chunks = 1)", 0, cut), ("shards mapped in 4 chunks", cut, 1 << 62)):
@@ -78,12 +79,36 @@ def report(outdir):
         inside = tot = 0
         for s, e in cs:
             tot += e - s
+            cov = 0
             for a, b in ms:
-                inside += max(0, min(e, b) - max(s, a))
-        inside = min(inside, tot)
+                cov += max(0, min(e, b) - max(s, a))
+            inside += min(cov, e - s)
         print(f"{name}: {len(ms)} map launches, {len(cs)} key-record copies, {tot / 1e3:.0f} us of copying, "
               f"{inside / 1e3:.0f} us of it ({100.0 * inside / max(tot, 1):.0f} %) while a map kernel was running")
 
 
+def timeline(outdir):
+    """The last chunked round, event by event: which queue ran what (the engines' streams map, the transfer streams copy)."""
+    rows = []
+    for f in glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            n, s0, e0 = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            kind = "MAP" if "k_map_fused" in n else "gather" if "k_key_gather" in n else \
+                "copy" if ("copyBuffer" in n and e0 - s0 > 4000) else "insert" if "k_keys_insert<" in n else None
+            if kind:
+                rows.append((s0, e0, kind, r["Queue_Id"]))
+    rows.sort()
+    maps = [r for r in rows if r[2] == "MAP"]
+    t0 = maps[-8][0]
+    print("the last round (2 ranks x 4 chunks), microseconds from its first map launch; queue = HIP stream:")
+    for s0, e0, k, q in rows:
+        if s0 >= t0 - 1000:
+            print(f"  {(s0 - t0) / 1e3:9.1f} .. {(e0 - t0) / 1e3:9.1f}  {k:6s} queue {q}")
+
+
 if __name__ == "__main__":
-    run() if sys.argv[1] == "run" else report(sys.argv[2])
+    if sys.argv[1] == "run":
+        run()
+    else:
+        report(sys.argv[2])
+        timeline(sys.argv[2])
