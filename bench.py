@@ -742,7 +742,7 @@ def main():
                          "secondary.mixed; this flag makes it the line's workload")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (mixed corpus, 128-byte aligned layout) of the default run")
     ap.add_argument("--strict-strings", action="store_true",
-                    help="ctmr_set_strict_strings(1): the opt-in pre-pass over the Names' string values (what it costs: ms_per_step "
+                    help="ctmr_set_strict_strings(1): the opt-in character-set check of the Names' string values, inside the walk (what it costs: ms_per_step "
                          "and kernel_ms.map of this line against the default line)")
     ap.add_argument("--no-strict-spki", action="store_true",
                     help="ctmr_set_strict_spki(0): skip the public key by length as rounds 1-3 did (the A/B of what parsing the "

@@ -595,13 +595,12 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // TBS_ONLY: the buffer is a bare TBSCertificate (what a precertificate entry's MerkleTreeLeaf carries) — what CT-go's
 // x509.ParseTBSCertificate accepts: the TBSCertificate SEQUENCE must fill the buffer ("trailing data" otherwise) and there
 // is no signatureAlgorithm / signatureValue behind it; everything inside is parsed as for a certificate.
-// NAMES_ONLY: stop behind the subject Name (k_name_strings: only where the two Names lie is wanted; whether the rest of
-// the certificate parses is the map's business).
+// NAMES_ONLY: stop behind the subject Name (round 3's pre-pass kernel stopped there; nothing instantiates it since round 4).
 // spki: also parse the public key as CT-go's parsePublicKey does (spki_key.h; ctmr_set_strict_spki, on by default).
 // EC_DEFER (the map kernels): an EC key's curve equation is not evaluated here — Walk.ec_* says what is owed (spki_key.h).
 // strings: strict_strings inside the walk (round 4: the pre-pass of round 3 filled the same front window a second time,
-// +11.5 ms per 100 M certificates) — right behind each Name, while the window holds it, the character sets of its string
-// values are checked (walk_name → value_strings_ok) and a violation is filed as WALK_NF_STRING.  The caller passes it only where the
+// +11.5 ms per 100 M certificates) — inside walk_name, on each value where the walk meets it while the window holds it, the
+// character sets are checked (value_strings_ok) and a violation is filed as WALK_NF_STRING.  The caller passes it only where the
 // finding can matter (a precertificate, a Chain[0] issuer — an X509 entry keeps its certificate either way).
 // STRINGS = false compiles the check out: the map kernels carry it in instantiations of their own (the code's mere presence
 // cost the default kernel 0.5 ms per 100 M certificates, A/B on one box, round 4).
@@ -859,10 +858,6 @@ template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr, bool spki = true, bool strings = false) {
   return filter ? walk_cert<R>(r, L, o, true, *filter, spki, strings)
                 : walk_cert<R>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki, strings);
-}
-template <class R>
-CTMR_HD bool walk_names(R& r, uint32_t L, Walk& o) {
-  return walk_cert<R, false, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr});
 }
 template <class R>
 CTMR_HD bool walk_tbs(R& r, uint32_t L, Walk& o, bool spki = true) {
