@@ -811,6 +811,10 @@ def main():
     local %= max(torch.cuda.device_count(), 1)      # (the tests let several ranks share the one reachable GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # placement experiment (EXPERIMENTS.md, "run-to-run spread"): an allocation of this many KiB made — and kept — before
+    # everything else shifts where the batch, the index and the arena come to lie
+    _pad = torch.empty(int(os.environ.get("CTMR_BENCH_PAD_KIB", "0")) << 10, dtype=torch.uint8, device=dev) \
+        if os.environ.get("CTMR_BENCH_PAD_KIB") else None
     gid = None
     if world > 1:
         # CONTROL path: the 128-byte group id reaches the ranks through the environment (spawned by this script) or by
