@@ -161,6 +161,7 @@ SIGNATURES = {
     "ctmr_set_issuer_autoregister": (C.c_int, [_P, C.c_int]),
     "ctmr_set_chain0_match": (C.c_int, [_P, C.c_int]),
     "ctmr_set_strict_leaf": (C.c_int, [_P, C.c_int]),
+    "ctmr_set_strict_extensions": (C.c_int, [_P, C.c_int]),
     "ctmr_set_strict_strings": (C.c_int, [_P, C.c_int]),
     "ctmr_set_strict_spki": (C.c_int, [_P, C.c_int]),
     "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),

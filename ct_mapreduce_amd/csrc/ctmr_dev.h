@@ -121,7 +121,8 @@ struct FilterDev {
   uint32_t log_expired;
   uint32_t strict_spki;  // ctmr_set_strict_spki: the walk also parses the public key (spki_key.h); on by default
   uint32_t strict_strings;  // ctmr_set_strict_strings: character sets of the Names' string values, inside the walk
-  uint32_t pad2;
+  uint32_t strict_ext;      // ctmr_set_strict_extensions: the bodies of the extensions Go unmarshals (der_walk.h ext_body_check)
+                            // (in what was a padding word: every other field keeps its place)
   long long now;
   uint32_t piece_len[64];
   uint32_t piece_word[64];  // index of the piece's first word in words[]

@@ -217,6 +217,7 @@ struct ctmr_engine {
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
   bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
   int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
+  bool strict_ext = false;                 // ctmr_set_strict_extensions: extension bodies Go unmarshals (fatal)
   bool strict_strings = false;             // ctmr_set_strict_strings: character sets of the Names' string values (non-fatal finding)
   bool strict_spki = true;                 // ctmr_set_strict_spki: parsePublicKey's verdict on the key inside subjectPublicKeyInfo (spki_key.h)
   bool strict_leaf = false;                // ctmr_set_strict_leaf: parse the leaf TBSCertificate of precertificate entries

@@ -42,7 +42,7 @@ struct DecodeArgs {
 // signature.  Runs BEFORE the decode + match kernel, which treats a flagged entry as undecodable: its Chain[0] is never
 // looked at, let alone registered.  Costs one more pass over ≈ 3 windows of every precertificate entry: opt-in.
 __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uint64_t* bounds, uint64_t n, uint64_t limit,
-                                                       uint8_t* leaf_bad, uint32_t strict_spki) {
+                                                       uint8_t* leaf_bad, uint32_t strict_spki, uint32_t strict_ext) {
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
@@ -65,7 +65,7 @@ __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uin
   if (pre) {
     WinReaderC<16> r{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)), (int32_t)(int64_t)(g_me - lo)}};
     Walk w;
-    ok = walk_tbs(r, len, w, strict_spki != 0u);
+    ok = walk_tbs(r, len, w, strict_spki != 0u, strict_ext != 0u);
   }
   if (i < n) leaf_bad[i] = (uint8_t)(pre && !ok);
 }

@@ -81,7 +81,7 @@ __device__ void sha256_lane(const R& r, uint32_t off, uint32_t len, const uint32
 // (ct-fetch.go:221) + NewIssuer + Issuer.ID()'s SHA-256 (storage/types.go:109-130,155-159).
 __global__ void CTMR_WALK_BOUNDS k_issuer_ids(const uint8_t* der, const uint64_t* offsets,
                                                    uint32_t n, uint8_t* valid, uint32_t* digest, uint32_t strict_strings,
-                                                   uint32_t strict_spki) {
+                                                   uint32_t strict_spki, uint32_t strict_ext) {
   __shared__ uint32_t kc[64];
   kc[threadIdx.x] = K256[threadIdx.x];
   __syncthreads();
@@ -91,7 +91,7 @@ __global__ void CTMR_WALK_BOUNDS k_issuer_ids(const uint8_t* der, const uint64_t
   const uint32_t L = (uint32_t)(offsets[i + 1] - offsets[i]);
   Walk w;
   // any err of x509.ParseCertificate(Chain[0]) skips the entry, non-fatal findings included (ct-fetch.go:221-225)
-  bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w, nullptr, strict_spki != 0u, strict_strings != 0u) &&
+  bool ok = (offsets[i + 1] - offsets[i]) <= 0x7fffffffull && walk_cert(r, L, w, nullptr, strict_spki != 0u, strict_strings != 0u, strict_ext != 0u) &&
             w.nonfatal == 0u;  // strict_strings: a character-set finding in either Name is one more of them (WALK_NF_STRING)
   valid[i] = ok ? 1 : 0;
   uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};

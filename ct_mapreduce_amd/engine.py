@@ -408,6 +408,11 @@ class Engine:
         first sighting per call, then identified by length + first/last 16 bytes) — include/ctmr.h."""
         self._ck(self._lib.ctmr_set_chain0_match(self._h, int(mode)))
 
+    def set_strict_extensions(self, on: bool):
+        """The bodies of the extensions Go unmarshals by plain struct rules become a fatal parse error (include/ctmr.h); off
+        by default."""
+        self._ck(self._lib.ctmr_set_strict_extensions(self._h, int(bool(on))))
+
     def set_strict_leaf(self, on: bool):
         """Walk the leaf TBSCertificate of precertificate entries as ct.LogEntryFromLeaf does (include/ctmr.h); default off."""
         self._ck(self._lib.ctmr_set_strict_leaf(self._h, int(bool(on))))

@@ -500,6 +500,16 @@ int ctmr_wait_entries(ctmr_engine* e, ctmr_ticket ticket, ctmr_record* records, 
  * ascending log index of first appearance) — for hosts that must keep the issuer tables of several engines
  * identical (multi-GPU key exchange: DESIGN.md §8): gather the pending lists of all ranks, register the union in
  * one agreed order with ctmr_add_issuers on every rank, call again. */
+/* strict_extensions (round 4, opt-in, default off).  Go 1.13's crypto/x509 parseCertificate unmarshals the VALUE of some
+ * extensions and fails the certificate when that fails; with on != 0 the walk does the same for the ones parsed by plain
+ * encoding/asn1 struct rules — keyUsage (one BIT STRING), subjectKeyIdentifier (one OCTET STRING), extKeyUsage (SEQUENCE OF
+ * OID), authorityKeyIdentifier (SEQUENCE with an optional [0]), certificatePolicies (SEQUENCE OF SEQUENCE { OID, … }),
+ * authorityInfoAccess (SEQUENCE OF SEQUENCE { OID, any element }), each filling its OCTET STRING ("trailing data") — as a
+ * FATAL parse error in every role (leaf, precertificate, Chain[0], the strict_leaf TBSCertificate).  subjectAltName,
+ * nameConstraints and cRLDistributionPoints are not modelled.  These are the standard library's rules: which of them
+ * certificate-transparency-go's fork files as non-fatal cannot be verified without its source — hence a switch.  Set it
+ * before the issuers are registered (a Chain[0] is judged when it is registered). */
+int ctmr_set_strict_extensions(ctmr_engine* e, int on);
 int ctmr_set_issuer_autoregister(ctmr_engine* e, int on);
 int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need, uint64_t* count);
 /* How Chain[0] is identified (cmd/ct-fetch/ct-fetch.go:221 parses it in full for every entry).

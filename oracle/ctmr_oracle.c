@@ -590,6 +590,54 @@ static void check_public_key(const uint8_t* d, uint64_t k, uint64_t k_end, orc_c
   if (key != key_small) free(key);
 }
 
+/* strict_extensions (orc_engine_set_strict_extensions; off by default).  Go 1.13 crypto/x509 parseCertificate unmarshals
+ * the VALUE of some extensions and fails the certificate when that fails — restated here for the ones it parses with plain
+ * encoding/asn1 struct rules (each followed by "x509: trailing data after X.509 …" when octets remain):
+ *   2.5.29.15 keyUsage               var usageBits asn1.BitString
+ *   2.5.29.14 subjectKeyIdentifier   var keyid []byte
+ *   2.5.29.37 extKeyUsage            var keyUsage []asn1.ObjectIdentifier
+ *   2.5.29.35 authorityKeyIdentifier struct { Id []byte `asn1:"optional,tag:0"` }
+ *   2.5.29.32 certificatePolicies    []struct { Policy asn1.ObjectIdentifier }        (what follows the OID is ignored)
+ *   1.3.6.1.5.5.7.1.1 authorityInfoAccess   []struct { Method asn1.ObjectIdentifier; Location asn1.RawValue }
+ * subjectAltName (URI / IP parsing), nameConstraints and cRLDistributionPoints (nested optional tags) are not restated.
+ * Which of these errors CT-go's fork files as non-fatal cannot be verified here: recalled from the standard library, like
+ * the string character sets.  Returns 0 = fine / not one of them, else an error site. */
+static int ext_body_site(const uint8_t* d, const uint8_t* oid, uint32_t oid_len, uint64_t o, uint64_t o_end) {
+  static const uint8_t AIA[8] = {0x2b, 0x06, 0x01, 0x05, 0x05, 0x07, 0x01, 0x01};
+  int arc = (oid_len == 3 && oid[0] == 0x55 && oid[1] == 0x1d) ? oid[2] : -1;
+  int aia = oid_len == 8 && memcmp(oid, AIA, 8) == 0;
+  tlv t;
+  if (!(arc == 15 || arc == 14 || arc == 37 || arc == 35 || arc == 32 || aia)) return 0;
+  if (!rd_tlv(d, o, o_end, &t)) return 100;                       /* the value is not one well-formed element */
+  if (o + t.hl + (uint64_t)t.len != o_end) return 101;            /* trailing data */
+  uint64_t c = o + t.hl, c_end = c + t.len;
+  if (arc == 15) return (t.tag == 0x03 && bit_string_ok(d, c, t.len)) ? 0 : 102;
+  if (arc == 14) return t.tag == 0x04 ? 0 : 103;
+  if (t.tag != 0x30) return 104;
+  if (arc == 35) {                                                /* optional first field: skipped when its tag differs */
+    tlv f;
+    if (c == c_end) return 0;
+    if (!rd_hdr(d, c, c_end, &f)) return 105;
+    if (f.tag == 0x80 && c + f.hl + (uint64_t)f.len > c_end) return 106;
+    return 0;
+  }
+  while (c < c_end) {                                             /* SEQUENCE OF */
+    tlv e;
+    if (!rd_tlv(d, c, c_end, &e)) return 107;
+    uint64_t x = c + e.hl, x_end = x + e.len;
+    if (arc == 37) {
+      if (e.tag != 0x06 || !oid_ok(d, x, e.len)) return 108;
+    } else {
+      tlv id, loc;
+      if (e.tag != 0x30) return 109;
+      if (!rd_tlv(d, x, x_end, &id) || id.tag != 0x06 || !oid_ok(d, x + id.hl, id.len)) return 110;
+      if (aia && !rd_tlv(d, x + id.hl + id.len, x_end, &loc)) return 111;
+    }
+    c = x_end;
+  }
+  return 0;
+}
+
 /* tbs_only: the buffer is a bare TBSCertificate — CT-go x509.ParseTBSCertificate, which ct.LogEntryFromLeaf applies to the
  * TBSCertificate of a precertificate entry's MerkleTreeLeaf (cmd/ct-fetch/ct-fetch.go:452): asn1.Unmarshal into
  * tbsCertificate, "trailing data" when anything follows it, then the same parseCertificate as for a whole certificate
@@ -726,6 +774,8 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
         }
         if (val.tag != 0x04) FAIL(34);
         if (x + val.hl + (uint64_t)val.len > x_end) FAIL(34);
+        if (!out->ext_fatal) /* the first one in certificate order; applied by the engine (strict_extensions) */
+          out->ext_fatal = (uint32_t)ext_body_site(d, d + oid_c, oid.len, x + val.hl, x + val.hl + val.len);
         if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x13) {
           /* basicConstraints struct { IsCA bool `optional`; MaxPathLen int `optional,default:-1` } must be the
            * whole OCTET STRING ("x509: trailing data after X.509 BasicConstraints"); inside the SEQUENCE an
@@ -1074,6 +1124,7 @@ struct orc_engine {
   size_t filter_len;
   int log_expired;
   int strict_strings; /* the stdlib's character-set rules for the Names' string values, as non-fatal findings (orc_engine_set_strict_strings) */
+  int strict_ext;  /* the bodies of the extensions Go unmarshals (orc_engine_set_strict_extensions; off by default): fatal */
   int strict_spki; /* parsePublicKey's verdict on the key inside subjectPublicKeyInfo (orc_engine_set_strict_spki; ON by default) */
   int strict_leaf; /* LogEntryFromLeaf's parse of a precertificate entry's leaf TBSCertificate (orc_engine_set_strict_leaf) */
   int64_t now;
@@ -1293,7 +1344,7 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   orc_parse_cert(leaf, leaf_len, &c); /* :198-204 */
   /* X509 entry: the certificate LogEntryFromLeaf parsed, kept unless the error was fatal (:452-459);
    * precertificate: parsed here, dropped on ANY error, x509.NonFatalErrors included (:202-209) */
-  if (!c.ok || (e->strict_spki && c.spki_fatal)) return ORC_ST_PARSE_ERROR;
+  if (!c.ok || (e->strict_spki && c.spki_fatal) || (e->strict_ext && c.ext_fatal)) return ORC_ST_PARSE_ERROR;
   if (entry_type == 1 && (c.nonfatal || (e->strict_strings && c.string_findings) || (e->strict_spki && c.spki_findings)))
     return ORC_ST_PARSE_ERROR; /* :206-209 */
   if (exp_hour) *exp_hour = orc_exp_hour(c.not_after);
@@ -1304,7 +1355,8 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   if (!issuer_der) return ORC_ST_NO_ISSUER; /* :215-219 */
   orc_cert ic;
   orc_parse_cert(issuer_der, issuer_len, &ic); /* :221 */
-  if (!ic.ok || ic.nonfatal || (e->strict_strings && ic.string_findings) || (e->strict_spki && (ic.spki_fatal || ic.spki_findings)))
+  if (!ic.ok || ic.nonfatal || (e->strict_strings && ic.string_findings) || (e->strict_spki && (ic.spki_fatal || ic.spki_findings)) ||
+      (e->strict_ext && ic.ext_fatal))
     return ORC_ST_ISSUER_PARSE_ERROR; /* any err :222-225 */
   /* Store: filesystemdatabase.go:158-211 */
   int32_t eh = orc_exp_hour(c.not_after);           /* :160 */
@@ -1450,6 +1502,7 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
 
 void orc_engine_set_strict_leaf(orc_engine* e, int on) { e->strict_leaf = on != 0; }
 void orc_engine_set_strict_spki(orc_engine* e, int on) { e->strict_spki = on != 0; }
+void orc_engine_set_strict_extensions(orc_engine* e, int on) { e->strict_ext = on != 0; }
 void orc_engine_set_strict_strings(orc_engine* e, int on) { e->strict_strings = on != 0; }
 
 void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
@@ -1468,7 +1521,7 @@ void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bo
        * downloader then drops (ct-fetch.go:452-459) — non-fatal findings are kept there */
       orc_cert tc;
       orc_parse_tbs(leaf + d.tbs_off, d.tbs_len, &tc);
-      if (!tc.ok || (e->strict_spki && tc.spki_fatal)) d.ok = 0;
+      if (!tc.ok || (e->strict_spki && tc.spki_fatal) || (e->strict_ext && tc.ext_fatal)) d.ok = 0;
     }
     if (d.ok) {
       /* ct-fetch.go:198-204 the certificate; :215 len(Chain) < 1; :221 Chain[0] */

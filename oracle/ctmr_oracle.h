@@ -69,6 +69,8 @@ typedef struct {
   int32_t spki_fatal;    /* parsePublicKey (CT-go, recalled): 0 = the key parses, else the check that failed — a FATAL error
                             of x509.ParseCertificate; kept apart from `ok`: an engine acts on it unless strict_spki is off */
   int32_t spki_findings; /* ORC_PK_*: what parsePublicKey files as non-fatal (same switch) */
+  uint32_t ext_fatal;    /* the body of an extension Go unmarshals does not parse (ext_body_site; Go stdlib rules): 0 = none,
+                            else the check that failed.  Only an engine with strict_extensions set acts on it (fatal) */
 } orc_cert;
 
 #define ORC_SF_PRINTABLE 1
@@ -196,6 +198,7 @@ void orc_engine_set_strict_leaf(orc_engine*, int on);
 void orc_engine_set_strict_strings(orc_engine*, int on);
 /* parsePublicKey's verdict on the key (ON by default: the reference always parses the key); 0 = rounds 1-3 behaviour */
 void orc_engine_set_strict_spki(orc_engine*, int on);
+void orc_engine_set_strict_extensions(orc_engine*, int on);
 void orc_engine_raw_batch(orc_engine*, const uint8_t* blob, const uint64_t* bounds, uint64_t n,
                           uint8_t* out_status, uint8_t* out_unknown, int32_t* out_exp_hour,
                           uint64_t* out_timestamp);

@@ -36,7 +36,8 @@ class Cert(C.Structure):
                 ("spki_off", C.c_uint32), ("spki_len", C.c_uint32),
                 ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32), ("issuer_off", C.c_uint32), ("issuer_len", C.c_uint32),
                 ("exts_off", C.c_uint32), ("exts_end", C.c_uint32), ("nonfatal", C.c_int32),
-                ("string_findings", C.c_int32), ("spki_fatal", C.c_int32), ("spki_findings", C.c_int32)]
+                ("string_findings", C.c_int32), ("spki_fatal", C.c_int32), ("spki_findings", C.c_int32),
+                ("ext_fatal", C.c_uint32)]
 
 
 NF_NEGATIVE_SERIAL, NF_LAX_INTEGER = 1, 2
@@ -66,6 +67,7 @@ def lib():
         L.orc_engine_set_strict_leaf.argtypes = [C.c_void_p, C.c_int]
         L.orc_engine_set_strict_strings.argtypes = [C.c_void_p, C.c_int]
         L.orc_engine_set_strict_spki.argtypes = [C.c_void_p, C.c_int]
+        L.orc_engine_set_strict_extensions.argtypes = [C.c_void_p, C.c_int]
         L.orc_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_b64url.restype = C.c_size_t
@@ -209,6 +211,11 @@ class Engine:
     def set_strict_spki(self, on: bool):
         """parsePublicKey's verdict on the key inside subjectPublicKeyInfo (default ON, as in the reference)."""
         lib().orc_engine_set_strict_spki(self._h, int(bool(on)))
+
+    def set_strict_extensions(self, on: bool):
+        """The bodies of the extensions Go unmarshals by struct rules (keyUsage, key identifiers, extKeyUsage, policies, AIA)
+        become a fatal parse error; off by default."""
+        lib().orc_engine_set_strict_extensions(self._h, int(bool(on)))
 
     def close(self):
         if self._h:

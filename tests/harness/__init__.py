@@ -81,6 +81,12 @@ def product_set_spki(on: bool):
     _walk.harness_set_spki(int(bool(on)))
 
 
+def product_set_ext(on: bool):
+    """The host build's strict_extensions switch (default off): the bodies of the extensions Go unmarshals."""
+    product_walk(b"\x30\x00")
+    _walk.harness_set_ext(int(bool(on)))
+
+
 def product_ec_point_bits(buf: bytes, xbit: int, curve: int) -> bool:
     """k_ec_resolve's loader + curve equation (host build): X starts at BIT xbit of buf; curve 1..5 = P-256, P-384, P-521,
     P-224, secp192r1."""

@@ -34,6 +34,9 @@ struct HarnessOut {
 // spki: 1 = the walk also parses the public key (ctmr_set_strict_spki, the default), 0 = rounds 1-3 behaviour
 static int g_spki = 1;
 extern "C" void harness_set_spki(int on) { g_spki = on; }
+// ext: 1 = strict_extensions (ctmr_set_strict_extensions; off by default)
+static int g_ext = 0;
+extern "C" void harness_set_ext(int on) { g_ext = on; }
 
 extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, const char* filter,
                                uint32_t flen, int use_filter, HarnessOut* out);
@@ -63,7 +66,7 @@ extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, c
   memcpy(buf.data(), der, len);
   PaddedReader r{buf.data()};
   ctmr::Walk w;
-  const bool ok = ctmr::walk_cert(r, len, w, use_filter ? &fv : nullptr, g_spki != 0);
+  const bool ok = ctmr::walk_cert(r, len, w, use_filter ? &fv : nullptr, g_spki != 0, false, g_ext != 0);
   memset(out, 0, sizeof *out);
   out->ok = ok;
   if (!ok) return;
@@ -83,7 +86,7 @@ extern "C" void harness_walk_tbs(const uint8_t* tbs, uint32_t len, uint8_t fill,
   memcpy(buf.data(), tbs, len);
   PaddedReader r{buf.data()};
   ctmr::Walk w;
-  const bool ok = ctmr::walk_tbs(r, len, w, g_spki != 0);
+  const bool ok = ctmr::walk_tbs(r, len, w, g_spki != 0, g_ext != 0);
   memset(out, 0, sizeof *out);
   out->ok = ok;
   if (!ok) return;
