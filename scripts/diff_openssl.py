@@ -61,6 +61,10 @@ def key_class(der, o):
     return alg
 
 
+MODELLED_EXTENSIONS = ("keyUsage", "subjectKeyIdentifier", "extKeyUsage", "authorityKeyIdentifier", "certificatePolicies",
+                       "authorityInfoAccess")
+
+
 def seeds():
     out = [(s, "edge") for s in edge_seeds()] * 4 + [(s, "key") for s in key_seeds()] * 3
     for s_, prof in ((201, 0), (202, 1)):
@@ -98,6 +102,17 @@ def bucket_of(der, o, v):
         if stage == "ext":
             stage = "ext:%s" % ext_name(v.ext_nid)
         hit = a_rule(stage, r, sub)
+        if hit and stage.startswith("ext:") and stage.split(":")[1] in MODELLED_EXTENSIONS:
+            # strict_extensions (opt-in) restates Go's rule for this extension: say which side of it the mutant lies on
+            if o.ext_fatal:
+                hit = (hit[0] + " / fails Go's struct rules", "modelled",
+                       "the value breaks the rule Go's parseCertificate applies to this extension (one BIT STRING / OCTET STRING, "
+                       "SEQUENCE OF OID, SEQUENCE OF SEQUENCE { OID, … }, no trailing data): ctmr_set_strict_extensions rejects it too, "
+                       "as a fatal parse error (opt-in, like the string rules: what CT-go's fork makes of it is not verifiable here)")
+            else:
+                hit = (hit[0] + " / passes Go's struct rules", "openssl",
+                       "the value satisfies the struct rules Go applies (what follows a policy's OID, the contents of a GeneralName or "
+                       "of a key identifier are not looked at by encoding/asn1): OpenSSL's extension decoders go deeper")
         raw = "%s | %s %s" % (stage, r, sub)
         return ("A",) + (hit if hit else (raw, None, None))
     site = SITES.get(o.err_site, "site %d" % o.err_site)
