@@ -275,7 +275,8 @@ namespace {
 enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_STAGE_B, SC_MISC, SC_PEM, SC_PEMOFF, SC_TMP, SC_VIEW, SC_ISS_A, SC_ISS_B, SC_ISS_C, SC_META, SC_ITEMS,
        SC_XSTAGE, SC_XWCNT, SC_XCNT, SC_XBASE, SC_XSLOT, SC_XL,
        SC_NFX,    // (round 3: strict_strings' pre-pass; unused since the check moved into the walk)
-       SC_KEYPOS  // strict_spki: where the EC points lie that owe the curve equation (map → k_ec_resolve)
+       SC_KEYPOS, // strict_spki: where the EC points lie that owe the curve equation (map → k_ec_resolve)
+       SC_PEMBLK  // k_pem_blocks: per 4 KiB output block of the PEM stream, the first certificate in it
        };  // strict_strings: the pre-pass's finding per entry  // owner-computes exchange (engine/exchange.inc)
 constexpr uint32_t UNREG_CAP = 16384;
 

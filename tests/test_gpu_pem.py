@@ -61,6 +61,50 @@ def test_pem_device_every_length_and_padding_case():
     eng.close()
 
 
+def test_pem_device_output_blocks_unaligned_pointer_large_and_tiny_certificates():
+    """k_pem_encode cuts the PEM stream into 4 KiB output blocks on 16-byte boundaries of the output ADDRESS: output
+    pointers at every offset mod 16, certificates far larger than a block (70 000 bytes: 24 blocks), runs of tiny ones
+    (more than 64 certificates inside one block: a second pass), and a stream that ends inside its first block."""
+    import base64
+    import torch
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+
+    def pem(b):
+        e = base64.b64encode(b)
+        return b"-----BEGIN CERTIFICATE-----\n" + b"".join(e[i:i + 64] + b"\n" for i in range(0, len(e), 64)) + \
+            b"-----END CERTIFICATE-----\n"
+
+    cases = [[70000, 3, 0, 1523, 12, 4095, 4096, 4097, 1],
+             [0] * 200 + [1, 2] * 100 + [1523] * 5,
+             [5],
+             [int(x) for x in rng.normal(1523, 64, 300)],
+             [int(x) for x in rng.integers(0, 9000, 120)]]
+    for ci, lens in enumerate(cases):
+        blobs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+        lead = int(rng.integers(0, 16))                                  # the first certificate at any address mod 16
+        offs = np.zeros(len(blobs) + 1, np.uint64)
+        offs[0] = lead
+        offs[1:] = lead + np.cumsum([len(b) for b in blobs])
+        payload = np.frombuffer(bytes(lead) + b"".join(blobs) + bytes(64), np.uint8)
+        idx = np.arange(len(blobs), dtype=np.uint64)
+        d_pay = torch.from_numpy(payload.copy()).to(dev)
+        d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        d_idx = torch.from_numpy(idx.astype(np.int64)).to(dev)
+        d_po = torch.zeros(len(idx) + 1, dtype=torch.int64, device=dev)
+        want = b"".join(pem(b) for b in blobs)
+        for shift in ([0, 1, 7, 15] if ci else list(range(16))):
+            d_pem = torch.full((len(want) + 64,), 0xEE, dtype=torch.uint8, device=dev)
+            total = eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), len(idx),
+                                          d_pem.data_ptr() + shift, len(want), d_po.data_ptr())
+            assert total == len(want)
+            raw = d_pem.cpu().numpy().tobytes()
+            assert raw[shift:shift + total] == want, (ci, shift)
+            assert raw[:shift] == b"\xee" * shift and raw[shift + total:] == b"\xee" * (64 - shift), "wrote outside its buffer"
+    eng.close()
+
+
 def test_fingerprint_matches_hashlib():
     """Auxiliary whole-certificate SHA-256 (not on the reference's path): every length 0..300 covers
     all block/padding cases (55/56/63/64-byte boundaries), plus typical DER sizes; packed and ranged addressing."""
