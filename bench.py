@@ -741,6 +741,12 @@ def main():
                          "behaves when the lanes of a wave do not walk identical layouts.  The default run reports it as "
                          "secondary.mixed; this flag makes it the line's workload")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (mixed corpus, 128-byte aligned layout) of the default run")
+    ap.add_argument("--profile", choices=("fast", "reference"), default="fast",
+                    help="ctmr_set_profile: 'fast' = the engine's defaults (the headline); 'reference' = strict_spki + strict_leaf + "
+                         "strict_strings + strict_extensions — what the reference's x509.ParseCertificate decides, as far as it can be "
+                         "known here (DESIGN.md §3.1).  The default run reports it as secondary.reference_profile")
+    ap.add_argument("--strict-extensions", action="store_true",
+                    help="ctmr_set_strict_extensions(1) alone: the extension bodies Go parses (what it costs on top of the default walk)")
     ap.add_argument("--strict-strings", action="store_true",
                     help="ctmr_set_strict_strings(1): the opt-in character-set check of the Names' string values, inside the walk (what it costs: ms_per_step "
                          "and kernel_ms.map of this line against the default line)")
@@ -857,8 +863,12 @@ def main():
                           pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
                           lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
         eng.set_filter(filt, False, now)
+        if args.profile == "reference":
+            eng.set_profile("reference")
         if args.strict_strings:
             eng.set_strict_strings(True)
+        if args.strict_extensions:
+            eng.set_strict_extensions(True)
         if args.no_strict_spki:
             eng.set_strict_spki(False)
         if not args.raw or world > 1:
@@ -1078,7 +1088,8 @@ def main():
     kernels = [kname] + (["k_decode_match"] if args.raw else []) + (["k_meta_new"] if args.meta else [])
     mode_args = (["--mixed"] if args.mixed else []) + (["--aligned", str(args.aligned)] if args.aligned else []) + (["--raw"] if args.raw else []) + (["--meta"] if args.meta else []) + \
                 (["--trusted-chain"] if args.trusted_chain else []) + (["--global-dedup", args.global_dedup] if args.global_dedup else []) + \
-                (["--strict-strings"] if args.strict_strings else []) + (["--no-strict-spki"] if args.no_strict_spki else [])
+                (["--strict-strings"] if args.strict_strings else []) + (["--no-strict-spki"] if args.no_strict_spki else []) + \
+                (["--profile", args.profile] if args.profile != "fast" else []) + (["--strict-extensions"] if args.strict_extensions else [])
     plain = not (args.raw or args.global_dedup or args.meta)
     if rank == 0 and world == 1 and not os.environ.get("CTMR_BENCH_CHILD"):
         if args.traffic_file and plain:
@@ -1144,6 +1155,8 @@ def main():
                    "dedup": mode, "parallelism": parallelism,
                    "map_variant": args.variant or DEFAULT_VARIANT,
                    **({"strict_strings": True} if args.strict_strings else {}),
+                   **({"strict_extensions": True} if args.strict_extensions else {}),
+                   "profile": args.profile,
                    **({"strict_spki": False} if args.no_strict_spki else {}),
                    "gen_seconds": round(t_gen, 2)},
         # roofline of the dominant kernel.  `frac` is PHYSICAL when the traffic was measured: HBM bytes the kernel moved
@@ -1353,7 +1366,12 @@ def main():
         legs = (("mixed", 1, 0, "the same batch on the MIXED corpus (half EC P-256 keys, 40 % OV-like subjects of 120-260 B, longer "
                  "issuer names, one GeneralizedTime in four): the lanes of a wave do not walk identical layouts", ["--mixed"]),
                 ("aligned128", 0, 128, "the headline corpus with every certificate laid at a multiple of 128 bytes (an entry view; "
-                 "the payload grows by the padding): the front window of a certificate then starts on a line boundary", ["--aligned", "128"]))
+                 "the payload grows by the padding): the front window of a certificate then starts on a line boundary", ["--aligned", "128"]),
+                ("reference_profile", 0, 0, "the headline batch under ctmr_set_profile(CTMR_PROFILE_REFERENCE): strict_spki + strict_leaf + "
+                 "strict_strings + strict_extensions — every rule the reference's x509.ParseCertificate is known to apply, the "
+                 "subjectAltName walked element by element; same results on this (well-formed) corpus, the price of the rules in "
+                 "map_ms and traffic", ["--profile", "reference"]))
+        headline_profile = args.profile
         for name, profile, align, what, leg_args in legs:
             try:
                 if eng is not None:
@@ -1364,6 +1382,7 @@ def main():
                 lcfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
                                     ca_permille=10, expired_permille=10, profile=profile)
                 args.aligned = align
+                args.profile = "reference" if name == "reference_profile" else headline_profile
                 eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(0, E, lcfg)
                 mms, mst = [], None
                 for k in range(1 + 3):
@@ -1386,12 +1405,15 @@ def main():
                        "note": "step = table clear + one map/reduce call, host-timed like the headline",
                        "map_ms": m_map, "mean_der_bytes": l_bytes / E, "n_new": int(mst.n_new),
                        "frac_algorithmic": m_alg / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "frac": None}
+                if name == "reference_profile":
+                    sec["same_results_as_the_fast_profile"] = bool(int(mst.n_new) == int(stats.n_new) and
+                                                                   [int(x) for x in mst.by_status] == [int(x) for x in stats.by_status])
                 if align:
                     sec["payload_bytes_per_entry_with_padding"] = raw_view["aligned"][1] / E
                     sec["same_results_as_the_packed_layout"] = bool(int(mst.n_new) == int(stats.n_new) and
                                                                     [int(x) for x in mst.by_status] == [int(x) for x in stats.by_status])
                 if args.traffic == "auto":
-                    targs = argparse.Namespace(**dict(vars(args), aligned=0))
+                    targs = argparse.Namespace(**dict(vars(args), aligned=0, profile="fast"))
                     mt, merr = measure_traffic(targs, min(E, args.traffic_entries), [kname], leg_args)
                     if mt:
                         sec["traffic_bytes_per_cert"] = mt["traffic_bytes_per_cert"]
@@ -1403,6 +1425,7 @@ def main():
             except (ctmr.CtmrError, RuntimeError) as ex:
                 out["secondary"][name] = {"error": str(ex)}
         args.aligned = 0
+        args.profile = headline_profile
     if rank == 0:
         print(json.dumps(out))
     if group is not None:

@@ -13,8 +13,9 @@ LIB_PATH = os.environ.get("CTMR_LIB") or os.path.join(HERE, "libctmr.so")
 ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
     ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
 ST_COUNT = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 CHAIN0_EXACT, CHAIN0_TRUSTED_LOG = 0, 1
+PROFILE_FAST, PROFILE_REFERENCE = 0, 1
 ENTRY_INVALID = 0xFF
 FL_PRECERT, FL_WAS_UNKNOWN, FL_LONG_SERIAL = 1, 2, 4
 NO_ISSUER = 0xFFFFFFFF
@@ -164,6 +165,7 @@ SIGNATURES = {
     "ctmr_set_strict_extensions": (C.c_int, [_P, C.c_int]),
     "ctmr_set_strict_strings": (C.c_int, [_P, C.c_int]),
     "ctmr_set_strict_spki": (C.c_int, [_P, C.c_int]),
+    "ctmr_set_profile": (C.c_int, [_P, C.c_int]),
     "ctmr_pending_issuers": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "ctmr_pem_encode_view_device": (C.c_int, [_P, _P, C.POINTER(EntryView), _P, C.c_uint64, _P, C.c_uint64, _P,
                                               C.POINTER(C.c_uint64)]),

@@ -348,7 +348,7 @@ int upload_filter(ctmr_engine* e) {
   return CTMR_OK;
 }
 
-int ensure_capacity(ctmr_engine* e, uint64_t incoming, bool round_start = false);
+int ensure_capacity(ctmr_engine* e, uint64_t incoming, bool round_start = false, uint64_t incoming_cells = ~0ull);
 
 // in-place prefix sum of n u64 on the engine's stream (reduce.h: k_scan64_*); tile sums live in scratch buffer `which`
 int scan_u64(ctmr_engine* e, uint64_t* d_data, uint64_t n, bool inclusive, int which) {
@@ -384,6 +384,9 @@ int point_op(ctmr_engine* e, int op, int32_t exp_hour, uint32_t canon, const uin
   uint32_t res[2];
   HIPCHK(e, hipMemcpyAsync(res, e->d_result, 8, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (op == 0 && !res[0]) e->arena_used--;  // nothing was inserted (known member, or no room): the cell goes back — the call
+                                            // holds e->mu and nothing allocated in between (a host that re-reads a log of known
+                                            // certificates through SetInsert leaked 64 bytes per call: advisor, round 4)
   if (res[1]) return fail(e, CTMR_E_FULL, "known-certificate or pair table is full");
   if (op == 0 && res[0]) e->occupied++;
   *out = (int)res[0];
@@ -445,9 +448,11 @@ static int ensure_arena(ctmr_engine* e, uint64_t incoming, bool round_start) {
   return CTMR_OK;
 }
 
-int ensure_capacity(ctmr_engine* e, uint64_t incoming, bool round_start) {
+// incoming: index slots the call may claim; incoming_cells: arena cells it takes (default: as many) — an owner-computes
+// round reserves slots for its own shard AND the received keys behind the map, but its own cells are taken already.
+int ensure_capacity(ctmr_engine* e, uint64_t incoming, bool round_start, uint64_t incoming_cells) {
   int ar;
-  if ((ar = ensure_arena(e, incoming, round_start))) return ar;  // one cell per entry / received key / point insert
+  if ((ar = ensure_arena(e, incoming_cells == ~0ull ? incoming : incoming_cells, round_start))) return ar;  // one cell per entry / received key / point insert
   if ((e->occupied + incoming) * 4 <= e->nslots * 3) return CTMR_OK;
   // how many members are alive decides the new size: count them with the rebuild itself when tombstones may exist
   uint64_t want = pow2_at_least((e->occupied + incoming) * 2);

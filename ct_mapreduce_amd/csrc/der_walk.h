@@ -52,6 +52,9 @@ struct Walk {
 constexpr uint32_t WALK_NF_NEGATIVE_SERIAL = 1u;  // "x509: negative serial number"
 constexpr uint32_t WALK_NF_LAX_INTEGER = 2u;      // an INTEGER only CT-go's lax asn1 re-parse accepts (not minimal)
 constexpr uint32_t WALK_NF_STRING = 4u;           // strict_strings only: a Name value breaks its string type's character set
+constexpr uint32_t WALK_EXT_ON = 1u, WALK_EXT_NF = 2u;  // walk_cert's ext_mode: strict_extensions; non-fatal findings inside bodies matter to the caller
+constexpr uint32_t WALK_NF_EXT = 16u;             // strict_extensions only: what CT-go files as non-fatal inside an extension body
+                                                  // (8u is WALK_NF_SPKI, spki_key.h)
 
 constexpr uint32_t META_NONE = 0u;           // no such element
 constexpr uint32_t META_HOST = 0xffffffffu;  // does not fit 16+16 bits, or the extension occurs twice: host parse
@@ -570,6 +573,36 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
   return ce;
 }
 
+// The RelativeDistinguishedNames [cs, s_end) without a Name's outer header: what a distribution point's
+// nameRelativeToCRLIssuer holds behind its IMPLICIT [1] tag (crl_dps below; strict_extensions only).  The same rules as
+// walk_name's loop, without its 12-byte fast form — kept apart from it so that the map kernels' code for the two Names is
+// the code that was measured (a shared loop changed the default kernel's register allocation, round 5).
+template <bool STRINGS, class R>
+CTMR_HD void walk_rdns(R& r, uint32_t L, uint32_t cs, uint32_t s_end, bool& ok, uint32_t& nf, bool strings) {
+  uint32_t a = cs;
+  while (ok & (a < s_end)) {
+    uint32_t t1, c1, e1;
+    r.touch(a, 32);
+    rd_hdr(r, L, a, s_end, ok, t1, c1, e1);          // RelativeDistinguishedName: a universal SET
+    ok = ok & (t1 == 0x31u);
+    uint32_t b = c1;
+    while (ok & (b < e1)) {
+      uint32_t t2, c2, e2, to, co, eo, tv, cv, ev;
+      r.touch(b, 32);
+      rd_hdr(r, L, b, e1, ok, t2, c2, e2);           // AttributeTypeAndValue
+      rd_hdr(r, L, c2, e2, ok, to, co, eo);          // type OID
+      rd_hdr(r, L, eo, e2, ok, tv, cv, ev);          // value: must be there and fit; anything behind it is ignored
+      ok = ok & (t2 == 0x30u) & (to == 0x06u);
+      ok = ok && oid_arcs_ok(r, L, co, eo);
+      if (ok & !value_plain(tv)) name_value_check(r, L, tv, cv, ev, ok, nf);
+      if constexpr (STRINGS)
+        if (strings & ok) nf = value_strings_ok(r, L, tv, cv, ev) ? nf : (nf | WALK_NF_STRING);
+      b = e2;
+    }
+    a = e1;
+  }
+}
+
 // strict_extensions (opt-in): the BODIES of the extensions Go 1.13's parseCertificate unmarshals with
 // plain struct rules — a malformed one is an error of x509.ParseCertificate there (which of them CT-go's fork downgrades
 // is not verifiable here: hence a switch, off by default):
@@ -586,8 +619,10 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
 CTMR_HD uint32_t ext_kind(uint32_t oid_len, uint32_t w0, uint32_t w1) {  // w0, w1: the OID's first eight octets
   if ((oid_len == 3u) & ((w0 & 0xffffu) == 0x1d55u)) {
     const uint32_t arc = (w0 >> 16) & 0xffu;
-    return arc == 15u ? 1u : arc == 14u ? 2u : arc == 37u ? 3u : arc == 35u ? 4u : arc == 32u ? 5u : 0u;
+    return arc == 15u ? 1u : arc == 14u ? 2u : arc == 37u ? 3u : arc == 35u ? 4u : arc == 32u ? 5u :
+           arc == 17u ? 7u : arc == 30u ? 8u : arc == 31u ? 9u : 0u;  // 7 subjectAltName, 8 nameConstraints, 9 cRLDistributionPoints
   }
+  if ((oid_len == 10u) & (w0 == 0x0401062bu) & (w1 == 0x0279d601u)) return 10u;  // 1.3.6.1.4.1.11129.2.4.x: the caller looks at x
   return ((oid_len == 8u) & (w0 == 0x0501062bu) & (w1 == 0x01010705u)) ? 6u : 0u;
 }
 template <class R>
@@ -636,6 +671,534 @@ CTMR_HD void ext_body_check(R& r, uint32_t L, uint32_t kind, uint32_t cv, uint32
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// strict_extensions, round 5: the three extensions whose VALUE Go parses with code of its own, and CT-go's embedded SCT
+// list.  Recalled from Go 1.13's crypto/x509, net/url, net and golang.org/x/crypto/cryptobyte (go.mod:24) and from
+// certificate-transparency-go v1.1.0's fork of crypto/x509 — not verifiable on this machine:
+//   subjectAltName 2.5.29.17 (parseSANExtension → forEachSAN): asn1.Unmarshal(value, &seq RawValue) — one element that
+//     fits, nothing behind it ("trailing data"), a universal constructed SEQUENCE ("bad SAN sequence"); every element of it
+//     a RawValue that fits, dispatched on v.Tag ALONE (the class is not looked at): 1 rfc822Name and 2 dNSName are kept as
+//     they are (this toolchain checks no character set when it parses); 6 URI: url.Parse must succeed and, when the URL
+//     has a host, domainToReverseLabels(host) — else fatal; 7 iPAddress: 4 or 16 octets, any other length is what CT-go
+//     files as a NON-FATAL finding (the standard library fails); every other name form is ignored.
+//   cRLDistributionPoints 2.5.29.31: asn1.Unmarshal(value, &[]distributionPoint), nothing behind it —
+//     distributionPoint { DistributionPoint distributionPointName `optional,tag:0`; Reason BitString `optional,tag:1`;
+//     CRLIssuer RawValue `optional,tag:2` }, distributionPointName { FullName []RawValue `optional,tag:0`; RelativeName
+//     pkix.RDNSequence `optional,tag:1` } by encoding/asn1's struct rules (crl_dps below).
+//   nameConstraints 2.5.29.30 (parseNameConstraintsExtension, cryptobyte): SEQUENCE { [0] permitted, [1] excluded } filling
+//     the value, in that order, nothing else; not both absent or empty; every subtree SEQUENCE { base, … }: [2] dNSName IA5
+//     and, without one leading '.', domainToReverseLabels; [7] iPAddress 8 or 32 octets, the second half a contiguous mask;
+//     [1] rfc822Name IA5 and parseRFC2821Mailbox when it holds an '@', else as a domain; [6] URI IA5, not net.ParseIP, as a
+//     domain; other forms ignored.
+//   embedded SCT list 1.3.6.1.4.1.11129.2.4.2 (CT-go only): an OCTET STRING holding the TLS vector
+//     SignedCertificateTimestampList — every failure an nfe.AddError: NON-FATAL.
+//
+// Where the work runs.  The structural part (headers, tag dispatch, lengths) is a few instructions per element and runs
+// wherever the walk runs.  The parts that read an element's CONTENTS octet by octet — a URI, a name constraint, a
+// nameRelativeToCRLIssuer, an SCT list — are rare in certificates of the public logs and would put their loops, and their
+// registers, into the map kernel's window walk: a reader whose ld4 is served by its LDS window alone (WinReaderS) is told
+// defer_exact() instead, and the kernel repeats that one certificate with the exact global-memory reader, as it does for a
+// walk that left the window (kernels/reduce.h).
+template <class R, class = void>
+struct has_defer_exact : std::false_type {};
+template <class R>
+struct has_defer_exact<R, std::void_t<decltype(std::declval<R&>().defer_exact())>> : std::true_type {};
+
+// octet i of the element [base, …) — the content readers below address their string from 0
+template <class R>
+struct Octets {
+  const R& r;
+  uint32_t L, base;
+  CTMR_HD uint32_t operator[](uint32_t i) const { return ldc(r, base + i, L) & 0xffu; }
+};
+
+// x509.domainToReverseLabels(s).ok, fed octet by octet: no empty label (no leading or trailing dot, no ".."), every rune in
+// 33..126 (an octet >= 0x80 is, or decodes to, a rune above 126).  No octets at all: ok.
+struct LabelCheck {
+  uint32_t n = 0u, prev = 0u, first = 0u;
+  bool bad = false;
+  CTMR_HD void feed(uint32_t b) {
+    first = n == 0u ? b : first;
+    bad = bad | (b < 33u) | (b > 126u) | ((n != 0u) & (prev == 0x2eu) & (b == 0x2eu));
+    prev = b;
+    n++;
+  }
+  CTMR_HD bool ok() const { return (n == 0u) | (!bad & (first != 0x2eu) & (prev != 0x2eu)); }
+};
+CTMR_HD bool is_hex_octet(uint32_t c) { return ((c - 0x30u) <= 9u) | (((c | 0x20u) - 0x61u) <= 5u); }
+CTMR_HD uint32_t unhex_octet(uint32_t c) { return c <= 0x39u ? c - 0x30u : (c | 0x20u) - 0x61u + 10u; }
+CTMR_HD bool is_alnum_octet(uint32_t c) { return ((c - 0x30u) <= 9u) | (((c | 0x20u) - 0x61u) <= 25u); }
+// 1 << (c - 32) for the octets 32..95 / 96..127 that a set holds
+CTMR_HD bool in_set(uint32_t c, unsigned long long lo_32_95, uint32_t hi_96_127) {
+  return (((c - 32u) < 64u) & (((lo_32_95 >> ((c - 32u) & 63u)) & 1ull) != 0ull)) |
+         (((c - 96u) < 32u) & (((hi_96_127 >> ((c - 96u) & 31u)) & 1u) != 0u));
+}
+// net/url shouldEscape(c, encodeHost): letters and digits pass, and  ! $ & ' ( ) * + , ; = : [ ] < > " - _ . ~
+CTMR_HD bool url_host_should_escape(uint32_t c) {
+  // 32..95:  ! " $ & ' ( ) * + , - . : ; < = > [ ] _      96..127: ~
+  constexpr unsigned long long LO = (1ull << 1) | (1ull << 2) | (1ull << 4) | (1ull << 6) | (1ull << 7) | (1ull << 8) | (1ull << 9) |
+                                    (1ull << 10) | (1ull << 11) | (1ull << 12) | (1ull << 13) | (1ull << 14) | (1ull << 26) |
+                                    (1ull << 27) | (1ull << 28) | (1ull << 29) | (1ull << 30) | (1ull << 59) | (1ull << 61) | (1ull << 63);
+  return !(is_alnum_octet(c) | in_set(c, LO, 1u << 30));
+}
+// net/url unescape(s[lo, hi), mode) as far as it can fail; mode 0 = path / fragment / userinfo (escapes only), 1 = host,
+// 2 = zone.  lc (host, zone): the unescaped octets go to the label check.
+template <class B>
+CTMR_HD bool url_unescape_ok(const B& s, uint32_t lo, uint32_t hi, uint32_t mode, LabelCheck& lc) {
+  bool good = true;
+  uint32_t i = lo;
+  while (good & (i < hi)) {
+    const uint32_t c = s[i];
+    if (c == 0x25u) {  // '%'
+      const uint32_t h1 = i + 1u < hi ? s[i + 1u] : 0u, h2 = i + 2u < hi ? s[i + 2u] : 0u;
+      good = (i + 2u < hi) & is_hex_octet(h1) & is_hex_octet(h2);
+      const bool is25 = (h1 == 0x32u) & (h2 == 0x35u);
+      const uint32_t v = (unhex_octet(h1) << 4) | unhex_octet(h2);
+      if (mode == 1u) good = good & ((unhex_octet(h1) >= 8u) | is25);
+      if (mode == 2u) good = good & (is25 | (v == 0x20u) | !url_host_should_escape(v));
+      if (mode) lc.feed(v);
+      i += 3u;
+    } else {
+      if (mode) {
+        good = good & ((c == 0x2bu) | (c >= 0x80u) | !url_host_should_escape(c));
+        lc.feed(c);
+      }
+      i++;
+    }
+  }
+  return good;
+}
+template <class B>
+CTMR_HD uint32_t octet_index(const B& s, uint32_t lo, uint32_t hi, uint32_t c) {  // first c in [lo, hi), else hi
+  uint32_t i = lo;
+  while ((i < hi) && (s[i] != c)) i++;
+  return i;
+}
+template <class B>
+CTMR_HD uint32_t octet_last_index(const B& s, uint32_t lo, uint32_t hi, uint32_t c) {  // last c in [lo, hi), else hi
+  uint32_t at = hi;
+  for (uint32_t i = lo; i < hi; i++) at = s[i] == c ? i : at;
+  return at;
+}
+template <class B>
+CTMR_HD bool url_port_ok(const B& s, uint32_t lo, uint32_t hi) {  // validOptionalPort
+  bool good = (lo == hi) || (s[lo] == 0x3au);
+  for (uint32_t i = lo + 1u; good & (i < hi); i++) good = (s[i] - 0x30u) <= 9u;
+  return good;
+}
+// url.Parse(s[0, n)) succeeds and the URL's host, when it has one, passes domainToReverseLabels (parseSANExtension,
+// nameTypeURI).  Go 1.13's net/url: the control-character test, getscheme, the opaque form, "first path segment in URL cannot
+// contain colon", parseAuthority / parseHost (IP-literal brackets, the RFC 6874 zone, the port), validUserinfo and the
+// escapes of userinfo, path and fragment; the query is not looked at.
+template <class B>
+CTMR_HD bool san_uri_ok(const B& s, uint32_t n) {
+  const uint32_t un = octet_index(s, 0u, n, 0x23u);  // '#': u = s[:un], fragment behind it
+  bool good = true;
+  for (uint32_t i = 0; good & (i < un); i++) good = (s[i] >= 0x20u) & (s[i] != 0x7fu);
+  LabelCheck host, none;
+  const bool star = (un == 1u) && (s[0] == 0x2au);
+  if (good & !star) {
+    uint32_t rest = 0u;
+    bool scheme = false;
+    {  // getscheme
+      uint32_t i = 0u;
+      bool more = true;
+      while (more & (i < un)) {
+        const uint32_t c = s[i];
+        const bool letter = ((c | 0x20u) - 0x61u) <= 25u;
+        const bool mark = ((c - 0x30u) <= 9u) | (c == 0x2bu) | (c == 0x2du) | (c == 0x2eu);
+        if (letter | (mark & (i != 0u))) {
+          i++;
+        } else {
+          if (c == 0x3au) {
+            good = i != 0u;  // "missing protocol scheme"
+            scheme = i != 0u;
+            rest = i != 0u ? i + 1u : 0u;
+          }
+          more = false;
+        }
+      }
+    }
+    uint32_t re = octet_index(s, rest, un, 0x3fu);  // the query goes, whatever its form
+    const bool rooted = (rest < re) && (s[rest] == 0x2fu);
+    bool opaque = false;
+    if (good & !rooted) {
+      opaque = scheme;
+      if (!scheme) {
+        const uint32_t colon = octet_index(s, rest, re, 0x3au), slash = octet_index(s, rest, re, 0x2fu);
+        good = !((colon < re) & ((slash == re) | (colon < slash)));
+      }
+    }
+    if (good & !opaque) {
+      const bool two = (re - rest >= 2u) && (s[rest] == 0x2fu) && (s[rest + 1u] == 0x2fu);
+      const bool three = two && (re - rest >= 3u) && (s[rest + 2u] == 0x2fu);
+      if (two & (scheme | !three)) {  // an authority
+        const uint32_t a0 = rest + 2u, a1 = octet_index(s, a0, re, 0x2fu);
+        const uint32_t at = octet_last_index(s, a0, a1, 0x40u);  // '@'
+        const uint32_t h0 = at < a1 ? at + 1u : a0;
+        // parseHost
+        if ((h0 < a1) && (s[h0] == 0x5bu)) {  // '[': an IP literal
+          const uint32_t rb = octet_last_index(s, h0, a1, 0x5du);
+          good = (rb < a1) && url_port_ok(s, rb + 1u, a1);
+          if (good) {
+            uint32_t z = h0;  // "%25" in front of the bracket: a zone
+            bool found = false;
+            while (!found & (z + 3u <= rb)) {
+              found = (s[z] == 0x25u) && (s[z + 1u] == 0x32u) && (s[z + 2u] == 0x35u);
+              z += found ? 0u : 1u;
+            }
+            if (found) good = url_unescape_ok(s, h0, z, 1u, host) && url_unescape_ok(s, z, rb, 2u, host) && url_unescape_ok(s, rb, a1, 1u, host);
+            else good = url_unescape_ok(s, h0, a1, 1u, host);
+          }
+        } else {
+          const uint32_t cl = octet_last_index(s, h0, a1, 0x3au);
+          good = (cl == a1) || url_port_ok(s, cl, a1);
+          good = good && url_unescape_ok(s, h0, a1, 1u, host);
+        }
+        if (good & (at < a1)) {  // validUserinfo, then the escapes of user and password
+          // 32..95: ! $ & ' ( ) * + , - . : ; = @ _     96..127: ~     (and '%', letters, digits)
+          constexpr unsigned long long UI = (1ull << 1) | (1ull << 4) | (1ull << 5) | (1ull << 6) | (1ull << 7) | (1ull << 8) | (1ull << 9) |
+                                            (1ull << 10) | (1ull << 11) | (1ull << 12) | (1ull << 13) | (1ull << 14) | (1ull << 26) |
+                                            (1ull << 27) | (1ull << 29) | (1ull << 32) | (1ull << 63);
+          for (uint32_t i = a0; good & (i < at); i++) good = is_alnum_octet(s[i]) | in_set(s[i], UI, 1u << 30);
+          good = good && url_unescape_ok(s, a0, at, 0u, none);
+        }
+        rest = a1;
+      }
+      good = good && url_unescape_ok(s, rest, re, 0u, none);  // setPath
+    }
+  }
+  if (good & (un < n)) good = url_unescape_ok(s, un + 1u, n, 0u, none);  // the fragment
+  return good && host.ok();
+}
+
+// subjectAltName: [cv, ev) = the extension's value.  nf: an iPAddress of another length than 4 or 16 (CT-go: non-fatal).
+template <class R>
+CTMR_HD void ext_san_check(R& r, uint32_t L, uint32_t cv, uint32_t ev, bool& ok, uint32_t& nf) {
+  uint32_t t, c, ce;
+  r.touch(cv, 48);
+  rd_hdr(r, L, cv, ev, ok, t, c, ce);
+  ok = ok & (ce == ev) & (t == 0x30u);  // one element, nothing behind it, a universal constructed SEQUENCE
+  uint32_t p = c;
+  while (ok & (p < ev)) {  // GeneralNames: every element a RawValue that fits; dispatch on the tag NUMBER alone
+    r.touch(p, 16);
+    const uint32_t w = ldc(r, p, L);
+    const uint32_t tg = w & 0xffu, lb = (w >> 8) & 0xffu;
+    uint32_t x, xe;
+    if (((tg & 0x1fu) != 0x1fu) & (lb < 0x80u)) {  // short form (every dNSName of the Web PKI): no second read
+      x = p + 2u;
+      xe = x + lb;
+      ok = ok & (xe <= ev);
+    } else {
+      uint32_t t2;
+      rd_hdr(r, L, p, ev, ok, t2, x, xe);
+    }
+    const uint32_t tn = tg & 0x1fu;  // (0x1f: the high-tag-number form — a number >= 31, no case below)
+    nf = (ok & (tn == 7u) & (xe - x != 4u) & (xe - x != 16u)) ? (nf | WALK_NF_EXT) : nf;
+    if (ok & (tn == 6u)) {
+      if constexpr (has_defer_exact<R>::value) r.defer_exact();
+      else ok = san_uri_ok(Octets<R>{r, L, x}, xe - x);
+    }
+    p = xe;
+  }
+}
+
+// cRLDistributionPoints: [cv, ev) = the extension's value, []distributionPoint by encoding/asn1's struct rules — fields in
+// order, each preceded by a header that must parse unless the contents are used up, a field of another tag skipped, a
+// matching field must fit, what follows the last field ignored.
+//   COLLECT  the FullName elements with tag NUMBER 6 go to uo/ul (certificate offsets / lengths; nu counts all of them):
+//            parseCertificate's CRLDistributionPoints, what IssuerMetadata.Accumulate reads (kernels/meta*.h)
+//   DEEP     a nameRelativeToCRLIssuer's contents are parsed as well (RelativeDistinguishedNames: walk_rdns) — the
+//            certificate check; the metadata side only needs to know where the URIs are
+template <bool COLLECT, bool DEEP, bool STRINGS, uint32_t MAXU, class R>
+CTMR_HD void crl_dps(R& r, uint32_t L, uint32_t cv, uint32_t ev, bool& ok, uint32_t (&uo)[MAXU], uint32_t (&ul)[MAXU],
+                     uint32_t& nu, uint32_t& nf, bool strings) {
+  uint32_t t, p, pe;
+  rd_hdr(r, L, cv, ev, ok, t, p, pe);
+  ok = ok & (t == 0x30u) & (pe == ev);
+  while (ok & (p < ev)) {
+    uint32_t td, off, end;
+    rd_hdr(r, L, p, ev, ok, td, off, end);
+    ok = ok & (td == 0x30u);
+    uint32_t tf = 0u, fc = 0u, fe = 0u;
+    if (ok & (off < end)) rd_hdr<false>(r, L, off, end, ok, tf, fc, fe);
+    if (ok & (off < end) & (tf == 0xa0u)) {  // DistributionPoint distributionPointName `optional,tag:0`
+      ok = ok & (fe <= end);
+      uint32_t n = fc, tg = 0u, gc = 0u, ge = 0u;
+      const uint32_t n_end = fe;
+      if (ok & (n < n_end)) rd_hdr<false>(r, L, n, n_end, ok, tg, gc, ge);
+      if (ok & (n < n_end) & (tg == 0xa0u)) {  // FullName []asn1.RawValue `optional,tag:0`
+        ok = ok & (ge <= n_end);
+        uint32_t q = gc;
+        while (ok & (q < ge)) {
+          uint32_t tn, u, ue;
+          rd_hdr(r, L, q, ge, ok, tn, u, ue);
+          if constexpr (COLLECT) {
+            if (ok & ((tn & 0x1fu) == 6u)) {
+#pragma unroll
+              for (uint32_t k = 0; k < MAXU; k++) {  // register arrays: no dynamic indexing
+                uo[k] = k == nu ? u : uo[k];
+                ul[k] = k == nu ? ue - u : ul[k];
+              }
+              nu++;
+            }
+          }
+          q = ue;
+        }
+        n = ge;
+        tg = 0u;
+        if (ok & (n < n_end)) rd_hdr<false>(r, L, n, n_end, ok, tg, gc, ge);
+      }
+      if (ok & (n < n_end) & (tg == 0xa1u)) {  // RelativeName pkix.RDNSequence `optional,tag:1`
+        ok = ok & (ge <= n_end);
+        if constexpr (DEEP) {
+          if (ok) {
+            if constexpr (has_defer_exact<R>::value) {
+              r.defer_exact();
+            } else {
+              uint32_t nfr = 0u;
+              walk_rdns<STRINGS>(r, L, gc, ge, ok, nfr, strings);
+              nf |= (nfr & WALK_NF_LAX_INTEGER) ? WALK_NF_EXT : 0u;
+              nf |= nfr & WALK_NF_STRING;
+            }
+          }
+        }
+      }
+      off = fe;
+      tf = 0u;
+      if (ok & (off < end)) rd_hdr<false>(r, L, off, end, ok, tf, fc, fe);
+    }
+    if (ok & (off < end) & (tf == 0x81u)) {  // Reason asn1.BitString `optional,tag:1`
+      ok = ok & (fe <= end);
+      bit_string_check(r, L, fc, fe - fc, ok);
+      off = fe;
+      tf = 0u;
+      if (ok & (off < end)) rd_hdr<false>(r, L, off, end, ok, tf, fc, fe);
+    }
+    if (ok & (off < end) & ((tf == 0x82u) | (tf == 0xa2u))) ok = fe <= end;  // CRLIssuer asn1.RawValue `optional,tag:2`
+    p = end;
+  }
+}
+
+// nameConstraints, read the way golang.org/x/crypto/cryptobyte reads it (a tag is the whole identifier octet, the
+// high-tag-number form is refused, an optional element is recognised by its first octet alone).  Contents only: callers
+// whose reader defers have done so.
+template <class B>
+CTMR_HD bool nc_ip_mask_ok(const B& s, uint32_t lo, uint32_t hi) {  // isValidIPMask: ones, then zeros
+  bool good = true, zero = false;
+  for (uint32_t i = lo; good & (i < hi); i++) {
+    const uint32_t b = s[i], inv = ~b & 0xffu;
+    good = zero ? (b == 0u) : ((inv & (inv + 1u)) == 0u);
+    zero = zero | (b != 0xffu);
+  }
+  return good;
+}
+template <class B>
+CTMR_HD bool labels_ok(const B& s, uint32_t lo, uint32_t hi) {
+  LabelCheck lc;
+  for (uint32_t i = lo; i < hi; i++) lc.feed(s[i]);
+  return lc.ok();
+}
+template <class B>
+CTMR_HD bool go_dtoi(const B& s, uint32_t& i, uint32_t hi, uint32_t& v) {  // net.dtoi: digits, value below 0xFFFFFF, at least one
+  const uint32_t i0 = i;
+  bool good = true;
+  v = 0u;
+  while (good & (i < hi) && ((s[i] - 0x30u) <= 9u)) {
+    v = v * 10u + (s[i] - 0x30u);
+    good = v < 0xFFFFFFu;
+    i += good ? 1u : 0u;
+  }
+  return good & (i != i0);
+}
+template <class B>
+CTMR_HD bool go_parse_ipv4(const B& s, uint32_t lo, uint32_t hi) {  // net.parseIPv4 of go1.13 (leading zeros are fine)
+  bool good = true;
+  uint32_t i = lo;
+  for (uint32_t k = 0; good & (k < 4u); k++) {
+    good = i < hi;
+    if (good & (k > 0u)) {
+      good = s[i] == 0x2eu;
+      i++;
+    }
+    uint32_t v = 0u;
+    good = good && go_dtoi(s, i, hi, v) && (v <= 0xffu);
+  }
+  return good & (i == hi);
+}
+template <class B>
+CTMR_HD bool go_parse_ipv6(const B& s, uint32_t lo, uint32_t hi) {  // net.parseIPv6 of go1.13 (no zone)
+  int ellipsis = -1;
+  uint32_t i = lo, at = 0u;  // at: octets of the address filled so far
+  if ((hi - lo >= 2u) && (s[lo] == 0x3au) && (s[lo + 1u] == 0x3au)) {
+    ellipsis = 0;
+    i = lo + 2u;
+    if (i == hi) return true;
+  }
+  bool good = true, more = true;
+  while (good & more & (at < 16u)) {
+    uint32_t v = 0u, c = i;  // xtoi
+    while (good & (c < hi) && is_hex_octet(s[c])) {
+      v = v * 16u + unhex_octet(s[c]);
+      good = v < 0xFFFFFFu;
+      c += good ? 1u : 0u;
+    }
+    good = good & (c != i) & (v <= 0xffffu);
+    if (!good) break;
+    if ((c < hi) && (s[c] == 0x2eu)) {  // a trailing dotted quad
+      good = !((ellipsis < 0) & (at != 12u)) & (at + 4u <= 16u) && go_parse_ipv4(s, i, hi);
+      i = hi;
+      at += 4u;
+      more = false;
+    } else {
+      at += 2u;
+      i = c;
+      if (i == hi) {
+        more = false;
+      } else {
+        good = (s[i] == 0x3au) & (hi - i != 1u);
+        i++;
+        if (good && (s[i] == 0x3au)) {
+          good = ellipsis < 0;
+          ellipsis = (int)at;
+          i++;
+          more = i != hi;
+        }
+      }
+    }
+  }
+  return good & (i == hi) & (at < 16u ? ellipsis >= 0 : ellipsis < 0);
+}
+template <class B>
+CTMR_HD bool go_parse_ip(const B& s, uint32_t lo, uint32_t hi) {  // net.ParseIP(s) != nil
+  for (uint32_t i = lo; i < hi; i++) {
+    if (s[i] == 0x2eu) return go_parse_ipv4(s, lo, hi);
+    if (s[i] == 0x3au) return go_parse_ipv6(s, lo, hi);
+  }
+  return false;
+}
+template <class B>
+CTMR_HD bool go_mailbox_ok(const B& s, uint32_t lo, uint32_t hi) {  // x509.parseRFC2821Mailbox(s).ok
+  if (lo == hi) return false;
+  uint32_t i = lo;
+  bool good = true;
+  if (s[lo] == 0x22u) {  // quoted-string
+    i = lo + 1u;
+    bool open = true;
+    while (good & open) {
+      good = i < hi;
+      if (!good) break;
+      const uint32_t c = s[i++];
+      if (c == 0x22u) {
+        open = false;
+      } else if (c == 0x5cu) {  // quoted-pair
+        const uint32_t e = i < hi ? s[i] : 0u;
+        good = (i < hi) & ((e == 11u) | (e == 12u) | ((e - 1u) <= 8u) | ((e - 14u) <= 113u));
+        i++;
+      } else {  // qtext (with the space RFC 3696's example needs)
+        good = (c == 11u) | (c == 12u) | (c == 32u) | (c == 33u) | (c == 127u) | ((c - 1u) <= 7u) | ((c - 14u) <= 17u) |
+               ((c - 35u) <= 56u) | ((c - 93u) <= 33u);
+      }
+    }
+  } else {  // Atom ("." Atom)*, backslash escapes accepted outside quotes as well
+    // 32..95: ! # $ % & ' * + - . / = ? ^ _     96..127: ` { | } ~
+    constexpr unsigned long long AT = (1ull << 1) | (1ull << 3) | (1ull << 4) | (1ull << 5) | (1ull << 6) | (1ull << 7) | (1ull << 10) |
+                                      (1ull << 11) | (1ull << 13) | (1ull << 14) | (1ull << 15) | (1ull << 29) | (1ull << 31) |
+                                      (1ull << 62) | (1ull << 63);
+    constexpr uint32_t AT_HI = (1u << 0) | (1u << 27) | (1u << 28) | (1u << 29) | (1u << 30);
+    uint32_t nlocal = 0u, first = 0u, last = 0u;
+    bool dots = false, more = true;
+    while (good & more & (i < hi)) {
+      const uint32_t c = s[i];
+      if (c == 0x5cu) {
+        i++;
+        good = i < hi;
+      } else if (!(is_alnum_octet(c) | in_set(c, AT, AT_HI))) {
+        more = false;
+      }
+      if (good & more) {
+        const uint32_t b = s[i++];  // after a backslash: the escaped octet, whatever it is
+        first = nlocal == 0u ? b : first;
+        dots = dots | ((nlocal != 0u) & (last == 0x2eu) & (b == 0x2eu));
+        last = b;
+        nlocal++;
+      }
+    }
+    good = good & (nlocal != 0u) & (first != 0x2eu) & (last != 0x2eu) & !dots;
+  }
+  good = good && (i < hi) && (s[i] == 0x40u);
+  return good && labels_ok(s, i + 1u, hi);
+}
+template <class R>
+CTMR_HD void nc_subtrees(const R& r, uint32_t L, uint32_t p, uint32_t end, bool& ok) {
+  while (ok & (p < end)) {
+    uint32_t t, c, ce, tv, v, ve;
+    rd_hdr(r, L, p, end, ok, t, c, ce);           // ReadASN1(&seq, SEQUENCE)
+    ok = ok & (t == 0x30u);
+    rd_hdr(r, L, c, ce, ok, tv, v, ve);           // seq.ReadAnyASN1(&value, &tag); minimum / maximum are not read
+    ok = ok & ((tv & 0x1fu) != 0x1fu);
+    if (ok) {
+      const Octets<R> s{r, L, 0u};
+      bool ia5 = true;
+      if ((tv == 0x82u) | (tv == 0x81u) | (tv == 0x86u))
+        for (uint32_t i = v; ia5 & (i < ve); i++) ia5 = s[i] < 0x80u;
+      const uint32_t v1 = ((v < ve) && (s[v] == 0x2eu)) ? v + 1u : v;  // one leading '.' is the constraint's own syntax
+      if (tv == 0x82u) {
+        ok = ia5 && labels_ok(s, v1, ve);
+      } else if (tv == 0x87u) {
+        const uint32_t n = ve - v;
+        ok = ((n == 8u) | (n == 32u)) && nc_ip_mask_ok(s, v + n / 2u, ve);
+      } else if (tv == 0x81u) {
+        ok = ia5 && (octet_index(s, v, ve, 0x40u) < ve ? go_mailbox_ok(s, v, ve) : labels_ok(s, v1, ve));
+      } else if (tv == 0x86u) {
+        ok = ia5 && !go_parse_ip(s, v, ve) && labels_ok(s, v1, ve);
+      }
+    }
+    p = ce;
+  }
+}
+template <class R>
+CTMR_HD void ext_nc_check(const R& r, uint32_t L, uint32_t cv, uint32_t ev, bool& ok) {
+  uint32_t t, p, pe;
+  ok = ok & (ev - cv >= 2u);
+  rd_hdr(r, L, cv, ev, ok, t, p, pe);             // outer.ReadASN1(&toplevel, SEQUENCE) && outer.Empty()
+  ok = ok & (t == 0x30u) & (pe == ev);
+  bool have_p = false, have_e = false;
+  uint32_t ps = 0u, pn = 0u, es = 0u, en = 0u, tf, fc, fe;
+  if (ok & (p < ev) && ((ldc(r, p, L) & 0xffu) == 0xa0u)) {
+    ok = ok & (ev - p >= 2u);
+    rd_hdr(r, L, p, ev, ok, tf, fc, fe);
+    have_p = true; ps = fc; pn = fe; p = fe;
+  }
+  if (ok & (p < ev) && ((ldc(r, p, L) & 0xffu) == 0xa1u)) {
+    ok = ok & (ev - p >= 2u);
+    rd_hdr(r, L, p, ev, ok, tf, fc, fe);
+    have_e = true; es = fc; en = fe; p = fe;
+  }
+  ok = ok & (p == ev);                             // toplevel.Empty()
+  ok = ok & (have_p | have_e) & ((pn != ps) | (en != es));  // "x509: empty name constraints extension"
+  if (have_p) nc_subtrees(r, L, ps, pn, ok);
+  if (have_e) nc_subtrees(r, L, es, en, ok);
+}
+
+// CT-go's embedded SCT list: OCTET STRING { opaque list<1..2^16-1> of opaque sct<1..2^16-1> }, nothing left over anywhere
+template <class R>
+CTMR_HD bool ext_sct_ok(const R& r, uint32_t L, uint32_t cv, uint32_t ev) {
+  bool good = true;
+  uint32_t t, c, ce;
+  rd_hdr(r, L, cv, ev, good, t, c, ce);
+  good = good & (t == 0x04u) & (ce == ev) & (ev - c >= 2u);
+  const uint32_t ll = __builtin_bswap32(ldc(r, c, L)) >> 16;
+  uint32_t p = c + 2u;
+  good = good && (ll >= 1u) && (p + ll == ev);
+  while (good & (p < ev)) {
+    const uint32_t sl = __builtin_bswap32(ldc(r, p, L)) >> 16;
+    good = (ev - p >= 2u) && (sl >= 1u) && (p + 2u + sl <= ev);
+    p += 2u + sl;
+  }
+  return good;
+}
+
 // `filter` may be null (no CN filter configured: cn_match = true).  r.touch(pos, need) tells a
 // windowed reader that about `need` bytes from pos are read next; r.touch_tail(pos, tail) that the
 // bytes from pos AND the bytes at `tail` are read next; other readers ignore both.
@@ -672,7 +1235,8 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // cost the default kernel 0.5 ms per 100 M certificates, A/B on one box, round 4).
 template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false, bool EC_DEFER = false, bool STRINGS = true>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv, bool spki = true, bool strings = false,
-                       bool ext = false) {
+                       uint32_t ext_mode = 0u) {
+  const bool ext = (ext_mode & WALK_EXT_ON) != 0u, ext_nf = (ext_mode & WALK_EXT_NF) != 0u;
   o.serial_off = o.serial_len = 0;
 #pragma unroll
   for (int k = 0; k < 5; k++) o.serial_w[k] = 0;
@@ -879,10 +1443,25 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         const uint32_t pk = o.meta_crl == META_NONE ? meta_pack(cv, ev - cv) : META_HOST;
         o.meta_crl = is_crl ? pk : o.meta_crl;
       }
-      if constexpr (STRINGS) {  // strict_extensions: the body of an extension Go unmarshals by plain struct rules
+      if constexpr (STRINGS) {  // strict_extensions: the body of an extension Go unmarshals
         if (ext & ok) {
           const uint32_t kind = ext_kind(eo - co, oidw, ldc(r, co + 4u, L));
-          if (kind) ext_body_check(r, L, kind, cv, ev, ok);
+          if ((kind >= 1u) & (kind <= 6u)) {
+            ext_body_check(r, L, kind, cv, ev, ok);
+          } else if (kind == 7u) {
+            ext_san_check(r, L, cv, ev, ok, o.nonfatal);
+          } else if (kind == 9u) {
+            uint32_t uo[1] = {0u}, ul[1] = {0u}, nu = 0u;
+            r.touch(cv, ev - cv < 200u ? ev - cv : 200u);
+            crl_dps<false, true, STRINGS, 1u>(r, L, cv, ev, ok, uo, ul, nu, o.nonfatal, strings);
+          } else if (kind == 8u) {  // (contents: a reader that serves its window alone hands the certificate to the exact one)
+            if constexpr (has_defer_exact<R>::value) r.defer_exact();
+            else ext_nc_check(r, L, cv, ev, ok);
+          } else if ((kind == 10u) & ext_nf && ((ldc(r, co + 8u, L) & 0xffffu) == 0x0204u)) {
+            // the embedded SCT list: a finding only a precertificate or an issuer could lose its place over
+            if constexpr (has_defer_exact<R>::value) r.defer_exact();
+            else o.nonfatal = ext_sct_ok(r, L, cv, ev) ? o.nonfatal : (o.nonfatal | WALK_NF_EXT);
+          }
         }
       }
       if (ok & (eo - co == 3u) & ((oidw & 0xffffffu) == 0x131d55u)) {
@@ -929,13 +1508,15 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
 
 template <class R>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, const FilterView* filter = nullptr, bool spki = true, bool strings = false,
-                       bool ext = false) {
-  return filter ? walk_cert<R>(r, L, o, true, *filter, spki, strings, ext)
-                : walk_cert<R>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki, strings, ext);
+                       bool ext = false, bool ext_nf = true) {
+  const uint32_t m = ext ? (ext_nf ? WALK_EXT_ON | WALK_EXT_NF : WALK_EXT_ON) : 0u;
+  return filter ? walk_cert<R>(r, L, o, true, *filter, spki, strings, m)
+                : walk_cert<R>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki, strings, m);
 }
 template <class R>
 CTMR_HD bool walk_tbs(R& r, uint32_t L, Walk& o, bool spki = true, bool ext = false) {
-  return walk_cert<R, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki, false, ext);
+  // (ct.LogEntryFromLeaf drops a precertificate entry over its TBSCertificate on FATAL errors only: no ext_nf)
+  return walk_cert<R, true>(r, L, o, false, FilterView{0, nullptr, nullptr, nullptr}, spki, false, ext ? WALK_EXT_ON : 0u);
 }
 
 }  // namespace ctmr

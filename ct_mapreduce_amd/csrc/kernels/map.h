@@ -78,7 +78,8 @@ __device__ __forceinline__ void map_one(R& r, uint64_t len64, uint64_t idx, cons
   const uint32_t iss = in.iss, et = in.et;
   // (STRICT is instantiated for engines with strict_strings OR strict_extensions: the filter says which)
   bool ok = walk_cert<R, false, false, true, STRICT>(r, L, w, f->active != 0u, fv, (f->strict_spki != 0u) & (a.keypos != nullptr),
-                                                     STRICT & (f->strict_strings != 0u) & (et == 1u), STRICT & (f->strict_ext != 0u));
+                                                     STRICT & (f->strict_strings != 0u) & (et == 1u),
+                                                     (STRICT & (f->strict_ext != 0u)) ? (et == 1u ? WALK_EXT_ON | WALK_EXT_NF : WALK_EXT_ON) : 0u);
   // An X509 entry's certificate was parsed by ct.LogEntryFromLeaf, which keeps it unless the error is fatal
   // (ct-fetch.go:452-459); a precertificate is parsed in insertCTWorker and dropped on ANY error, CT-go's
   // x509.NonFatalErrors included (:202-209).  Fields of a dropped certificate are not reported.

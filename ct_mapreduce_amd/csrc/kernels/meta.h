@@ -235,18 +235,13 @@ __global__ void __launch_bounds__(256) k_meta_new(MetaArgs a) {
   bool crl_ok = false;
   if (!host && cr_len != 0u) {
     const uint32_t e = cr_s + cr_len;
-    bool ok = true;
-    uint32_t tag, cs, ce;
+    bool ok;
     if (cr_lds) {
       LdsTlvReader g{cw, cr_s};
-      rd_hdr(g, e, cr_s, e, ok, tag, cs, ce);  // L = e: reads clamp to the staged value, not to the certificate
-      ok = ok && tag == 0x30u && ce == e;
-      ok = ok && walk_crl_dps(g, e, cs, e, uo, ul, nu, host);
+      ok = walk_crl_dps(g, e, cr_s, e, uo, ul, nu, host);  // L = e: reads clamp to the staged value, not to the certificate
     } else {
       ByteReader g{cert};
-      rd_hdr(g, L, cr_s, e, ok, tag, cs, ce);
-      ok = ok && tag == 0x30u && ce == e;
-      ok = ok && walk_crl_dps(g, L, cs, e, uo, ul, nu, host);
+      ok = walk_crl_dps(g, L, cr_s, e, uo, ul, nu, host);
     }
     crl_ok = ok && !host;
   }

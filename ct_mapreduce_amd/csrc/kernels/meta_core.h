@@ -108,47 +108,19 @@ struct LdsTlvReader {  // rd_hdr over the staged cRLDistributionPoints value: po
   }
 };
 
-// DistributionPoint walk (RFC 5280 §4.2.1.13) over [cs, e): collects up to META_MAX_URIS URI ranges (certificate
-// offsets); returns false when the value is malformed.  `host` is set when a URI is too long or there are too many.
+// Where the URIs of a cRLDistributionPoints value [cv, e) lie: der_walk.h crl_dps<COLLECT> — Go's positional struct
+// rules, the FullName elements with tag NUMBER 6 (round 5; rounds 1–4 took every [0] { [0] { [6] } } in any order).
+// Returns false when the value is malformed (it yields NO URIs then, as the oracle defines); `host` is set when a URI is
+// too long or there are too many.
 template <class R>
-__device__ __forceinline__ bool walk_crl_dps(const R& g, uint32_t L, uint32_t cs, uint32_t e, uint32_t uo[META_MAX_URIS],
-                                             uint32_t ul[META_MAX_URIS], uint32_t& nu, bool& host) {
+__device__ __forceinline__ bool walk_crl_dps(const R& g, uint32_t L, uint32_t cv, uint32_t e, uint32_t (&uo)[META_MAX_URIS],
+                                             uint32_t (&ul)[META_MAX_URIS], uint32_t& nu, bool& host) {
   bool ok = true;
-  uint32_t p = cs;
-  while (ok && p < e) {
-    uint32_t t1, f, f_end;
-    rd_hdr(g, L, p, e, ok, t1, f, f_end);
-    ok = ok && t1 == 0x30u;
-    while (ok && f < f_end) {
-      uint32_t t2, n, n_end;
-      rd_hdr(g, L, f, f_end, ok, t2, n, n_end);
-      if (ok && t2 == 0xa0u) {
-        while (ok && n < n_end) {
-          uint32_t t3, q, q_end;
-          rd_hdr(g, L, n, n_end, ok, t3, q, q_end);
-          if (ok && t3 == 0xa0u) {
-            while (ok && q < q_end) {
-              uint32_t t4, u, u_end;
-              rd_hdr(g, L, q, q_end, ok, t4, u, u_end);
-              if (ok && t4 == 0x86u) {
-                if (u_end - u > META_MAX_BYTES || nu >= META_MAX_URIS) host = true;
+  uint32_t nf = 0u;
+  crl_dps<true, false, false, META_MAX_URIS>(g, L, cv, e, ok, uo, ul, nu, nf, false);
+  host = host | (nu > META_MAX_URIS);
 #pragma unroll
-                for (uint32_t k = 0; k < META_MAX_URIS; k++) {  // register array: no dynamic indexing
-                  uo[k] = k == nu ? u : uo[k];
-                  ul[k] = k == nu ? u_end - u : ul[k];
-                }
-                nu++;
-              }
-              q = u_end;
-            }
-          }
-          n = q_end;
-        }
-      }
-      f = n_end;
-    }
-    p = f_end;
-  }
+  for (uint32_t k = 0; k < META_MAX_URIS; k++) host = host | ((k < nu) & (ul[k] > META_MAX_BYTES));
   return ok;
 }
 
@@ -266,11 +238,8 @@ __device__ __forceinline__ MetaTail meta_tail_issue(const MetaCheck& m, unsigned
 #pragma unroll
       for (uint32_t k = 0; k < META_MAX_URIS; k++) uo[k] = ul[k] = 0;
       bool ok = true, host = false;
-      uint32_t tag, cs, ce;
       const uint32_t e = cr_s + cr_len;
-      rd_hdr(g, e, cr_s, e, ok, tag, cs, ce);
-      ok = ok && tag == 0x30u && ce == e;
-      ok = ok && walk_crl_dps(g, e, cs, e, uo, ul, nu, host);
+      ok = walk_crl_dps(g, e, cr_s, e, uo, ul, nu, host);  // L = e: reads clamp to the value, not to the certificate
       if (host) t.state = 0;                 // k_meta_new hands this certificate to the host
       else if (!ok || nu == 0u) t.state = 1; // a malformed value yields NO URIs (k_meta_new, oracle): nothing to contribute
       else if (nu == 1u) {

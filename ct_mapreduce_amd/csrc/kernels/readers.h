@@ -207,6 +207,8 @@ struct WinReaderS : WinReaderC<WCH> {
     const uint32_t i = rel >> 2;
     return __builtin_amdgcn_alignbyte(this->win[i + 1], this->win[i], rel & 3u);
   }
+  // der_walk.h (strict_extensions): the contents of this element are read octet by octet — not through the window
+  __device__ __forceinline__ void defer_exact() { miss |= 1u; }
   __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t tail) {
     const uint64_t ta = this->base + tail;
     const bool have = ta + 32u <= this->limit;

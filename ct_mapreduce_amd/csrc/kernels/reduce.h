@@ -631,7 +631,9 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
       uint4* rp = (uint4*)(records + i);
       if (!good) {  // x509.ParseCertificate fails: map_one's record of such a certificate
         const uint4 r0 = rp[0];
-        rp[0] = make_uint4(CTMR_ST_PARSE_ERROR | (((r0.x >> 8) & CTMR_FL_PRECERT) << 8), 0u, r0.z, 0u);
+        // (an entry the downloader had dropped already — entry_type CTMR_ENTRY_INVALID through ctmr_map_batch — stays that)
+        const uint32_t stn = (r0.x & 0xffu) == CTMR_ST_ENTRY_DECODE_ERROR ? (uint32_t)CTMR_ST_ENTRY_DECODE_ERROR : (uint32_t)CTMR_ST_PARSE_ERROR;
+        rp[0] = make_uint4(stn | (((r0.x >> 8) & CTMR_FL_PRECERT) << 8), 0u, r0.z, 0u);
         rp[1] = make_uint4(0u, 0u, 0u, 0u);
         if ((kp >> 38) & 1ull) {
           a.stage[(i & ~63ull) + ((kp >> 39) & 63ull)].meta = 0ull;  // the owner ignores it
@@ -642,7 +644,7 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
           // uninitialised tail — owner 0, order 0 — which cost entry 0 of rank 0 its WasUnknown.)
           atomicAdd(&a.stats->n_xl, ~0ull);
         }
-        a.ent[i] = ent_pack(CTMR_ST_PARSE_ERROR, ES_NONE, e >> 8);
+        a.ent[i] = ent_pack(stn, ES_NONE, e >> 8);
       } else if (ent_state(e) != ES_PENDING) {  // filtered, without issuer, left for its owner, host-side serial: as the map said
         a.ent[i] = e & ~ENT_KEY_PENDING;
       } else {

@@ -413,6 +413,12 @@ class Engine:
         by default."""
         self._ck(self._lib.ctmr_set_strict_extensions(self._h, int(bool(on))))
 
+    def set_profile(self, profile):
+        """ctmr_set_profile: "fast" (the defaults) or "reference" (strict_spki + strict_leaf + strict_strings +
+        strict_extensions: what the reference does, as far as it can be known here).  Before the issuers are registered."""
+        p = {"fast": N.PROFILE_FAST, "reference": N.PROFILE_REFERENCE}.get(profile, profile)
+        self._ck(self._lib.ctmr_set_profile(self._h, int(p)))
+
     def set_strict_leaf(self, on: bool):
         """Walk the leaf TBSCertificate of precertificate entries as ct.LogEntryFromLeaf does (include/ctmr.h); default off."""
         self._ck(self._lib.ctmr_set_strict_leaf(self._h, int(bool(on))))

@@ -24,7 +24,7 @@ using namespace ctmr::storage;
 namespace {
 struct Job {
   std::vector<std::thread> workers;
-  std::atomic<uint64_t> files{0}, bytes{0}, skipped{0};
+  std::atomic<uint64_t> files{0}, bytes{0}, skipped{0}, failed{0};
   std::string err;
   std::mutex mu;
   std::chrono::steady_clock::time_point t0;
@@ -79,9 +79,10 @@ int ctmr_host_writer_submit(ctmr_host_writer* w, const uint8_t* pem, const uint6
     const uint64_t lo = count * (uint64_t)t / (uint64_t)T, hi = count * (uint64_t)(t + 1) / (uint64_t)T;
     if (lo == hi) continue;
     j->workers.emplace_back([w, j, pem, pem_off, recs, lo, hi]() {
-      uint64_t files = 0, bytes = 0, skipped = 0;
+      uint64_t files = 0, bytes = 0, skipped = 0, failed = 0;
+      uint64_t k = lo;
       try {
-        for (uint64_t k = lo; k < hi; k++) {
+        for (; k < hi; k++) {
           const ctmr_record& r = recs[k];
           if (r.serial_len > 20 || r.issuer_idx >= w->issuers.size()) {
             skipped++;
@@ -94,15 +95,23 @@ int ctmr_host_writer_submit(ctmr_host_writer* w, const uint8_t* pem, const uint6
           files++;
           bytes += len;
         }
-      } catch (const std::exception& ex) {
+      } catch (const std::exception& ex) {  // the backend threw at certificate k: it and the rest of this worker's range were not stored
+        failed = hi - k;
         std::lock_guard<std::mutex> g(j->mu);
         j->err = ex.what();
       }
       j->files += files;
       j->bytes += bytes;
       j->skipped += skipped;
+      j->failed += failed;
     });
   }
+  // job ids are slots: a finished job's slot is free again (a double-buffered stream uses two for ever)
+  for (size_t id = 0; id < w->jobs.size(); id++)
+    if (!w->jobs[id]) {
+      w->jobs[id] = std::move(job);
+      return (int)id;
+    }
   w->jobs.push_back(std::move(job));
   return (int)w->jobs.size() - 1;
 }
@@ -122,7 +131,7 @@ int ctmr_host_writer_wait(ctmr_host_writer* w, int job, uint64_t out[3], double*
   }
   if (seconds) *seconds = j->seconds;
   const bool bad = !j->err.empty();
-  if (bad) w->err = j->err;
+  if (bad) w->err = j->err + " (" + std::to_string((unsigned long long)j->failed) + " certificates of this job were not stored)";
   w->jobs[job].reset();
   return bad ? -1 : 0;
 }

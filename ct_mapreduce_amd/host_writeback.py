@@ -50,6 +50,8 @@ class HostWriter:
 
     def submit(self, pem_ptr, pem_off_ptr, recs_ptr, count) -> int:
         """Host pointers (ints) that stay valid and untouched until wait(job)."""
+        if not self._h:
+            raise RuntimeError("host writer is closed")
         job = self._L.ctmr_host_writer_submit(self._h, pem_ptr, pem_off_ptr, recs_ptr, count)
         if job < 0:
             raise RuntimeError("ctmr_host_writer_submit failed")
@@ -57,6 +59,8 @@ class HostWriter:
 
     def wait(self, job):
         """→ (files handed to the backend, their PEM bytes, skipped long serials, seconds from submit to done)"""
+        if not self._h:
+            raise RuntimeError("host writer is closed")
         out = (C.c_uint64 * 3)()
         sec = C.c_double(0)
         if self._L.ctmr_host_writer_wait(self._h, job, out, C.byref(sec)):

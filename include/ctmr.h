@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTMR_ABI_VERSION 5
+#define CTMR_ABI_VERSION 6
 
 enum {
   CTMR_OK = 0,
@@ -500,15 +500,26 @@ int ctmr_wait_entries(ctmr_engine* e, ctmr_ticket ticket, ctmr_record* records, 
  * ascending log index of first appearance) — for hosts that must keep the issuer tables of several engines
  * identical (multi-GPU key exchange: DESIGN.md §8): gather the pending lists of all ranks, register the union in
  * one agreed order with ctmr_add_issuers on every rank, call again. */
-/* strict_extensions (round 4, opt-in, default off).  Go 1.13's crypto/x509 parseCertificate unmarshals the VALUE of some
- * extensions and fails the certificate when that fails; with on != 0 the walk does the same for the ones parsed by plain
- * encoding/asn1 struct rules — keyUsage (one BIT STRING), subjectKeyIdentifier (one OCTET STRING), extKeyUsage (SEQUENCE OF
- * OID), authorityKeyIdentifier (SEQUENCE with an optional [0]), certificatePolicies (SEQUENCE OF SEQUENCE { OID, … }),
- * authorityInfoAccess (SEQUENCE OF SEQUENCE { OID, any element }), each filling its OCTET STRING ("trailing data") — as a
- * FATAL parse error in every role (leaf, precertificate, Chain[0], the strict_leaf TBSCertificate).  subjectAltName,
- * nameConstraints and cRLDistributionPoints are not modelled.  These are the standard library's rules: which of them
- * certificate-transparency-go's fork files as non-fatal cannot be verified without its source — hence a switch.  Set it
- * before the issuers are registered (a Chain[0] is judged when it is registered). */
+/* strict_extensions (opt-in, default off; part of CTMR_PROFILE_REFERENCE).  Go 1.13's crypto/x509 parseCertificate parses
+ * the VALUE of the extensions it knows and fails the certificate when that fails; with on != 0 the walk does the same:
+ *   by plain encoding/asn1 struct rules, each filling its OCTET STRING ("trailing data") — keyUsage (one BIT STRING),
+ *     subjectKeyIdentifier (one OCTET STRING), extKeyUsage (SEQUENCE OF OID), authorityKeyIdentifier (SEQUENCE with an
+ *     optional [0]), certificatePolicies (SEQUENCE OF SEQUENCE { OID, … }), authorityInfoAccess (SEQUENCE OF SEQUENCE
+ *     { OID, any element }), cRLDistributionPoints (SEQUENCE OF distributionPoint: three optional fields in order, a
+ *     nameRelativeToCRLIssuer parsed like a Name) [the last one: ABI v6];
+ *   subjectAltName [v6] — one universal SEQUENCE of elements that fit, dispatched on the tag NUMBER: a URI (6) goes
+ *     through net/url's Parse and, when it has a host, x509's domainToReverseLabels;
+ *   nameConstraints [v6] — as golang.org/x/crypto/cryptobyte reads it: SEQUENCE { [0] permitted, [1] excluded }, not both
+ *     absent or empty; dNSName / rfc822Name / URI constraints IA5 and well-formed (parseRFC2821Mailbox, not an IP literal,
+ *     no empty label), iPAddress 8 or 32 octets with a contiguous mask.
+ * A violation is a FATAL parse error in every role (leaf, precertificate, Chain[0], the strict_leaf TBSCertificate).
+ * NON-FATAL findings, as CT-go files them (an X509 entry keeps its certificate; a precertificate and a Chain[0] issuer are
+ * dropped) [v6]: a subjectAltName iPAddress that is not 4 or 16 octets long; an embedded SCT list
+ * (1.3.6.1.4.1.11129.2.4.2) that does not decode; an INTEGER inside a nameRelativeToCRLIssuer that is not minimally
+ * encoded (with strict_strings: also its string values' character sets).
+ * These are the standard library's rules plus what is recalled of certificate-transparency-go v1.1.0's changes to them;
+ * neither can be verified without CT-go's source — hence a switch.  Set it before the issuers are
+ * registered (a Chain[0] is judged when it is registered). */
 int ctmr_set_strict_extensions(ctmr_engine* e, int on);
 int ctmr_set_issuer_autoregister(ctmr_engine* e, int on);
 int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need, uint64_t* count);
@@ -560,6 +571,20 @@ int ctmr_set_strict_spki(ctmr_engine* e, int on);
  * precertificate while its walk holds them (since round 4; a pre-pass over every certificate before); issuers are
  * judged when they are registered (set the switch before registering them). */
 int ctmr_set_strict_strings(ctmr_engine* e, int on);
+/* The accept/reject profile as ONE choice (ABI v6) — what x509.ParseCertificate / ct.LogEntryFromLeaf decide at
+ * cmd/ct-fetch/ct-fetch.go:202-209, :221-225, :452-459:
+ *   CTMR_PROFILE_FAST       the engine's defaults: strict_spki on; strict_leaf, strict_strings, strict_extensions off — every
+ *                           rule whose bytes the path reads anyway.  Looser than the reference on malformed extension
+ *                           bodies, Name character sets and the leaf TBSCertificate of precertificate entries; identical
+ *                           on everything a CA's encoder and a log that validated its submissions produce.
+ *   CTMR_PROFILE_REFERENCE  all four switches on: what the reference does, as far as it can be known without CT-go's
+ *                           source (DESIGN.md §3.1 says which rules are recalled from where).  Costs the map the bytes of
+ *                           the subjectAltName and a character-set pass over the Names (bench.py --profile reference
+ *                           prices it).
+ * Equivalent to the four ctmr_set_strict_* calls; like them, set it BEFORE the issuers are registered. */
+#define CTMR_PROFILE_FAST 0
+#define CTMR_PROFILE_REFERENCE 1
+int ctmr_set_profile(ctmr_engine* e, int profile);
 /* ctmr_pem_encode_device for an entry view: PEM of the certificates d_idx[0..n_idx) names, straight out of the blob. */
 int ctmr_pem_encode_view_device(ctmr_engine* e, const uint8_t* d_blob, const ctmr_entry_view* d_view,
                                 const uint64_t* d_idx, uint64_t n_idx, uint8_t* d_pem, uint64_t pem_cap,

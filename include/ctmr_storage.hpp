@@ -755,15 +755,14 @@ class HostCert {
         if (parts.empty() || d_.compare(parts[0][1], parts[0][2] - parts[0][1], "\x55\x1d\x1f") != 0) continue;
         size_t dps, dpe;
         tlv(parts.back()[1], parts.back()[2], &tag, &dps, &dpe);
-        for (auto& dp : children(dps, dpe))            // DistributionPoint
-          for (auto& f : children(dp[1], dp[2])) {
-            if (f[0] != 0xa0) continue;                // distributionPoint [0]
-            for (auto& fn : children(f[1], f[2])) {
-              if (fn[0] != 0xa0) continue;             // fullName [0]
-              for (auto& gn : children(fn[1], fn[2]))
-                if (gn[0] == 0x86) crlDistributionPoints.push_back(d_.substr(gn[1], gn[2] - gn[1]));
-            }
-          }
+        for (auto& dp : children(dps, dpe)) {          // DistributionPoint: Go's struct fields are positional —
+          auto f = children(dp[1], dp[2]);             // distributionPoint [0] is the FIRST element or absent,
+          if (f.empty() || f[0][0] != 0xa0) continue;
+          auto fn = children(f[0][1], f[0][2]);        // fullName [0] the first element inside it,
+          if (fn.empty() || fn[0][0] != 0xa0) continue;
+          for (auto& gn : children(fn[0][1], fn[0][2]))  // and a name is a URI when its tag NUMBER is 6 (x509.go: fullName.Tag == 6)
+            if ((gn[0] & 0x1f) == 6) crlDistributionPoints.push_back(d_.substr(gn[1], gn[2] - gn[1]));
+        }
       }
     }
   }

@@ -317,10 +317,19 @@ static int string_findings(const uint8_t* s, uint32_t n, uint32_t tag) {
   }
 }
 
+/* the elements of an RDNSequence, [r, r_end): SET OF SEQUENCE { type OID, value ANY } each (also what a
+ * distributionPointName's nameRelativeToCRLIssuer holds behind its IMPLICIT [1] tag, ext_crldp_site) */
+static int rdn_elements(const uint8_t* d, uint64_t r, uint64_t r_end, uint32_t* cn_off, uint32_t* cn_len,
+                        int* site_out, int site, int32_t* sfind, int32_t* nfind);
+
 static int rdn_sequence(const uint8_t* d, uint64_t p, uint64_t end, tlv* t, uint32_t* cn_off, uint32_t* cn_len,
                         int* site_out, int site, int32_t* sfind, int32_t* nfind) {
   if (!rd_tlv(d, p, end, t) || t->tag != 0x30) FAIL0(site);
-  uint64_t r = p + t->hl, r_end = r + t->len;
+  return rdn_elements(d, p + t->hl, p + t->hl + t->len, cn_off, cn_len, site_out, site, sfind, nfind);
+}
+
+static int rdn_elements(const uint8_t* d, uint64_t r, uint64_t r_end, uint32_t* cn_off, uint32_t* cn_len,
+                        int* site_out, int site, int32_t* sfind, int32_t* nfind) {
   while (r < r_end) {
     tlv set;
     if (!rd_tlv(d, r, r_end, &set) || set.tag != 0x31) FAIL0(site + 1);
@@ -638,6 +647,489 @@ static int ext_body_site(const uint8_t* d, const uint8_t* oid, uint32_t oid_len,
   return 0;
 }
 
+/* ------------------------------------------------------------------ strict_extensions, round 5: the three extensions whose
+ * VALUE Go parses with code of its own (not a plain struct unmarshal), and CT-go's embedded SCT list.  Like everything at
+ * the CT-go boundary: RECALLED from Go 1.13's crypto/x509, net/url, net and golang.org/x/crypto/cryptobyte (go.mod:24) and
+ * from CT-go v1.1.0's fork of crypto/x509 — not verifiable on this machine.
+ *
+ * subjectAltName 2.5.29.17 — parseSANExtension → forEachSAN:
+ *   asn1.Unmarshal(value, &seq RawValue): one element that fits; rest → "x509: trailing data after X.509 extension";
+ *   !seq.IsCompound || seq.Tag != 16 || seq.Class != 0 → "bad SAN sequence"; then every element of seq.Bytes is
+ *   unmarshalled as a RawValue (header parses, contents fit) and dispatched on v.Tag ALONE — the class is not looked at:
+ *     1 rfc822Name, 2 dNSName   kept as they are (this toolchain checks no character set on the parse side)
+ *     6 URI                     url.Parse must succeed and, when the URL has a host, domainToReverseLabels(host) → else fatal
+ *     7 iPAddress               length 4 or 16 — CT-go files any other length as a NON-FATAL finding (the stdlib fails)
+ *     anything else             ignored */
+
+/* net/url (go1.13) — only what can make url.Parse fail, and the unescaped host it hands to domainToReverseLabels */
+static int is_hex(uint8_t c) { return (c >= '0' && c <= '9') || ((c | 0x20) >= 'a' && (c | 0x20) <= 'f'); }
+static int unhex(uint8_t c) { return c <= '9' ? c - '0' : (c | 0x20) - 'a' + 10; }
+static int is_alnum(uint8_t c) { return (c >= '0' && c <= '9') || ((c | 0x20) >= 'a' && (c | 0x20) <= 'z'); }
+/* shouldEscape(c, encodeHost) == shouldEscape(c, encodeZone) */
+static int host_should_escape(uint8_t c) {
+  if (is_alnum(c)) return 0;
+  return !c || !strchr("!$&'()*+,;=:[]<>\"-_.~", c);
+}
+enum { URL_MODE_PATH, URL_MODE_HOST, URL_MODE_ZONE };
+/* unescape(s, mode): every '%' is followed by two hex digits; in a host "%XX" may only stand for a non-ASCII octet or be
+ * "%25"; in a zone it may also stand for a space or an octet a host may hold; an ASCII octet of a host / zone must be one
+ * shouldEscape lets through.  out (optional): the unescaped octets, *out_n their number. */
+static int url_unescape(const uint8_t* s, uint32_t n, int mode, uint8_t* out, uint32_t* out_n) {
+  uint32_t i = 0;
+  while (i < n) {
+    if (s[i] == '%') {
+      if (i + 2 >= n || !is_hex(s[i + 1]) || !is_hex(s[i + 2])) return 0; /* EscapeError — `i+2 >= len(s)` as in the source */
+      int is25 = s[i + 1] == '2' && s[i + 2] == '5';
+      uint8_t v = (uint8_t)(unhex(s[i + 1]) << 4 | unhex(s[i + 2]));
+      if (mode == URL_MODE_HOST && unhex(s[i + 1]) < 8 && !is25) return 0;
+      if (mode == URL_MODE_ZONE && !is25 && v != ' ' && host_should_escape(v)) return 0;
+      if (out) out[(*out_n)++] = v;
+      i += 3;
+    } else {
+      if (mode != URL_MODE_PATH && s[i] != '+' && s[i] < 0x80 && host_should_escape(s[i])) return 0; /* InvalidHostError */
+      if (out) out[(*out_n)++] = s[i];
+      i++;
+    }
+  }
+  return 1;
+}
+static int64_t idx_of(const uint8_t* s, uint32_t n, uint8_t c) {
+  for (uint32_t i = 0; i < n; i++) if (s[i] == c) return i;
+  return -1;
+}
+static int64_t last_idx_of(const uint8_t* s, uint32_t n, uint8_t c) {
+  for (uint32_t i = n; i > 0; i--) if (s[i - 1] == c) return i - 1;
+  return -1;
+}
+static int valid_optional_port(const uint8_t* s, uint32_t n) {
+  if (n == 0) return 1;
+  if (s[0] != ':') return 0;
+  for (uint32_t i = 1; i < n; i++) if (s[i] < '0' || s[i] > '9') return 0;
+  return 1;
+}
+/* x509.domainToReverseLabels(domain).ok: no empty label (so no leading or trailing dot, no "..") and every rune in 33..126
+ * (an octet >= 0x80 is, or decodes to, a rune above 126) */
+static int domain_labels_ok(const uint8_t* s, uint32_t n) {
+  if (n == 0) return 1; /* no labels at all: ok (the callers that need a host test len > 0 first) */
+  if (s[0] == '.' || s[n - 1] == '.') return 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (s[i] < 33 || s[i] > 126) return 0;
+    if (i + 1 < n && s[i] == '.' && s[i + 1] == '.') return 0;
+  }
+  return 1;
+}
+/* parseHost(host): *out / *out_n = the unescaped host (with its port) */
+static int url_parse_host(const uint8_t* h, uint32_t n, uint8_t* out, uint32_t* out_n) {
+  if (n && h[0] == '[') {
+    int64_t i = last_idx_of(h, n, ']');
+    if (i < 0) return 0;                                         /* missing ']' in host */
+    if (!valid_optional_port(h + i + 1, n - (uint32_t)i - 1)) return 0;
+    int64_t zone = -1;
+    for (int64_t z = 0; z + 3 <= i; z++) if (h[z] == '%' && h[z + 1] == '2' && h[z + 2] == '5') { zone = z; break; }
+    if (zone >= 0)
+      return url_unescape(h, (uint32_t)zone, URL_MODE_HOST, out, out_n) &&
+             url_unescape(h + zone, (uint32_t)(i - zone), URL_MODE_ZONE, out, out_n) &&
+             url_unescape(h + i, n - (uint32_t)i, URL_MODE_HOST, out, out_n);
+  } else {
+    int64_t i = last_idx_of(h, n, ':');
+    if (i >= 0 && !valid_optional_port(h + i, n - (uint32_t)i)) return 0;
+  }
+  return url_unescape(h, n, URL_MODE_HOST, out, out_n);
+}
+static int valid_userinfo(const uint8_t* s, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++)
+    if (!is_alnum(s[i]) && (!s[i] || !strchr("-._:~!$&'()*+,;=%@", s[i]))) return 0;
+  return 1;
+}
+/* url.Parse(s) succeeds && (uri.Host == "" || domainToReverseLabels(uri.Host) ok) */
+static int go_san_uri_ok(const uint8_t* s, uint32_t n) {
+  /* Parse: u, frag = split(rawurl, "#", true) */
+  int64_t hash = idx_of(s, n, '#');
+  uint32_t un = hash < 0 ? n : (uint32_t)hash;
+  const uint8_t* frag = hash < 0 ? s + n : s + hash + 1;
+  uint32_t fragn = hash < 0 ? 0 : n - (uint32_t)hash - 1;
+  uint8_t* host = (uint8_t*)malloc(n + 1);
+  uint32_t hostn = 0;
+  int ok = 0;
+  /* parse(u, viaRequest = false) */
+  for (uint32_t i = 0; i < un; i++) if (s[i] < 0x20 || s[i] == 0x7f) goto done; /* invalid control character in URL */
+  if (un == 1 && s[0] == '*') { ok = 1; goto frag_check; }
+  {
+    /* getscheme */
+    uint32_t rest0 = 0;
+    int has_scheme = 0;
+    for (uint32_t i = 0; i < un; i++) {
+      uint8_t c = s[i];
+      if (((c | 0x20) >= 'a' && (c | 0x20) <= 'z')) continue;
+      if ((c >= '0' && c <= '9') || c == '+' || c == '-' || c == '.') {
+        if (i == 0) break;
+        continue;
+      }
+      if (c == ':') {
+        if (i == 0) goto done; /* missing protocol scheme */
+        has_scheme = 1;
+        rest0 = i + 1;
+      }
+      break;
+    }
+    const uint8_t* rest = s + rest0;
+    uint32_t rn = un - rest0;
+    /* the query goes: a lone trailing '?' (ForceQuery) or everything from the first '?' */
+    int64_t q = idx_of(rest, rn, '?');
+    if (q >= 0) rn = (uint32_t)q;
+    if (!(rn && rest[0] == '/')) {
+      if (has_scheme) { ok = 1; goto frag_check; } /* opaque */
+      int64_t colon = idx_of(rest, rn, ':'), slash = idx_of(rest, rn, '/');
+      if (colon >= 0 && (slash < 0 || colon < slash)) goto done; /* first path segment in URL cannot contain colon */
+    }
+    if ((has_scheme || !(rn >= 3 && rest[0] == '/' && rest[1] == '/' && rest[2] == '/')) && rn >= 2 && rest[0] == '/' && rest[1] == '/') {
+      const uint8_t* auth = rest + 2;
+      int64_t sl = idx_of(auth, rn - 2, '/');
+      uint32_t an = sl < 0 ? rn - 2 : (uint32_t)sl;
+      /* parseAuthority */
+      int64_t at = last_idx_of(auth, an, '@');
+      if (!url_parse_host(auth + (at + 1), an - (uint32_t)(at + 1), host, &hostn)) goto done;
+      if (at >= 0) {
+        if (!valid_userinfo(auth, (uint32_t)at)) goto done;
+        if (!url_unescape(auth, (uint32_t)at, URL_MODE_PATH, NULL, NULL)) goto done; /* user and password: escapes only */
+      }
+      rest = auth + an;
+      rn = rn - 2 - an;
+    }
+    if (!url_unescape(rest, rn, URL_MODE_PATH, NULL, NULL)) goto done; /* setPath */
+    ok = 1;
+  }
+frag_check:
+  if (ok && fragn && !url_unescape(frag, fragn, URL_MODE_PATH, NULL, NULL)) ok = 0;
+  if (ok && hostn && !domain_labels_ok(host, hostn)) ok = 0; /* "x509: cannot parse URI …: invalid domain" */
+done:
+  free(host);
+  return ok;
+}
+
+static int ext_san_site(const uint8_t* d, uint64_t o, uint64_t o_end, int32_t* xf) {
+  tlv t;
+  if (!rd_tlv(d, o, o_end, &t)) return 120;
+  if (o + t.hl + (uint64_t)t.len != o_end) return 121;           /* trailing data */
+  if (t.tag != 0x30) return 122;                                  /* bad SAN sequence */
+  uint64_t p = o + t.hl;
+  while (p < o_end) {
+    tlv g;
+    if (!rd_tlv(d, p, o_end, &g)) return 123;
+    uint64_t c = p + g.hl;
+    int tagnum = (g.tag & 0x1f) == 0x1f ? -1 : (g.tag & 0x1f);    /* v.Tag; a high-tag-number form is >= 31 */
+    if (tagnum == 6 && !go_san_uri_ok(d + c, g.len)) return 124;
+    if (tagnum == 7 && g.len != 4 && g.len != 16) *xf |= ORC_XF_SAN_IP;
+    p = c + g.len;
+  }
+  return 0;
+}
+
+/* cRLDistributionPoints 2.5.29.31 — asn1.Unmarshal(value, &[]distributionPoint) + "trailing data":
+ *   distributionPoint     struct { DistributionPoint distributionPointName `optional,tag:0`; Reason asn1.BitString
+ *                                  `optional,tag:1`; CRLIssuer asn1.RawValue `optional,tag:2` }
+ *   distributionPointName struct { FullName []asn1.RawValue `optional,tag:0`; RelativeName pkix.RDNSequence `optional,tag:1` }
+ * encoding/asn1's struct rules: the fields are taken IN ORDER; at each field the header at the current offset must
+ * parse (unless the contents are used up); a field whose class/number (and, except for a RawValue, primitive/constructed
+ * bit) does not match is skipped without consuming anything; a field that matches must fit; what is left behind the last
+ * field is ignored.  uris (optional): collects the FullName elements with Tag == 6 in order (parseCertificate:
+ * CRLDistributionPoints — again the tag number alone). */
+static int dp_field_hdr(const uint8_t* d, uint64_t off, uint64_t end, tlv* t) { return off == end ? -1 : rd_hdr(d, off, end, t); }
+
+static int ext_crldp_site(const uint8_t* d, uint64_t o, uint64_t o_end, orc_meta* uris, int deep, int32_t* sfind, int32_t* nfind) {
+  tlv t;
+  if (!rd_tlv(d, o, o_end, &t) || t.tag != 0x30) return 130;
+  if (o + t.hl + (uint64_t)t.len != o_end) return 131;
+  uint64_t p = o + t.hl;
+  while (p < o_end) {                                             /* parseSequenceOf: SEQUENCE elements that fit */
+    tlv dp;
+    if (!rd_tlv(d, p, o_end, &dp) || dp.tag != 0x30) return 132;
+    uint64_t off = p + dp.hl, end = off + dp.len;
+    tlv f;
+    int h = dp_field_hdr(d, off, end, &f);
+    if (h == 0) return 133;
+    if (h > 0 && f.tag == 0xa0) {                                 /* DistributionPoint */
+      if (off + f.hl + (uint64_t)f.len > end) return 134;
+      uint64_t n = off + f.hl, n_end = n + f.len;
+      tlv g;
+      int hn = dp_field_hdr(d, n, n_end, &g);
+      if (hn == 0) return 135;
+      if (hn > 0 && g.tag == 0xa0) {                              /* FullName []asn1.RawValue */
+        if (n + g.hl + (uint64_t)g.len > n_end) return 136;
+        uint64_t q = n + g.hl, q_end = q + g.len;
+        while (q < q_end) {
+          tlv nm;
+          if (!rd_tlv(d, q, q_end, &nm)) return 137;
+          if (uris && (nm.tag & 0x1f) == 6) {
+            if (uris->n_crl < ORC_MAX_CRL) {
+              uris->crl_off[uris->n_crl] = (uint32_t)(q + nm.hl);
+              uris->crl_len[uris->n_crl] = nm.len;
+            }
+            uris->n_crl++;
+          }
+          q += nm.hl + nm.len;
+        }
+        n = q_end;
+        hn = dp_field_hdr(d, n, n_end, &g);
+        if (hn == 0) return 138;
+      }
+      if (hn > 0 && g.tag == 0xa1) {                              /* RelativeName pkix.RDNSequence */
+        if (n + g.hl + (uint64_t)g.len > n_end) return 139;
+        int site = 0; /* deep = 0 (orc_cert_meta: where the URIs lie): the name's own contents are not looked at */
+        if (deep && !rdn_elements(d, n + g.hl, n + g.hl + g.len, NULL, NULL, &site, 140, sfind, nfind)) return site;
+      }
+      off += f.hl + f.len;
+      h = dp_field_hdr(d, off, end, &f);
+      if (h == 0) return 146;
+    }
+    if (h > 0 && f.tag == 0x81) {                                 /* Reason asn1.BitString */
+      if (off + f.hl + (uint64_t)f.len > end || !bit_string_ok(d, off + f.hl, f.len)) return 147;
+      off += f.hl + f.len;
+      h = dp_field_hdr(d, off, end, &f);
+      if (h == 0) return 148;
+    }
+    if (h > 0 && (f.tag == 0x82 || f.tag == 0xa2) && off + f.hl + (uint64_t)f.len > end) return 149; /* CRLIssuer asn1.RawValue */
+    p += dp.hl + dp.len;
+  }
+  return 0;
+}
+
+/* nameConstraints 2.5.29.30 — parseNameConstraintsExtension reads it with golang.org/x/crypto/cryptobyte, whose ReadASN1
+ * differs from encoding/asn1 in two ways that show: a tag is matched as the whole identifier octet, and the
+ * high-tag-number form is refused outright.  PeekASN1Tag / ReadOptionalASN1 look at the first octet only.
+ *   outer.ReadASN1(&toplevel, SEQUENCE) && outer.Empty()
+ *   toplevel.ReadOptionalASN1(&permitted, [0] constructed) && toplevel.ReadOptionalASN1(&excluded, [1] constructed)
+ *   && toplevel.Empty()                                      else "x509: invalid NameConstraints extension"
+ *   neither present, or both empty                            →   "x509: empty name constraints extension"
+ *   every subtree: ReadASN1(&seq, SEQUENCE) && seq.ReadAnyASN1(&value, &tag); minimum / maximum are not read
+ *     [2] dNSName       IA5; without one leading '.', domainToReverseLabels
+ *     [7] iPAddress     8 or 32 octets, the second half a contiguous mask
+ *     [1] rfc822Name    IA5; with '@': parseRFC2821Mailbox; else without one leading '.', domainToReverseLabels
+ *     [6] URI           IA5; not net.ParseIP; without one leading '.', domainToReverseLabels
+ *     other tags        ignored */
+static int cb_read(const uint8_t* d, uint64_t p, uint64_t end, tlv* t) {  /* cryptobyte readASN1 */
+  if (end - p < 2) return 0;
+  if ((d[p] & 0x1f) == 0x1f) return 0;
+  return rd_tlv(d, p, end, t);
+}
+static int ip_mask_ok(const uint8_t* m, uint32_t n) {
+  int seen_zero = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (seen_zero) {
+      if (m[i]) return 0;
+      continue;
+    }
+    if (m[i] == 0xff) continue;
+    /* 0x00 0x80 0xc0 0xe0 0xf0 0xf8 0xfc 0xfe: ones then zeros */
+    uint8_t inv = (uint8_t)~m[i];
+    if ((inv & (inv + 1)) != 0) return 0;
+    seen_zero = 1;
+  }
+  return 1;
+}
+/* net.ParseIP(s) != nil (go1.13: leading zeros in a dotted quad are fine, no zone) */
+static int go_dtoi(const uint8_t* s, uint32_t n, uint32_t* v, uint32_t* used) {
+  uint32_t x = 0, i = 0;
+  for (; i < n && s[i] >= '0' && s[i] <= '9'; i++) {
+    x = x * 10 + (s[i] - '0');
+    if (x >= 0xFFFFFF) return 0;
+  }
+  if (i == 0) return 0;
+  *v = x; *used = i;
+  return 1;
+}
+static int go_parse_ipv4(const uint8_t* s, uint32_t n) {
+  for (int i = 0; i < 4; i++) {
+    if (n == 0) return 0;
+    if (i > 0) {
+      if (s[0] != '.') return 0;
+      s++; n--;
+    }
+    uint32_t v, c;
+    if (!go_dtoi(s, n, &v, &c) || v > 0xFF) return 0;
+    s += c; n -= c;
+  }
+  return n == 0;
+}
+static int go_xtoi(const uint8_t* s, uint32_t n, uint32_t* v, uint32_t* used) {
+  uint32_t x = 0, i = 0;
+  for (; i < n; i++) {
+    if (!is_hex(s[i])) break;
+    x = x * 16 + (uint32_t)unhex(s[i]);
+    if (x >= 0xFFFFFF) return 0;
+  }
+  if (i == 0) return 0;
+  *v = x; *used = i;
+  return 1;
+}
+static int go_parse_ipv6(const uint8_t* s, uint32_t n) {
+  int ellipsis = -1, i = 0;
+  if (n >= 2 && s[0] == ':' && s[1] == ':') {
+    ellipsis = 0;
+    s += 2; n -= 2;
+    if (n == 0) return 1;
+  }
+  while (i < 16) {
+    uint32_t v, c;
+    if (!go_xtoi(s, n, &v, &c) || v > 0xFFFF) return 0;
+    if (c < n && s[c] == '.') {
+      if (ellipsis < 0 && i != 12) return 0;
+      if (i + 4 > 16) return 0;
+      if (!go_parse_ipv4(s, n)) return 0;
+      n = 0;
+      i += 4;
+      break;
+    }
+    i += 2;
+    s += c; n -= c;
+    if (n == 0) break;
+    if (s[0] != ':' || n == 1) return 0;
+    s++; n--;
+    if (s[0] == ':') {
+      if (ellipsis >= 0) return 0;
+      ellipsis = i;
+      s++; n--;
+      if (n == 0) break;
+    }
+  }
+  if (n != 0) return 0;
+  if (i < 16) return ellipsis >= 0;
+  return ellipsis < 0;
+}
+static int go_parse_ip(const uint8_t* s, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    if (s[i] == '.') return go_parse_ipv4(s, n);
+    if (s[i] == ':') return go_parse_ipv6(s, n);
+  }
+  return 0;
+}
+/* x509.parseRFC2821Mailbox(in).ok */
+static int go_mailbox_ok(const uint8_t* in, uint32_t n) {
+  if (n == 0) return 0;
+  uint32_t i = 0;
+  if (in[0] == '"') {
+    i = 1;
+    for (;;) {
+      if (i >= n) return 0;
+      uint8_t c = in[i++];
+      if (c == '"') break;
+      if (c == '\\') {
+        if (i >= n) return 0;
+        uint8_t e = in[i];
+        if (e == 11 || e == 12 || (e >= 1 && e <= 9) || (e >= 14 && e <= 127)) i++;
+        else return 0;
+      } else if (c == 11 || c == 12 || c == 32 || c == 33 || c == 127 || (c >= 1 && c <= 8) || (c >= 14 && c <= 31) ||
+                 (c >= 35 && c <= 91) || (c >= 93 && c <= 126)) {
+      } else {
+        return 0;
+      }
+    }
+  } else {
+    uint32_t nlocal = 0;
+    uint8_t first = 0, last = 0;
+    int two_dots = 0;
+    while (i < n) {
+      uint8_t c = in[i];
+      if (c == '\\') {
+        i++;
+        if (i >= n) return 0;
+      } else if (!(is_alnum(c) || (c && strchr("!#$%&'*+-/=?^_`{|}~.", c)))) {
+        break;
+      }
+      uint8_t b = in[i++];                     /* the octet that joins the local part: the escaped one after a backslash */
+      if (nlocal == 0) first = b;
+      if (nlocal && last == '.' && b == '.') two_dots = 1;
+      last = b;
+      nlocal++;
+    }
+    if (nlocal == 0) return 0;
+    if (first == '.' || last == '.' || two_dots) return 0;
+  }
+  if (i >= n || in[i] != '@') return 0;
+  i++;
+  return domain_labels_ok(in + i, n - i);      /* (an empty domain has no labels: ok, as in the source) */
+}
+static int ia5_ok(const uint8_t* s, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) if (s[i] >= 0x80) return 0;
+  return 1;
+}
+static int nc_subtrees_site(const uint8_t* d, uint64_t p, uint64_t end) {
+  while (p < end) {
+    tlv seq, v;
+    if (!cb_read(d, p, end, &seq) || seq.tag != 0x30) return 155;
+    uint64_t c = p + seq.hl, c_end = c + seq.len;
+    if (!cb_read(d, c, c_end, &v)) return 156;
+    const uint8_t* s = d + c + v.hl;
+    uint32_t n = v.len;
+    if (v.tag == 0x82) {
+      if (!ia5_ok(s, n)) return 157;
+      if (n && s[0] == '.') { s++; n--; }
+      if (!domain_labels_ok(s, n)) return 158;
+    } else if (v.tag == 0x87) {
+      if (n != 8 && n != 32) return 159;
+      if (!ip_mask_ok(s + n / 2, n / 2)) return 160;
+    } else if (v.tag == 0x81) {
+      if (!ia5_ok(s, n)) return 161;
+      if (idx_of(s, n, '@') >= 0) {
+        if (!go_mailbox_ok(s, n)) return 162;
+      } else {
+        if (n && s[0] == '.') { s++; n--; }
+        if (!domain_labels_ok(s, n)) return 163;
+      }
+    } else if (v.tag == 0x86) {
+      if (!ia5_ok(s, n)) return 164;
+      if (go_parse_ip(s, n)) return 165;
+      if (n && s[0] == '.') { s++; n--; }
+      if (!domain_labels_ok(s, n)) return 166;
+    }
+    p = c_end;
+  }
+  return 0;
+}
+static int ext_nc_site(const uint8_t* d, uint64_t o, uint64_t o_end) {
+  tlv top, f;
+  if (!cb_read(d, o, o_end, &top) || top.tag != 0x30) return 150;
+  if (o + top.hl + (uint64_t)top.len != o_end) return 150;
+  uint64_t p = o + top.hl, end = o_end;
+  int have_p = 0, have_e = 0;
+  uint64_t ps = 0, pe = 0, es = 0, ee = 0;
+  if (p < end && d[p] == 0xa0) {
+    if (!cb_read(d, p, end, &f)) return 151;
+    have_p = 1; ps = p + f.hl; pe = ps + f.len; p = pe;
+  }
+  if (p < end && d[p] == 0xa1) {
+    if (!cb_read(d, p, end, &f)) return 152;
+    have_e = 1; es = p + f.hl; ee = es + f.len; p = ee;
+  }
+  if (p != end) return 153;
+  if ((!have_p && !have_e) || (pe == ps && ee == es)) return 154;   /* empty name constraints extension */
+  int r = have_p ? nc_subtrees_site(d, ps, pe) : 0;
+  if (!r && have_e) r = nc_subtrees_site(d, es, ee);
+  return r;
+}
+
+/* CT-go only: the embedded SCT list, 1.3.6.1.4.1.11129.2.4.2 — asn1.Unmarshal(value, &RawSCT []byte), no rest, then
+ * tls.Unmarshal(RawSCT, &SignedCertificateTimestampList{ SCTList []SerializedSCT `tls:"minlen:1,maxlen:65535"` }) with
+ * SerializedSCT{ Val []byte `tls:"minlen:1,maxlen:65535"` }, no rest.  Every failure is an nfe.AddError: non-fatal. */
+static int ext_sct_ok(const uint8_t* d, uint64_t o, uint64_t o_end) {
+  tlv t;
+  if (!rd_tlv(d, o, o_end, &t) || t.tag != 0x04) return 0;
+  if (o + t.hl + (uint64_t)t.len != o_end) return 0;
+  uint64_t p = o + t.hl;
+  if (o_end - p < 2) return 0;
+  uint32_t ll = (uint32_t)d[p] << 8 | d[p + 1];
+  p += 2;
+  if (ll < 1 || p + ll != o_end) return 0;
+  while (p < o_end) {
+    if (o_end - p < 2) return 0;
+    uint32_t sl = (uint32_t)d[p] << 8 | d[p + 1];
+    p += 2;
+    if (sl < 1 || p + sl > o_end) return 0;
+    p += sl;
+  }
+  return 1;
+}
+
 /* tbs_only: the buffer is a bare TBSCertificate — CT-go x509.ParseTBSCertificate, which ct.LogEntryFromLeaf applies to the
  * TBSCertificate of a precertificate entry's MerkleTreeLeaf (cmd/ct-fetch/ct-fetch.go:452): asn1.Unmarshal into
  * tbsCertificate, "trailing data" when anything follows it, then the same parseCertificate as for a whole certificate
@@ -776,6 +1268,19 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
         if (x + val.hl + (uint64_t)val.len > x_end) FAIL(34);
         if (!out->ext_fatal) /* the first one in certificate order; applied by the engine (strict_extensions) */
           out->ext_fatal = (uint32_t)ext_body_site(d, d + oid_c, oid.len, x + val.hl, x + val.hl + val.len);
+        if (!out->ext_fatal) { /* round 5: subjectAltName, nameConstraints, cRLDistributionPoints; CT-go's SCT list */
+          static const uint8_t SCT[10] = {0x2b, 0x06, 0x01, 0x04, 0x01, 0xd6, 0x79, 0x02, 0x04, 0x02};
+          const uint64_t o = x + val.hl, o_end = o + val.len;
+          const int arc = (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d) ? d[oid_c + 2] : -1;
+          if (arc == 17) out->ext_fatal = (uint32_t)ext_san_site(d, o, o_end, &out->ext_findings);
+          else if (arc == 30) out->ext_fatal = (uint32_t)ext_nc_site(d, o, o_end);
+          else if (arc == 31) {
+            int32_t lax = 0;
+            out->ext_fatal = (uint32_t)ext_crldp_site(d, o, o_end, NULL, 1, &out->ext_string_findings, &lax);
+            if (lax) out->ext_findings |= ORC_XF_LAX;
+          }
+          else if (oid.len == 10 && memcmp(d + oid_c, SCT, 10) == 0 && !ext_sct_ok(d, o, o_end)) out->ext_findings |= ORC_XF_SCT;
+        }
         if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x13) {
           /* basicConstraints struct { IsCA bool `optional`; MaxPathLen int `optional,default:-1` } must be the
            * whole OCTET STRING ("x509: trailing data after X.509 BasicConstraints"); inside the SEQUENCE an
@@ -1345,7 +1850,8 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   /* X509 entry: the certificate LogEntryFromLeaf parsed, kept unless the error was fatal (:452-459);
    * precertificate: parsed here, dropped on ANY error, x509.NonFatalErrors included (:202-209) */
   if (!c.ok || (e->strict_spki && c.spki_fatal) || (e->strict_ext && c.ext_fatal)) return ORC_ST_PARSE_ERROR;
-  if (entry_type == 1 && (c.nonfatal || (e->strict_strings && c.string_findings) || (e->strict_spki && c.spki_findings)))
+  if (entry_type == 1 && (c.nonfatal || (e->strict_strings && c.string_findings) || (e->strict_spki && c.spki_findings) ||
+                          (e->strict_ext && (c.ext_findings || (e->strict_strings && c.ext_string_findings)))))
     return ORC_ST_PARSE_ERROR; /* :206-209 */
   if (exp_hour) *exp_hour = orc_exp_hour(c.not_after);
   if (serial) *serial = leaf + c.serial_off;
@@ -1356,7 +1862,7 @@ int orc_engine_entry(orc_engine* e, const uint8_t* leaf, size_t leaf_len, int en
   orc_cert ic;
   orc_parse_cert(issuer_der, issuer_len, &ic); /* :221 */
   if (!ic.ok || ic.nonfatal || (e->strict_strings && ic.string_findings) || (e->strict_spki && (ic.spki_fatal || ic.spki_findings)) ||
-      (e->strict_ext && ic.ext_fatal))
+      (e->strict_ext && (ic.ext_fatal || ic.ext_findings || (e->strict_strings && ic.ext_string_findings))))
     return ORC_ST_ISSUER_PARSE_ERROR; /* any err :222-225 */
   /* Store: filesystemdatabase.go:158-211 */
   int32_t eh = orc_exp_hour(c.not_after);           /* :160 */
@@ -1538,46 +2044,11 @@ void orc_engine_raw_batch(orc_engine* e, const uint8_t* blob, const uint64_t* bo
 
 /* ------------------------------------------------------------------------------------------------
  * IssuerMetadata.Accumulate inputs (storage/issuermetadata.go:92-138): RawIssuer and CRLDistributionPoints. */
+/* where the URIs of a cRLDistributionPoints value lie: ext_crldp_site with deep = 0 — Go's positional struct rules, the
+ * FullName elements with tag NUMBER 6 (round 5; rounds 1-4 took every [0] { [0] { [6] } } in any order).  0 = malformed. */
 static int collect_dp_uris(const uint8_t* d, uint64_t s, uint64_t e, orc_meta* m) {
-  /* CRLDistributionPoints ::= SEQUENCE OF DistributionPoint, filling the OCTET STRING */
-  tlv seq;
-  if (!rd_tlv(d, s, e, &seq) || seq.tag != 0x30 || (uint64_t)seq.hl + seq.len != e - s) return 0;
-  uint64_t p = s + seq.hl, p_end = e;
-  while (p < p_end) {
-    tlv dp;
-    if (!rd_tlv(d, p, p_end, &dp) || dp.tag != 0x30) return 0;
-    uint64_t f = p + dp.hl, f_end = p + dp.hl + dp.len;
-    while (f < f_end) {          /* distributionPoint [0], reasons [1], cRLIssuer [2] */
-      tlv fld;
-      if (!rd_tlv(d, f, f_end, &fld)) return 0;
-      if (fld.tag == 0xa0) {     /* DistributionPointName: fullName [0] | nameRelativeToCRLIssuer [1] */
-        uint64_t n = f + fld.hl, n_end = f + fld.hl + fld.len;
-        while (n < n_end) {
-          tlv nm;
-          if (!rd_tlv(d, n, n_end, &nm)) return 0;
-          if (nm.tag == 0xa0) {  /* GeneralNames */
-            uint64_t g = n + nm.hl, g_end = n + nm.hl + nm.len;
-            while (g < g_end) {
-              tlv gn;
-              if (!rd_tlv(d, g, g_end, &gn)) return 0;
-              if (gn.tag == 0x86) {  /* uniformResourceIdentifier [6] IA5String */
-                if (m->n_crl < ORC_MAX_CRL) {
-                  m->crl_off[m->n_crl] = (uint32_t)(g + gn.hl);
-                  m->crl_len[m->n_crl] = gn.len;
-                }
-                m->n_crl++;
-              }
-              g += gn.hl + gn.len;
-            }
-          }
-          n += nm.hl + nm.len;
-        }
-      }
-      f += fld.hl + fld.len;
-    }
-    p += dp.hl + dp.len;
-  }
-  return 1;
+  int32_t a = 0, b = 0;
+  return ext_crldp_site(d, s, e, m, 0, &a, &b) == 0;
 }
 
 int orc_cert_meta(const uint8_t* d, size_t L, orc_meta* m) {

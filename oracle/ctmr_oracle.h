@@ -71,7 +71,15 @@ typedef struct {
   int32_t spki_findings; /* ORC_PK_*: what parsePublicKey files as non-fatal (same switch) */
   uint32_t ext_fatal;    /* the body of an extension Go unmarshals does not parse (ext_body_site; Go stdlib rules): 0 = none,
                             else the check that failed.  Only an engine with strict_extensions set acts on it (fatal) */
+  int32_t ext_findings;  /* ORC_XF_*: what CT-go files as NON-fatal inside an extension body (same switch; dropped for a
+                            precertificate or a Chain[0] issuer, kept for an X509 entry) */
+  int32_t ext_string_findings; /* ORC_SF_* inside a distribution point's nameRelativeToCRLIssuer: strict_extensions AND
+                                  strict_strings */
 } orc_cert;
+
+#define ORC_XF_SAN_IP 1   /* subjectAltName iPAddress of a length other than 4 or 16 */
+#define ORC_XF_SCT 2      /* the embedded SCT list (1.3.6.1.4.1.11129.2.4.2) does not decode */
+#define ORC_XF_LAX 4      /* an INTEGER inside nameRelativeToCRLIssuer that only the lax re-parse accepts */
 
 #define ORC_SF_PRINTABLE 1
 #define ORC_SF_NUMERIC 2

@@ -37,7 +37,7 @@ class Cert(C.Structure):
                 ("tbs_off", C.c_uint32), ("tbs_len", C.c_uint32), ("issuer_off", C.c_uint32), ("issuer_len", C.c_uint32),
                 ("exts_off", C.c_uint32), ("exts_end", C.c_uint32), ("nonfatal", C.c_int32),
                 ("string_findings", C.c_int32), ("spki_fatal", C.c_int32), ("spki_findings", C.c_int32),
-                ("ext_fatal", C.c_uint32)]
+                ("ext_fatal", C.c_uint32), ("ext_findings", C.c_int32), ("ext_string_findings", C.c_int32)]
 
 
 NF_NEGATIVE_SERIAL, NF_LAX_INTEGER = 1, 2

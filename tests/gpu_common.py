@@ -16,7 +16,7 @@ def run_oracle(batch, issuers, filt=b"", log_expired=False, now=0, engine=None):
     return o, st, unk, eh
 
 
-def expected_records(batch, st, unk, eh, strict_strings=False, strict_spki=True):
+def expected_records(batch, st, unk, eh, strict_strings=False, strict_spki=True, strict_ext=False):
     """What the 32-byte records must contain, derived from the oracle."""
     n = batch.n
     serial_len = np.zeros(n, np.uint16)
@@ -28,8 +28,9 @@ def expected_records(batch, st, unk, eh, strict_strings=False, strict_spki=True)
         c = orc.parse_cert(der, strict_spki)
         if batch.entry_type[i] == 1:
             flags[i] |= 1
-        nonfatal = c.nonfatal or (strict_strings and c.string_findings)
-        if not c.ok or (batch.entry_type[i] == 1 and nonfatal):     # a dropped certificate reports no fields
+        nonfatal = c.nonfatal or (strict_strings and c.string_findings) or \
+            (strict_ext and (c.ext_findings or (strict_strings and c.ext_string_findings)))
+        if not c.ok or (strict_ext and c.ext_fatal) or (batch.entry_type[i] == 1 and nonfatal):     # a dropped certificate reports no fields
             continue
         exp_hour[i] = eh[i]
         serial_len[i] = min(c.serial_len, 0xffff)
@@ -42,8 +43,8 @@ def expected_records(batch, st, unk, eh, strict_strings=False, strict_spki=True)
     return flags, serial_len, exp_hour, serial
 
 
-def assert_records_equal(res, batch, st, unk, eh, strict_strings=False, strict_spki=True):
-    flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh, strict_strings, strict_spki)
+def assert_records_equal(res, batch, st, unk, eh, strict_strings=False, strict_spki=True, strict_ext=False):
+    flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh, strict_strings, strict_spki, strict_ext)
     r = res.records
     assert (r["status"] == st).all(), np.nonzero(r["status"] != st)[0][:10]
     assert (r["flags"] == flags).all(), np.nonzero(r["flags"] != flags)[0][:10]

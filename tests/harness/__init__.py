@@ -87,6 +87,23 @@ def product_set_ext(on: bool):
     _walk.harness_set_ext(int(bool(on)))
 
 
+def product_set_strings(on: bool):
+    """The host build's strict_strings switch (default off): findings arrive as WALK_NF_STRING (4) in .nonfatal."""
+    product_walk(b"\x30\x00")
+    _walk.harness_set_strings(int(bool(on)))
+
+
+def product_crl_uris(der: bytes, cv: int, ev: int):
+    """der_walk.h crl_dps<COLLECT> over the cRLDistributionPoints value der[cv:ev]: None = malformed, else the URIs."""
+    product_walk(b"\x30\x00")
+    out = (C.c_uint32 * 16)()
+    _walk.harness_crl_uris.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
+    n = _walk.harness_crl_uris(der, len(der), cv, ev, out, 8)
+    if n < 0:
+        return None
+    return [bytes(der[out[2 * k]:out[2 * k] + out[2 * k + 1]]) for k in range(min(n, 8))]
+
+
 def product_ec_point_bits(buf: bytes, xbit: int, curve: int) -> bool:
     """k_ec_resolve's loader + curve equation (host build): X starts at BIT xbit of buf; curve 1..5 = P-256, P-384, P-521,
     P-224, secp192r1."""

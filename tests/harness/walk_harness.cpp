@@ -38,8 +38,26 @@ extern "C" void harness_set_spki(int on) { g_spki = on; }
 static int g_ext = 0;
 extern "C" void harness_set_ext(int on) { g_ext = on; }
 
+// strings: 1 = strict_strings inside the walk (findings arrive as WALK_NF_STRING in HarnessOut.nonfatal)
+static int g_strings = 0;
+extern "C" void harness_set_strings(int on) { g_strings = on; }
+
 extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, const char* filter,
                                uint32_t flen, int use_filter, HarnessOut* out);
+
+// Where the URIs of a cRLDistributionPoints value lie (der_walk.h crl_dps<COLLECT>: what kernels/meta*.h use):
+// returns -1 = malformed, else the number of URIs; the first `cap` (offset, length) pairs go to out.
+extern "C" int harness_crl_uris(const uint8_t* der, uint32_t len, uint32_t cv, uint32_t ev, uint32_t* out, uint32_t cap) {
+  std::vector<uint8_t> buf((size_t)len + 64, 0xA5);
+  memcpy(buf.data(), der, len);
+  PaddedReader r{buf.data()};
+  uint32_t uo[8] = {0}, ul[8] = {0}, nu = 0, nf = 0;
+  bool ok = true;
+  ctmr::crl_dps<true, false, false, 8u>(r, len, cv, ev, ok, uo, ul, nu, nf, false);
+  if (!ok) return -1;
+  for (uint32_t k = 0; k < nu && k < cap && k < 8; k++) { out[2 * k] = uo[k]; out[2 * k + 1] = ul[k]; }
+  return (int)nu;
+}
 
 extern "C" void harness_walk(const uint8_t* der, uint32_t len, uint8_t fill, HarnessOut* out) {
   harness_walk_f(der, len, fill, nullptr, 0, 0, out);
@@ -66,7 +84,7 @@ extern "C" void harness_walk_f(const uint8_t* der, uint32_t len, uint8_t fill, c
   memcpy(buf.data(), der, len);
   PaddedReader r{buf.data()};
   ctmr::Walk w;
-  const bool ok = ctmr::walk_cert(r, len, w, use_filter ? &fv : nullptr, g_spki != 0, false, g_ext != 0);
+  const bool ok = ctmr::walk_cert(r, len, w, use_filter ? &fv : nullptr, g_spki != 0, g_strings != 0, g_ext != 0);
   memset(out, 0, sizeof *out);
   out->ok = ok;
   if (!ok) return;

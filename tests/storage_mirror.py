@@ -435,16 +435,16 @@ class HostCert:
                     continue
                 _, vs, ve = parts[-1]
                 _, dps, dpe = _tlv(d, vs)
-                for (_, ps, pe) in _children(d, dps, dpe):            # DistributionPoint
-                    for (t1, a, b_) in _children(d, ps, pe):
-                        if t1 != 0xa0:
-                            continue
-                        for (t2, c, e2) in _children(d, a, b_):         # fullName [0]
-                            if t2 != 0xa0:
-                                continue
-                            for (t3, u, v) in _children(d, c, e2):
-                                if t3 == 0x86:                           # uniformResourceIdentifier
-                                    self.crl_dps.append(bytes(d[u:v]).decode("latin1"))
+                for (_, ps, pe) in _children(d, dps, dpe):            # DistributionPoint: Go's struct fields are positional
+                    f = _children(d, ps, pe)
+                    if not f or f[0][0] != 0xa0:                        # distributionPoint [0]: the first element or absent
+                        continue
+                    fn = _children(d, f[0][1], f[0][2])
+                    if not fn or fn[0][0] != 0xa0:                      # fullName [0]: the first element inside it
+                        continue
+                    for (t3, u, v) in _children(d, fn[0][1], fn[0][2]):
+                        if t3 & 0x1f == 6:                              # x509.go: fullName.Tag == 6 — the tag number alone
+                            self.crl_dps.append(bytes(d[u:v]).decode("latin1"))
 
     def issuer_string(self) -> str:
         return name_string(self.issuer_atvs)

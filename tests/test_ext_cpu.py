@@ -22,17 +22,34 @@ def aia(value):
     return D.seq(AIA_OID, D.tlv(0x04, value))
 
 
-def verdicts(c):
-    """(structure parses, strict_extensions accepts) — asserted equal between the oracle and the product."""
+NF_STRING, NF_EXT = 4, 16
+
+
+def verdicts(c, findings=None):
+    """(structure parses, strict_extensions accepts) — asserted equal between the oracle and the product, and with them
+    the NON-fatal findings of an accepted certificate: what CT-go files as non-fatal inside an extension body
+    (WALK_NF_EXT ⇔ orc_cert.ext_findings) and, with strict_strings on as well, the character sets inside a distribution
+    point's nameRelativeToCRLIssuer (WALK_NF_STRING ⇔ string_findings | ext_string_findings).  findings: a list that
+    receives (ext finding, string finding) of an accepted certificate."""
     o = orc.parse_cert(c)
     harness.product_set_ext(False)
     p0 = harness.product_walk(c)
     harness.product_set_ext(True)
     p1 = harness.product_walk(c)
+    harness.product_set_strings(True)
+    p2 = harness.product_walk(c)
+    harness.product_set_strings(False)
     harness.product_set_ext(False)
     assert bool(o.ok) == bool(p0.ok), (o.ok, o.err_site, p0.ok)
     strict_ok = bool(o.ok) and not o.ext_fatal
-    assert strict_ok == bool(p1.ok), (o.ok, o.ext_fatal, p1.ok)
+    assert strict_ok == bool(p1.ok) == bool(p2.ok), (o.ok, o.ext_fatal, p1.ok, p2.ok)
+    if strict_ok:
+        assert bool(p1.nonfatal & NF_EXT) == bool(o.ext_findings) == bool(p2.nonfatal & NF_EXT), (o.ext_findings, p1.nonfatal)
+        assert not (p1.nonfatal & NF_STRING)
+        assert bool(p2.nonfatal & NF_STRING) == bool(o.string_findings or o.ext_string_findings), \
+            (o.string_findings, o.ext_string_findings, p2.nonfatal)
+        if findings is not None:
+            findings.append((bool(o.ext_findings), bool(o.ext_string_findings)))
     return bool(o.ok), strict_ok
 
 
@@ -106,9 +123,195 @@ def test_authority_info_access_elements_carry_an_oid_and_a_location():
         bad(aia(v))
 
 
+def san(*names):
+    return x(17, D.seq(*names))
+
+
+def uri(u):
+    return D.tlv(0x86, u if isinstance(u, bytes) else u.encode())
+
+
+def nonfatal(e, ext=True, strings=False):
+    f = []
+    assert verdicts(D.cert(exts=[e]), f) == (True, True), e.hex()
+    assert f == [(ext, strings)], (f, e.hex())
+
+
+def test_subject_alt_name_is_a_sequence_of_general_names():
+    """forEachSAN: one universal constructed SEQUENCE filling the value, every element a TLV that fits, dispatched on the
+    tag NUMBER alone."""
+    good(san(D.tlv(0x82, b"a.example"), D.tlv(0x81, b"x@a.example"), D.tlv(0x87, bytes(4)), D.tlv(0x87, bytes(16)),
+             uri("https://a.example/x")))
+    good(san())                                                       # empty: parses (only "unhandled" when critical)
+    good(san(D.tlv(0x82, b"\xff\x00 not IA5")))                       # no character set is checked on the parse side
+    good(san(D.tlv(0xa0, b"\xff\xff"), D.tlv(0xa4, b"\x05"), D.tlv(0x88, b""), D.tlv(0x05, b"")))   # other names: not looked into
+    good(san(b"\x9f\x21\x01\x00"))                                   # a high-tag-number element: number 33, no case
+    for v in (b"", D.tlv(0x31, D.tlv(0x82, b"a")), D.tlv(0x10, D.tlv(0x82, b"a")),                  # not 0x30
+              D.seq(D.tlv(0x82, b"a")) + b"\x00", D.seq(b"\x82\x05ab"), D.seq(b"\x82"), D.seq(b"\x82\x81\x01a"),
+              D.seq(b"\x9f\x1e\x00")):                                # a high-tag-number form for a number below 31
+        bad(x(17, v))
+    # iPAddress of another length: CT-go files it as NON-fatal (the stdlib fails); any class with number 7 counts
+    for n in (0, 3, 5, 8, 15, 17, 32):
+        nonfatal(san(D.tlv(0x87, bytes(n))))
+    nonfatal(san(D.tlv(0x07, b"abc")))
+    nonfatal(san(D.tlv(0xa7, D.tlv(0x04, b"abc"))))
+    nonfatal(san(D.tlv(0x82, b"ok"), D.tlv(0x87, bytes(4)), D.tlv(0x87, bytes(5))))
+
+
+def test_subject_alt_name_uri_goes_through_url_parse():
+    ok = ["https://a.example/x", "http://a.example:8080/p?q#f", "urn:isbn:0451450523", "mailto:u@h", "", "*", "/just/a/path",
+          "relative/path", "?q=1", "#frag", "http://", "http:///path", "///three", "//host.example/x", "http://[::1]:80/",
+          "http://[fe80::1%25en0]/", "http://u:p@h.example/", "http://u%41@h.example",
+          "http://h.example/%41", "http://h.example/a%20b", "http://a.b/c?%zz", "HTTP://A.EXAMPLE", "a+b-c.d:rest",
+          "http://h.example:/x", "http://h!$&'()*+,;=.example", "http://h.example/\x80\xff",
+          "http://a.example/#%41", "http://a_b.example", "x://h<>\"/", "http://h/a:b", "./a:b", "http://h/?\x01"[:9], "*#f",
+          "http://@h/", "http://:@h/", "http://h.example:80", "x:", "x:%zz", "http://a@b@c/"]
+    bad_ = [":", ":x", "a b"[0:0] + "\x7f", "http://a\x01", "\x00", "http://h/\x1f", "a b:c",   # control characters; a colon in the first segment
+            "//h:port/", "http://h:80x/", "http://h:-1", "http://[::1", "http://[::1]x", "http://[::1]:x", "http://a:b:c/",
+            "http://h%20x/", "http://h%41/", "http://%zz/", "http://h/%", "http://h/%4", "http://h/%zz", "http://h/#%", "http://h/#%g1",
+            "http://h x/", "http://h\\x/", "http://h^x/", "http://h`x/", "http://h{x/", "http://h|x/", "http://h}x/",
+            "http://u ser@h/", "http://us\x80er@h/", "http://u%zz@h/", "http://u:p%@h/", "http://a@b@c d/",
+            "http://.example/", "http://example./", "http://a..b/", "http://h\x80/", "http://h%c3%a9/", "http://[::1%25\x80]/",
+            "http://[fe80::1%25e%7fn]/", "//.h/", "*\x01", "http://h/%41%zz",
+            "1http://x/y",                                            # no scheme (a digit first): a colon in the first path segment
+            "http://[fe80::1%25e%20n]/"]                              # url.Parse takes the space in the zone, domainToReverseLabels does not
+    for u in ok:
+        good(san(uri(u.encode("latin-1"))))
+    for u in bad_:
+        if u:
+            bad(san(uri(u.encode("latin-1"))))
+    # any class with number 6; the URI among other names
+    bad(san(D.tlv(0x06, b":x")))
+    bad(san(D.tlv(0x82, b"fine"), uri("http://ok.example"), D.tlv(0xa6, b"\x7f")))
+
+
+def dps(*points):
+    return x(31, D.seq(*points))
+
+
+def fullname(*names):
+    return D.tlv(0xa0, D.tlv(0xa0, b"".join(names)))
+
+
+def test_crl_distribution_points_follow_the_struct_rules():
+    u = D.tlv(0x86, b"http://crl.example/a.crl")
+    good(dps(D.seq(fullname(u))))
+    good(dps())                                                       # an empty SEQUENCE OF
+    good(dps(D.seq()))                                                # every field optional
+    good(dps(D.seq(fullname(u), D.tlv(0x81, b"\x01\x06"), D.tlv(0xa2, D.tlv(0xa4, b"")))))
+    good(dps(D.seq(fullname(u, D.tlv(0x82, b"x"), D.tlv(0x05, b"")), b"\x05\x00\xff")))   # names of any kind; behind the fields only the next header must parse
+    good(dps(D.seq(D.tlv(0x81, b"\x00"), fullname(b"\xff"))))                      # fields out of order: [0] behind reasons is never parsed
+    good(dps(D.seq(D.tlv(0x82, b"anything"))))                        # cRLIssuer primitive
+    good(dps(D.seq(D.tlv(0x80, b"\xff"))))                            # [0] primitive: no field matches, skipped
+    good(dps(D.seq(D.tlv(0xa0, b""))))                                # an empty distributionPointName
+    good(dps(D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), D.tlv(0x0c, b"rel"))))))))   # nameRelativeToCRLIssuer
+    good(dps(D.seq(D.tlv(0xa0, D.tlv(0xa0, b"") + D.tlv(0xa1, b"")))))              # both, empty
+    good(dps(D.seq(D.tlv(0xa0, D.tlv(0xa2, b"\xff") + b"\x00\x00"))))              # inside [0]: another tag skipped, the rest ignored
+    for v in (b"", D.tlv(0x31, b""), D.seq() + b"\x00", D.seq(D.tlv(0x31, b"")), D.seq(D.tlv(0x04, b"")),      # outer, elements
+              D.seq(D.seq(b"\xa0")), D.seq(D.seq(b"\xa0\x05ab")), D.seq(D.seq(b"\x9f")),                      # a field header that does not parse / fit
+              D.seq(D.seq(D.tlv(0xa0, b"\xa0"))), D.seq(D.seq(D.tlv(0xa0, b"\xa0\x03ab"))),                   # … inside the name
+              D.seq(D.seq(fullname(b"\x86\x05ab"))), D.seq(D.seq(fullname(u, b"\x86"))),                     # FullName elements must fit
+              D.seq(D.seq(D.tlv(0x81, b""))), D.seq(D.seq(D.tlv(0x81, b"\x08\x00"))), D.seq(D.seq(D.tlv(0x81, b"\x01\x01"))),   # reasons: parseBitString
+              D.seq(D.seq(D.tlv(0x81, b"\x00"), b"\x82\x05ab")), D.seq(D.seq(b"\xa2\x05ab")),               # cRLIssuer must fit
+              D.seq(D.seq(fullname(u), b"\x9f")), D.seq(D.seq(D.tlv(0x81, b"\x00"), b"\x81")),               # the header behind a field
+              D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x30, b""))))),                                        # RelativeName: SET elements
+              D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 3))))))),                   # … the value is not optional
+              D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.tlv(0x06, b"\x55\x84"), D.tlv(0x0c, b"x"))))))),
+              D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), D.tlv(0x02, b""))))))),
+              D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa0, b"") + D.tlv(0xa1, b"\x31"))))):
+        bad(x(31, v))
+    # findings inside nameRelativeToCRLIssuer: an INTEGER only the lax parser takes; a PrintableString with '@'
+    rel = lambda val: dps(D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 5), val))))))
+    nonfatal(rel(D.tlv(0x02, b"\x00\x01")))
+    nonfatal(rel(D.tlv(0x13, b"a@b")), ext=False, strings=True)
+    # where the URIs lie (kernels/meta*.h, orc_cert_meta): FullName elements with tag NUMBER 6, positional fields
+    def uris(value):
+        c = D.cert(exts=[x(31, value)])
+        _, ulist, m = orc.cert_meta(c)
+        o = orc.parse_cert(c)
+        at = c.index(value)
+        got = harness.product_crl_uris(c, at, at + len(value))
+        want = None if m.bad_crl else ulist[:8]
+        assert got == want and o.ok, (got, want)
+        return got
+    assert uris(D.seq(D.seq(fullname(u, D.tlv(0x06, b"oid-as-uri"), D.tlv(0x82, b"dns"), D.tlv(0xa6, b"cons"))))) == \
+        [b"http://crl.example/a.crl", b"oid-as-uri", b"cons"]
+    assert uris(D.seq(D.seq(D.tlv(0x81, b"\x00"), fullname(u)))) == []                # out of order: not reached
+    assert uris(D.seq(D.seq(fullname(u)), D.seq(fullname(D.tlv(0x86, b"second"))))) == [b"http://crl.example/a.crl", b"second"]
+    assert uris(D.seq(D.seq(fullname(u), b"\x9f"))) is None
+    assert uris(D.seq(D.seq(D.tlv(0xa0, D.tlv(0xa0, u) + D.tlv(0xa1, D.tlv(0x30, b"")))))) == [b"http://crl.example/a.crl"]   # RelativeName contents: not the metadata's business
+
+
+def nc(permitted=None, excluded=None, raw=None):
+    body = b""
+    if permitted is not None:
+        body += D.tlv(0xa0, b"".join(D.seq(c) for c in permitted))
+    if excluded is not None:
+        body += D.tlv(0xa1, b"".join(D.seq(c) for c in excluded))
+    return x(30, D.seq(body) if raw is None else raw)
+
+
+def test_name_constraints_as_cryptobyte_reads_them():
+    dns = lambda b: D.tlv(0x82, b)
+    good(nc([dns(b"example.com")], [dns(b".example.org")]))
+    good(nc([dns(b"")]))                                              # an empty domain has no labels: fine
+    good(nc(None, [D.tlv(0x87, bytes(4) + b"\xff\xff\xf0\x00")]))
+    good(nc([D.tlv(0x87, bytes(16) + b"\xff" * 8 + bytes(8))]))
+    good(nc([D.tlv(0x81, b"user@example.com"), D.tlv(0x81, b"example.com"), D.tlv(0x81, b".example.com"),
+             D.tlv(0x81, b'"quoted string"@example.com'), D.tlv(0x81, b"a\\@b@example.com"), D.tlv(0x81, b"u@")]))
+    good(nc([D.tlv(0x86, b"example.com"), D.tlv(0x86, b".example.com"), D.tlv(0x86, b"1.2.3"), D.tlv(0x86, b"1.2.3.256")]))
+    good(nc([D.tlv(0xa4, b"\xff"), D.tlv(0x88, b"\x2a"), D.tlv(0x02, b"")]))        # other name forms: unhandled, not an error
+    good(nc([dns(b"a") + D.tlv(0x80, b"\x00") + b"\xff\xff"]))                     # minimum / maximum are never read
+    for e in (nc(raw=b""), nc(raw=D.seq()), nc([], []), nc(raw=D.tlv(0x31, D.tlv(0xa0, D.seq(dns(b"a"))))),
+              nc(raw=D.seq(D.tlv(0xa0, D.seq(dns(b"a")))) + b"\x00"),
+              nc(raw=D.seq(D.tlv(0xa1, D.seq(dns(b"a"))) + D.tlv(0xa0, D.seq(dns(b"a"))))),   # [1] before [0]: toplevel not empty
+              nc(raw=D.seq(D.tlv(0xa0, D.seq(dns(b"a"))) + b"\x05\x00")),
+              nc(raw=D.seq(b"\xa0\x05ab")), nc(raw=D.seq(D.tlv(0xa0, D.tlv(0x31, dns(b"a"))))),
+              nc(raw=D.seq(D.tlv(0xa0, D.seq()))), nc(raw=D.seq(D.tlv(0xa0, D.seq(b"\x82")))),
+              nc(raw=D.seq(D.tlv(0xa0, D.seq(b"\x9f\x21\x00")))),                     # cryptobyte refuses the high-tag-number form
+              nc(raw=D.seq(D.tlv(0x80, b"")))):                                        # [0] primitive: not the optional element
+        bad(e)
+    for c in (dns(b"exa mple.com"), dns(b"example..com"), dns(b"example.com."), dns(b"..example.com"), dns(b"\x80"), dns(b"a\x7fb"),
+              D.tlv(0x87, bytes(7)), D.tlv(0x87, bytes(9)), D.tlv(0x87, bytes(4) + b"\xff\x00\xff\x00"), D.tlv(0x87, bytes(4) + b"\xfd\x00\x00\x00"),
+              D.tlv(0x87, bytes(16) + b"\x00" * 15 + b"\x01"),
+              D.tlv(0x81, b"@example.com"), D.tlv(0x81, b".user@example.com"), D.tlv(0x81, b"us..er@example.com"), D.tlv(0x81, b"user.@x"),
+              D.tlv(0x81, b'"unterminated@example.com'), D.tlv(0x81, b'"a"b@example.com'), D.tlv(0x81, b"a b@example.com"),
+              D.tlv(0x81, b"user@exa mple"), D.tlv(0x81, b"user@.example"), D.tlv(0x81, b"u\\@x"), D.tlv(0x81, b'"\\\n"@x'), D.tlv(0x81, b"ex ample.com"),
+              D.tlv(0x81, b"\xe9@example.com"),
+              D.tlv(0x86, b"1.2.3.4"), D.tlv(0x86, b"01.02.03.004"), D.tlv(0x86, b"::1"), D.tlv(0x86, b"::"), D.tlv(0x86, b"2001:db8::1"),
+              D.tlv(0x86, b"1:2:3:4:5:6:7:8"), D.tlv(0x86, b"::ffff:1.2.3.4"), D.tlv(0x86, b"1:2:3:4:5:6:1.2.3.4"),
+              D.tlv(0x86, b"exa mple"), D.tlv(0x86, b"a..b"), D.tlv(0x86, b"\xff")):
+        bad(nc([c]))
+        bad(nc(None, [c]))
+    # not addresses → judged as domains (all fine: ':' is a printable label octet)
+    for c in (b"1:2:3:4:5:6:7", b"1:2:3:4:5:6:7:8:9", b"::1::", b"1::2::3", b"12345::", b":1", b"1:", b"::1.2.3", b"1.2.3.4.5",
+              b"1:2:3:4:5:1.2.3.4", b"g::1", b"1:2:3:4:5:6:7:1.2.3.4", b"ffffff::"):
+        good(nc([D.tlv(0x86, c)]))
+
+
+SCT_OID = D.tlv(0x06, bytes.fromhex("2b06010401d679020402"))
+
+
+def sct_ext(value):
+    return D.seq(SCT_OID, D.tlv(0x04, value))
+
+
+def test_embedded_sct_list_findings_are_non_fatal():
+    one = b"\x00\x03abc"
+    lst = lambda *s: D.tlv(0x04, len(b"".join(s)).to_bytes(2, "big") + b"".join(s))
+    good(sct_ext(lst(one)))
+    good(sct_ext(lst(one, b"\x00\x01x")))
+    for v in (b"", D.tlv(0x04, b""), D.tlv(0x04, b"\x00"), D.tlv(0x04, b"\x00\x00"), lst(), lst(b"\x00\x00"), lst(one) + b"\x00",
+              D.tlv(0x04, b"\x00\x06" + one), D.tlv(0x04, b"\x00\x04" + one), lst(b"\x00\x05abc"), lst(one, b"\x00"),
+              D.tlv(0x03, b"\x00\x05" + one), D.tlv(0x24, lst(one))):
+        nonfatal(sct_ext(v))
+    # the neighbouring OID …2.4.3 (the precertificate poison) is not an SCT list
+    good(D.seq(D.tlv(0x06, bytes.fromhex("2b06010401d679020403")), D.tlv(0x01, b"\xff"), D.tlv(0x04, b"\x05\x00")))
+
+
 def test_other_extensions_and_the_switch_off():
-    # subjectAltName, nameConstraints, cRLDistributionPoints and unknown extensions are not looked into
-    for e in (x(17, b"\xff\xff"), x(30, b""), x(31, b"\x30\x80"), D.seq(D.tlv(0x06, b"\x2a\x03\x04"), D.tlv(0x04, b"\xff"))):
+    # unknown extensions are not looked into
+    for e in (x(18, b"\xff\xff"), x(9, b""), D.seq(D.tlv(0x06, b"\x2a\x03\x04"), D.tlv(0x04, b"\xff"))):
         good(e)
     # a repeated extension: every occurrence is checked
     c = D.cert(exts=[x(15, D.tlv(0x03, b"\x05\xa0")), x(15, D.tlv(0x03, b"\x08\x00"))])
@@ -153,20 +356,70 @@ def test_real_world_certificates_pass_the_switch(golden_certs=None):
     assert n_ok >= 3
 
 
+def rich_seeds():
+    """Certificates that carry every extension body strict_extensions looks into (the fuzz campaigns' seeds)."""
+    old = [x(15, D.tlv(0x03, b"\x05\xa0")), x(14, D.tlv(0x04, b"\x11" * 20)), x(37, D.seq(EKU_SRV, EKU_CLI)),
+           x(35, D.seq(D.tlv(0x80, b"\x22" * 20))), x(32, D.seq(D.seq(POL))),
+           aia(D.seq(D.seq(OCSP, D.tlv(0x86, b"http://o.example")))), D.BC_NOT_CA]
+    u = D.tlv(0x86, b"http://crl.example/a.crl")
+    rel = D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), D.tlv(0x13, b"rel name"))))
+    lst = lambda *q: D.tlv(0x04, len(b"".join(q)).to_bytes(2, "big") + b"".join(q))
+    web = [san(D.tlv(0x82, b"a.example"), D.tlv(0x82, b"*.b.example"), D.tlv(0x87, bytes(4)), D.tlv(0x87, bytes(16)),
+               uri("https://u:p@a.example:8443/x%20y?q#f"), D.tlv(0x81, b"m@a.example"), uri("http://[fe80::1%25en0]:80/")),
+           dps(D.seq(fullname(u)), D.seq(D.tlv(0xa0, rel), D.tlv(0x81, b"\x01\x06"), D.tlv(0xa2, D.tlv(0xa4, b"")))),
+           sct_ext(lst(b"\x00\x03abc", b"\x00\x02xy")), D.BC_NOT_CA]
+    ca = [nc([D.tlv(0x82, b".example.com"), D.tlv(0x87, bytes(4) + b"\xff\xff\x00\x00"), D.tlv(0x81, b"user@example.com"),
+              D.tlv(0x81, b'"q s"@example.com'), D.tlv(0x86, b".example.com")],
+             [D.tlv(0x87, bytes(16) + b"\xff" * 6 + bytes(10)), D.tlv(0x82, b"x.y"), D.tlv(0x86, b"1:2:3:4:5:6:7")]),
+          D.BC_CA]
+    return [D.cert(exts=old), D.cert(exts=web), D.cert(exts=ca), D.cert(exts=web[:2] + old)]
+
+
+def mutate_exts(rng, der, lo, hi):
+    c = bytearray(der)
+    for _k in range(rng.choice((1, 1, 2, 3))):
+        p = rng.randrange(lo, hi)
+        c[p] = rng.choice((c[p] ^ (1 << rng.randrange(8)), rng.randrange(256), 0x00, 0x80, 0x30, 0x06, 0x04, 0x03, 0x25, 0x2e, 0x3a,
+                           0x40, 0x5b, 0x5d, 0x2f, 0x23, 0x3f, 0x5c, 0x22, 0xa0, 0xa1, 0x86, 0x87, 0x82, 0x81, 0x31))
+    return bytes(c)
+
+
 def test_product_equals_oracle_on_mutated_extension_bodies():
     rng = random.Random(20261012)
-    seeds = [D.cert(exts=[x(15, D.tlv(0x03, b"\x05\xa0")), x(14, D.tlv(0x04, b"\x11" * 20)), x(37, D.seq(EKU_SRV, EKU_CLI)),
-                          x(35, D.seq(D.tlv(0x80, b"\x22" * 20))), x(32, D.seq(D.seq(POL))),
-                          aia(D.seq(D.seq(OCSP, D.tlv(0x86, b"http://o.example")))), D.BC_NOT_CA])]
-    o = orc.parse_cert(seeds[0])
-    lo, hi = o.exts_off, o.exts_end
-    n = rejected = 0
-    for _ in range(30000):
-        c = bytearray(seeds[0])
-        for _k in range(rng.choice((1, 1, 2, 3))):
-            p = rng.randrange(lo, hi)
-            c[p] = rng.choice((c[p] ^ (1 << rng.randrange(8)), rng.randrange(256), 0x00, 0x80, 0x30, 0x06, 0x04, 0x03))
-        a, b = verdicts(bytes(c))
+    seeds = rich_seeds()
+    rng_ranges = []
+    for sd in seeds:
+        o = orc.parse_cert(sd)
+        assert o.ok and not o.ext_fatal and not o.ext_findings
+        rng_ranges.append((o.exts_off, o.exts_end))
+    n = rejected = nf = 0
+    for _ in range(40000):
+        k = rng.randrange(len(seeds))
+        f = []
+        a, b = verdicts(mutate_exts(rng, seeds[k], *rng_ranges[k]), f)
         n += 1
         rejected += a and not b
-    assert rejected > 1000                                             # the switch had something to say
+        nf += bool(f and (f[0][0] or f[0][1]))
+    assert rejected > 1000 and nf > 20                                 # the switch had something to say, both ways
+
+
+def test_product_equals_oracle_on_random_uris_and_constraints():
+    """Strings made for the content parsers (url.Parse, parseRFC2821Mailbox, net.ParseIP, domainToReverseLabels, the IP mask):
+    product (host build) ≡ oracle on each, as a subjectAltName URI and as each kind of name constraint."""
+    rng = random.Random(20261013)
+    alpha_u = "ab1:/@[]%25.?#-+~! \\\"<>_*|\x01\x7f\x80é"
+    alpha_m = "ab1.@\\\" -!#\x0b\x7f"
+    alpha_i = "0123456789abcdefg:.:."
+    seen = set()
+    for t in range(12000):
+        a = (alpha_u, alpha_m, alpha_i)[t % 3]
+        sx = "".join(rng.choice(a) for _ in range(rng.randrange(0, 14)))
+        if t % 7 == 0:
+            sx = rng.choice(("http://", "//", "http://[", "x:", "http://u@", "")) + sx
+        b = sx.encode("latin-1")
+        e = [san(uri(b)), nc([D.tlv(0x86, b)]), nc(None, [D.tlv(0x81, b)]), nc([D.tlv(0x82, b)])][rng.randrange(4)]
+        seen.add(verdicts(D.cert(exts=[e]))[1])
+        if t % 5 == 0:
+            m = bytes(rng.choice((0, 0xff, 0x80, 0xfe, 0xf0, 0x01)) for _ in range(rng.choice((4, 4, 16, 3))))
+            seen.add(verdicts(D.cert(exts=[nc([D.tlv(0x87, bytes(len(m)) + m)])]))[1])
+    assert seen == {True, False}

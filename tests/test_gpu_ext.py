@@ -13,7 +13,7 @@ from ct_mapreduce_amd.engine import RECORD_DTYPE  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests import der as D  # noqa: E402
 from tests.gpu_common import run_oracle  # noqa: E402
-from tests.test_ext_cpu import x, aia, EKU_SRV, EKU_CLI, POL, OCSP  # noqa: E402
+from tests.test_ext_cpu import x, aia, san, uri, dps, fullname, nc, sct_ext, EKU_SRV, EKU_CLI, POL, OCSP  # noqa: E402
 
 NOW = synth.BASE_TIME
 
@@ -22,9 +22,21 @@ def corpus(rng, n):
     issuer_name = D.name(D.rdn(3, b"Ext Issuer"))
     good = [x(15, D.tlv(0x03, b"\x05\xa0")), x(14, D.tlv(0x04, b"\x11" * 20)), x(37, D.seq(EKU_SRV, EKU_CLI)),
             x(35, D.seq(D.tlv(0x80, b"\x22" * 20))), x(32, D.seq(D.seq(POL))),
-            aia(D.seq(D.seq(OCSP, D.tlv(0x86, b"http://o.example")))), D.BC_NOT_CA]
+            aia(D.seq(D.seq(OCSP, D.tlv(0x86, b"http://o.example")))), D.BC_NOT_CA,
+            # round 5: subjectAltName (long enough to leave the walk's LDS window; a URI: the exact reader's business),
+            # cRLDistributionPoints with a nameRelativeToCRLIssuer, an embedded SCT list
+            san(*[D.tlv(0x82, b"host-%02d.a-rather-long-name.example" % k) for k in range(12)], D.tlv(0x87, bytes(4)),
+                uri("https://u@a.example:8443/x%20y?q#f")),
+            dps(D.seq(fullname(D.tlv(0x86, b"http://crl.example/a.crl"))),
+                D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), D.tlv(0x13, b"rel"))))), D.tlv(0x81, b"\x01\x06"))),
+            sct_ext(D.tlv(0x04, b"\x00\x05\x00\x03abc"))]
     bad = [x(15, D.tlv(0x03, b"\x08\x00")), x(14, D.tlv(0x03, b"\x00\x11")), x(37, D.seq(EKU_SRV, D.tlv(0x0c, b"x"))),
-           x(35, D.seq(b"\x80\x7f\x01")), x(32, D.seq(POL)), aia(D.seq(D.seq(OCSP))), x(15, D.tlv(0x03, b"\x05\xa0") + b"\x00")]
+           x(35, D.seq(b"\x80\x7f\x01")), x(32, D.seq(POL)), aia(D.seq(D.seq(OCSP))), x(15, D.tlv(0x03, b"\x05\xa0") + b"\x00"),
+           san(D.tlv(0x82, b"a"), uri("http://a b/")), san(uri(":x")), san(D.tlv(0x82, b"a")) [:-1] + b"\x00",   # fatal
+           san(D.tlv(0x87, bytes(5))), sct_ext(D.tlv(0x04, b"\x00\x06\x00\x03abc")),                           # non-fatal: precertificates only
+           dps(D.seq(D.tlv(0x81, b"\x08\x00"))), dps(D.seq(fullname(b"\x86\x05ab"))),
+           dps(D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 3))))))),
+           nc([D.tlv(0x82, b"exa mple")])]
     certs = []
     for i in range(n):
         exts = list(good)
@@ -48,9 +60,13 @@ def test_packed_batches_follow_the_oracle(strict):
     rng = random.Random(5)
     issuer_ok = D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA, x(15, D.tlv(0x03, b"\x01\x06"))])
     issuer_bad = D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA, x(15, D.tlv(0x03, b"\x08\x00"))])
-    issuers = [issuer_ok, issuer_bad]
+    issuers = [issuer_ok, issuer_bad,
+               D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), spki=D.EC_SPKI_2,
+                      exts=[D.BC_CA, nc([D.tlv(0x82, b".example.com"), D.tlv(0x81, b"u@example.com")], [D.tlv(0x87, bytes(4) + b"\xff\xff\x00\x00")])]),
+               D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA, nc([D.tlv(0x86, b"1.2.3.4")])]),        # a URI constraint that is an IP
+               D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA, san(D.tlv(0x87, bytes(3)))])]          # a non-fatal finding drops an issuer
     certs = corpus(rng, 3000)
-    b = ctmr.Batch.from_certs(certs, [rng.randrange(2) for _ in certs], [rng.randrange(2) for _ in certs])
+    b = ctmr.Batch.from_certs(certs, [rng.randrange(len(issuers)) for _ in certs], [rng.randrange(2) for _ in certs])
     o = orc.Engine(b"", True, NOW)
     o.set_strict_extensions(strict)
     o, st, unk, eh = run_oracle(b, issuers, b"", True, NOW, engine=o)
@@ -65,6 +81,36 @@ def test_packed_batches_follow_the_oracle(strict):
     if strict:
         assert (st == orc.ST_PARSE_ERROR).sum() > 1000 and (st == orc.ST_ISSUER_PARSE_ERROR).sum() > 300   # … and the refused issuer's entries
     eng.close()
+
+
+def test_the_reference_profile_is_the_four_switches():
+    """ctmr_set_profile(CTMR_PROFILE_REFERENCE) ≡ strict_spki + strict_leaf + strict_strings + strict_extensions, and
+    CTMR_PROFILE_FAST restores the defaults — on a corpus where each switch has something to say."""
+    rng = random.Random(7)
+    issuer = D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA])
+    certs = corpus(rng, 1500)
+    for i in range(0, len(certs), 7):                                 # Names with a character-set finding
+        certs[i] = D.cert(serial=bytes([7, i % 251, i // 251]), issuer=D.name(D.rdn(10, b"a@b", 0x13), D.rdn(3, b"Ext Issuer")))
+    b = ctmr.Batch.from_certs(certs, [0] * len(certs), [rng.randrange(2) for _ in certs])
+    got = {}
+    for mode in ("reference", "switches", "fast", "defaults"):
+        eng = ctmr.Engine(device=0, table_slots=1 << 13, pair_slots=1 << 10)
+        if mode == "switches":
+            eng.set_strict_leaf(True); eng.set_strict_strings(True); eng.set_strict_extensions(True); eng.set_strict_spki(True)
+        elif mode == "reference":
+            eng.set_profile("reference")
+        elif mode == "fast":
+            eng.set_profile("reference"); eng.set_profile("fast")
+        eng.add_issuers([issuer])
+        eng.set_filter(b"", True, NOW)
+        got[mode] = eng.map_batch(b).records["status"].copy()
+        eng.close()
+    assert (got["reference"] == got["switches"]).all() and (got["fast"] == got["defaults"]).all()
+    o = orc.Engine(b"", True, NOW)
+    o.set_strict_extensions(True); o.set_strict_strings(True)
+    st = run_oracle(b, [issuer], b"", True, NOW, engine=o)[1]
+    assert (got["reference"] == st).all()
+    assert (got["reference"] != got["fast"]).sum() > 300
 
 
 def test_raw_entries_with_strict_leaf_and_the_switch():
