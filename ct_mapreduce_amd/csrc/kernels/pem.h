@@ -36,33 +36,39 @@ struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };  // una
 
 // ------------------------------------------------------------------ k_pem_encode (round 5: output-block design)
 // The PEM blocks of the NEW list are ONE contiguous byte stream (pem_off is an exclusive scan), so the work is cut by
-// OUTPUT bytes, not by certificate: one wave produces one 4 KiB block of the stream at a time — whatever certificates
+// OUTPUT bytes, not by certificate: one wave produces one 3.5 KiB block of the stream at a time — whatever certificates
 // and parts of certificates lie in it — and every global access is a naturally aligned 16-byte vector covering whole
 // 128-byte lines:
 //   1. lane j fetches the bounds of the j-th certificate that overlaps the block (k_pem_blocks left the first one's
-//      index per block, k_pem_len its place in the payload) and works out which of its 12-byte → 16-character tasks fall
-//      into the block;
-//   2. the input bytes those tasks need (≤ 3 KiB, contiguous per certificate) come in as aligned, non-temporal
-//      16-byte loads, 1 KiB per instruction, and are parked in LDS;
-//   3. each lane encodes tasks: 12 bytes from LDS (aligned dword reads + v_alignbyte: the misalignment is the
-//      certificate's start address mod 4), four v_perm_b32 make the big-endian 24-bit groups, the 16 characters come
-//      from the 64-byte alphabet in LDS (one ds_read_u8 per character, conflict-free: the compare/select alphabet cost
-//      ≈ 9 VALU instructions per character), and go to the block's image in LDS at
-//      their final stream position — 65-byte lines put every line at another alignment, so the 16 characters are
-//      stored as three aligned dwords + four single bytes (an unaligned ds_write_b128 is replayed at 64 cycles);
-//      the line ends and the two framing lines are byte stores into the same image;
-//   4. the image leaves as 4 × 64 aligned, non-temporal 16-byte stores.
-// Round 4's kernel (one wave per certificate, unaligned dwordx3 loads, 16-byte stores at a 65-byte pitch that never
-// meet a sector boundary, one byte store per line end) reached 3.4 TB/s read + written; see DESIGN.md §9 N1.
-constexpr uint32_t PEM_S = 4096;              // output bytes per block
-constexpr uint32_t PEM_MARGIN = 32;           // a task that straddles a block edge is encoded whole by both blocks
-constexpr uint32_t PEM_IN_CHUNKS = 256;       // 16-byte input chunks parked per pass
+//      index per block, k_pem_len its place in the payload) and works out which of its base64 LINES fall into the block;
+//   2. the input bytes of those lines (≤ 3 KiB, contiguous per certificate) come in as aligned, non-temporal 16-byte
+//      loads, 1 KiB per instruction, and are parked in LDS;
+//   3. ONE LANE ENCODES ONE LINE: 48 bytes from LDS (aligned dword reads + v_alignbyte), sixteen v_perm_b32 make the
+//      big-endian 24-bit groups, the 64 characters come from the 64-byte alphabet in LDS (one v_bfe + one ds_read_u8 per
+//      character; sixteen dwords in sixteen banks: conflict-free) and go to the block's image in LDS at their final
+//      stream position — a line is 65 bytes, so every line sits at another alignment: sixteen v_alignbyte shift it onto
+//      aligned dwords, the two ends and the line end are byte stores.  A certificate's last, shorter line is encoded
+//      apart, by up to four lanes in 12-byte → 16-character tasks (whatever they write past the line's end lands in the
+//      END line's place, which is written afterwards), and so are the two framing lines;
+//   4. the image leaves as 224 aligned, non-temporal 16-byte stores.
+// The loop over a wave's blocks is software-pipelined: while block i is encoded, the BYTES of block i + 1 and the BOUNDS of
+// block i + 2 are in flight.
+// History (profiles/r05/pem_*): round 4's kernel — one wave per certificate, unaligned dwordx3 loads, 16-byte stores at
+// a 65-byte pitch that never meet a sector boundary, a byte store per line end, ≈ 9 VALU instructions per character for
+// the alphabet — 3.4 TB/s read + written.  The block design with one lane per 12-byte task: 2.9 TB/s unpipelined, 3.1
+// pipelined, 3.4 with a conflict-free alphabet table — and the counters said why: 935 vector instructions and 202 LDS
+// instructions per 4 KiB block, the vector ALU 80 % busy.  One lane per line cuts both by more than half.
+constexpr uint32_t PEM_S = 3584;              // output bytes per block: ≈ 55 lines, so that one lane per line fits one pass
+constexpr uint32_t PEM_MARGIN = 80;           // a line that straddles a block edge is encoded whole by both blocks
+constexpr uint32_t PEM_IN_CHUNKS = 192;       // 16-byte input chunks parked per pass
 constexpr uint32_t PEM_LUT_BYTES = 64 + 64;   // the alphabet + the two framing lines
 constexpr uint32_t PEM_OBUF = PEM_S + 2 * PEM_MARGIN;
-constexpr uint32_t PEM_IBUF = PEM_IN_CHUNKS * 16 + 16;
-constexpr uint32_t PEM_WAVE_LDS = PEM_OBUF + PEM_IBUF;
+constexpr uint32_t PEM_IBUF = PEM_IN_CHUNKS * 16 + 64;
+constexpr uint32_t PEM_TRASH = 256;           // one dword per lane: where a store that must not happen goes
+constexpr uint32_t PEM_WAVE_LDS = PEM_OBUF + PEM_IBUF + PEM_TRASH;
 constexpr uint32_t PEM_WAVES = 4;             // waves per workgroup (they share the tables, nothing else)
-constexpr uint32_t PEM_LDS_BYTES = PEM_LUT_BYTES + PEM_WAVES * PEM_WAVE_LDS;
+constexpr uint32_t PEM_LDS_BYTES = PEM_WAVES * PEM_WAVE_LDS;  // dynamic; + PEM_LUT_BYTES static
+constexpr uint32_t PEM_FAST_CERTS = 16;       // certificates per block the one-pass path takes (4 task lanes each)
 
 __device__ __forceinline__ uint32_t b64_char(uint32_t v) {  // base64.StdEncoding alphabet
   int32_t off = 65;                 // 'A'
@@ -89,12 +95,23 @@ struct PemCert {
   uint64_t p0, p1, lo, len;  // its PEM block [p0, p1) in the stream, its DER [lo, lo + len) in the payload
   bool have;                 // such a certificate exists (r < n_idx)
 };
-// what lane j's certificate contributes to the block [B0, B1): its 12-byte → 16-character tasks k_lo … k_lo + ntask − 1, the
-// nch 16-byte input chunks from payload offset a0 they read; pre = inclusive prefix sum of nch over the lanes
+// what lane j's certificate contributes to the block [B0, B1): nfl whole lines from line ln_lo on (48 bytes → 64 characters
+// + line end each), the ntk tasks (12 bytes → 16 characters) of its last, shorter line from task tk_lo on, and the nch
+// 16-byte input chunks from payload offset a0 they read
 struct PemPlan {
-  uint32_t k_lo, ntask, nch, pre, nq, ncert;
+  uint32_t ln_lo, nfl, tk_lo, ntk, nch, nq, ncert;
   uint64_t a0;
   bool inblk;
+};
+// what a lane does in a block: its line (lines), its task of some certificate's last line (tasks); ib / ob: where the
+// certificate's byte 0 lies in ibuf, its first base64 character in obuf
+struct PemWork {
+  uint32_t ln, l_ib;
+  int32_t l_ob;
+  bool l_act;
+  uint32_t tk, t_ib, t_len, t_nq;
+  int32_t t_ob;
+  bool t_act, any_task;
 };
 
 // (unconditional loads from a clamped index: a load under a branch reaches the loop's carried registers through a copy, and
@@ -113,141 +130,196 @@ __device__ __forceinline__ PemCert pem_cert_load(const uint64_t* __restrict__ pe
   return c;
 }
 
-__device__ __forceinline__ PemPlan pem_plan(const PemCert& c, uint64_t B0, uint64_t B1, uint32_t lane) {
-  PemPlan p{0u, 0u, 0u, 0u, (uint32_t)((c.len + 11u) / 12u), 0u, 0ull, c.have && c.p0 < B1};
+__device__ __forceinline__ PemPlan pem_plan(const PemCert& c, uint64_t B0, uint64_t B1) {
+  PemPlan p{0u, 0u, 0u, 0u, 0u, (uint32_t)((c.len + 11u) / 12u), 0u, 0ull, c.have && c.p0 < B1};
   p.ncert = (uint32_t)__popcll(__ballot(p.inblk));  // p0 ascends: lanes 0 … ncert − 1
   if (p.inblk) {
     const uint64_t body = c.p0 + 28u, body_end = c.p1 - 26u;  // the base64 lines with their line ends
     const uint64_t s = B0 > body ? B0 : body, e = B1 < body_end ? B1 : body_end;
     if (e > s) {
-      const uint32_t rl = (uint32_t)(s - body), rh = (uint32_t)(e - 1u - body);
-      const uint32_t l0 = rl / 65u, c0 = rl - 65u * l0, l1 = rh / 65u, c1 = rh - 65u * l1;
-      uint32_t k_lo = 4u * l0 + (c0 >> 4 > 3u ? 3u : c0 >> 4), k_hi = 4u * l1 + (c1 >> 4 > 3u ? 3u : c1 >> 4);
-      k_lo = k_lo < p.nq ? k_lo : p.nq - 1u;
-      k_hi = k_hi < p.nq ? k_hi : p.nq - 1u;
-      p.k_lo = k_lo;
-      p.ntask = k_hi - k_lo + 1u;
-      const uint64_t in_lo = c.lo + 12ull * k_lo, in_end = 12ull * (k_hi + 1u) < c.len ? c.lo + 12ull * (k_hi + 1u) : c.lo + c.len;
+      const uint32_t L = (uint32_t)c.len, nfull = L / 48u;        // (a certificate is shorter than 2^31 bytes)
+      const uint32_t ln_lo = (uint32_t)(s - body) / 65u, ln_hi = (uint32_t)(e - 1u - body) / 65u;
+      const bool last = (L != 48u * nfull) & (ln_hi == nfull);     // the shorter last line lies in the block
+      const uint32_t fl_end = ln_hi + 1u < nfull ? ln_hi + 1u : nfull;  // whole lines: [ln_lo, fl_end)
+      p.ln_lo = ln_lo;
+      p.nfl = fl_end > ln_lo ? fl_end - ln_lo : 0u;
+      p.tk_lo = 4u * nfull;
+      p.ntk = last ? p.nq - 4u * nfull : 0u;
+      const uint64_t in_lo = c.lo + 48ull * ln_lo, in_end = last ? c.lo + L : c.lo + 48ull * fl_end;
       p.a0 = in_lo & ~15ull;
       p.nch = (uint32_t)((((in_end + 15ull) & ~15ull) - p.a0) >> 4);
     }
   }
-  uint32_t pre = p.nch;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(pre, d);
-    pre += lane >= (uint32_t)d ? t : 0u;
-  }
-  p.pre = pre;
   return p;
 }
 
-// the input bytes of the certificates [done, upto) of a plan: flat chunk f of them belongs to the certificate whose prefix
-// range holds it.  Aligned, non-temporal 16-byte loads, 1 KiB per instruction; v[q] = chunk 64·q + lane.
-__device__ __forceinline__ uint32_t pem_issue(const uint8_t* __restrict__ payload, const PemPlan& p, uint32_t done, uint32_t upto, uint32_t lane,
-                                              uint4 (&v)[4]) {
-  const uint32_t base = done ? __shfl(p.pre, (int)done - 1) : 0u;
-  uint32_t nflat = __shfl(p.pre, (int)upto - 1) - base;
-  nflat = nflat < PEM_IN_CHUNKS ? nflat : PEM_IN_CHUNKS;
-  uint64_t src[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-  for (uint32_t j = done; j < upto; j++) {
-    const uint32_t pj = __shfl(p.pre, (int)j) - base, nj = __shfl(p.nch, (int)j);
-    const uint64_t aj = __shfl(p.a0, (int)j);
+__device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)j); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t j) {
+  return (uint64_t)rl32((uint32_t)v, j) | ((uint64_t)rl32((uint32_t)(v >> 32), j) << 32);
+}
+__device__ __forceinline__ uint32_t gather32(uint32_t v, uint32_t from) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
+
+// Certificates [j0, j1) of a plan: hands every lane its input chunks (src[q]: payload offset of flat chunk 64·q + lane, ~0 =
+// none), its line and its task, and says whether one pass can take them (≤ 192 chunks, ≤ 64 lines, ≤ 16 certificates).  A
+// scalar loop over the certificates (three counts each, v_readlane) tells every lane WHICH certificate owns its chunk, its
+// line, its task; what it needs of that certificate it then fetches from the certificate's lane (ds_bpermute) — selecting
+// every value inside the loop cost ≈ 40 vector instructions per certificate.
+__device__ __forceinline__ bool pem_assign(const PemCert& c, const PemPlan& p, uint32_t j0, uint32_t j1, long long B0s, uint32_t lane,
+                                           uint64_t (&src)[3], uint32_t& nflat, PemWork& w) {
+  uint32_t cown[3] = {64u, 64u, 64u}, lown = 64u;  // owner lanes; 64 = none (a bpermute from lane 64 reads lane 0: unused)
+  uint32_t my_cbase = 0u, my_lbase = 0u, cbase = 0u, lbase = 0u;
+  bool any_task = false;
+  for (uint32_t j = j0; j < j1; j++) {
+    const uint32_t nch = rl32(p.nch, j), nfl = rl32(p.nfl, j);
+    any_task = any_task | (rl32(p.ntk, j) != 0u);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t f = 64u * q + lane;
-      if (f < pj && f >= pj - nj) src[q] = aj + 16ull * (f - (pj - nj));
-    }
+    for (int q = 0; q < 3; q++) cown[q] = (64u * q + lane - cbase) < nch ? j : cown[q];
+    lown = (lane - lbase) < nfl ? j : lown;
+    my_cbase = lane == j ? cbase : my_cbase;
+    my_lbase = lane == j ? lbase : my_lbase;
+    cbase += nch;
+    lbase += nfl;
   }
+  // lane j's certificate: where its byte 0 lies in ibuf, its first base64 character in obuf
+  const uint32_t my_ib = 16u * my_cbase + (uint32_t)(c.lo - p.a0);  // (wraps below zero when ln_lo > 0: 48·ln brings it back)
+  const int32_t my_ob = (int32_t)((long long)(c.p0 + 28u) - B0s) + (int32_t)PEM_MARGIN;
 #pragma unroll
-  for (int q = 0; q < 4; q++)
-    v[q] = (64u * q + lane < nflat && src[q] != ~0ull) ? ld_payload16((const uint4*)(payload + src[q])) : make_uint4(0, 0, 0, 0);
-  return nflat;
+  for (int q = 0; q < 3; q++) {
+    const uint32_t o = cown[q];
+    const uint64_t a0 = (uint64_t)gather32((uint32_t)p.a0, o) | ((uint64_t)gather32((uint32_t)(p.a0 >> 32), o) << 32);
+    src[q] = o < 64u ? a0 + 16ull * (64u * q + lane - gather32(my_cbase, o)) : ~0ull;
+  }
+  w.l_act = lown < 64u;
+  w.ln = gather32(p.ln_lo, lown) + (lane - gather32(my_lbase, lown));
+  w.l_ib = gather32(my_ib, lown);
+  w.l_ob = (int32_t)gather32((uint32_t)my_ob, lown);
+  const uint32_t town = j0 + (lane >> 2);  // four task lanes per certificate
+  const uint32_t ntk = gather32(p.ntk, town);
+  w.t_act = (town < j1) & ((lane & 3u) < ntk);
+  w.tk = gather32(p.tk_lo, town) + (lane & 3u);
+  w.t_ib = gather32(my_ib, town);
+  w.t_ob = (int32_t)gather32((uint32_t)my_ob, town);
+  w.t_len = gather32((uint32_t)c.len, town);
+  w.t_nq = gather32(p.nq, town);
+  w.any_task = any_task;
+  nflat = cbase < PEM_IN_CHUNKS ? cbase : PEM_IN_CHUNKS;
+  return cbase <= PEM_IN_CHUNKS && lbase <= 64u && j1 - j0 <= PEM_FAST_CERTS;
 }
 
-__device__ __forceinline__ void pem_park(uint8_t* ibuf, const uint4 (&v)[4], uint32_t nflat, uint32_t lane) {
+// aligned, non-temporal 16-byte loads, 1 KiB per instruction; v[q] = flat chunk 64·q + lane
+__device__ __forceinline__ void pem_issue(const uint8_t* __restrict__ payload, const uint64_t (&src)[3], uint4 (&v)[3]) {
 #pragma unroll
-  for (int q = 0; q < 4; q++)
+  for (int q = 0; q < 3; q++)
+    v[q] = src[q] != ~0ull ? ld_payload16((const uint4*)(payload + src[q])) : make_uint4(0, 0, 0, 0);
+}
+
+__device__ __forceinline__ void pem_park(uint8_t* ibuf, const uint4 (&v)[3], uint32_t nflat, uint32_t lane) {
+#pragma unroll
+  for (int q = 0; q < 3; q++)
     if (64u * q < nflat) ((uint4*)ibuf)[64u * q + lane] = v[q];
   __builtin_amdgcn_wave_barrier();
 }
 
-// the tasks and the framing lines of the certificates [done, upto) into the block's image
-__device__ __forceinline__ void pem_encode_certs(const PemCert& c, const PemPlan& p, uint32_t done, uint32_t upto, long long B0s,
-                                                 const uint8_t* abc, const uint8_t* frame, uint8_t* obuf, const uint8_t* ibuf,
-                                                 uint32_t lane) {
-  const uint32_t base = done ? __shfl(p.pre, (int)done - 1) : 0u;
-  for (uint32_t j = done; j < upto; j++) {
-    const uint32_t kj = __shfl(p.k_lo, (int)j), nt = __shfl(p.ntask, (int)j), nqj = __shfl(p.nq, (int)j);
-    const uint64_t p0j = __shfl(c.p0, (int)j), p1j = __shfl(c.p1, (int)j), loj = __shfl(c.lo, (int)j), aj = __shfl(p.a0, (int)j);
-    const uint64_t Lj = __shfl(c.len, (int)j);
-    // ibuf offset of the certificate's byte 0 (wraps below zero when k_lo > 0: 12·k brings it back)
-    const uint32_t ib = 16u * (__shfl(p.pre, (int)j) - __shfl(p.nch, (int)j) - base) + (uint32_t)(loj - aj);
-    const int32_t ob = (int32_t)((long long)(p0j + 28u) - B0s) + (int32_t)PEM_MARGIN;  // obuf offset of body byte 0
-    for (uint32_t t = lane; t < nt; t += 64u) {
-      const uint32_t k = kj + t;
-      const uint32_t at = ib + 12u * k;  // input byte 12·k of the certificate, in ibuf
-      const uint32_t m = at & 3u;
-      const uint32_t* w = (const uint32_t*)(ibuf + (at & ~3u));
-      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-      uint32_t d0 = __builtin_amdgcn_alignbyte(w1, w0, m), d1 = __builtin_amdgcn_alignbyte(w2, w1, m),
-               d2 = __builtin_amdgcn_alignbyte(w3, w2, m);
-      const uint64_t ip = 12ull * k;
-      const uint32_t nin = (uint32_t)(Lj - ip < 12ull ? Lj - ip : 12ull);
-      if (nin < 12u) {  // the certificate's last, partial task: bytes behind the certificate count as zero
-        const uint32_t keep = nin & 3u ? (1u << (8u * (nin & 3u))) - 1u : 0u;
-        d0 = nin >= 4u ? d0 : (d0 & keep);
-        d1 = nin >= 8u ? d1 : (nin > 4u ? (d1 & keep) : 0u);
-        d2 = nin > 8u ? (d2 & keep) : 0u;
-      }
-      // big-endian 24-bit groups, then 4 × 6 bits → the pre-shifted tables
-      const uint32_t g0 = __builtin_amdgcn_perm(d0, d0, 0x0c000102u), g1 = __builtin_amdgcn_perm(d1, d0, 0x0c030405u),
-                     g2 = __builtin_amdgcn_perm(d2, d1, 0x0c020304u), g3 = __builtin_amdgcn_perm(d2, d2, 0x0c010203u);
-      // the 64-byte alphabet: sixteen dwords in sixteen banks, so any two lanes either read the same dword (a broadcast) or
-      // different banks — four pre-shifted 64-DWORD tables put entries e and e + 32 on one bank, and 32 random lanes made
-      // every read a three- to four-way conflict
-      const auto enc = [&](uint32_t g) {
-        return (uint32_t)abc[g >> 18] | ((uint32_t)abc[(g >> 12) & 63u] << 8) | ((uint32_t)abc[(g >> 6) & 63u] << 16) |
-               ((uint32_t)abc[g & 63u] << 24);
-      };
-      uint32_t ch[4] = {enc(g0), enc(g1), enc(g2), enc(g3)};
-      bool nl = ((k & 3u) == 3u) | (k == nqj - 1u);  // the 17th byte: the line end
-      if (nin < 12u) {  // '=' padding, and the line end right behind the last character
-        const uint32_t gl = (nin - 1u) / 3u, rem = nin - 3u * gl;
-        const uint32_t msk = rem == 1u ? 0x0000ffffu : rem == 2u ? 0x00ffffffu : 0xffffffffu;
-        const uint32_t pad = rem == 1u ? 0x3d3d0000u : rem == 2u ? 0x3d000000u : 0u;
+__device__ __forceinline__ uint32_t pem_enc4(const uint8_t* abc, uint32_t g) {  // a big-endian 24-bit group → four characters
+  const uint32_t c0 = abc[__builtin_amdgcn_ubfe(g, 18, 6)], c1 = abc[__builtin_amdgcn_ubfe(g, 12, 6)],
+                 c2 = abc[__builtin_amdgcn_ubfe(g, 6, 6)], c3 = abc[g & 63u];
+  // two v_perm_b32 and an or (written as shifts and ors the compiler makes four to five instructions of it)
+  return __builtin_amdgcn_perm(c1, c0, 0x0c0c0400u) | __builtin_amdgcn_perm(c3, c2, 0x04000c0cu);
+}
+
+// the whole lines: one lane, one line
+__device__ __forceinline__ void pem_encode_lines(const PemWork& w, const uint8_t* abc, uint8_t* obuf, const uint8_t* ibuf,
+                                                 uint32_t* trash) {
+  if (!w.l_act) return;
+  const uint32_t at = w.l_ib + 48u * w.ln, m = at & 3u;
+  const uint32_t* x = (const uint32_t*)(ibuf + (at & ~3u));
+  uint32_t r[13];
 #pragma unroll
-        for (uint32_t q = 0; q < 4u; q++) {
-          ch[q] = q == gl ? ((ch[q] & msk) | pad) : ch[q];
-          ch[q] = q == gl + 1u ? 0x0au : ch[q];
-        }
-        nl = gl == 3u;
-      }
-      // the 16 characters at their stream position: body byte (k >> 2)·65 + (k & 3)·16
-      const int32_t P = ob + (int32_t)((k >> 2) * 65u + (k & 3u) * 16u);
-      uint8_t* const o = obuf + P;
-      const uint32_t s = (uint32_t)P & 3u;
-      uint32_t* const q = (uint32_t*)(o - s);  // aligned; dwords 1..3 of the five the characters touch are whole
-      const uint32_t sh = 4u - s;               // (s = 0: the selects below take the unshifted dwords)
-      q[1] = s ? __builtin_amdgcn_alignbyte(ch[1], ch[0], sh) : ch[1];
-      q[2] = s ? __builtin_amdgcn_alignbyte(ch[2], ch[1], sh) : ch[2];
-      q[3] = s ? __builtin_amdgcn_alignbyte(ch[3], ch[2], sh) : ch[3];
-      // the four bytes left over: ch[0]'s first 4 − s in front, ch[3]'s last s behind (s = 0: ch[0] whole)
+  for (int k = 0; k < 13; k++) r[k] = x[k];
+  uint32_t ch[17];
 #pragma unroll
-      for (uint32_t t4 = 0; t4 < 4u; t4++) {
-        const bool front = t4 < sh;
-        o[front ? t4 : 12u + t4] = (uint8_t)((front ? ch[0] : ch[3]) >> (8u * t4));
-      }
-      if (nl) o[16] = (uint8_t)'\n';
+  for (int g = 0; g < 16; g += 4) {  // 12 input bytes = three dwords → four groups
+    const int j = 3 * (g >> 2);
+    const uint32_t d0 = __builtin_amdgcn_alignbyte(r[j + 1], r[j], m), d1 = __builtin_amdgcn_alignbyte(r[j + 2], r[j + 1], m),
+                   d2 = __builtin_amdgcn_alignbyte(r[j + 3], r[j + 2], m);
+    ch[g] = pem_enc4(abc, __builtin_amdgcn_perm(d0, d0, 0x0c000102u));
+    ch[g + 1] = pem_enc4(abc, __builtin_amdgcn_perm(d1, d0, 0x0c030405u));
+    ch[g + 2] = pem_enc4(abc, __builtin_amdgcn_perm(d2, d1, 0x0c020304u));
+    ch[g + 3] = pem_enc4(abc, __builtin_amdgcn_perm(d2, d2, 0x0c010203u));
+  }
+  ch[16] = 0x0au;
+  // the 64 characters and the line end at stream position P (body byte 65·ln): with s = P mod 4, aligned dword k of the
+  // line is alignbyte(ch[k], ch[k − 1], 4 − s) — for s = 0 that is ch[k − 1], which belongs one dword earlier: the base moves
+  const int32_t P = w.l_ob + (int32_t)(65u * w.ln);
+  uint8_t* const o = obuf + P;
+  const uint32_t s = (uint32_t)P & 3u, sh = (4u - s) & 3u;
+  uint32_t* const A = (uint32_t*)(o - s - (s ? 0u : 4u));
+#pragma unroll
+  for (int k = 1; k < 16; k++) A[k] = __builtin_amdgcn_alignbyte(ch[k], ch[k - 1], sh);
+  // dword 16 is a whole one for s = 0 (the last four characters) and s = 3 (three characters and the line end); for
+  // s = 1, 2 its other bytes are the next line's — it goes nowhere, and the bytes below cover it
+  *(((s == 0u) | (s == 3u)) ? A + 16 : trash) = __builtin_amdgcn_alignbyte(ch[16], ch[15], sh);
+#pragma unroll
+  for (uint32_t t4 = 0; t4 < 4u; t4++) {  // the first 4 − s characters in front, the last s behind (s = 0: the first four, again)
+    const bool front = t4 < 4u - s;
+    o[front ? t4 : 60u + t4] = (uint8_t)((front ? ch[0] : ch[15]) >> (8u * t4));
+  }
+  o[64] = (uint8_t)'\n';
+}
+
+// the shorter last lines: one lane, one 12-byte → 16-character task
+__device__ __forceinline__ void pem_encode_tasks(const PemWork& w, const uint8_t* abc, uint8_t* obuf, const uint8_t* ibuf) {
+  if (!w.t_act) return;
+  const uint32_t k = w.tk;
+  const uint32_t at = w.t_ib + 12u * k, m = at & 3u;
+  const uint32_t* x = (const uint32_t*)(ibuf + (at & ~3u));
+  const uint32_t w0 = x[0], w1 = x[1], w2 = x[2], w3 = x[3];
+  uint32_t d0 = __builtin_amdgcn_alignbyte(w1, w0, m), d1 = __builtin_amdgcn_alignbyte(w2, w1, m), d2 = __builtin_amdgcn_alignbyte(w3, w2, m);
+  const uint32_t left = w.t_len - 12u * k, nin = left < 12u ? left : 12u;
+  if (nin < 12u) {  // the certificate's last, partial task: bytes behind the certificate count as zero
+    const uint32_t keep = nin & 3u ? (1u << (8u * (nin & 3u))) - 1u : 0u;
+    d0 = nin >= 4u ? d0 : (d0 & keep);
+    d1 = nin >= 8u ? d1 : (nin > 4u ? (d1 & keep) : 0u);
+    d2 = nin > 8u ? (d2 & keep) : 0u;
+  }
+  uint32_t ch[4] = {pem_enc4(abc, __builtin_amdgcn_perm(d0, d0, 0x0c000102u)), pem_enc4(abc, __builtin_amdgcn_perm(d1, d0, 0x0c030405u)),
+                    pem_enc4(abc, __builtin_amdgcn_perm(d2, d1, 0x0c020304u)), pem_enc4(abc, __builtin_amdgcn_perm(d2, d2, 0x0c010203u))};
+  bool nl = k == w.t_nq - 1u;  // the 17th byte: the line end (a last line has at most four tasks)
+  if (nin < 12u) {  // '=' padding, and the line end right behind the last character
+    const uint32_t gl = (nin - 1u) / 3u, rem = nin - 3u * gl;
+    const uint32_t msk = rem == 1u ? 0x0000ffffu : rem == 2u ? 0x00ffffffu : 0xffffffffu;
+    const uint32_t pad = rem == 1u ? 0x3d3d0000u : rem == 2u ? 0x3d000000u : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++) {
+      ch[q] = q == gl ? ((ch[q] & msk) | pad) : ch[q];
+      ch[q] = q == gl + 1u ? 0x0au : ch[q];
     }
-    // the framing lines, behind the tasks in program order (LDS operations of a wave execute in order): the tail of a
-    // partial last task overshoots into the END line's place, which is written here
-    {
-      const bool hd = lane < 28u, tr = (lane >= 32u) & (lane < 58u);
-      const long long pos = hd ? (long long)(p0j + lane) - B0s : (long long)(p1j - 26u + (lane - 32u)) - B0s;
-      if ((hd | tr) && pos >= -(long long)PEM_MARGIN && pos < (long long)(PEM_S + PEM_MARGIN))
-        obuf[(int32_t)pos + (int32_t)PEM_MARGIN] = frame[lane];
-    }
+    nl = gl == 3u;
+  }
+  const int32_t P = w.t_ob + (int32_t)((k >> 2) * 65u + (k & 3u) * 16u);
+  uint8_t* const o = obuf + P;
+  const uint32_t s = (uint32_t)P & 3u, sh = 4u - s;
+  uint32_t* const q = (uint32_t*)(o - s);  // aligned; dwords 1..3 of the five the characters touch are whole
+  q[1] = s ? __builtin_amdgcn_alignbyte(ch[1], ch[0], sh) : ch[1];
+  q[2] = s ? __builtin_amdgcn_alignbyte(ch[2], ch[1], sh) : ch[2];
+  q[3] = s ? __builtin_amdgcn_alignbyte(ch[3], ch[2], sh) : ch[3];
+#pragma unroll
+  for (uint32_t t4 = 0; t4 < 4u; t4++) {
+    const bool front = t4 < sh;
+    o[front ? t4 : 12u + t4] = (uint8_t)((front ? ch[0] : ch[3]) >> (8u * t4));
+  }
+  if (nl) o[16] = (uint8_t)'\n';
+}
+
+// the framing lines of certificates [j0, j1), behind the lines and tasks in program order (LDS operations of a wave
+// execute in order): the tail of a partial last task overshoots into the END line's place, which is written here
+__device__ __forceinline__ void pem_frames(const PemCert& c, uint32_t j0, uint32_t j1, long long B0s, const uint8_t* frame,
+                                           uint8_t* obuf, uint32_t lane) {
+  const bool hd = lane < 28u, tr = (lane >= 32u) & (lane < 58u);
+  const uint8_t fb = frame[lane];
+  for (uint32_t j = j0; j < j1; j++) {
+    const long long pos = hd ? (long long)(rl64(c.p0, j) + lane) - B0s : (long long)(rl64(c.p1, j) - 26u + (lane - 32u)) - B0s;
+    if ((hd | tr) && pos >= -(long long)PEM_MARGIN && pos < (long long)(PEM_S + PEM_MARGIN)) obuf[(int32_t)pos + (int32_t)PEM_MARGIN] = fb;
   }
 }
 
@@ -256,106 +328,117 @@ __global__ void __launch_bounds__(64 * PEM_WAVES) k_pem_encode(const uint8_t* __
                                                               const uint32_t* __restrict__ block_first, uint64_t n_blocks,
                                                               uint64_t total, uint32_t a, uint8_t* __restrict__ out) {
   const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t* const abc = smem;           // the base64 alphabet, 64 bytes
-  uint8_t* const frame = smem + 64;    // 28 bytes "-----BEGIN CERTIFICATE-----\n", then 26 bytes "-----END CERTIFICATE-----\n" at +32
+  // static LDS (its address is a compile-time constant: a table behind the dynamic region's symbol cost one v_add per
+  // character): the base64 alphabet, then 28 bytes "-----BEGIN CERTIFICATE-----\n" at +64 and 26 bytes
+  // "-----END CERTIFICATE-----\n" at +96.  128 bytes: the dynamic region behind it stays 16-byte aligned.
+  __shared__ __attribute__((aligned(16))) uint8_t pem_tab[128];
+  uint8_t* const abc = pem_tab;
+  uint8_t* const frame = pem_tab + 64;
   if (threadIdx.x < 64u) {
     abc[threadIdx.x] = (uint8_t)b64_char(threadIdx.x);
   } else if (threadIdx.x < 128u) {
     const char* const H = "-----BEGIN CERTIFICATE-----\n";
     const char* const T = "-----END CERTIFICATE-----\n";
     const uint32_t t = threadIdx.x - 64u;
-    if (t < 28u) frame[t] = (uint8_t)H[t];
-    else if (t >= 32u && t < 58u) frame[t] = (uint8_t)T[t - 32u];
+    frame[t] = t < 28u ? (uint8_t)H[t] : (t >= 32u && t < 58u) ? (uint8_t)T[t - 32u] : (uint8_t)0;
   }
   __syncthreads();
-  uint8_t* const obuf = smem + PEM_LUT_BYTES + wv * PEM_WAVE_LDS;  // image of stream bytes [B0s − MARGIN, B0s + S + MARGIN)
+  uint8_t* const obuf = smem + wv * PEM_WAVE_LDS;  // image of stream bytes [B0s − MARGIN, B0s + S + MARGIN)
   uint8_t* const ibuf = obuf + PEM_OBUF;
+  uint32_t* const trash = (uint32_t*)(ibuf + PEM_IBUF) + lane;
   const uint64_t stride = (uint64_t)gridDim.x * PEM_WAVES;
   const auto bounds = [&](uint64_t b, long long& B0s, uint64_t& B0, uint64_t& B1) {
     B0s = (long long)(b * PEM_S) - (long long)a;  // out + B0s is 16-byte aligned
     B0 = B0s < 0 ? 0ull : (uint64_t)B0s;
     B1 = (uint64_t)(B0s + (long long)PEM_S) < total ? (uint64_t)(B0s + (long long)PEM_S) : total;
   };
+  const auto first_of = [&](uint64_t blk) { return (uint64_t)block_first[blk < n_blocks ? blk : n_blocks - 1u]; };
   // A block's work hangs off a chain of dependent loads: block → first certificate → the certificates' bounds → their
-  // bytes.  With one block at a time per wave the kernel waited on that chain (2.9 TB/s read + written, round 5's first
-  // build): the loop is software-pipelined — while block i is encoded, the BYTES of block i + 1 (its plan made from bounds
-  // that arrived an iteration ago) and the BOUNDS of block i + 2 (from a first-certificate index fetched an iteration ago)
-  // are on their way.  A block that one pass cannot serve (64 or more certificates in it, or more input chunks than the
-  // buffer holds: tiny certificates) is done on the spot, outside the pipeline.
+  // bytes.  While block i is encoded, the BYTES of block i + 1 (its plan made from bounds that arrived an iteration ago) and
+  // the BOUNDS of block i + 2 (from a first-certificate index fetched an iteration ago) are on their way.  A block that one
+  // pass cannot serve (more than 16 certificates in it: tiny ones) is done certificate by certificate, outside the pipeline.
   uint64_t b = (uint64_t)blockIdx.x * PEM_WAVES + wv;
   if (b >= n_blocks) return;
   long long B0s;
   uint64_t B0, B1;
   bounds(b, B0s, B0, B1);
-  const auto first_of = [&](uint64_t blk) { return (uint64_t)block_first[blk < n_blocks ? blk : n_blocks - 1u]; };
   uint64_t c_cur = first_of(b), c_nxt = first_of(b + stride), c_nx2 = first_of(b + 2u * stride);
   PemCert cc = pem_cert_load(pem_off, info, n_idx, c_cur + lane);
-  PemPlan pc = pem_plan(cc, B0, B1, lane);
-  bool simple = pc.ncert < 64u && __shfl(pc.pre, 63) <= PEM_IN_CHUNKS;
-  uint4 v[4];
+  PemPlan pc = pem_plan(cc, B0, B1);
+  uint64_t src[3];
+  uint4 v[3];
   uint32_t nflat = 0u;
-  if (simple && pc.ncert) nflat = pem_issue(payload, pc, 0u, pc.ncert, lane, v);
+  PemWork wk;
+  bool simple = pc.ncert <= PEM_FAST_CERTS && pem_assign(cc, pc, 0u, pc.ncert, B0s, lane, src, nflat, wk);
+  if (simple) pem_issue(payload, src, v);
   PemCert cn = pem_cert_load(pem_off, info, n_idx, c_nxt + lane);
   for (;;) {
-    if (!simple) {  // passes of up to 64 certificates, sub-passes of up to PEM_IN_CHUNKS input chunks
+    if (!simple) {  // certificate by certificate, in passes of 64 certificates
       uint64_t c_first = c_cur;
       for (;;) {
-        if (pc.ncert == 0u) break;
-        uint32_t done = 0u;
-        while (done < pc.ncert) {
-          const uint32_t base = done ? __shfl(pc.pre, (int)done - 1) : 0u;
-          uint32_t upto = done + (uint32_t)__popcll(__ballot(pc.inblk && lane >= done && pc.pre - base <= PEM_IN_CHUNKS));
-          upto = upto > done ? upto : done + 1u;  // (a single certificate never needs more than the buffer holds)
-          uint4 w[4];
-          const uint32_t nf = pem_issue(payload, pc, done, upto, lane, w);
-          pem_park(ibuf, w, nf, lane);
-          pem_encode_certs(cc, pc, done, upto, B0s, abc, frame, obuf, ibuf, lane);
+        for (uint32_t j = 0; j < pc.ncert; j++) {
+          uint64_t s1[3];
+          uint4 w1[3];
+          uint32_t nf;
+          PemWork w;
+          (void)pem_assign(cc, pc, j, j + 1u, B0s, lane, s1, nf, w);  // (one certificate's share of a block always fits a pass)
+          pem_issue(payload, s1, w1);
+          pem_park(ibuf, w1, nf, lane);
+          pem_encode_lines(w, abc, obuf, ibuf, trash);
+          if (w.any_task) pem_encode_tasks(w, abc, obuf, ibuf);
+          pem_frames(cc, j, j + 1u, B0s, frame, obuf, lane);
           __builtin_amdgcn_wave_barrier();
-          done = upto;
         }
         if (pc.ncert < 64u) break;
         c_first += 64u;
         cc = pem_cert_load(pem_off, info, n_idx, c_first + lane);
-        pc = pem_plan(cc, B0, B1, lane);
+        pc = pem_plan(cc, B0, B1);
       }
-    } else if (pc.ncert) {
+    } else {
       pem_park(ibuf, v, nflat, lane);
     }
     // ---- the bounds of the block after the next, then the next block's bytes: in flight while this block is encoded.  (In
     // this order: the bounds are copied into the loop's registers before the stores below are issued, and a wait for them
-    // then leaves the four byte loads — issued later — in flight.)
+    // then leaves the byte loads — issued later — in flight.)
     const PemCert cn2 = pem_cert_load(pem_off, info, n_idx, c_nx2 + lane);  // (past the last block: the last block's again, unused)
     const uint64_t c_nx3 = first_of(b + 3u * stride);
     const bool has_next = b + stride < n_blocks;
     long long N0s = 0;
     uint64_t N0 = 0, N1 = 0;
     PemPlan pn = pc;
+    PemWork wn = wk;
     bool simple_n = false;
     uint32_t nflat_n = 0u;
     if (has_next) {
       bounds(b + stride, N0s, N0, N1);
-      pn = pem_plan(cn, N0, N1, lane);
-      simple_n = pn.ncert < 64u && __shfl(pn.pre, 63) <= PEM_IN_CHUNKS;
-      if (simple_n && pn.ncert) nflat_n = pem_issue(payload, pn, 0u, pn.ncert, lane, v);
+      pn = pem_plan(cn, N0, N1);
+      simple_n = pn.ncert <= PEM_FAST_CERTS && pem_assign(cn, pn, 0u, pn.ncert, N0s, lane, src, nflat_n, wn);
+      if (simple_n) pem_issue(payload, src, v);
     }
-    // ---- this block: the tasks, then the image leaves as aligned 16-byte vectors (only the first and the last block of the
-    // stream have edges)
-    if (simple && pc.ncert) pem_encode_certs(cc, pc, 0u, pc.ncert, B0s, abc, frame, obuf, ibuf, lane);
+    // ---- this block: lines, last lines, framing lines; then the image leaves as aligned 16-byte vectors (only the first
+    // and the last block of the stream have edges)
+    if (simple) {
+      pem_encode_lines(wk, abc, obuf, ibuf, trash);
+      if (wk.any_task) pem_encode_tasks(wk, abc, obuf, ibuf);
+      pem_frames(cc, 0u, pc.ncert, B0s, frame, obuf, lane);
+    }
     __builtin_amdgcn_wave_barrier();
     const long long S0s = B0s;  // (this block's place: the loop's registers move on to the next block before the stores)
     const uint64_t S0 = B0, S1 = B1;
-    cc = cn; pc = pn; simple = simple_n; nflat = nflat_n;
+    cc = cn; pc = pn; wk = wn; simple = simple_n; nflat = nflat_n;
     cn = cn2;
     c_cur = c_nxt; c_nxt = c_nx2; c_nx2 = c_nx3;
     B0s = N0s; B0 = N0; B1 = N1;
-    if (S0s >= 0 && (uint64_t)S0s + PEM_S <= total) {  // an interior block: four whole-line stores, nothing to decide
+    if (S0s >= 0 && (uint64_t)S0s + PEM_S <= total) {  // an interior block: whole-line stores, nothing to decide
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        st_stream16((uint4*)(out + S0s) + 64 * q + lane, *(const uint4*)(obuf + PEM_MARGIN + 16u * (64u * q + lane)));
+        if (q < 3 || lane < 32u)
+          st_stream16((uint4*)(out + S0s) + 64 * q + lane, *(const uint4*)(obuf + PEM_MARGIN + 16u * (64u * q + lane)));
     } else {
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
         const long long ps = S0s + 16ll * (64 * q + (int)lane);
+        if (64u * q + lane >= PEM_S / 16u) continue;
         const uint4 vv = *(const uint4*)(obuf + PEM_MARGIN + 16u * (64u * q + lane));
         if (ps >= (long long)S0 && (uint64_t)ps + 16u <= S1) {
           st_stream16((uint4*)(out + ps), vv);
