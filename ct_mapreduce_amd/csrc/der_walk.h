@@ -1233,6 +1233,14 @@ CTMR_HD void note_issuer_if(R& r, uint32_t pos, uint32_t len) {
 // finding can matter (a precertificate, a Chain[0] issuer — an X509 entry keeps its certificate either way).
 // STRINGS = false compiles the check out: the map kernels carry it in instantiations of their own (the code's mere presence
 // cost the default kernel 0.5 ms per 100 M certificates, A/B on one box, round 4).
+// Measurement builds (scripts/run.sh attribution; never shipped): -DCTMR_EXP_STOP_AFTER=k ends the walk behind stage k — the
+// instruction stream up to there is the product's, the results are not.  1 serial  2 issuer Name  3 validity  4 subject Name
+// 5 SubjectPublicKeyInfo and key  6 unique ids and extensions  (7 = the whole walk).
+#ifdef CTMR_EXP_STOP_AFTER
+#define CTMR_STAGE(k) do { if constexpr ((CTMR_EXP_STOP_AFTER) <= (k)) return ok; } while (0)
+#else
+#define CTMR_STAGE(k) do { } while (0)
+#endif
 template <class R, bool TBS_ONLY = false, bool NAMES_ONLY = false, bool EC_DEFER = false, bool STRINGS = true>
 CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterView fv, bool spki = true, bool strings = false,
                        uint32_t ext_mode = 0u) {
@@ -1301,6 +1309,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     }
   }
   q = ce;
+  CTMR_STAGE(1);
   // signature AlgorithmIdentifier
   alg_id(r, L, q, tbs_end, ok, q);
   // issuer Name → last string-typed CommonName
@@ -1312,6 +1321,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     note_issuer_if(r, n0, q - n0);  // readers that look the Name up while it is at hand (the map kernel's memo pre-check)
     if (use_filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, fv) : false;
   }
+  CTMR_STAGE(2);
   r.touch(q, 48);
   // validity: two Times; anything behind them is ignored
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
@@ -1324,6 +1334,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     rd_time(r, L, c1, t1, e1 - c1, ok, o.not_after);
   }
   q = ce;
+  CTMR_STAGE(3);
   // subject Name: same structure, nothing of it is consumed
   {
 #ifdef CTMR_EXPERIMENT_SKIP_SUBJECT  // sweep builds only: what validating the subject costs (round 1 skipped it by length)
@@ -1337,6 +1348,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
 #endif
   }
   if constexpr (NAMES_ONLY) return ok;
+  CTMR_STAGE(4);
   // subjectPublicKeyInfo (full TLV = RawSubjectPublicKeyInfo): publicKeyInfo ::= SEQUENCE { AlgorithmIdentifier,
   // BIT STRING }; the key bits themselves are skipped by length.  A long subject (OV/EV certificates) puts this header
   // past the front window: say so, instead of leaving a window-only reader to its slow exact path.
@@ -1369,6 +1381,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     spki_key_finish<EC_DEFER>(r, L, key_alg, key_pending, ok, o.nonfatal, ecp);
     o.ec_curve = ecp.curve; o.ec_pos = ecp.pos; o.ec_shift = ecp.shift;
   }
+  CTMR_STAGE(5);
   // UniqueId, SubjectUniqueId asn1.BitString `optional,tag:1|2`, Extensions `optional,explicit,tag:3`: each parses the
   // header at the current position (which must be a valid header) and skips itself when the tag is not its own;
   // whatever is left in the TBSCertificate after the three is ignored.
@@ -1493,6 +1506,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
       e = x_end;
     }
   }
+  CTMR_STAGE(6);
   if constexpr (!TBS_ONLY) {
     // signatureAlgorithm, signatureValue BIT STRING (Go asn1 parseBitString); bytes behind them are ignored
     const TailView<R> tv{r};

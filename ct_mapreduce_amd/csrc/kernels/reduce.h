@@ -617,6 +617,10 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
       cert_range(a.offsets, a.ends, i, lo, hi);
       const uint32_t pos = (uint32_t)kp, curve = (uint32_t)(kp >> 32) & 7u, shift = (uint32_t)(kp >> 35) & 7u;
       const unsigned long long xbit = 8ull * (lo + pos) - shift;  // where X starts, as a bit position in the payload
+      // the entry's record, asked for NOW: it arrives while the equation is evaluated instead of costing a round trip of its
+      // own behind it (round 5)
+      uint4* rp = (uint4*)(records + i);
+      const uint4 r0 = rp[0], r1 = rp[1];
       bool good;
       if constexpr (P256) {
         good = ec_point_bits<CurveP256>((const uint32_t*)a.payload, xbit);
@@ -628,9 +632,7 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
           default: good = ec_point_bits<CurveP192>((const uint32_t*)a.payload, xbit); break;
         }
       }
-      uint4* rp = (uint4*)(records + i);
       if (!good) {  // x509.ParseCertificate fails: map_one's record of such a certificate
-        const uint4 r0 = rp[0];
         // (an entry the downloader had dropped already — entry_type CTMR_ENTRY_INVALID through ctmr_map_batch — stays that)
         const uint32_t stn = (r0.x & 0xffu) == CTMR_ST_ENTRY_DECODE_ERROR ? (uint32_t)CTMR_ST_ENTRY_DECODE_ERROR : (uint32_t)CTMR_ST_PARSE_ERROR;
         rp[0] = make_uint4(stn | (((r0.x >> 8) & CTMR_FL_PRECERT) << 8), 0u, r0.z, 0u);
@@ -648,7 +650,6 @@ __global__ void __launch_bounds__(256) k_ec_resolve(InsertArgs a, ctmr_record* r
       } else if (ent_state(e) != ES_PENDING) {  // filtered, without issuer, left for its owner, host-side serial: as the map said
         a.ent[i] = e & ~ENT_KEY_PENDING;
       } else {
-        const uint4 r0 = rp[0], r1 = rp[1];
         unsigned long long s[5];
         record_key(a, i, r0, r1, s);
         const unsigned long long meta = key_meta((int32_t)r0.y, e >> 8, r0.x >> 16);

@@ -6,7 +6,8 @@
 #   bench:NAME:ARGS…         python bench.py ARGS…            → NAME.json (+ .err); ARGS separated by ':' or ','
 #   lib:PATH                 export CTMR_LIB=PATH for the steps that follow (a sweep / experiment build); lib: resets it
 #   prof:NAME:ARGS…          rocprofv3 --kernel-trace --stats of bench.py ARGS… → NAME_kernel_stats.csv
-#   pmc:NAME:COUNTERS:ARGS…  one rocprofv3 --pmc pass per counter (comma list) of bench.py ARGS… → NAME_pmc.txt (per kernel sums)
+#   pmc:NAME:COUNTERS:ARGS…  rocprofv3 --pmc passes of bench.py ARGS… (',' separates passes, '+' joins the counters of one pass)
+#                            → NAME_pmc.txt (per kernel means)
 #   py:NAME:SCRIPT:ARGS…     python SCRIPT ARGS…              → NAME.txt      (fuzz campaigns, calibrations)
 #   env:K=V                  export K=V for the steps that follow
 #   hip:NAME:SRC:ARGS…       hipcc SRC (scripts/*.hip) && run it with ARGS → NAME.txt
@@ -40,8 +41,8 @@ for STEP in "$@"; do
           find $OUT/$NAME.kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${NAME}_kernel_stats.csv; rm -rf $OUT/$NAME.kt
           head -12 $OUT/${NAME}_kernel_stats.csv | cut -c1-180; python -c "$J" $OUT/$NAME.kt.log ;;
     pmc) CNT=${ARGS%%:*}; BARGS=${ARGS#*:}
-         for c in $(echo $CNT | tr ',' ' '); do
-           timeout 1500 rocprofv3 --pmc $c -d $OUT/$NAME.pmc/$c -o pmc --output-format csv -- python $R/bench.py $(split "$BARGS") > $OUT/$NAME.$c.log 2>&1
+         for c in $(echo $CNT | tr ',' ' '); do   # ',' separates passes, '+' joins counters of one pass (SQ: 8 slots, TCC: 4)
+           timeout 1500 rocprofv3 --pmc $(echo $c | tr '+' ' ') -d $OUT/$NAME.pmc/$c -o pmc --output-format csv -- python $R/bench.py $(split "$BARGS") > $OUT/$NAME.$c.log 2>&1
          done
          python $R/scripts/pmc_summary.py $OUT/$NAME.pmc > $OUT/${NAME}_pmc.txt 2>&1; rm -rf $OUT/$NAME.pmc; head -40 $OUT/${NAME}_pmc.txt ;;
     py) SCRIPT=${ARGS%%:*}; PARGS=${ARGS#*:}; [ "$PARGS" = "$ARGS" ] && PARGS=""

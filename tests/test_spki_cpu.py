@@ -350,3 +350,30 @@ def test_every_synthetic_key_decodes_in_openssl():
             c = orc.parse_cert(der)
             assert c.ok and c.nonfatal == 0 and harness.product_walk(der).ok
     assert 4000 < n_ec < 6000
+
+
+def test_p256_reduction_without_multiplications_against_python_integers():
+    """Round 5: the P-256 instantiation of the curve equation reduces with additions (p256_redc_step: −p⁻¹ ≡ 1 mod 2³², p's
+    limbs are 0 / ±1 / 2³² − 1).  Random and edge-case x with both roots y, a neighbour of y, a random y, and x + p — the
+    product's verdict (host build) against Python's integers."""
+    p = 2**256 - 2**224 + 2**192 + 2**96 - 1
+    b = 0x5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b
+    rng = random.Random(5)
+    specials = [0, 1, 2, p - 1, p - 2, 2**32 - 1, 2**224, 2**255, p - 2**96, 2**96 - 1, 2**192]
+    accepted = 0
+    for t in range(600):
+        x = specials[t] if t < len(specials) else (rng.getrandbits(256) % p if t % 3 else
+                                                  rng.choice([rng.getrandbits(32), p - rng.getrandbits(32) - 1,
+                                                              rng.getrandbits(256) & ((1 << 256) - (1 << 128))]) % p)
+        rhs = (x * x * x - 3 * x + b) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        on = (y * y) % p == rhs
+        for yy, want in ((y, on), (p - y if y else 0, on), ((y + 1) % p, None), (rng.getrandbits(256) % p, None)):
+            want = ((yy * yy) % p == rhs) if want is None else want
+            buf = bytes(7) + x.to_bytes(32, "big") + yy.to_bytes(32, "big") + bytes(16)
+            assert harness.product_ec_point_bits(buf, 56, 1) == want, (hex(x), hex(yy), want)
+            accepted += want
+        if x + p < 2**256:                                            # a coordinate that is not reduced: elliptic.Unmarshal refuses it
+            buf = bytes(7) + (x + p).to_bytes(32, "big") + y.to_bytes(32, "big") + bytes(16)
+            assert not harness.product_ec_point_bits(buf, 56, 1)
+    assert accepted > 400
