@@ -488,6 +488,11 @@ class WriteBack:
         out = {"backend": "LocalDiskBackend" if self.disk else "NoopBackend", "new_certificates": self.new_total,
                "files_handed_to_the_backend": self.files, "long_serials_left_to_the_host_parse": self.skipped,
                "pem_bytes": self.pem_bytes, "pem_GB_per_s_of_the_encode_kernels": self.pem_bytes / max(self.t_pem, 1e-9) / 1e9,
+               # what the PEM calls move: the DER they read (recovered from the PEM size: 54 framing bytes per certificate, 65 output
+               # bytes per 48 input bytes; exact to the padding) plus the PEM they write, over the calls' wall time (k_pem_len,
+               # the scan, k_pem_blocks and k_pem_encode of every chunk) against the 8 TB/s HBM peak
+               "pem_read_plus_written_GB_per_s": (self.pem_bytes + (self.pem_bytes - 54 * self.new_total) * 48 / 65) / max(self.t_pem, 1e-9) / 1e9,
+               "pem_frac_of_hbm_peak": (self.pem_bytes + (self.pem_bytes - 54 * self.new_total) * 48 / 65) / max(self.t_pem, 1e-9) / 1e9 / HBM_PEAK_GBPS,
                "ms_meta_total": self.t_meta * 1e3, "ms_pem_total": self.t_pem * 1e3,
                "meta_first_sightings": self.meta_items, "ok": bool(ok)}
         if self.disk:

@@ -903,6 +903,61 @@ CTMR_HD void ext_san_check(R& r, uint32_t L, uint32_t cv, uint32_t ev, bool& ok,
   }
 }
 
+// The same walk for readers with a wave-cooperative refill (the map kernels' LDS windows), called BEHIND the extension loop,
+// where the lanes of the wave are together again: a subjectAltName is 0.5–1 KB, two to four windows — met inside the loop,
+// every lane refilled its own window whenever IT ran out (≈ 14 refill events of 16 loads per wave, measured: VMEM_RD 42 →
+// 265 instructions per wave, round 5's first build).  Here all lanes still walking refill together, 16 lanes per
+// certificate, once per round; between refills a lane hops from header to header inside its window.  [cv, ev) = the
+// value (ev = 0: this certificate has no subjectAltName).
+template <class R, class = void>
+struct has_coop_refill : std::false_type {};
+template <class R>
+struct has_coop_refill<R, std::void_t<decltype(std::declval<R&>().coop_refill(0u, false))>> : std::true_type {};
+template <class R>
+CTMR_HD void ext_san_coop(R& r, uint32_t L, uint32_t cv, uint32_t ev, bool& ok, uint32_t& nf) {
+  if (!R::whole_wave()) {  // the batch's last wave: lane by lane
+    if (cv < ev) ext_san_check(r, L, cv, ev, ok, nf);
+    return;
+  }
+  bool act = ok & (cv < ev), first = true;
+  uint32_t p = cv;
+  for (;;) {
+    const bool want = act & (p < ev);
+    if (!R::any_lane(want)) break;  // (wave-uniform)
+    r.coop_refill(p, want);
+    if (want) {
+      if (first) {  // one element filling the value: a universal constructed SEQUENCE
+        uint32_t t, c, ce;
+        rd_hdr(r, L, cv, ev, ok, t, c, ce);
+        ok = ok & (ce == ev) & (t == 0x30u);
+        p = c;
+        first = false;
+      }
+      while (ok & (p < ev) && r.holds(p, 16u)) {
+        const uint32_t w = r.ld4(p);
+        const uint32_t tg = w & 0xffu, lb = (w >> 8) & 0xffu;
+        uint32_t x, xe;
+        if (((tg & 0x1fu) != 0x1fu) & (lb < 0x80u)) {
+          x = p + 2u;
+          xe = x + lb;
+          ok = ok & (xe <= ev);
+        } else {
+          uint32_t t2;
+          rd_hdr(r, L, p, ev, ok, t2, x, xe);
+        }
+        const uint32_t tn = tg & 0x1fu;
+        nf = (ok & (tn == 7u) & (xe - x != 4u) & (xe - x != 16u)) ? (nf | WALK_NF_EXT) : nf;
+        if (ok & (tn == 6u)) {  // a URI's contents: the exact reader's business (see above) — or a reader that reaches anywhere
+          if constexpr (has_defer_exact<R>::value) r.defer_exact();
+          else ok = san_uri_ok(Octets<R>{r, L, x}, xe - x);
+        }
+        p = xe;
+      }
+      act = ok;
+    }
+  }
+}
+
 // cRLDistributionPoints: [cv, ev) = the extension's value, []distributionPoint by encoding/asn1's struct rules — fields in
 // order, each preceded by a header that must parse unless the contents are used up, a field of another tag skipped, a
 // matching field must fit, what follows the last field ignored.
@@ -1386,6 +1441,8 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // header at the current position (which must be a valid header) and skips itself when the tag is not its own;
   // whatever is left in the TBSCertificate after the three is ignored.
   uint32_t nt = 0u;
+  uint32_t san_cv = 0u, san_ev = 0u;  // strict_extensions, cooperative readers: the subjectAltName's value, walked behind the loop
+  (void)san_cv; (void)san_ev;
   if (ok & (q < tbs_end)) {
     rd_hdr<false>(r, L, q, tbs_end, ok, tag, cs, ce);
     nt = ok ? tag : 0u;
@@ -1462,7 +1519,12 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
           if ((kind >= 1u) & (kind <= 6u)) {
             ext_body_check(r, L, kind, cv, ev, ok);
           } else if (kind == 7u) {
-            ext_san_check(r, L, cv, ev, ok, o.nonfatal);
+            if constexpr (has_coop_refill<R>::value) {  // walked behind the loop, by the whole wave (ext_san_coop)
+              if ((san_ev == 0u) & (ev > cv)) { san_cv = cv; san_ev = ev; }
+              else ext_san_check(r, L, cv, ev, ok, o.nonfatal);  // an empty value (an error), or a second subjectAltName
+            } else {
+              ext_san_check(r, L, cv, ev, ok, o.nonfatal);
+            }
           } else if (kind == 9u) {
             uint32_t uo[1] = {0u}, ul[1] = {0u}, nu = 0u;
             r.touch(cv, ev - cv < 200u ? ev - cv : 200u);
@@ -1505,6 +1567,9 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
       }
       e = x_end;
     }
+  }
+  if constexpr (STRINGS && has_coop_refill<R>::value) {
+    if (ext) ext_san_coop(r, L, san_cv, ok ? san_ev : 0u, ok, o.nonfatal);
   }
   CTMR_STAGE(6);
   if constexpr (!TBS_ONLY) {

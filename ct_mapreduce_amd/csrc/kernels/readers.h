@@ -82,6 +82,26 @@ __device__ __forceinline__ void coop_fill(const uint8_t* payload, uint64_t limit
 #endif
 }
 
+// The same for SOME windows (der_walk.h ext_san_coop: the lanes still walking a subjectAltName): a lane whose g_me is ~0
+// keeps its window as it is.
+__device__ __forceinline__ void coop_refill_some(const uint8_t* payload, uint64_t limit, uint64_t g_me, uint32_t lane) {
+  const uint32_t sub = lane & 15u;
+  uint4 v[16];
+  unsigned take = 0u;
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
+    const uint64_t at = g + 16u * sub;
+    take |= (g != ~0ull ? 1u : 0u) << it;
+    v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(payload + at)) : make_uint4(0, 0, 0, 0);
+  }
+  __builtin_amdgcn_wave_barrier();  // every lane is done reading the old contents
+#pragma unroll
+  for (int it = 0; it < 16; it++)
+    if ((take >> it) & 1u) *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + 16u * sub) = v[it];
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------ byte readers
 // ld4(pos): 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
 struct GlobalReader {
@@ -169,6 +189,18 @@ struct WinReaderC : WinReader<WCH> {
     this->grel = (int32_t)(int64_t)(g_me - this->base);
     coop_fill<true>((const uint8_t*)this->g32, this->limit, g_me, threadIdx.x & 63u);
   }
+  // der_walk.h ext_san_coop — wave-collective (every lane of a WHOLE wave calls it from converged code): the lanes that
+  // `want` get their window refilled at pos, 16 lanes per certificate as above; the others keep theirs.
+  __device__ __forceinline__ void coop_refill(uint32_t pos, bool want) {
+    const uint64_t g_me = want ? (this->base + pos) & ~15ull : ~0ull;
+    if (want) this->grel = (int32_t)(int64_t)(g_me - this->base);
+    coop_refill_some((const uint8_t*)this->g32, this->limit, g_me, threadIdx.x & 63u);
+  }
+  __device__ __forceinline__ bool holds(uint32_t pos, uint32_t need) const {  // [pos, pos + need) lies in the window
+    return pos - (uint32_t)this->grel <= WinReader<WCH>::WBYTES - need;
+  }
+  static __device__ __forceinline__ bool whole_wave() { return __ballot(1) == ~0ull; }
+  static __device__ __forceinline__ bool any_lane(bool x) { return __ballot(x) != 0ull; }
 };
 
 // WinReaderC whose ld4() is served by the LDS window ALONE: no per-access "outside the window → global load"

@@ -62,11 +62,14 @@ def key_class(der, o):
 
 
 MODELLED_EXTENSIONS = ("keyUsage", "subjectKeyIdentifier", "extKeyUsage", "authorityKeyIdentifier", "certificatePolicies",
-                       "authorityInfoAccess")
+                       "authorityInfoAccess",
+                       "subjectAltName", "crlDistributionPoints", "nameConstraints", "ctPrecertSCTs")   # round 5
 
 
 def seeds():
     out = [(s, "edge") for s in edge_seeds()] * 4 + [(s, "key") for s in key_seeds()] * 3
+    from tests.test_ext_cpu import rich_seeds       # round 5: every extension body strict_extensions looks into
+    out += [(s, "ext") for s in rich_seeds()] * 12
     for s_, prof in ((201, 0), (202, 1)):
         cfg = synth.config(seed=s_, n_issuers=8, ca_permille=150, expired_permille=50, profile=prof)
         out += [(synth.leaf(cfg, i)[0], "synth%d" % prof) for i in range(40)]
@@ -105,12 +108,18 @@ def bucket_of(der, o, v):
         if hit and stage.startswith("ext:") and stage.split(":")[1] in MODELLED_EXTENSIONS:
             # strict_extensions (opt-in) restates Go's rule for this extension: say which side of it the mutant lies on
             if o.ext_fatal:
-                hit = (hit[0] + " / fails Go's struct rules", "modelled",
+                hit = (hit[0] + " / fails Go's rules", "modelled",
                        "the value breaks the rule Go's parseCertificate applies to this extension (one BIT STRING / OCTET STRING, "
-                       "SEQUENCE OF OID, SEQUENCE OF SEQUENCE { OID, … }, no trailing data): ctmr_set_strict_extensions rejects it too, "
-                       "as a fatal parse error (opt-in, like the string rules: what CT-go's fork makes of it is not verifiable here)")
+                       "SEQUENCE OF OID, SEQUENCE OF SEQUENCE { OID, … }, the distributionPoint struct, forEachSAN + url.Parse, the "
+                       "cryptobyte reading of nameConstraints; no trailing data): ctmr_set_strict_extensions / CTMR_PROFILE_REFERENCE "
+                       "rejects it too, as a fatal parse error (what CT-go's fork makes of it is not verifiable here: hence a profile)")
+            elif o.ext_findings:
+                hit = (hit[0] + " / a non-fatal finding", "modelled",
+                       "what CT-go files as a NON-fatal finding inside the value (an iPAddress of another length than 4 or 16, an "
+                       "SCT list that does not decode, an INTEGER only the lax parser takes): under strict_extensions an X509 entry "
+                       "keeps its certificate, a precertificate and a Chain[0] issuer are dropped")
             else:
-                hit = (hit[0] + " / passes Go's struct rules", "openssl",
+                hit = (hit[0] + " / passes Go's rules", "openssl",
                        "the value satisfies the struct rules Go applies (what follows a policy's OID, the contents of a GeneralName or "
                        "of a key identifier are not looked at by encoding/asn1): OpenSSL's extension decoders go deeper")
         raw = "%s | %s %s" % (stage, r, sub)

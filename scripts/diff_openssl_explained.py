@@ -3,7 +3,8 @@ and OpenSSL 3, who is closer to Go's crypto/x509 + encoding/asn1 as certificate-
 what this repository does about it.  `status` is one of
     go-rule      the oracle follows a Go rule (recalled) that OpenSSL does not have — nothing to do
     modelled     … and the rule sits behind a switch (named)
-    looser       the oracle accepts what Go would also reject: a gap, listed in DESIGN.md §3.1 ("still not checked")
+    looser       the oracle accepts what Go would also reject: a gap (round 4: the bodies of subjectAltName, cRLDistributionPoints,
+                 nameConstraints; round 5: none left)
     openssl      an OpenSSL-only rule (or an OpenSSL leniency) with no counterpart in Go
 """
 import re
@@ -46,8 +47,13 @@ A_RULES = [
      "validity time with a numeric zone whose hours are above 23 (…+8100): time.Parse of the Go 1.13 toolchain does not range-check the zone's hours and Format prints them back, so the serialise-back test passes (DESIGN §3.1); OpenSSL's ASN1_TIME_check refuses it"),
     ("extbc", r"", "go-rule",
      "basicConstraints IS modelled, by Go's struct rules: `struct { IsCA bool optional; MaxPathLen int optional }` — an element of another type leaves the optional field at its default and whatever follows inside the SEQUENCE is ignored (DESIGN §3.1); OpenSSL's BASIC_CONSTRAINTS template wants BOOLEAN then INTEGER and nothing else"),
-    ("ext", r"", "looser",
-     "the BODY of an extension other than basicConstraints is malformed.  crypto/x509 parses keyUsage, subjectAltName, nameConstraints, cRLDistributionPoints, authorityKeyIdentifier, extKeyUsage, subjectKeyIdentifier, certificatePolicies and authorityInfoAccess and fails on a malformed one (which of these CT-go downgrades to non-fatal is not recoverable here); the walk skips those bodies by length — 0.5–1 KB per certificate it never fetches.  Listed in DESIGN §3.1 as not checked; extensions Go has no parser for are in this bucket only because OpenSSL has one"),
+    ("ext", r"", "go-rule",
+     "the BODY of an extension Go 1.13's parseCertificate has no case for (issuerAltName, policyMappings, policyConstraints, "
+     "inhibitAnyPolicy, the Netscape extensions, …) is malformed: Go does not look into it (the extension is 'unhandled', which only "
+     "matters to Verify when it is critical) — OpenSSL has a decoder for it.  The extensions Go DOES parse — keyUsage, subjectAltName, "
+     "nameConstraints, cRLDistributionPoints, authorityKeyIdentifier, extKeyUsage, subjectKeyIdentifier, certificatePolicies, "
+     "authorityInfoAccess, CT-go's SCT list — are restated behind strict_extensions / CTMR_PROFILE_REFERENCE and land in the "
+     "'modelled' buckets (round 5: no 'looser' bucket is left)"),
 ]
 
 # ---- direction B: the oracle REJECTS, OpenSSL accepts.  oracle error site name → (status, text)

@@ -23,7 +23,7 @@ except Exception as e:
     print("no JSON line:", e); sys.exit(0)
 r=d.get("roofline",{})
 print({k:d.get(k) for k in ("value","ms_per_step","n_gpus")}, "map_ms", d.get("kernel_ms",{}).get("map"), "frac", r.get("frac"), "alg", r.get("frac_algorithmic"),
-      "checks", d.get("checks"), "parity", (d.get("parity_vs_oracle_on_sample") or {}).get("mismatches"))
+      "checks", d.get("checks"), "parity", d.get("parity_vs_oracle_on_sample"), (d.get("parity_sample") or {}).get("entries_checked_all_ranks"))
 for k,v in (d.get("secondary") or {}).items(): print("  secondary", k, {x:v.get(x) for x in ("value","ms_per_step","map_ms","frac","traffic_bytes_per_cert","error","same_results_as_the_fast_profile")})
 for k in ("pem","stream","write_back","exchange"):
     if k in d: print("  ",k,d[k])'
