@@ -36,31 +36,39 @@ struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };  // una
 
 // ------------------------------------------------------------------ k_pem_encode (round 5: output-block design)
 // The PEM blocks of the NEW list are ONE contiguous byte stream (pem_off is an exclusive scan), so the work is cut by
-// OUTPUT bytes, not by certificate: one wave produces one 3.5 KiB block of the stream at a time — whatever certificates
+// OUTPUT bytes, not by certificate: one wave produces one 7 KiB block of the stream at a time — whatever certificates
 // and parts of certificates lie in it — and every global access is a naturally aligned 16-byte vector covering whole
 // 128-byte lines:
 //   1. lane j fetches the bounds of the j-th certificate that overlaps the block (k_pem_blocks left the first one's
 //      index per block, k_pem_len its place in the payload) and works out which of its base64 LINES fall into the block;
-//   2. the input bytes of those lines (≤ 3 KiB, contiguous per certificate) come in as aligned, non-temporal 16-byte
+//   2. the input bytes of those lines (≤ 5.5 KiB, contiguous per certificate) come in as aligned, non-temporal 16-byte
 //      loads, 1 KiB per instruction, and are parked in LDS;
-//   3. ONE LANE ENCODES ONE LINE: 48 bytes from LDS (aligned dword reads + v_alignbyte), sixteen v_perm_b32 make the
+//   3. ONE LANE ENCODES ONE LINE (two of them per block: lines lane and 64 + lane): 48 bytes from LDS (aligned dword reads + v_alignbyte), sixteen v_perm_b32 make the
 //      big-endian 24-bit groups, the 64 characters come from the 64-byte alphabet in LDS (one v_bfe + one ds_read_u8 per
 //      character; sixteen dwords in sixteen banks: conflict-free) and go to the block's image in LDS at their final
 //      stream position — a line is 65 bytes, so every line sits at another alignment: sixteen v_alignbyte shift it onto
 //      aligned dwords, the two ends and the line end are byte stores.  A certificate's last, shorter line is encoded
 //      apart, by up to four lanes in 12-byte → 16-character tasks (whatever they write past the line's end lands in the
 //      END line's place, which is written afterwards), and so are the two framing lines;
-//   4. the image leaves as 224 aligned, non-temporal 16-byte stores.
+//   4. the image leaves as 448 aligned, non-temporal 16-byte stores.
 // The loop over a wave's blocks is software-pipelined: while block i is encoded, the BYTES of block i + 1 and the BOUNDS of
 // block i + 2 are in flight.
 // History (profiles/r05/pem_*): round 4's kernel — one wave per certificate, unaligned dwordx3 loads, 16-byte stores at
 // a 65-byte pitch that never meet a sector boundary, a byte store per line end, ≈ 9 VALU instructions per character for
 // the alphabet — 3.4 TB/s read + written.  The block design with one lane per 12-byte task: 2.9 TB/s unpipelined, 3.1
 // pipelined, 3.4 with a conflict-free alphabet table — and the counters said why: 935 vector instructions and 202 LDS
-// instructions per 4 KiB block, the vector ALU 80 % busy.  One lane per line cuts both by more than half.
-constexpr uint32_t PEM_S = 3584;              // output bytes per block: ≈ 55 lines, so that one lane per line fits one pass
+// instructions per 4 KiB block, the vector ALU 80 % busy.  One lane per line cuts both by more than half (580 vector
+// instructions per 3.5 KiB block, of which the lines themselves are 190: the rest is per-block bookkeeping — bounds, plan,
+// assignment, last lines, framing lines); two lines per lane and 7 KiB blocks pay that bookkeeping once for twice the
+// bytes: 13.9 → 12.7 ms on 16 M certificates, at 12 instead of 16 waves per CU (163 VGPRs, 13 KB of LDS per wave).
+#ifndef CTMR_PEM_LPL
+#define CTMR_PEM_LPL 2
+#endif
+constexpr uint32_t PEM_LPL = CTMR_PEM_LPL;    // base64 lines per lane and block: the per-block bookkeeping is paid once for them
+constexpr uint32_t PEM_S = 3584 * PEM_LPL;    // output bytes per block: ≈ 55 lines per 3584 bytes, so that one lane per line fits
 constexpr uint32_t PEM_MARGIN = 80;           // a line that straddles a block edge is encoded whole by both blocks
-constexpr uint32_t PEM_IN_CHUNKS = 192;       // 16-byte input chunks parked per pass
+constexpr uint32_t PEM_NQ = PEM_LPL == 1 ? 3 : 6;                // 16-byte input loads per lane and block
+constexpr uint32_t PEM_IN_CHUNKS = PEM_LPL == 1 ? 192 : 352;     // 16-byte input chunks parked per pass
 constexpr uint32_t PEM_LUT_BYTES = 64 + 64;   // the alphabet + the two framing lines
 constexpr uint32_t PEM_OBUF = PEM_S + 2 * PEM_MARGIN;
 constexpr uint32_t PEM_IBUF = PEM_IN_CHUNKS * 16 + 64;
@@ -106,9 +114,9 @@ struct PemPlan {
 // what a lane does in a block: its line (lines), its task of some certificate's last line (tasks); ib / ob: where the
 // certificate's byte 0 lies in ibuf, its first base64 character in obuf
 struct PemWork {
-  uint32_t ln, l_ib;
-  int32_t l_ob;
-  bool l_act;
+  uint32_t ln[PEM_LPL], l_ib[PEM_LPL];
+  int32_t l_ob[PEM_LPL];
+  bool l_act[PEM_LPL];
   uint32_t tk, t_ib, t_len, t_nq;
   int32_t t_ob;
   bool t_act, any_task;
@@ -160,21 +168,26 @@ __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t j) {
 __device__ __forceinline__ uint32_t gather32(uint32_t v, uint32_t from) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
 
 // Certificates [j0, j1) of a plan: hands every lane its input chunks (src[q]: payload offset of flat chunk 64·q + lane, ~0 =
-// none), its line and its task, and says whether one pass can take them (≤ 192 chunks, ≤ 64 lines, ≤ 16 certificates).  A
+// none), its lines and its task, and says whether one pass can take them (≤ 352 chunks, ≤ 128 lines, ≤ 16 certificates).  A
 // scalar loop over the certificates (three counts each, v_readlane) tells every lane WHICH certificate owns its chunk, its
 // line, its task; what it needs of that certificate it then fetches from the certificate's lane (ds_bpermute) — selecting
 // every value inside the loop cost ≈ 40 vector instructions per certificate.
 __device__ __forceinline__ bool pem_assign(const PemCert& c, const PemPlan& p, uint32_t j0, uint32_t j1, long long B0s, uint32_t lane,
-                                           uint64_t (&src)[3], uint32_t& nflat, PemWork& w) {
-  uint32_t cown[3] = {64u, 64u, 64u}, lown = 64u;  // owner lanes; 64 = none (a bpermute from lane 64 reads lane 0: unused)
+                                           uint64_t (&src)[PEM_NQ], uint32_t& nflat, PemWork& w) {
+  uint32_t cown[PEM_NQ], lown[PEM_LPL];  // owner lanes; 64 = none (a bpermute from lane 64 reads lane 0: unused)
+#pragma unroll
+  for (uint32_t q = 0; q < PEM_NQ; q++) cown[q] = 64u;
+#pragma unroll
+  for (uint32_t l = 0; l < PEM_LPL; l++) lown[l] = 64u;
   uint32_t my_cbase = 0u, my_lbase = 0u, cbase = 0u, lbase = 0u;
   bool any_task = false;
   for (uint32_t j = j0; j < j1; j++) {
     const uint32_t nch = rl32(p.nch, j), nfl = rl32(p.nfl, j);
     any_task = any_task | (rl32(p.ntk, j) != 0u);
 #pragma unroll
-    for (int q = 0; q < 3; q++) cown[q] = (64u * q + lane - cbase) < nch ? j : cown[q];
-    lown = (lane - lbase) < nfl ? j : lown;
+    for (uint32_t q = 0; q < PEM_NQ; q++) cown[q] = (64u * q + lane - cbase) < nch ? j : cown[q];
+#pragma unroll
+    for (uint32_t l = 0; l < PEM_LPL; l++) lown[l] = (64u * l + lane - lbase) < nfl ? j : lown[l];
     my_cbase = lane == j ? cbase : my_cbase;
     my_lbase = lane == j ? lbase : my_lbase;
     cbase += nch;
@@ -184,15 +197,22 @@ __device__ __forceinline__ bool pem_assign(const PemCert& c, const PemPlan& p, u
   const uint32_t my_ib = 16u * my_cbase + (uint32_t)(c.lo - p.a0);  // (wraps below zero when ln_lo > 0: 48·ln brings it back)
   const int32_t my_ob = (int32_t)((long long)(c.p0 + 28u) - B0s) + (int32_t)PEM_MARGIN;
 #pragma unroll
-  for (int q = 0; q < 3; q++) {
+  for (uint32_t q = 0; q < PEM_NQ; q++) {
     const uint32_t o = cown[q];
     const uint64_t a0 = (uint64_t)gather32((uint32_t)p.a0, o) | ((uint64_t)gather32((uint32_t)(p.a0 >> 32), o) << 32);
-    src[q] = o < 64u ? a0 + 16ull * (64u * q + lane - gather32(my_cbase, o)) : ~0ull;
+    // (every gather in a statement of its own: inside the conditional expression it runs under the mask "has an owner", and
+    //  ds_bpermute returns 0 for a source lane that is masked off — the owner's lane, when the row's last chunks are few)
+    const uint32_t ocb = gather32(my_cbase, o);
+    src[q] = o < 64u ? a0 + 16ull * (64u * q + lane - ocb) : ~0ull;
   }
-  w.l_act = lown < 64u;
-  w.ln = gather32(p.ln_lo, lown) + (lane - gather32(my_lbase, lown));
-  w.l_ib = gather32(my_ib, lown);
-  w.l_ob = (int32_t)gather32((uint32_t)my_ob, lown);
+#pragma unroll
+  for (uint32_t l = 0; l < PEM_LPL; l++) {
+    const uint32_t o = lown[l];
+    w.l_act[l] = o < 64u;
+    w.ln[l] = gather32(p.ln_lo, o) + (64u * l + lane - gather32(my_lbase, o));
+    w.l_ib[l] = gather32(my_ib, o);
+    w.l_ob[l] = (int32_t)gather32((uint32_t)my_ob, o);
+  }
   const uint32_t town = j0 + (lane >> 2);  // four task lanes per certificate
   const uint32_t ntk = gather32(p.ntk, town);
   w.t_act = (town < j1) & ((lane & 3u) < ntk);
@@ -203,20 +223,20 @@ __device__ __forceinline__ bool pem_assign(const PemCert& c, const PemPlan& p, u
   w.t_nq = gather32(p.nq, town);
   w.any_task = any_task;
   nflat = cbase < PEM_IN_CHUNKS ? cbase : PEM_IN_CHUNKS;
-  return cbase <= PEM_IN_CHUNKS && lbase <= 64u && j1 - j0 <= PEM_FAST_CERTS;
+  return cbase <= PEM_IN_CHUNKS && lbase <= 64u * PEM_LPL && j1 - j0 <= PEM_FAST_CERTS;
 }
 
 // aligned, non-temporal 16-byte loads, 1 KiB per instruction; v[q] = flat chunk 64·q + lane
-__device__ __forceinline__ void pem_issue(const uint8_t* __restrict__ payload, const uint64_t (&src)[3], uint4 (&v)[3]) {
+__device__ __forceinline__ void pem_issue(const uint8_t* __restrict__ payload, const uint64_t (&src)[PEM_NQ], uint4 (&v)[PEM_NQ]) {
 #pragma unroll
-  for (int q = 0; q < 3; q++)
+  for (uint32_t q = 0; q < PEM_NQ; q++)
     v[q] = src[q] != ~0ull ? ld_payload16((const uint4*)(payload + src[q])) : make_uint4(0, 0, 0, 0);
 }
 
-__device__ __forceinline__ void pem_park(uint8_t* ibuf, const uint4 (&v)[3], uint32_t nflat, uint32_t lane) {
+__device__ __forceinline__ void pem_park(uint8_t* ibuf, const uint4 (&v)[PEM_NQ], uint32_t nflat, uint32_t lane) {
 #pragma unroll
-  for (int q = 0; q < 3; q++)
-    if (64u * q < nflat) ((uint4*)ibuf)[64u * q + lane] = v[q];
+  for (uint32_t q = 0; q < PEM_NQ; q++)
+    if (64u * q < nflat && 64u * q + lane < PEM_IN_CHUNKS) ((uint4*)ibuf)[64u * q + lane] = v[q];
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -228,10 +248,10 @@ __device__ __forceinline__ uint32_t pem_enc4(const uint8_t* abc, uint32_t g) {  
 }
 
 // the whole lines: one lane, one line
-__device__ __forceinline__ void pem_encode_lines(const PemWork& w, const uint8_t* abc, uint8_t* obuf, const uint8_t* ibuf,
-                                                 uint32_t* trash) {
-  if (!w.l_act) return;
-  const uint32_t at = w.l_ib + 48u * w.ln, m = at & 3u;
+__device__ __forceinline__ void pem_encode_line(bool act, uint32_t ln, uint32_t l_ib, int32_t l_ob, const uint8_t* abc, uint8_t* obuf,
+                                                const uint8_t* ibuf, uint32_t* trash) {
+  if (!act) return;
+  const uint32_t at = l_ib + 48u * ln, m = at & 3u;
   const uint32_t* x = (const uint32_t*)(ibuf + (at & ~3u));
   uint32_t r[13];
 #pragma unroll
@@ -250,7 +270,7 @@ __device__ __forceinline__ void pem_encode_lines(const PemWork& w, const uint8_t
   ch[16] = 0x0au;
   // the 64 characters and the line end at stream position P (body byte 65·ln): with s = P mod 4, aligned dword k of the
   // line is alignbyte(ch[k], ch[k − 1], 4 − s) — for s = 0 that is ch[k − 1], which belongs one dword earlier: the base moves
-  const int32_t P = w.l_ob + (int32_t)(65u * w.ln);
+  const int32_t P = l_ob + (int32_t)(65u * ln);
   uint8_t* const o = obuf + P;
   const uint32_t s = (uint32_t)P & 3u, sh = (4u - s) & 3u;
   uint32_t* const A = (uint32_t*)(o - s - (s ? 0u : 4u));
@@ -265,6 +285,11 @@ __device__ __forceinline__ void pem_encode_lines(const PemWork& w, const uint8_t
     o[front ? t4 : 60u + t4] = (uint8_t)((front ? ch[0] : ch[15]) >> (8u * t4));
   }
   o[64] = (uint8_t)'\n';
+}
+__device__ __forceinline__ void pem_encode_lines(const PemWork& w, const uint8_t* abc, uint8_t* obuf, const uint8_t* ibuf,
+                                                 uint32_t* trash) {
+#pragma unroll
+  for (uint32_t l = 0; l < PEM_LPL; l++) pem_encode_line(w.l_act[l], w.ln[l], w.l_ib[l], w.l_ob[l], abc, obuf, ibuf, trash);
 }
 
 // the shorter last lines: one lane, one 12-byte → 16-character task
@@ -365,8 +390,8 @@ __global__ void __launch_bounds__(64 * PEM_WAVES) k_pem_encode(const uint8_t* __
   uint64_t c_cur = first_of(b), c_nxt = first_of(b + stride), c_nx2 = first_of(b + 2u * stride);
   PemCert cc = pem_cert_load(pem_off, info, n_idx, c_cur + lane);
   PemPlan pc = pem_plan(cc, B0, B1);
-  uint64_t src[3];
-  uint4 v[3];
+  uint64_t src[PEM_NQ];
+  uint4 v[PEM_NQ];
   uint32_t nflat = 0u;
   PemWork wk;
   bool simple = pc.ncert <= PEM_FAST_CERTS && pem_assign(cc, pc, 0u, pc.ncert, B0s, lane, src, nflat, wk);
@@ -377,8 +402,8 @@ __global__ void __launch_bounds__(64 * PEM_WAVES) k_pem_encode(const uint8_t* __
       uint64_t c_first = c_cur;
       for (;;) {
         for (uint32_t j = 0; j < pc.ncert; j++) {
-          uint64_t s1[3];
-          uint4 w1[3];
+          uint64_t s1[PEM_NQ];
+          uint4 w1[PEM_NQ];
           uint32_t nf;
           PemWork w;
           (void)pem_assign(cc, pc, j, j + 1u, B0s, lane, s1, nf, w);  // (one certificate's share of a block always fits a pass)
@@ -431,12 +456,12 @@ __global__ void __launch_bounds__(64 * PEM_WAVES) k_pem_encode(const uint8_t* __
     B0s = N0s; B0 = N0; B1 = N1;
     if (S0s >= 0 && (uint64_t)S0s + PEM_S <= total) {  // an interior block: whole-line stores, nothing to decide
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (q < 3 || lane < 32u)
+      for (uint32_t q = 0; q < (PEM_S + 1023u) / 1024u; q++)
+        if (64u * (q + 1u) <= PEM_S / 16u || 64u * q + lane < PEM_S / 16u)
           st_stream16((uint4*)(out + S0s) + 64 * q + lane, *(const uint4*)(obuf + PEM_MARGIN + 16u * (64u * q + lane)));
     } else {
 #pragma unroll 1
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < (int)((PEM_S + 1023u) / 1024u); q++) {
         const long long ps = S0s + 16ll * (64 * q + (int)lane);
         if (64u * q + lane >= PEM_S / 16u) continue;
         const uint4 vv = *(const uint4*)(obuf + PEM_MARGIN + 16u * (64u * q + lane));

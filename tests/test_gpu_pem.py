@@ -62,8 +62,8 @@ def test_pem_device_every_length_and_padding_case():
 
 
 def test_pem_device_output_blocks_unaligned_pointer_large_and_tiny_certificates():
-    """k_pem_encode cuts the PEM stream into 4 KiB output blocks on 16-byte boundaries of the output ADDRESS: output
-    pointers at every offset mod 16, certificates far larger than a block (70 000 bytes: 24 blocks), runs of tiny ones
+    """k_pem_encode cuts the PEM stream into 7 KiB output blocks on 16-byte boundaries of the output ADDRESS: output
+    pointers at every offset mod 16, certificates far larger than a block (70 000 bytes: 13 blocks), runs of tiny ones
     (more than 64 certificates inside one block: a second pass), and a stream that ends inside its first block."""
     import base64
     import torch
@@ -80,7 +80,11 @@ def test_pem_device_output_blocks_unaligned_pointer_large_and_tiny_certificates(
              [0] * 200 + [1, 2] * 100 + [1523] * 5,
              [5],
              [int(x) for x in rng.normal(1523, 64, 300)],
-             [int(x) for x in rng.integers(0, 9000, 120)]]
+             [int(x) for x in rng.integers(0, 9000, 120)],
+             # every residue of "input chunks in a block" mod 64, with 3-20 certificates per block: a row of chunk loads whose
+             # few active lanes do not include their owner's lane (round 5: a gather under that mask read zero)
+             [int(x) for x in rng.integers(150, 1300, 6000)],
+             [int(x) for x in rng.integers(40, 3000, 3000)]]
     for ci, lens in enumerate(cases):
         blobs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
         lead = int(rng.integers(0, 16))                                  # the first certificate at any address mod 16

@@ -247,3 +247,25 @@ def test_groups_withdraw_the_keys_of_certificates_whose_point_is_off_the_curve(w
     g.close()
     for e in engines:
         e.close()
+
+
+def test_an_entry_the_downloader_dropped_keeps_its_status_whatever_its_key():
+    """Advisor, round 4: entry_type CTMR_ENTRY_INVALID through ctmr_map_batch is ENTRY_DECODE_ERROR — with a well-formed
+    certificate whose EC point is off its curve k_ec_resolve used to rewrite it to PARSE_ERROR, while a bad RSA key (judged
+    inside the map) left it alone: the status histogram depended on the key type."""
+    issuer = D.cert(serial=b"\x01", exts=[D.BC_CA])
+    off_curve = D.cert(serial=b"\x21", spki=ec_spki(pt=bytes(range(64))))
+    bad_rsa = D.cert(serial=b"\x22", spki=D.rsa_spki(e=b"\x00"))
+    fine = D.cert(serial=b"\x23")
+    certs = [off_curve, bad_rsa, fine, off_curve, fine]
+    ets = [N.ENTRY_INVALID, N.ENTRY_INVALID, N.ENTRY_INVALID, 0, 0]
+    batch = Batch.from_certs(certs, [0] * 5, ets)
+    batch.payload = np.concatenate([batch.payload, np.zeros(N.PAYLOAD_PAD, np.uint8)])
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+    eng.add_issuers([issuer])
+    eng.set_filter(b"", True, NOW)
+    res = eng.map_batch(batch)
+    assert list(res.records["status"]) == [N.ST_ENTRY_DECODE_ERROR] * 3 + [N.ST_PARSE_ERROR, N.ST_PASS]
+    assert res.stats.by_status[N.ST_ENTRY_DECODE_ERROR] == 3 and res.stats.by_status[N.ST_PARSE_ERROR] == 1
+    assert eng.total_count() == 1
+    eng.close()

@@ -168,3 +168,21 @@ def test_redis_dump_of_the_gpu_sets_equals_the_oracle_and_restores(engine):
     for k in okeys[::7]:
         assert e2.set_list(k) == sorted(o.members(k))
     e2.close()
+
+
+def test_set_insert_of_known_members_does_not_eat_arena_cells():
+    """Advisor, round 4: every SetInsert took a fresh 64-byte key cell and a known member never gave it back — a host that
+    re-reads a log of known certificates through RemoteCache.SetInsert grew the arena until hipMalloc failed."""
+    import ct_mapreduce_amd as ctmr
+    from ct_mapreduce_amd import synth
+    cfg = synth.config(seed=3, n_issuers=2)
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+    eng.add_issuers(synth.issuers(cfg))
+    key = b"serials::2027-01-01-00::" + eng.issuer_id(0).encode()
+    assert eng.set_insert(key, b"\x01\x02") and eng.set_insert(key, b"\x01\x03")
+    used = eng.table_info().arena_used
+    for _ in range(300):
+        assert not eng.set_insert(key, b"\x01\x02")
+    assert eng.table_info().arena_used == used and eng.set_cardinality(key) == 2
+    assert eng.set_insert(key, b"\x01\x04") and eng.table_info().arena_used == used + 1
+    eng.close()
