@@ -67,8 +67,8 @@ struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };  // una
 constexpr uint32_t PEM_LPL = CTMR_PEM_LPL;    // base64 lines per lane and block: the per-block bookkeeping is paid once for them
 constexpr uint32_t PEM_S = 3584 * PEM_LPL;    // output bytes per block: ≈ 55 lines per 3584 bytes, so that one lane per line fits
 constexpr uint32_t PEM_MARGIN = 80;           // a line that straddles a block edge is encoded whole by both blocks
-constexpr uint32_t PEM_NQ = PEM_LPL == 1 ? 3 : 6;                // 16-byte input loads per lane and block
-constexpr uint32_t PEM_IN_CHUNKS = PEM_LPL == 1 ? 192 : 352;     // 16-byte input chunks parked per pass
+constexpr uint32_t PEM_NQ = PEM_LPL == 1 ? 3 : PEM_LPL == 2 ? 6 : 8;                // 16-byte input loads per lane and block
+constexpr uint32_t PEM_IN_CHUNKS = PEM_LPL == 1 ? 192 : PEM_LPL == 2 ? 352 : 512;     // 16-byte input chunks parked per pass
 constexpr uint32_t PEM_LUT_BYTES = 64 + 64;   // the alphabet + the two framing lines
 constexpr uint32_t PEM_OBUF = PEM_S + 2 * PEM_MARGIN;
 constexpr uint32_t PEM_IBUF = PEM_IN_CHUNKS * 16 + 64;
