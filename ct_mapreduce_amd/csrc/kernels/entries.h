@@ -163,6 +163,13 @@ __device__ __forceinline__ U16 ld_chain16(const uint8_t* p) {
   return r;
 }
 
+// Round 5 asked whether the comparison's instructions or the alignment of its loads hold k_decode_match back
+// (profiles/r05/ab_raw_chain0_compare.txt, raw_decode_match_pmc_*.txt; one box, alternating): neither.  Without masks — the last
+// chunk anchored at the certificate's END, every lane comparing 16 whole bytes; 1 624 → 846 vector instructions in the
+// listing, no SGPR spills without the occupancy attribute — decode + match take 11.19 / 11.30 ms per 40 M entries against
+// 10.89 / 11.11 ms for this form; with 16-byte ALIGNED loads of the covering chunks, the neighbour's chunk by
+// v_mov_b32_dpp wave_shl:1 and a v_alignbyte funnel: 12.76 ms.  The kernel is bound by what a CU keeps in flight times
+// the latency of a pattern with three isolated lines per entry.
 __device__ __forceinline__ bool eq16_prefix(const U16& x, const uint4& y, uint32_t rem) {  // first min(rem,16) bytes equal
   const uint32_t d[4] = {x.a ^ y.x, x.b ^ y.y, x.c ^ y.z, x.d ^ y.w};
   bool eq = true;
