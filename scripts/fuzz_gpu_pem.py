@@ -1,7 +1,7 @@
 """GPU campaign for k_pem_encode (N1): random certificate-length mixtures, payload alignments and output addresses against
 Python's base64 — the block cutter, the owner gathers, the last-line tasks and the slow path for blocks of tiny certificates
 all depend on how lengths fall into the 7 KiB output blocks.
-    python scripts/fuzz_gpu_pem.py <trials> <seed>
+    python scripts/fuzz_gpu_pem.py <trials> <seed> [<certificates of one big call in front>]
 """
 import base64
 import os
@@ -44,12 +44,46 @@ def lengths(rng):
     return rng.choice([0, 1, 2, 3, 47, 48, 49, 95, 96, 97, 5375, 5376, 5377], n)
 
 
+def big(eng, dev, rng, n):
+    """One call over n certificates: every wave of the resident grid walks MANY blocks (the software-pipelined loop, which a
+    few hundred certificates never enter: they give every wave one block)."""
+    t0 = time.time()
+    lens = rng.normal(1523, 64, n).clip(0).astype(np.int64)
+    odd = rng.random(n)
+    lens = np.where(odd < 0.01, rng.integers(0, 100, n), np.where(odd > 0.999, rng.integers(10000, 60000, n), lens))
+    offs = np.zeros(n + 1, np.int64)
+    offs[0] = int(rng.integers(0, 16))
+    offs[1:] = offs[0] + np.cumsum(lens)
+    payload = rng.integers(0, 256, int(offs[-1]) + 64, dtype=np.uint8)
+    pb = payload.tobytes()
+    want = b"".join(pem(pb[offs[i]:offs[i + 1]]) for i in range(n))
+    d_pay = torch.from_numpy(payload).to(dev)
+    d_off = torch.from_numpy(offs).to(dev)
+    d_idx = torch.arange(n, dtype=torch.int64, device=dev)
+    d_po = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    shift = int(rng.integers(0, 16))
+    d_pem = torch.full((len(want) + 64,), 0xEE, dtype=torch.uint8, device=dev)
+    total = eng.pem_encode_device(d_pay.data_ptr(), d_off.data_ptr(), d_idx.data_ptr(), n, d_pem.data_ptr() + shift, len(want),
+                                  d_po.data_ptr())
+    d_want = torch.from_numpy(np.frombuffer(want, np.uint8).copy()).to(dev)
+    same = total == len(want) and bool(torch.equal(d_pem[shift:shift + total], d_want)) and \
+        bool((d_pem[:shift] == 0xEE).all()) and bool((d_pem[shift + total:] == 0xEE).all())
+    if not same:
+        bad = torch.nonzero(d_pem[shift:shift + len(want)] != d_want)
+        raise AssertionError(f"FUZZ GPU PEM MISMATCH big call of {n}: total {total} want {len(want)}, {bad.numel()} bad bytes, "
+                             f"first {int(bad[0]) if bad.numel() else -1}")
+    print(f"FUZZ GPU PEM BIG OK one call over {n} certificates: {total} PEM bytes = {(total + 7167) // 7168} blocks of 7 KiB, "
+          f"0 differences, {time.time() - t0:.0f} s", flush=True)
+
+
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
     eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+    if len(sys.argv) > 3:
+        big(eng, dev, rng, int(sys.argv[3]))
     t0 = time.time()
     certs = nbytes = 0
     for t in range(trials):

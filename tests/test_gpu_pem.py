@@ -138,3 +138,14 @@ def test_fingerprint_matches_hashlib():
     for k, b in enumerate(blobs):
         assert got[32 * k:32 * k + 32] == hashlib.sha256(b[:-1]).digest(), lens[k]
     eng.close()
+
+
+def test_pem_device_many_blocks_per_wave():
+    """The resident grid of k_pem_encode is 12 waves per CU; a NEW list of a few thousand certificates gives every wave one
+    block and never enters the software-pipelined loop (next block's bytes and the bounds of the block after in flight).  300 000
+    certificates are ≈ 90 000 blocks: ≈ 30 per wave, compared bytewise on the device."""
+    import torch
+    from scripts.fuzz_gpu_pem import big
+    eng = ctmr.Engine(device=0, table_slots=1 << 10, pair_slots=1 << 10)
+    big(eng, torch.device("cuda:0"), np.random.default_rng(23), 300_000)      # raises on a difference
+    eng.close()
