@@ -712,18 +712,19 @@ struct Octets {
   CTMR_HD uint32_t operator[](uint32_t i) const { return ldc(r, base + i, L) & 0xffu; }
 };
 
-// x509.domainToReverseLabels(s).ok, fed octet by octet: no empty label (no leading or trailing dot, no ".."), every rune in
-// 33..126 (an octet >= 0x80 is, or decodes to, a rune above 126).  No octets at all: ok.
+// x509.domainToReverseLabels(s).ok, fed octet by octet: no empty label (no trailing dot, no ".."), every rune in 33..126 (an
+// octet >= 0x80 is, or decodes to, a rune above 126).  No octets at all: ok.
 struct LabelCheck {
-  uint32_t n = 0u, prev = 0u, first = 0u;
+  uint32_t n = 0u, prev = 0u;
   bool bad = false;
   CTMR_HD void feed(uint32_t b) {
-    first = n == 0u ? b : first;
     bad = bad | (b < 33u) | (b > 126u) | ((n != 0u) & (prev == 0x2eu) & (b == 0x2eu));
     prev = b;
     n++;
   }
-  CTMR_HD bool ok() const { return (n == 0u) | (!bad & (first != 0x2eu) & (prev != 0x2eu)); }
+  // (one leading dot passes: the loop cuts labels off the END and never records the empty one in front — the release the
+  //  reference builds with predates the fix that appends it)
+  CTMR_HD bool ok() const { return (n == 0u) | (!bad & (prev != 0x2eu)); }
 };
 CTMR_HD bool is_hex_octet(uint32_t c) { return ((c - 0x30u) <= 9u) | (((c | 0x20u) - 0x61u) <= 5u); }
 CTMR_HD uint32_t unhex_octet(uint32_t c) { return c <= 0x39u ? c - 0x30u : (c | 0x20u) - 0x61u + 10u; }

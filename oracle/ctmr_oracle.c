@@ -707,11 +707,14 @@ static int valid_optional_port(const uint8_t* s, uint32_t n) {
   for (uint32_t i = 1; i < n; i++) if (s[i] < '0' || s[i] > '9') return 0;
   return 1;
 }
-/* x509.domainToReverseLabels(domain).ok: no empty label (so no leading or trailing dot, no "..") and every rune in 33..126
- * (an octet >= 0x80 is, or decodes to, a rune above 126) */
+/* x509.domainToReverseLabels(domain).ok: no empty label (no trailing dot, no "..") and every rune in 33..126 (an octet
+ * >= 0x80 is, or decodes to, a rune above 126).  ONE LEADING DOT PASSES: the loop cuts labels off the end
+ * (LastIndexByte; domain = domain[:i]) and stops when nothing is left, so the empty label in front of a leading dot is
+ * never recorded — ".a" gives ["a"].  Later Go releases append "" when i == 0 ("domain is prefixed with an empty label");
+ * the toolchain of go.mod and CT-go v1.1.0's fork predate that fix. */
 static int domain_labels_ok(const uint8_t* s, uint32_t n) {
   if (n == 0) return 1; /* no labels at all: ok (the callers that need a host test len > 0 first) */
-  if (s[0] == '.' || s[n - 1] == '.') return 0;
+  if (s[n - 1] == '.') return 0;
   for (uint32_t i = 0; i < n; i++) {
     if (s[i] < 33 || s[i] > 126) return 0;
     if (i + 1 < n && s[i] == '.' && s[i + 1] == '.') return 0;

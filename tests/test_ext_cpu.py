@@ -165,14 +165,17 @@ def test_subject_alt_name_uri_goes_through_url_parse():
           "http://h.example/%41", "http://h.example/a%20b", "http://a.b/c?%zz", "HTTP://A.EXAMPLE", "a+b-c.d:rest",
           "http://h.example:/x", "http://h!$&'()*+,;=.example", "http://h.example/\x80\xff",
           "http://a.example/#%41", "http://a_b.example", "x://h<>\"/", "http://h/a:b", "./a:b", "http://h/?\x01"[:9], "*#f",
-          "http://@h/", "http://:@h/", "http://h.example:80", "x:", "x:%zz", "http://a@b@c/"]
+          "http://@h/", "http://:@h/", "http://h.example:80", "x:", "x:%zz", "http://a@b@c/",
+          # ONE leading dot passes domainToReverseLabels in the release the reference builds with: labels are cut off the END and
+          # the empty one in front is never recorded (later releases append it: "domain is prefixed with an empty label")
+          "http://.example/", "//.h/", "http://.a.b:80/"]
     bad_ = [":", ":x", "a b"[0:0] + "\x7f", "http://a\x01", "\x00", "http://h/\x1f", "a b:c",   # control characters; a colon in the first segment
             "//h:port/", "http://h:80x/", "http://h:-1", "http://[::1", "http://[::1]x", "http://[::1]:x", "http://a:b:c/",
             "http://h%20x/", "http://h%41/", "http://%zz/", "http://h/%", "http://h/%4", "http://h/%zz", "http://h/#%", "http://h/#%g1",
             "http://h x/", "http://h\\x/", "http://h^x/", "http://h`x/", "http://h{x/", "http://h|x/", "http://h}x/",
             "http://u ser@h/", "http://us\x80er@h/", "http://u%zz@h/", "http://u:p%@h/", "http://a@b@c d/",
-            "http://.example/", "http://example./", "http://a..b/", "http://h\x80/", "http://h%c3%a9/", "http://[::1%25\x80]/",
-            "http://[fe80::1%25e%7fn]/", "//.h/", "*\x01", "http://h/%41%zz",
+            "http://..example/", "http://./", "http://example./", "http://a..b/", "http://h\x80/", "http://h%c3%a9/", "http://[::1%25\x80]/",
+            "http://[fe80::1%25e%7fn]/", "//..h/", "*\x01", "http://h/%41%zz",
             "1http://x/y",                                            # no scheme (a digit first): a colon in the first path segment
             "http://[fe80::1%25e%20n]/"]                              # url.Parse takes the space in the zone, domainToReverseLabels does not
     for u in ok:
@@ -254,6 +257,9 @@ def nc(permitted=None, excluded=None, raw=None):
 def test_name_constraints_as_cryptobyte_reads_them():
     dns = lambda b: D.tlv(0x82, b)
     good(nc([dns(b"example.com")], [dns(b".example.org")]))
+    # one leading dot is trimmed by the caller, a second one passes domainToReverseLabels (see the URI cases); a third does not
+    good(nc([dns(b"..example.com"), D.tlv(0x81, b"user@.example"), D.tlv(0x81, b"..example.com"), D.tlv(0x86, b"..example.com"),
+             dns(b"."), dns(b"")]))                                                     # (trimmed to nothing: no labels, no complaint)
     good(nc([dns(b"")]))                                              # an empty domain has no labels: fine
     good(nc(None, [D.tlv(0x87, bytes(4) + b"\xff\xff\xf0\x00")]))
     good(nc([D.tlv(0x87, bytes(16) + b"\xff" * 8 + bytes(8))]))
@@ -271,12 +277,12 @@ def test_name_constraints_as_cryptobyte_reads_them():
               nc(raw=D.seq(D.tlv(0xa0, D.seq(b"\x9f\x21\x00")))),                     # cryptobyte refuses the high-tag-number form
               nc(raw=D.seq(D.tlv(0x80, b"")))):                                        # [0] primitive: not the optional element
         bad(e)
-    for c in (dns(b"exa mple.com"), dns(b"example..com"), dns(b"example.com."), dns(b"..example.com"), dns(b"\x80"), dns(b"a\x7fb"),
+    for c in (dns(b"exa mple.com"), dns(b"example..com"), dns(b"example.com."), dns(b"...example.com"), dns(b".."), dns(b"\x80"), dns(b"a\x7fb"),
               D.tlv(0x87, bytes(7)), D.tlv(0x87, bytes(9)), D.tlv(0x87, bytes(4) + b"\xff\x00\xff\x00"), D.tlv(0x87, bytes(4) + b"\xfd\x00\x00\x00"),
               D.tlv(0x87, bytes(16) + b"\x00" * 15 + b"\x01"),
               D.tlv(0x81, b"@example.com"), D.tlv(0x81, b".user@example.com"), D.tlv(0x81, b"us..er@example.com"), D.tlv(0x81, b"user.@x"),
               D.tlv(0x81, b'"unterminated@example.com'), D.tlv(0x81, b'"a"b@example.com'), D.tlv(0x81, b"a b@example.com"),
-              D.tlv(0x81, b"user@exa mple"), D.tlv(0x81, b"user@.example"), D.tlv(0x81, b"u\\@x"), D.tlv(0x81, b'"\\\n"@x'), D.tlv(0x81, b"ex ample.com"),
+              D.tlv(0x81, b"user@exa mple"), D.tlv(0x81, b"user@..example"), D.tlv(0x81, b"user@example."), D.tlv(0x81, b"u\\@x"), D.tlv(0x81, b'"\\\n"@x'), D.tlv(0x81, b"ex ample.com"),
               D.tlv(0x81, b"\xe9@example.com"),
               D.tlv(0x86, b"1.2.3.4"), D.tlv(0x86, b"01.02.03.004"), D.tlv(0x86, b"::1"), D.tlv(0x86, b"::"), D.tlv(0x86, b"2001:db8::1"),
               D.tlv(0x86, b"1:2:3:4:5:6:7:8"), D.tlv(0x86, b"::ffff:1.2.3.4"), D.tlv(0x86, b"1:2:3:4:5:6:1.2.3.4"),
