@@ -47,9 +47,11 @@ struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };  // una
 //      big-endian 24-bit groups, the 64 characters come from the 64-byte alphabet in LDS (one v_bfe + one ds_read_u8 per
 //      character; sixteen dwords in sixteen banks: conflict-free) and go to the block's image in LDS at their final
 //      stream position — a line is 65 bytes, so every line sits at another alignment: sixteen v_alignbyte shift it onto
-//      aligned dwords, the two ends and the line end are byte stores.  A certificate's last, shorter line is encoded
-//      apart, by up to four lanes in 12-byte → 16-character tasks (whatever they write past the line's end lands in the
-//      END line's place, which is written afterwards), and so are the two framing lines;
+//      aligned dwords, the two ends and the line end are byte stores.  A certificate's last, shorter line is a line like
+//      any other (PEM_FOLD; until late in round 5 up to four lanes encoded it apart in 12-byte → 16-character tasks — 120
+//      vector instructions per block for a handful of lanes): the lane encodes 48 octets whatever the line holds (the two
+//      octets behind the certificate are zeroed in LDS first), sets the '=' and the line end where they belong, and what it
+//      writes behind them is the place of the two framing lines, which are written afterwards;
 //   4. the image leaves as 448 aligned, non-temporal 16-byte stores.
 // The loop over a wave's blocks is software-pipelined: while block i is encoded, the BYTES of block i + 1 and the BOUNDS of
 // block i + 2 are in flight.
@@ -60,7 +62,8 @@ struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };  // una
 // instructions per 4 KiB block, the vector ALU 80 % busy.  One lane per line cuts both by more than half (580 vector
 // instructions per 3.5 KiB block, of which the lines themselves are 190: the rest is per-block bookkeeping — bounds, plan,
 // assignment, last lines, framing lines); two lines per lane and 7 KiB blocks pay that bookkeeping once for twice the
-// bytes: 13.9 → 12.7 ms on 16 M certificates, at 12 instead of 16 waves per CU (163 VGPRs, 13 KB of LDS per wave).
+// bytes: 13.9 → 12.7 ms on 16 M certificates, at 12 instead of 16 waves per CU (163 VGPRs, 13 KB of LDS per wave).  The last
+// lines folded into the line pass: 468 → 427 vector instructions per 3.5 KiB, 151 VGPRs, 12.8 → 12.4 ms.
 #ifndef CTMR_PEM_LPL
 #define CTMR_PEM_LPL 2
 #endif
@@ -76,7 +79,11 @@ constexpr uint32_t PEM_TRASH = 256;           // one dword per lane: where a sto
 constexpr uint32_t PEM_WAVE_LDS = PEM_OBUF + PEM_IBUF + PEM_TRASH;
 constexpr uint32_t PEM_WAVES = 4;             // waves per workgroup (they share the tables, nothing else)
 constexpr uint32_t PEM_LDS_BYTES = PEM_WAVES * PEM_WAVE_LDS;  // dynamic; + PEM_LUT_BYTES static
-constexpr uint32_t PEM_FAST_CERTS = 16;       // certificates per block the one-pass path takes (4 task lanes each)
+#ifndef CTMR_PEM_FOLD
+#define CTMR_PEM_FOLD 1
+#endif
+constexpr bool PEM_FOLD = CTMR_PEM_FOLD != 0; // a certificate's shorter last line is encoded by a line lane like any other line
+constexpr uint32_t PEM_FAST_CERTS = PEM_FOLD ? 32 : 16;  // certificates per block the one-pass path takes (without PEM_FOLD: 4 task lanes each)
 
 __device__ __forceinline__ uint32_t b64_char(uint32_t v) {  // base64.StdEncoding alphabet
   int32_t off = 65;                 // 'A'
@@ -114,9 +121,11 @@ struct PemPlan {
 // what a lane does in a block: its line (lines), its task of some certificate's last line (tasks); ib / ob: where the
 // certificate's byte 0 lies in ibuf, its first base64 character in obuf
 struct PemWork {
-  uint32_t ln[PEM_LPL], l_ib[PEM_LPL];
+  uint32_t ln[PEM_LPL], l_ib[PEM_LPL], l_len[PEM_LPL];  // (l_len: the certificate's length — a line knows from it whether it is the last, shorter one)
   int32_t l_ob[PEM_LPL];
   bool l_act[PEM_LPL];
+  uint32_t z_at;   // PEM_FOLD, lane j: where its certificate ends in ibuf — the two octets there are zeroed for the last group
+  bool z_act;
   uint32_t tk, t_ib, t_len, t_nq;
   int32_t t_ob;
   bool t_act, any_task;
@@ -148,12 +157,14 @@ __device__ __forceinline__ PemPlan pem_plan(const PemCert& c, uint64_t B0, uint6
       const uint32_t L = (uint32_t)c.len, nfull = L / 48u;        // (a certificate is shorter than 2^31 bytes)
       const uint32_t ln_lo = (uint32_t)(s - body) / 65u, ln_hi = (uint32_t)(e - 1u - body) / 65u;
       const bool last = (L != 48u * nfull) & (ln_hi == nfull);     // the shorter last line lies in the block
-      const uint32_t fl_end = ln_hi + 1u < nfull ? ln_hi + 1u : nfull;  // whole lines: [ln_lo, fl_end)
+      const uint32_t nlines = PEM_FOLD ? nfull + (L != 48u * nfull ? 1u : 0u) : nfull;  // PEM_FOLD: the shorter last line is a line
+      const uint32_t fl_end = ln_hi + 1u < nlines ? ln_hi + 1u : nlines;  // lines: [ln_lo, fl_end)
       p.ln_lo = ln_lo;
       p.nfl = fl_end > ln_lo ? fl_end - ln_lo : 0u;
       p.tk_lo = 4u * nfull;
-      p.ntk = last ? p.nq - 4u * nfull : 0u;
-      const uint64_t in_lo = c.lo + 48ull * ln_lo, in_end = last ? c.lo + L : c.lo + 48ull * fl_end;
+      p.ntk = last ? (PEM_FOLD ? 1u : p.nq - 4u * nfull) : 0u;  // (PEM_FOLD: just "has a last line here")
+      // (PEM_FOLD: two octets behind the certificate belong to its chunks too — they are zeroed in ibuf for the last group)
+      const uint64_t in_lo = c.lo + 48ull * ln_lo, in_end = last ? c.lo + L + (PEM_FOLD ? 2u : 0u) : c.lo + 48ull * fl_end;
       p.a0 = in_lo & ~15ull;
       p.nch = (uint32_t)((((in_end + 15ull) & ~15ull) - p.a0) >> 4);
     }
@@ -212,15 +223,26 @@ __device__ __forceinline__ bool pem_assign(const PemCert& c, const PemPlan& p, u
     w.ln[l] = gather32(p.ln_lo, o) + (64u * l + lane - gather32(my_lbase, o));
     w.l_ib[l] = gather32(my_ib, o);
     w.l_ob[l] = (int32_t)gather32((uint32_t)my_ob, o);
+    w.l_len[l] = PEM_FOLD ? gather32((uint32_t)c.len, o) : 0u;
   }
-  const uint32_t town = j0 + (lane >> 2);  // four task lanes per certificate
-  const uint32_t ntk = gather32(p.ntk, town);
-  w.t_act = (town < j1) & ((lane & 3u) < ntk);
-  w.tk = gather32(p.tk_lo, town) + (lane & 3u);
-  w.t_ib = gather32(my_ib, town);
-  w.t_ob = (int32_t)gather32((uint32_t)my_ob, town);
-  w.t_len = gather32((uint32_t)c.len, town);
-  w.t_nq = gather32(p.nq, town);
+  if constexpr (PEM_FOLD) {
+    w.z_act = (lane >= j0) & (lane < j1) & (p.ntk != 0u);
+    w.z_at = my_ib + (uint32_t)c.len;
+    w.t_act = false;
+    w.tk = w.t_ib = w.t_len = w.t_nq = 0u;
+    w.t_ob = 0;
+  } else {
+    const uint32_t town = j0 + (lane >> 2);  // four task lanes per certificate
+    const uint32_t ntk = gather32(p.ntk, town);
+    w.t_act = (town < j1) & ((lane & 3u) < ntk);
+    w.tk = gather32(p.tk_lo, town) + (lane & 3u);
+    w.t_ib = gather32(my_ib, town);
+    w.t_ob = (int32_t)gather32((uint32_t)my_ob, town);
+    w.t_len = gather32((uint32_t)c.len, town);
+    w.t_nq = gather32(p.nq, town);
+    w.z_act = false;
+    w.z_at = 0u;
+  }
   w.any_task = any_task;
   nflat = cbase < PEM_IN_CHUNKS ? cbase : PEM_IN_CHUNKS;
   return cbase <= PEM_IN_CHUNKS && lbase <= 64u * PEM_LPL && j1 - j0 <= PEM_FAST_CERTS;
@@ -248,9 +270,19 @@ __device__ __forceinline__ uint32_t pem_enc4(const uint8_t* abc, uint32_t g) {  
 }
 
 // the whole lines: one lane, one line
-__device__ __forceinline__ void pem_encode_line(bool act, uint32_t ln, uint32_t l_ib, int32_t l_ob, const uint8_t* abc, uint8_t* obuf,
-                                                const uint8_t* ibuf, uint32_t* trash) {
+__device__ __forceinline__ void pem_encode_line(bool act, uint32_t ln, uint32_t l_ib, int32_t l_ob, uint32_t l_len, const uint8_t* abc,
+                                                uint8_t* obuf, const uint8_t* ibuf, uint32_t* trash) {
   if (!act) return;
+  // PEM_FOLD: a certificate's last line may be shorter — rem octets, nch characters of which the last npad are '=', then the
+  // line end.  The lane encodes 48 octets all the same (ibuf holds zeros where the last group needs them; what lies behind is
+  // arbitrary) and writes 65 octets: behind the line end lie "-----END CERTIFICATE-----\n" and the next certificate's
+  // "-----BEGIN CERTIFICATE-----\n", 54 octets that pem_frames writes AFTER the lines — only a line of 4 or 8 characters
+  // would reach past them (into the next certificate's first line): its stores above byte 56 go nowhere.
+  const uint32_t rem = PEM_FOLD ? l_len - 48u * ln : 48u;
+  const bool shortl = rem < 48u;
+  const uint32_t nch = shortl ? 4u * ((rem + 2u) / 3u) : 64u;
+  const uint32_t npad = shortl ? (nch >> 2) * 3u - rem : 0u;
+  const bool tiny = nch < 12u;
   const uint32_t at = l_ib + 48u * ln, m = at & 3u;
   const uint32_t* x = (const uint32_t*)(ibuf + (at & ~3u));
   uint32_t r[13];
@@ -275,21 +307,37 @@ __device__ __forceinline__ void pem_encode_line(bool act, uint32_t ln, uint32_t 
   const uint32_t s = (uint32_t)P & 3u, sh = (4u - s) & 3u;
   uint32_t* const A = (uint32_t*)(o - s - (s ? 0u : 4u));
 #pragma unroll
-  for (int k = 1; k < 16; k++) A[k] = __builtin_amdgcn_alignbyte(ch[k], ch[k - 1], sh);
+  for (int k = 1; k < 15; k++) A[k] = __builtin_amdgcn_alignbyte(ch[k], ch[k - 1], sh);
+  *((PEM_FOLD && tiny) ? trash : A + 15) = __builtin_amdgcn_alignbyte(ch[15], ch[14], sh);
   // dword 16 is a whole one for s = 0 (the last four characters) and s = 3 (three characters and the line end); for
   // s = 1, 2 its other bytes are the next line's — it goes nowhere, and the bytes below cover it
-  *(((s == 0u) | (s == 3u)) ? A + 16 : trash) = __builtin_amdgcn_alignbyte(ch[16], ch[15], sh);
+  *((((s == 0u) | (s == 3u)) & !(PEM_FOLD && tiny)) ? A + 16 : trash) = __builtin_amdgcn_alignbyte(ch[16], ch[15], sh);
+  uint8_t* const trash_b = (uint8_t*)trash;
 #pragma unroll
   for (uint32_t t4 = 0; t4 < 4u; t4++) {  // the first 4 − s characters in front, the last s behind (s = 0: the first four, again)
     const bool front = t4 < 4u - s;
-    o[front ? t4 : 60u + t4] = (uint8_t)((front ? ch[0] : ch[15]) >> (8u * t4));
+    *(front ? o + t4 : ((PEM_FOLD && tiny) ? trash_b : o + 60u + t4)) = (uint8_t)((front ? ch[0] : ch[15]) >> (8u * t4));
   }
-  o[64] = (uint8_t)'\n';
+  if constexpr (PEM_FOLD) {  // (behind every other store of this lane: LDS operations of a wave execute in order)
+    o[nch] = (uint8_t)'\n';  // nch = 64 for a whole line
+    *(npad >= 1u ? o + nch - 1u : trash_b) = (uint8_t)'=';
+    *(npad == 2u ? o + nch - 2u : trash_b) = (uint8_t)'=';
+  } else {
+    o[64] = (uint8_t)'\n';
+  }
 }
 __device__ __forceinline__ void pem_encode_lines(const PemWork& w, const uint8_t* abc, uint8_t* obuf, const uint8_t* ibuf,
                                                  uint32_t* trash) {
 #pragma unroll
-  for (uint32_t l = 0; l < PEM_LPL; l++) pem_encode_line(w.l_act[l], w.ln[l], w.l_ib[l], w.l_ob[l], abc, obuf, ibuf, trash);
+  for (uint32_t l = 0; l < PEM_LPL; l++) pem_encode_line(w.l_act[l], w.ln[l], w.l_ib[l], w.l_ob[l], w.l_len[l], abc, obuf, ibuf, trash);
+}
+// PEM_FOLD: the two octets behind every certificate that ends in this pass become zero in ibuf (a partial last group is
+// encoded with zero bits for what it lacks); behind pem_park, in front of the lines
+__device__ __forceinline__ void pem_zero_tails(const PemWork& w, uint8_t* ibuf) {
+  if (w.z_act) {
+    ibuf[w.z_at] = 0;
+    ibuf[w.z_at + 1u] = 0;
+  }
 }
 
 // the shorter last lines: one lane, one 12-byte → 16-character task
@@ -409,8 +457,9 @@ __global__ void __launch_bounds__(64 * PEM_WAVES) k_pem_encode(const uint8_t* __
           (void)pem_assign(cc, pc, j, j + 1u, B0s, lane, s1, nf, w);  // (one certificate's share of a block always fits a pass)
           pem_issue(payload, s1, w1);
           pem_park(ibuf, w1, nf, lane);
+          if (PEM_FOLD && w.any_task) pem_zero_tails(w, ibuf);
           pem_encode_lines(w, abc, obuf, ibuf, trash);
-          if (w.any_task) pem_encode_tasks(w, abc, obuf, ibuf);
+          if (!PEM_FOLD && w.any_task) pem_encode_tasks(w, abc, obuf, ibuf);
           pem_frames(cc, j, j + 1u, B0s, frame, obuf, lane);
           __builtin_amdgcn_wave_barrier();
         }
@@ -443,8 +492,9 @@ __global__ void __launch_bounds__(64 * PEM_WAVES) k_pem_encode(const uint8_t* __
     // ---- this block: lines, last lines, framing lines; then the image leaves as aligned 16-byte vectors (only the first
     // and the last block of the stream have edges)
     if (simple) {
+      if (PEM_FOLD && wk.any_task) pem_zero_tails(wk, ibuf);
       pem_encode_lines(wk, abc, obuf, ibuf, trash);
-      if (wk.any_task) pem_encode_tasks(wk, abc, obuf, ibuf);
+      if (!PEM_FOLD && wk.any_task) pem_encode_tasks(wk, abc, obuf, ibuf);
       pem_frames(cc, 0u, pc.ncert, B0s, frame, obuf, lane);
     }
     __builtin_amdgcn_wave_barrier();
