@@ -48,9 +48,9 @@ def pow2_at_least(v):
     return p
 
 
-def cpu_baseline(batch_arrays, issuers, filt, now, sample, entry_type=None):
+def cpu_baseline(batch_arrays, issuers, filt, now, sample, entry_type=None, profile="reference"):
     """The oracle's restatement of the reference loop, timed on one host core (kind "port"), over `sample` entries of
-    the SAME batch the GPU processed (payload, offsets, issuer_idx[, entry_type])."""
+    the SAME batch the GPU processed (payload, offsets, issuer_idx[, entry_type]), in the SAME accept/reject profile."""
     import numpy as np
     from oracle import oracle as orc
     payload, offsets, issuer_idx = batch_arrays
@@ -58,6 +58,7 @@ def cpu_baseline(batch_arrays, issuers, filt, now, sample, entry_type=None):
     io[1:] = np.cumsum([len(x) for x in issuers])
     blob = np.frombuffer(b"".join(issuers), np.uint8)
     o = orc.Engine(filt, False, now)
+    o.set_profile(profile)
     t0 = time.perf_counter()
     st, unk, eh = o.batch(payload, offsets, issuer_idx, blob, io, entry_type=entry_type)
     dt = time.perf_counter() - t0
@@ -87,7 +88,7 @@ def cpu_quota():
     return aff, None
 
 
-def cpu_baseline_threads(batch_arrays, issuers, filt, now, sample, threads):
+def cpu_baseline_threads(batch_arrays, issuers, filt, now, sample, threads, profile="reference"):
     """The same restatement on `threads` host threads: contiguous slices of the sample, one oracle engine (its own
     in-process sets) per thread — T reference processes with -offset/-limit, minus the Redis they would share, so
     this flatters the CPU side slightly.  ctypes releases the GIL for the duration of each call."""
@@ -99,6 +100,8 @@ def cpu_baseline_threads(batch_arrays, issuers, filt, now, sample, threads):
     io[1:] = np.cumsum([len(x) for x in issuers])
     blob = np.frombuffer(b"".join(issuers), np.uint8)
     engines = [orc.Engine(filt, False, now) for _ in range(threads)]
+    for e in engines:
+        e.set_profile(profile)
     bounds = [sample * t // threads for t in range(threads + 1)]
     gate = threading.Barrier(threads + 1)
     n_pass = [0] * threads
@@ -656,7 +659,7 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
 
 
 def oracle_sample_check(np, torch, ctmr, synth, N, cfg, dup_permille, issuers, filt, now, dev, base, E, d_off, d_pay, d_iss,
-                        d_et, d_rec, slices, per):
+                        d_et, d_rec, slices, per, profile="reference"):
     """The oracle-checked sample of ONE rank's shard = the one-core cpu_baseline leg: `slices` equally spaced slices of
     the shard, copied back from HBM, plus — generated on the host, byte-identical to the device generator
     (tests/test_gpu_parity.py) — every entry outside them whose key a sampled duplicate repeats, WHEREVER in the log it
@@ -671,7 +674,7 @@ def oracle_sample_check(np, torch, ctmr, synth, N, cfg, dup_permille, issuers, f
     extra_certs = [synth.leaf(cfg, int(i)) for i in extra]
     arrays = gather_sample(d_off, d_pay, d_iss, d_et, ranges, extra, extra_certs, N.PAYLOAD_PAD, np, base=base)
     sample = len(arrays[4])
-    cpu, (ost, ounk) = cpu_baseline(arrays[:3], issuers, filt, now, sample, arrays[3])
+    cpu, (ost, ounk) = cpu_baseline(arrays[:3], issuers, filt, now, sample, arrays[3], profile)
     cpu["sample"] = (f"{slices} equally spaced slices of {per} entries of the same synthetic batch, copied back from HBM, + the "
                      f"{len(extra)} entries outside them whose keys sampled duplicates repeat; " + cpu["sample"])
     mine = (arrays[4] >= base) & (arrays[4] < base + E)            # the rest are sources that live in other shards
@@ -746,10 +749,11 @@ def main():
                          "behaves when the lanes of a wave do not walk identical layouts.  The default run reports it as "
                          "secondary.mixed; this flag makes it the line's workload")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (mixed corpus, 128-byte aligned layout) of the default run")
-    ap.add_argument("--profile", choices=("fast", "reference"), default="fast",
-                    help="ctmr_set_profile: 'fast' = the engine's defaults (the headline); 'reference' = strict_spki + strict_leaf + "
+    ap.add_argument("--profile", choices=("fast", "reference"), default="reference",
+                    help="ctmr_set_profile: 'reference' (the engine's default and the headline) = strict_spki + strict_leaf + "
                          "strict_strings + strict_extensions — what the reference's x509.ParseCertificate decides, as far as it can be "
-                         "known here (DESIGN.md §3.1).  The default run reports it as secondary.reference_profile")
+                         "known here (DESIGN.md §3.1); 'fast' = strict_spki only, for a host that has parsed already.  The default "
+                         "run reports it as secondary.fast_profile")
     ap.add_argument("--strict-extensions", action="store_true",
                     help="ctmr_set_strict_extensions(1) alone: the extension bodies Go parses (what it costs on top of the default walk)")
     ap.add_argument("--strict-strings", action="store_true",
@@ -868,8 +872,7 @@ def main():
                           pair_slots=1 << 22, map_variant=args.variant, certs_per_tile=args.certs_per_tile,
                           lds_tile_bytes=args.lds_bytes, profile=True, collect_meta=args.meta)
         eng.set_filter(filt, False, now)
-        if args.profile == "reference":
-            eng.set_profile("reference")
+        eng.set_profile(args.profile)          # "reference" is also what ctmr_create gives (ABI v7); said explicitly here
         if args.strict_strings:
             eng.set_strict_strings(True)
         if args.strict_extensions:
@@ -1094,7 +1097,7 @@ def main():
     mode_args = (["--mixed"] if args.mixed else []) + (["--aligned", str(args.aligned)] if args.aligned else []) + (["--raw"] if args.raw else []) + (["--meta"] if args.meta else []) + \
                 (["--trusted-chain"] if args.trusted_chain else []) + (["--global-dedup", args.global_dedup] if args.global_dedup else []) + \
                 (["--strict-strings"] if args.strict_strings else []) + (["--no-strict-spki"] if args.no_strict_spki else []) + \
-                (["--profile", args.profile] if args.profile != "fast" else []) + (["--strict-extensions"] if args.strict_extensions else [])
+                ["--profile", args.profile] + (["--strict-extensions"] if args.strict_extensions else [])
     plain = not (args.raw or args.global_dedup or args.meta)
     if rank == 0 and world == 1 and not os.environ.get("CTMR_BENCH_CHILD"):
         if args.traffic_file and plain:
@@ -1176,6 +1179,7 @@ def main():
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (traffic if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_measurement": traffic_info,
+                     "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                      "frac_of_streaming_ceiling": (traffic / (avg_ms * 1e-3) / 1e9 / 6290.0) if traffic else None,
                      "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
@@ -1283,7 +1287,7 @@ def main():
                       "chain0_match": "trusted-log (bytewise on first sighting per call, then length + first/last 16 B)"
                                       if args.trusted_chain else "exact (every byte of every Chain[0])",
                       "chain0_bytes": c0_bytes, "certificate_bytes_the_map_parses": cert_bytes,
-                      "note": "decode and the first match round are one kernel (ms_decode = 0, ms_match = both)",
+                      "note": "decode and the first match round are one kernel (ms_match = both); ms_decode = strict_leaf's walk of the precertificate entries' leaf TBSCertificates (k_leaf_tbs_check; reference profile), else 0",
                       "parity_note": "the decode's oracle follows RFC 6962 3.4/4.6 and CT-go's struct tags; the reference holds "
                                      "no raw-entry fixture, so parity with CT-go's LogEntryFromLeaf is UNPINNED (DESIGN.md 3.2)"}
         rdm = {"bound": "hbm", "kernel": "k_decode_match", "alg_bytes_per_launch": dm_alg, "avg_launch_ms": dm_ms,
@@ -1305,7 +1309,8 @@ def main():
         per_rank_sample = max(min(args.cpu_sample, total) // world, 1)
         per = args.sample_per_slice or max(1, min(per_rank_sample, E) // args.sample_slices)
         base_cpu, pinfo, arrays, ranges = oracle_sample_check(np, torch, ctmr, synth, N, cfg, dup_permille, issuers, filt, now, dev,
-                                                              first, E, d_off, d_pay, d_iss, d_et, d_rec, args.sample_slices, per)
+                                                              first, E, d_off, d_pay, d_iss, d_et, d_rec, args.sample_slices, per,
+                                                              profile=args.profile)
         mism = np.array([pinfo["status_mismatches"], pinfo["was_unknown_mismatches"], pinfo["entries_of_this_shard"],
                          pinfo["known_duplicates"]], np.uint64)
         if world > 1:
@@ -1348,7 +1353,7 @@ def main():
                 arrays_mt = (pay_mt.numpy(), offs_mt, d_iss[:sample_mt].cpu().numpy().astype(np.uint32))
                 best = None
                 for _ in range(3):
-                    v, dt_mt, npass = cpu_baseline_threads(arrays_mt, issuers, filt, now, sample_mt, threads)
+                    v, dt_mt, npass = cpu_baseline_threads(arrays_mt, issuers, filt, now, sample_mt, threads, args.profile)
                     if best is None or v > best[0]:
                         best = (v, dt_mt, npass)
                 ok_mt = best[2] == int((d_rec.view(-1, 32)[:sample_mt, 0] == 0).sum().item())
@@ -1372,10 +1377,10 @@ def main():
                  "issuer names, one GeneralizedTime in four): the lanes of a wave do not walk identical layouts", ["--mixed"]),
                 ("aligned128", 0, 128, "the headline corpus with every certificate laid at a multiple of 128 bytes (an entry view; "
                  "the payload grows by the padding): the front window of a certificate then starts on a line boundary", ["--aligned", "128"]),
-                ("reference_profile", 0, 0, "the headline batch under ctmr_set_profile(CTMR_PROFILE_REFERENCE): strict_spki + strict_leaf + "
-                 "strict_strings + strict_extensions — every rule the reference's x509.ParseCertificate is known to apply, the "
-                 "subjectAltName walked element by element; same results on this (well-formed) corpus, the price of the rules in "
-                 "map_ms and traffic", ["--profile", "reference"]))
+                ("fast_profile", 0, 0, "the headline batch under ctmr_set_profile(CTMR_PROFILE_FAST), the opt-in of a host that has "
+                 "already parsed its certificates: strict_spki only — extension bodies, Name character sets and the subjectAltName "
+                 "are skipped by length (looser than the reference on malformed ones); same results on this (well-formed) corpus",
+                 ["--profile", "fast"]))
         headline_profile = args.profile
         for name, profile, align, what, leg_args in legs:
             try:
@@ -1387,7 +1392,7 @@ def main():
                 lcfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
                                     ca_permille=10, expired_permille=10, profile=profile)
                 args.aligned = align
-                args.profile = "reference" if name == "reference_profile" else headline_profile
+                args.profile = "fast" if name == "fast_profile" else headline_profile
                 eng, d_off, d_pay, d_iss, d_et, d_rec, d_new = setup(0, E, lcfg)
                 mms, mst = [], None
                 for k in range(1 + 3):
@@ -1410,16 +1415,17 @@ def main():
                        "note": "step = table clear + one map/reduce call, host-timed like the headline",
                        "map_ms": m_map, "mean_der_bytes": l_bytes / E, "n_new": int(mst.n_new),
                        "frac_algorithmic": m_alg / (m_map * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "frac": None}
-                if name == "reference_profile":
-                    sec["same_results_as_the_fast_profile"] = bool(int(mst.n_new) == int(stats.n_new) and
+                if name == "fast_profile":
+                    sec["same_results_as_the_reference_profile"] = bool(int(mst.n_new) == int(stats.n_new) and
                                                                    [int(x) for x in mst.by_status] == [int(x) for x in stats.by_status])
                 if align:
                     sec["payload_bytes_per_entry_with_padding"] = raw_view["aligned"][1] / E
                     sec["same_results_as_the_packed_layout"] = bool(int(mst.n_new) == int(stats.n_new) and
                                                                     [int(x) for x in mst.by_status] == [int(x) for x in stats.by_status])
                 if args.traffic == "auto":
-                    targs = argparse.Namespace(**dict(vars(args), aligned=0, profile="fast"))
-                    mt, merr = measure_traffic(targs, min(E, args.traffic_entries), [kname], leg_args)
+                    targs = argparse.Namespace(**dict(vars(args), aligned=0))
+                    mt, merr = measure_traffic(targs, min(E, args.traffic_entries), [kname],
+                                               leg_args if name == "fast_profile" else leg_args + ["--profile", headline_profile])
                     if mt:
                         sec["traffic_bytes_per_cert"] = mt["traffic_bytes_per_cert"]
                         sec["traffic"] = mt["traffic_bytes_per_cert"] * E
@@ -1431,6 +1437,45 @@ def main():
                 out["secondary"][name] = {"error": str(ex)}
         args.aligned = 0
         args.profile = headline_profile
+        # raw_reference (round 6, VERDICT r05 #4a): the step IN FRONT of the path under the same profile — raw get-entries
+        # buffers through LogEntryFromLeaf's decode (with strict_leaf: the leaf TBSCertificate of every precertificate entry
+        # walked), the exact Chain[0] match and the map.  Decode parity with CT-go stays UNPINNED (no raw-entry vector in
+        # the reference): the leg is a measurement, not a parity claim.
+        try:
+            if eng is not None:
+                eng.close()
+            eng = d_off = d_pay = d_iss = d_et = d_rec = d_new = None
+            raw_view.clear()
+            torch.cuda.empty_cache()
+            E_raw = min(E, int(os.environ.get("CTMR_BENCH_RAW_ENTRIES", 20_000_000)))
+            args.raw = True
+            rcfg = synth.config(seed=20260921 + 4, n_issuers=args.issuers, zipf=1, dup_permille=dup_permille,
+                                ca_permille=10, expired_permille=10, profile=0)
+            eng, r_bounds, r_blob, r_ts, _, r_rec, r_new = setup(0, E_raw, rcfg)
+            rms = []
+            for k in range(1 + 3):
+                torch.cuda.synchronize()
+                t0r = time.perf_counter()
+                eng.reset_known()
+                rds = eng.decode_entries_device(r_blob.data_ptr(), r_bounds.data_ptr(), E_raw, raw_view["view"])
+                rst = eng.map_view_device(r_blob.data_ptr(), raw_view["blob_bytes"], raw_view["view"], E_raw, r_rec.data_ptr(),
+                                          r_new.data_ptr())
+                if k:
+                    rms.append((time.perf_counter() - t0r, rds.ms_decode, rds.ms_match, rst.ms_map))
+            r_step = sum(t[0] for t in rms) / len(rms)
+            out["secondary"]["raw_reference"] = {
+                "workload": f"{E_raw} RAW get-entries ({raw_view['blob_bytes'] / E_raw:.0f} B/entry) under the {headline_profile} profile: "
+                            "leaf TBSCertificate walk of the precertificate entries (strict_leaf) + LogEntryFromLeaf decode + exact "
+                            "Chain[0] match + map/reduce; issuers registered by the engine",
+                "value": E_raw / r_step, "unit": "entries/sec", "ms_per_step": r_step * 1e3, "steps": len(rms),
+                "kernel_ms": {"leaf_tbs_check": sum(t[1] for t in rms) / len(rms), "decode_match": sum(t[2] for t in rms) / len(rms),
+                              "map": sum(t[3] for t in rms) / len(rms)},
+                "n_new": int(rst.n_new), "by_status": [int(x) for x in rst.by_status],
+                "parity_note": "decode parity with CT-go's LogEntryFromLeaf is UNPINNED (the reference holds no raw-entry vector)"}
+            del r_bounds, r_blob, r_ts, r_rec, r_new
+        except (ctmr.CtmrError, RuntimeError) as ex:
+            out["secondary"]["raw_reference"] = {"error": str(ex)}
+        args.raw = False
     if rank == 0:
         print(json.dumps(out))
     if group is not None:

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CTMR_LIB") or os.path.join(HERE, "libctmr.so")
 ST_PASS, ST_PARSE_ERROR, ST_FILTERED_CA, ST_FILTERED_EXPIRED, ST_FILTERED_CN, ST_NO_ISSUER, \
     ST_ISSUER_PARSE_ERROR, ST_ENTRY_DECODE_ERROR = range(8)
 ST_COUNT = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 CHAIN0_EXACT, CHAIN0_TRUSTED_LOG = 0, 1
 PROFILE_FAST, PROFILE_REFERENCE = 0, 1
 ENTRY_INVALID = 0xFF

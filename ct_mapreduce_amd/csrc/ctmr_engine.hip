@@ -217,10 +217,12 @@ struct ctmr_engine {
   std::unordered_map<std::string, uint32_t> der_to_idx;  // first registration of each distinct certificate
   bool auto_register = true;               // raw-entry calls register unseen Chain[0] certificates themselves
   int chain0_mode = CTMR_CHAIN0_EXACT;     // ctmr_set_chain0_match
-  bool strict_ext = false;                 // ctmr_set_strict_extensions: extension bodies Go unmarshals (fatal)
-  bool strict_strings = false;             // ctmr_set_strict_strings: character sets of the Names' string values (non-fatal finding)
+  // ctmr_create = CTMR_PROFILE_REFERENCE (round 6): all four switches on — what the reference does; ctmr_set_profile(e,
+  // CTMR_PROFILE_FAST) is the opt-in of a host that has parsed already
+  bool strict_ext = true;                  // ctmr_set_strict_extensions: extension bodies Go unmarshals (fatal)
+  bool strict_strings = true;              // ctmr_set_strict_strings: character sets of the Names' string values (non-fatal finding)
   bool strict_spki = true;                 // ctmr_set_strict_spki: parsePublicKey's verdict on the key inside subjectPublicKeyInfo (spki_key.h)
-  bool strict_leaf = false;                // ctmr_set_strict_leaf: parse the leaf TBSCertificate of precertificate entries
+  bool strict_leaf = true;                 // ctmr_set_strict_leaf: parse the leaf TBSCertificate of precertificate entries
   uint64_t meta_precheck_n = 0;            // entries of the last map call whose ent[] carries the memo pre-check (0 = none)
   const uint32_t* meta_precheck_ent = nullptr;
   std::unordered_map<unsigned long long, uint32_t> qh_first;  // (upper half of the candidate hash, length) → table slot of the first registered certificate with it

@@ -47,11 +47,12 @@ __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uin
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
   DevBytes b{blob};
-  uint64_t lo = 0;
+  uint64_t lo = 0, l0 = 0;
   uint32_t len = 0;
   bool pre = false;
   if (i < n) {
-    const uint64_t l0 = bounds[2 * i], l1 = bounds[2 * i + 1];
+    l0 = bounds[2 * i];
+    const uint64_t l1 = bounds[2 * i + 1];
     // MerkleTreeLeaf: version(1) leaf_type(1) timestamp(8) entry_type(2) | issuer_key_hash(32) | TBSCertificate<1..2^24-1>
     if (l1 >= l0 + 47u && b.u8(l0 + 1) == 0u && b.be(l0 + 10, 2) == 1u) {
       len = b.be(l0 + 44, 3);
@@ -59,11 +60,14 @@ __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uin
       pre = len != 0u && lo + len <= l1;  // anything else is the decoder's business
     }
   }
-  const uint64_t g_me = pre ? (lo & ~15ull) : ~0ull;
-  coop_fill<false>(blob, limit, g_me, lane);
+  const WaveBuf wb = wave_buf(blob, limit, l0);  // lane 0's entry: the blob's entries ascend
+  const uint32_t lrel = wave_rel(wb, lo, pre);
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~15u);
+  coop_fill<false>(wb, w_me, lane);
   bool ok = true;
   if (pre) {
-    WinReaderC<16> r{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)), (int32_t)(int64_t)(g_me - lo)}};
+    WinReaderC<16> r{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)),
+                      lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}};
     Walk w;
     ok = walk_tbs(r, len, w, strict_spki != 0u, strict_ext != 0u);
   }

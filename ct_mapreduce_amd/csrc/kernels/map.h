@@ -180,12 +180,15 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   const uint64_t limit = map_limit(a);
   uint64_t lo = 0, hi = 0;
   if (live) cert_range(a.offsets, a.ends, i, lo, hi);
-  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
-  coop_fill<false>(a.payload, limit, g_me, lane);
+  const WaveBuf wb = wave_buf(a.payload, limit, lo);  // (lane 0 is live whenever the workgroup exists: k_map_fused)
+  const uint32_t lrel = wave_rel(wb, lo, live);
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~15u);
+  coop_fill<false>(wb, w_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   if (live) {
+    // (out of the descriptor's reach: a window that holds nothing — every read takes this reader's global-memory path)
     WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
-                       (int32_t)(int64_t)(g_me - lo)}};
+                       lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}};
     map_one<STRICT>(r, hi - lo, i, a, o0, o1);
   }
   store_records_wave(a, first, live, o0, o1);

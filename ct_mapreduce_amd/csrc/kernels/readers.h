@@ -25,85 +25,108 @@ __device__ __forceinline__ void st_stream16(uint4* p, const uint4& v) {
   __builtin_nontemporal_store(t, (ctmr_u32x4*)p);
 }
 // ------------------------------------------------------------------ the per-lane LDS windows of one wave
-// One wave per workgroup; lane c owns a 256-byte window (16 chunks of 16 bytes) at smem + win_off(c).
-//   default        lane stride 272 bytes (16-B aligned for ds_write_b128, ≤ 4-way bank conflicts on equal in-window
-//                  offsets), filled through registers: 16 global_load_dwordx4 → 16 ds_write_b128 per lane
-//   CTMR_WIN_GLDS  (experiment, round 3) filled by LDS-DMA — global_load_lds_dwordx4 writes M0 + lane·16, i.e. ONE
-//                  instruction fills four whole windows that must be contiguous: groups of 4 windows (1 KiB) + 16 B
-//                  pad per group (the same 4-way conflict class as the default), no staging registers, no ds_write pass
+// One wave per workgroup; lane c owns a 256-byte window (16 chunks of 16 bytes) at smem + win_off(c): lane stride 272
+// bytes (16-B aligned for ds_write_b128, ≤ 4-way bank conflicts on equal in-window offsets), filled through registers:
+// 16 buffer_load_dwordx4 → 16 ds_write_b128 per lane.
+// (Round 3's LDS-DMA variant of the fill — CTMR_WIN_GLDS, global_load_lds_dwordx4 — measured no gain and left the tree in
+//  round 6 together with the 64-bit address arithmetic it shared with the fill below: EXPERIMENTS.md.)
 extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-#ifdef CTMR_WIN_GLDS
-constexpr uint32_t WIN_GROUP = 4u * 256u + 16u;
-constexpr uint32_t WIN_LDS_BYTES = 16u * WIN_GROUP;
-__device__ __forceinline__ uint32_t win_off(uint32_t c) { return (c >> 2) * WIN_GROUP + (c & 3u) * 256u; }
-typedef __attribute__((address_space(1))) const void* ctmr_gptr;
-typedef __attribute__((address_space(3))) void* ctmr_lptr;
-#else
 constexpr uint32_t WIN_STRIDE = 16u * 16u + 16u;
 constexpr uint32_t WIN_LDS_BYTES = 64u * WIN_STRIDE;
 __device__ __forceinline__ uint32_t win_off(uint32_t c) { return c * WIN_STRIDE; }
-#endif
+
+// Round 6: the wave's view of the payload as ONE buffer descriptor (SRSRC in scalar registers) whose base is the 128-byte
+// line of the wave's first certificate, so that every window position of every lane is a 32-BIT offset from it.  Rounds
+// 1-5 carried 64-bit payload offsets through the fills: per 16-byte chunk two ds_bpermute (the 64-bit window start of the
+// certificate the chunk belongs to), two 64-bit adds, two 64-bit compares against the payload's end, an exec-mask branch
+// around the load and four v_mov to zero the chunk when it lay beyond — 13 vector + 5 scalar instructions per chunk, and
+// an s_waitcnt on every shuffle before its load could issue (≈ 200 + 100 instructions and ≈ 1 000 cycles per fill; two
+// fills per certificate in the fast profile, five in the reference profile).  With the descriptor the hardware does the
+// range check (a load at or beyond num_records returns zeros): one ds_bpermute, one add and one buffer_load per chunk, all
+// sixteen shuffles in flight before the first load.
+// REL_NONE: "no window" — beyond every num_records (≤ 2^31 − 1), so such a chunk loads as zeros.
+constexpr uint32_t REL_NONE = 0x80000000u;
+constexpr uint64_t REL_SPAN = 0x7e000000ull;  // certificates farther than this from the wave's base take the exact reader
+struct WaveBuf {
+  __amdgpu_buffer_rsrc_t rs;  // base = payload + b128; num_records = min(limit − b128, 2^31 − 1)
+  uint64_t b128;              // payload offset of the base: wave-uniform, a multiple of 128
+};
+// lo0: a payload offset at or below every certificate of the wave IN THE FIRST ACTIVE LANE (a packed batch, a decoded
+// get-entries blob: the first lane's own certificate — offsets ascend); other lanes' values are not looked at.  A lane
+// whose certificate lies below it or ≥ REL_SPAN beyond (a caller-made entry view in no order) gets REL_NONE from
+// wave_rel() and is handed to the exact reader by its kernel.
+__device__ __forceinline__ WaveBuf wave_buf(const uint8_t* payload, uint64_t limit, uint64_t lo0) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)lo0), h = __builtin_amdgcn_readfirstlane((uint32_t)(lo0 >> 32));
+  const uint64_t b128 = (((uint64_t)h << 32) | l) & ~127ull;
+  uint64_t span = limit > b128 ? limit - b128 : 0ull;
+  span = span > 0x7fffffffull ? 0x7fffffffull : span;
+  return WaveBuf{__builtin_amdgcn_make_buffer_rsrc((void*)(payload + b128), 0, (int)span, 0x00020000), b128};
+}
+// the certificate at payload offset lo as an offset from the wave's base (REL_NONE: out of the descriptor's reach)
+__device__ __forceinline__ uint32_t wave_rel(const WaveBuf& wb, uint64_t lo, bool has) {
+  const uint64_t d = lo - wb.b128;
+  return (has & (lo >= wb.b128) & (d < REL_SPAN)) ? (uint32_t)d : REL_NONE;
+}
+__device__ __forceinline__ uint4 ld_chunk(const WaveBuf& wb, uint32_t off) {  // non-temporal, like ld_payload16
+  const ctmr_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wb.rs, (int)off, 0, 2 /* nt */);
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
 
 // Wave-cooperative fill of all 64 windows: instead of every lane issuing 16 loads of ITS certificate (64 uncoalesced
 // 16-byte requests per instruction), 16 adjacent lanes fetch the 16 chunks of one certificate's window, 4 certificates
-// per instruction — the texture addresser sees 8 lanes per 128-byte line.  g_me = this lane's 16-byte aligned window
-// start in the payload (~0: no certificate); bytes at or beyond `limit` read as zero (GLDS: as whatever lies below).
+// per instruction — the texture addresser sees 8 lanes per 128-byte line.  w_me = this lane's 16-byte aligned window
+// start as an offset from the wave's base (REL_NONE: no certificate — its window fills with zeros); bytes at or beyond
+// the payload's readable end read as zero.
 // BARRIER_BEFORE_STORES: the windows are being re-filled (every lane must be done reading the old contents).
 template <bool BARRIER_BEFORE_STORES>
-__device__ __forceinline__ void coop_fill(const uint8_t* payload, uint64_t limit, uint64_t g_me, uint32_t lane) {
-  const uint32_t sub = lane & 15u;
-#ifdef CTMR_WIN_GLDS
-  if (BARRIER_BEFORE_STORES) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my own ds_reads of the old window have returned
-    __builtin_amdgcn_wave_barrier();
-  }
-#pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
-    uint64_t at = g + 16u * sub;
-    at = (g != ~0ull && at + 16u <= limit) ? at : 0ull;  // LDS-DMA cannot zero-fill: read SOMETHING readable instead
-    __builtin_amdgcn_global_load_lds((ctmr_gptr)(payload + at), (ctmr_lptr)(smem + it * WIN_GROUP), 16, 0, 2 /* nt */);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hipcc does not count LDS-DMA: the data has landed after this …
-  __builtin_amdgcn_wave_barrier();                   // … for every lane of the (single-wave) workgroup
-#else
+__device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
+  const uint32_t sub16 = (lane & 15u) * 16u;
+  uint32_t o[16];
   uint4 v[16];
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
-    const uint64_t at = g + 16u * sub;
-    v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(payload + at)) : make_uint4(0, 0, 0, 0);
-  }
+  for (int it = 0; it < 16; it++) o[it] = __shfl(w_me, 4 * it + (int)(lane >> 4));
+#pragma unroll
+  for (int it = 0; it < 16; it++) v[it] = ld_chunk(wb, o[it] + sub16);
   if (BARRIER_BEFORE_STORES) __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int it = 0; it < 16; it++)
-    *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + 16u * sub) = v[it];
+    *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + sub16) = v[it];
   __builtin_amdgcn_wave_barrier();
-#endif
 }
 
-// The same for SOME windows (der_walk.h ext_san_coop: the lanes still walking a subjectAltName): a lane whose g_me is ~0
-// keeps its window as it is.
-__device__ __forceinline__ void coop_refill_some(const uint8_t* payload, uint64_t limit, uint64_t g_me, uint32_t lane) {
-  const uint32_t sub = lane & 15u;
+// The same for SOME windows (der_walk.h ext_san_coop: the lanes still walking a subjectAltName): a lane whose w_me is
+// REL_NONE keeps its window as it is (its chunks load as zeros — no memory access — and are not stored).
+__device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
+  const uint32_t sub16 = (lane & 15u) * 16u;
+  uint32_t o[16];
   uint4 v[16];
-  unsigned take = 0u;
 #pragma unroll
-  for (int it = 0; it < 16; it++) {
-    const uint64_t g = __shfl(g_me, 4 * it + (int)(lane >> 4));
-    const uint64_t at = g + 16u * sub;
-    take |= (g != ~0ull ? 1u : 0u) << it;
-    v[it] = (g != ~0ull && at + 16u <= limit) ? ld_payload16((const uint4*)(payload + at)) : make_uint4(0, 0, 0, 0);
-  }
+  for (int it = 0; it < 16; it++) o[it] = __shfl(w_me, 4 * it + (int)(lane >> 4));
+#pragma unroll
+  for (int it = 0; it < 16; it++) v[it] = ld_chunk(wb, o[it] + sub16);
   __builtin_amdgcn_wave_barrier();  // every lane is done reading the old contents
 #pragma unroll
   for (int it = 0; it < 16; it++)
-    if ((take >> it) & 1u) *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + 16u * sub) = v[it];
+    if (o[it] != REL_NONE) *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + sub16) = v[it];
   __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------ byte readers
 // ld4(pos): 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
+// Round 6: inside an LDS window it is ONE ds_read_b32 at the byte address itself — gfx950 runs with unaligned LDS access
+// enabled (hipcc itself emits ds_read_b32 / ds_read_u16 for align-1 pointers; scripts/probe_lds_unaligned.hip checks the
+// hardware's answer) — instead of ds_read2_b32 + v_alignbyte + the shift and mask that fed them: three vector
+// instructions less on each of the walk's ≈ 90 reads.  -DCTMR_LDS_ALIGNED_ONLY restores the two-dword form (A/B builds).
+typedef uint32_t __attribute__((aligned(1))) ctmr_u32_u;
+typedef uint16_t __attribute__((aligned(1))) ctmr_u16_u;
+__device__ __forceinline__ uint32_t lds_ld4(const uint32_t* win, uint32_t rel) {
+#ifdef CTMR_LDS_ALIGNED_ONLY
+  const uint32_t i = rel >> 2;
+  return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
+#else
+  return *(const ctmr_u32_u*)((const uint8_t*)win + rel);
+#endif
+}
 struct GlobalReader {
   const uint32_t* words;  // 4-byte aligned base of the buffer (kernel argument: global address space)
   uint64_t base;          // byte offset of this certificate inside the buffer
@@ -133,14 +156,18 @@ struct WinReader {
   uint64_t limit;       // readable bytes of payload (offsets[n] + CTMR_PAYLOAD_PAD)
   uint32_t* win;        // this lane's window words in LDS
   int32_t grel;         // window start relative to the certificate start; (base+grel) % 16 == 0
+  // round 6 (set by the kernel behind the constructor): the wave's buffer descriptor and this certificate's start as an
+  // offset from its base (REL_NONE: out of reach — cooperative fills leave such a lane's window alone / zero)
+  WaveBuf wb;
+  uint32_t lrel;
   static constexpr uint32_t WBYTES = WCH * 16;
+  __device__ __forceinline__ uint32_t wrel(uint32_t pos, uint32_t align) const {  // window start for [pos, …), from the wave's base
+    return lrel == REL_NONE ? REL_NONE : ((lrel + pos) & ~(align - 1u));
+  }
 
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     const uint32_t rel = pos - (uint32_t)grel;
-    if (rel <= WBYTES - 8u) {
-      const uint32_t i = rel >> 2;
-      return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
-    }
+    if (rel <= WBYTES - 8u) return lds_ld4(win, rel);
     const uint64_t a = base + pos;
     const uint64_t i = a >> 2;
     return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
@@ -148,7 +175,7 @@ struct WinReader {
   __device__ __forceinline__ RawCert raw() const { return RawCert{g32, base}; }  // spki_key.h: the out-of-line key checks
   // spki_key.h key_reader_of: a snapshot of this base reader, by value (window hit, else a plain global load; none of the
   // derived readers' miss bookkeeping)
-  __device__ __forceinline__ WinReader<WCH> key_bytes() const { return WinReader<WCH>{g32, base, limit, win, grel}; }
+  __device__ __forceinline__ WinReader<WCH> key_bytes() const { return WinReader<WCH>{g32, base, limit, win, grel, wb, lrel}; }
   __device__ __forceinline__ uint32_t ldg(uint32_t pos) const {  // straight from global memory
     const uint64_t a = base + pos;
     const uint64_t i = a >> 2;
@@ -185,17 +212,34 @@ struct WinReaderC : WinReader<WCH> {
       this->refill(pos);
       return;
     }
-    const uint64_t g_me = (this->base + pos) & ~15ull;
-    this->grel = (int32_t)(int64_t)(g_me - this->base);
-    coop_fill<true>((const uint8_t*)this->g32, this->limit, g_me, threadIdx.x & 63u);
+    const uint32_t w = this->wrel(pos, 16u);
+    if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
+    coop_fill<true>(this->wb, w, threadIdx.x & 63u);
   }
   // der_walk.h ext_san_coop — wave-collective (every lane of a WHOLE wave calls it from converged code): the lanes that
   // `want` get their window refilled at pos, 16 lanes per certificate as above; the others keep theirs.
   __device__ __forceinline__ void coop_refill(uint32_t pos, bool want) {
-    const uint64_t g_me = want ? (this->base + pos) & ~15ull : ~0ull;
-    if (want) this->grel = (int32_t)(int64_t)(g_me - this->base);
-    coop_refill_some((const uint8_t*)this->g32, this->limit, g_me, threadIdx.x & 63u);
+    const uint32_t w = want ? this->wrel(pos, 16u) : REL_NONE;
+    if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
+    coop_refill_some(this->wb, w, threadIdx.x & 63u);
   }
+  // … the same with the window starting on a 128-byte LINE of the payload: two whole lines, the next round's window begins
+  // where this one ends (der_walk.h ext_san_coop, round 6)
+  __device__ __forceinline__ void coop_refill_lines(uint32_t pos, bool want) {
+    const uint32_t w = want ? this->wrel(pos, 128u) : REL_NONE;   // (the wave's base is a multiple of 128: so is the line)
+    if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
+    coop_refill_some(this->wb, w, threadIdx.x & 63u);
+  }
+  // the two octets at pos, which the caller knows to lie in the window (holds): two byte reads, no alignment arithmetic
+  __device__ __forceinline__ uint32_t ld2(uint32_t pos) const {
+    const uint8_t* b = (const uint8_t*)this->win + (pos - (uint32_t)this->grel);
+#ifdef CTMR_LDS_ALIGNED_ONLY
+    return (uint32_t)b[0] | ((uint32_t)b[1] << 8);
+#else
+    return *(const ctmr_u16_u*)b;
+#endif
+  }
+  __device__ __forceinline__ uint32_t wend() const { return (uint32_t)this->grel + WinReader<WCH>::WBYTES; }  // certificate offset of the window's end
   __device__ __forceinline__ bool holds(uint32_t pos, uint32_t need) const {  // [pos, pos + need) lies in the window
     return pos - (uint32_t)this->grel <= WinReader<WCH>::WBYTES - need;
   }
@@ -220,7 +264,10 @@ struct NoRefillHook {
 template <int WCH, class Hook = NoRefillHook>
 struct WinReaderS : WinReaderC<WCH> {
   static constexpr bool kNoClamp = true;  // ld4 clamps into the window itself
+  // `miss` holds the LARGEST window-relative offset any read asked for (round 6: one v_max per read instead of compare +
+  // select + or); missed() = some read lay outside the window.  Constructed with 0 (or ~0: no window at all).
   mutable uint32_t miss;
+  __device__ __forceinline__ bool missed() const { return miss > WinReader<WCH>::WBYTES - 8u; }
   // The 32 bytes behind the TBSCertificate (signatureAlgorithm, the signatureValue header, its pad octet), fetched
   // by touch_tail() TOGETHER with the extension-block refill: the three ldg() reads at the end of the walk were
   // three dependent, uncoalesced global round trips per wave; now they are register selects.
@@ -234,13 +281,12 @@ struct WinReaderS : WinReaderC<WCH> {
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     uint32_t rel = pos - (uint32_t)this->grel;
     constexpr uint32_t LAST = WinReader<WCH>::WBYTES - 8u;
-    miss |= (uint32_t)(rel > LAST);
+    miss = rel > miss ? rel : miss;
     rel = rel > LAST ? LAST : rel;
-    const uint32_t i = rel >> 2;
-    return __builtin_amdgcn_alignbyte(this->win[i + 1], this->win[i], rel & 3u);
+    return lds_ld4(this->win, rel);
   }
   // der_walk.h (strict_extensions): the contents of this element are read octet by octet — not through the window
-  __device__ __forceinline__ void defer_exact() { miss |= 1u; }
+  __device__ __forceinline__ void defer_exact() { miss = 0xffffffffu; }
   __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t tail) {
     const uint64_t ta = this->base + tail;
     const bool have = ta + 32u <= this->limit;

@@ -411,8 +411,12 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
         hour_row = mc.hour_pages[canon / META_HOUR_PAGE] + (uint64_t)(canon % META_HOUR_PAGE) * (META_HOUR_BITS / 32);
     }
   }
-  const uint64_t g_me = live ? (lo & ~15ull) : ~0ull;
-  coop_fill<false>(a.payload, limit, g_me, lane);
+  // the wave's buffer descriptor (readers.h): its base is lane 0's certificate — the lowest of a packed batch or a decoded
+  // blob; lane 0 is live whenever the workgroup exists — and every window position is a 32-bit offset from it
+  const WaveBuf wb = wave_buf(a.payload, limit, lo);
+  const uint32_t lrel = wave_rel(wb, lo, live);
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~15u);
+  coop_fill<false>(wb, w_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   unsigned long long kmeta = 0ull, ks[5] = {0ull, 0ull, 0ull, 0ull, 0ull};  // the entry's key, for its arena cell
   bool keyed = false;
@@ -423,8 +427,11 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   bool pending = false;
   if (live) {
     using Hook = typename std::conditional<META, MetaHook, NoRefillHook>::type;
+    // (a certificate out of the descriptor's reach — an entry view in no order — has no window: every read misses, and the
+    //  exact reader below decides)
     WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
-                              (int32_t)(int64_t)(g_me - lo)}}, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
+                              lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}},
+                            lrel == REL_NONE ? 0xffffffffu : 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
     if constexpr (META) {
       r.hook.mc = mc;
       r.hook.canon = canon;
@@ -433,7 +440,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
     }
     uint2 ml = make_uint2(META_NONE, META_NONE);
     map_one<STRICT>(r, hi - lo, i, a, in, o0, o1, &ml, &keypos);
-    if (r.miss) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
+    if (r.missed()) {  // some access left the window: the exact reader decides (rare: hostile or odd layouts)
       GlobalReader g{(const uint32_t*)a.payload, lo};
       map_one<STRICT>(g, hi - lo, i, a, in, o0, o1, nullptr, &keypos);
     }
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
     MetaTail mt;
     bool meta_try = false;
     if constexpr (META) {
-      meta_try = mc.enabled && status == CTMR_ST_PASS && !r.miss && ml.x != META_NONE && ml.x != META_HOST && r.hook.dn_seen;
+      meta_try = mc.enabled && status == CTMR_ST_PASS && !r.missed() && ml.x != META_NONE && ml.x != META_HOST && r.hook.dn_seen;
       if (meta_try)
         mt = meta_tail_issue(mc, crl_ref, hour_row, (int32_t)o0.y, ml.y, r.win, r.grel, WinReader<WCH>::WBYTES - 8u);
     }

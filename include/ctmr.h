@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTMR_ABI_VERSION 6
+#define CTMR_ABI_VERSION 7
 
 enum {
   CTMR_OK = 0,
@@ -471,7 +471,8 @@ typedef struct {
   uint64_t n_no_chain;        /* decoded entries with len(Chain) < 1 */
   uint64_t n_issuers_added;   /* distinct Chain[0] certificates this call registered */
   uint64_t blob_bytes;        /* bounds[2n] - bounds[0] */
-  float ms_decode, ms_match;  /* filled when config.profile; decode and the first match round run as one kernel: ms_decode = 0, ms_match = both */
+  float ms_decode, ms_match;  /* filled when config.profile; decode and the first match round run as one kernel: ms_match = both;
+                                 ms_decode = what runs in front of it: strict_leaf's TBSCertificate walk (k_leaf_tbs_check), else ≈ 0 */
 } ctmr_decode_stats;
 
 int ctmr_decode_entries_device(ctmr_engine* e, const uint8_t* d_blob, const uint64_t* d_bounds, uint64_t n,
@@ -500,7 +501,7 @@ int ctmr_wait_entries(ctmr_engine* e, ctmr_ticket ticket, ctmr_record* records, 
  * ascending log index of first appearance) — for hosts that must keep the issuer tables of several engines
  * identical (multi-GPU key exchange: DESIGN.md §8): gather the pending lists of all ranks, register the union in
  * one agreed order with ctmr_add_issuers on every rank, call again. */
-/* strict_extensions (opt-in, default off; part of CTMR_PROFILE_REFERENCE).  Go 1.13's crypto/x509 parseCertificate parses
+/* strict_extensions (ON by default since ABI v7: part of CTMR_PROFILE_REFERENCE, the engine's default).  Go 1.13's crypto/x509 parseCertificate parses
  * the VALUE of the extensions it knows and fails the certificate when that fails; with on != 0 the walk does the same:
  *   by plain encoding/asn1 struct rules, each filling its OCTET STRING ("trailing data") — keyUsage (one BIT STRING),
  *     subjectKeyIdentifier (one OCTET STRING), extKeyUsage (SEQUENCE OF OID), authorityKeyIdentifier (SEQUENCE with an
@@ -518,7 +519,8 @@ int ctmr_wait_entries(ctmr_engine* e, ctmr_ticket ticket, ctmr_record* records, 
  * (1.3.6.1.4.1.11129.2.4.2) that does not decode; an INTEGER inside a nameRelativeToCRLIssuer that is not minimally
  * encoded (with strict_strings: also its string values' character sets).
  * These are the standard library's rules plus what is recalled of certificate-transparency-go v1.1.0's changes to them;
- * neither can be verified without CT-go's source — hence a switch.  Set it before the issuers are
+ * neither can be verified without CT-go's source — hence a switch: on = 0 is for a host that has parsed the
+ * certificates already.  Set it before the issuers are
  * registered (a Chain[0] is judged when it is registered). */
 int ctmr_set_strict_extensions(ctmr_engine* e, int on);
 int ctmr_set_issuer_autoregister(ctmr_engine* e, int on);
@@ -543,9 +545,9 @@ int ctmr_pending_issuers(ctmr_engine* e, uint8_t* out, size_t cap, size_t* need,
 int ctmr_set_chain0_match(ctmr_engine* e, int mode);
 /* Precertificate entries: ct.LogEntryFromLeaf (cmd/ct-fetch/ct-fetch.go:452) also parses the TBSCertificate the
  * MerkleTreeLeaf carries (CT-go x509.ParseTBSCertificate) and the downloader drops the entry when that fails fatally
- * (:453-459).  Default (0): the leaf TBSCertificate is length-checked only — identical results on every entry a log
- * that validated its submissions can serve, and one pass less over ≈ 400 bytes of every precertificate entry.
- * on = 1: the raw-entry calls walk it (the certificate walk without the outer wrapper and the signature) before anything
+ * (:453-459).  on = 0 (CTMR_PROFILE_FAST): the leaf TBSCertificate is length-checked only — identical results on every
+ * entry a log that validated its submissions can serve, and one pass less over ≈ 400 bytes of every precertificate entry.
+ * on = 1 (the default since ABI v7): the raw-entry calls walk it (the certificate walk without the outer wrapper and the signature) before anything
  * else looks at the entry; an entry whose leaf TBSCertificate does not parse gets CTMR_ENTRY_INVALID /
  * CTMR_ST_ENTRY_DECODE_ERROR and its Chain[0] is never registered, as in the reference. */
 int ctmr_set_strict_leaf(ctmr_engine* e, int on);
@@ -565,22 +567,24 @@ int ctmr_set_strict_spki(ctmr_engine* e, int on);
  * with an octet outside A-Z a-z 0-9 space ' ( ) + , - . / : = ? (and '*', '&', which it tolerates), a NumericString
  * with anything but digits and space, an IA5String with an octet >= 0x80 and a UTF8String that is not valid UTF-8.
  * certificate-transparency-go's fork of that package is more lenient towards some of these — which, cannot be verified
- * without its source — so the rules are an OPT-IN (default 0: not checked, as in earlier versions) and a violation is
- * filed as a NON-FATAL finding: an X509 entry keeps its certificate, a precertificate and a Chain[0] issuer are
+ * without its source — so the rules are a SWITCH (on by default since ABI v7, as part of the reference profile; 0: not
+ * checked, as in ABI v1-v6's defaults) and a violation is filed as a NON-FATAL finding: an X509 entry keeps its certificate, a precertificate and a Chain[0] issuer are
  * dropped (cmd/ct-fetch/ct-fetch.go:202-209, 221-225, 452-459).  on = 1: the map checks the two Names of every
  * precertificate while its walk holds them (since round 4; a pre-pass over every certificate before); issuers are
  * judged when they are registered (set the switch before registering them). */
 int ctmr_set_strict_strings(ctmr_engine* e, int on);
 /* The accept/reject profile as ONE choice (ABI v6) — what x509.ParseCertificate / ct.LogEntryFromLeaf decide at
  * cmd/ct-fetch/ct-fetch.go:202-209, :221-225, :452-459:
- *   CTMR_PROFILE_FAST       the engine's defaults: strict_spki on; strict_leaf, strict_strings, strict_extensions off — every
- *                           rule whose bytes the path reads anyway.  Looser than the reference on malformed extension
- *                           bodies, Name character sets and the leaf TBSCertificate of precertificate entries; identical
- *                           on everything a CA's encoder and a log that validated its submissions produce.
- *   CTMR_PROFILE_REFERENCE  all four switches on: what the reference does, as far as it can be known without CT-go's
- *                           source (DESIGN.md §3.1 says which rules are recalled from where).  Costs the map the bytes of
- *                           the subjectAltName and a character-set pass over the Names (bench.py --profile reference
- *                           prices it).
+ *   CTMR_PROFILE_REFERENCE  THE DEFAULT of ctmr_create (since ABI v7): all four switches on — what the reference does, as
+ *                           far as it can be known without CT-go's source (DESIGN.md §3.1 says which rules are recalled
+ *                           from where).  The map reads the subjectAltName and checks the Names' character sets; it is
+ *                           what bench.py's headline measures.
+ *   CTMR_PROFILE_FAST       the opt-in of a host that has ALREADY parsed its certificates (or trusts its log to have):
+ *                           strict_spki on; strict_leaf, strict_strings, strict_extensions off — every rule whose bytes
+ *                           the path reads anyway.  Looser than the reference on malformed extension bodies, Name
+ *                           character sets and the leaf TBSCertificate of precertificate entries; identical on everything
+ *                           a CA's encoder and a log that validated its submissions produce (bench.py reports it as
+ *                           secondary.fast_profile).
  * Equivalent to the four ctmr_set_strict_* calls; like them, set it BEFORE the issuers are registered. */
 #define CTMR_PROFILE_FAST 0
 #define CTMR_PROFILE_REFERENCE 1

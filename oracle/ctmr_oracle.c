@@ -599,7 +599,7 @@ static void check_public_key(const uint8_t* d, uint64_t k, uint64_t k_end, orc_c
   if (key != key_small) free(key);
 }
 
-/* strict_extensions (orc_engine_set_strict_extensions; off by default).  Go 1.13 crypto/x509 parseCertificate unmarshals
+/* strict_extensions (orc_engine_set_strict_extensions; ON by default since round 6, like the product).  Go 1.13 crypto/x509 parseCertificate unmarshals
  * the VALUE of some extensions and fails the certificate when that fails — restated here for the ones it parses with plain
  * encoding/asn1 struct rules (each followed by "x509: trailing data after X.509 …" when octets remain):
  *   2.5.29.15 keyUsage               var usageBits asn1.BitString
@@ -608,13 +608,17 @@ static void check_public_key(const uint8_t* d, uint64_t k, uint64_t k_end, orc_c
  *   2.5.29.35 authorityKeyIdentifier struct { Id []byte `asn1:"optional,tag:0"` }
  *   2.5.29.32 certificatePolicies    []struct { Policy asn1.ObjectIdentifier }        (what follows the OID is ignored)
  *   1.3.6.1.5.5.7.1.1 authorityInfoAccess   []struct { Method asn1.ObjectIdentifier; Location asn1.RawValue }
+ *   1.3.6.1.5.5.7.1.11 subjectInfoAccess    the same []accessDescription — CT-go's fork only (round 6; the standard library does
+ *                                           not know the extension).  CT-go also refuses an EMPTY list of either kind
+ *                                           ("x509: empty AuthorityInfoAccess / SubjectInfoAccess extension") — recalled by
+ *                                           the round-5 review and by the author alike, verifiable by neither: modelled as fatal.
  * subjectAltName (URI / IP parsing), nameConstraints and cRLDistributionPoints (nested optional tags) are not restated.
  * Which of these errors CT-go's fork files as non-fatal cannot be verified here: recalled from the standard library, like
  * the string character sets.  Returns 0 = fine / not one of them, else an error site. */
 static int ext_body_site(const uint8_t* d, const uint8_t* oid, uint32_t oid_len, uint64_t o, uint64_t o_end) {
-  static const uint8_t AIA[8] = {0x2b, 0x06, 0x01, 0x05, 0x05, 0x07, 0x01, 0x01};
+  static const uint8_t AIA[7] = {0x2b, 0x06, 0x01, 0x05, 0x05, 0x07, 0x01};  /* id-pe; .1 = AIA, .11 = SIA */
   int arc = (oid_len == 3 && oid[0] == 0x55 && oid[1] == 0x1d) ? oid[2] : -1;
-  int aia = oid_len == 8 && memcmp(oid, AIA, 8) == 0;
+  int aia = oid_len == 8 && memcmp(oid, AIA, 7) == 0 && (oid[7] == 0x01 || oid[7] == 0x0b);
   tlv t;
   if (!(arc == 15 || arc == 14 || arc == 37 || arc == 35 || arc == 32 || aia)) return 0;
   if (!rd_tlv(d, o, o_end, &t)) return 100;                       /* the value is not one well-formed element */
@@ -630,6 +634,7 @@ static int ext_body_site(const uint8_t* d, const uint8_t* oid, uint32_t oid_len,
     if (f.tag == 0x80 && c + f.hl + (uint64_t)f.len > c_end) return 106;
     return 0;
   }
+  if (aia && c == c_end) return 112;                              /* CT-go: "x509: empty …InfoAccess extension" */
   while (c < c_end) {                                             /* SEQUENCE OF */
     tlv e;
     if (!rd_tlv(d, c, c_end, &e)) return 107;
@@ -1111,6 +1116,134 @@ static int ext_nc_site(const uint8_t* d, uint64_t o, uint64_t o_end) {
   return r;
 }
 
+/* RFC 3779 (round 6; CT-go ONLY — x509/rpki.go of certificate-transparency-go v1.1.0, go.mod:10; the standard library does not
+ * know these extensions).  Recalled, not verifiable here: parseRPKIAddrBlocks / parseRPKIASIdentifiers decode the value with
+ * plain (strict) asn1.Unmarshal calls and file EVERY failure with nfe.AddError — non-fatal: an X509 entry keeps its
+ * certificate, a precertificate and a Chain[0] issuer are dropped (ct-fetch.go:202-209,221-225,452-459).
+ *   sbgp-ipAddrBlock 1.3.6.1.5.5.7.1.7: []ipAddressFamily { AddressFamily []byte; Choice asn1.RawValue } filling the value;
+ *     AddressFamily 2 or 3 octets; Choice == 05 00 (inherit), or else []asn1.RawValue whose elements are, by tag NUMBER
+ *     alone, 3 → asn1.BitString (so: universal, primitive, parseBitString) or 16 → struct { Min, Max asn1.BitString };
+ *     any other tag number is a finding.
+ *   sbgp-autonomousSysNum 1.3.6.1.5.5.7.1.8: struct { ASNum RawValue `optional,tag:0`; RDI RawValue `optional,tag:1` }
+ *     filling the value; each present choice's CONTENTS are 05 00 (inherit) or one []asn1.RawValue filling them whose
+ *     elements are, by tag number, 2 → int (universal primitive INTEGER, minimal, at most 8 octets) or 16 → struct { Min, Max int }.
+ * Returns 1 when rpki.go decodes the value without a finding. */
+static int rpki_bit_string(const uint8_t* d, uint64_t p, uint64_t end, uint64_t* after) {  /* a field of type asn1.BitString */
+  tlv t;
+  if (!rd_tlv(d, p, end, &t) || t.tag != 0x03 || !bit_string_ok(d, p + t.hl, t.len)) return 0;
+  *after = p + t.hl + t.len;
+  return 1;
+}
+static int rpki_int(const uint8_t* d, uint64_t p, uint64_t end, uint64_t* after) {  /* a field of type int (64-bit): parseInt64 */
+  tlv t;
+  if (!rd_tlv(d, p, end, &t) || t.tag != 0x02 || check_integer(d, p + t.hl, t.len) != 1 || t.len > 8) return 0;
+  *after = p + t.hl + t.len;
+  return 1;
+}
+static int ext_ipaddr_ok(const uint8_t* d, uint64_t o, uint64_t o_end) {
+  tlv t;
+  if (!rd_tlv(d, o, o_end, &t) || t.tag != 0x30) return 0;
+  if (o + t.hl + (uint64_t)t.len != o_end) return 0;              /* "trailing data after ipAddrBlocks extension" */
+  int good = 1;
+  uint64_t c = o + t.hl;
+  /* pass 1: asn1.Unmarshal(data, &addrBlocks) as a whole — any failure is ONE finding and nothing else is looked at */
+  for (uint64_t q = c; q < o_end;) {
+    tlv f, af, ch;
+    if (!rd_tlv(d, q, o_end, &f) || f.tag != 0x30) return 0;
+    uint64_t x = q + f.hl, x_end = x + f.len;
+    if (!rd_tlv(d, x, x_end, &af) || af.tag != 0x04) return 0;    /* AddressFamily []byte: universal primitive OCTET STRING */
+    if (!rd_tlv(d, x + af.hl + af.len, x_end, &ch)) return 0;     /* Choice RawValue: must be there and fit */
+    q = x_end;
+  }
+  /* pass 2: the loop over the blocks; each finding is filed and the loop goes on — one is enough here */
+  for (uint64_t q = c; q < o_end;) {
+    tlv f, af, ch;
+    rd_tlv(d, q, o_end, &f);
+    uint64_t x = q + f.hl, x_end = x + f.len;
+    rd_tlv(d, x, x_end, &af);
+    uint64_t cp = x + af.hl + af.len;
+    rd_tlv(d, cp, x_end, &ch);
+    q = x_end;
+    if (af.len < 2 || af.len > 3) { good = 0; continue; }
+    if (ch.tag == 0x05 && ch.hl == 2 && ch.len == 0) continue;     /* bytes.Equal(FullBytes, asn1.NullBytes) */
+    if (ch.tag != 0x30) { good = 0; continue; }                    /* []asn1.RawValue: a universal SEQUENCE */
+    uint64_t r = cp + ch.hl, r_end = r + ch.len;
+    int list_ok = 1;
+    for (uint64_t y = r; y < r_end;) {                             /* every element a RawValue that fits, else the Unmarshal fails */
+      tlv e;
+      if (!rd_tlv(d, y, r_end, &e)) { list_ok = 0; break; }
+      y += e.hl + e.len;
+    }
+    if (!list_ok) { good = 0; continue; }
+    for (uint64_t y = r; y < r_end;) {
+      tlv e;
+      uint64_t a;
+      rd_tlv(d, y, r_end, &e);
+      uint64_t e_end = y + e.hl + e.len;
+      const int tn = e.tag & 0x1f;
+      if (tn == 3) {
+        if (!rpki_bit_string(d, y, e_end, &a)) good = 0;
+      } else if (tn == 16) {                                        /* ipAddressRange { Min, Max asn1.BitString } */
+        if (e.tag != 0x30 || !rpki_bit_string(d, y + e.hl, e_end, &a) || !rpki_bit_string(d, a, e_end, &a)) good = 0;
+      } else {
+        good = 0;
+      }
+      y = e_end;
+    }
+  }
+  return good;
+}
+static int rpki_asid_choice_ok(const uint8_t* d, uint64_t c, uint64_t c_end) {  /* parseASIDChoice(val): val.Bytes = [c, c_end) */
+  tlv t;
+  if (c_end - c == 2 && d[c] == 0x05 && d[c + 1] == 0x00) return 1;  /* inherit */
+  if (!rd_tlv(d, c, c_end, &t) || t.tag != 0x30) return 0;
+  if (c + t.hl + (uint64_t)t.len != c_end) return 0;              /* "trailing data after ASIdentifiers.asIdsOrRanges" */
+  uint64_t r = c + t.hl;
+  for (uint64_t y = r; y < c_end;) {
+    tlv e;
+    if (!rd_tlv(d, y, c_end, &e)) return 0;
+    y += e.hl + e.len;
+  }
+  int good = 1;
+  for (uint64_t y = r; y < c_end;) {
+    tlv e;
+    uint64_t a;
+    rd_tlv(d, y, c_end, &e);
+    uint64_t e_end = y + e.hl + e.len;
+    const int tn = e.tag & 0x1f;
+    if (tn == 2) {
+      if (!rpki_int(d, y, e_end, &a)) good = 0;
+    } else if (tn == 16) {                                          /* ASIDRange { Min, Max int } */
+      if (e.tag != 0x30 || !rpki_int(d, y + e.hl, e_end, &a) || !rpki_int(d, a, e_end, &a)) good = 0;
+    } else {
+      good = 0;
+    }
+    y = e_end;
+  }
+  return good;
+}
+static int ext_asnum_ok(const uint8_t* d, uint64_t o, uint64_t o_end) {
+  tlv t, f;
+  if (!rd_tlv(d, o, o_end, &t) || t.tag != 0x30) return 0;
+  if (o + t.hl + (uint64_t)t.len != o_end) return 0;              /* "trailing data after ASIdentifiers extension" */
+  uint64_t off = o + t.hl;
+  int good = 1, have = 0;
+  /* two optional fields in order: at each one the header at the current position must parse unless the contents are used
+   * up; a field of another tag is skipped without consuming anything; a matching one must fit; what follows is ignored */
+  for (int k = 0; k < 2; k++) {
+    if (off == o_end) break;
+    if (!rd_hdr(d, off, o_end, &f)) return 0;
+    if (f.tag == (0x80 | k) || f.tag == (0xa0 | k)) {               /* RawValue `tag:k`: context class, any form */
+      if (off + f.hl + (uint64_t)f.len > o_end) return 0;
+      have |= 1 << k;
+      if (!rpki_asid_choice_ok(d, off + f.hl, off + f.hl + f.len)) good = 0;
+      off += f.hl + f.len;
+    }
+  }
+  (void)have;
+  return good;
+}
+
 /* CT-go only: the embedded SCT list, 1.3.6.1.4.1.11129.2.4.2 — asn1.Unmarshal(value, &RawSCT []byte), no rest, then
  * tls.Unmarshal(RawSCT, &SignedCertificateTimestampList{ SCTList []SerializedSCT `tls:"minlen:1,maxlen:65535"` }) with
  * SerializedSCT{ Val []byte `tls:"minlen:1,maxlen:65535"` }, no rest.  Every failure is an nfe.AddError: non-fatal. */
@@ -1283,6 +1416,10 @@ static void parse_impl(const uint8_t* d, size_t L, orc_cert* out, int tbs_only) 
             if (lax) out->ext_findings |= ORC_XF_LAX;
           }
           else if (oid.len == 10 && memcmp(d + oid_c, SCT, 10) == 0 && !ext_sct_ok(d, o, o_end)) out->ext_findings |= ORC_XF_SCT;
+          else if (oid.len == 8 && memcmp(d + oid_c, "\x2b\x06\x01\x05\x05\x07\x01", 7) == 0 &&
+                   (d[oid_c + 7] == 0x07 || d[oid_c + 7] == 0x08)) {  /* RFC 3779: sbgp-ipAddrBlock, sbgp-autonomousSysNum (CT-go: non-fatal) */
+            if (!(d[oid_c + 7] == 0x07 ? ext_ipaddr_ok(d, o, o_end) : ext_asnum_ok(d, o, o_end))) out->ext_findings |= ORC_XF_RPKI;
+          }
         }
         if (oid.len == 3 && d[oid_c] == 0x55 && d[oid_c + 1] == 0x1d && d[oid_c + 2] == 0x13) {
           /* basicConstraints struct { IsCA bool `optional`; MaxPathLen int `optional,default:-1` } must be the
@@ -1632,7 +1769,7 @@ struct orc_engine {
   size_t filter_len;
   int log_expired;
   int strict_strings; /* the stdlib's character-set rules for the Names' string values, as non-fatal findings (orc_engine_set_strict_strings) */
-  int strict_ext;  /* the bodies of the extensions Go unmarshals (orc_engine_set_strict_extensions; off by default): fatal */
+  int strict_ext;  /* the bodies of the extensions Go unmarshals (orc_engine_set_strict_extensions; ON by default since round 6, like the product): fatal */
   int strict_spki; /* parsePublicKey's verdict on the key inside subjectPublicKeyInfo (orc_engine_set_strict_spki; ON by default) */
   int strict_leaf; /* LogEntryFromLeaf's parse of a precertificate entry's leaf TBSCertificate (orc_engine_set_strict_leaf) */
   int64_t now;
@@ -1649,7 +1786,9 @@ orc_engine* orc_engine_new(const char* filter, size_t filter_len, int log_expire
   e->filter[filter_len] = 0;
   e->filter_len = filter_len;
   e->log_expired = log_expired;
-  e->strict_spki = 1;
+  /* the reference profile — the product's default since round 6 (ctmr_create = CTMR_PROFILE_REFERENCE): what
+   * x509.ParseCertificate / ct.LogEntryFromLeaf decide at cmd/ct-fetch/ct-fetch.go:202-209,221-225,452-459 */
+  e->strict_spki = e->strict_strings = e->strict_ext = e->strict_leaf = 1;
   e->now = now;
   e->k2s_n = 64;
   e->key_to_set = (uint64_t*)calloc(e->k2s_n * 2, sizeof(uint64_t));

@@ -80,6 +80,7 @@ typedef struct {
 #define ORC_XF_SAN_IP 1   /* subjectAltName iPAddress of a length other than 4 or 16 */
 #define ORC_XF_SCT 2      /* the embedded SCT list (1.3.6.1.4.1.11129.2.4.2) does not decode */
 #define ORC_XF_LAX 4      /* an INTEGER inside nameRelativeToCRLIssuer that only the lax re-parse accepts */
+#define ORC_XF_RPKI 8     /* RFC 3779 sbgp-ipAddrBlock / sbgp-autonomousSysNum that CT-go's rpki.go does not decode (round 6) */
 
 #define ORC_SF_PRINTABLE 1
 #define ORC_SF_NUMERIC 2
@@ -202,7 +203,7 @@ void orc_decode_entry(const uint8_t* leaf_input, size_t leaf_len, const uint8_t*
  * ORC_ST_ENTRY_DECODE_ERROR.  out_timestamp may be NULL. */
 /* 1: a precertificate entry whose leaf TBSCertificate does not parse is undecodable (ct.LogEntryFromLeaf, ct-fetch.go:452) */
 void orc_engine_set_strict_leaf(orc_engine*, int on);
-/* Go stdlib character-set rules for the string values of both Names, filed as non-fatal findings (default off) */
+/* Go stdlib character-set rules for the string values of both Names, filed as non-fatal findings (default ON since round 6) */
 void orc_engine_set_strict_strings(orc_engine*, int on);
 /* parsePublicKey's verdict on the key (ON by default: the reference always parses the key); 0 = rounds 1-3 behaviour */
 void orc_engine_set_strict_spki(orc_engine*, int on);

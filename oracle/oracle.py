@@ -200,12 +200,19 @@ class Engine:
     def __init__(self, issuer_cn_filter: bytes = b"", log_expired: bool = False, now: int = 0):
         self._h = lib().orc_engine_new(issuer_cn_filter, len(issuer_cn_filter), int(log_expired), now)
 
+    def set_profile(self, profile):
+        """The four switches at once, like ctmr_set_profile: "reference" (the default: all on) or "fast" (strict_spki only)."""
+        ref = profile in ("reference", 1)
+        self.set_strict_spki(True)
+        for f in (self.set_strict_leaf, self.set_strict_strings, self.set_strict_extensions):
+            f(ref)
+
     def set_strict_leaf(self, on: bool):
         """Precertificate entries: fail the entry when its leaf TBSCertificate does not parse (LogEntryFromLeaf)."""
         lib().orc_engine_set_strict_leaf(self._h, int(bool(on)))
 
     def set_strict_strings(self, on: bool):
-        """Character sets of the Names' string values (Go stdlib rules) as one more non-fatal finding; default off."""
+        """Character sets of the Names' string values (Go stdlib rules) as one more non-fatal finding; default on (the reference profile)."""
         lib().orc_engine_set_strict_strings(self._h, int(bool(on)))
 
     def set_strict_spki(self, on: bool):
@@ -214,7 +221,7 @@ class Engine:
 
     def set_strict_extensions(self, on: bool):
         """The bodies of the extensions Go unmarshals by struct rules (keyUsage, key identifiers, extKeyUsage, policies, AIA)
-        become a fatal parse error; off by default."""
+        become a fatal parse error; on by default (the reference profile)."""
         lib().orc_engine_set_strict_extensions(self._h, int(bool(on)))
 
     def close(self):

@@ -16,8 +16,9 @@ def run_oracle(batch, issuers, filt=b"", log_expired=False, now=0, engine=None):
     return o, st, unk, eh
 
 
-def expected_records(batch, st, unk, eh, strict_strings=False, strict_spki=True, strict_ext=False):
-    """What the 32-byte records must contain, derived from the oracle."""
+def expected_records(batch, st, unk, eh, strict_strings=True, strict_spki=True, strict_ext=True):
+    """What the 32-byte records must contain, derived from the oracle.  The switches default to the engine's own defaults:
+    CTMR_PROFILE_REFERENCE, everything on (round 6)."""
     n = batch.n
     serial_len = np.zeros(n, np.uint16)
     serial = np.zeros((n, 20), np.uint8)
@@ -43,7 +44,7 @@ def expected_records(batch, st, unk, eh, strict_strings=False, strict_spki=True,
     return flags, serial_len, exp_hour, serial
 
 
-def assert_records_equal(res, batch, st, unk, eh, strict_strings=False, strict_spki=True, strict_ext=False):
+def assert_records_equal(res, batch, st, unk, eh, strict_strings=True, strict_spki=True, strict_ext=True):
     flags, serial_len, exp_hour, serial = expected_records(batch, st, unk, eh, strict_strings, strict_spki, strict_ext)
     r = res.records
     assert (r["status"] == st).all(), np.nonzero(r["status"] != st)[0][:10]

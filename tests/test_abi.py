@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), n
         assert n in N.SIGNATURES, f"{n} missing from the ctypes binding"
     assert sorted(N.SIGNATURES) == sorted(names + bench)
-    assert lib.ctmr_abi_version() == N.ABI_VERSION == 6
+    assert lib.ctmr_abi_version() == N.ABI_VERSION == 7
 
 
 def test_struct_sizes_match_the_header():

@@ -193,8 +193,9 @@ def test_raw_batch_equals_packed_batch_through_the_oracle():
 
 
 def test_strict_leaf_drops_precert_entries_whose_leaf_tbs_does_not_parse():
-    """ct.LogEntryFromLeaf parses a precertificate entry's leaf TBSCertificate too (ct-fetch.go:452); with strict_leaf the
-    oracle fails the entry when that parse fails fatally, X509 entries and the default mode are untouched."""
+    """ct.LogEntryFromLeaf parses a precertificate entry's leaf TBSCertificate too (ct-fetch.go:452); with strict_leaf (the
+    default: the reference profile) the oracle fails the entry when that parse fails fatally; X509 entries and the fast
+    profile are untouched."""
     from ct_mapreduce_amd import synth
     from ct_mapreduce_amd.engine import RawEntries
     from tests.test_walk_cpu import tbs_of
@@ -215,10 +216,10 @@ def test_strict_leaf_drops_precert_entries_whose_leaf_tbs_does_not_parse():
     raw = RawEntries.from_pairs(pairs)
     blob = np.concatenate([raw.blob, np.zeros(64, np.uint8)])
     lax = orc.Engine(b"", False, synth.BASE_TIME)
+    lax.set_strict_leaf(False)                                  # CTMR_PROFILE_FAST's choice
     st0, unk0, _, _ = lax.raw_batch(blob, raw.bounds)
     assert (st0 == orc.ST_PASS).all() and unk0.all()
-    strict = orc.Engine(b"", False, synth.BASE_TIME)
-    strict.set_strict_leaf(True)
+    strict = orc.Engine(b"", False, synth.BASE_TIME)            # the default since round 6: the reference profile
     st1, unk1, _, ts1 = strict.raw_batch(blob, raw.bounds)
     E = orc.ST_ENTRY_DECODE_ERROR
     assert list(st1) == [orc.ST_PASS, E, E, E, orc.ST_PASS, orc.ST_PASS]

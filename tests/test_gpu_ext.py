@@ -13,7 +13,8 @@ from ct_mapreduce_amd.engine import RECORD_DTYPE  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests import der as D  # noqa: E402
 from tests.gpu_common import run_oracle  # noqa: E402
-from tests.test_ext_cpu import x, aia, san, uri, dps, fullname, nc, sct_ext, EKU_SRV, EKU_CLI, POL, OCSP  # noqa: E402
+from tests.test_ext_cpu import (x, aia, san, uri, dps, fullname, nc, sct_ext, EKU_SRV, EKU_CLI, POL, OCSP,  # noqa: E402
+                                sia, ipaddr, asnum, bits, CA_REPO, NULL)
 
 NOW = synth.BASE_TIME
 
@@ -29,8 +30,15 @@ def corpus(rng, n):
                 uri("https://u@a.example:8443/x%20y?q#f")),
             dps(D.seq(fullname(D.tlv(0x86, b"http://crl.example/a.crl"))),
                 D.seq(D.tlv(0xa0, D.tlv(0xa1, D.tlv(0x31, D.seq(D.oid(0x55, 4, 3), D.tlv(0x13, b"rel"))))), D.tlv(0x81, b"\x01\x06"))),
-            sct_ext(D.tlv(0x04, b"\x00\x05\x00\x03abc"))]
-    bad = [x(15, D.tlv(0x03, b"\x08\x00")), x(14, D.tlv(0x03, b"\x00\x11")), x(37, D.seq(EKU_SRV, D.tlv(0x0c, b"x"))),
+            sct_ext(D.tlv(0x04, b"\x00\x05\x00\x03abc")),
+            # round 6: what only CT-go's fork parses — subjectInfoAccess, RFC 3779 address blocks and AS identifiers
+            sia(D.seq(D.seq(CA_REPO, D.tlv(0x86, b"rsync://repo.example/ca/")))),
+            ipaddr(D.seq(D.seq(D.tlv(0x04, b"\x00\x01"), D.seq(bits(b"\x0a"), D.seq(bits(b"\xc0\xa8"), bits(b"\xc0\xa9\x80", 7)))))),
+            asnum(D.seq(D.tlv(0xa0, D.seq(D.tlv(0x02, b"\x00\xfd\xe8"))), D.tlv(0xa1, NULL)))]
+    bad = [aia(D.seq()), sia(D.seq()), sia(D.seq(D.seq(CA_REPO))), sia(D.seq(D.seq(CA_REPO, NULL)) + b"\x00"),          # fatal (CT-go: recalled)
+           ipaddr(D.seq(D.seq(D.tlv(0x04, b"\x01"), NULL))), ipaddr(D.seq(D.seq(D.tlv(0x04, b"\x00\x01"), D.seq(bits(b"\x0b", 1))))),   # non-fatal
+           asnum(D.seq(D.tlv(0xa0, D.seq(D.tlv(0x02, b"\x00\x01"))))), asnum(D.seq(D.tlv(0xa0, NULL)) + b"\x00"), asnum(b""),          # non-fatal
+           x(15, D.tlv(0x03, b"\x08\x00")), x(14, D.tlv(0x03, b"\x00\x11")), x(37, D.seq(EKU_SRV, D.tlv(0x0c, b"x"))),
            x(35, D.seq(b"\x80\x7f\x01")), x(32, D.seq(POL)), aia(D.seq(D.seq(OCSP))), x(15, D.tlv(0x03, b"\x05\xa0") + b"\x00"),
            san(D.tlv(0x82, b"a"), uri("http://a b/")), san(uri(":x")), san(D.tlv(0x82, b"a")) [:-1] + b"\x00",   # fatal
            san(D.tlv(0x87, bytes(5))), sct_ext(D.tlv(0x04, b"\x00\x06\x00\x03abc")),                           # non-fatal: precertificates only
@@ -64,7 +72,11 @@ def test_packed_batches_follow_the_oracle(strict):
                D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), spki=D.EC_SPKI_2,
                       exts=[D.BC_CA, nc([D.tlv(0x82, b".example.com"), D.tlv(0x81, b"u@example.com")], [D.tlv(0x87, bytes(4) + b"\xff\xff\x00\x00")])]),
                D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA, nc([D.tlv(0x86, b"1.2.3.4")])]),        # a URI constraint that is an IP
-               D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA, san(D.tlv(0x87, bytes(3)))])]          # a non-fatal finding drops an issuer
+               D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA, san(D.tlv(0x87, bytes(3)))]),         # a non-fatal finding drops an issuer
+               D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), spki=D.EC_SPKI_2,
+                      exts=[D.BC_CA, asnum(D.seq(D.tlv(0xa0, D.seq(D.tlv(0x04, b"\x01")))))]),                       # … an RFC 3779 finding too (round 6)
+               D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), spki=D.EC_SPKI_2,
+                      exts=[D.BC_CA, asnum(D.seq(D.tlv(0xa0, D.seq(D.tlv(0x02, b"\x01"))))), sia(D.seq(D.seq(CA_REPO, NULL)))])]   # a well-formed RPKI CA
     certs = corpus(rng, 3000)
     b = ctmr.Batch.from_certs(certs, [rng.randrange(len(issuers)) for _ in certs], [rng.randrange(2) for _ in certs])
     o = orc.Engine(b"", True, NOW)
@@ -84,8 +96,8 @@ def test_packed_batches_follow_the_oracle(strict):
 
 
 def test_the_reference_profile_is_the_four_switches():
-    """ctmr_set_profile(CTMR_PROFILE_REFERENCE) ≡ strict_spki + strict_leaf + strict_strings + strict_extensions, and
-    CTMR_PROFILE_FAST restores the defaults — on a corpus where each switch has something to say."""
+    """ctmr_set_profile(CTMR_PROFILE_REFERENCE) ≡ strict_spki + strict_leaf + strict_strings + strict_extensions ≡ what
+    ctmr_create gives (round 6), and CTMR_PROFILE_FAST ≡ the three opt-outs — on a corpus where each switch has something to say."""
     rng = random.Random(7)
     issuer = D.cert(subject=D.name(D.rdn(3, b"Ext Issuer")), exts=[D.BC_CA])
     certs = corpus(rng, 1500)
@@ -93,23 +105,29 @@ def test_the_reference_profile_is_the_four_switches():
         certs[i] = D.cert(serial=bytes([7, i % 251, i // 251]), issuer=D.name(D.rdn(10, b"a@b", 0x13), D.rdn(3, b"Ext Issuer")))
     b = ctmr.Batch.from_certs(certs, [0] * len(certs), [rng.randrange(2) for _ in certs])
     got = {}
-    for mode in ("reference", "switches", "fast", "defaults"):
+    for mode in ("reference", "switches", "fast", "fast_switches", "defaults"):
         eng = ctmr.Engine(device=0, table_slots=1 << 13, pair_slots=1 << 10)
         if mode == "switches":
+            eng.set_profile("fast")
             eng.set_strict_leaf(True); eng.set_strict_strings(True); eng.set_strict_extensions(True); eng.set_strict_spki(True)
         elif mode == "reference":
-            eng.set_profile("reference")
+            eng.set_profile("fast"); eng.set_profile("reference")
         elif mode == "fast":
-            eng.set_profile("reference"); eng.set_profile("fast")
+            eng.set_profile("fast")
+        elif mode == "fast_switches":
+            eng.set_strict_leaf(False); eng.set_strict_strings(False); eng.set_strict_extensions(False)
         eng.add_issuers([issuer])
         eng.set_filter(b"", True, NOW)
         got[mode] = eng.map_batch(b).records["status"].copy()
         eng.close()
-    assert (got["reference"] == got["switches"]).all() and (got["fast"] == got["defaults"]).all()
-    o = orc.Engine(b"", True, NOW)
-    o.set_strict_extensions(True); o.set_strict_strings(True)
+    assert (got["reference"] == got["switches"]).all() and (got["reference"] == got["defaults"]).all()
+    assert (got["fast"] == got["fast_switches"]).all()
+    o = orc.Engine(b"", True, NOW)                                   # the oracle's defaults are the reference profile too
     st = run_oracle(b, [issuer], b"", True, NOW, engine=o)[1]
     assert (got["reference"] == st).all()
+    of = orc.Engine(b"", True, NOW)
+    of.set_profile("fast")
+    assert (got["fast"] == run_oracle(b, [issuer], b"", True, NOW, engine=of)[1]).all()
     assert (got["reference"] != got["fast"]).sum() > 300
 
 

@@ -70,7 +70,7 @@ def run_both(certs, iss, ets, issuers, strict_spki=True, table=1 << 14):
     o = orc.Engine(b"", True, NOW)
     o.set_strict_spki(strict_spki)
     o, st, unk, eh = run_oracle(batch, issuers, b"", True, NOW, engine=o)
-    assert_records_equal(res, batch, st, unk, eh, False, strict_spki)
+    assert_records_equal(res, batch, st, unk, eh, strict_spki=strict_spki)
     assert_state_equal(eng, o, len(issuers))
     eng.close()
     return st

@@ -78,6 +78,7 @@ def test_StoreBatch_end_to_end(tmp_path, mode):
     try:
         if mode == "raw_entries":
             from tests.test_entry_decode_cpu import x509_leaf, precert_leaf, chain, asn1cert
+            from tests.test_walk_cpu import tbs_of
             from ct_mapreduce_amd.engine import RawEntries
 
             def raw_of(lo, hi):
@@ -87,7 +88,9 @@ def test_StoreBatch_end_to_end(tmp_path, mode):
                     if batch.entry_type[i] == 0:
                         pairs.append((x509_leaf(leafs[i], ts=i), ch))
                     else:
-                        pairs.append((precert_leaf(b"\x30\x00", ts=i), asn1cert(leafs[i]) + ch))
+                        # (the MerkleTreeLeaf of a precertificate entry carries its TBSCertificate: LogEntryFromLeaf parses it —
+                        #  strict_leaf, part of the default profile since round 6)
+                        pairs.append((precert_leaf(tbs_of(leafs[i]), ts=i), asn1cert(leafs[i]) + ch))
                 r = RawEntries.from_pairs(pairs)
                 r.blob = np.concatenate([r.blob, np.zeros(32, np.uint8)])
                 return r
