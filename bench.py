@@ -1233,6 +1233,8 @@ def main():
         gi = group.info()
         out["exchange"] = {"mode": mode, "transport": "rccl" if gi.transport else "local (one rank: nothing to exchange)",
                            "ms_phase_rank0": {nm: float(phase_ms[k]) / args.steps for k, nm in enumerate(names)},
+                           "ms_control": float(phase_ms[6]) / args.steps,
+                           "host_syncs_per_round": float(phase_ms[7]) / args.steps,
                            "wire_bytes_sent_by_rank0_per_step": wire[0] / args.steps,
                            "key_records_sent_by_rank0_per_step": wire[1] / args.steps,
                            "filter_bytes_received_by_rank0_per_step": wire[2] / args.steps,

@@ -83,6 +83,17 @@ CTMR_HD uint32_t ldc(const R& r, uint32_t p, uint32_t L) {
   else return r.ld4(p < L ? p : L);
 }
 
+// the two octets at p (readers with a clamped two-octet read of their own use it: a window's last two bytes are in reach)
+template <class R, class = void>
+struct has_ld2c : std::false_type {};
+template <class R>
+struct has_ld2c<R, std::void_t<decltype(std::declval<const R&>().ld2c(0u))>> : std::true_type {};
+template <class R>
+CTMR_HD uint32_t ld2(const R& r, uint32_t p, uint32_t L) {
+  if constexpr (has_ld2c<R>::value) return r.ld2c(p);
+  else return ldc(r, p, L) & 0xffffu;
+}
+
 // certIsFilteredOut filter (3): strings.HasPrefix(Issuer.CommonName, piece) for some piece
 // (ct-fetch.go:57-69).  Pieces are wave-uniform, the CN bytes per lane.
 template <class R>
@@ -444,52 +455,73 @@ CTMR_HD bool string_word_ok(uint32_t tag, uint32_t w) {
 }
 
 // the value [cv, ev) of universal type tv against its character set
+// Round 6: sixteen octets per step — four independent window reads, one OR — decide what nearly every value needs decided:
+// "all octets below 0x80" (every IA5String and every UTF8String of ASCII text is done with that; round 4 took four octets
+// per step through the UTF-8 automaton's fast exit: 28 instructions per four octets, 450 per wave of the headline corpus).
+// Only a UTF8String that does hold an octet >= 0x80 goes through the automaton, only Printable / NumericStrings through
+// their per-word predicate.
 template <class R>
-CTMR_HD bool value_strings_ok(R& r, uint32_t L, uint32_t tv, uint32_t cv, uint32_t ev) {
+CTMR_HD bool utf8_exact_ok(R& r, uint32_t L, uint32_t cv, uint32_t ev) {
   bool good = true;
-  if ((tv == 0x13u) | (tv == 0x12u) | (tv == 0x16u)) {
-    for (uint32_t p = cv; good & (p < ev); p += 4u) {
-      if (((p - cv) & 63u) == 0u) r.touch(p, ev - p < 64u ? ev - p : 64u);
-      const uint32_t nb = ev - p < 4u ? ev - p : 4u, keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
-      const uint32_t w = (ldc(r, p, L) & keep) | (0x30303030u & ~keep);  // octets behind the value count as '0': in every set
-      good = good & ((w & 0x80808080u) == 0u);                           // all three sets are 7-bit
-      if (tv != 0x16u) good = good & string_word_ok(tv, w & 0x7f7f7f7fu);
-    }
-  } else if (tv == 0x0cu) {
-    uint32_t need = 0u, lo = 0x80u, hi = 0xbfu;  // continuation octets still owed, and the range of the next one
-    for (uint32_t p = cv; good & (p < ev); p += 4u) {
-      if (((p - cv) & 63u) == 0u) r.touch(p, ev - p < 64u ? ev - p : 64u);
-      const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
-      const uint32_t keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
-      if ((need == 0u) & ((w & keep & 0x80808080u) == 0u)) continue;  // four ASCII octets between sequences
-      for (uint32_t k = 0; k < nb; k++) {
-        const uint32_t b = (w >> (8u * k)) & 0xffu;
-        if (need == 0u) {
-          if (b < 0x80u) {
-          } else if ((b >= 0xc2u) & (b <= 0xdfu)) {
-            need = 1u;
-          } else if ((b >= 0xe0u) & (b <= 0xefu)) {
-            need = 2u;
-            lo = b == 0xe0u ? 0xa0u : 0x80u;
-            hi = b == 0xedu ? 0x9fu : 0xbfu;
-          } else if ((b >= 0xf0u) & (b <= 0xf4u)) {
-            need = 3u;
-            lo = b == 0xf0u ? 0x90u : 0x80u;
-            hi = b == 0xf4u ? 0x8fu : 0xbfu;
-          } else {
-            good = false;
-          }
+  uint32_t need = 0u, lo = 0x80u, hi = 0xbfu;  // continuation octets still owed, and the range of the next one
+  for (uint32_t p = cv; good & (p < ev); p += 4u) {
+    if (((p - cv) & 63u) == 0u) r.touch(p, ev - p < 64u ? ev - p : 64u);
+    const uint32_t w = ldc(r, p, L), nb = ev - p < 4u ? ev - p : 4u;
+    const uint32_t keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+    if ((need == 0u) & ((w & keep & 0x80808080u) == 0u)) continue;  // four ASCII octets between sequences
+    for (uint32_t k = 0; k < nb; k++) {
+      const uint32_t b = (w >> (8u * k)) & 0xffu;
+      if (need == 0u) {
+        if (b < 0x80u) {
+        } else if ((b >= 0xc2u) & (b <= 0xdfu)) {
+          need = 1u;
+        } else if ((b >= 0xe0u) & (b <= 0xefu)) {
+          need = 2u;
+          lo = b == 0xe0u ? 0xa0u : 0x80u;
+          hi = b == 0xedu ? 0x9fu : 0xbfu;
+        } else if ((b >= 0xf0u) & (b <= 0xf4u)) {
+          need = 3u;
+          lo = b == 0xf0u ? 0x90u : 0x80u;
+          hi = b == 0xf4u ? 0x8fu : 0xbfu;
         } else {
-          good = good & (b >= lo) & (b <= hi);
-          lo = 0x80u;
-          hi = 0xbfu;
-          need--;
+          good = false;
         }
+      } else {
+        good = good & (b >= lo) & (b <= hi);
+        lo = 0x80u;
+        hi = 0xbfu;
+        need--;
       }
     }
-    good = good & (need == 0u);
   }
-  return good;
+  return good & (need == 0u);
+}
+template <class R>
+CTMR_HD bool value_strings_ok(R& r, uint32_t L, uint32_t tv, uint32_t cv, uint32_t ev) {
+  const bool seven = (tv == 0x13u) | (tv == 0x12u) | (tv == 0x16u), utf8 = tv == 0x0cu;
+  if (!(seven | utf8)) return true;
+  bool good = true;
+  uint32_t high = 0u;  // the OR of every octet of the value (bit 7 of each byte lane: some octet >= 0x80)
+  for (uint32_t p = cv; p < ev; p += 16u) {
+    if (((p - cv) & 63u) == 0u) r.touch(p, ev - p < 64u ? ev - p : 64u);
+    const uint32_t n = ev - p;  // octets left, >= 1
+    uint32_t w[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      const uint32_t at = p + 4u * k;
+      const uint32_t left = n > 4u * k ? n - 4u * k : 0u;  // octets of this word that belong to the value
+      const uint32_t keep = left >= 4u ? 0xffffffffu : ((1u << (8u * left)) - 1u);
+      w[k] = (left ? ldc(r, at, L) & keep : 0u) | (0x30303030u & ~keep);  // octets behind the value count as '0': in every set
+    }
+    high |= (w[0] | w[1]) | (w[2] | w[3]);
+    if ((tv == 0x13u) | (tv == 0x12u)) {
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) good = good & string_word_ok(tv, w[k] & 0x7f7f7f7fu);
+    }
+  }
+  const bool ascii = (high & 0x80808080u) == 0u;
+  if (seven) return good & ascii;                 // the three 7-bit sets
+  return ascii || utf8_exact_ok(r, L, cv, ev);    // utf8.Valid: ASCII is; anything else takes the automaton
 }
 
 // pkix.RDNSequence at q (asn1.RawValue in the tbsCertificate, then asn1.Unmarshal into pkix.RDNSequence): SEQUENCE OF
@@ -525,6 +557,22 @@ CTMR_HD void name_value_check(const R& r, uint32_t L, uint32_t tag, uint32_t c, 
   }
 }
 
+// touch() at a point of the walk that every lane of a wave passes: readers that can refill together do (touch_coop)
+template <class R, class = void>
+struct has_touch_coop : std::false_type {};
+template <class R>
+struct has_touch_coop<R, std::void_t<decltype(std::declval<R&>().touch_coop(0u, 0u))>> : std::true_type {};
+template <class R>
+CTMR_HD void touch_all(R& r, uint32_t pos, uint32_t need) {
+  if constexpr (has_touch_coop<R>::value) r.touch_coop(pos, need);
+  else r.touch(pos, need);
+}
+
+// What the walk reads from the start of a SubjectPublicKeyInfo before the next window is asked for: its header, the
+// AlgorithmIdentifier of an RSA key (15 octets), the BIT STRING's header and pad octet, the RSAPublicKey and modulus headers
+// and the modulus' first two octets — 34 octets for every RSA key of 2048 bits and more.  (Round 6: the hints used to say
+// 48; a 224-byte window holds a synthetic certificate's front only when they say what is read.)
+constexpr uint32_t SPKI_HEAD_NEED = 34u;
 template <bool CN, bool STRINGS, class R>
 CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool& ok, uint32_t& cn_off, uint32_t& cn_len,
                            uint32_t& nf, bool strings) {
@@ -534,7 +582,8 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
   const uint32_t s_end = ce;
   // a long Name (OV/EV subjects) that runs past the window: refill ONCE, here, where the window then covers the whole
   // Name and the SubjectPublicKeyInfo header behind it — instead of somewhere in the middle and again at the key
-  if constexpr (!CN) r.touch(cs, ok ? (ce - cs) + 48u : 0u);
+  if constexpr (!CN) touch_all(r, cs, ok ? (ce - cs) + SPKI_HEAD_NEED : 0u);
+  else touch_all(r, cs, ok ? (ce - cs) : 0u);  // (the issuer: what follows it — the validity — has a hint of its own)
   uint32_t a = cs, a_end = cs;
   while (ok & (a < s_end)) {
     uint32_t t1, c1, e1;
@@ -648,6 +697,14 @@ CTMR_HD uint32_t ext_kind(uint32_t oid_len, uint32_t w0, uint32_t w1) {  // w0, 
   }
   return 0u;
 }
+// oid_arcs_ok with the id-pkix family recognised by two compares (1.3.6.1.5.5.7.x.y: eight octets, all below 0x80 — every arc
+// one octet, a valid encoding): the extKeyUsage purposes and the accessMethods of nearly every certificate
+template <class R>
+CTMR_HD bool oid_arcs_ok_pkix(const R& r, uint32_t L, uint32_t c, uint32_t e) {
+  const uint32_t w0 = ldc(r, c, L), w1 = ldc(r, c + 4u, L);
+  const bool pkix = (e - c == 8u) & (w0 == 0x0501062bu) & ((w1 & 0x8080ffffu) == 0x00000705u);
+  return pkix || oid_arcs_ok(r, L, c, e);
+}
 template <class R>
 CTMR_HD void ext_body_check(R& r, uint32_t L, uint32_t kind, uint32_t cv, uint32_t ev, bool& ok) {
   uint32_t t, c, ce;
@@ -676,13 +733,13 @@ CTMR_HD void ext_body_check(R& r, uint32_t L, uint32_t kind, uint32_t cv, uint32
         rd_hdr_q(r, L, p, ce, ok, te, x, xe);
         if (kind == 3u) {
           ok = ok & (te == 0x06u);
-          ok = ok && oid_arcs_ok(r, L, x, xe);
+          ok = ok && oid_arcs_ok_pkix(r, L, x, xe);
         } else {
           uint32_t to, co, eo;
           ok = ok & (te == 0x30u);
           rd_hdr_q(r, L, x, xe, ok, to, co, eo);
           ok = ok & (to == 0x06u);
-          ok = ok && oid_arcs_ok(r, L, co, eo);
+          ok = ok && oid_arcs_ok_pkix(r, L, co, eo);
           if (kind == 6u) {  // accessLocation: asn1.RawValue, not optional
             uint32_t tl, cl, el;
             r.touch(eo, 8);
@@ -1554,7 +1611,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     if (use_filter) o.cn_match = ok ? cn_prefix_match(r, L, o.cn_off, o.cn_len, fv) : false;
   }
   CTMR_STAGE(2);
-  r.touch(q, 48);
+  touch_all(r, q, 48);
   // validity: two Times; anything behind them is ignored
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
@@ -1586,7 +1643,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   // past the front window: say so, instead of leaving a window-only reader to its slow exact path.
   // (A wave-cooperative form of this refill — the lanes in need served 16 lanes per certificate, as touch_tail does —
   //  measured no gain on the mixed corpus: 25.45 ms against 25.3 ms per 100 M, session 5.)
-  r.touch(q, 48);
+  touch_all(r, q, SPKI_HEAD_NEED);
   rd_hdr(r, L, q, tbs_end, ok, tag, cs, ce);
   ok = ok & (tag == 0x30u);
   o.spki_off = q;
@@ -1655,7 +1712,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
     e_end = tag == 0x30u ? e_end : e;
     while (ok & (e < e_end)) {
       uint32_t t1, x, x_end, to, co, eo, tv, cv, ev, oidw;
-      r.touch(e, 48);
+      r.touch(e, 16);  // the 12 octets of the fast form (and the OID's second word, for strict_extensions)
       // Fast form: Extension hdr, a 3-byte extnID with its hdr, optional critical BOOLEAN and the extnValue hdr
       // lie in the 12 bytes at e when every length is short form (every 2.5.29.x extension under 128 bytes).
       const uint32_t w0 = ldc(r, e, L), w1 = ldc(r, e + 4u, L), w2 = ldc(r, e + 8u, L);
@@ -1672,6 +1729,7 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
         ev = cv + (cr ? (w2 >> 24) : (w2 & 0xffu));
         ok = ok & (x_end <= e_end) & (ev <= x_end);
       } else {
+        r.touch(e, 24);  // three headers and the OID's first words (a subjectAltName's: 30 82 ll ll 06 03 55 1d 11 04 82 ll ll)
         rd_hdr(r, L, e, e_end, ok, t1, x, x_end);   // Extension
         rd_hdr(r, L, x, x_end, ok, to, co, eo);     // extnID
         oidw = ldc(r, co, L);

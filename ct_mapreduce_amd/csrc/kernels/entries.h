@@ -62,14 +62,23 @@ __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uin
   }
   const WaveBuf wb = wave_buf(blob, limit, l0);  // lane 0's entry: the blob's entries ascend
   const uint32_t lrel = wave_rel(wb, lo, pre);
-  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~15u);
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
   coop_fill<false>(wb, w_me, lane);
   bool ok = true;
   if (pre) {
-    WinReaderC<16> r{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)),
-                      lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}};
+    // Round 6: the map kernel's reader — every read served by the LDS window alone, a walk that leaves it repeated with the
+    // exact global-memory reader (rounds 3-5: WinReaderC, whose every read carries a global-memory path of its own — 168
+    // VGPRs with 36 spills under this kernel's occupancy attribute; strict_leaf is part of the default profile now)
+    WinReaderS<WIN_CH> r{{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)),
+                       lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}}};
+    r.miss = lrel == REL_NONE ? 0xffffffffu : 0u;
+    r.tl_pos = 0x80000000u;
     Walk w;
     ok = walk_tbs(r, len, w, strict_spki != 0u, strict_ext != 0u);
+    if (r.missed()) {
+      GlobalReader g{(const uint32_t*)blob, lo};
+      ok = walk_tbs(g, len, w, strict_spki != 0u, strict_ext != 0u);
+    }
   }
   if (i < n) leaf_bad[i] = (uint8_t)(pre && !ok);
 }

@@ -172,7 +172,7 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
 // The first fill is wave-cooperative (coop_fill, readers.h).
 template <int WCH, bool STRICT = false>
 __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
-  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
+  static_assert(WCH == WIN_CH, "the cooperative fills fill windows of WIN_CH chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   if (live) cert_range(a.offsets, a.ends, i, lo, hi);
   const WaveBuf wb = wave_buf(a.payload, limit, lo);  // (lane 0 is live whenever the workgroup exists: k_map_fused)
   const uint32_t lrel = wave_rel(wb, lo, live);
-  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~15u);
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
   coop_fill<false>(wb, w_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   if (live) {

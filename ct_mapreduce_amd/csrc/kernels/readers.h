@@ -31,9 +31,33 @@ __device__ __forceinline__ void st_stream16(uint4* p, const uint4& v) {
 // (Round 3's LDS-DMA variant of the fill — CTMR_WIN_GLDS, global_load_lds_dwordx4 — measured no gain and left the tree in
 //  round 6 together with the 64-bit address arithmetic it shared with the fill below: EXPERIMENTS.md.)
 extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-constexpr uint32_t WIN_STRIDE = 16u * 16u + 16u;
+// Round 6: the window geometry decides how many waves a CU holds — the map kernels are bound by the 160 KB of LDS, not
+// by registers (133 / 157 VGPRs: three waves per SIMD, twelve per CU) — and once the fills and the reads were cheap their
+// time followed the number of resident waves (a build that cost one wave per CU lost exactly 1/9: EXPERIMENTS.md).
+//   WIN_CH 16, stride 272   17 408 B per wave → 9 waves per CU; equal in-window offsets collide 4-way (rounds 1-5)
+//   WIN_CH 15, stride 248   15 872 B per wave: the occupancy API promises 10 waves per CU (scripts/probe_lds_occupancy.hip:
+//                           ≤ 16 447 B), the counters show 9 as before — LDS is handed out in pieces of 1 280 B
+//                           (160 KB / 128), 15 872 B take thirteen of them, 16 640 B (profiles/r06/win_15_chunks_*)
+//   WIN_CH 14, stride 236   15 104 B per wave = twelve pieces → 10 waves per CU; 59 dwords a lane: an ODD stride, equal
+//                           in-window offsets never collide; the windows are 4-byte aligned (a chunk is stored as two
+//                           ds_write2_b32).  224 bytes hold what the walk reads of the front of a synthetic certificate
+//                           — through the first two octets of the modulus, 220 bytes in — only because a window now
+//                           begins AT its position give or take 3 bytes (a chunk load needs dword alignment; rounds 1-5
+//                           began windows on 16-byte boundaries and lost up to 15) and because the walk's hints
+//                           (touch) say what is read, not a round figure.
+#ifndef CTMR_WIN_CH
+#define CTMR_WIN_CH 14
+#endif
+constexpr int WIN_CH = CTMR_WIN_CH;
+constexpr uint32_t WIN_STRIDE = WIN_CH == 16 ? 272u : WIN_CH == 15 ? 248u : (uint32_t)WIN_CH * 16u + 12u;
 constexpr uint32_t WIN_LDS_BYTES = 64u * WIN_STRIDE;
 __device__ __forceinline__ uint32_t win_off(uint32_t c) { return c * WIN_STRIDE; }
+typedef uint32_t ctmr_u32x4_a8 __attribute__((ext_vector_type(4), aligned(WIN_CH >= 15 ? 8 : 4)));  // a chunk in a window
+__device__ __forceinline__ void st_chunk(uint8_t* at, const uint4& v) {
+  ctmr_u32x4_a8 t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(ctmr_u32x4_a8*)at = t;
+}
 
 // Round 6: the wave's view of the payload as ONE buffer descriptor (SRSRC in scalar registers) whose base is the 128-byte
 // line of the wave's first certificate, so that every window position of every lane is a 32-BIT offset from it.  Rounds
@@ -81,16 +105,18 @@ __device__ __forceinline__ uint4 ld_chunk(const WaveBuf& wb, uint32_t off) {  //
 template <bool BARRIER_BEFORE_STORES>
 __device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
   const uint32_t sub16 = (lane & 15u) * 16u;
+  const bool mine = (lane & 15u) < (uint32_t)WIN_CH;  // (a window of 15 chunks: the sixteenth lane of a group idles)
   uint32_t o[16];
   uint4 v[16];
 #pragma unroll
   for (int it = 0; it < 16; it++) o[it] = __shfl(w_me, 4 * it + (int)(lane >> 4));
 #pragma unroll
-  for (int it = 0; it < 16; it++) v[it] = ld_chunk(wb, o[it] + sub16);
+  for (int it = 0; it < 16; it++) v[it] = ld_chunk(wb, mine ? o[it] + sub16 : REL_NONE);
   if (BARRIER_BEFORE_STORES) __builtin_amdgcn_wave_barrier();
+  if (mine) {
 #pragma unroll
-  for (int it = 0; it < 16; it++)
-    *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + sub16) = v[it];
+    for (int it = 0; it < 16; it++) st_chunk(smem + win_off(4 * it + (lane >> 4)) + sub16, v[it]);
+  }
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -98,33 +124,42 @@ __device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint
 // REL_NONE keeps its window as it is (its chunks load as zeros — no memory access — and are not stored).
 __device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
   const uint32_t sub16 = (lane & 15u) * 16u;
+  const bool mine = (lane & 15u) < (uint32_t)WIN_CH;
   uint32_t o[16];
   uint4 v[16];
 #pragma unroll
-  for (int it = 0; it < 16; it++) o[it] = __shfl(w_me, 4 * it + (int)(lane >> 4));
+  for (int it = 0; it < 16; it++) {
+    o[it] = __shfl(w_me, 4 * it + (int)(lane >> 4));
+    o[it] = mine ? o[it] : REL_NONE;
+  }
 #pragma unroll
   for (int it = 0; it < 16; it++) v[it] = ld_chunk(wb, o[it] + sub16);
   __builtin_amdgcn_wave_barrier();  // every lane is done reading the old contents
 #pragma unroll
   for (int it = 0; it < 16; it++)
-    if (o[it] != REL_NONE) *(uint4*)(smem + win_off(4 * it + (lane >> 4)) + sub16) = v[it];
+    if (o[it] != REL_NONE) st_chunk(smem + win_off(4 * it + (lane >> 4)) + sub16, v[it]);
   __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------ byte readers
-// ld4(pos): 4-byte little-endian window at an arbitrary byte position, from two aligned dwords.
-// Round 6: inside an LDS window it is ONE ds_read_b32 at the byte address itself — gfx950 runs with unaligned LDS access
-// enabled (hipcc itself emits ds_read_b32 / ds_read_u16 for align-1 pointers; scripts/probe_lds_unaligned.hip checks the
-// hardware's answer) — instead of ds_read2_b32 + v_alignbyte + the shift and mask that fed them: three vector
-// instructions less on each of the walk's ≈ 90 reads.  -DCTMR_LDS_ALIGNED_ONLY restores the two-dword form (A/B builds).
+// ld4(pos): 4-byte little-endian window at an arbitrary byte position, from two aligned dwords (ds_read2_b32 + v_alignbyte).
+// Round 6 tried ONE ds_read_b32 at the byte address itself — gfx950 runs with unaligned LDS access enabled (hipcc emits
+// ds_read_b32 / ds_read_u16 for align-1 pointers; scripts/probe_lds_unaligned.hip: the hardware returns the right bytes) —
+// three vector instructions less on each of the walk's ≈ 90 reads.  The LDS pays for them: SQ_LDS_IDX_ACTIVE 4 017 →
+// 10 430 cycles per wave (an unaligned dword is not one access), ten waves of a CU kept its one LDS pipeline two-thirds
+// busy, and the map kernel ran 4.6 % SLOWER under the reference profile (38.7 against 36.9 ms per 100 M, A/B/A/B on one
+// box, profiles/r06/lds_reads_*).  -DCTMR_LDS_UNALIGNED builds that form.
 typedef uint32_t __attribute__((aligned(1))) ctmr_u32_u;
 typedef uint16_t __attribute__((aligned(1))) ctmr_u16_u;
+// the last window offset a 4-byte read may start at: WBYTES − 4 in both forms (the two-dword form's second dword may lie
+// in the pad behind the window — every stride leaves at least 8 bytes — and none of its bytes is used then)
+constexpr uint32_t LD4_SPAN = 4u;
 __device__ __forceinline__ uint32_t lds_ld4(const uint32_t* win, uint32_t rel) {
-#ifdef CTMR_LDS_ALIGNED_ONLY
+#ifdef CTMR_LDS_UNALIGNED
+  return *(const ctmr_u32_u*)((const uint8_t*)win + rel);
+#else
   const uint32_t i = rel >> 2;
   return __builtin_amdgcn_alignbyte(win[i + 1], win[i], rel & 3u);
-#else
-  return *(const ctmr_u32_u*)((const uint8_t*)win + rel);
 #endif
 }
 struct GlobalReader {
@@ -155,7 +190,7 @@ struct WinReader {
   uint64_t base;        // certificate start (byte offset into payload)
   uint64_t limit;       // readable bytes of payload (offsets[n] + CTMR_PAYLOAD_PAD)
   uint32_t* win;        // this lane's window words in LDS
-  int32_t grel;         // window start relative to the certificate start; (base+grel) % 16 == 0
+  int32_t grel;         // window start relative to the certificate start; (base+grel) % 4 == 0 (% 16 after a per-lane refill)
   // round 6 (set by the kernel behind the constructor): the wave's buffer descriptor and this certificate's start as an
   // offset from its base (REL_NONE: out of reach — cooperative fills leave such a lane's window alone / zero)
   WaveBuf wb;
@@ -167,7 +202,7 @@ struct WinReader {
 
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     const uint32_t rel = pos - (uint32_t)grel;
-    if (rel <= WBYTES - 8u) return lds_ld4(win, rel);
+    if (rel <= WBYTES - LD4_SPAN) return lds_ld4(win, rel);
     const uint64_t a = base + pos;
     const uint64_t i = a >> 2;
     return __builtin_amdgcn_alignbyte(g32[i + 1], g32[i], (uint32_t)a & 3u);
@@ -190,7 +225,7 @@ struct WinReader {
     for (int k = 0; k < WCH; k++)
       v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < WCH; k++) ((uint4*)win)[k] = v[k];
+    for (int k = 0; k < WCH; k++) st_chunk((uint8_t*)win + 16 * k, v[k]);
   }
   __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
     if (need > WBYTES - 16u) need = WBYTES - 16u;  // the window start is 16-B aligned in HBM
@@ -206,15 +241,32 @@ struct WinReader {
 // instruction.  Falls back to the per-lane refill when some lane of the wave is not at that point.
 template <int WCH>
 struct WinReaderC : WinReader<WCH> {
-  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
+  static_assert(WCH == WIN_CH, "the cooperative fills fill windows of WIN_CH chunks");
   __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) {
     if (__ballot(1) != ~0ull) {
       this->refill(pos);
       return;
     }
-    const uint32_t w = this->wrel(pos, 16u);
+    const uint32_t w = this->wrel(pos, 4u);  // (a chunk load needs dword alignment only: the window begins AT pos, give or take 3)
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
     coop_fill<true>(this->wb, w, threadIdx.x & 63u);
+  }
+  // der_walk.h touch_all (round 6) — a hint at a point of the walk EVERY lane passes (the walk never returns early): the lanes
+  // whose window lacks [pos, pos + need) are refilled TOGETHER, sixteen lanes per certificate, the others keep theirs.
+  // touch() refills lane by lane — sixteen uncoalesced loads and a round trip the whole wave waits for: what a long subject
+  // (the mixed corpus: 40 % of its certificates) or a window a few bytes short costs there.
+  __device__ __forceinline__ void touch_coop(uint32_t pos, uint32_t need) {
+    if (need > WinReader<WCH>::WBYTES - 16u) need = WinReader<WCH>::WBYTES - 16u;
+    const bool lack = pos - (uint32_t)this->grel > WinReader<WCH>::WBYTES - need;
+    if (__ballot(1) != ~0ull) {  // the batch's last wave
+      if (lack) this->refill(pos);
+      return;
+    }
+    if (__ballot(lack) == 0ull) return;
+    const uint32_t w = lack ? this->wrel(pos, 4u) : REL_NONE;
+    if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
+    else if (lack) this->refill(pos);  // (out of the descriptor's reach: the lane's own loads)
+    coop_refill_some(this->wb, w, threadIdx.x & 63u);
   }
   // der_walk.h ext_san_coop — wave-collective (every lane of a WHOLE wave calls it from converged code): the lanes that
   // `want` get their window refilled at pos, 16 lanes per certificate as above; the others keep theirs.
@@ -226,17 +278,20 @@ struct WinReaderC : WinReader<WCH> {
   // … the same with the window starting on a 128-byte LINE of the payload: two whole lines, the next round's window begins
   // where this one ends (der_walk.h ext_san_coop, round 6)
   __device__ __forceinline__ void coop_refill_lines(uint32_t pos, bool want) {
-    const uint32_t w = want ? this->wrel(pos, 128u) : REL_NONE;   // (the wave's base is a multiple of 128: so is the line)
+    // whole lines when the window is a whole number of them (256 bytes), else from a 64-byte sector (a window of 224 bytes
+    // is three and a half: from a line boundary it would hold 1.75 lines and every round would fetch its second line again)
+    constexpr uint32_t AL = (WinReader<WCH>::WBYTES % 128u == 0u) ? 128u : 64u;
+    const uint32_t w = want ? this->wrel(pos, AL) : REL_NONE;     // (the wave's base is a multiple of 128)
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
     coop_refill_some(this->wb, w, threadIdx.x & 63u);
   }
   // the two octets at pos, which the caller knows to lie in the window (holds): two byte reads, no alignment arithmetic
   __device__ __forceinline__ uint32_t ld2(uint32_t pos) const {
     const uint8_t* b = (const uint8_t*)this->win + (pos - (uint32_t)this->grel);
-#ifdef CTMR_LDS_ALIGNED_ONLY
-    return (uint32_t)b[0] | ((uint32_t)b[1] << 8);
-#else
+#ifdef CTMR_LDS_UNALIGNED
     return *(const ctmr_u16_u*)b;
+#else
+    return (uint32_t)b[0] | ((uint32_t)b[1] << 8);
 #endif
   }
   __device__ __forceinline__ uint32_t wend() const { return (uint32_t)this->grel + WinReader<WCH>::WBYTES; }  // certificate offset of the window's end
@@ -267,7 +322,7 @@ struct WinReaderS : WinReaderC<WCH> {
   // `miss` holds the LARGEST window-relative offset any read asked for (round 6: one v_max per read instead of compare +
   // select + or); missed() = some read lay outside the window.  Constructed with 0 (or ~0: no window at all).
   mutable uint32_t miss;
-  __device__ __forceinline__ bool missed() const { return miss > WinReader<WCH>::WBYTES - 8u; }
+  __device__ __forceinline__ bool missed() const { return miss > WinReader<WCH>::WBYTES - LD4_SPAN; }
   // The 32 bytes behind the TBSCertificate (signatureAlgorithm, the signatureValue header, its pad octet), fetched
   // by touch_tail() TOGETHER with the extension-block refill: the three ldg() reads at the end of the walk were
   // three dependent, uncoalesced global round trips per wave; now they are register selects.
@@ -280,10 +335,19 @@ struct WinReaderS : WinReaderC<WCH> {
   Hook hook{};  // by value: a pointer to state that lives across loop iterations keeps that state out of registers
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     uint32_t rel = pos - (uint32_t)this->grel;
-    constexpr uint32_t LAST = WinReader<WCH>::WBYTES - 8u;
+    constexpr uint32_t LAST = WinReader<WCH>::WBYTES - LD4_SPAN;
     miss = rel > miss ? rel : miss;
     rel = rel > LAST ? LAST : rel;
     return lds_ld4(this->win, rel);
+  }
+  // two octets, clamped and remembered like ld4 (the last read of the front window: spki_key.h)
+  __device__ __forceinline__ uint32_t ld2c(uint32_t pos) const {
+    uint32_t rel = pos - (uint32_t)this->grel;
+    constexpr uint32_t LAST2 = WinReader<WCH>::WBYTES - 2u;
+    miss = rel > LAST2 ? 0xffffffffu : miss;
+    rel = rel > LAST2 ? LAST2 : rel;
+    const uint8_t* b = (const uint8_t*)this->win + rel;
+    return (uint32_t)b[0] | ((uint32_t)b[1] << 8);
   }
   // der_walk.h (strict_extensions): the contents of this element are read octet by octet — not through the window
   __device__ __forceinline__ void defer_exact() { miss = 0xffffffffu; }

@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 //             rank's cumulative filter with one fire-and-forget 8-byte atomicOr — no separate pass over the records.
 template <int WCH, bool META, int MODE, bool STRICT = false>
 __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
-  static_assert(WCH == 16, "cooperative fill assumes 16 chunks");
+  static_assert(WCH == WIN_CH, "the cooperative fills fill windows of WIN_CH chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   // blob; lane 0 is live whenever the workgroup exists — and every window position is a 32-bit offset from it
   const WaveBuf wb = wave_buf(a.payload, limit, lo);
   const uint32_t lrel = wave_rel(wb, lo, live);
-  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~15u);
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
   coop_fill<false>(wb, w_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   unsigned long long kmeta = 0ull, ks[5] = {0ull, 0ull, 0ull, 0ull, 0ull};  // the entry's key, for its arena cell

@@ -153,7 +153,9 @@ CTMR_HD void key_integer(const V& v, uint32_t L, uint32_t p, uint32_t end, bool&
 // reduction step t ← (t + t[0]·p) / 2^32 needs no multiplication: limb 0 cancels, and what is left of t[0]·p is ± t[0] at
 // the limbs 3, 6, 7, 8 — seven additions with carry instead of eight 32 × 32 → 64-bit multiply-adds, which run at a quarter
 // of the vector rate (round 5; the generic CIOS product spent half its multiplications there).
-CTMR_HD void p256_redc_step(uint32_t (&t)[9]) {
+// top: limb 8 of t as the multiply-add row left it — up to 33 bits (t_prev + b_i·a ≤ p − 1 + 2^32·a can pass 2^288 when a
+// is within ≈ 2^160 of p; the ninth limb then needs its carry, which rounds 5's `(uint32_t)top` dropped: ADVICE r05)
+CTMR_HD void p256_redc_step(uint32_t (&t)[9], unsigned long long top) {
   const long long m = (long long)t[0];
   t[0] = t[1];
   t[1] = t[2];
@@ -167,7 +169,7 @@ CTMR_HD void p256_redc_step(uint32_t (&t)[9]) {
   t[5] = (uint32_t)s;
   s = (long long)t[7] - m + (s >> 32);  // (an arithmetic shift: the carry may be −1 here)
   t[6] = (uint32_t)s;
-  s = (long long)t[8] + m + (s >> 32);
+  s = (long long)top + m + (s >> 32);
   t[7] = (uint32_t)s;
   t[8] = (uint32_t)(s >> 32);
 }
@@ -196,8 +198,7 @@ CTMR_HD void mont_mul(const uint32_t (&a)[C::NL], uint32_t (&b)[C::NL]) {
     }
     unsigned long long top = (unsigned long long)t[NL] + c;
     if constexpr (is_p256<C>::value) {
-      t[NL] = (uint32_t)top;  // (t < 2p·2^32 before the step: top fits a limb)
-      p256_redc_step(t);
+      p256_redc_step(t, top);
     } else {
       const uint32_t m = t[0] * C::N0;
       unsigned long long s = (unsigned long long)m * C::P[0] + t[0];
@@ -307,7 +308,7 @@ CTMR_HD bool ec_equation(uint32_t (&x)[C::NL], uint32_t (&y)[C::NL]) {
     for (int j = 0; j < 8; j++) t[j] = u[j];
     t[8] = 0u;
 #pragma unroll 1
-    for (int i = 0; i < 8; i++) p256_redc_step(t);
+    for (int i = 0; i < 8; i++) p256_redc_step(t, t[8]);
     unsigned long long br = 0ull;  // t < p + 1 ≤ 2p: one conditional subtraction
 #pragma unroll
     for (int j = 0; j < 8; j++) br = (((unsigned long long)t[j] - C::P[j] - br) >> 32) & 1ull;
@@ -427,7 +428,7 @@ CTMR_HD void spki_key_begin(const R& r, uint32_t L, const AlgView& a, uint32_t c
     // The shape every RSA key of 2048 bits and more has — 30 82 ll ll | 02 82 nn nn | modulus, minimal and positive — is
     // recognised from three reads of the window (the general parse below costs ≈ 100 vector instructions more per
     // certificate, and on a power-limited part instructions are clock: DESIGN.md §7).  Anything else takes the general parse.
-    const uint32_t h0 = ldc(r, kp.c0, L), h1 = ldc(r, kp.c0 + 4u, L), h2 = ldc(r, kp.c0 + 8u, L);
+    const uint32_t h0 = ldc(r, kp.c0, L), h1 = ldc(r, kp.c0 + 4u, L), h2 = ld2(r, kp.c0 + 8u, L);  // (two octets: SPKI_HEAD_NEED)
     const uint32_t seqlen = __builtin_bswap32(h0) & 0xffffu, nlen = __builtin_bswap32(h1) & 0xffffu;
     const uint32_t b0 = h2 & 0xffu, b1 = (h2 >> 8) & 0xffu;
     const bool shape = (kp.shift == 0u) & ((h0 & 0xffffu) == 0x8230u) & (seqlen >= 256u) & (kp.c0 + 4u + seqlen == ek) &

@@ -391,7 +391,9 @@ typedef struct {
   /* wall time of the last round's phases on this process, ms (each phase ends with the ranks' streams drained):
    * [0] map (+ the insert of locally owned keys, + filter add)  [1] key export / filter all-gather + probe
    * [2] key records all-to-all  [3] owner insert / exact lookup (+ this shard's resolve)  [4] flags all-to-all
-   * [5] apply + NEW-list compaction  [6] the control collectives (counts, status) */
+   * [5] apply + NEW-list compaction  [6] the control collectives (counts, status)
+   * [7] NOT a time: how often the round drained a stream on the host (ABI v7) — every control row, every all-to-all and
+   *     every phase boundary is one; with RCCL each is a latency no kernel hides */
   float ms_phase[8];
 } ctmr_group_stats;
 int ctmr_group_create_local(ctmr_engine* const* engines, uint32_t n, ctmr_group** out);
@@ -406,7 +408,9 @@ int ctmr_group_info(ctmr_group* g, ctmr_group_stats* out);
  * once at the end over everything.  Results are those of the unchunked round, entry for entry (inside one round the order
  * in which keys reach their owner does not matter: storage/rediscache.go:57-65 answers per key, not per batch).  Costs one
  * small control collective per chunk and exchange buffers sized for the worst case.  Every rank of the group sets the same
- * value (checked in the round's opening control row); Bloom and LOCAL rounds ignore it. */
+ * value (checked in the round's opening control row); Bloom and LOCAL rounds ignore it.  With chunks > 1 on an RCCL group
+ * the call is COLLECTIVE (ABI v7): it makes the transfer streams and the second communicator the chunk transfers run on —
+ * every rank calls it, with the same count; a rank-local failure fails every rank's call together. */
 int ctmr_group_set_chunks(ctmr_group* g, uint32_t chunks);
 /* bits per rank: power of two, ≈16 per key a rank will ever hold; same on every rank.  (A group of ONE rank has no peer
  * to ask: it keeps no filter and its Bloom rounds are the plain reduce.)  * One mode per group: the first round's mode is the only one the group accepts afterwards (CTMR_E_INVAL otherwise) — the

@@ -753,16 +753,16 @@ class HostCert {
       for (auto& x : children(es, ee)) {
         auto parts = children(x[1], x[2]);
         if (parts.empty() || d_.compare(parts[0][1], parts[0][2] - parts[0][1], "\x55\x1d\x1f") != 0) continue;
-        size_t dps, dpe;
-        tlv(parts.back()[1], parts.back()[2], &tag, &dps, &dpe);
-        for (auto& dp : children(dps, dpe)) {          // DistributionPoint: Go's struct fields are positional —
-          auto f = children(dp[1], dp[2]);             // distributionPoint [0] is the FIRST element or absent,
-          if (f.empty() || f[0][0] != 0xa0) continue;
-          auto fn = children(f[0][1], f[0][2]);        // fullName [0] the first element inside it,
-          if (fn.empty() || fn[0][0] != 0xa0) continue;
-          for (auto& gn : children(fn[0][1], fn[0][2]))  // and a name is a URI when its tag NUMBER is 6 (x509.go: fullName.Tag == 6)
-            if ((gn[0] & 0x1f) == 6) crlDistributionPoints.push_back(d_.substr(gn[1], gn[2] - gn[1]));
-        }
+        // asn1.Unmarshal(value, &[]distributionPoint) as the device walk restates it (csrc/der_walk.h crl_dps): the WHOLE
+        // value must unmarshal — one SEQUENCE filling it, every distributionPoint a SEQUENCE whose three optional fields
+        // are taken in order (a header must parse at each field's position unless the contents are used up; a field of
+        // another tag is skipped unconsumed; a matching one must fit; Reason is a BIT STRING) — or parseCertificate fails
+        // and there are NO distribution points (round 6, ADVICE r05: this mirror used to keep the URIs of a value whose
+        // later part was malformed, where the device — under CTMR_PROFILE_FAST, which lets such a certificate through —
+        // reports none).
+        std::vector<std::string> uris;
+        if (crlDps(parts.back()[1], parts.back()[2], &uris))
+          for (auto& u : uris) crlDistributionPoints.push_back(u);
       }
     }
   }
@@ -837,6 +837,105 @@ class HostCert {
       o += c;
     }
     return o;
+  }
+  // Go encoding/asn1 parseTagAndLength at p inside [p, end): low tag numbers only (a high-tag-number element matches no
+  // field here), definite minimal lengths.  fit: the contents must lie inside as well.  false = the header does not parse.
+  bool goHdr(size_t p, size_t end, bool fit, uint8_t* tag, size_t* cs, size_t* ce) const {
+    if (p + 2 > end) return false;
+    *tag = (uint8_t)d_[p];
+    if ((*tag & 0x1f) == 0x1f) return false;                      // (parses in Go, matches nothing below: treated as a failure
+    const uint8_t b = (uint8_t)d_[p + 1];                         //  only where a field MUST match — see crlDps)
+    size_t len, hl;
+    if (b < 0x80) { len = b; hl = 2; }
+    else {
+      const size_t n = b & 0x7f;
+      if (n == 0 || n > 4 || p + 2 + n > end || d_[p + 2] == 0) return false;
+      len = 0;
+      for (size_t i = 0; i < n; i++) len = (len << 8) | (uint8_t)d_[p + 2 + i];
+      if (len < 0x80 || len > 0x7fffffff) return false;
+      hl = 2 + n;
+    }
+    *cs = p + hl;
+    *ce = p + hl + len;
+    return !fit || *ce <= end;
+  }
+  bool bitStringOk(size_t c, size_t e) const {                      // parseBitString
+    if (e == c) return false;
+    const uint8_t pad = (uint8_t)d_[c];
+    if (pad > 7 || (e - c == 1 && pad != 0)) return false;
+    return pad == 0 || ((uint8_t)d_[e - 1] & ((1u << pad) - 1)) == 0;
+  }
+  bool crlDps(size_t ov, size_t oe, std::vector<std::string>* uris) const {
+    uint8_t t, td, tf, tg, tn;
+    size_t v, ve, p, pe, off, end, fc, fe, gc, ge, u, ue;
+    v = ov; ve = oe;                                                   // [ov, oe) = the extnValue's contents
+    if (!goHdr(v, ve, true, &t, &p, &pe) || t != 0x30 || pe != ve) return false;
+    while (p < ve) {
+      if (!goHdr(p, ve, true, &td, &off, &end) || td != 0x30) return false;
+      tf = 0;
+      if (off < end && !goHdr(off, end, false, &tf, &fc, &fe)) return false;
+      if (off < end && tf == 0xa0) {                                  // DistributionPoint distributionPointName `optional,tag:0`
+        if (fe > end) return false;
+        size_t n = fc;
+        tg = 0;
+        if (n < fe && !goHdr(n, fe, false, &tg, &gc, &ge)) return false;
+        if (n < fe && tg == 0xa0) {                                   // FullName []asn1.RawValue `optional,tag:0`
+          if (ge > fe) return false;
+          for (size_t q = gc; q < ge; q = ue) {
+            if (!goHdrAny(q, ge, &tn, &u, &ue)) return false;
+            if ((tn & 0x1f) == 6 && (tn & 0x1f) != 0x1f) uris->push_back(d_.substr(u, ue - u));   // Tag == 6: the NUMBER alone
+          }
+          n = ge;
+          tg = 0;
+          if (n < fe && !goHdr(n, fe, false, &tg, &gc, &ge)) return false;
+        }
+        if (n < fe && tg == 0xa1 && ge > fe) return false;            // RelativeName: must fit (its RDNs are the walk's business)
+        off = fe;
+        tf = 0;
+        if (off < end && !goHdr(off, end, false, &tf, &fc, &fe)) return false;
+      }
+      if (off < end && tf == 0x81) {                                  // Reason asn1.BitString `optional,tag:1`
+        if (fe > end || !bitStringOk(fc, fe)) return false;
+        off = fe;
+        tf = 0;
+        if (off < end && !goHdr(off, end, false, &tf, &fc, &fe)) return false;
+      }
+      if (off < end && (tf == 0x82 || tf == 0xa2) && fe > end) return false;   // CRLIssuer asn1.RawValue `optional,tag:2`
+      p = end;
+    }
+    return true;
+  }
+  // a RawValue element: any TLV that fits, the high-tag-number form included (its number is never 6)
+  bool goHdrAny(size_t p, size_t end, uint8_t* tag, size_t* cs, size_t* ce) const {
+    if (p >= end) return false;
+    if (((uint8_t)d_[p] & 0x1f) != 0x1f) return goHdr(p, end, true, tag, cs, ce);
+    size_t o = p + 1, k = 0;
+    unsigned long long val = 0;
+    for (;; k++) {
+      if (o >= end || k == 5) return false;
+      const uint8_t b = (uint8_t)d_[o++];
+      if (k == 0 && b == 0x80) return false;
+      val = (val << 7) | (b & 0x7f);
+      if (!(b & 0x80)) break;
+    }
+    if (val > 0x7fffffffull || val < 0x1f) return false;
+    // the length octets behind the tag: reuse goHdr on a header whose identifier octet is one low-tag octet earlier
+    if (o >= end) return false;
+    const uint8_t b = (uint8_t)d_[o];
+    size_t len, hl;
+    if (b < 0x80) { len = b; hl = 1; }
+    else {
+      const size_t n = b & 0x7f;
+      if (n == 0 || n > 4 || o + 1 + n > end || d_[o + 1] == 0) return false;
+      len = 0;
+      for (size_t i = 0; i < n; i++) len = (len << 8) | (uint8_t)d_[o + 1 + i];
+      if (len < 0x80 || len > 0x7fffffff) return false;
+      hl = 1 + n;
+    }
+    *tag = 0x1f;
+    *cs = o + hl;
+    *ce = o + hl + len;
+    return *ce <= end;
   }
   void tlv(size_t p, size_t end, uint8_t* tag, size_t* cs, size_t* ce) const {
     if (p + 2 > end) throw Error("asn1: truncated");

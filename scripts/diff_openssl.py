@@ -63,7 +63,8 @@ def key_class(der, o):
 
 MODELLED_EXTENSIONS = ("keyUsage", "subjectKeyIdentifier", "extKeyUsage", "authorityKeyIdentifier", "certificatePolicies",
                        "authorityInfoAccess",
-                       "subjectAltName", "crlDistributionPoints", "nameConstraints", "ctPrecertSCTs")   # round 5
+                       "subjectAltName", "crlDistributionPoints", "nameConstraints", "ctPrecertSCTs",   # round 5
+                       "subjectInfoAccess", "sbgp-ipAddrBlock", "sbgp-autonomousSysNum")                 # round 6: CT-go's own
 
 
 def seeds():
@@ -116,7 +117,8 @@ def bucket_of(der, o, v):
             elif o.ext_findings:
                 hit = (hit[0] + " / a non-fatal finding", "modelled",
                        "what CT-go files as a NON-fatal finding inside the value (an iPAddress of another length than 4 or 16, an "
-                       "SCT list that does not decode, an INTEGER only the lax parser takes): under strict_extensions an X509 entry "
+                       "SCT list that does not decode, an INTEGER only the lax parser takes, an RFC 3779 address block or AS "
+                       "identifier list its rpki.go does not decode): under strict_extensions an X509 entry "
                        "keeps its certificate, a precertificate and a Chain[0] issuer are dropped")
             else:
                 hit = (hit[0] + " / passes Go's rules", "openssl",
@@ -169,7 +171,8 @@ def ext_name(nid):
              88: "crlNumber", 89: "certificatePolicies", 90: "authorityKeyIdentifier", 103: "crlDistributionPoints",
              126: "extKeyUsage", 177: "authorityInfoAccess", 666: "nameConstraints", 747: "policyMappings",
              401: "policyConstraints", 430: "holdInstructionCode", 140: "deltaCRL", 857: "freshestCRL", 748: "inhibitAnyPolicy",
-             71: "netscapeCertType", 72: "nsBaseUrl", 78: "nsComment", 951: "ctPrecertSCTs", 952: "ctPrecertPoison"}
+             71: "netscapeCertType", 72: "nsBaseUrl", 78: "nsComment", 951: "ctPrecertSCTs", 952: "ctPrecertPoison",
+             398: "subjectInfoAccess", 290: "sbgp-ipAddrBlock", 291: "sbgp-autonomousSysNum"}
     return names.get(nid, "nid%d" % nid)
 
 

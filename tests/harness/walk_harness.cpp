@@ -181,6 +181,86 @@ extern "C" int harness_walk_touched(const uint8_t* der, uint32_t len, uint32_t p
   return ok;
 }
 
+// The device's per-lane LDS window, simulated (round 6): same bookkeeping as kernels/readers.h WinReaderS — a window of
+// `wbytes` bytes beginning `slack` bytes in front of the certificate, touch() refilling it from a 16-byte boundary when the
+// hinted range is not inside, touch_tail() moving it to a dword boundary, reads outside it counted as misses — so that the
+// walk's hints can be checked against a window geometry on the CPU: a per-lane refill on the GPU is sixteen uncoalesced
+// loads and a round trip for the whole wave, a miss repeats the certificate with the exact reader.
+struct WindowSim {
+  const uint8_t* p;
+  uint32_t base_phase;  // (payload offset of the certificate) mod 16
+  uint32_t wbytes;
+  mutable int64_t grel;
+  mutable uint32_t refills = 0, misses = 0, first_refill_pos = 0, first_miss_pos = 0;
+  uint32_t ld4(uint32_t pos) const {
+    const int64_t rel = (int64_t)pos - grel;
+    if (rel < 0 || rel > (int64_t)wbytes - 4) {
+      if (!misses) first_miss_pos = pos;
+      misses++;
+    }
+    uint32_t v;
+    memcpy(&v, p + pos, 4);
+    return v;
+  }
+  uint32_t ld2c(uint32_t pos) const {
+    const int64_t rel = (int64_t)pos - grel;
+    if (rel < 0 || rel > (int64_t)wbytes - 2) {
+      if (!misses) first_miss_pos = pos;
+      misses++;
+    }
+    uint32_t v;
+    memcpy(&v, p + pos, 4);
+    return v & 0xffffu;
+  }
+  uint32_t ldg(uint32_t pos) const { uint32_t v; memcpy(&v, p + pos, 4); return v; }  // the tail registers
+  void touch(uint32_t pos, uint32_t need) const {
+    if (need > wbytes - 16u) need = wbytes - 16u;
+    const int64_t rel = (int64_t)pos - grel;
+    if (rel < 0 || rel > (int64_t)(wbytes - need)) {
+      if (!refills) first_refill_pos = pos;
+      refills++;
+      grel = (int64_t)pos - (int64_t)((base_phase + pos) & 15u);
+    }
+  }
+  void touch_tail(uint32_t pos, uint32_t) const { grel = (int64_t)pos - (int64_t)((base_phase + pos) & 3u); }
+  // the key tail registers (the RSA exponent at the end of the SubjectPublicKeyInfo arrives with touch_tail's burst)
+  struct KeyTail { bool valid; uint32_t at; uint32_t w[4]; };
+  KeyTail key_tail(uint32_t pos) const {
+    KeyTail t{pos >= 12u, pos - 12u, {0, 0, 0, 0}};
+    if (t.valid) memcpy(t.w, p + pos - 12u, 16);
+    return t;
+  }
+  // the wave-cooperative side of the device reader, for a wave of one lane: the subjectAltName walk is ext_san_coop's
+  mutable uint32_t coop = 0, deferred = 0;
+  static bool whole_wave() { return true; }
+  static bool any_lane(bool x) { return x; }
+  void coop_refill(uint32_t pos, bool want) const {
+    if (want) { coop++; grel = (int64_t)pos - (int64_t)((base_phase + pos) & 15u); }
+  }
+  void coop_refill_lines(uint32_t pos, bool want) const {  // (base_phase is the offset within a 128-byte line here: see the caller)
+    if (want) { coop++; grel = (int64_t)pos - (int64_t)((base_phase + pos) & 127u); }
+  }
+  bool holds(uint32_t pos, uint32_t need) const {
+    const int64_t rel = (int64_t)pos - grel;
+    return rel >= 0 && rel <= (int64_t)wbytes - (int64_t)need;
+  }
+  uint32_t ld2(uint32_t pos) const { uint32_t v; memcpy(&v, p + pos, 4); return v & 0xffffu; }
+  uint32_t wend() const { return (uint32_t)(grel + wbytes); }
+  void defer_exact() const { deferred++; }
+};
+// returns ok; out = {per-lane refills, misses, position of the first refill, position of the first miss, cooperative
+// refills of the subjectAltName walk, defer_exact calls}; phase = the certificate's offset within a 128-byte line
+extern "C" int harness_walk_window(const uint8_t* der, uint32_t len, uint32_t phase, uint32_t wbytes, int strings, int ext,
+                                   uint32_t* out) {
+  std::vector<uint8_t> buf((size_t)len + 64, 0);
+  memcpy(buf.data(), der, len);
+  WindowSim r{buf.data(), phase & 127u, wbytes, -(int64_t)(phase & 3u)};
+  ctmr::Walk w;
+  const bool ok = ctmr::walk_cert(r, len, w, nullptr, true, strings != 0, ext != 0);
+  out[0] = r.refills; out[1] = r.misses; out[2] = r.first_refill_pos; out[3] = r.first_miss_pos; out[4] = r.coop; out[5] = r.deferred;
+  return ok;
+}
+
 // k_ec_resolve's loader + equation on the host: the point whose X starts at BIT `xbit` of buf (RightAlign as a bit offset)
 extern "C" int harness_ec_point_bits(const uint8_t* buf, uint32_t len, uint64_t xbit, int curve) {
   std::vector<uint32_t> w((len + 3) / 4 + 40, 0xa5a5a5a5u);

@@ -233,6 +233,33 @@ def test_the_resolve_kernels_bit_offset_loader():
                 assert not harness.product_ec_point_bits(bytes(bad), xbit, cid), (curve, phase, shift, at)
 
 
+def test_p256_coordinates_next_to_the_prime():
+    """the P-256 reduction kept the ninth accumulator limb in 32 bits; with a multiplicand within ≈ 2^160 of p
+    (and b_i saturated) the row sum t + b_i·a can pass 2^288.  Points whose x is p − k (both factors of x·x next to p, low
+    limbs ffffffff) must be accepted when they lie on the curve and refused one bit off."""
+    prime, b = PRIMES["P256"], BS["P256"]
+    found = 0
+    for k in range(1, 4000):
+        x = prime - k
+        rhs = (pow(x, 3, prime) - 3 * x + b) % prime
+        y = pow(rhs, (prime + 1) // 4, prime)                    # p ≡ 3 (mod 4)
+        if y * y % prime != rhs:
+            continue
+        for yy in (y, prime - y):
+            buf = bytes(9) + x.to_bytes(32, "big") + yy.to_bytes(32, "big") + bytes(8)
+            assert harness.product_ec_point_bits(buf, 8 * 9, 1), hex(x)
+            bad = bytearray(buf)
+            bad[9 + 63] ^= 1
+            assert not harness.product_ec_point_bits(bytes(bad), 8 * 9, 1), hex(x)
+        found += 1
+    assert found > 1500
+    # … and through the whole key check: an SPKI with such a point parses
+    x = next(prime - k for k in range(1, 100)
+             if pow((pow(prime - k, 3, prime) - 3 * (prime - k) + b) % prime, (prime - 1) // 2, prime) == 1)
+    y = pow((pow(x, 3, prime) - 3 * x + b) % prime, (prime + 1) // 4, prime)
+    assert verdict(cert(ec_spki("P256", x.to_bytes(32, "big") + y.to_bytes(32, "big")))) == (True, 0)
+
+
 def test_ec_parameters():
     good = bytes.fromhex(CURVES["P256"][0])
     for params, ok in ((D.tlv(0x06, good), True), (b"", False), (D.NULL, False), (D.tlv(0x06, good[:-1]), False),
