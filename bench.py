@@ -35,7 +35,15 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32
 
 
-MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<16, false>", 15: "k_map_fused<16, false, 0, false>"}   # 1, 2: sweep build only
+MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<14, false>", 15: "k_map_fused<14, false, 0, false>"}   # 1, 2: sweep build only
+# … under the reference profile (and with strict_strings / strict_extensions alone): the STRICT instantiation
+MAP_KERNELS_STRICT = {13: "k_map_winc<14, true>", 15: "k_map_fused<14, false, 0, true>"}
+
+
+def map_kernel_name(args):
+    v = args.variant or DEFAULT_VARIANT
+    strict = args.profile == "reference" or args.strict_strings or args.strict_extensions
+    return MAP_KERNELS_STRICT.get(v, MAP_KERNELS[v]) if strict else MAP_KERNELS[v]
 DEFAULT_VARIANT = 15
 FUSED = (15,)          # map kernels that also do pass 1 of the known-certificate insert
 ALG_BYTES_PROBE = 64   # per PASS entry: 32 B slot read + 32 B slot write — fused kernels only
@@ -208,14 +216,14 @@ def measure_traffic(args, entries, kernels, mode_args=()):
     return out, None
 
 
-def needed_bytes_per_cert(certs, starts, filt):
+def needed_bytes_per_cert(certs, starts, filt, reference_profile=True):
     """What the walk READS of a certificate (the product's walk compiled for the host with a marking reader,
     tests/harness): bytes covered by its reads, and the distinct 128-byte HBM lines they lie in at the certificate's
     real position in the payload — the floor of the map kernel's fetch traffic at line granularity."""
     from tests import harness
     nb = nl = 0
     for der, st in zip(certs, starts):
-        _, b, l = harness.walk_touched(der, int(st) & 127, filt)
+        _, b, l = harness.walk_touched(der, int(st) & 127, filt, reference_profile)
         nb += b
         nl += l
     return nb / len(certs), nl * 128.0 / len(certs)
@@ -529,6 +537,7 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
     slots = min(pow2_at_least(int(per_rank_keys * 1.6)), 1 << 31)
     eng = ctmr.Engine(device=local, table_slots=slots, pair_slots=1 << 22, map_variant=args.variant, profile=True,
                       collect_meta=bool(wb))
+    eng.set_profile(args.profile)          # before the issuers are registered
     eng.add_issuers(synth.issuers(cfg))
     eng.set_filter(filt, False, now)
     group = None
@@ -625,8 +634,8 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
                                      f", every wave split by log-index range over {world} GPUs, sets persisting on the ranks "
                                      "(BASELINE configs[4])") + "; generation untimed",
                       "dedup": mode, "table_slots_per_rank": int(slots), "map_variant": args.variant or DEFAULT_VARIANT},
-           "roofline": {"bound": "hbm", "kernel": MAP_KERNELS[args.variant or DEFAULT_VARIANT].split("<")[0] if world > 1 else
-                        MAP_KERNELS[args.variant or DEFAULT_VARIANT], "achieved": achieved,
+           "roofline": {"bound": "hbm", "kernel": map_kernel_name(args).split("<")[0] if world > 1 else
+                        map_kernel_name(args), "achieved": achieved,
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                         "achieved_basis": "ALGORITHMIC bytes of rank 0 / its map kernel time",
                         "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBPS,
@@ -1091,7 +1100,7 @@ def main():
     # passes — this script re-executes itself under the profiler on a smaller batch of the same corpus and mode (bytes
     # per entry do not depend on the batch size: every launch streams ≫ the 256 MB of on-die cache) and scales.
     traffic = traffic_info = traffic_err = None
-    vname = MAP_KERNELS[args.variant or DEFAULT_VARIANT]
+    vname = map_kernel_name(args)
     kname = vname.split("<")[0]
     kernels = [kname] + (["k_decode_match"] if args.raw else []) + (["k_meta_new"] if args.meta else [])
     mode_args = (["--mixed"] if args.mixed else []) + (["--aligned", str(args.aligned)] if args.aligned else []) + (["--raw"] if args.raw else []) + (["--meta"] if args.meta else []) + \
@@ -1331,7 +1340,7 @@ def main():
             offs_k = arrays[1][:k + 1]
             certs_k = [arrays[0][int(offs_k[i]):int(offs_k[i + 1])].tobytes() for i in range(k)]
             starts_k = d_off[ranges[0][0]:ranges[0][0] + k].cpu().numpy()
-            nb, nl = needed_bytes_per_cert(certs_k, starts_k, filt)
+            nb, nl = needed_bytes_per_cert(certs_k, starts_k, filt, args.profile == "reference")
             n_pass = int(stats.by_status[0])
             fixed = ALG_BYTES_FIXED * E + 4 * E + ALG_BYTES_PROBE * n_pass      # arrays + record + ent[] word; slot read + write
             out["roofline"]["needed_bytes"] = nb * E + fixed

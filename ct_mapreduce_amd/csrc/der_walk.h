@@ -583,7 +583,10 @@ CTMR_HD uint32_t walk_name(R& r, uint32_t L, uint32_t q, uint32_t tbs_end, bool&
   // a long Name (OV/EV subjects) that runs past the window: refill ONCE, here, where the window then covers the whole
   // Name and the SubjectPublicKeyInfo header behind it — instead of somewhere in the middle and again at the key
   if constexpr (!CN) touch_all(r, cs, ok ? (ce - cs) + SPKI_HEAD_NEED : 0u);
-  else touch_all(r, cs, ok ? (ce - cs) : 0u);  // (the issuer: what follows it — the validity — has a hint of its own)
+  // (No such hint for the issuer: its Name lies in the first window.  A build that had one — same form, need = the Name's
+  //  length — issued a lane-by-lane refill in EVERY wave of the headline corpus, 14 loads and a round trip, fast profile
+  //  23.2 instead of 20.9 ms; the window simulator of the CPU harness sees no lane lacking anything there, the listing
+  //  shows the threshold computed as written.  Not understood; profiles/r06/issuer_hint_*, EXPERIMENTS.md.)
   uint32_t a = cs, a_end = cs;
   while (ok & (a < s_end)) {
     uint32_t t1, c1, e1;

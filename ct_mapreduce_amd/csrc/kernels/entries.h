@@ -41,6 +41,8 @@ struct DecodeArgs {
 // the same per-lane LDS windows as the map (coop_fill), walk_tbs = the certificate walk without the outer wrapper and the
 // signature.  Runs BEFORE the decode + match kernel, which treats a flagged entry as undecodable: its Chain[0] is never
 // looked at, let alone registered.  Costs one more pass over ≈ 3 windows of every precertificate entry: opt-in.
+// (CTMR_WALK_BOUNDS holds the kernel to three waves per SIMD at the price of 20 spilled registers — the inlined curve
+//  arithmetic wants more.  Without the attribute: 11.9 instead of 5.3 ms per 20 M raw entries, round 6.)
 __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uint64_t* bounds, uint64_t n, uint64_t limit,
                                                        uint8_t* leaf_bad, uint32_t strict_spki, uint32_t strict_ext) {
   const uint64_t first = (uint64_t)blockIdx.x * 64;
@@ -63,13 +65,13 @@ __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uin
   const WaveBuf wb = wave_buf(blob, limit, l0);  // lane 0's entry: the blob's entries ascend
   const uint32_t lrel = wave_rel(wb, lo, pre);
   const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
-  coop_fill<false>(wb, w_me, lane);
+  coop_fill<WIN_CH_STRICT, false>(wb, w_me, lane);
   bool ok = true;
   if (pre) {
     // Round 6: the map kernel's reader — every read served by the LDS window alone, a walk that leaves it repeated with the
     // exact global-memory reader (rounds 3-5: WinReaderC, whose every read carries a global-memory path of its own — 168
     // VGPRs with 36 spills under this kernel's occupancy attribute; strict_leaf is part of the default profile now)
-    WinReaderS<WIN_CH> r{{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off(lane)),
+    WinReaderS<WIN_CH_STRICT> r{{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off<WIN_CH_STRICT>(lane)),
                        lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}}};
     r.miss = lrel == REL_NONE ? 0xffffffffu : 0u;
     r.tl_pos = 0x80000000u;

@@ -168,11 +168,10 @@ __device__ __forceinline__ void store_records_wave(const MapArgs& a, uint64_t fi
 
 // Window map (variant 13; the exchange modes and `map_variant = 13` use it, the default is k_map_fused in reduce.h):
 // one certificate per lane, all 64 lanes busy, DER stays in global memory and is pulled through a per-lane LDS
-// window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: WIN_LDS_BYTES per wave.
+// window.  One wave per workgroup, so LDS (not the 256-thread granule) sets the occupancy: WinGeo<WCH>::LDS_BYTES per wave.
 // The first fill is wave-cooperative (coop_fill, readers.h).
 template <int WCH, bool STRICT = false>
 __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
-  static_assert(WCH == WIN_CH, "the cooperative fills fill windows of WIN_CH chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
@@ -183,11 +182,11 @@ __global__ void __launch_bounds__(64) k_map_winc(MapArgs a) {
   const WaveBuf wb = wave_buf(a.payload, limit, lo);  // (lane 0 is live whenever the workgroup exists: k_map_fused)
   const uint32_t lrel = wave_rel(wb, lo, live);
   const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
-  coop_fill<false>(wb, w_me, lane);
+  coop_fill<WCH, false>(wb, w_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   if (live) {
     // (out of the descriptor's reach: a window that holds nothing — every read takes this reader's global-memory path)
-    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
+    WinReaderC<WCH> r{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off<WCH>(lane)),
                        lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}};
     map_one<STRICT>(r, hi - lo, i, a, o0, o1);
   }

@@ -34,29 +34,52 @@ extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 // Round 6: the window geometry decides how many waves a CU holds — the map kernels are bound by the 160 KB of LDS, not
 // by registers (133 / 157 VGPRs: three waves per SIMD, twelve per CU) — and once the fills and the reads were cheap their
 // time followed the number of resident waves (a build that cost one wave per CU lost exactly 1/9: EXPERIMENTS.md).
-//   WIN_CH 16, stride 272   17 408 B per wave → 9 waves per CU; equal in-window offsets collide 4-way (rounds 1-5)
-//   WIN_CH 15, stride 248   15 872 B per wave: the occupancy API promises 10 waves per CU (scripts/probe_lds_occupancy.hip:
+//   16 chunks, stride 272  17 408 B per wave → 9 waves per CU; equal in-window offsets collide 4-way (rounds 1-5)
+//   15 chunks, stride 248  15 872 B per wave: the occupancy API promises 10 waves per CU (scripts/probe_lds_occupancy.hip:
 //                           ≤ 16 447 B), the counters show 9 as before — LDS is handed out in pieces of 1 280 B
 //                           (160 KB / 128), 15 872 B take thirteen of them, 16 640 B (profiles/r06/win_15_chunks_*)
-//   WIN_CH 14, stride 236   15 104 B per wave = twelve pieces → 10 waves per CU; 59 dwords a lane: an ODD stride, equal
+//   14 chunks, stride 236  15 104 B per wave = twelve pieces → 10 waves per CU; 59 dwords a lane: an ODD stride, equal
 //                           in-window offsets never collide; the windows are 4-byte aligned (a chunk is stored as two
 //                           ds_write2_b32).  224 bytes hold what the walk reads of the front of a synthetic certificate
 //                           — through the first two octets of the modulus, 220 bytes in — only because a window now
 //                           begins AT its position give or take 3 bytes (a chunk load needs dword alignment; rounds 1-5
 //                           began windows on 16-byte boundaries and lost up to 15) and because the walk's hints
 //                           (touch) say what is read, not a round figure.
-#ifndef CTMR_WIN_CH
-#define CTMR_WIN_CH 14
+// Each map kernel takes its geometry as a template parameter (WCH, round 6); both profiles run 14 chunks:
+//   fast profile        14 chunks, stride 236: ten waves per CU, the same two fills per certificate as with 16
+//   reference profile   14 chunks as well.  With 16 its subjectAltName walk refills in whole 128-byte lines — three rounds
+//                       where 224-byte windows need four, and no half sector fetched twice at a window's end (1 742 against
+//                       1 961 bytes of traffic per certificate) — and on two boxes the two geometries ran within a per cent
+//                       of each other; on a third the tenth wave was worth 9 % (36.2 against 39.8 ms, alternating:
+//                       profiles/r06/win_geometry_*).  Never slower, sometimes much faster: 14, and the traffic ratio
+//                       (1.20 × the algorithmic bytes instead of 1.07) is the price.  -DCTMR_WIN_CH_STRICT=16 builds the other.
+#ifndef CTMR_WIN_CH_FAST
+#define CTMR_WIN_CH_FAST 14
 #endif
-constexpr int WIN_CH = CTMR_WIN_CH;
-constexpr uint32_t WIN_STRIDE = WIN_CH == 16 ? 272u : WIN_CH == 15 ? 248u : (uint32_t)WIN_CH * 16u + 12u;
-constexpr uint32_t WIN_LDS_BYTES = 64u * WIN_STRIDE;
-__device__ __forceinline__ uint32_t win_off(uint32_t c) { return c * WIN_STRIDE; }
-typedef uint32_t ctmr_u32x4_a8 __attribute__((ext_vector_type(4), aligned(WIN_CH >= 15 ? 8 : 4)));  // a chunk in a window
+#ifndef CTMR_WIN_CH_STRICT
+#define CTMR_WIN_CH_STRICT 14
+#endif
+constexpr int WIN_CH_FAST = CTMR_WIN_CH_FAST, WIN_CH_STRICT = CTMR_WIN_CH_STRICT;
+template <int WCH>
+struct WinGeo {
+  static constexpr uint32_t STRIDE = WCH == 16 ? 272u : WCH == 15 ? 248u : (uint32_t)WCH * 16u + 12u;
+  static constexpr uint32_t LDS_BYTES = 64u * STRIDE;
+  static constexpr uint32_t ALIGN = STRIDE % 16u == 0u ? 16u : STRIDE % 8u == 0u ? 8u : 4u;  // of a chunk in a window
+};
+constexpr uint32_t WIN_LDS_MAX = WinGeo<WIN_CH_STRICT>::LDS_BYTES > WinGeo<WIN_CH_FAST>::LDS_BYTES ? WinGeo<WIN_CH_STRICT>::LDS_BYTES
+                                                                                               : WinGeo<WIN_CH_FAST>::LDS_BYTES;
+template <int WCH>
+__device__ __forceinline__ uint32_t win_off(uint32_t c) { return c * WinGeo<WCH>::STRIDE; }
+typedef uint32_t ctmr_u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+typedef uint32_t ctmr_u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t ctmr_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <int WCH>
 __device__ __forceinline__ void st_chunk(uint8_t* at, const uint4& v) {
-  ctmr_u32x4_a8 t;
+  using vec_t = typename std::conditional<WinGeo<WCH>::ALIGN == 16u, ctmr_u32x4_a16,
+                                          typename std::conditional<WinGeo<WCH>::ALIGN == 8u, ctmr_u32x4_a8, ctmr_u32x4_a4>::type>::type;
+  vec_t t;
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-  *(ctmr_u32x4_a8*)at = t;
+  *(vec_t*)at = t;
 }
 
 // Round 6: the wave's view of the payload as ONE buffer descriptor (SRSRC in scalar registers) whose base is the 128-byte
@@ -91,8 +114,9 @@ __device__ __forceinline__ uint32_t wave_rel(const WaveBuf& wb, uint64_t lo, boo
   const uint64_t d = lo - wb.b128;
   return (has & (lo >= wb.b128) & (d < REL_SPAN)) ? (uint32_t)d : REL_NONE;
 }
+template <bool NT = true>
 __device__ __forceinline__ uint4 ld_chunk(const WaveBuf& wb, uint32_t off) {  // non-temporal, like ld_payload16
-  const ctmr_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wb.rs, (int)off, 0, 2 /* nt */);
+  const ctmr_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wb.rs, (int)off, 0, NT ? 2 /* nt */ : 0);
   return make_uint4(t.x, t.y, t.z, t.w);
 }
 
@@ -102,10 +126,10 @@ __device__ __forceinline__ uint4 ld_chunk(const WaveBuf& wb, uint32_t off) {  //
 // start as an offset from the wave's base (REL_NONE: no certificate — its window fills with zeros); bytes at or beyond
 // the payload's readable end read as zero.
 // BARRIER_BEFORE_STORES: the windows are being re-filled (every lane must be done reading the old contents).
-template <bool BARRIER_BEFORE_STORES>
+template <int WCH, bool BARRIER_BEFORE_STORES>
 __device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
   const uint32_t sub16 = (lane & 15u) * 16u;
-  const bool mine = (lane & 15u) < (uint32_t)WIN_CH;  // (a window of 15 chunks: the sixteenth lane of a group idles)
+  const bool mine = (lane & 15u) < (uint32_t)WCH;  // (a window of 14 chunks: two lanes of a group idle)
   uint32_t o[16];
   uint4 v[16];
 #pragma unroll
@@ -115,16 +139,20 @@ __device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint
   if (BARRIER_BEFORE_STORES) __builtin_amdgcn_wave_barrier();
   if (mine) {
 #pragma unroll
-    for (int it = 0; it < 16; it++) st_chunk(smem + win_off(4 * it + (lane >> 4)) + sub16, v[it]);
+    for (int it = 0; it < 16; it++) st_chunk<WCH>(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it]);
   }
   __builtin_amdgcn_wave_barrier();
 }
 
 // The same for SOME windows (der_walk.h ext_san_coop: the lanes still walking a subjectAltName): a lane whose w_me is
 // REL_NONE keeps its window as it is (its chunks load as zeros — no memory access — and are not stored).
+// (NT = false — plain instead of non-temporal loads for the subjectAltName's refills, so that the half sector at a 224-byte
+//  window's end might still be in L2 when the next round asks for it again — measured no less traffic: 1 976 against 1 961
+//  bytes per certificate, profiles/r06/san_refills_plain_loads_*.)
+template <int WCH, bool NT = true>
 __device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
   const uint32_t sub16 = (lane & 15u) * 16u;
-  const bool mine = (lane & 15u) < (uint32_t)WIN_CH;
+  const bool mine = (lane & 15u) < (uint32_t)WCH;
   uint32_t o[16];
   uint4 v[16];
 #pragma unroll
@@ -133,11 +161,11 @@ __device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_m
     o[it] = mine ? o[it] : REL_NONE;
   }
 #pragma unroll
-  for (int it = 0; it < 16; it++) v[it] = ld_chunk(wb, o[it] + sub16);
+  for (int it = 0; it < 16; it++) v[it] = ld_chunk<NT>(wb, o[it] + sub16);
   __builtin_amdgcn_wave_barrier();  // every lane is done reading the old contents
 #pragma unroll
   for (int it = 0; it < 16; it++)
-    if (o[it] != REL_NONE) st_chunk(smem + win_off(4 * it + (lane >> 4)) + sub16, v[it]);
+    if (o[it] != REL_NONE) st_chunk<WCH>(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it]);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -225,7 +253,7 @@ struct WinReader {
     for (int k = 0; k < WCH; k++)
       v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < WCH; k++) st_chunk((uint8_t*)win + 16 * k, v[k]);
+    for (int k = 0; k < WCH; k++) st_chunk<WCH>((uint8_t*)win + 16 * k, v[k]);
   }
   __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
     if (need > WBYTES - 16u) need = WBYTES - 16u;  // the window start is 16-B aligned in HBM
@@ -241,7 +269,7 @@ struct WinReader {
 // instruction.  Falls back to the per-lane refill when some lane of the wave is not at that point.
 template <int WCH>
 struct WinReaderC : WinReader<WCH> {
-  static_assert(WCH == WIN_CH, "the cooperative fills fill windows of WIN_CH chunks");
+  static_assert(WCH >= 12 && WCH <= 16, "a window is filled by groups of sixteen lanes");
   __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) {
     if (__ballot(1) != ~0ull) {
       this->refill(pos);
@@ -249,7 +277,7 @@ struct WinReaderC : WinReader<WCH> {
     }
     const uint32_t w = this->wrel(pos, 4u);  // (a chunk load needs dword alignment only: the window begins AT pos, give or take 3)
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
-    coop_fill<true>(this->wb, w, threadIdx.x & 63u);
+    coop_fill<WCH, true>(this->wb, w, threadIdx.x & 63u);
   }
   // der_walk.h touch_all (round 6) — a hint at a point of the walk EVERY lane passes (the walk never returns early): the lanes
   // whose window lacks [pos, pos + need) are refilled TOGETHER, sixteen lanes per certificate, the others keep theirs.
@@ -266,14 +294,14 @@ struct WinReaderC : WinReader<WCH> {
     const uint32_t w = lack ? this->wrel(pos, 4u) : REL_NONE;
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
     else if (lack) this->refill(pos);  // (out of the descriptor's reach: the lane's own loads)
-    coop_refill_some(this->wb, w, threadIdx.x & 63u);
+    coop_refill_some<WCH>(this->wb, w, threadIdx.x & 63u);
   }
   // der_walk.h ext_san_coop — wave-collective (every lane of a WHOLE wave calls it from converged code): the lanes that
   // `want` get their window refilled at pos, 16 lanes per certificate as above; the others keep theirs.
   __device__ __forceinline__ void coop_refill(uint32_t pos, bool want) {
     const uint32_t w = want ? this->wrel(pos, 16u) : REL_NONE;
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
-    coop_refill_some(this->wb, w, threadIdx.x & 63u);
+    coop_refill_some<WCH>(this->wb, w, threadIdx.x & 63u);
   }
   // … the same with the window starting on a 128-byte LINE of the payload: two whole lines, the next round's window begins
   // where this one ends (der_walk.h ext_san_coop, round 6)
@@ -283,7 +311,7 @@ struct WinReaderC : WinReader<WCH> {
     constexpr uint32_t AL = (WinReader<WCH>::WBYTES % 128u == 0u) ? 128u : 64u;
     const uint32_t w = want ? this->wrel(pos, AL) : REL_NONE;     // (the wave's base is a multiple of 128)
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
-    coop_refill_some(this->wb, w, threadIdx.x & 63u);
+    coop_refill_some<WCH>(this->wb, w, threadIdx.x & 63u);
   }
   // the two octets at pos, which the caller knows to lie in the window (holds): two byte reads, no alignment arithmetic
   __device__ __forceinline__ uint32_t ld2(uint32_t pos) const {

@@ -381,7 +381,6 @@ __global__ void __launch_bounds__(256) k_insert2(InsertArgs a, ctmr_record* reco
 //             rank's cumulative filter with one fire-and-forget 8-byte atomicOr — no separate pass over the records.
 template <int WCH, bool META, int MODE, bool STRICT = false>
 __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, MetaCheck mc, XchgArgs xa) {
-  static_assert(WCH == WIN_CH, "the cooperative fills fill windows of WIN_CH chunks");
   const uint64_t first = (uint64_t)blockIdx.x * 64;
   const uint32_t lane = threadIdx.x;
   const uint64_t i = first + lane;
@@ -416,7 +415,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   const WaveBuf wb = wave_buf(a.payload, limit, lo);
   const uint32_t lrel = wave_rel(wb, lo, live);
   const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
-  coop_fill<false>(wb, w_me, lane);
+  coop_fill<WCH, false>(wb, w_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   unsigned long long kmeta = 0ull, ks[5] = {0ull, 0ull, 0ull, 0ull, 0ull};  // the entry's key, for its arena cell
   bool keyed = false;
@@ -429,7 +428,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
     using Hook = typename std::conditional<META, MetaHook, NoRefillHook>::type;
     // (a certificate out of the descriptor's reach — an entry view in no order — has no window: every read misses, and the
     //  exact reader below decides)
-    WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off(lane)),
+    WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off<WCH>(lane)),
                               lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}},
                             lrel == REL_NONE ? 0xffffffffu : 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
     if constexpr (META) {

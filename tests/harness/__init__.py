@@ -128,10 +128,12 @@ def product_name_strings(der: bytes, fill=0xA5) -> int:
     return _walk.harness_name_strings(der, len(der), fill)
 
 
-def walk_touched(der: bytes, phase: int = 0, cn_filter: bytes = b""):
+def walk_touched(der: bytes, phase: int = 0, cn_filter: bytes = b"", reference_profile: bool = False):
     """(accepted, bytes the walk's reads cover, distinct 128-byte lines they lie in when the certificate starts at
-    byte `phase` of a line) — bench.py's needed_bytes accounting."""
+    byte `phase` of a line) — bench.py's needed_bytes accounting.  reference_profile: the walk with strict_strings and
+    strict_extensions (the subjectAltName's headers and the extension bodies are read)."""
     product_walk(b"\x30\x00")          # builds / loads the library
+    _walk.harness_touched_profile(int(reference_profile))
     fn = _walk.harness_walk_touched
     fn.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32),
                    C.POINTER(C.c_uint32)]

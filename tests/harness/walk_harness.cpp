@@ -147,6 +147,8 @@ struct CountingReader {
   void touch_tail(uint32_t, uint32_t) const {}
 };
 
+static int g_touched_strict = 0;  // harness_walk_touched under the reference profile (strict_strings + strict_extensions)
+extern "C" void harness_touched_profile(int strict) { g_touched_strict = strict; }
 extern "C" int harness_walk_touched(const uint8_t* der, uint32_t len, uint32_t phase, const char* filter, uint32_t flen,
                                     uint32_t* bytes, uint32_t* lines128) {
   uint32_t piece_len[64], piece_word[64], words[1024] = {0}, np = 0, nw = 0;
@@ -167,7 +169,7 @@ extern "C" int harness_walk_touched(const uint8_t* der, uint32_t len, uint32_t p
   std::vector<uint8_t> mark(len, 0);
   CountingReader r{buf.data(), &mark};
   ctmr::Walk w;
-  const bool ok = ctmr::walk_cert(r, len, w, flen ? &fv : nullptr);
+  const bool ok = ctmr::walk_cert(r, len, w, flen ? &fv : nullptr, true, g_touched_strict != 0, g_touched_strict != 0);
   uint32_t nb = 0, nl = 0;
   int64_t last_line = -1;
   for (uint32_t i = 0; i < len; i++)
