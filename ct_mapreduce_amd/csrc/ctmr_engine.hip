@@ -278,7 +278,7 @@ enum { SC_RECORDS = 0, SC_SLOTID, SC_BLKNEW, SC_BLKBASE, SC_ENT, SC_STAGE_A, SC_
        SC_XSTAGE, SC_XWCNT, SC_XCNT, SC_XBASE, SC_XSLOT, SC_XL,
        SC_NFX,    // (round 3: strict_strings' pre-pass; unused since the check moved into the walk)
        SC_KEYPOS, // strict_spki: where the EC points lie that owe the curve equation (map → k_ec_resolve)
-       SC_PEMBLK, // k_pem_blocks: per 4 KiB output block of the PEM stream, the first certificate in it
+       SC_PEMBLK, // k_pem_blocks: per 7 KiB output block (PEM_S) of the PEM stream, the first certificate in it
        SC_PEMINFO // k_pem_len: (offset, length) of every certificate of the NEW list
        };  // strict_strings: the pre-pass's finding per entry  // owner-computes exchange (engine/exchange.inc)
 constexpr uint32_t UNREG_CAP = 16384;

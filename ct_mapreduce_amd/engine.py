@@ -98,7 +98,7 @@ class Engine:
     def __init__(self, device=0, table_slots=0, pair_slots=0, max_issuers=0, certs_per_tile=0,
                  lds_tile_bytes=0, map_variant=0, profile=False, collect_meta=False, max_table_slots=0):
         self._lib = N.lib()
-        if not map_variant:   # kernel experiments (scripts/run_*.sh with a sweep build of the library): whole test suites on another variant
+        if not map_variant:   # kernel experiments (scripts/run.sh TAG lib:PATH STEP… with a sweep build of the library): whole test suites on another variant
             map_variant = int(os.environ.get("CTMR_MAP_VARIANT", "0"))
         cfg = N.Config(struct_size=C.sizeof(N.Config), device=device, table_slots=table_slots,
                        pair_slots=pair_slots, max_issuers=max_issuers, certs_per_tile=certs_per_tile,

@@ -67,6 +67,7 @@ def main():
         strict = bool(os.environ.get("STRICT_LEAF")) and rng.random() < 0.5
         eng = ctmr.Engine(device=0, table_slots=1 << 18, pair_slots=1 << 18, collect_meta=True)
         eng.set_filter(filt, log_exp, now)
+        eng.set_profile("fast")     # (an engine is created under the reference profile since round 6: every switch is set here)
         eng.set_strict_leaf(strict)
         strings = bool(os.environ.get("STRICT_STRINGS")) and rng.random() < 0.5
         eng.set_strict_strings(strings)
@@ -76,6 +77,7 @@ def main():
             strict = strings = True
         res = eng.map_entries(raw)
         o = orc.Engine(filt, log_exp, now)
+        o.set_profile("fast")
         o.set_strict_leaf(strict)
         o.set_strict_strings(strings)
         o.set_strict_extensions(ref)
