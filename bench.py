@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 ALG_BYTES_FIXED = 45     # offsets 8 + issuer_idx 4 + entry_type 1 + record 32
 
 
-MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<14, false>", 15: "k_map_fused<14, false, 0, false>"}   # 1, 2: sweep build only
+MAP_KERNELS = {1: "k_map_tile", 2: "k_map_direct", 13: "k_map_winc<13, false>", 15: "k_map_fused<13, false, 0, false>"}   # 1, 2: sweep build only
 # … under the reference profile (and with strict_strings / strict_extensions alone): the STRICT instantiation
 MAP_KERNELS_STRICT = {13: "k_map_winc<14, true>", 15: "k_map_fused<14, false, 0, true>"}
 

@@ -83,6 +83,28 @@ CTMR_HD uint32_t ldc(const R& r, uint32_t p, uint32_t L) {
   else return r.ld4(p < L ? p : L);
 }
 
+// Readers whose first window begins BEHIND the outer headers (kernels/readers.h WinGeo::SKIP) hold the certificate's first
+// sixteen octets in registers; the walk reads the Certificate / TBSCertificate headers through this view of them.  A read
+// that does not lie in them (a high tag number, a length of three or four octets, a certificate shorter than its headers
+// say) is remembered, and the caller hands the certificate to the exact reader.
+template <class R>
+constexpr auto reader_has_head(int) -> decltype(R::kHead, bool()) { return R::kHead; }
+template <class R>
+constexpr bool reader_has_head(...) { return false; }
+struct HeadView {
+  static constexpr bool kNoClamp = true;
+  uint32_t w0, w1, w2, w3;
+  mutable bool out;
+  CTMR_HD uint32_t ld4(uint32_t pos) const {
+    out = out | (pos > 12u);
+    const uint32_t i = pos >> 2;
+    const uint32_t lo = i == 0u ? w0 : i == 1u ? w1 : i == 2u ? w2 : w3;
+    const uint32_t hi = i == 0u ? w1 : i == 1u ? w2 : i == 2u ? w3 : 0u;
+    const uint32_t sh = 8u * (pos & 3u);
+    return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+  }
+};
+
 // the two octets at p (readers with a clamped two-octet read of their own use it: a window's last two bytes are in reach)
 template <class R, class = void>
 struct has_ld2c : std::false_type {};
@@ -1553,17 +1575,29 @@ CTMR_HD bool walk_cert(R& r, uint32_t L, Walk& o, bool use_filter, const FilterV
   bool ok = L <= 0x7fffffffu;
   L = ok ? L : 0u;  // no early return: every lane of a wave stays on the same path (ok-accumulate)
   uint32_t tag, cs, ce;
-  r.touch(0, 256);
-  if constexpr (!TBS_ONLY) {
-    // Certificate ::= SEQUENCE filling the buffer exactly
-    rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+  if constexpr (reader_has_head<R>(0)) {
+    // (the first window begins behind these headers: they are read from the sixteen octets the lane holds in registers)
+    const HeadView hv{r.hd[0], r.hd[1], r.hd[2], r.hd[3], !r.hd_ok};
+    rd_hdr(hv, L, 0, L, ok, tag, cs, ce);
     ok = ok & (tag == 0x30u) & (ce == L);
-    // tbsCertificate
-    rd_hdr(r, L, cs, L, ok, tag, cs, ce);
-    ok = ok & (tag == 0x30u);
+    if constexpr (!TBS_ONLY) {
+      rd_hdr(hv, L, cs, L, ok, tag, cs, ce);
+      ok = ok & (tag == 0x30u);
+    }
+    if (hv.out) r.defer_exact();
   } else {
-    rd_hdr(r, L, 0, L, ok, tag, cs, ce);
-    ok = ok & (tag == 0x30u) & (ce == L);
+    r.touch(0, 256);
+    if constexpr (!TBS_ONLY) {
+      // Certificate ::= SEQUENCE filling the buffer exactly
+      rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+      ok = ok & (tag == 0x30u) & (ce == L);
+      // tbsCertificate
+      rd_hdr(r, L, cs, L, ok, tag, cs, ce);
+      ok = ok & (tag == 0x30u);
+    } else {
+      rd_hdr(r, L, 0, L, ok, tag, cs, ce);
+      ok = ok & (tag == 0x30u) & (ce == L);
+    }
   }
   const uint32_t tbs_end = ce;
   uint32_t q = cs;

@@ -64,7 +64,15 @@ __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uin
   }
   const WaveBuf wb = wave_buf(blob, limit, l0);  // lane 0's entry: the blob's entries ascend
   const uint32_t lrel = wave_rel(wb, lo, pre);
-  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
+  // (dword aligned: the window loses at most 3 bytes in front; WinGeo::SKIP: it begins behind the TBSCertificate's header — half
+  //  of what a Certificate's two headers take — which the walk reads from the sixteen octets below)
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : ((lrel + WinGeo<WIN_CH_STRICT>::SKIP / 2u) & ~3u);
+  U16t hd16{0u, 0u, 0u, 0u};
+  bool hd_ok = false;
+  if constexpr (WinGeo<WIN_CH_STRICT>::SKIP != 0u) {
+    hd_ok = pre & (lo + 16ull <= limit);
+    hd16 = *(const U16t*)(blob + (hd_ok ? lo : 0ull));
+  }
   coop_fill<WIN_CH_STRICT, false>(wb, w_me, lane);
   bool ok = true;
   if (pre) {
@@ -75,6 +83,10 @@ __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uin
                        lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}}};
     r.miss = lrel == REL_NONE ? 0xffffffffu : 0u;
     r.tl_pos = 0x80000000u;
+    if constexpr (WinGeo<WIN_CH_STRICT>::SKIP != 0u) {
+      r.hd[0] = hd16.a; r.hd[1] = hd16.b; r.hd[2] = hd16.c; r.hd[3] = hd16.d;
+      r.hd_ok = hd_ok;
+    }
     Walk w;
     ok = walk_tbs(r, len, w, strict_spki != 0u, strict_ext != 0u);
     if (r.missed()) {

@@ -45,24 +45,38 @@ extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 //                           begins AT its position give or take 3 bytes (a chunk load needs dword alignment; rounds 1-5
 //                           began windows on 16-byte boundaries and lost up to 15) and because the walk's hints
 //                           (touch) say what is read, not a round figure.
-// Each map kernel takes its geometry as a template parameter (WCH, round 6); both profiles run 14 chunks:
-//   fast profile        14 chunks, stride 236: ten waves per CU, the same two fills per certificate as with 16
-//   reference profile   14 chunks as well.  With 16 its subjectAltName walk refills in whole 128-byte lines — three rounds
-//                       where 224-byte windows need four, and no half sector fetched twice at a window's end (1 742 against
-//                       1 961 bytes of traffic per certificate) — and on two boxes the two geometries ran within a per cent
-//                       of each other; on a third the tenth wave was worth 9 % (36.2 against 39.8 ms, alternating:
-//                       profiles/r06/win_geometry_*).  Never slower, sometimes much faster: 14, and the traffic ratio
-//                       (1.20 × the algorithmic bytes instead of 1.07) is the price.  -DCTMR_WIN_CH_STRICT=16 builds the other.
+// Each map kernel takes its geometry as a template parameter (WCH, round 6):
+//   fast profile        13 chunks + 2 dwords, stride 220: eleven waves per CU, the same two fills per certificate — 21.2
+//                       against 22.6 ms on one box (profiles/r06/win_13_chunks_*); ten waves at 14 chunks were worth 6 % over
+//                       nine, the eleventh 6 % again
+//   reference profile   14 chunks, stride 236, ten waves.  The eleventh wave bought 1.7 % here (the subjectAltName rounds
+//                       make a wave's life longer, and what eleven waves ask of the memory system lengthens every round
+//                       trip) and cost the mixed corpus 2 % (long subjects refill once more).  16 chunks (nine waves, the
+//                       subjectAltName refilled in whole 128-byte lines: 1 742 instead of 1 961 bytes of traffic per
+//                       certificate) ran within a per cent on two boxes and 9 % slower on a third
+//                       (profiles/r06/win_geometry_*): -DCTMR_WIN_CH_STRICT=16 / =13 build the others.
 #ifndef CTMR_WIN_CH_FAST
-#define CTMR_WIN_CH_FAST 14
+#define CTMR_WIN_CH_FAST 13
 #endif
 #ifndef CTMR_WIN_CH_STRICT
 #define CTMR_WIN_CH_STRICT 14
 #endif
 constexpr int WIN_CH_FAST = CTMR_WIN_CH_FAST, WIN_CH_STRICT = CTMR_WIN_CH_STRICT;
+//   13 chunks + 2 dwords, stride 220  (late in round 6) 14 080 B per wave = eleven pieces → 11 waves per CU.  216 bytes hold
+//                           the front of a synthetic certificate only when the window begins BEHIND the two outer headers
+//                           (Certificate, TBSCertificate: 8 octets) — those come from sixteen octets a lane loads for itself
+//                           next to the first fill (WinReaderS::hd, der_walk.h HeadView).  The two dwords behind the thirteenth
+//                           chunk are what the lane that would load a fourteenth stores of it.
 template <int WCH>
 struct WinGeo {
-  static constexpr uint32_t STRIDE = WCH == 16 ? 272u : WCH == 15 ? 248u : (uint32_t)WCH * 16u + 12u;
+  static constexpr uint32_t XDW = WCH == 13 ? 2u : 0u;                          // dwords behind the last whole chunk
+  static constexpr uint32_t WBYTES = (uint32_t)WCH * 16u + XDW * 4u;
+  static constexpr uint32_t STRIDE = WCH == 16 ? 272u : WCH == 15 ? 248u : WCH == 13 ? 220u : (uint32_t)WCH * 16u + 12u;
+#ifdef CTMR_WIN_NO_SKIP
+  static constexpr uint32_t SKIP = 0u;
+#else
+  static constexpr uint32_t SKIP = WCH == 13 ? 8u : 0u;
+#endif  // octets of a Certificate in front of its first window (a TBSCertificate: half)
   static constexpr uint32_t LDS_BYTES = 64u * STRIDE;
   static constexpr uint32_t ALIGN = STRIDE % 16u == 0u ? 16u : STRIDE % 8u == 0u ? 8u : 4u;  // of a chunk in a window
 };
@@ -73,6 +87,7 @@ __device__ __forceinline__ uint32_t win_off(uint32_t c) { return c * WinGeo<WCH>
 typedef uint32_t ctmr_u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
 typedef uint32_t ctmr_u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t ctmr_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t ctmr_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 template <int WCH>
 __device__ __forceinline__ void st_chunk(uint8_t* at, const uint4& v) {
   using vec_t = typename std::conditional<WinGeo<WCH>::ALIGN == 16u, ctmr_u32x4_a16,
@@ -81,6 +96,30 @@ __device__ __forceinline__ void st_chunk(uint8_t* at, const uint4& v) {
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
   *(vec_t*)at = t;
 }
+// the XDW dwords behind the last whole chunk (stored by the lane that loaded the chunk they begin)
+template <int WCH>
+__device__ __forceinline__ void st_part(uint8_t* at, const uint4& v) {
+  if constexpr (WinGeo<WCH>::XDW == 2u) {
+    ctmr_u32x2_a4 t;
+    t.x = v.x; t.y = v.y;
+    *(ctmr_u32x2_a4*)at = t;
+  } else if constexpr (WinGeo<WCH>::XDW == 1u) {
+    *(uint32_t*)at = v.x;
+  } else if constexpr (WinGeo<WCH>::XDW == 3u) {
+    ctmr_u32x2_a4 t;
+    t.x = v.x; t.y = v.y;
+    *(ctmr_u32x2_a4*)at = t;
+    *(uint32_t*)(at + 8) = v.z;
+  }
+}
+__device__ __forceinline__ void st_half(uint8_t* at, uint32_t x, uint32_t y) {
+  ctmr_u32x2_a4 t;
+  t.x = x; t.y = y;
+  *(ctmr_u32x2_a4*)at = t;
+}
+// lanes of a group of sixteen that load a chunk: the WCH whole ones and, with XDW, one more
+template <int WCH>
+constexpr uint32_t win_loaders() { return (uint32_t)WCH + (WinGeo<WCH>::XDW ? 1u : 0u); }
 
 // Round 6: the wave's view of the payload as ONE buffer descriptor (SRSRC in scalar registers) whose base is the 128-byte
 // line of the wave's first certificate, so that every window position of every lane is a 32-BIT offset from it.  Rounds
@@ -129,7 +168,8 @@ __device__ __forceinline__ uint4 ld_chunk(const WaveBuf& wb, uint32_t off) {  //
 template <int WCH, bool BARRIER_BEFORE_STORES>
 __device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
   const uint32_t sub16 = (lane & 15u) * 16u;
-  const bool mine = (lane & 15u) < (uint32_t)WCH;  // (a window of 14 chunks: two lanes of a group idle)
+  const bool mine = (lane & 15u) < win_loaders<WCH>();  // (a window of 14 chunks: two lanes of a group idle)
+  const bool whole = (lane & 15u) < (uint32_t)WCH;
   uint32_t o[16];
   uint4 v[16];
 #pragma unroll
@@ -137,9 +177,23 @@ __device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint
 #pragma unroll
   for (int it = 0; it < 16; it++) v[it] = ld_chunk(wb, mine ? o[it] + sub16 : REL_NONE);
   if (BARRIER_BEFORE_STORES) __builtin_amdgcn_wave_barrier();
-  if (mine) {
+  if constexpr (WinGeo<WCH>::XDW == 2u) {
+    // one code path for the loaders: the first half of the chunk from every one of them, the second half from the whole ones
+    // (a 4-byte aligned chunk is two ds_write2_b32 anyway; two differently shaped store blocks cost 17 registers)
+    if (mine) {
 #pragma unroll
-    for (int it = 0; it < 16; it++) st_chunk<WCH>(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it]);
+      for (int it = 0; it < 16; it++) st_half(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it].x, v[it].y);
+    }
+    if (whole) {
+#pragma unroll
+      for (int it = 0; it < 16; it++) st_half(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16 + 8u, v[it].z, v[it].w);
+    }
+  } else {
+    static_assert(WinGeo<WCH>::XDW == 0u, "extra dwords: two or none");
+    if (whole) {
+#pragma unroll
+      for (int it = 0; it < 16; it++) st_chunk<WCH>(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it]);
+    }
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -152,7 +206,8 @@ __device__ __forceinline__ void coop_fill(const WaveBuf& wb, uint32_t w_me, uint
 template <int WCH, bool NT = true>
 __device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
   const uint32_t sub16 = (lane & 15u) * 16u;
-  const bool mine = (lane & 15u) < (uint32_t)WCH;
+  const bool mine = (lane & 15u) < win_loaders<WCH>();
+  const bool whole = (lane & 15u) < (uint32_t)WCH;
   uint32_t o[16];
   uint4 v[16];
 #pragma unroll
@@ -163,9 +218,18 @@ __device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_m
 #pragma unroll
   for (int it = 0; it < 16; it++) v[it] = ld_chunk<NT>(wb, o[it] + sub16);
   __builtin_amdgcn_wave_barrier();  // every lane is done reading the old contents
+  if constexpr (WinGeo<WCH>::XDW == 2u) {
 #pragma unroll
-  for (int it = 0; it < 16; it++)
-    if (o[it] != REL_NONE) st_chunk<WCH>(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it]);
+    for (int it = 0; it < 16; it++) {
+      uint8_t* const at = smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16;
+      if (o[it] != REL_NONE) st_half(at, v[it].x, v[it].y);
+      if ((o[it] != REL_NONE) & whole) st_half(at + 8u, v[it].z, v[it].w);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      if (o[it] != REL_NONE) st_chunk<WCH>(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it]);
+  }
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -180,7 +244,7 @@ __device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_m
 typedef uint32_t __attribute__((aligned(1))) ctmr_u32_u;
 typedef uint16_t __attribute__((aligned(1))) ctmr_u16_u;
 // the last window offset a 4-byte read may start at: WBYTES − 4 in both forms (the two-dword form's second dword may lie
-// in the pad behind the window — every stride leaves at least 8 bytes — and none of its bytes is used then)
+// in the pad behind the window — every stride leaves at least 4 bytes — and none of its bytes is used then)
 constexpr uint32_t LD4_SPAN = 4u;
 __device__ __forceinline__ uint32_t lds_ld4(const uint32_t* win, uint32_t rel) {
 #ifdef CTMR_LDS_UNALIGNED
@@ -223,7 +287,7 @@ struct WinReader {
   // offset from its base (REL_NONE: out of reach — cooperative fills leave such a lane's window alone / zero)
   WaveBuf wb;
   uint32_t lrel;
-  static constexpr uint32_t WBYTES = WCH * 16;
+  static constexpr uint32_t WBYTES = WinGeo<WCH>::WBYTES;
   __device__ __forceinline__ uint32_t wrel(uint32_t pos, uint32_t align) const {  // window start for [pos, …), from the wave's base
     return lrel == REL_NONE ? REL_NONE : ((lrel + pos) & ~(align - 1u));
   }
@@ -254,6 +318,10 @@ struct WinReader {
       v[k] = (g + 16u * k + 16u <= limit) ? src[k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < WCH; k++) st_chunk<WCH>((uint8_t*)win + 16 * k, v[k]);
+    if constexpr (WinGeo<WCH>::XDW != 0u) {
+      const uint4 x = (g + 16u * WCH + 16u <= limit) ? src[WCH] : make_uint4(0, 0, 0, 0);
+      st_part<WCH>((uint8_t*)win + 16 * WCH, x);
+    }
   }
   __device__ __forceinline__ void touch(uint32_t pos, uint32_t need) {
     if (need > WBYTES - 16u) need = WBYTES - 16u;  // the window start is 16-B aligned in HBM
@@ -306,9 +374,14 @@ struct WinReaderC : WinReader<WCH> {
   // … the same with the window starting on a 128-byte LINE of the payload: two whole lines, the next round's window begins
   // where this one ends (der_walk.h ext_san_coop, round 6)
   __device__ __forceinline__ void coop_refill_lines(uint32_t pos, bool want) {
-    // whole lines when the window is a whole number of them (256 bytes), else from a 64-byte sector (a window of 224 bytes
-    // is three and a half: from a line boundary it would hold 1.75 lines and every round would fetch its second line again)
-    constexpr uint32_t AL = (WinReader<WCH>::WBYTES % 128u == 0u) ? 128u : 64u;
+    // whole lines when the window is a whole number of them (256 bytes); a window of 224 bytes is seven 32-byte sectors and
+    // begins on one: from a 64-byte boundary its last half sector was fetched again by the next round — 1 955 against 1 899
+    // bytes of traffic per certificate and 40.1 against 38.7 / 38.9 ms per step on one box (16-byte boundaries: 1 912 bytes,
+    // 39.1 / 37.8 ms; profiles/r06/san_refill_alignment_*)
+#ifndef CTMR_SAN_ALIGN
+#define CTMR_SAN_ALIGN 32u
+#endif
+    constexpr uint32_t AL = (WinReader<WCH>::WBYTES % 128u == 0u) ? 128u : CTMR_SAN_ALIGN;
     const uint32_t w = want ? this->wrel(pos, AL) : REL_NONE;     // (the wave's base is a multiple of 128)
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
     coop_refill_some<WCH>(this->wb, w, threadIdx.x & 63u);
@@ -360,6 +433,12 @@ struct WinReaderS : WinReaderC<WCH> {
   // there, spki_key.h): one more unaligned 16-byte load in the same burst instead of dependent reads ~0.3 KB off the window
   uint32_t kt[4];
   bool kt_ok;
+  // … and, for geometries whose first window begins behind the outer headers (WinGeo::SKIP), the certificate's first
+  // sixteen octets, loaded by the lane itself next to the first fill (the kernel sets them): der_walk.h reads the
+  // Certificate and TBSCertificate headers out of these
+  static constexpr bool kHead = WinGeo<WCH>::SKIP != 0u;
+  uint32_t hd[4];
+  bool hd_ok;
   Hook hook{};  // by value: a pointer to state that lives across loop iterations keeps that state out of registers
   __device__ __forceinline__ uint32_t ld4(uint32_t pos) const {
     uint32_t rel = pos - (uint32_t)this->grel;

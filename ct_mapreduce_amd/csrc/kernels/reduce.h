@@ -414,7 +414,15 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
   // blob; lane 0 is live whenever the workgroup exists — and every window position is a 32-bit offset from it
   const WaveBuf wb = wave_buf(a.payload, limit, lo);
   const uint32_t lrel = wave_rel(wb, lo, live);
-  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : (lrel & ~3u);  // (dword aligned: the window loses at most 3 bytes in front)
+  // (dword aligned: the window loses at most 3 bytes in front; WinGeo::SKIP: it begins behind the two outer headers, which the
+  //  walk reads from the sixteen octets below — on their way together with the fill)
+  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : ((lrel + WinGeo<WCH>::SKIP) & ~3u);
+  U16t hd16{0u, 0u, 0u, 0u};
+  bool hd_ok = false;
+  if constexpr (WinGeo<WCH>::SKIP != 0u) {
+    hd_ok = live & (lo + 16ull <= limit);
+    hd16 = *(const U16t*)(a.payload + (hd_ok ? lo : 0ull));
+  }
   coop_fill<WCH, false>(wb, w_me, lane);
   uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
   unsigned long long kmeta = 0ull, ks[5] = {0ull, 0ull, 0ull, 0ull, 0ull};  // the entry's key, for its arena cell
@@ -431,6 +439,10 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
     WinReaderS<WCH, Hook> r{{{(const uint32_t*)a.payload, lo, limit, (uint32_t*)(smem + win_off<WCH>(lane)),
                               lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}},
                             lrel == REL_NONE ? 0xffffffffu : 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, 0x80000000u};
+    if constexpr (WinGeo<WCH>::SKIP != 0u) {
+      r.hd[0] = hd16.a; r.hd[1] = hd16.b; r.hd[2] = hd16.c; r.hd[3] = hd16.d;
+      r.hd_ok = hd_ok;
+    }
     if constexpr (META) {
       r.hook.mc = mc;
       r.hook.canon = canon;

@@ -142,15 +142,20 @@ def walk_touched(der: bytes, phase: int = 0, cn_filter: bytes = b"", reference_p
     return bool(ok), nb.value, nl.value
 
 
-def walk_window(der: bytes, phase: int = 0, wbytes: int = 224, strings: bool = False, ext: bool = False):
+def walk_window(der: bytes, phase: int = 0, wbytes: int = 224, strings: bool = False, ext: bool = False, skip: int = 0):
     """The walk through a SIMULATED per-lane window of `wbytes` bytes (kernels/readers.h geometry) for a certificate that
     starts at byte `phase` of its 128-byte line: (accepted, per-lane refills the hints asked for, reads that missed the
     window, position of the first refill, position of the first miss, cooperative refills of the subjectAltName walk,
     defer_exact calls)."""
     product_walk(b"\x30\x00")
+    out = (C.c_uint32 * 6)()
+    if skip:    # the first window begins `skip` octets in, the outer headers come from sixteen octets held apart (WinGeo::SKIP)
+        fn = _walk.harness_walk_window_skip
+        fn.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+        ok = fn(der, len(der), phase, wbytes, skip, int(strings), int(ext), out)
+        return bool(ok), out[0], out[1], out[2], out[3], out[4], out[5]
     fn = _walk.harness_walk_window
     fn.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
-    out = (C.c_uint32 * 6)()
     ok = fn(der, len(der), phase, wbytes, int(strings), int(ext), out)
     return bool(ok), out[0], out[1], out[2], out[3], out[4], out[5]
 

@@ -188,7 +188,12 @@ extern "C" int harness_walk_touched(const uint8_t* der, uint32_t len, uint32_t p
 // hinted range is not inside, touch_tail() moving it to a dword boundary, reads outside it counted as misses — so that the
 // walk's hints can be checked against a window geometry on the CPU: a per-lane refill on the GPU is sixteen uncoalesced
 // loads and a round trip for the whole wave, a miss repeats the certificate with the exact reader.
-struct WindowSim {
+template <bool HEAD>
+struct WindowSimT {
+  // HEAD: the first window begins behind the outer headers, which the walk reads from sixteen octets held apart (WinGeo::SKIP)
+  static constexpr bool kHead = HEAD;
+  uint32_t hd[4] = {0, 0, 0, 0};
+  bool hd_ok = false;
   const uint8_t* p;
   uint32_t base_phase;  // (payload offset of the certificate) mod 16
   uint32_t wbytes;
@@ -240,7 +245,8 @@ struct WindowSim {
     if (want) { coop++; grel = (int64_t)pos - (int64_t)((base_phase + pos) & 15u); }
   }
   void coop_refill_lines(uint32_t pos, bool want) const {  // (base_phase is the offset within a 128-byte line here: see the caller)
-    if (want) { coop++; grel = (int64_t)pos - (int64_t)((base_phase + pos) & 127u); }
+    // (whole lines for windows that are a whole number of them, else 32-byte sectors: readers.h CTMR_SAN_ALIGN)
+    if (want) { coop++; grel = (int64_t)pos - (int64_t)((base_phase + pos) & (wbytes % 128u == 0u ? 127u : 31u)); }
   }
   bool holds(uint32_t pos, uint32_t need) const {
     const int64_t rel = (int64_t)pos - grel;
@@ -250,13 +256,27 @@ struct WindowSim {
   uint32_t wend() const { return (uint32_t)(grel + wbytes); }
   void defer_exact() const { deferred++; }
 };
+using WindowSim = WindowSimT<false>;
 // returns ok; out = {per-lane refills, misses, position of the first refill, position of the first miss, cooperative
 // refills of the subjectAltName walk, defer_exact calls}; phase = the certificate's offset within a 128-byte line
 extern "C" int harness_walk_window(const uint8_t* der, uint32_t len, uint32_t phase, uint32_t wbytes, int strings, int ext,
                                    uint32_t* out) {
   std::vector<uint8_t> buf((size_t)len + 64, 0);
   memcpy(buf.data(), der, len);
-  WindowSim r{buf.data(), phase & 127u, wbytes, -(int64_t)(phase & 3u)};
+  WindowSim r{{0, 0, 0, 0}, false, buf.data(), phase & 127u, wbytes, -(int64_t)(phase & 3u)};
+  ctmr::Walk w;
+  const bool ok = ctmr::walk_cert(r, len, w, nullptr, true, strings != 0, ext != 0);
+  out[0] = r.refills; out[1] = r.misses; out[2] = r.first_refill_pos; out[3] = r.first_miss_pos; out[4] = r.coop; out[5] = r.deferred;
+  return ok;
+}
+// … with the first window beginning `skip` octets into the certificate (dword-aligned down in the payload) and the outer
+// headers read from the certificate's first sixteen octets (kernels/readers.h WinGeo::SKIP, der_walk.h HeadView)
+extern "C" int harness_walk_window_skip(const uint8_t* der, uint32_t len, uint32_t phase, uint32_t wbytes, uint32_t skip, int strings,
+                                        int ext, uint32_t* out) {
+  std::vector<uint8_t> buf((size_t)len + 64, 0);
+  memcpy(buf.data(), der, len);
+  WindowSimT<true> r{{0, 0, 0, 0}, true, buf.data(), phase & 127u, wbytes, (int64_t)skip - (int64_t)((phase + skip) & 3u)};
+  memcpy(r.hd, buf.data(), 16);
   ctmr::Walk w;
   const bool ok = ctmr::walk_cert(r, len, w, nullptr, true, strings != 0, ext != 0);
   out[0] = r.refills; out[1] = r.misses; out[2] = r.first_refill_pos; out[3] = r.first_miss_pos; out[4] = r.coop; out[5] = r.deferred;
