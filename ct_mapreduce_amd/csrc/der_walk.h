@@ -1042,7 +1042,7 @@ CTMR_HD void ext_san_coop(R& r, uint32_t L, uint32_t cv, uint32_t ev, bool& ok, 
     const bool want = act & (p < ev);
     if (!R::any_lane(want)) break;  // (wave-uniform)
     const bool need = want & (again | !r.holds(p, 2u));
-    if (R::any_lane(need)) r.coop_refill_lines(p, need);
+    if (R::any_lane(need)) r.coop_refill_lines_to(p, need, ev);  // (what is left of the value, not a whole window)
     again = false;
     if (want) {
       if (first) {  // one element filling the value: a universal constructed SEQUENCE

@@ -62,6 +62,9 @@ extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #define CTMR_WIN_CH_STRICT 14
 #endif
 constexpr int WIN_CH_FAST = CTMR_WIN_CH_FAST, WIN_CH_STRICT = CTMR_WIN_CH_STRICT;
+#ifndef CTMR_SAN_ALIGN
+#define CTMR_SAN_ALIGN 32u  // where a subjectAltName refill of a window that is no whole number of lines begins (coop_refill_lines)
+#endif
 //   13 chunks + 2 dwords, stride 220  (late in round 6) 14 080 B per wave = eleven pieces → 11 waves per CU.  216 bytes hold
 //                           the front of a synthetic certificate only when the window begins BEHIND the two outer headers
 //                           (Certificate, TBSCertificate: 8 octets) — those come from sixteen octets a lane loads for itself
@@ -233,6 +236,39 @@ __device__ __forceinline__ void coop_refill_some(const WaveBuf& wb, uint32_t w_m
   __builtin_amdgcn_wave_barrier();
 }
 
+// … and of SOME CHUNKS of them (round 6, late): w_me carries, in its four low bits, the number of chunks wanted minus one —
+// the subjectAltName's last round needs what is left of the value, not a whole window: the chunks behind it (the
+// signature) are not loaded and keep whatever the window held (der_walk.h ext_san_coop never looks past the value's end;
+// WinReaderC::part tells everybody else that the window is no longer whole).  w_me a multiple of 16 otherwise.
+template <int WCH, bool NT = true>
+__device__ __forceinline__ void coop_refill_some_n(const WaveBuf& wb, uint32_t w_me, uint32_t lane) {
+  const uint32_t li = lane & 15u, sub16 = li * 16u;
+  const bool whole = li < (uint32_t)WCH;
+  uint32_t o[16];
+  uint4 v[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const uint32_t x = __shfl(w_me, 4 * it + (int)(lane >> 4));
+    o[it] = ((x != REL_NONE) & (li <= (x & 15u))) ? (x & ~15u) : REL_NONE;  // (li <= count - 1 < loaders)
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) v[it] = ld_chunk<NT>(wb, o[it] + sub16);
+  __builtin_amdgcn_wave_barrier();  // every lane is done reading the old contents
+  if constexpr (WinGeo<WCH>::XDW == 2u) {
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      uint8_t* const at = smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16;
+      if (o[it] != REL_NONE) st_half(at, v[it].x, v[it].y);
+      if ((o[it] != REL_NONE) & whole) st_half(at + 8u, v[it].z, v[it].w);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; it++)
+      if (o[it] != REL_NONE) st_chunk<WCH>(smem + win_off<WCH>(4 * it + (lane >> 4)) + sub16, v[it]);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------ byte readers
 // ld4(pos): 4-byte little-endian window at an arbitrary byte position, from two aligned dwords (ds_read2_b32 + v_alignbyte).
 // Round 6 tried ONE ds_read_b32 at the byte address itself — gfx950 runs with unaligned LDS access enabled (hipcc emits
@@ -338,6 +374,8 @@ struct WinReader {
 template <int WCH>
 struct WinReaderC : WinReader<WCH> {
   static_assert(WCH >= 12 && WCH <= 16, "a window is filled by groups of sixteen lanes");
+  bool part;  // the last cooperative refill brought only the chunks it was asked for (coop_refill_lines_to): what lies behind
+              // them in the window is stale — readers of the window other than the walk (reduce.h: the memo pre-check) ask
   __device__ __forceinline__ void touch_tail(uint32_t pos, uint32_t) {
     if (__ballot(1) != ~0ull) {
       this->refill(pos);
@@ -378,13 +416,29 @@ struct WinReaderC : WinReader<WCH> {
     // begins on one: from a 64-byte boundary its last half sector was fetched again by the next round — 1 955 against 1 899
     // bytes of traffic per certificate and 40.1 against 38.7 / 38.9 ms per step on one box (16-byte boundaries: 1 912 bytes,
     // 39.1 / 37.8 ms; profiles/r06/san_refill_alignment_*)
-#ifndef CTMR_SAN_ALIGN
-#define CTMR_SAN_ALIGN 32u
-#endif
     constexpr uint32_t AL = (WinReader<WCH>::WBYTES % 128u == 0u) ? 128u : CTMR_SAN_ALIGN;
     const uint32_t w = want ? this->wrel(pos, AL) : REL_NONE;     // (the wave's base is a multiple of 128)
     if (w != REL_NONE) this->grel = (int32_t)(w - this->lrel);
     coop_refill_some<WCH>(this->wb, w, threadIdx.x & 63u);
+  }
+  // … and only as far as `end` (+ 4 octets: a read that begins in front of the end may reach across it), a certificate
+  // offset: the rest of the window is not loaded
+  __device__ __forceinline__ void coop_refill_lines_to(uint32_t pos, bool want, uint32_t end) {
+    constexpr uint32_t AL = (WinReader<WCH>::WBYTES % 128u == 0u) ? 128u : CTMR_SAN_ALIGN;
+    if constexpr (AL < 16u) {  // (the chunk count travels in the window start's four low bits: whole windows otherwise)
+      coop_refill_lines(pos, want);
+      return;
+    }
+    uint32_t w = want ? this->wrel(pos, AL) : REL_NONE;
+    if (w != REL_NONE) {
+      this->grel = (int32_t)(w - this->lrel);
+      const uint32_t need = (this->lrel + end + 4u) - w;  // (pos < end: at least 5)
+      uint32_t n = (need + 15u) >> 4;
+      n = n > win_loaders<WCH>() ? win_loaders<WCH>() : n;
+      part = part | (n < win_loaders<WCH>());
+      w |= n - 1u;
+    }
+    coop_refill_some_n<WCH>(this->wb, w, threadIdx.x & 63u);
   }
   // the two octets at pos, which the caller knows to lie in the window (holds): two byte reads, no alignment arithmetic
   __device__ __forceinline__ uint32_t ld2(uint32_t pos) const {

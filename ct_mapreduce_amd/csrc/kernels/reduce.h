@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(64) k_map_fused(MapArgs a, InsertArgs ia, Meta
     if constexpr (META) {
       meta_try = mc.enabled && status == CTMR_ST_PASS && !r.missed() && ml.x != META_NONE && ml.x != META_HOST && r.hook.dn_seen;
       if (meta_try)
-        mt = meta_tail_issue(mc, crl_ref, hour_row, (int32_t)o0.y, ml.y, r.win, r.grel, WinReader<WCH>::WBYTES - 8u);
+        mt = meta_tail_issue(mc, crl_ref, hour_row, (int32_t)o0.y, ml.y, r.win, r.grel, r.part ? 0u : WinReader<WCH>::WBYTES - 8u);
     }
     if (status == CTMR_ST_PASS) {
       const uint32_t slen = o0.x >> 16;

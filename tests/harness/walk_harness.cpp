@@ -248,6 +248,7 @@ struct WindowSimT {
     // (whole lines for windows that are a whole number of them, else 32-byte sectors: readers.h CTMR_SAN_ALIGN)
     if (want) { coop++; grel = (int64_t)pos - (int64_t)((base_phase + pos) & (wbytes % 128u == 0u ? 127u : 31u)); }
   }
+  void coop_refill_lines_to(uint32_t pos, bool want, uint32_t) const { coop_refill_lines(pos, want); }
   bool holds(uint32_t pos, uint32_t need) const {
     const int64_t rel = (int64_t)pos - grel;
     return rel >= 0 && rel <= (int64_t)wbytes - (int64_t)need;
