@@ -260,3 +260,56 @@ def test_precheck_against_a_warm_memo():
     assert res3.stats.n_new >= res2.stats.n_new > 0
     assert exp3 == {k for k in exp3 if k[0] == N.MK_HOST}         # host-routed certificates are handed over every time
     eng.close()
+
+
+@pytest.mark.parametrize("profile", ["reference", "fast"])
+def test_precheck_when_the_subject_alt_name_precedes_the_distribution_points(profile):
+    """Round 6: under the reference profile the subjectAltName is walked by the whole wave through windows of its own, and
+    its last round loads only the chunks up to the value's end — what lies behind them in the window is stale.  A
+    cRLDistributionPoints extension BEHIND a long subjectAltName lies exactly there: the memo pre-check must not read it
+    from the window (WinReaderC::part).  Warm memo, then the same issuer's certificates with SAN lengths that end a round
+    anywhere in a window, known and new distribution points: first sightings as the reference's memo semantics say."""
+    cfg = synth.config(seed=20260921 + 61, n_issuers=8, dup_permille=0, ca_permille=0, expired_permille=0)
+    issuers = synth.issuers(cfg)
+    eng = ctmr.Engine(device=0, table_slots=1 << 16, pair_slots=1 << 12, collect_meta=True)
+    eng.set_profile(profile)
+    eng.add_issuers(issuers)
+    eng.set_filter(b"", True, NOW)
+    seen_total = set()
+
+    def run(certs, idx):
+        res = eng.map_batch(Batch.from_certs(certs, idx))
+        assert (res.records["status"] == N.ST_PASS).all()
+        exp = expected_first_sightings(certs, [int(k) for k in idx], [int(i) for i in res.new_idx], res.records["exp_hour"])
+        exp -= seen_total
+        items = eng.meta_new()
+        got = got_first_sightings(eng, items)
+        assert len(items) == len(got) and got == exp
+        seen_total.update(k for k in exp if k[0] != N.MK_HOST)
+        return exp
+
+    b1 = synth.host_batch(cfg, 0, 4000)
+    run([b1.cert(i) for i in range(b1.n)], b1.issuer_idx)
+    i0 = int(np.nonzero(b1.issuer_idx == 0)[0][0])
+    name0, uris0, _ = orc.cert_meta(b1.cert(i0))
+    known, fresh = uris0[0], b"http://crl.example/behind-the-names.crl"
+
+    def san(n_bytes, rng):
+        names, total = [], 0
+        while total < n_bytes:
+            nm = b"h%d.example.org" % rng.randrange(10 ** rng.randrange(1, 9))
+            names.append(D.tlv(0x82, nm))
+            total += len(names[-1])
+        return D.ext(0x11, D.seq(*names))
+
+    rng = random.Random(61)
+    certs = []
+    for k in range(1500):
+        u = known if k % 3 else fresh
+        certs.append(D.cert(serial=b"\x61" + k.to_bytes(3, "big"), issuer=name0, spki=D.rsa_spki(),
+                            exts=[D.BC_NOT_CA, san(rng.randrange(40, 900), rng), dp_ext(dp(uri(u)))]))
+    exp = run(certs, [0] * len(certs))
+    assert (N.MK_CRL, 0, 0, fresh) in exp and (N.MK_CRL, 0, 0, known) not in exp
+    eng.reset_known()
+    assert not any(k[0] == N.MK_CRL for k in run(certs, [0] * len(certs)))   # steady state: everything seen
+    eng.close()
