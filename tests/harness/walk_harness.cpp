@@ -199,15 +199,19 @@ struct WindowSimT {
   uint32_t wbytes;
   mutable int64_t grel;
   mutable uint32_t refills = 0, misses = 0, first_refill_pos = 0, first_miss_pos = 0;
+  uint32_t size = 0xffffffffu;  // of the buffer behind p (set by the caller: damaged lengths ask for octets far outside)
+  uint32_t at(uint32_t pos) const {
+    uint32_t v = 0;
+    if ((uint64_t)pos + 4u <= size) memcpy(&v, p + pos, 4);
+    return v;
+  }
   uint32_t ld4(uint32_t pos) const {
     const int64_t rel = (int64_t)pos - grel;
     if (rel < 0 || rel > (int64_t)wbytes - 4) {
       if (!misses) first_miss_pos = pos;
       misses++;
     }
-    uint32_t v;
-    memcpy(&v, p + pos, 4);
-    return v;
+    return at(pos);
   }
   uint32_t ld2c(uint32_t pos) const {
     const int64_t rel = (int64_t)pos - grel;
@@ -215,11 +219,9 @@ struct WindowSimT {
       if (!misses) first_miss_pos = pos;
       misses++;
     }
-    uint32_t v;
-    memcpy(&v, p + pos, 4);
-    return v & 0xffffu;
+    return at(pos) & 0xffffu;
   }
-  uint32_t ldg(uint32_t pos) const { uint32_t v; memcpy(&v, p + pos, 4); return v; }  // the tail registers
+  uint32_t ldg(uint32_t pos) const { return at(pos); }  // the tail registers
   void touch(uint32_t pos, uint32_t need) const {
     if (need > wbytes - 16u) need = wbytes - 16u;
     const int64_t rel = (int64_t)pos - grel;
@@ -233,7 +235,7 @@ struct WindowSimT {
   // the key tail registers (the RSA exponent at the end of the SubjectPublicKeyInfo arrives with touch_tail's burst)
   struct KeyTail { bool valid; uint32_t at; uint32_t w[4]; };
   KeyTail key_tail(uint32_t pos) const {
-    KeyTail t{pos >= 12u, pos - 12u, {0, 0, 0, 0}};
+    KeyTail t{pos >= 12u && (uint64_t)pos + 4u <= size, pos - 12u, {0, 0, 0, 0}};
     if (t.valid) memcpy(t.w, p + pos - 12u, 16);
     return t;
   }
@@ -253,7 +255,7 @@ struct WindowSimT {
     const int64_t rel = (int64_t)pos - grel;
     return rel >= 0 && rel <= (int64_t)wbytes - (int64_t)need;
   }
-  uint32_t ld2(uint32_t pos) const { uint32_t v; memcpy(&v, p + pos, 4); return v & 0xffffu; }
+  uint32_t ld2(uint32_t pos) const { return at(pos) & 0xffffu; }
   uint32_t wend() const { return (uint32_t)(grel + wbytes); }
   void defer_exact() const { deferred++; }
 };
@@ -265,6 +267,7 @@ extern "C" int harness_walk_window(const uint8_t* der, uint32_t len, uint32_t ph
   std::vector<uint8_t> buf((size_t)len + 64, 0);
   memcpy(buf.data(), der, len);
   WindowSim r{{0, 0, 0, 0}, false, buf.data(), phase & 127u, wbytes, -(int64_t)(phase & 3u)};
+  r.size = (uint32_t)buf.size();
   ctmr::Walk w;
   const bool ok = ctmr::walk_cert(r, len, w, nullptr, true, strings != 0, ext != 0);
   out[0] = r.refills; out[1] = r.misses; out[2] = r.first_refill_pos; out[3] = r.first_miss_pos; out[4] = r.coop; out[5] = r.deferred;
@@ -278,6 +281,7 @@ extern "C" int harness_walk_window_skip(const uint8_t* der, uint32_t len, uint32
   memcpy(buf.data(), der, len);
   WindowSimT<true> r{{0, 0, 0, 0}, true, buf.data(), phase & 127u, wbytes, (int64_t)skip - (int64_t)((phase + skip) & 3u)};
   memcpy(r.hd, buf.data(), 16);
+  r.size = (uint32_t)buf.size();
   ctmr::Walk w;
   const bool ok = ctmr::walk_cert(r, len, w, nullptr, true, strings != 0, ext != 0);
   out[0] = r.refills; out[1] = r.misses; out[2] = r.first_refill_pos; out[3] = r.first_miss_pos; out[4] = r.coop; out[5] = r.deferred;

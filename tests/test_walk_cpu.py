@@ -288,3 +288,35 @@ def test_product_tbs_walk_equals_oracle_on_mutations(golden_certs):
     for r in range(8000):
         accepted += same_tbs(mutate(rng, seeds[r % len(seeds)]))
     assert 400 < accepted < 7600
+
+
+def test_the_walk_behind_register_held_outer_headers_decides_like_the_plain_walk(golden_certs):
+    """Round 6: the fast kernels' first window begins BEHIND the Certificate and TBSCertificate headers, which the walk
+    reads from sixteen octets held in registers (kernels/readers.h WinGeo::SKIP, der_walk.h HeadView).  The device's
+    bookkeeping simulated on the host (harness.walk_window, skip = 8): whenever no read left the window and the head view
+    did not hand the certificate over (on the GPU both mean: the exact reader repeats it), the verdict is the plain
+    walk's — for damage anywhere, and for damage aimed at the first sixteen octets (high tag numbers, lengths of one to
+    four octets, headers that overrun)."""
+    rng = random.Random(20260930)
+    cfg = synth.config(seed=9, n_issuers=16, ca_permille=100, expired_permille=50)
+    seeds = list(golden_certs.values()) + [synth.leaf(cfg, i)[0] for i in range(30)]
+    decided = handed_over = accepted = 0
+    for r in range(6000):
+        der = seeds[r % len(seeds)]
+        if r % 3 == 0:
+            der = mutate(rng, der)
+        else:                                # the outer headers
+            b = bytearray(der)
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(min(16, len(b)))] = rng.choice((0x30, 0x1f, 0x3f, 0x80, 0x81, 0x82, 0x83, 0x84, 0x00, 0xff, 0xa0,
+                                                                rng.randrange(256)))
+            der = bytes(b)
+        phase = rng.randrange(128)
+        ok, refills, misses, _, _, coop, deferred = harness.walk_window(der, phase, 216, False, False, skip=8)
+        if misses or deferred:
+            handed_over += 1
+            continue
+        decided += 1
+        assert ok == bool(harness.product_walk(der).ok), (r, der[:24].hex())
+        accepted += ok
+    assert decided > 1500 and handed_over > 500 and accepted > 200
