@@ -70,9 +70,12 @@ constexpr int WIN_CH_FAST = CTMR_WIN_CH_FAST, WIN_CH_STRICT = CTMR_WIN_CH_STRICT
 //                           (Certificate, TBSCertificate: 8 octets) — those come from sixteen octets a lane loads for itself
 //                           next to the first fill (WinReaderS::hd, der_walk.h HeadView).  The two dwords behind the thirteenth
 //                           chunk are what the lane that would load a fourteenth stores of it.
+#ifndef CTMR_WIN_XDW14
+#define CTMR_WIN_XDW14 0u  // (2u: 14 chunks + 2 dwords = 232 bytes at the same stride — fewer subjectAltName rounds per wave, 3.05 against 3.42, and 3 % SLOWER: a window that ends inside a sector; profiles/r06/win_232_bytes_*)
+#endif
 template <int WCH>
 struct WinGeo {
-  static constexpr uint32_t XDW = WCH == 13 ? 2u : 0u;                          // dwords behind the last whole chunk
+  static constexpr uint32_t XDW = WCH == 13 ? 2u : WCH == 14 ? CTMR_WIN_XDW14 : 0u;  // dwords behind the last whole chunk
   static constexpr uint32_t WBYTES = (uint32_t)WCH * 16u + XDW * 4u;
   static constexpr uint32_t STRIDE = WCH == 16 ? 272u : WCH == 15 ? 248u : WCH == 13 ? 220u : (uint32_t)WCH * 16u + 12u;
 #ifdef CTMR_WIN_NO_SKIP
