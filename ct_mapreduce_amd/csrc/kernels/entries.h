@@ -37,64 +37,94 @@ struct DecodeArgs {
 
 // strict_leaf (round 3): ct.LogEntryFromLeaf parses a precertificate entry's leaf TBSCertificate
 // (x509.ParseTBSCertificate) and fails — the downloader drops the entry (cmd/ct-fetch/ct-fetch.go:452-459) — when that
-// parse fails fatally; the default decode only length-checks it.  One precertificate entry per lane, the TBS pulled through
+// parse fails fatally; the fast profile's decode only length-checks it.  One precertificate entry per lane, the TBS pulled through
 // the same per-lane LDS windows as the map (coop_fill), walk_tbs = the certificate walk without the outer wrapper and the
 // signature.  Runs BEFORE the decode + match kernel, which treats a flagged entry as undecodable: its Chain[0] is never
 // looked at, let alone registered.  Costs one more pass over ≈ 3 windows of every precertificate entry: opt-in.
 // (CTMR_WALK_BOUNDS holds the kernel to three waves per SIMD at the price of 20 spilled registers — the inlined curve
 //  arithmetic wants more.  Without the attribute: 11.9 instead of 5.3 ms per 20 M raw entries, round 6.)
+// (Round 6, late) A wave takes a TILE of 256 entries, finds the precertificate entries among them (four header reads per
+// lane), compacts their numbers within the tile into 256 bytes of LDS behind the windows — in log order — and walks them 64
+// at a time.  With one entry per lane, as before, the X509 entries' lanes idled AND no wave was whole: every refill of the
+// walk fell back to its lane-by-lane form (the cooperative fills and the subjectAltName rounds want all 64 lanes).
+constexpr uint32_t LEAF_TILE = 256u;
+constexpr uint32_t LEAF_LDS_BYTES = WinGeo<WIN_CH_STRICT>::LDS_BYTES + LEAF_TILE;
+// a precertificate entry's TBSCertificate: [lo, lo + len) inside the blob (pre = false: not one, or the decoder's business)
+__device__ __forceinline__ bool leaf_tbs_of(const DevBytes& b, const uint64_t* bounds, uint64_t i, uint64_t n, uint64_t& l0, uint64_t& lo,
+                                            uint32_t& len) {
+  l0 = lo = 0;
+  len = 0;
+  if (i >= n) return false;
+  l0 = bounds[2 * i];
+  const uint64_t l1 = bounds[2 * i + 1];
+  // MerkleTreeLeaf: version(1) leaf_type(1) timestamp(8) entry_type(2) | issuer_key_hash(32) | TBSCertificate<1..2^24-1>
+  if (l1 >= l0 + 47u && b.u8(l0 + 1) == 0u && b.be(l0 + 10, 2) == 1u) {
+    len = b.be(l0 + 44, 3);
+    lo = l0 + 47u;
+    return len != 0u && lo + len <= l1;  // anything else is the decoder's business
+  }
+  return false;
+}
 __global__ void CTMR_WALK_BOUNDS k_leaf_tbs_check(const uint8_t* blob, const uint64_t* bounds, uint64_t n, uint64_t limit,
                                                        uint8_t* leaf_bad, uint32_t strict_spki, uint32_t strict_ext) {
-  const uint64_t first = (uint64_t)blockIdx.x * 64;
+  const uint64_t first = (uint64_t)blockIdx.x * LEAF_TILE;
   const uint32_t lane = threadIdx.x;
-  const uint64_t i = first + lane;
   DevBytes b{blob};
-  uint64_t lo = 0, l0 = 0;
-  uint32_t len = 0;
-  bool pre = false;
-  if (i < n) {
-    l0 = bounds[2 * i];
-    const uint64_t l1 = bounds[2 * i + 1];
-    // MerkleTreeLeaf: version(1) leaf_type(1) timestamp(8) entry_type(2) | issuer_key_hash(32) | TBSCertificate<1..2^24-1>
-    if (l1 >= l0 + 47u && b.u8(l0 + 1) == 0u && b.be(l0 + 10, 2) == 1u) {
-      len = b.be(l0 + 44, 3);
-      lo = l0 + 47u;
-      pre = len != 0u && lo + len <= l1;  // anything else is the decoder's business
-    }
+  uint8_t* const list = smem + WinGeo<WIN_CH_STRICT>::LDS_BYTES;  // tile-relative numbers of the precertificate entries, ascending
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < LEAF_TILE / 64u; k++) {
+    const uint64_t i = first + 64u * k + lane;
+    uint64_t l0, lo;
+    uint32_t len;
+    const bool pre = leaf_tbs_of(b, bounds, i, n, l0, lo, len);
+    if ((i < n) & !pre) leaf_bad[i] = 0;  // (a precertificate entry's byte is written by the pass that walks it)
+    const unsigned long long m = __ballot(pre);
+    if (pre) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)(64u * k + lane);
+    cnt += (uint32_t)__popcll(m);
   }
-  const WaveBuf wb = wave_buf(blob, limit, l0);  // lane 0's entry: the blob's entries ascend
-  const uint32_t lrel = wave_rel(wb, lo, pre);
-  // (dword aligned: the window loses at most 3 bytes in front; WinGeo::SKIP: it begins behind the TBSCertificate's header — half
-  //  of what a Certificate's two headers take — which the walk reads from the sixteen octets below)
-  const uint32_t w_me = lrel == REL_NONE ? REL_NONE : ((lrel + WinGeo<WIN_CH_STRICT>::SKIP / 2u) & ~3u);
-  U16t hd16{0u, 0u, 0u, 0u};
-  bool hd_ok = false;
-  if constexpr (WinGeo<WIN_CH_STRICT>::SKIP != 0u) {
-    hd_ok = pre & (lo + 16ull <= limit);
-    hd16 = *(const U16t*)(blob + (hd_ok ? lo : 0ull));
-  }
-  coop_fill<WIN_CH_STRICT, false>(wb, w_me, lane);
-  bool ok = true;
-  if (pre) {
-    // Round 6: the map kernel's reader — every read served by the LDS window alone, a walk that leaves it repeated with the
-    // exact global-memory reader (rounds 3-5: WinReaderC, whose every read carries a global-memory path of its own — 168
-    // VGPRs with 36 spills under this kernel's occupancy attribute; strict_leaf is part of the default profile now)
-    WinReaderS<WIN_CH_STRICT> r{{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off<WIN_CH_STRICT>(lane)),
-                       lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}}};
-    r.miss = lrel == REL_NONE ? 0xffffffffu : 0u;
-    r.tl_pos = 0x80000000u;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t p0 = 0; p0 < cnt; p0 += 64u) {  // (wave-uniform)
+    const bool pre = p0 + lane < cnt;
+    const uint64_t i = first + (pre ? (uint32_t)list[p0 + lane] : 0u);
+    uint64_t l0, lo;
+    uint32_t len;
+    (void)leaf_tbs_of(b, bounds, pre ? i : n, n, l0, lo, len);  // (the bounds again: an L2 hit, instead of 16 bytes of LDS per entry)
+    const WaveBuf wb = wave_buf(blob, limit, l0);  // lane 0 holds the pass's first — lowest — entry: the blob's entries ascend
+    const uint32_t lrel = wave_rel(wb, lo, pre);
+    // (dword aligned: the window loses at most 3 bytes in front; WinGeo::SKIP: it begins behind the TBSCertificate's header — half
+    //  of what a Certificate's two headers take — which the walk reads from the sixteen octets below)
+    const uint32_t w_me = lrel == REL_NONE ? REL_NONE : ((lrel + WinGeo<WIN_CH_STRICT>::SKIP / 2u) & ~3u);
+    U16t hd16{0u, 0u, 0u, 0u};
+    bool hd_ok = false;
     if constexpr (WinGeo<WIN_CH_STRICT>::SKIP != 0u) {
-      r.hd[0] = hd16.a; r.hd[1] = hd16.b; r.hd[2] = hd16.c; r.hd[3] = hd16.d;
-      r.hd_ok = hd_ok;
+      hd_ok = pre & (lo + 16ull <= limit);
+      hd16 = *(const U16t*)(blob + (hd_ok ? lo : 0ull));
     }
-    Walk w;
-    ok = walk_tbs(r, len, w, strict_spki != 0u, strict_ext != 0u);
-    if (r.missed()) {
-      GlobalReader g{(const uint32_t*)blob, lo};
-      ok = walk_tbs(g, len, w, strict_spki != 0u, strict_ext != 0u);
+    coop_fill<WIN_CH_STRICT, true>(wb, w_me, lane);
+    bool ok = true;
+    if (pre) {
+      // Round 6: the map kernel's reader — every read served by the LDS window alone, a walk that leaves it repeated with the
+      // exact global-memory reader (rounds 3-5: WinReaderC, whose every read carries a global-memory path of its own — 168
+      // VGPRs with 36 spills under this kernel's occupancy attribute; strict_leaf is part of the default profile now)
+      WinReaderS<WIN_CH_STRICT> r{{{(const uint32_t*)blob, lo, limit, (uint32_t*)(smem + win_off<WIN_CH_STRICT>(lane)),
+                         lrel == REL_NONE ? (int32_t)0x80000000 : (int32_t)(w_me - lrel), wb, lrel}}};
+      r.miss = lrel == REL_NONE ? 0xffffffffu : 0u;
+      r.tl_pos = 0x80000000u;
+      if constexpr (WinGeo<WIN_CH_STRICT>::SKIP != 0u) {
+        r.hd[0] = hd16.a; r.hd[1] = hd16.b; r.hd[2] = hd16.c; r.hd[3] = hd16.d;
+        r.hd_ok = hd_ok;
+      }
+      Walk w;
+      ok = walk_tbs(r, len, w, strict_spki != 0u, strict_ext != 0u);
+      if (r.missed()) {
+        GlobalReader g{(const uint32_t*)blob, lo};
+        ok = walk_tbs(g, len, w, strict_spki != 0u, strict_ext != 0u);
+      }
+      leaf_bad[i] = (uint8_t)!ok;
     }
+    __builtin_amdgcn_wave_barrier();  // (the next pass fills the windows again)
   }
-  if (i < n) leaf_bad[i] = (uint8_t)(pre && !ok);
 }
 
 
