@@ -655,9 +655,11 @@ def run_stream(args, ctmr, synth, N, torch, np, dev, local, rank, world, cfg, fi
         r = out["roofline"]
         r["traffic"] = traffic_info["traffic_bytes_per_cert"] * T          # over the whole stream
         r["traffic_measurement"] = traffic_info
-        r["achieved"] = r["traffic"] / (t_map * 1e-3) / 1e9
-        r["frac"] = r["achieved"] / HBM_PEAK_GBPS
-        r["achieved_basis"] = "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, 40 M-entry stream of the same corpus) / map kernel time"
+        r["achieved_physical"] = r["traffic"] / (t_map * 1e-3) / 1e9
+        r["frac_physical"] = r["achieved_physical"] / HBM_PEAK_GBPS
+        if r["achieved_physical"] < r["achieved_algorithmic"]:   # the smaller of the two byte counts is priced (see the plain line)
+            r["achieved"], r["frac"] = r["achieved_physical"], r["frac_physical"]
+            r["achieved_basis"] = "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, 40 M-entry stream of the same corpus) / map kernel time"
     elif traffic_err:
         out["roofline"]["traffic_error"] = traffic_err
     if rank == 0:
@@ -1176,17 +1178,23 @@ def main():
                    "profile": args.profile,
                    **({"strict_spki": False} if args.no_strict_spki else {}),
                    "gen_seconds": round(t_gen, 2)},
-        # roofline of the dominant kernel.  `frac` is PHYSICAL when the traffic was measured: HBM bytes the kernel moved
-        # (PMC counters) ÷ its average launch time ÷ peak.  The walk skips key, SAN body and signature by length, so the
-        # SURVEY §8(d) algorithmic figure (every certificate byte "read once") counts bytes that never move:
-        # `frac_algorithmic` is kept beside it, never instead of it.
+        # roofline of the dominant kernel.  `achieved` / `frac` price the SMALLER of two byte counts: the SURVEY §8(d)
+        # algorithmic bytes (every certificate byte "read once" + arrays + the table probe) and the HBM traffic the kernel was
+        # measured to move (PMC counters).  Under the fast profile the walk skips key, SAN body and signature by length — the
+        # algorithmic figure counts bytes that never move, and the physical one is the honest fraction; under the reference
+        # profile the kernel moves MORE than the algorithmic bytes (sector-granular windows), and the algorithmic one is.
+        # Both are always in the line: `frac_physical`, `frac_algorithmic`.
         "roofline": {"bound": "hbm", "kernel": vname if (mode == "plain" and not args.meta) else kname,
-                     "achieved": (traffic if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9,
-                     "achieved_basis": "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE) / avg launch time" if traffic
+                     "achieved": (min(traffic, alg_bytes) if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9,
+                     "achieved_basis": ("measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE) / avg launch time: less than the algorithmic bytes"
+                                        if traffic < alg_bytes else
+                                        "ALGORITHMIC bytes / avg launch time (the kernel moves more: traffic_over_algorithmic)") if traffic
                                        else "ALGORITHMIC bytes / avg launch time (no PMC measurement in this run"
                                             + (": " + traffic_err if traffic_err else "") + ")",
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": (traffic if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac": (min(traffic, alg_bytes) if traffic else alg_bytes) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "achieved_physical": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                     "frac_physical": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                      "traffic": traffic, "traffic_measurement": traffic_info,
                      "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                      "frac_of_streaming_ceiling": (traffic / (avg_ms * 1e-3) / 1e9 / 6290.0) if traffic else None,

@@ -51,9 +51,10 @@ def test_numbers_design_md_quotes_for_a_profile_file_are_that_files_numbers():
     fast = d["secondary"]["fast_profile"]
     rawref = d["secondary"]["raw_reference"]
     assert d["config"]["profile"] == "reference" and d["roofline"]["kernel"] == K and fast["same_results_as_the_reference_profile"] is True
+    assert d["roofline"]["frac"] == min(d["roofline"]["frac_physical"], d["roofline"]["frac_algorithmic"])    # the conservative one
     quotes = {
         R + "final_bench_default.json": [g9(d["value"]), "%.1f ms per step" % d["ms_per_step"], "map kernel %.2f ms" % d["kernel_ms"]["map"],
-                                         "`roofline.frac` %.3f" % d["roofline"]["frac"], "%.3f on the algorithmic bytes" % d["roofline"]["frac_algorithmic"],
+                                         "`roofline.frac` %.3f" % d["roofline"]["frac"], "`frac_physical` %.3f" % d["roofline"]["frac_physical"],
                                          "`traffic_over_algorithmic` %.2f" % d["roofline"]["traffic_over_algorithmic"],
                                          g9(fast["value"]), "map %.1f ms" % fast["map_ms"], "`frac` %.3f" % fast["frac"],
                                          "%.2f × 10⁹ entries/s" % (rawref["value"] / 1e9)],
